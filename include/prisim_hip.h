@@ -1,0 +1,180 @@
+/*
+ * prisim_hip.h -- C-ABI of the MI355X-native PRISim sky-sum library (libprisim_hip.so).
+ *
+ * The reference (nithyanandan/PRISim) has NO native / FFI / plugin interface for this
+ * path: the sky-sum is inline numpy inside InterferometerArray.observe()
+ * (prisim/interferometry.py:6255-6376).  This header therefore declares the boundary a
+ * maintainer would bind with ctypes; every entry point cites the
+ * reference statements it replaces.  Plain C types only -- no torch, no C++ exceptions.
+ *
+ * Conventions
+ *   - all host arrays are C-contiguous, caller-owned, and only read/written during the call;
+ *   - every function returns 0 on success or a negative PRISIM_E* code; the message for the
+ *     last failure on a context is available from prisim_hip_last_error();
+ *   - one context <-> one GPU <-> one HIP stream; calls on one context must be serialised
+ *     by the caller, distinct contexts are independent;
+ *   - complex arrays are interleaved (re, im) pairs.
+ */
+#ifndef PRISIM_HIP_H
+#define PRISIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct prisim_ctx prisim_ctx;
+
+enum {
+  PRISIM_OK = 0,
+  PRISIM_EINVAL = -1,      /* bad argument (maps to ValueError / TypeError in the Python shim) */
+  PRISIM_ENODEV = -2,      /* no usable HIP device / HIP runtime error */
+  PRISIM_ENOMEM = -3,      /* device allocation failed (MemoryError) */
+  PRISIM_ESTATE = -4,      /* call order violated (e.g. compute before set_array) */
+  PRISIM_ELIB = -5,        /* optional library (rocFFT / RCCL) unavailable */
+  PRISIM_EINTERNAL = -6
+};
+
+/* precision of the accumulate / phasor arithmetic */
+enum {
+  PRISIM_FP64 = 0,         /* reference default path, interferometry.py:6332-6343 */
+  PRISIM_FP32 = 1          /* reference "memsave" path, :6323-6330; here the phase is range-reduced
+                              in fp64 before the fp32 phasor recurrence */
+};
+
+/* kernel selection for prisim_hip_compute() */
+enum {
+  PRISIM_KERNEL_AUTO = 0,        /* channel-recurrence kernel when the channel grid is uniform, else direct */
+  PRISIM_KERNEL_RECURRENCE = 1,  /* phasor recurrence along frequency (needs uniform channel spacing) */
+  PRISIM_KERNEL_DIRECT = 2       /* one sincospi per term; any channel grid; fp64 only; slow cross-check */
+};
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device` (index after HIP_VISIBLE_DEVICES). */
+int prisim_hip_create(int device, prisim_ctx** out);
+void prisim_hip_destroy(prisim_ctx* ctx);
+/* Message of the last error on ctx (ctx may be NULL: last error of a failed create). */
+const char* prisim_hip_last_error(const prisim_ctx* ctx);
+/* Library version string "prisim_hip <major>.<minor> gfx950". */
+const char* prisim_hip_version(void);
+
+/* ---- array: baselines + channels, resident across snapshots ---------------------------- */
+
+/* Replaces the per-call use of self.baselines / self.channels in observe()
+ * (interferometry.py:6151, 6332).  bl_enu: [nbl][3] metres, local East-North-Up
+ * (baseline_coords='localenu').  freqs_hz: [nchan] Hz.  nt_max: number of snapshot slots to
+ * allocate in the device visibility cube (layout [nt][nbl][nchan] complex128). */
+int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl,
+                         const double* freqs_hz, int64_t nchan, int64_t nt_max);
+
+/* ---- sky for one snapshot --------------------------------------------------------------- */
+
+typedef struct prisim_sky {
+  int64_t nsrc;              /* sources inside the region of interest (may be 0, :6378-6382) */
+  const double* dircos;      /* [nsrc][3] ENU direction cosines (GEOM.altaz2dircos of skypos_altaz_roi, :6255/:6263) */
+  const void* pbflux;        /* [nsrc][nchan] beam x flux = pb * fluxes (:6254); dtype per pbflux_is_f32 */
+  int32_t pbflux_is_f32;     /* 0: float64, 1: float32 (external beams are stored float32, :4466) */
+  const double* pc_dircos;   /* [3] phase-centre direction cosines (:6164) */
+  const double* fwhm_deg;    /* [nsrc] sqrt(maj*min) of skymodel.src_shape in degrees (:6267), or NULL:
+                                no source-shape taper (skymodel.src_shape is None, :6258) */
+} prisim_sky;
+
+/* Upload the snapshot's sky to the device (pbflux is repacked on the device into per-channel-tile
+ * slabs).  Replaces nothing numerically; it is the H2D half of :6254-6255. */
+int prisim_hip_set_sky(prisim_ctx* ctx, const prisim_sky* sky);
+
+/* Compute the snapshot from device-resident inputs into cube slot `slot`:
+ *   V[b,f] = sum_s pbflux[s,f] * w[s,b,f] * exp(-2 pi i f (tau[s,b] - taupc[b]))     (:6320-6343)
+ *   tau = dc . bl^T / c (baseline_delay_horizon.py:240),  taupc (:6165),  w (:6257-6283).
+ * want_grad != 0 additionally computes G_k[b,f] = sum_s dircos[s,k] * (summand), k=0..2 (:6338,:6343)
+ * into the gradient cube slot.  Asynchronous on the context stream. */
+int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad, int64_t slot);
+
+/* Copy slot `slot` to the host.  out_is_c64 = 0: complex128 [nbl][nchan]; 1: complex64 (memsave dtype, :6183).
+ * grad (may be NULL): [3][nbl][nchan], same dtype.  Synchronises the stream. */
+int prisim_hip_get_vis(prisim_ctx* ctx, int64_t slot, void* vis, void* grad, int out_is_c64);
+
+/* One-shot drop-in for interferometry.py:6255-6376: set_sky + compute + get_vis. */
+int prisim_hip_skyvis(prisim_ctx* ctx, const prisim_sky* sky, int precision, int kernel,
+                      void* vis, void* grad, int out_is_c64);
+
+/* ---- fused analytic primary beams on the device ------------------------ */
+
+enum {
+  PRISIM_BEAM_DELTA = 0,     /* pb = 1 (telescope shape 'delta', primary_beams.py:357-359) */
+  PRISIM_BEAM_GAUSSIAN = 1,  /* primary_beams.py:716-728 (power pattern) */
+  PRISIM_BEAM_AIRY = 2       /* primary_beams.py:609-623 (power pattern, HERA D=14 m preset :239-247) */
+};
+
+typedef struct prisim_beam_sky {
+  int64_t nsrc;
+  const double* dircos;        /* [nsrc][3] ENU */
+  const double* flux_ref;      /* [nsrc] flux density at ref_freq_hz (Jy) */
+  const double* spindex;       /* [nsrc] spectral index: S(f) = flux_ref * (f/ref_freq)^spindex */
+  double ref_freq_hz;
+  int32_t beam_kind;           /* PRISIM_BEAM_* */
+  double diameter_m;           /* dish diameter / Gaussian FWHM aperture size */
+  const double* beam_pc_dircos;/* [3] beam pointing centre (ENU); zenith = {0,0,1} */
+  const double* pc_dircos;     /* [3] phase centre */
+  const double* fwhm_deg;      /* [nsrc] or NULL */
+} prisim_beam_sky;
+
+/* Build pbflux[s,f] = beam(s,f) * flux(s,f) on the device (no nsrc x nchan host array) and make it the
+ * current sky.  Replaces primary_beam_generator + generate_spectrum(power law) + :6254 for these leaves. */
+int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky);
+
+/* Read back the device pbflux (float64 [nsrc][nchan]) -- for parity tests of the fused beams. */
+int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out);
+
+/* ---- delay transform (follow-on stage, interferometry.py:8052-8137) ---------------------- */
+
+/* For slots [0, nt): x = V * bpwts (bpwts: [nbl][nchan] real weights = bp*bp_wts, or NULL = 1),
+ * zero-pad by npad = int(nchan*pad) at the high-frequency end (:8123-8125), inverse FFT along
+ * frequency (rocFFT), fftshift, scale by (nchan+npad)*df (:8125), keep every (1+pad)-th lag (:8132).
+ * out: host complex128 [nt][nbl][nchan_out]; lags_out: [nchan_out] seconds (may be NULL).
+ * power != 0 writes |.|^2 * power_scale into out_power [nt][nbl][nchan_out] float64
+ * (delay_spectrum.py:3992-3993) instead of / in addition to out (either may be NULL). */
+int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts, double pad,
+                               double* out, double* lags_out, double* out_power, double power_scale);
+
+/* ---- multi-GPU: baseline shards + one RCCL all-gather ---------------------- */
+
+/* 128-byte RCCL unique id; rank 0 creates it, the launcher distributes it out of band. */
+int prisim_hip_comm_unique_id(char id[128]);
+int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int rank);
+/* All-gather the local cube (equal-sized baseline shards, [nt][nbl_shard][nchan] complex128) into
+ * a device cube [nranks][nt][nbl_shard][nchan] held by the context.  Replaces the reference's
+ * per-rank _part_i.hdf5 files + rank-0 concatenate (scripts/run_prisim.py:2207, 2233-2242). */
+int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt);
+/* Copy the gathered cube to the host: out complex128 [nranks][nt][nbl_shard][nchan]. */
+int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, double* out);
+/* 64-bit checksum (sum of all re,im as double) of the gathered cube, computed on the device. */
+int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out);
+
+/* ---- timing / introspection -------------------------------------------------------------- */
+
+typedef struct prisim_timing {
+  double last_kernel_ms;     /* hipEvent duration of the dominant sky-sum kernel of the last compute() */
+  double last_compute_ms;    /* hipEvent duration of the whole last compute() (pack + sum + reduce) */
+  double sum_kernel_ms;      /* accumulated over compute() calls since the last reset */
+  int64_t n_kernel;          /* number of sky-sum kernel launches accumulated */
+  int64_t last_terms;        /* nbl*nchan*nsrc of the last compute() */
+  int32_t last_kernel_id;    /* PRISIM_KERNEL_* actually used */
+  int32_t last_chan_tile;    /* channels per thread of the recurrence kernel */
+  int32_t last_nsplit;       /* source split factor */
+  int32_t reserved;
+} prisim_timing;
+
+int prisim_hip_sync(prisim_ctx* ctx);
+int prisim_hip_get_timing(prisim_ctx* ctx, prisim_timing* out, int reset);
+/* Device properties: CU count and clock (kHz) used to re-derive the VALU peak on the box. */
+int prisim_hip_device_info(prisim_ctx* ctx, int* cu_count, int* clock_khz, char name[64]);
+/* Tuning knobs (0 = library default): channels per thread, sources per LDS chunk, split factor. */
+int prisim_hip_set_tuning(prisim_ctx* ctx, int chan_tile, int src_chunk, int nsplit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRISIM_HIP_H */

@@ -1,0 +1,24 @@
+"""CPU oracle for the PRISim sky-sum hot path -- TEST INFRASTRUCTURE ONLY.
+
+Nothing under ``oracle/`` is part of the shipped product.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import or execute it, and there only as the checker / reported CPU baseline --
+never as the thing measured or shipped.  ``prisim_amd`` never imports it.
+
+Pinning status (see DESIGN.md, section "Oracle"):
+  * PINNED against the reference's own statements executed under Python 3 on
+    seeded inputs (tests/golden/make_golden.py reads the cited line ranges of
+    /root/reference at generation time, in this container only):
+      - geometric delay (dircos path)        baseline_delay_horizon.py:236-240
+      - fp64 DFT sum                          interferometry.py:6332, 6340
+      - fp32 ("memsave") DFT sum              interferometry.py:6323, 6327
+      - source-shape taper                    interferometry.py:6259-6283
+      - baseline gradient                     interferometry.py:6338, 6343
+      - Gaussian / Airy beams (zenith)        primary_beams.py:609-623, 716-728
+  * PARITY UNPINNED (un-vendored, un-pinned third-party dependency
+    ``astroutils``; the reference has no tests or golden vectors for them):
+      - altaz<->dircos / hadec->altaz geometry (convention taken from in-tree
+        docstrings, primary_beams.py:122-123, 255-258, 275-278)
+      - DSP.FT1D / DSP.downsampler / DSP.spectral_axis (delay transform)
+      - SkyModel.generate_spectrum
+"""

@@ -1,0 +1,296 @@
+"""ctypes binding of libprisim_hip.so (include/prisim_hip.h) -- numpy + ctypes only, no torch.
+
+The product path FAILS LOUDLY when the HIP library or a GPU is missing: there is no CPU
+fallback anywhere in ``prisim_amd``.
+"""
+import ctypes as C
+import os
+
+import numpy as NP
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libprisim_hip.so')
+
+PRISIM_OK = 0
+PRISIM_EINVAL, PRISIM_ENODEV, PRISIM_ENOMEM, PRISIM_ESTATE, PRISIM_ELIB, PRISIM_EINTERNAL = -1, -2, -3, -4, -5, -6
+PRISIM_FP64, PRISIM_FP32 = 0, 1
+PRISIM_KERNEL_AUTO, PRISIM_KERNEL_RECURRENCE, PRISIM_KERNEL_DIRECT = 0, 1, 2
+PRISIM_BEAM_DELTA, PRISIM_BEAM_GAUSSIAN, PRISIM_BEAM_AIRY = 0, 1, 2
+
+# every symbol include/prisim_hip.h declares (tests check the library exports all of them)
+EXPORTS = (
+    'prisim_hip_create', 'prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version',
+    'prisim_hip_set_array', 'prisim_hip_set_sky', 'prisim_hip_compute', 'prisim_hip_get_vis',
+    'prisim_hip_skyvis', 'prisim_hip_set_sky_analytic', 'prisim_hip_get_pbflux',
+    'prisim_hip_delay_transform', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
+    'prisim_hip_allgather', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
+    'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
+)
+
+
+class PrisimSky(C.Structure):
+    _fields_ = [('nsrc', C.c_int64), ('dircos', C.c_void_p), ('pbflux', C.c_void_p),
+                ('pbflux_is_f32', C.c_int32), ('pc_dircos', C.c_void_p), ('fwhm_deg', C.c_void_p)]
+
+
+class PrisimBeamSky(C.Structure):
+    _fields_ = [('nsrc', C.c_int64), ('dircos', C.c_void_p), ('flux_ref', C.c_void_p), ('spindex', C.c_void_p),
+                ('ref_freq_hz', C.c_double), ('beam_kind', C.c_int32), ('diameter_m', C.c_double),
+                ('beam_pc_dircos', C.c_void_p), ('pc_dircos', C.c_void_p), ('fwhm_deg', C.c_void_p)]
+
+
+class PrisimTiming(C.Structure):
+    _fields_ = [('last_kernel_ms', C.c_double), ('last_compute_ms', C.c_double), ('sum_kernel_ms', C.c_double),
+                ('n_kernel', C.c_int64), ('last_terms', C.c_int64), ('last_kernel_id', C.c_int32),
+                ('last_chan_tile', C.c_int32), ('last_nsplit', C.c_int32), ('reserved', C.c_int32)]
+
+
+class PrisimHipError(RuntimeError):
+    """Raised when libprisim_hip.so is missing/unloadable or no GPU is usable."""
+
+
+_lib = None
+
+
+def load_library():
+    """Load libprisim_hip.so and declare the prototypes.  Raises PrisimHipError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PrisimHipError('HIP extension not built: {0} is missing. Run `python -c "import __graft_entry__ as g; '
+                             'g.build()"` (or make -C prisim_amd/csrc). There is no CPU fallback.'.format(LIB_PATH))
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise PrisimHipError('cannot load {0}: {1}'.format(LIB_PATH, exc))
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
+    lib.prisim_hip_create.argtypes = [i32, C.POINTER(vp)]
+    lib.prisim_hip_destroy.argtypes = [vp]
+    lib.prisim_hip_destroy.restype = None
+    lib.prisim_hip_last_error.argtypes = [vp]
+    lib.prisim_hip_last_error.restype = C.c_char_p
+    lib.prisim_hip_version.argtypes = []
+    lib.prisim_hip_version.restype = C.c_char_p
+    lib.prisim_hip_set_array.argtypes = [vp, vp, i64, vp, i64, i64]
+    lib.prisim_hip_set_sky.argtypes = [vp, C.POINTER(PrisimSky)]
+    lib.prisim_hip_compute.argtypes = [vp, i32, i32, i32, i64]
+    lib.prisim_hip_get_vis.argtypes = [vp, i64, vp, vp, i32]
+    lib.prisim_hip_skyvis.argtypes = [vp, C.POINTER(PrisimSky), i32, i32, vp, vp, i32]
+    lib.prisim_hip_set_sky_analytic.argtypes = [vp, C.POINTER(PrisimBeamSky)]
+    lib.prisim_hip_get_pbflux.argtypes = [vp, vp]
+    lib.prisim_hip_delay_transform.argtypes = [vp, i64, vp, dbl, vp, vp, vp, dbl]
+    lib.prisim_hip_comm_unique_id.argtypes = [C.c_char_p]
+    lib.prisim_hip_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
+    lib.prisim_hip_allgather.argtypes = [vp, i64]
+    lib.prisim_hip_get_gathered.argtypes = [vp, i64, vp]
+    lib.prisim_hip_gathered_checksum.argtypes = [vp, i64, C.POINTER(dbl)]
+    lib.prisim_hip_sync.argtypes = [vp]
+    lib.prisim_hip_get_timing.argtypes = [vp, C.POINTER(PrisimTiming), i32]
+    lib.prisim_hip_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p]
+    lib.prisim_hip_set_tuning.argtypes = [vp, i32, i32, i32]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ('prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version'):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(arr):
+    return None if arr is None else arr.ctypes.data_as(C.c_void_p)
+
+
+def _raise(code, msg):
+    """Map the C-ABI error codes onto the exception types the reference raises inline."""
+    if code == PRISIM_EINVAL:
+        raise ValueError(msg)
+    if code == PRISIM_ENOMEM:
+        raise MemoryError(msg)
+    if code == PRISIM_ESTATE:
+        raise RuntimeError(msg)
+    raise PrisimHipError(msg)
+
+
+class Context(object):
+    """One GPU <-> one context <-> one HIP stream (include/prisim_hip.h)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.prisim_hip_create(int(device), C.byref(h))
+        if rc != PRISIM_OK:
+            msg = self._lib.prisim_hip_last_error(None).decode()
+            _raise(rc, 'prisim_hip_create(device={0}) failed: {1}'.format(device, msg))
+        self._h = h
+        self.nbl = self.nchan = self.nt_max = 0
+        self.nsrc = 0
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.prisim_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != PRISIM_OK:
+            msg = self._lib.prisim_hip_last_error(self._h).decode()
+            _raise(rc, '{0} failed: {1}'.format(what, msg))
+
+    # ---- array ----
+    def set_array(self, baselines, freqs_hz, nt_max=1):
+        bl = NP.ascontiguousarray(baselines, dtype=NP.float64).reshape(-1, 3)
+        fr = NP.ascontiguousarray(freqs_hz, dtype=NP.float64).ravel()
+        self._check(self._lib.prisim_hip_set_array(self._h, _ptr(bl), bl.shape[0], _ptr(fr), fr.size, int(nt_max)),
+                    'prisim_hip_set_array')
+        self.nbl, self.nchan, self.nt_max = bl.shape[0], fr.size, int(nt_max)
+
+    # ---- sky ----
+    def _sky_struct(self, dircos, pbflux, pc_dircos, fwhm_deg):
+        dc = NP.ascontiguousarray(dircos, dtype=NP.float64).reshape(-1, 3)
+        nsrc = dc.shape[0]
+        pbflux = NP.asarray(pbflux)
+        is_f32 = pbflux.dtype == NP.float32
+        pb = NP.ascontiguousarray(pbflux, dtype=NP.float32 if is_f32 else NP.float64)
+        if nsrc > 0 and pb.size != nsrc * self.nchan:
+            raise ValueError('pbflux must have shape (nsrc, nchan) = ({0}, {1}), got {2}'.format(nsrc, self.nchan, pb.shape))
+        pc = NP.ascontiguousarray(pc_dircos, dtype=NP.float64).ravel()
+        if pc.size != 3:
+            raise ValueError('pc_dircos must have 3 elements')
+        fw = None
+        if fwhm_deg is not None:
+            fw = NP.ascontiguousarray(fwhm_deg, dtype=NP.float64).ravel()
+            if fw.size != nsrc:
+                raise ValueError('fwhm_deg must have nsrc elements')
+        sky = PrisimSky(nsrc, _ptr(dc), _ptr(pb), 1 if is_f32 else 0, _ptr(pc), _ptr(fw))
+        return sky, (dc, pb, pc, fw)
+
+    def set_sky(self, dircos, pbflux, pc_dircos, fwhm_deg=None):
+        sky, keep = self._sky_struct(dircos, pbflux, pc_dircos, fwhm_deg)
+        self._check(self._lib.prisim_hip_set_sky(self._h, C.byref(sky)), 'prisim_hip_set_sky')
+        self.nsrc = sky.nsrc
+
+    def set_sky_analytic(self, dircos, flux_ref, spindex, ref_freq_hz, beam_kind, diameter_m, beam_pc_dircos,
+                         pc_dircos, fwhm_deg=None):
+        dc = NP.ascontiguousarray(dircos, dtype=NP.float64).reshape(-1, 3)
+        nsrc = dc.shape[0]
+        fr = NP.ascontiguousarray(flux_ref, dtype=NP.float64).ravel()
+        sp = NP.ascontiguousarray(spindex, dtype=NP.float64).ravel()
+        if fr.size != nsrc or sp.size != nsrc:
+            raise ValueError('flux_ref and spindex must have nsrc elements')
+        bpc = NP.ascontiguousarray(beam_pc_dircos, dtype=NP.float64).ravel()
+        pc = NP.ascontiguousarray(pc_dircos, dtype=NP.float64).ravel()
+        fw = None
+        if fwhm_deg is not None:
+            fw = NP.ascontiguousarray(fwhm_deg, dtype=NP.float64).ravel()
+            if fw.size != nsrc:
+                raise ValueError('fwhm_deg must have nsrc elements')
+        sky = PrisimBeamSky(nsrc, _ptr(dc), _ptr(fr), _ptr(sp), float(ref_freq_hz), int(beam_kind), float(diameter_m),
+                            _ptr(bpc), _ptr(pc), _ptr(fw))
+        self._check(self._lib.prisim_hip_set_sky_analytic(self._h, C.byref(sky)), 'prisim_hip_set_sky_analytic')
+        self.nsrc = nsrc
+
+    def get_pbflux(self):
+        out = NP.empty((self.nsrc, self.nchan), dtype=NP.float64)
+        self._check(self._lib.prisim_hip_get_pbflux(self._h, _ptr(out)), 'prisim_hip_get_pbflux')
+        return out
+
+    # ---- compute ----
+    def compute(self, precision=PRISIM_FP64, kernel=PRISIM_KERNEL_AUTO, want_grad=False, slot=0):
+        self._check(self._lib.prisim_hip_compute(self._h, int(precision), int(kernel), 1 if want_grad else 0, int(slot)),
+                    'prisim_hip_compute')
+
+    def get_vis(self, slot=0, want_grad=False, complex64=False):
+        ctype = NP.complex64 if complex64 else NP.complex128
+        vis = NP.empty((self.nbl, self.nchan), dtype=ctype)
+        grad = NP.empty((3, self.nbl, self.nchan), dtype=ctype) if want_grad else None
+        self._check(self._lib.prisim_hip_get_vis(self._h, int(slot), _ptr(vis), _ptr(grad), 1 if complex64 else 0),
+                    'prisim_hip_get_vis')
+        return (vis, grad) if want_grad else vis
+
+    def skyvis(self, dircos, pbflux, pc_dircos, fwhm_deg=None, precision=PRISIM_FP64, kernel=PRISIM_KERNEL_AUTO,
+               want_grad=False, complex64=False):
+        """One-shot drop-in for interferometry.py:6255-6376."""
+        sky, keep = self._sky_struct(dircos, pbflux, pc_dircos, fwhm_deg)
+        ctype = NP.complex64 if complex64 else NP.complex128
+        vis = NP.empty((self.nbl, self.nchan), dtype=ctype)
+        grad = NP.empty((3, self.nbl, self.nchan), dtype=ctype) if want_grad else None
+        self._check(self._lib.prisim_hip_skyvis(self._h, C.byref(sky), int(precision), int(kernel), _ptr(vis), _ptr(grad),
+                                                1 if complex64 else 0), 'prisim_hip_skyvis')
+        self.nsrc = sky.nsrc
+        return (vis, grad) if want_grad else vis
+
+    # ---- delay transform ----
+    def delay_transform(self, nt, bpwts=None, pad=1.0, want_power=False, power_scale=1.0, want_lag=True):
+        pad = max(float(pad), 0.0)
+        nchan = self.nchan
+        nfft = nchan + int(nchan * pad)
+        nout = int(NP.arange(0, nfft, 1.0 + pad).size)
+        w = None
+        if bpwts is not None:
+            w = NP.ascontiguousarray(bpwts, dtype=NP.float64).reshape(self.nbl, nchan)
+        out = NP.empty((nt, self.nbl, nout), dtype=NP.complex128) if want_lag else None
+        pw = NP.empty((nt, self.nbl, nout), dtype=NP.float64) if want_power else None
+        lags = NP.empty(nchan, dtype=NP.float64)
+        self._check(self._lib.prisim_hip_delay_transform(self._h, int(nt), _ptr(w), pad, _ptr(out), _ptr(lags), _ptr(pw),
+                                                         float(power_scale)), 'prisim_hip_delay_transform')
+        return out, lags, pw
+
+    # ---- multi-GPU ----
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.prisim_hip_comm_unique_id(buf)
+        if rc != PRISIM_OK:
+            _raise(rc, 'prisim_hip_comm_unique_id failed: ' + lib.prisim_hip_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, uid, nranks, rank):
+        if len(uid) != 128:
+            raise ValueError('unique id must be 128 bytes')
+        self._check(self._lib.prisim_hip_comm_init(self._h, uid, int(nranks), int(rank)), 'prisim_hip_comm_init')
+        self.nranks = int(nranks)
+
+    def allgather(self, nt):
+        self._check(self._lib.prisim_hip_allgather(self._h, int(nt)), 'prisim_hip_allgather')
+
+    def get_gathered(self, nt, nranks):
+        out = NP.empty((nranks, nt, self.nbl, self.nchan), dtype=NP.complex128)
+        self._check(self._lib.prisim_hip_get_gathered(self._h, int(nt), _ptr(out)), 'prisim_hip_get_gathered')
+        return out
+
+    def gathered_checksum(self, nt):
+        v = C.c_double()
+        self._check(self._lib.prisim_hip_gathered_checksum(self._h, int(nt), C.byref(v)), 'prisim_hip_gathered_checksum')
+        return v.value
+
+    # ---- misc ----
+    def sync(self):
+        self._check(self._lib.prisim_hip_sync(self._h), 'prisim_hip_sync')
+
+    def timing(self, reset=False):
+        t = PrisimTiming()
+        self._check(self._lib.prisim_hip_get_timing(self._h, C.byref(t), 1 if reset else 0), 'prisim_hip_get_timing')
+        return {k: getattr(t, k) for k, _ in PrisimTiming._fields_}
+
+    def device_info(self):
+        cu, clk = C.c_int(), C.c_int()
+        name = C.create_string_buffer(64)
+        self._check(self._lib.prisim_hip_device_info(self._h, C.byref(cu), C.byref(clk), name), 'prisim_hip_device_info')
+        return {'name': name.value.decode(), 'cu_count': cu.value, 'clock_khz': clk.value}
+
+    def set_tuning(self, chan_tile=0, src_chunk=0, nsplit=0):
+        self._check(self._lib.prisim_hip_set_tuning(self._h, int(chan_tile), int(src_chunk), int(nsplit)),
+                    'prisim_hip_set_tuning')

@@ -1,0 +1,178 @@
+// aux_kernels.hip -- fused analytic primary beam x power-law flux, delay-transform pre/post
+// passes around rocFFT, and the gathered-cube checksum.  gfx950 only.
+//
+// Reference statements restated:
+//   Gaussian power beam   prisim/primary_beams.py:716-728
+//   Airy power beam       prisim/primary_beams.py:609-623   (HERA preset D = 14 m, :239-247)
+//   pbfluxes = pb*fluxes  prisim/interferometry.py:6254
+//   delay transform       prisim/interferometry.py:8114-8134
+//   delay power           prisim/delay_spectrum.py:3992-3993
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "skyvis_kernels.h"
+#include "../../include/prisim_hip.h"
+
+namespace prisim {
+
+static constexpr double kC = 299792458.0;
+static constexpr double kPi = 3.14159265358979323846;
+
+// thread per (source, channel); channel fastest (coalesced store of pb_out[s][f])
+__global__ __launch_bounds__(256)
+void k_beam_flux(const BeamParams p) {
+  const int64_t total = p.nsrc * p.nchan;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = i / p.nchan;
+    const int64_t k = i - s * p.nchan;
+    const double4 d = reinterpret_cast<const double4*>(p.dirs)[s];
+    const double f = p.freqs[k];
+    // angle to the beam pointing centre: cos = s.p, sin = |s x p|
+    const double cx = d.y * p.bpc_z - d.z * p.bpc_y;
+    const double cy = d.z * p.bpc_x - d.x * p.bpc_z;
+    const double cz = d.x * p.bpc_y - d.y * p.bpc_x;
+    const double sinx = sqrt(cx * cx + cy * cy + cz * cz);
+    const double cosx = d.x * p.bpc_x + d.y * p.bpc_y + d.z * p.bpc_z;
+    // blank beyond the horizon of the dish or of the sky (primary_beams.py:607, 714)
+    const bool blank = (cosx <= 0.0) || (d.z <= 0.0);
+    double pb = 1.0;
+    if (p.beam_kind == PRISIM_BEAM_GAUSSIAN) {
+      const double sigma_aprtr = p.diameter / (2.0 * sqrt(2.0 * log(2.0))) / (kC / f);   // :717
+      const double sigma_dircos = 1.0 / (2.0 * kPi * sigma_aprtr);                        // :721
+      const double r = sinx / sigma_dircos;
+      const double field = exp(-0.5 * r * r);                                             // :724
+      pb = blank ? 0.0 : field * field;                                                   // :725-728
+    } else if (p.beam_kind == PRISIM_BEAM_AIRY) {
+      const double kk = 2.0 * kPi * f / kC;                                               // :609
+      const double tol = 1e-10;                                                           // small_angle_tol
+      const double sin_tol = sin(tol);
+      const double sx = sinx < sin_tol ? sin_tol : sinx;                                  // :611-612 (x >= tol)
+      const double a = kk * 0.5 * p.diameter * sx;
+      const double a0 = kk * 0.5 * p.diameter * sin_tol;
+      const double pat = 2.0 * j1(a) / a;                                                 // :614
+      const double mx = 2.0 * j1(a0) / a0;                                                // :618
+      pb = blank ? 0.0 : (pat * pat) / (mx * mx);                                         // :616-623
+    } else {
+      pb = 1.0;
+    }
+    const double flux = p.flux_ref[s] * pow(f / p.ref_freq, p.spindex[s]);
+    p.pb_out[i] = pb * flux;
+  }
+}
+
+hipError_t launch_beam_flux(const BeamParams& p, hipStream_t stream) {
+  const int64_t total = p.nsrc * p.nchan;
+  if (total == 0) return hipSuccess;
+  int64_t g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(k_beam_flux, dim3((unsigned)g), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+// ---- delay transform -----------------------------------------------------------------------
+// work[row][n] (complex128, nfft per row) = cube[row][n] * w[b][n] for n < nchan, else 0.
+__global__ void k_dt_prepare(const double2* __restrict__ cube, const double* __restrict__ bpwts,
+                             double2* __restrict__ work, int64_t nrows, int64_t nbl, int64_t nchan, int64_t nfft) {
+  const int64_t total = nrows * nfft;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nfft;
+    const int64_t n = i - row * nfft;
+    double2 v = make_double2(0.0, 0.0);
+    if (n < nchan) {
+      v = cube[row * nchan + n];
+      if (bpwts) {
+        const double w = bpwts[(row % nbl) * nchan + n];
+        v.x *= w; v.y *= w;
+      }
+    }
+    work[i] = v;
+  }
+}
+
+// out[row][j] = scale * shifted[row][j*factor] with linear interpolation for non-integer factor,
+// shifted = fftshift(work) (zero lag moved to index nfft/2).
+__global__ void k_dt_finish(const double2* __restrict__ work, double2* __restrict__ out, double* __restrict__ out_power,
+                            int64_t nrows, int64_t nfft, int64_t nout, double factor, double scale,
+                            double power_scale) {
+  const int64_t total = nrows * nout;
+  const int64_t half = nfft / 2;   // numpy fftshift: shifted[i] = x[(i + nfft - half) % nfft]  (half = floor(n/2))
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nout;
+    const int64_t j = i - row * nout;
+    const double pos = (double)j * factor;
+    int64_t i0 = (int64_t)floor(pos);
+    double frac = pos - (double)i0;
+    if (i0 >= nfft - 1) { i0 = nfft - 1; frac = 0.0; }
+    const int64_t src0 = (i0 + nfft - half) % nfft;
+    double2 v = work[row * nfft + src0];
+    if (frac != 0.0) {
+      const int64_t src1 = (i0 + 1 + nfft - half) % nfft;
+      const double2 v1 = work[row * nfft + src1];
+      v.x += frac * (v1.x - v.x);
+      v.y += frac * (v1.y - v.y);
+    }
+    v.x *= scale; v.y *= scale;
+    if (out) out[i] = v;
+    if (out_power) out_power[i] = (v.x * v.x + v.y * v.y) * power_scale;
+  }
+}
+
+static unsigned grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+hipError_t launch_dt_prepare(const double* cube, const double* bpwts, double* work, int64_t nrows, int64_t nbl,
+                             int64_t nchan, int64_t nfft, hipStream_t stream) {
+  hipLaunchKernelGGL(k_dt_prepare, dim3(grid_for(nrows * nfft)), dim3(256), 0, stream,
+                     reinterpret_cast<const double2*>(cube), bpwts, reinterpret_cast<double2*>(work), nrows, nbl, nchan,
+                     nfft);
+  return hipGetLastError();
+}
+
+hipError_t launch_dt_finish(const double* work, double* out, double* out_power, int64_t nrows, int64_t nfft,
+                            int64_t nout, double factor, double scale, double power_scale, hipStream_t stream) {
+  hipLaunchKernelGGL(k_dt_finish, dim3(grid_for(nrows * nout)), dim3(256), 0, stream,
+                     reinterpret_cast<const double2*>(work), reinterpret_cast<double2*>(out), out_power, nrows, nfft,
+                     nout, factor, scale, power_scale);
+  return hipGetLastError();
+}
+
+// ---- deterministic checksum: fixed 1024-block partial sums, then one block ------------------
+__global__ __launch_bounds__(256)
+void k_checksum_partial(const double* __restrict__ data, int64_t n, double* __restrict__ partial) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a += data[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256)
+void k_checksum_final(const double* __restrict__ partial, int np, double* __restrict__ out) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) a += partial[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+hipError_t launch_checksum(const double* data, int64_t n, double* out /* [1025] device scratch: out[0]=result */,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(k_checksum_partial, dim3(1024), dim3(256), 0, stream, data, n, out + 1);
+  hipLaunchKernelGGL(k_checksum_final, dim3(1), dim3(256), 0, stream, out + 1, 1024, out);
+  return hipGetLastError();
+}
+
+}  // namespace prisim

@@ -1,0 +1,800 @@
+// capi.cpp -- C-ABI of libprisim_hip.so (declared in include/prisim_hip.h).
+//
+// Owns the per-GPU context: HIP stream, resident array (baselines, channels), per-snapshot sky,
+// the device visibility cube, and lazily dlopen()ed rocFFT / RCCL handles.  No C++ exception
+// crosses the ABI; every export returns 0 or a negative PRISIM_E* code.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <rocfft/rocfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/prisim_hip.h"
+#include "skyvis_kernels.h"
+
+using namespace prisim;
+
+namespace {
+
+constexpr double kC = 299792458.0;   // scipy.constants.c (baseline_delay_horizon.py:236)
+
+std::string g_create_error;
+
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+
+struct RocfftApi {
+  void* handle = nullptr;
+  bool setup_done = false;
+  decltype(&rocfft_setup) setup = nullptr;
+  decltype(&rocfft_plan_create) plan_create = nullptr;
+  decltype(&rocfft_plan_destroy) plan_destroy = nullptr;
+  decltype(&rocfft_plan_get_work_buffer_size) plan_get_work_buffer_size = nullptr;
+  decltype(&rocfft_execution_info_create) execution_info_create = nullptr;
+  decltype(&rocfft_execution_info_destroy) execution_info_destroy = nullptr;
+  decltype(&rocfft_execution_info_set_stream) execution_info_set_stream = nullptr;
+  decltype(&rocfft_execution_info_set_work_buffer) execution_info_set_work_buffer = nullptr;
+  decltype(&rocfft_execute) execute = nullptr;
+};
+RocfftApi g_rocfft;
+
+template <typename F>
+bool load_sym(void* h, const char* name, F& out) {
+  out = reinterpret_cast<F>(dlsym(h, name));
+  return out != nullptr;
+}
+
+bool load_rccl(std::string& err) {
+  if (g_rccl.handle) return true;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+  bool ok = load_sym(h, "ncclGetUniqueId", g_rccl.GetUniqueId) && load_sym(h, "ncclCommInitRank", g_rccl.CommInitRank) &&
+            load_sym(h, "ncclAllGather", g_rccl.AllGather) && load_sym(h, "ncclCommDestroy", g_rccl.CommDestroy) &&
+            load_sym(h, "ncclGetErrorString", g_rccl.GetErrorString);
+  if (!ok) { err = "librccl lacks a required symbol"; dlclose(h); return false; }
+  g_rccl.handle = h;
+  return true;
+}
+
+bool load_rocfft(std::string& err) {
+  if (g_rocfft.handle) return true;
+  void* h = dlopen("librocfft.so.0", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librocfft.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librocfft.so.0", RTLD_NOW | RTLD_LOCAL);
+  if (!h) { err = std::string("cannot load librocfft: ") + dlerror(); return false; }
+  RocfftApi& a = g_rocfft;
+  bool ok = load_sym(h, "rocfft_setup", a.setup) && load_sym(h, "rocfft_plan_create", a.plan_create) &&
+            load_sym(h, "rocfft_plan_destroy", a.plan_destroy) &&
+            load_sym(h, "rocfft_plan_get_work_buffer_size", a.plan_get_work_buffer_size) &&
+            load_sym(h, "rocfft_execution_info_create", a.execution_info_create) &&
+            load_sym(h, "rocfft_execution_info_destroy", a.execution_info_destroy) &&
+            load_sym(h, "rocfft_execution_info_set_stream", a.execution_info_set_stream) &&
+            load_sym(h, "rocfft_execution_info_set_work_buffer", a.execution_info_set_work_buffer) &&
+            load_sym(h, "rocfft_execute", a.execute);
+  if (!ok) { err = "librocfft lacks a required symbol"; dlclose(h); return false; }
+  a.handle = h;
+  return true;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct prisim_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  char devname[64] = {0};
+  int cu_count = 0, clock_khz = 0;
+
+  // array
+  bool array_set = false;
+  int64_t nbl = 0, nchan = 0, nt_max = 0;
+  DevBuf blx, bly, blz, freqs, fsq, cube, grad;
+  std::vector<double> h_freqs;
+  bool uniform = false;
+  double f0 = 0.0, df = 0.0;
+  int64_t nchan_pad = 0;
+
+  // sky
+  bool sky_set = false;
+  int64_t nsrc = 0;
+  bool taper = false;
+  double pc[3] = {0, 0, 1};
+  DevBuf dirs, dirs_prep, pb, packed, partial, scratch;
+
+  // events / timing
+  hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+  bool timing_pending = false;
+  prisim_timing timing{};
+
+  // tuning overrides
+  int tune_ct = 0, tune_chunk = 0, tune_nsplit = 0;
+
+  // comm
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  DevBuf gathered;
+
+  // fft
+  rocfft_plan fft_plan = nullptr;
+  rocfft_execution_info fft_info = nullptr;
+  size_t fft_len = 0, fft_batch = 0;
+  DevBuf fft_work, fft_buf, dt_out, dt_pow, dt_wts;
+};
+
+namespace {
+
+int fail(prisim_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? PRISIM_ENOMEM : PRISIM_ENODEV,              \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                         \
+    }                                                                                          \
+  } while (0)
+
+int ensure(prisim_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (b.bytes >= bytes && b.p) return PRISIM_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return fail(ctx, PRISIM_ENOMEM, std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+  }
+  b.bytes = bytes;
+  return PRISIM_OK;
+}
+
+void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// Collect the pending hipEvent timings of the last compute() (requires the stream to be idle).
+void harvest_timing(prisim_ctx* ctx) {
+  if (!ctx->timing_pending) return;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, ctx->ev_c0, ctx->ev_c1) == hipSuccess) ctx->timing.last_compute_ms = ms;
+  if (hipEventElapsedTime(&ms, ctx->ev_k0, ctx->ev_k1) == hipSuccess) {
+    ctx->timing.last_kernel_ms = ms;
+    ctx->timing.sum_kernel_ms += ms;
+    ctx->timing.n_kernel += 1;
+  }
+  ctx->timing_pending = false;
+}
+
+struct Plan {
+  int kernel;      // PRISIM_KERNEL_*
+  bool f32;
+  int ct;
+  int chunk;
+  int nsplit;
+  int64_t src_per_split;
+  int64_t nsrc_pad;
+  int ntiles;
+  int nbgroups;
+};
+
+Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
+  Plan pl{};
+  pl.f32 = (precision == PRISIM_FP32);
+  pl.kernel = kernel;
+  if (kernel == PRISIM_KERNEL_AUTO) pl.kernel = ctx->uniform ? PRISIM_KERNEL_RECURRENCE : PRISIM_KERNEL_DIRECT;
+  const int64_t nbl = ctx->nbl, nchan = ctx->nchan, nsrc = ctx->nsrc;
+  pl.nbgroups = (int)((nbl + kBlockThreads - 1) / kBlockThreads);
+  // channel tile: largest tile that still yields enough blocks to fill 256 CUs x 4 blocks
+  const int max_ct = pl.f32 ? 32 : 16;
+  int ct = ctx->tune_ct;
+  if (ct == 0) {
+    ct = max_ct;
+    const int64_t want_blocks = 1024;
+    while (ct > 8) {
+      const int64_t tiles = (nchan + ct - 1) / ct;
+      const int64_t max_split = std::max<int64_t>(1, nsrc / 64);
+      if (tiles * pl.nbgroups * max_split >= want_blocks) break;
+      ct /= 2;
+    }
+  }
+  pl.ct = ct;
+  pl.ntiles = (int)((nchan + ct - 1) / ct);
+  // LDS chunk: <= 16 KiB of pbflux per chunk (4 x 16-byte pieces per thread)
+  const int esz = pl.f32 ? 4 : 8;
+  int chunk = ctx->tune_chunk ? ctx->tune_chunk : 64;
+  const int max_chunk = 16384 / (ct * esz);
+  if (chunk > max_chunk) chunk = max_chunk;
+  if (chunk > 256) chunk = 256;
+  if (chunk < 1) chunk = 1;
+  pl.chunk = chunk;
+  pl.nsrc_pad = round_up(std::max<int64_t>(nsrc, 1), chunk);
+  // source split so that small problems still fill the GPU; each split is a multiple of the chunk
+  int nsplit = ctx->tune_nsplit;
+  const int64_t nchunks = pl.nsrc_pad / chunk;
+  if (nsplit == 0) {
+    const int64_t base = (int64_t)pl.ntiles * pl.nbgroups;
+    nsplit = 1;
+    if (base < 1024) nsplit = (int)std::min<int64_t>((1024 + base - 1) / base, nchunks);
+    if (nsplit > 64) nsplit = 64;
+  }
+  if (nsplit > nchunks) nsplit = (int)nchunks;
+  if (nsplit < 1) nsplit = 1;
+  const int64_t chunks_per_split = (nchunks + nsplit - 1) / nsplit;
+  pl.src_per_split = chunks_per_split * chunk;
+  pl.nsplit = (int)((nchunks + chunks_per_split - 1) / chunks_per_split);
+  return pl;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* prisim_hip_version(void) { return "prisim_hip 0.1 gfx950"; }
+
+const char* prisim_hip_last_error(const prisim_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int prisim_hip_create(int device, prisim_ctx** out) {
+  if (!out) return fail(nullptr, PRISIM_EINVAL, "out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, PRISIM_ENODEV, std::string("no HIP device available: ") + hipGetErrorString(e));
+  if (device < 0 || device >= ndev)
+    return fail(nullptr, PRISIM_EINVAL, "device index out of range (" + std::to_string(ndev) + " visible)");
+  prisim_ctx* ctx = new (std::nothrow) prisim_ctx();
+  if (!ctx) return fail(nullptr, PRISIM_ENOMEM, "out of host memory");
+  ctx->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev_c0)) != hipSuccess || (e = hipEventCreate(&ctx->ev_c1)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev_k0)) != hipSuccess || (e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) {
+    std::string m = std::string("HIP context setup failed: ") + hipGetErrorString(e);
+    delete ctx;
+    return fail(nullptr, PRISIM_ENODEV, m);
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s)", prop.name, prop.gcnArchName);
+    ctx->cu_count = prop.multiProcessorCount;
+    ctx->clock_khz = prop.clockRate;
+  }
+  *out = ctx;
+  return PRISIM_OK;
+}
+
+void prisim_hip_destroy(prisim_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+  if (ctx->fft_plan && g_rocfft.plan_destroy) g_rocfft.plan_destroy(ctx->fft_plan);
+  if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
+  for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->cube, &ctx->grad, &ctx->dirs,
+                    &ctx->dirs_prep, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered,
+                    &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts})
+    release(*b);
+  for (hipEvent_t ev : {ctx->ev_c0, ctx->ev_c1, ctx->ev_k0, ctx->ev_k1})
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, const double* freqs_hz, int64_t nchan,
+                         int64_t nt_max) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!bl_enu || !freqs_hz) return fail(ctx, PRISIM_EINVAL, "bl_enu / freqs_hz is NULL");
+  if (nbl <= 0 || nchan <= 0 || nt_max <= 0) return fail(ctx, PRISIM_EINVAL, "nbl, nchan and nt_max must be positive");
+  if (nbl > (int64_t)1 << 30 || nchan > (int64_t)1 << 24) return fail(ctx, PRISIM_EINVAL, "nbl or nchan too large");
+  for (int64_t i = 0; i < nchan; ++i)
+    if (!std::isfinite(freqs_hz[i])) return fail(ctx, PRISIM_EINVAL, "non-finite channel frequency");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->array_set = false;
+  ctx->sky_set = false;
+  std::vector<double> x(nbl), y(nbl), z(nbl);
+  for (int64_t b = 0; b < nbl; ++b) {
+    x[b] = bl_enu[3 * b]; y[b] = bl_enu[3 * b + 1]; z[b] = bl_enu[3 * b + 2];
+    if (!std::isfinite(x[b]) || !std::isfinite(y[b]) || !std::isfinite(z[b]))
+      return fail(ctx, PRISIM_EINVAL, "non-finite baseline component");
+  }
+  int rc;
+  const size_t bb = (size_t)nbl * sizeof(double);
+  if ((rc = ensure(ctx, ctx->blx, bb)) || (rc = ensure(ctx, ctx->bly, bb)) || (rc = ensure(ctx, ctx->blz, bb))) return rc;
+  ctx->nchan_pad = round_up(nchan, 64);
+  if ((rc = ensure(ctx, ctx->freqs, (size_t)nchan * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->fsq, (size_t)ctx->nchan_pad * sizeof(float)))) return rc;
+  const size_t cube_bytes = (size_t)nt_max * nbl * nchan * 2 * sizeof(double);
+  if ((rc = ensure(ctx, ctx->cube, cube_bytes))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->blx.p, x.data(), bb, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->bly.p, y.data(), bb, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->blz.p, z.data(), bb, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->freqs.p, freqs_hz, (size_t)nchan * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->cube.p, 0, cube_bytes, ctx->stream));
+  HIPCHK(ctx, launch_fsq((const double*)ctx->freqs.p, (float*)ctx->fsq.p, nchan, ctx->nchan_pad, 1e-8, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->h_freqs.assign(freqs_hz, freqs_hz + nchan);
+  ctx->nbl = nbl; ctx->nchan = nchan; ctx->nt_max = nt_max;
+  // uniform channel grid?  f_k = f0 + k*df to within 1e-7 Hz (phase error <= 1e-13 cycles at 1 us delay)
+  ctx->f0 = freqs_hz[0];
+  ctx->df = nchan > 1 ? (freqs_hz[nchan - 1] - freqs_hz[0]) / (double)(nchan - 1) : 0.0;
+  ctx->uniform = true;
+  for (int64_t k = 0; k < nchan; ++k)
+    if (std::fabs(freqs_hz[k] - (ctx->f0 + (double)k * ctx->df)) > 1e-7) { ctx->uniform = false; break; }
+  release(ctx->grad);
+  ctx->array_set = true;
+  return PRISIM_OK;
+}
+
+static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, const double* pc_dircos,
+                         const double* fwhm_deg) {
+  if (nsrc < 0) return fail(ctx, PRISIM_EINVAL, "nsrc must be non-negative");
+  if (nsrc > 0 && !dircos) return fail(ctx, PRISIM_EINVAL, "dircos is NULL");
+  if (!pc_dircos) return fail(ctx, PRISIM_EINVAL, "pc_dircos is NULL");
+  for (int i = 0; i < 3; ++i)
+    if (!std::isfinite(pc_dircos[i])) return fail(ctx, PRISIM_EINVAL, "non-finite pc_dircos");
+  std::vector<double> d4((size_t)std::max<int64_t>(nsrc, 1) * 4, 0.0);
+  for (int64_t s = 0; s < nsrc; ++s) {
+    for (int i = 0; i < 3; ++i) {
+      const double v = dircos[3 * s + i];
+      if (!std::isfinite(v)) return fail(ctx, PRISIM_EINVAL, "non-finite direction cosine");
+      d4[4 * s + i] = v;
+    }
+    double kappa = 0.0;
+    if (fwhm_deg) {
+      const double fw = fwhm_deg[s];
+      if (!std::isfinite(fw) || fw < 0.0) return fail(ctx, PRISIM_EINVAL, "invalid source FWHM");
+      // interferometry.py:6268-6283:  w = exp(-ln2 * (2 sin(FWHM/2))^2 * (|b|^2 - (b.s)^2) * f^2 / c^2)
+      const double fd = 2.0 * std::sin(0.5 * fw * M_PI / 180.0);
+      kappa = M_LN2 * fd * fd;
+    }
+    d4[4 * s + 3] = kappa;
+  }
+  int rc;
+  if ((rc = ensure(ctx, ctx->dirs, d4.size() * sizeof(double)))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->dirs.p, d4.data(), d4.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // d4 is a local
+  ctx->nsrc = nsrc;
+  ctx->taper = fwhm_deg != nullptr;
+  for (int i = 0; i < 3; ++i) ctx->pc[i] = pc_dircos[i];
+  return PRISIM_OK;
+}
+
+int prisim_hip_set_sky(prisim_ctx* ctx, const prisim_sky* sky) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->sky_set = false;
+  if (sky->nsrc > 0 && !sky->pbflux) return fail(ctx, PRISIM_EINVAL, "pbflux is NULL");
+  int rc = upload_common(ctx, sky->nsrc, sky->dircos, sky->pc_dircos, sky->fwhm_deg);
+  if (rc) return rc;
+  const int64_t n = sky->nsrc * ctx->nchan;
+  if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+  if (n > 0) {
+    if (sky->pbflux_is_f32) {
+      DevBuf tmp;
+      if ((rc = ensure(ctx, tmp, (size_t)n * sizeof(float)))) return rc;
+      hipError_t e = hipMemcpyAsync(tmp.p, sky->pbflux, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = launch_f32_to_f64((const float*)tmp.p, (double*)ctx->pb.p, n, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      release(tmp);
+      HIPCHK(ctx, e);
+    } else {
+      HIPCHK(ctx, hipMemcpyAsync(ctx->pb.p, sky->pbflux, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
+  ctx->sky_set = true;
+  return PRISIM_OK;
+}
+
+int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_analytic");
+  if (sky->beam_kind < PRISIM_BEAM_DELTA || sky->beam_kind > PRISIM_BEAM_AIRY)
+    return fail(ctx, PRISIM_EINVAL, "unknown beam_kind");
+  if (sky->nsrc > 0 && (!sky->flux_ref || !sky->spindex)) return fail(ctx, PRISIM_EINVAL, "flux_ref / spindex is NULL");
+  if (!(sky->ref_freq_hz > 0.0)) return fail(ctx, PRISIM_EINVAL, "ref_freq_hz must be positive");
+  if (sky->beam_kind != PRISIM_BEAM_DELTA && !(sky->diameter_m > 0.0))
+    return fail(ctx, PRISIM_EINVAL, "diameter_m must be positive");
+  if (!sky->beam_pc_dircos) return fail(ctx, PRISIM_EINVAL, "beam_pc_dircos is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->sky_set = false;
+  int rc = upload_common(ctx, sky->nsrc, sky->dircos, sky->pc_dircos, sky->fwhm_deg);
+  if (rc) return rc;
+  const int64_t ns = sky->nsrc;
+  const int64_t n = ns * ctx->nchan;
+  if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+  if (ns > 0) {
+    DevBuf fr, sp;
+    if ((rc = ensure(ctx, fr, (size_t)ns * sizeof(double))) || (rc = ensure(ctx, sp, (size_t)ns * sizeof(double)))) {
+      release(fr); release(sp);
+      return rc;
+    }
+    hipError_t e = hipMemcpyAsync(fr.p, sky->flux_ref, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sp.p, sky->spindex, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      BeamParams bp{};
+      bp.dirs = (const double*)ctx->dirs.p;
+      bp.flux_ref = (const double*)fr.p;
+      bp.spindex = (const double*)sp.p;
+      bp.freqs = (const double*)ctx->freqs.p;
+      bp.ref_freq = sky->ref_freq_hz;
+      bp.beam_kind = sky->beam_kind;
+      bp.diameter = sky->diameter_m;
+      bp.bpc_x = sky->beam_pc_dircos[0]; bp.bpc_y = sky->beam_pc_dircos[1]; bp.bpc_z = sky->beam_pc_dircos[2];
+      bp.nsrc = ns; bp.nchan = ctx->nchan;
+      bp.pb_out = (double*)ctx->pb.p;
+      e = launch_beam_flux(bp, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release(fr); release(sp);
+    HIPCHK(ctx, e);
+  }
+  ctx->sky_set = true;
+  return PRISIM_OK;
+}
+
+int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->sky_set) return fail(ctx, PRISIM_ESTATE, "no sky set");
+  if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int64_t n = ctx->nsrc * ctx->nchan;
+  if (n > 0) HIPCHK(ctx, hipMemcpy(out, ctx->pb.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return PRISIM_OK;
+}
+
+// one sky-sum pass into `dst` ([nbl][nchan] complex128); scale_comp >= 0 multiplies pbflux rows by dircos[:,comp]
+static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp, bool timed) {
+  SkyvisParams p{};
+  p.bl_x = (const double*)ctx->blx.p; p.bl_y = (const double*)ctx->bly.p; p.bl_z = (const double*)ctx->blz.p;
+  p.nbl = ctx->nbl; p.nchan = ctx->nchan;
+  p.f0 = ctx->f0; p.df = ctx->df; p.inv_c = 1.0 / kC;
+  p.dirs = (const double*)ctx->dirs.p;
+  p.dirs_prep = (const double*)ctx->dirs_prep.p;
+  p.pb_packed = ctx->packed.p;
+  p.fsq = (const float*)ctx->fsq.p;
+  p.fsq_scale = 1e16;
+  p.nsrc = ctx->nsrc; p.nsrc_pad = pl.nsrc_pad;
+  p.pc_x = ctx->pc[0]; p.pc_y = ctx->pc[1]; p.pc_z = ctx->pc[2];
+  p.taper = ctx->taper ? 1 : 0;
+  p.ntiles = pl.ntiles; p.nbgroups = pl.nbgroups; p.nsplit = pl.nsplit; p.src_per_split = pl.src_per_split;
+  p.src_chunk = pl.chunk;
+  p.flush_src = 1024;
+  p.scale_comp = scale_comp;
+  if (pl.kernel == PRISIM_KERNEL_DIRECT) {
+    p.out = dst;
+    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    HIPCHK(ctx, launch_skyvis_direct(p, (const double*)ctx->freqs.p, (const double*)ctx->pb.p,
+                                     scale_comp >= 0 ? (const double*)ctx->dirs.p : nullptr, ctx->stream));
+    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    return PRISIM_OK;
+  }
+  HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
+                          pl.ntiles, (const double*)ctx->dirs.p, scale_comp, ctx->stream));
+  p.out = pl.nsplit > 1 ? (double*)ctx->partial.p : dst;
+  if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+  HIPCHK(ctx, launch_skyvis_rec(p, pl.f32, pl.ct, ctx->stream));
+  if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  if (pl.nsplit > 1)
+    HIPCHK(ctx, launch_reduce_partials((const double*)ctx->partial.p, dst, ctx->nbl * ctx->nchan * 2, pl.nsplit, ctx->stream));
+  return PRISIM_OK;
+}
+
+int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad, int64_t slot) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set || !ctx->sky_set) return fail(ctx, PRISIM_ESTATE, "set_array and set_sky must precede compute");
+  if (precision != PRISIM_FP64 && precision != PRISIM_FP32) return fail(ctx, PRISIM_EINVAL, "unknown precision");
+  if (kernel < PRISIM_KERNEL_AUTO || kernel > PRISIM_KERNEL_DIRECT) return fail(ctx, PRISIM_EINVAL, "unknown kernel id");
+  if (slot < 0 || slot >= ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "slot out of range");
+  if (kernel == PRISIM_KERNEL_RECURRENCE && !ctx->uniform)
+    return fail(ctx, PRISIM_EINVAL, "recurrence kernel needs a uniform channel grid");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->timing_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); harvest_timing(ctx); }
+  const size_t slot_elems = (size_t)ctx->nbl * ctx->nchan * 2;
+  double* dst = (double*)ctx->cube.p + (size_t)slot * slot_elems;
+  int rc;
+  if (want_grad) {
+    const size_t gbytes = (size_t)ctx->nt_max * 3 * slot_elems * sizeof(double);
+    if (!ctx->grad.p) {
+      if ((rc = ensure(ctx, ctx->grad, gbytes))) return rc;
+      HIPCHK(ctx, hipMemsetAsync(ctx->grad.p, 0, gbytes, ctx->stream));
+    }
+  }
+  if (ctx->nsrc == 0) {   // interferometry.py:6378-6382: visibilities stay zero
+    HIPCHK(ctx, hipMemsetAsync(dst, 0, slot_elems * sizeof(double), ctx->stream));
+    if (want_grad)
+      HIPCHK(ctx, hipMemsetAsync((double*)ctx->grad.p + (size_t)slot * 3 * slot_elems, 0, 3 * slot_elems * sizeof(double), ctx->stream));
+    ctx->timing.last_terms = 0;
+    return PRISIM_OK;
+  }
+  const Plan pl = make_plan(ctx, precision, kernel);
+  if (pl.kernel == PRISIM_KERNEL_RECURRENCE) {
+    const size_t pbytes = (size_t)pl.ntiles * pl.nsrc_pad * pl.ct * (pl.f32 ? 4 : 8);
+    if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;
+    if ((rc = ensure(ctx, ctx->dirs_prep, (size_t)pl.nsrc_pad * 4 * sizeof(double)))) return rc;
+    if (pl.nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)pl.nsplit * slot_elems * sizeof(double)))) return rc;
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));
+  if (pl.kernel == PRISIM_KERNEL_RECURRENCE)
+    HIPCHK(ctx, launch_prep_dirs((const double*)ctx->dirs.p, (double*)ctx->dirs_prep.p, ctx->nsrc, pl.nsrc_pad, ctx->pc[0],
+                                 ctx->pc[1], ctx->pc[2], 1.0 / kC, ctx->stream));
+  if ((rc = run_pass(ctx, pl, dst, -1, true))) return rc;
+  if (want_grad) {
+    for (int comp = 0; comp < 3; ++comp) {
+      double* gdst = (double*)ctx->grad.p + ((size_t)slot * 3 + comp) * slot_elems;
+      if ((rc = run_pass(ctx, pl, gdst, comp, false))) return rc;
+    }
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev_c1, ctx->stream));
+  ctx->timing_pending = true;
+  ctx->timing.last_terms = ctx->nbl * ctx->nchan * ctx->nsrc;
+  ctx->timing.last_kernel_id = pl.kernel;
+  ctx->timing.last_chan_tile = pl.kernel == PRISIM_KERNEL_RECURRENCE ? pl.ct : 1;
+  ctx->timing.last_nsplit = pl.kernel == PRISIM_KERNEL_RECURRENCE ? pl.nsplit : 1;
+  return PRISIM_OK;
+}
+
+static void to_c64(const double* in, float* out, size_t n2) {
+  for (size_t i = 0; i < n2; ++i) out[i] = (float)in[i];
+}
+
+int prisim_hip_get_vis(prisim_ctx* ctx, int64_t slot, void* vis, void* grad, int out_is_c64) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (slot < 0 || slot >= ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "slot out of range");
+  if (!vis) return fail(ctx, PRISIM_EINVAL, "vis is NULL");
+  if (grad && !ctx->grad.p) return fail(ctx, PRISIM_ESTATE, "no gradient has been computed");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  harvest_timing(ctx);
+  const size_t slot_elems = (size_t)ctx->nbl * ctx->nchan * 2;
+  const double* src = (const double*)ctx->cube.p + (size_t)slot * slot_elems;
+  const double* gsrc = grad ? (const double*)ctx->grad.p + (size_t)slot * 3 * slot_elems : nullptr;
+  if (!out_is_c64) {
+    HIPCHK(ctx, hipMemcpy(vis, src, slot_elems * sizeof(double), hipMemcpyDeviceToHost));
+    if (grad) HIPCHK(ctx, hipMemcpy(grad, gsrc, 3 * slot_elems * sizeof(double), hipMemcpyDeviceToHost));
+  } else {
+    std::vector<double> tmp;
+    try { tmp.resize(grad ? 3 * slot_elems : slot_elems); } catch (...) { return fail(ctx, PRISIM_ENOMEM, "host staging"); }
+    HIPCHK(ctx, hipMemcpy(tmp.data(), src, slot_elems * sizeof(double), hipMemcpyDeviceToHost));
+    to_c64(tmp.data(), (float*)vis, slot_elems);
+    if (grad) {
+      HIPCHK(ctx, hipMemcpy(tmp.data(), gsrc, 3 * slot_elems * sizeof(double), hipMemcpyDeviceToHost));
+      to_c64(tmp.data(), (float*)grad, 3 * slot_elems);
+    }
+  }
+  return PRISIM_OK;
+}
+
+int prisim_hip_skyvis(prisim_ctx* ctx, const prisim_sky* sky, int precision, int kernel, void* vis, void* grad,
+                      int out_is_c64) {
+  int rc = prisim_hip_set_sky(ctx, sky);
+  if (rc) return rc;
+  if ((rc = prisim_hip_compute(ctx, precision, kernel, grad != nullptr, 0))) return rc;
+  return prisim_hip_get_vis(ctx, 0, vis, grad, out_is_c64);
+}
+
+int prisim_hip_sync(prisim_ctx* ctx) {
+  if (!ctx) return PRISIM_EINVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  harvest_timing(ctx);
+  return PRISIM_OK;
+}
+
+int prisim_hip_get_timing(prisim_ctx* ctx, prisim_timing* out, int reset) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
+  if (ctx->timing_pending) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    harvest_timing(ctx);
+  }
+  *out = ctx->timing;
+  if (reset) { ctx->timing.sum_kernel_ms = 0.0; ctx->timing.n_kernel = 0; }
+  return PRISIM_OK;
+}
+
+int prisim_hip_device_info(prisim_ctx* ctx, int* cu_count, int* clock_khz, char name[64]) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (cu_count) *cu_count = ctx->cu_count;
+  if (clock_khz) *clock_khz = ctx->clock_khz;
+  if (name) { memcpy(name, ctx->devname, 64); name[63] = 0; }
+  return PRISIM_OK;
+}
+
+int prisim_hip_set_tuning(prisim_ctx* ctx, int chan_tile, int src_chunk, int nsplit) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (chan_tile != 0 && chan_tile != 8 && chan_tile != 16 && chan_tile != 32 && chan_tile != 64)
+    return fail(ctx, PRISIM_EINVAL, "chan_tile must be 0, 8, 16, 32 or 64");
+  if (src_chunk < 0 || src_chunk > 256 || nsplit < 0 || nsplit > 4096)
+    return fail(ctx, PRISIM_EINVAL, "src_chunk must be in [0,256], nsplit in [0,4096]");
+  ctx->tune_ct = chan_tile; ctx->tune_chunk = src_chunk; ctx->tune_nsplit = nsplit;
+  return PRISIM_OK;
+}
+
+// ---- delay transform ------------------------------------------------------------------------
+
+int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts, double pad, double* out,
+                               double* lags_out, double* out_power, double power_scale) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
+  if (!(pad >= 0.0) || !std::isfinite(pad)) pad = 0.0;   // interferometry.py:8091-8092
+  if (!ctx->uniform || ctx->nchan < 2) return fail(ctx, PRISIM_EINVAL, "delay transform needs >= 2 uniformly spaced channels");
+  std::string lerr;
+  if (!load_rocfft(lerr)) return fail(ctx, PRISIM_ELIB, lerr);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  RocfftApi& F = g_rocfft;
+  if (!F.setup_done) {
+    if (F.setup() != rocfft_status_success) return fail(ctx, PRISIM_ELIB, "rocfft_setup failed");
+    F.setup_done = true;
+  }
+  const int64_t nchan = ctx->nchan, nbl = ctx->nbl;
+  const int64_t npad = (int64_t)((double)nchan * pad);                  // :8123
+  const int64_t nfft = nchan + npad;
+  const double factor = 1.0 + pad;                                      // :8131
+  const int64_t nout = (int64_t)std::ceil((double)nfft / factor - 1e-12);   // len(arange(0, nfft, factor))
+  const int64_t nrows = nt * nbl;
+  int rc;
+  if ((rc = ensure(ctx, ctx->fft_buf, (size_t)nrows * nfft * 2 * sizeof(double)))) return rc;
+  if (bpwts) {
+    if ((rc = ensure(ctx, ctx->dt_wts, (size_t)nbl * nchan * sizeof(double)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dt_wts.p, bpwts, (size_t)nbl * nchan * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (!ctx->fft_plan || ctx->fft_len != (size_t)nfft || ctx->fft_batch != (size_t)nrows) {
+    if (ctx->fft_plan) { F.plan_destroy(ctx->fft_plan); ctx->fft_plan = nullptr; }
+    size_t len = (size_t)nfft;
+    if (F.plan_create(&ctx->fft_plan, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                      rocfft_precision_double, 1, &len, (size_t)nrows, nullptr) != rocfft_status_success) {
+      ctx->fft_plan = nullptr;
+      return fail(ctx, PRISIM_ELIB, "rocfft_plan_create failed");
+    }
+    ctx->fft_len = (size_t)nfft; ctx->fft_batch = (size_t)nrows;
+    if (!ctx->fft_info && F.execution_info_create(&ctx->fft_info) != rocfft_status_success)
+      return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_create failed");
+    if (F.execution_info_set_stream(ctx->fft_info, ctx->stream) != rocfft_status_success)
+      return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_stream failed");
+    size_t wbytes = 0;
+    F.plan_get_work_buffer_size(ctx->fft_plan, &wbytes);
+    if (wbytes) {
+      if ((rc = ensure(ctx, ctx->fft_work, wbytes))) return rc;
+      if (F.execution_info_set_work_buffer(ctx->fft_info, ctx->fft_work.p, wbytes) != rocfft_status_success)
+        return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_work_buffer failed");
+    }
+  }
+  HIPCHK(ctx, launch_dt_prepare((const double*)ctx->cube.p, bpwts ? (const double*)ctx->dt_wts.p : nullptr,
+                                (double*)ctx->fft_buf.p, nrows, nbl, nchan, nfft, ctx->stream));
+  void* bufs[1] = {ctx->fft_buf.p};
+  if (F.execute(ctx->fft_plan, bufs, nullptr, ctx->fft_info) != rocfft_status_success)
+    return fail(ctx, PRISIM_ELIB, "rocfft_execute failed");
+  // rocFFT's inverse is unnormalised: sum_n x[n] e^{+2 pi i k n / N'}.  The reference forms
+  // ifft(x) * N' * df (:8125) = that sum times df.
+  const double scale = ctx->df;
+  if (out && (rc = ensure(ctx, ctx->dt_out, (size_t)nrows * nout * 2 * sizeof(double)))) return rc;
+  if (out_power && (rc = ensure(ctx, ctx->dt_pow, (size_t)nrows * nout * sizeof(double)))) return rc;
+  HIPCHK(ctx, launch_dt_finish((const double*)ctx->fft_buf.p, out ? (double*)ctx->dt_out.p : nullptr,
+                               out_power ? (double*)ctx->dt_pow.p : nullptr, nrows, nfft, nout, factor, scale, power_scale,
+                               ctx->stream));
+  if (out) HIPCHK(ctx, hipMemcpyAsync(out, ctx->dt_out.p, (size_t)nrows * nout * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_power) HIPCHK(ctx, hipMemcpyAsync(out_power, ctx->dt_pow.p, (size_t)nrows * nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (lags_out) {
+    // DSP.spectral_axis(nchan, delx=df, shift=True) (:8114) == fftshift(fftfreq(nchan, df))
+    for (int64_t i = 0; i < nchan; ++i) {
+      const int64_t k = i - nchan / 2;
+      lags_out[i] = (double)k / ((double)nchan * ctx->df);
+    }
+  }
+  return PRISIM_OK;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------
+
+int prisim_hip_comm_unique_id(char id[128]) {
+  if (!id) return PRISIM_EINVAL;
+  std::string lerr;
+  if (!load_rccl(lerr)) return fail(nullptr, PRISIM_ELIB, lerr);
+  ncclUniqueId uid;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclResult_t r = g_rccl.GetUniqueId(&uid);
+  if (r != ncclSuccess) return fail(nullptr, PRISIM_ELIB, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
+  memcpy(id, &uid, 128);
+  return PRISIM_OK;
+}
+
+int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int rank) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!id || nranks <= 0 || rank < 0 || rank >= nranks) return fail(ctx, PRISIM_EINVAL, "bad communicator arguments");
+  std::string lerr;
+  if (!load_rccl(lerr)) return fail(ctx, PRISIM_ELIB, lerr);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->comm) { g_rccl.CommDestroy(ctx->comm); ctx->comm = nullptr; }
+  ncclUniqueId uid;
+  memcpy(&uid, id, 128);
+  ncclResult_t r = g_rccl.CommInitRank(&ctx->comm, nranks, uid, rank);
+  if (r != ncclSuccess) {
+    ctx->comm = nullptr;
+    return fail(ctx, PRISIM_ELIB, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+  }
+  ctx->nranks = nranks; ctx->rank = rank;
+  return PRISIM_OK;
+}
+
+int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t shard = (size_t)nt * ctx->nbl * ctx->nchan * 2;   // doubles
+  int rc;
+  if ((rc = ensure(ctx, ctx->gathered, shard * (size_t)ctx->nranks * sizeof(double)))) return rc;
+  if (ctx->nranks == 1 && !ctx->comm) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->gathered.p, ctx->cube.p, shard * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return PRISIM_OK;
+  }
+  if (!ctx->comm) return fail(ctx, PRISIM_ESTATE, "comm_init has not been called");
+  ncclResult_t r = g_rccl.AllGather(ctx->cube.p, ctx->gathered.p, shard, ncclDouble, ctx->comm, ctx->stream);
+  if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+  return PRISIM_OK;
+}
+
+int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, double* out) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
+  if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)nt * ctx->nbl * ctx->nchan * 2 * (size_t)ctx->nranks * sizeof(double);
+  if (bytes > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt larger than the gathered cube");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(out, ctx->gathered.p, bytes, hipMemcpyDeviceToHost));
+  return PRISIM_OK;
+}
+
+int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
+  if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int64_t n = nt * ctx->nbl * ctx->nchan * 2 * (int64_t)ctx->nranks;
+  if ((size_t)n * sizeof(double) > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt larger than the gathered cube");
+  int rc;
+  if ((rc = ensure(ctx, ctx->scratch, 1025 * sizeof(double)))) return rc;
+  HIPCHK(ctx, launch_checksum((const double*)ctx->gathered.p, n, (double*)ctx->scratch.p, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->scratch.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PRISIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// skyvis_kernels.h -- internal launcher interface between the C-ABI layer (capi.cpp) and the
+// HIP kernels (skyvis_kernels.hip, beam_kernels.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace prisim {
+
+static constexpr int kBlockThreads = 256;   // 4 wavefronts; lanes = baselines
+
+struct SkyvisParams {
+  // array (resident)
+  const double* bl_x;        // [nbl] metres, East
+  const double* bl_y;        // [nbl] North
+  const double* bl_z;        // [nbl] Up
+  int64_t nbl;
+  int64_t nchan;
+  double f0;                 // Hz, channel 0 (recurrence kernel: uniform grid f0 + k*df)
+  double df;                 // Hz
+  double inv_c;              // 1 / 299792458
+  // sky (per snapshot)
+  const double* dirs;        // [nsrc][4]: l, m, n, kappa = ln2 * (2 sin(fwhm/2))^2   (raw)
+  const double* dirs_prep;   // [nsrc_pad][4]: (l-lpc)/c, (m-mpc)/c, (n-npc)/c, kappa; zero rows past nsrc
+  const void* pb_packed;     // [ntiles][nsrc_pad][CT] of T, zero rows past nsrc
+  const float* fsq;          // [npad] (f_k*1e-8)^2*log2(e) (fp32 taper)
+  double fsq_scale;          // 1e16
+  int64_t nsrc;
+  int64_t nsrc_pad;          // nsrc rounded up to a multiple of src_chunk
+  double pc_x, pc_y, pc_z;   // phase-centre direction cosines
+  int32_t taper;
+  // decomposition
+  int32_t ntiles;            // channel tiles of CT channels
+  int32_t nbgroups;          // baseline groups of kBlockThreads
+  int32_t nsplit;            // source split factor (partials reduced afterwards)
+  int64_t src_per_split;
+  int32_t src_chunk;         // sources per LDS chunk
+  int32_t flush_src;         // fp32: flush accumulators into the fp64 cube every this many sources
+  int32_t scale_comp;        // direct kernel: gradient component or -1
+  int32_t pad_;
+  double* out;               // [nsplit][nbl][nchan] complex128 (nsplit==1: the cube slot itself)
+};
+
+hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);
+hipError_t launch_skyvis_direct(const SkyvisParams& p, const double* freqs, const double* pb, const double* scale,
+                                hipStream_t stream);
+hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct,
+                       int ntiles, const double* dirs, int scale_comp, hipStream_t stream);
+hipError_t launch_prep_dirs(const double* dirs, double* prep, int64_t nsrc, int64_t nsrc_pad, double pcx, double pcy,
+                            double pcz, double inv_c, hipStream_t stream);
+hipError_t launch_reduce_partials(const double* part, double* out, int64_t n2, int nsplit, hipStream_t stream);
+hipError_t launch_f32_to_f64(const float* in, double* out, int64_t n, hipStream_t stream);
+hipError_t launch_fsq(const double* freqs, float* fsq, int64_t nchan, int64_t npad, double scale, hipStream_t stream);
+
+// beam_kernels.hip
+struct BeamParams {
+  const double* dirs;        // [nsrc][4]
+  const double* flux_ref;    // [nsrc]
+  const double* spindex;     // [nsrc]
+  const double* freqs;       // [nchan]
+  double ref_freq;
+  int32_t beam_kind;
+  double diameter;
+  double bpc_x, bpc_y, bpc_z;  // beam pointing centre
+  int64_t nsrc, nchan;
+  double* pb_out;            // [nsrc][nchan]
+};
+hipError_t launch_beam_flux(const BeamParams& p, hipStream_t stream);
+
+// delay transform helpers (delay_kernels.hip)
+hipError_t launch_dt_prepare(const double* cube, const double* bpwts, double* work, int64_t nrows, int64_t nbl,
+                             int64_t nchan, int64_t nfft, hipStream_t stream);
+hipError_t launch_dt_finish(const double* work, double* out, double* out_power, int64_t nrows, int64_t nfft,
+                            int64_t nout, double factor, double scale, double power_scale, hipStream_t stream);
+hipError_t launch_checksum(const double* data, int64_t n, double* out, hipStream_t stream);
+
+}  // namespace prisim

@@ -1,0 +1,527 @@
+// skyvis_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the PRISim per-baseline sky-sum.
+//
+// Reference path replaced: prisim/interferometry.py:6255-6376 (InterferometerArray.observe):
+//   V[b,f] = sum_s pbflux[s,f] * w[s,b,f] * exp(-2 pi i f (tau[s,b] - taupc[b]))
+//   tau = dc . bl^T / c               (prisim/baseline_delay_horizon.py:240)
+//   w   = exp(-1/2 (u_perp/sigma)^2)  (prisim/interferometry.py:6265-6283)
+//
+// MI355X mapping:
+//   * lanes = baselines (64 consecutive baselines per wavefront), so pbflux[s,f] and the source
+//     direction are wave-uniform and are served by LDS broadcast reads; no cross-lane reduction is
+//     needed on the main path.
+//   * each thread owns CT consecutive channels of one baseline: 2*CT accumulators in VGPRs.
+//   * the nsrc x nbl x nchan phase matrix of the reference is never materialised: per (source,
+//     baseline, channel tile) one range-reduced seed phasor and one step phasor are formed
+//     (fp64 phase reduction), then the phasor is advanced along frequency by a complex rotation
+//     (4 VALU) and accumulated (2 FMA): 6 VALU slots / term.  The tile is seeded at its centre
+//     channel and walked in both directions (two independent dependency chains, half the drift).
+//   * sources are streamed through a double-buffered LDS ring in chunks (global -> VGPR -> LDS).
+//   * block id -> (pbflux slab, baseline group) is XCD-aware: all blocks resident on one XCD
+//     read the same pbflux slab, which therefore stays in that XCD's 4 MiB L2.
+//   * fp32 mode accumulates in fp32 registers and flushes into the fp64 cube every
+//     FLUSH_SRC sources, so the summation error does not grow with nsrc.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "skyvis_kernels.h"
+
+namespace prisim {
+
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ------------------------------------------------------------------------------------------
+// sincos of an angle given in CYCLES, |x| <= 0.5 (double), result in T.
+// returns (cos 2 pi x, sin 2 pi x)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sincos_cycles(double x, float& c, float& s) {
+  // quadrant reduction in fp64 (exact), polynomial in fp32 on |y| <= 1/8 cycle
+  double q = __builtin_rint(4.0 * x);
+  float y = (float)__builtin_fma(-0.25, q, x);
+  int qi = (int)q;
+  float y2 = y * y;
+  // sin(2 pi y) = y * (2pi + y^2 * (-(2pi)^3/3! + y^2 * ((2pi)^5/5! + y^2 * (-(2pi)^7/7! + y^2 * (2pi)^9/9!))))
+  float ps = 42.058693944897655f;                          // (2pi)^9/9! = 42.0586939...
+  ps = __builtin_fmaf(ps, y2, -76.70585975306136f);        // -(2pi)^7/7!
+  ps = __builtin_fmaf(ps, y2, 81.60524927607504f);         // (2pi)^5/5!
+  ps = __builtin_fmaf(ps, y2, -41.341702240399755f);       // -(2pi)^3/3!
+  float sy = __builtin_fmaf(y * y2, ps, y * 6.2831855f);   // 2pi rounded to f32: 6.28318548
+  sy = __builtin_fmaf(y, -1.7484555e-7f, sy);              // + y * (2pi - fl32(2pi))
+  // cos(2 pi y) = 1 + y^2 * (-(2pi)^2/2 + y^2 * ((2pi)^4/4! + y^2 * (-(2pi)^6/6! + y^2 * ((2pi)^8/8! - y^2 (2pi)^10/10!))))
+  float pc = -26.42625678337438f;                          // -(2pi)^10/10!
+  pc = __builtin_fmaf(pc, y2, 60.24464137187666f);         // (2pi)^8/8!
+  pc = __builtin_fmaf(pc, y2, -85.45681720669373f);        // -(2pi)^6/6!
+  pc = __builtin_fmaf(pc, y2, 64.93939402266829f);         // (2pi)^4/4!
+  pc = __builtin_fmaf(pc, y2, -19.739208802178716f);       // -(2pi)^2/2
+  float cy = __builtin_fmaf(pc, y2, 1.0f);
+  // rotate by q quarter turns: q=0:(c,s) 1:(-s,c) 2:(-c,-s) 3:(s,-c)
+  bool swap = (qi & 1) != 0;
+  float cc = swap ? sy : cy;
+  float ss = swap ? cy : sy;
+  bool negc = ((qi + 1) & 2) != 0;   // q mod 4 in {1,2}
+  bool negs = (qi & 2) != 0;         // q mod 4 in {2,3}
+  c = negc ? -cc : cc;
+  s = negs ? -ss : ss;
+}
+
+__device__ __forceinline__ void sincos_cycles(double x, double& c, double& s) {
+  // ocml sincospi: sin(pi*a), cos(pi*a)
+  sincospi(2.0 * x, &s, &c);
+}
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<double> { using type = double4; };
+
+// ------------------------------------------------------------------------------------------
+// Recurrence kernel
+// ------------------------------------------------------------------------------------------
+// waves per SIMD the register allocator is asked to leave room for (hipcc otherwise spends
+// up to 256 VGPRs on scheduling freedom and drops to 1-2 waves/SIMD, too few to keep the
+// 2-cycle fp32 VALU issue slots filled -- see tools/microbench_valu.hip results).
+template <typename T, int CT> struct WavesPerEU {
+  static constexpr int value = (sizeof(T) == 4) ? (CT <= 32 ? 4 : 2) : (CT <= 8 ? 4 : (CT <= 16 ? 3 : 2));
+};
+
+template <typename T, int CT, bool TAPER>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(WavesPerEU<T, CT>::value)))
+void k_skyvis_rec(const SkyvisParams p) {
+  static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
+  constexpr int HC = CT / 2;                       // channels per chain
+  constexpr int VE = 16 / (int)sizeof(T);           // elements per 16-byte piece
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int S = p.src_chunk;
+  // layout: [S][CT] T  |  [S] double4 = (s - s_pc)/c, kappa   (prepared by k_prep_dirs)
+  T* const lds_p = reinterpret_cast<T*>(smem_raw);
+  double4* const lds_d = reinterpret_cast<double4*>(smem_raw + (size_t)S * CT * sizeof(T));
+
+  // ---- XCD-aware block -> (slab, baseline group) map ------------------------------------
+  // Blocks are dealt round-robin to the 8 XCDs (blockIdx % 8 shares an XCD), so slab ids that
+  // are equal mod 8 live on one XCD and its L2 keeps that slab's pbflux rows hot.
+  const int xcd = blockIdx.x & 7;
+  const int j = blockIdx.x >> 3;
+  const int slab = xcd + 8 * (j / p.nbgroups);
+  const int bg = j % p.nbgroups;
+  if (slab >= p.ntiles * p.nsplit) return;
+  const int tile = slab % p.ntiles;
+  const int split = slab / p.ntiles;
+
+  const int64_t s_begin = (int64_t)split * p.src_per_split;
+  int64_t s_end = s_begin + p.src_per_split;
+  if (s_end > p.nsrc) s_end = p.nsrc;
+
+  const int tid = threadIdx.x;
+  const int64_t b_raw = (int64_t)bg * kBlockThreads + tid;
+  const bool b_valid = b_raw < p.nbl;
+  const int64_t b = b_valid ? b_raw : (p.nbl - 1);
+  // a wavefront whose first baseline is out of range does no arithmetic (wave-uniform)
+  const bool wave_active = ((int64_t)bg * kBlockThreads + (tid & ~63)) < p.nbl;
+
+  const double bx = p.bl_x[b], by = p.bl_y[b], bz = p.bl_z[b];
+  const int k0 = tile * CT;
+  const double fc = p.f0 + (double)(k0 + HC) * p.df;   // frequency of the seed (centre) channel
+  const double df = p.df;
+
+  // taper per-lane constants
+  double bl2_c2 = 0.0, bpc = 0.0;
+  if (TAPER) {
+    bl2_c2 = (bx * bx + by * by + bz * bz) * (p.inv_c * p.inv_c);
+    bpc = (bx * p.pc_x + by * p.pc_y + bz * p.pc_z) * p.inv_c;   // tau_pc: un-offset delay = d + bpc
+  }
+
+  T acc_re[CT], acc_im[CT];
+#pragma unroll
+  for (int k = 0; k < CT; ++k) { acc_re[k] = (T)0; acc_im[k] = (T)0; }
+
+  const T* const gp = reinterpret_cast<const T*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT;
+  const double4* const gd = reinterpret_cast<const double4*>(p.dirs_prep);
+
+  const int npieces = S * CT / VE;                 // 16-byte pieces of pbflux per chunk
+  constexpr int kMaxPiecesPerThread = 4;           // S*CT*sizeof(T) <= 16 KiB  (host enforces)
+
+  // global -> VGPR -> LDS staging of one chunk of sources.  The packed pbflux and the direction
+  // table are zero-padded by the host layer to a multiple of S sources past nsrc, and split
+  // ranges are multiples of S, so no bounds checks are needed here.
+  auto stage_chunk = [&](int64_t s0) {
+    T* lp = lds_p;
+    const uint4* src = reinterpret_cast<const uint4*>(gp + (size_t)s0 * CT);
+#pragma unroll
+    for (int u = 0; u < kMaxPiecesPerThread; ++u) {
+      const int i = tid + u * kBlockThreads;
+      if (i < npieces) reinterpret_cast<uint4*>(lp)[i] = src[i];
+    }
+    if (tid < S) lds_d[tid] = gd[s0 + tid];
+  };
+
+  double* const out = p.out + ((size_t)split * p.nbl * p.nchan) * 2;   // partial buffer of this split
+  bool first_flush = true;
+  int since_flush = 0;
+
+  auto flush = [&]() {
+    if (b_valid) {
+      double2* orow = reinterpret_cast<double2*>(out) + (size_t)b * p.nchan + k0;
+#pragma unroll
+      for (int k = 0; k < CT; ++k) {
+        if (k0 + k < p.nchan) {
+          double2 v = make_double2((double)acc_re[k], (double)acc_im[k]);
+          if (!first_flush) { double2 o = orow[k]; v.x += o.x; v.y += o.y; }
+          orow[k] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CT; ++k) { acc_re[k] = (T)0; acc_im[k] = (T)0; }
+    first_flush = false;
+    since_flush = 0;
+  };
+
+  const int64_t nsrc_local = s_end - s_begin;
+  const int nchunks = (int)((nsrc_local + S - 1) / S);
+
+  for (int ci = 0; ci < nchunks; ++ci) {
+    const int64_t s0 = s_begin + (int64_t)ci * S;
+    const bool more = (ci + 1) < nchunks;
+    __syncthreads();                 // everyone is done reading the previous chunk
+    stage_chunk(s0);
+    __syncthreads();
+
+    int ns = (int)((s_end - s0) < S ? (s_end - s0) : S);
+    if (wave_active) {
+      const T* lp = lds_p;
+      const double4* ld = lds_d;
+      for (int s = 0; s < ns; ++s) {
+        const double4 sv = ld[s];                                  // LDS broadcast
+        const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));   // seconds
+        double phc = d * fc;                                       // cycles at the centre channel
+        double th = d * df;                                        // cycles per channel step
+        phc -= __builtin_rint(phc);
+        th -= __builtin_rint(th);
+        T zc, zs, rc, rs;
+        sincos_cycles(phc, zc, zs);
+        sincos_cycles(th, rc, rs);
+        // exp(-2 pi i phi): z = (cos, -sin)
+        T ur = zc, ui = -zs;            // up chain: channel HC + jj
+        const T rr = rc, ri = -rs;      // step forward; step backward is conj(r)
+        T dr = fma_(ur, rr, ui * ri);        // z * conj(r): channel HC-1
+        T di = fma_(ui, rr, -(ur * ri));
+        const T* prow = lp + (size_t)s * CT;
+
+        if constexpr (!TAPER) {
+#pragma unroll
+          for (int jj = 0; jj < HC; jj += 4) {
+            // 4 channels up [HC+jj .. HC+jj+3], 4 channels down [HC-1-jj .. HC-4-jj]
+            const typename Vec4<T>::type pu = *reinterpret_cast<const typename Vec4<T>::type*>(prow + HC + jj);
+            const typename Vec4<T>::type pd = *reinterpret_cast<const typename Vec4<T>::type*>(prow + HC - 4 - jj);
+            const T pus[4] = {pu.x, pu.y, pu.z, pu.w};
+            const T pds[4] = {pd.w, pd.z, pd.y, pd.x};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ku = HC + jj + e, kd = HC - 1 - jj - e;
+              acc_re[ku] = fma_(pus[e], ur, acc_re[ku]);
+              acc_im[ku] = fma_(pus[e], ui, acc_im[ku]);
+              acc_re[kd] = fma_(pds[e], dr, acc_re[kd]);
+              acc_im[kd] = fma_(pds[e], di, acc_im[kd]);
+              const T nur = fma_(ur, rr, -(ui * ri));
+              const T nui = fma_(ur, ri, ui * rr);
+              const T ndr = fma_(dr, rr, di * ri);
+              const T ndi = fma_(di, rr, -(dr * ri));
+              ur = nur; ui = nui; dr = ndr; di = ndi;
+            }
+          }
+        } else {
+          // source-shape taper  w = exp(-g f^2),  g = kappa_s * (|b|^2/c^2 - tau^2),  tau = d + b.s_pc/c
+          const double tau = d + bpc;
+          double gq = sv.w * (bl2_c2 - tau * tau);
+          gq = gq > 0.0 ? gq : 0.0;      // |b|^2 >= (b.s)^2 up to rounding
+          if constexpr (sizeof(T) == 4) {
+            // fp32: direct exp2 per term (no error accumulation); f_k^2 * log2(e) staged per tile in p.fsq
+            const float g2 = (float)(gq * p.fsq_scale);
+#pragma unroll
+            for (int jj = 0; jj < HC; jj += 4) {
+              const float4 pu = *reinterpret_cast<const float4*>(prow + HC + jj);
+              const float4 pd = *reinterpret_cast<const float4*>(prow + HC - 4 - jj);
+              const float pus[4] = {pu.x, pu.y, pu.z, pu.w};
+              const float pds[4] = {pd.w, pd.z, pd.y, pd.x};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int ku = HC + jj + e, kd = HC - 1 - jj - e;
+                const float wu = __builtin_amdgcn_exp2f(-g2 * p.fsq[k0 + ku]);
+                const float wd = __builtin_amdgcn_exp2f(-g2 * p.fsq[k0 + kd]);
+                const float au = pus[e] * wu, ad = pds[e] * wd;
+                acc_re[ku] = __builtin_fmaf(au, ur, acc_re[ku]);
+                acc_im[ku] = __builtin_fmaf(au, ui, acc_im[ku]);
+                acc_re[kd] = __builtin_fmaf(ad, dr, acc_re[kd]);
+                acc_im[kd] = __builtin_fmaf(ad, di, acc_im[kd]);
+                const float nur = __builtin_fmaf(ur, rr, -(ui * ri));
+                const float nui = __builtin_fmaf(ur, ri, ui * rr);
+                const float ndr = __builtin_fmaf(dr, rr, di * ri);
+                const float ndi = __builtin_fmaf(di, rr, -(dr * ri));
+                ur = nur; ui = nui; dr = ndr; di = ndi;
+              }
+            }
+          } else {
+            // fp64: second-order multiplicative recurrence of the Gaussian in frequency:
+            //   w_{k+1} = w_k q_k,  q_{k+1} = q_k h,   h = exp(-2 g df^2)
+            //   w_{k-1} = w_k q'_k, q'_{k-1} = q'_k h
+            const double e1 = exp(-2.0 * gq * fc * df);
+            const double e2 = exp(-gq * df * df);
+            const double h = e2 * e2;
+            double wu = exp(-gq * fc * fc);           // channel HC
+            double qu = e1 * e2;                      // w_{HC+1}/w_{HC}
+            double qd = e2 / e1;                      // w_{HC-1}/w_{HC}
+            double wd = wu * qd;                      // channel HC-1
+            qd *= h;                                  // w_{HC-2}/w_{HC-1}
+#pragma unroll
+            for (int jj = 0; jj < HC; jj += 2) {
+              const double2 pu = *reinterpret_cast<const double2*>(prow + HC + jj);
+              const double2 pd = *reinterpret_cast<const double2*>(prow + HC - 2 - jj);
+              const double pus[2] = {pu.x, pu.y};
+              const double pds[2] = {pd.y, pd.x};
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const int ku = HC + jj + e, kd = HC - 1 - jj - e;
+                const double au = pus[e] * wu, ad = pds[e] * wd;
+                acc_re[ku] = fma_(au, ur, acc_re[ku]);
+                acc_im[ku] = fma_(au, ui, acc_im[ku]);
+                acc_re[kd] = fma_(ad, dr, acc_re[kd]);
+                acc_im[kd] = fma_(ad, di, acc_im[kd]);
+                const double nur = fma_(ur, rr, -(ui * ri));
+                const double nui = fma_(ur, ri, ui * rr);
+                const double ndr = fma_(dr, rr, di * ri);
+                const double ndi = fma_(di, rr, -(dr * ri));
+                ur = nur; ui = nui; dr = ndr; di = ndi;
+                wu *= qu; qu *= h; wd *= qd; qd *= h;
+              }
+            }
+          }
+        }
+      }
+    }
+    since_flush += ns;
+    if (sizeof(T) == 4 && since_flush >= p.flush_src && more) flush();
+  }
+  flush();
+}
+
+// ------------------------------------------------------------------------------------------
+// Direct kernel: one (baseline, channel) output per thread, one sincospi per term, fp64 only.
+// Works for any channel grid (no uniform-spacing assumption).  Slow; used as the on-device
+// cross-check and as the fallback for non-uniform channel arrays.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads)
+void k_skyvis_direct(const SkyvisParams p, const double* __restrict__ freqs,
+                     const double* __restrict__ pb /* [nsrc][nchan] */, const double* __restrict__ scale) {
+  // block = 64 baselines x 4 channels
+  __shared__ double4 sd[64];
+  __shared__ double sp[64][4];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int64_t nchan4 = (p.nchan + 3) / 4;
+  const int64_t bgi = blockIdx.x / nchan4;
+  const int64_t kq = blockIdx.x % nchan4;
+  const int64_t b_raw = bgi * 64 + lane;
+  const bool valid_b = b_raw < p.nbl;
+  const int64_t b = valid_b ? b_raw : p.nbl - 1;
+  const int64_t k_raw = kq * 4 + w;
+  const bool valid_k = k_raw < p.nchan;
+  const int64_t k = valid_k ? k_raw : p.nchan - 1;
+  const double bx = p.bl_x[b], by = p.bl_y[b], bz = p.bl_z[b];
+  const double f = freqs[k];
+  const double bl2_c2 = (bx * bx + by * by + bz * bz) * (p.inv_c * p.inv_c);
+  const double bpc = (bx * p.pc_x + by * p.pc_y + bz * p.pc_z) * p.inv_c;
+  const double4* gd = reinterpret_cast<const double4*>(p.dirs);
+  double are = 0.0, aim = 0.0;
+  for (int64_t s0 = 0; s0 < p.nsrc; s0 += 64) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int64_t s = s0 + threadIdx.x;
+      double4 v = make_double4(0, 0, 0, 0);
+      if (s < p.nsrc) v = gd[s];
+      sd[threadIdx.x] = make_double4((v.x - p.pc_x) * p.inv_c, (v.y - p.pc_y) * p.inv_c, (v.z - p.pc_z) * p.inv_c, v.w);
+    }
+    {
+      const int ss = threadIdx.x >> 2, kk = threadIdx.x & 3;
+      const int64_t s = s0 + ss;
+      const int64_t kc = kq * 4 + kk;
+      double v = 0.0;
+      if (s < p.nsrc && kc < p.nchan) {
+        v = pb[(size_t)s * p.nchan + kc];
+        if (scale) v *= scale[(size_t)s * 4 + p.scale_comp];
+      }
+      sp[ss][kk] = v;
+    }
+    __syncthreads();
+    const int ns = (int)((p.nsrc - s0) < 64 ? (p.nsrc - s0) : 64);
+    for (int s = 0; s < ns; ++s) {
+      const double4 sv = sd[s];
+      const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));
+      double ph = d * f;
+      ph -= __builtin_rint(ph);
+      double sn, cs;
+      sincospi(2.0 * ph, &sn, &cs);
+      double a = sp[s][w];
+      if (p.taper) {
+        const double tau = d + bpc;
+        double gq = sv.w * (bl2_c2 - tau * tau);
+        gq = gq > 0.0 ? gq : 0.0;
+        a *= exp(-gq * f * f);
+      }
+      are = __builtin_fma(a, cs, are);
+      aim = __builtin_fma(a, -sn, aim);
+    }
+  }
+  if (valid_b && valid_k) {
+    double2* o = reinterpret_cast<double2*>(p.out);
+    o[(size_t)b * p.nchan + k] = make_double2(are, aim);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pack: pb[nsrc][nchan] (double) -> packed[ntiles][nsrc][CT] (T), optional per-source scale
+// (gradient passes multiply the rows by a direction-cosine component, interferometry.py:6338).
+// Channels beyond nchan in the last tile are zero-filled.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_pack(const double* __restrict__ pb, T* __restrict__ packed, int64_t nsrc, int64_t nsrc_pad,
+                       int64_t nchan, int ct, int ntiles, const double* __restrict__ dirs, int scale_comp) {
+  const int64_t total = (int64_t)ntiles * nsrc_pad * ct;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ct);
+    const int64_t s = (i / ct) % nsrc_pad;
+    const int tile = (int)(i / ((int64_t)ct * nsrc_pad));
+    const int64_t k = (int64_t)tile * ct + c;
+    double v = 0.0;
+    if (k < nchan && s < nsrc) {
+      v = pb[(size_t)s * nchan + k];
+      if (scale_comp >= 0) v *= dirs[(size_t)s * 4 + scale_comp];
+    }
+    packed[i] = (T)v;
+  }
+}
+
+// dirs_prep[s] = ((l,m,n) - s_pc)/c, kappa   for s < nsrc;  zeros for nsrc <= s < nsrc_pad
+__global__ void k_prep_dirs(const double* __restrict__ dirs, double* __restrict__ prep, int64_t nsrc, int64_t nsrc_pad,
+                            double pcx, double pcy, double pcz, double inv_c) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nsrc_pad; s += (int64_t)gridDim.x * blockDim.x) {
+    double4 v = make_double4(0, 0, 0, 0);
+    if (s < nsrc) {
+      const double4 r = reinterpret_cast<const double4*>(dirs)[s];
+      v = make_double4((r.x - pcx) * inv_c, (r.y - pcy) * inv_c, (r.z - pcz) * inv_c, r.w);
+    }
+    reinterpret_cast<double4*>(prep)[s] = v;
+  }
+}
+
+// sum nsplit partial cubes [nsplit][n] (complex as 2 doubles) -> out[n]; deterministic order.
+__global__ void k_reduce_partials(const double* __restrict__ part, double* __restrict__ out, int64_t n2, int nsplit) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    double a = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) a += part[(size_t)sp * n2 + i];
+    out[i] = a;
+  }
+}
+
+__global__ void k_f32_to_f64(const float* __restrict__ in, double* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (double)in[i];
+}
+
+__global__ void k_fsq(const double* __restrict__ freqs, float* __restrict__ fsq, int64_t nchan, int64_t npad,
+                      double scale) {
+  // fsq[k] = (f_k * scale)^2 * log2(e) in fp32; scale keeps g*fsq in fp32 range
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += (int64_t)gridDim.x * blockDim.x) {
+    double f = freqs[i < nchan ? i : nchan - 1] * scale;
+    fsq[i] = (float)(f * f * 1.4426950408889634);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+template <typename T, int CT>
+static hipError_t launch_rec_ct(const SkyvisParams& p, hipStream_t stream) {
+  const int nslabs = p.ntiles * p.nsplit;
+  const int slabs_per_xcd = (nslabs + 7) / 8;
+  const unsigned grid = 8u * (unsigned)slabs_per_xcd * (unsigned)p.nbgroups;
+  const size_t lds = (size_t)p.src_chunk * CT * sizeof(T) + (size_t)p.src_chunk * sizeof(double4);
+  if (p.taper)
+    hipLaunchKernelGGL((k_skyvis_rec<T, CT, true>), dim3(grid), dim3(kBlockThreads), lds, stream, p);
+  else
+    hipLaunchKernelGGL((k_skyvis_rec<T, CT, false>), dim3(grid), dim3(kBlockThreads), lds, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream) {
+  if (f32) {
+    switch (ct) {
+      case 8: return launch_rec_ct<float, 8>(p, stream);
+      case 16: return launch_rec_ct<float, 16>(p, stream);
+      case 32: return launch_rec_ct<float, 32>(p, stream);
+      case 64: return launch_rec_ct<float, 64>(p, stream);
+    }
+  } else {
+    switch (ct) {
+      case 8: return launch_rec_ct<double, 8>(p, stream);
+      case 16: return launch_rec_ct<double, 16>(p, stream);
+      case 32: return launch_rec_ct<double, 32>(p, stream);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_skyvis_direct(const SkyvisParams& p, const double* freqs, const double* pb, const double* scale,
+                                hipStream_t stream) {
+  const int64_t nchan4 = (p.nchan + 3) / 4;
+  const int64_t nbg = (p.nbl + 63) / 64;
+  const int64_t grid = nbg * nchan4;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_skyvis_direct, dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, p, freqs, pb, scale);
+  return hipGetLastError();
+}
+
+static unsigned grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct,
+                       int ntiles, const double* dirs, int scale_comp, hipStream_t stream) {
+  const int64_t total = (int64_t)ntiles * nsrc_pad * ct;
+  if (total == 0) return hipSuccess;
+  if (f32)
+    hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(total)), dim3(256), 0, stream, pb, (float*)packed, nsrc, nsrc_pad,
+                       nchan, ct, ntiles, dirs, scale_comp);
+  else
+    hipLaunchKernelGGL(k_pack<double>, dim3(grid_for(total)), dim3(256), 0, stream, pb, (double*)packed, nsrc, nsrc_pad,
+                       nchan, ct, ntiles, dirs, scale_comp);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(const double* part, double* out, int64_t n2, int nsplit, hipStream_t stream) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(grid_for(n2)), dim3(256), 0, stream, part, out, n2, nsplit);
+  return hipGetLastError();
+}
+
+hipError_t launch_f32_to_f64(const float* in, double* out, int64_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_f32_to_f64, dim3(grid_for(n)), dim3(256), 0, stream, in, out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_prep_dirs(const double* dirs, double* prep, int64_t nsrc, int64_t nsrc_pad, double pcx, double pcy,
+                            double pcz, double inv_c, hipStream_t stream) {
+  if (nsrc_pad == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_prep_dirs, dim3(grid_for(nsrc_pad)), dim3(256), 0, stream, dirs, prep, nsrc, nsrc_pad, pcx, pcy,
+                     pcz, inv_c);
+  return hipGetLastError();
+}
+
+hipError_t launch_fsq(const double* freqs, float* fsq, int64_t nchan, int64_t npad, double scale, hipStream_t stream) {
+  hipLaunchKernelGGL(k_fsq, dim3(grid_for(npad)), dim3(256), 0, stream, freqs, fsq, nchan, npad, scale);
+  return hipGetLastError();
+}
+
+}  // namespace prisim
