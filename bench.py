@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native PRISim sky-sum.
+
+Metric (BASELINE.json): visibility-terms/s = nbl * nchan * nsrc * nt / wall, on the synthetic
+HERA-350 x 1024-channel x 1e4-source workload (SURVEY.md 8(d) config 3, fp32 with tolerance check).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one snapshot: one pass of the hot path (prep + pack + sky-sum kernel) over the whole
+sky with all inputs already resident in HBM.  With N > 1 the baselines are sharded in contiguous
+blocks (one process per GPU, the reference's pp.key='bl' model, scripts/run_prisim.py:1775-1791),
+each rank writes snapshot t into slot t of its shard of the visibility cube, and the single
+RCCL all-gather of the cube at the end of the run is INSIDE the timed region.  The total workload is
+fixed as N grows ("scaling": "strong").  torch is used only for the multi-process rendezvous
+(gloo barrier / max-reduce / unique-id broadcast); all GPU work goes through libprisim_hip.so.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as NP
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from prisim_amd import _abi, workloads as W   # noqa: E402
+
+FLOPS_PER_TERM = 10.0       # rotate (4 mul + 2 add) + accumulate (2 mul + 2 add) = 6 VALU slots
+PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # MI355X_MICROARCH.md chip table: vector FP32 157.3 TF; FP64 = half
+HBM_PEAK_GBS = 8000.0
+
+
+def shard_range(nbl, world, rank):
+    """Contiguous equal-size baseline blocks, ceil(nbl/world) each (last ones padded by repeating
+    the final baseline so that every rank -- and the all-gather -- has the same shard size)."""
+    per = (nbl + world - 1) // world
+    lo = min(rank * per, nbl)
+    hi = min(lo + per, nbl)
+    return per, lo, hi
+
+
+def shard_baselines(bl, world, rank):
+    per, lo, hi = shard_range(bl.shape[0], world, rank)
+    mine = bl[lo:hi]
+    if mine.shape[0] < per:
+        pad = NP.repeat(bl[-1:], per - mine.shape[0], axis=0)
+        mine = NP.vstack((mine, pad))
+    return mine, hi - lo
+
+
+def cpu_baseline(cfg, pbflux_sample_fn, target_terms=1.0e10):
+    """Time the C oracle (oracle/skyvis_oracle.c, the checker) on a bounded baseline sample of the same
+    workload, on this box's host cores.  Reported baseline only -- never the thing measured above."""
+    from oracle import c_oracle as CO
+    threads = max(1, min(16, os.cpu_count() or 1, CO.max_threads()))
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    nsrc, nchan = sky['dircos'].shape[0], ch.size
+    nbl_s = int(max(threads, min(bl.shape[0], target_terms // (nsrc * nchan))))
+    stride = max(1, bl.shape[0] // nbl_s)
+    bls = NP.ascontiguousarray(bl[::stride][:nbl_s])
+    pb = pbflux_sample_fn()
+    zen = NP.array([0.0, 0.0, 1.0])
+    fw = sky['fwhm_deg'] if cfg['taper'] else None
+    CO.skyvis(bls[:threads], ch, sky['dircos'], pb, zen, fwhm_deg=fw, nthreads=threads)     # warm-up
+    t0 = time.perf_counter()
+    ref = CO.skyvis(bls, ch, sky['dircos'], pb, zen, fwhm_deg=fw, nthreads=threads)
+    dt = time.perf_counter() - t0
+    terms = float(bls.shape[0]) * nchan * nsrc
+    return {'value': terms / dt, 'unit': 'terms/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d of %d baselines (every %d-th) x %d ch x %d src = %.3g terms in %.1f s, C/OpenMP libm-sincos port of '
+                      'interferometry.py:6332-6340' % (bls.shape[0], bl.shape[0], stride, nchan, nsrc, terms, dt)}, bls, ref, stride
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--precision', choices=('fp32', 'fp64'), default='fp32')
+    ap.add_argument('--nsrc', type=int, default=10000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    cfg = W.config3(nsrc=args.nsrc)
+    bl_all, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    nbl_total, nchan, nsrc = bl_all.shape[0], ch.size, sky['dircos'].shape[0]
+    bl_mine, n_real = shard_baselines(bl_all, world, rank)
+    prec = _abi.PRISIM_FP32 if args.precision == 'fp32' else _abi.PRISIM_FP64
+    dtype = 'f32' if args.precision == 'fp32' else 'f64'
+    K, Wm = max(1, args.steps), max(0, args.warmup)
+    zen = NP.array([0.0, 0.0, 1.0])
+
+    ctx = _abi.Context(local_rank)
+    ctx.set_array(bl_mine, ch, nt_max=K)
+    # inputs resident in HBM before the timed region: directions, reference fluxes, spectral indices;
+    # beam x flux (nsrc x nchan) is built on the device (fused Airy beam x power law)
+    ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY,
+                         cfg['diameter'], zen, zen, fwhm_deg=(sky['fwhm_deg'] if cfg['taper'] else None))
+    if world > 1:
+        uid = [_abi.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], world, rank)
+
+    for i in range(Wm):
+        ctx.compute(precision=prec, slot=i % K)
+    if world > 1 and Wm > 0:
+        ctx.allgather(K, complex64=(prec == _abi.PRISIM_FP32))
+    ctx.sync()
+    ctx.timing(reset=True)
+
+    barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for t in range(K):
+        ctx.compute(precision=prec, slot=t)
+    if world > 1:
+        ctx.allgather(K, complex64=(prec == _abi.PRISIM_FP32))
+    ctx.sync()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    tm = ctx.timing()
+    gather_ok = None
+    if world > 1:
+        # every rank must hold the same gathered cube: compare device checksums
+        cs = ctx.gathered_checksum(K, complex64=(prec == _abi.PRISIM_FP32))
+        import torch
+        allcs = [None] * world
+        dist.all_gather_object(allcs, cs)
+        gather_ok = bool(all(abs(c - allcs[0]) <= 1e-9 * max(1.0, abs(allcs[0])) for c in allcs))
+
+    if rank == 0:
+        terms_total = float(nbl_total) * nchan * nsrc * K
+        value = terms_total / elapsed
+        kern_ms = tm['sum_kernel_ms'] / max(1, tm['n_kernel'])
+        # terms one launch of the dominant kernel processes on this rank (padded shard)
+        terms_launch = float(bl_mine.shape[0]) * nchan * nsrc
+        ach_tflops = terms_launch * FLOPS_PER_TERM / (kern_ms * 1e-3) / 1e12
+        wp = 4 if prec == _abi.PRISIM_FP32 else 8
+        alg_bytes = nsrc * nchan * wp + 24 * nsrc + 24 * bl_mine.shape[0] + 8 * nchan + 2 * 8 * bl_mine.shape[0] * nchan
+        ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'visibility-terms/sec', 'value': value, 'unit': 'terms/s', 'n_gpus': world, 'steps': K, 'warmup': Wm,
+            'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': dtype, 'data': 'synthetic',
+            'config': {'workload': cfg['name'], 'nbl': nbl_total, 'nchan': nchan, 'nsrc': nsrc, 'nt': K,
+                       'beam': 'airy D=14 m fused on device', 'sharding': 'baselines/%d + 1 RCCL all-gather' % world,
+                       'kernel': 'recurrence ct=%d nsplit=%d' % (tm['last_chan_tile'], tm['last_nsplit'])},
+            'roofline': {'bound': 'valu', 'achieved': ach_tflops, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
+                         'frac': ach_tflops / PEAK_TFLOPS[dtype], 'traffic': None,
+                         'kernel': 'k_skyvis_rec', 'avg_kernel_ms': kern_ms, 'flops_per_term': FLOPS_PER_TERM,
+                         'terms_per_launch': terms_launch},
+            'roofline_hbm': {'bound': 'hbm', 'achieved': ach_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': ach_gbs / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes_per_launch': alg_bytes},
+        }
+        if gather_ok is not None:
+            out['gather_ok'] = gather_ok
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                def pb_sample():
+                    return ctx.get_pbflux()
+                cb, bls, ref, stride = cpu_baseline(cfg, pb_sample)
+                out['cpu_baseline'] = cb
+                # parity spot-check of the timed GPU result against the checker on the same sample
+                vis = ctx.get_vis(slot=K - 1)
+                gpu = vis[::stride][:bls.shape[0]]
+                scale = NP.sum(NP.abs(pb_sample()), axis=0)[None, :]
+                out['parity_max_err_rel_sumflux'] = float(NP.max(NP.abs(gpu - ref) / scale))
+            except Exception as exc:   # the baseline is a report, never a reason to lose the bench line
+                out['cpu_baseline'] = {'value': None, 'unit': 'terms/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -144,13 +144,17 @@ int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts,
 /* 128-byte RCCL unique id; rank 0 creates it, the launcher distributes it out of band. */
 int prisim_hip_comm_unique_id(char id[128]);
 int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int rank);
-/* All-gather the local cube (equal-sized baseline shards, [nt][nbl_shard][nchan] complex128) into
- * a device cube [nranks][nt][nbl_shard][nchan] held by the context.  Replaces the reference's
- * per-rank _part_i.hdf5 files + rank-0 concatenate (scripts/run_prisim.py:2207, 2233-2242). */
-int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt);
-/* Copy the gathered cube to the host: out complex128 [nranks][nt][nbl_shard][nchan]. */
-int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, double* out);
-/* 64-bit checksum (sum of all re,im as double) of the gathered cube, computed on the device. */
+/* All-gather the local cube (equal-sized baseline shards, [nt][nbl_shard][nchan]) into a device cube
+ * [nranks][nt][nbl_shard][nchan] held by the context.  as_c64 = 0: complex128 on the wire; 1: the
+ * shard is first rounded to complex64 on the device (the reference's memsave dtype, :6183) and
+ * half the bytes cross xGMI.  Replaces the reference's per-rank _part_i.hdf5 files + rank-0
+ * concatenate (scripts/run_prisim.py:2207, 2233-2242).  Asynchronous on the context stream. */
+int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt, int as_c64);
+/* Copy the gathered cube to the host: out [nranks][nt][nbl_shard][nchan], complex128 or complex64
+ * according to the as_c64 of the last allgather. */
+int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out);
+/* Checksum (sum of all re,im accumulated in double, fixed reduction order) of the gathered cube,
+ * computed on the device. */
 int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out);
 
 /* ---- timing / introspection -------------------------------------------------------------- */

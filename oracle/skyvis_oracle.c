@@ -1,0 +1,74 @@
+#define _GNU_SOURCE
+/*
+ * skyvis_oracle.c -- plain C restatement of the PRISim sky-sum (TEST INFRASTRUCTURE / CPU baseline).
+ *
+ * Follows prisim/interferometry.py:6332-6343 (fp64 path) without materialising the
+ * nsrc x nbl x nchan matrix: one libm sincos per (source, baseline, channel) term, summed
+ * sequentially over sources per output exactly like NP.sum(axis=0) (:6340).  Geometric delay per
+ * prisim/baseline_delay_horizon.py:240, phase-centre offset :6165, taper :6265-6283.
+ * OpenMP over baselines = the reference's own parallel model (mpirun ranks over baseline chunks,
+ * scripts/run_prisim.py:1775-1791), one thread standing in for one rank.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
+ * Build: make -C oracle   (gcc -O3 -march=native -fopenmp)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define C_LIGHT 299792458.0
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* vis: [nbl][nchan] interleaved (re, im); fwhm_deg may be NULL; nthreads <= 0: OpenMP default */
+int oracle_skyvis_f64(const double* bl, int64_t nbl, const double* freqs, int64_t nchan, const double* dircos,
+                      const double* pbflux, int64_t nsrc, const double* pc, const double* fwhm_deg, double* vis,
+                      int nthreads) {
+  if (!bl || !freqs || !pc || !vis || nbl <= 0 || nchan <= 0 || nsrc < 0) return -1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+  const double twopi = 2.0 * M_PI;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t b = 0; b < nbl; ++b) {
+    const double bx = bl[3 * b], by = bl[3 * b + 1], bz = bl[3 * b + 2];
+    const double taupc = (bx * pc[0] + by * pc[1] + bz * pc[2]) / C_LIGHT;     /* :6165 */
+    const double blen2 = bx * bx + by * by + bz * bz;                            /* :5684 */
+    double* out = vis + 2 * b * nchan;
+    for (int64_t k = 0; k < 2 * nchan; ++k) out[k] = 0.0;
+    for (int64_t s = 0; s < nsrc; ++s) {
+      const double tau = (bx * dircos[3 * s] + by * dircos[3 * s + 1] + bz * dircos[3 * s + 2]) / C_LIGHT; /* bdh:240 */
+      const double dtau = tau - taupc;
+      double g = 0.0;
+      int taper = 0;
+      if (fwhm_deg && fwhm_deg[s] > 0.0) {
+        const double fdc = 2.0 * sin(0.5 * fwhm_deg[s] * M_PI / 180.0);            /* :6268 */
+        double perp2 = blen2 - (C_LIGHT * tau) * (C_LIGHT * tau);                   /* :6265 */
+        if (perp2 < 0.0) perp2 = 0.0;
+        g = M_LN2 * fdc * fdc * perp2 / (C_LIGHT * C_LIGHT);                        /* :6270, 6283 */
+        taper = 1;
+      }
+      const double* p = pbflux + s * nchan;
+      for (int64_t k = 0; k < nchan; ++k) {
+        const double f = freqs[k];
+        const double ph = twopi * dtau * f;                                         /* :6332 */
+        double sn, cs;
+        sincos(ph, &sn, &cs);
+        double a = p[k];
+        if (taper) a *= exp(-g * f * f);
+        out[2 * k] += a * cs;                                                       /* :6340 exp(-1j*phase) */
+        out[2 * k + 1] -= a * sn;
+      }
+    }
+  }
+  return 0;
+}

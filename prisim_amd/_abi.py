@@ -82,7 +82,7 @@ def load_library():
     lib.prisim_hip_delay_transform.argtypes = [vp, i64, vp, dbl, vp, vp, vp, dbl]
     lib.prisim_hip_comm_unique_id.argtypes = [C.c_char_p]
     lib.prisim_hip_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
-    lib.prisim_hip_allgather.argtypes = [vp, i64]
+    lib.prisim_hip_allgather.argtypes = [vp, i64, i32]
     lib.prisim_hip_get_gathered.argtypes = [vp, i64, vp]
     lib.prisim_hip_gathered_checksum.argtypes = [vp, i64, C.POINTER(dbl)]
     lib.prisim_hip_sync.argtypes = [vp]
@@ -263,15 +263,17 @@ class Context(object):
         self._check(self._lib.prisim_hip_comm_init(self._h, uid, int(nranks), int(rank)), 'prisim_hip_comm_init')
         self.nranks = int(nranks)
 
-    def allgather(self, nt):
-        self._check(self._lib.prisim_hip_allgather(self._h, int(nt)), 'prisim_hip_allgather')
+    def allgather(self, nt, complex64=False):
+        self._check(self._lib.prisim_hip_allgather(self._h, int(nt), 1 if complex64 else 0), 'prisim_hip_allgather')
+        self._gathered_c64 = bool(complex64)
 
-    def get_gathered(self, nt, nranks):
-        out = NP.empty((nranks, nt, self.nbl, self.nchan), dtype=NP.complex128)
+    def get_gathered(self, nt, nranks=None):
+        nranks = getattr(self, 'nranks', 1) if nranks is None else nranks
+        out = NP.empty((nranks, nt, self.nbl, self.nchan), dtype=NP.complex64 if getattr(self, '_gathered_c64', False) else NP.complex128)
         self._check(self._lib.prisim_hip_get_gathered(self._h, int(nt), _ptr(out)), 'prisim_hip_get_gathered')
         return out
 
-    def gathered_checksum(self, nt):
+    def gathered_checksum(self, nt, complex64=None):
         v = C.c_double()
         self._check(self._lib.prisim_hip_gathered_checksum(self._h, int(nt), C.byref(v)), 'prisim_hip_gathered_checksum')
         return v.value

@@ -140,11 +140,12 @@ hipError_t launch_dt_finish(const double* work, double* out, double* out_power, 
 }
 
 // ---- deterministic checksum: fixed 1024-block partial sums, then one block ------------------
+template <typename T>
 __global__ __launch_bounds__(256)
-void k_checksum_partial(const double* __restrict__ data, int64_t n, double* __restrict__ partial) {
+void k_checksum_partial(const T* __restrict__ data, int64_t n, double* __restrict__ partial) {
   __shared__ double red[256];
   double a = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a += data[i];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a += (double)data[i];
   red[threadIdx.x] = a;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -168,9 +169,23 @@ void k_checksum_final(const double* __restrict__ partial, int np, double* __rest
   if (threadIdx.x == 0) out[0] = red[0];
 }
 
-hipError_t launch_checksum(const double* data, int64_t n, double* out /* [1025] device scratch: out[0]=result */,
+__global__ void k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (float)in[i];
+}
+
+hipError_t launch_f64_to_f32(const double* in, float* out, int64_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_f64_to_f32, dim3(grid_for(n)), dim3(256), 0, stream, in, out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_checksum(const void* data, bool is_f32, int64_t n, double* out /* [1025] device scratch: out[0]=result */,
                            hipStream_t stream) {
-  hipLaunchKernelGGL(k_checksum_partial, dim3(1024), dim3(256), 0, stream, data, n, out + 1);
+  if (is_f32)
+    hipLaunchKernelGGL(k_checksum_partial<float>, dim3(1024), dim3(256), 0, stream, (const float*)data, n, out + 1);
+  else
+    hipLaunchKernelGGL(k_checksum_partial<double>, dim3(1024), dim3(256), 0, stream, (const double*)data, n, out + 1);
   hipLaunchKernelGGL(k_checksum_final, dim3(1), dim3(256), 0, stream, out + 1, 1024, out);
   return hipGetLastError();
 }

@@ -134,7 +134,8 @@ struct prisim_ctx {
   // comm
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
-  DevBuf gathered;
+  DevBuf gathered, sendbuf;
+  bool gathered_c64 = false;
 
   // fft
   rocfft_plan fft_plan = nullptr;
@@ -298,7 +299,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->fft_plan && g_rocfft.plan_destroy) g_rocfft.plan_destroy(ctx->fft_plan);
   if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->cube, &ctx->grad, &ctx->dirs,
-                    &ctx->dirs_prep, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered,
+                    &ctx->dirs_prep, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf,
                     &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts})
     release(*b);
   for (hipEvent_t ev : {ctx->ev_c0, ctx->ev_c1, ctx->ev_k0, ctx->ev_k1})
@@ -752,31 +753,40 @@ int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int ra
   return PRISIM_OK;
 }
 
-int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt) {
+int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt, int as_c64) {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
   if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  const size_t shard = (size_t)nt * ctx->nbl * ctx->nchan * 2;   // doubles
+  const size_t shard = (size_t)nt * ctx->nbl * ctx->nchan * 2;   // reals
+  const size_t esz = as_c64 ? sizeof(float) : sizeof(double);
   int rc;
-  if ((rc = ensure(ctx, ctx->gathered, shard * (size_t)ctx->nranks * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->gathered, shard * (size_t)ctx->nranks * esz))) return rc;
+  const void* send = ctx->cube.p;
+  if (as_c64) {
+    if ((rc = ensure(ctx, ctx->sendbuf, shard * sizeof(float)))) return rc;
+    HIPCHK(ctx, launch_f64_to_f32((const double*)ctx->cube.p, (float*)ctx->sendbuf.p, (int64_t)shard, ctx->stream));
+    send = ctx->sendbuf.p;
+  }
+  ctx->gathered_c64 = as_c64 != 0;
   if (ctx->nranks == 1 && !ctx->comm) {
-    HIPCHK(ctx, hipMemcpyAsync(ctx->gathered.p, ctx->cube.p, shard * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->gathered.p, send, shard * esz, hipMemcpyDeviceToDevice, ctx->stream));
     return PRISIM_OK;
   }
   if (!ctx->comm) return fail(ctx, PRISIM_ESTATE, "comm_init has not been called");
-  ncclResult_t r = g_rccl.AllGather(ctx->cube.p, ctx->gathered.p, shard, ncclDouble, ctx->comm, ctx->stream);
+  ncclResult_t r = g_rccl.AllGather(send, ctx->gathered.p, shard, as_c64 ? ncclFloat : ncclDouble, ctx->comm, ctx->stream);
   if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
   return PRISIM_OK;
 }
 
-int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, double* out) {
+int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out) {
   if (!ctx) return PRISIM_EINVAL;
   if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
   if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  const size_t bytes = (size_t)nt * ctx->nbl * ctx->nchan * 2 * (size_t)ctx->nranks * sizeof(double);
-  if (bytes > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt larger than the gathered cube");
+  const size_t esz = ctx->gathered_c64 ? sizeof(float) : sizeof(double);
+  const size_t bytes = (size_t)nt * ctx->nbl * ctx->nchan * 2 * (size_t)ctx->nranks * esz;
+  if (nt <= 0 || bytes > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt does not match the gathered cube");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipMemcpy(out, ctx->gathered.p, bytes, hipMemcpyDeviceToHost));
   return PRISIM_OK;
@@ -787,11 +797,12 @@ int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out) {
   if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
   if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t esz = ctx->gathered_c64 ? sizeof(float) : sizeof(double);
   const int64_t n = nt * ctx->nbl * ctx->nchan * 2 * (int64_t)ctx->nranks;
-  if ((size_t)n * sizeof(double) > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt larger than the gathered cube");
+  if (nt <= 0 || (size_t)n * esz > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt does not match the gathered cube");
   int rc;
   if ((rc = ensure(ctx, ctx->scratch, 1025 * sizeof(double)))) return rc;
-  HIPCHK(ctx, launch_checksum((const double*)ctx->gathered.p, n, (double*)ctx->scratch.p, ctx->stream));
+  HIPCHK(ctx, launch_checksum(ctx->gathered.p, ctx->gathered_c64, n, (double*)ctx->scratch.p, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(out, ctx->scratch.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return PRISIM_OK;

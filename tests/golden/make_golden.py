@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by EXECUTING THE REFERENCE'S OWN STATEMENTS.
+
+Runs only in the build container, where /root/reference is mounted read-only; the GPU box never
+sees the reference, only the small .npz fixtures this script writes (inputs + expected outputs).
+
+The reference package cannot be imported (Python-2 syntax elsewhere in the files, un-vendored
+astroutils/astropy -- SURVEY.md 8(c)), but the statements of the hot path are plain numpy and
+run unchanged under Python 3.  This script reads the cited line ranges from the reference
+source AT GENERATION TIME, dedents them and exec()s them on seeded inputs.  No reference
+source text is stored in this repository.
+
+  golden_skyvis.npz    interferometry.py:6332,6340 (fp64), 6335 (+taper), 6338/6343 (gradient),
+                       6323,6326,6327,6330 (fp32 "memsave"), taper 6259-6262,6265-6270,6281-6283,
+                       baseline_delay_horizon.py:133-241 (function geometric_delay, dircos path)
+  golden_beams.npz     primary_beams.py:517-625 (airy_disk_pattern), 629-730 (gaussian_beam),
+                       9-441 (primary_beam_generator dispatch, shapes 'gaussian' / 'dish' / 'delta')
+"""
+import os
+import sys
+import textwrap
+import types
+
+import numpy as NP
+import scipy.constants as FCNST
+import scipy.special as SPS
+
+REF = '/root/reference/prisim'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _pick(fname, ranges):
+    with open(os.path.join(REF, fname)) as f:
+        lines = f.readlines()
+    picked = []
+    for lo, hi in ranges:
+        picked += lines[lo - 1:hi]
+    return picked
+
+
+def ref_block(fname, ranges):
+    """Source text of a contiguous block (a whole function definition), dedented as a unit."""
+    return textwrap.dedent(''.join(_pick(fname, ranges)))
+
+
+def ref_stmts(fname, ranges):
+    """Source text of single-line statements picked from different nesting levels: each line is
+    stripped of its own indentation (every picked line is one complete statement)."""
+    return ''.join(line.lstrip() for line in _pick(fname, ranges))
+
+
+def altaz2dircos(altaz):
+    alt = NP.radians(altaz[:, 0])
+    az = NP.radians(altaz[:, 1])
+    return NP.stack((NP.cos(alt) * NP.sin(az), NP.cos(alt) * NP.cos(az), NP.sin(alt)), axis=1)
+
+
+def make_skyvis():
+    rng = NP.random.default_rng(20261003)
+    nsrc, nbl, nchan = 37, 9, 24
+    baselines = rng.uniform(-150.0, 150.0, size=(nbl, 3))
+    baselines[:, 2] *= 0.02
+    channels = 150e6 + (NP.arange(nchan) - nchan // 2) * 390625.0
+    alt = NP.degrees(NP.arcsin(rng.uniform(0.1, 1.0, nsrc)))
+    az = rng.uniform(0.0, 360.0, nsrc)
+    skypos_dircos_roi = altaz2dircos(NP.stack((alt, az), axis=1))
+    pbfluxes = rng.uniform(0.1, 10.0, size=(nsrc, 1)) * (channels / 150e6).reshape(1, -1) ** -0.83 \
+        * rng.uniform(0.3, 1.0, size=(nsrc, nchan))
+    pc_dircos = altaz2dircos(NP.array([[78.0, 40.0]]))
+    src_shape = NP.stack((rng.uniform(0.05, 1.0, nsrc), rng.uniform(0.05, 1.0, nsrc), NP.zeros(nsrc)), axis=1)
+    src_shape[::6, :2] = 0.0        # zero-size sources: sigma = inf, w = 1 (divide-by-zero warning in the reference)
+
+    # geometric_delay(): the reference function itself (dircos path uses only NP and FCNST)
+    ns = {'NP': NP, 'FCNST': FCNST, 'GEOM': None}
+    exec(ref_block('baseline_delay_horizon.py', [(133, 241)]), ns)
+    geometric_delays = ns['geometric_delay'](baselines, skypos_dircos_roi, altaz=False, hadec=False, dircos=True)
+    pc_delay_offsets = ns['geometric_delay'](baselines, pc_dircos, altaz=False, hadec=False, dircos=True)
+
+    self_ = types.SimpleNamespace(geometric_delays=[geometric_delays], channels=channels,
+                                  baseline_lengths=NP.sqrt(NP.sum(baselines ** 2, axis=1)),   # :5684
+                                  baselines=baselines)
+    skymodel = types.SimpleNamespace(src_shape=src_shape)
+    m2 = NP.arange(nsrc)
+    env = {'NP': NP, 'FCNST': FCNST, 'self': self_, 'skymodel': skymodel, 'm2': m2,
+           'geometric_delays': geometric_delays, 'pc_delay_offsets': pc_delay_offsets, 'pbfluxes': pbfluxes,
+           'skypos_dircos_roi': skypos_dircos_roi}
+
+    out = {}
+    # ---- fp64, no taper: :6332 then :6340, gradient :6343
+    e = dict(env)
+    exec(ref_stmts('interferometry.py', [(6332, 6332), (6340, 6340), (6343, 6343)]), e)
+    out['skyvis_f64'] = e['skyvis']
+    out['grad_f64'] = e['skyvis_gradient']
+    # ---- taper weights :6259-6262, 6265, 6267-6268, 6270, 6281, 6283
+    with NP.errstate(divide='ignore', invalid='ignore'):
+        e = dict(env)
+        exec(ref_stmts('interferometry.py', [(6259, 6262), (6265, 6265), (6267, 6268), (6270, 6270), (6281, 6281), (6283, 6283)]), e)
+    vis_wts = e['vis_wts']
+    out['vis_wts'] = vis_wts
+    # ---- fp64 with taper :6332, 6335, 6338
+    e = dict(env, vis_wts=vis_wts)
+    exec(ref_stmts('interferometry.py', [(6332, 6332), (6335, 6335), (6338, 6338)]), e)
+    out['skyvis_f64_taper'] = e['skyvis']
+    out['grad_f64_taper'] = e['skyvis_gradient']
+    # ---- fp32 ("memsave") :6286 cast, :6287 delays cast, :6323, 6327, 6330 ; with taper also :6289, 6326
+    e = dict(env)
+    e['pbfluxes'] = pbfluxes.astype(NP.float32)                                   # :6286
+    e['self'] = types.SimpleNamespace(geometric_delays=[geometric_delays.astype(NP.float32)], channels=channels)  # :6287
+    e['pc_delay_offsets'] = pc_delay_offsets.astype(NP.float32)                   # :6167
+    exec(ref_stmts('interferometry.py', [(6323, 6323), (6327, 6327), (6330, 6330)]), e)
+    out['skyvis_f32'] = e['skyvis']
+    out['grad_f32'] = e['skyvis_gradient']
+    e = dict(env)
+    e['pbfluxes'] = pbfluxes.astype(NP.float32)
+    e['self'] = types.SimpleNamespace(geometric_delays=[geometric_delays.astype(NP.float32)], channels=channels)
+    e['pc_delay_offsets'] = pc_delay_offsets.astype(NP.float32)
+    e['vis_wts'] = vis_wts.astype(NP.float32)                                     # :6289
+    exec(ref_stmts('interferometry.py', [(6323, 6323), (6326, 6327)]), e)
+    out['skyvis_f32_taper'] = e['skyvis']
+
+    NP.savez_compressed(os.path.join(HERE, 'golden_skyvis.npz'),
+                        baselines=baselines, channels=channels, dircos=skypos_dircos_roi, pbfluxes=pbfluxes,
+                        pc_dircos=pc_dircos.ravel(), src_shape=src_shape, geometric_delays=geometric_delays,
+                        pc_delay_offsets=pc_delay_offsets, **out)
+    print('golden_skyvis.npz:', {k: v.shape for k, v in out.items()})
+
+
+def make_beams():
+    rng = NP.random.default_rng(77)
+    nsrc, nchan = 41, 12
+    alt = NP.concatenate(([90.0, 89.999999, 0.0, -5.0], NP.degrees(NP.arcsin(rng.uniform(0.0, 1.0, nsrc - 4)))))
+    az = rng.uniform(0.0, 360.0, nsrc)
+    skypos = NP.stack((alt, az), axis=1)
+    freq_hz = 150e6 + (NP.arange(nchan) - nchan // 2) * 4e6
+    ns = {'NP': NP, 'FCNST': FCNST, 'SPS': SPS, 'GEOM': None}
+    exec(ref_block('primary_beams.py', [(517, 625)]), ns)      # airy_disk_pattern
+    exec(ref_block('primary_beams.py', [(629, 730)]), ns)      # gaussian_beam
+    exec(ref_block('primary_beams.py', [(9, 441)]), ns)        # primary_beam_generator (dispatch)
+    out = {}
+    with NP.errstate(divide='ignore', invalid='ignore'):
+        out['airy_power_d14'] = ns['airy_disk_pattern'](14.0, skypos, freq_hz, skyunits='altaz', peak=1.0,
+                                                        pointing_center=None, power=True, small_angle_tol=1e-10)
+        out['gauss_power_d14'] = ns['gaussian_beam'](14.0, skypos, freq_hz, skyunits='altaz', pointing_center=None, power=True)
+        # dispatcher: frequency passed in GHz with freq_scale='GHz' exactly like observe() does (:6252)
+        out['pbg_gaussian_d14'] = ns['primary_beam_generator'](skypos, freq_hz / 1e9, {'shape': 'gaussian', 'size': 14.0},
+                                                               freq_scale='GHz', skyunits='altaz')
+        out['pbg_dish_d14'] = ns['primary_beam_generator'](skypos, freq_hz / 1e9, {'shape': 'dish', 'size': 14.0},
+                                                           freq_scale='GHz', skyunits='altaz')
+        out['pbg_delta'] = ns['primary_beam_generator'](skypos, freq_hz / 1e9, {'shape': 'delta'},
+                                                        freq_scale='GHz', skyunits='altaz')
+    NP.savez_compressed(os.path.join(HERE, 'golden_beams.npz'), skypos_altaz=skypos, freq_hz=freq_hz, **out)
+    print('golden_beams.npz:', {k: v.shape for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    if not os.path.isdir(REF):
+        sys.exit('reference tree not available: golden vectors can only be regenerated in the build container')
+    make_skyvis()
+    make_beams()
