@@ -79,6 +79,8 @@ typedef struct prisim_sky {
   const double* pc_dircos;   /* [3] phase-centre direction cosines (:6164) */
   const double* fwhm_deg;    /* [nsrc] sqrt(maj*min) of skymodel.src_shape in degrees (:6267), or NULL:
                                 no source-shape taper (skymodel.src_shape is None, :6258) */
+  const double* fluxes;      /* optional [nsrc][nchan] float64: when non-NULL `pbflux` holds the beam pb only and the
+                                product pb * fluxes (:6254) is formed on the device; NULL: pbflux is already the product */
 } prisim_sky;
 
 /* Upload the snapshot's sky to the device (pbflux is repacked on the device into per-channel-tile
@@ -95,6 +97,10 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
 /* Copy slot `slot` to the host.  out_is_c64 = 0: complex128 [nbl][nchan]; 1: complex64 (memsave dtype, :6183).
  * grad (may be NULL): [3][nbl][nchan], same dtype.  Synchronises the stream. */
 int prisim_hip_get_vis(prisim_ctx* ctx, int64_t slot, void* vis, void* grad, int out_is_c64);
+
+/* Upload a host visibility snapshot [nbl][nchan] complex128 into cube slot `slot` (used to delay-transform
+ * cubes that live on the host, e.g. vis_freq / vis_noise_freq of interferometry.py:8116-8118). */
+int prisim_hip_set_vis(prisim_ctx* ctx, int64_t slot, const double* vis);
 
 /* One-shot drop-in for interferometry.py:6255-6376: set_sky + compute + get_vis. */
 int prisim_hip_skyvis(prisim_ctx* ctx, const prisim_sky* sky, int precision, int kernel,
@@ -113,6 +119,8 @@ typedef struct prisim_beam_sky {
   const double* dircos;        /* [nsrc][3] ENU */
   const double* flux_ref;      /* [nsrc] flux density at ref_freq_hz (Jy) */
   const double* spindex;       /* [nsrc] spectral index: S(f) = flux_ref * (f/ref_freq)^spindex */
+  const double* flux_spectrum; /* optional [nsrc][nchan] float64 spectra (SkyModel.generate_spectrum output, :6249);
+                                  when non-NULL it replaces the power law and flux_ref/spindex may be NULL */
   double ref_freq_hz;
   int32_t beam_kind;           /* PRISIM_BEAM_* */
   double diameter_m;           /* dish diameter / Gaussian FWHM aperture size */

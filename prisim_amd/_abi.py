@@ -21,7 +21,7 @@ PRISIM_BEAM_DELTA, PRISIM_BEAM_GAUSSIAN, PRISIM_BEAM_AIRY = 0, 1, 2
 EXPORTS = (
     'prisim_hip_create', 'prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version',
     'prisim_hip_set_array', 'prisim_hip_set_sky', 'prisim_hip_compute', 'prisim_hip_get_vis',
-    'prisim_hip_skyvis', 'prisim_hip_set_sky_analytic', 'prisim_hip_get_pbflux',
+    'prisim_hip_skyvis', 'prisim_hip_set_vis', 'prisim_hip_set_sky_analytic', 'prisim_hip_get_pbflux',
     'prisim_hip_delay_transform', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
     'prisim_hip_allgather', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
@@ -30,12 +30,12 @@ EXPORTS = (
 
 class PrisimSky(C.Structure):
     _fields_ = [('nsrc', C.c_int64), ('dircos', C.c_void_p), ('pbflux', C.c_void_p),
-                ('pbflux_is_f32', C.c_int32), ('pc_dircos', C.c_void_p), ('fwhm_deg', C.c_void_p)]
+                ('pbflux_is_f32', C.c_int32), ('pc_dircos', C.c_void_p), ('fwhm_deg', C.c_void_p), ('fluxes', C.c_void_p)]
 
 
 class PrisimBeamSky(C.Structure):
     _fields_ = [('nsrc', C.c_int64), ('dircos', C.c_void_p), ('flux_ref', C.c_void_p), ('spindex', C.c_void_p),
-                ('ref_freq_hz', C.c_double), ('beam_kind', C.c_int32), ('diameter_m', C.c_double),
+                ('flux_spectrum', C.c_void_p), ('ref_freq_hz', C.c_double), ('beam_kind', C.c_int32), ('diameter_m', C.c_double),
                 ('beam_pc_dircos', C.c_void_p), ('pc_dircos', C.c_void_p), ('fwhm_deg', C.c_void_p)]
 
 
@@ -76,6 +76,7 @@ def load_library():
     lib.prisim_hip_set_sky.argtypes = [vp, C.POINTER(PrisimSky)]
     lib.prisim_hip_compute.argtypes = [vp, i32, i32, i32, i64]
     lib.prisim_hip_get_vis.argtypes = [vp, i64, vp, vp, i32]
+    lib.prisim_hip_set_vis.argtypes = [vp, i64, vp]
     lib.prisim_hip_skyvis.argtypes = [vp, C.POINTER(PrisimSky), i32, i32, vp, vp, i32]
     lib.prisim_hip_set_sky_analytic.argtypes = [vp, C.POINTER(PrisimBeamSky)]
     lib.prisim_hip_get_pbflux.argtypes = [vp, vp]
@@ -157,7 +158,7 @@ class Context(object):
         self.nbl, self.nchan, self.nt_max = bl.shape[0], fr.size, int(nt_max)
 
     # ---- sky ----
-    def _sky_struct(self, dircos, pbflux, pc_dircos, fwhm_deg):
+    def _sky_struct(self, dircos, pbflux, pc_dircos, fwhm_deg, fluxes=None):
         dc = NP.ascontiguousarray(dircos, dtype=NP.float64).reshape(-1, 3)
         nsrc = dc.shape[0]
         pbflux = NP.asarray(pbflux)
@@ -173,22 +174,37 @@ class Context(object):
             fw = NP.ascontiguousarray(fwhm_deg, dtype=NP.float64).ravel()
             if fw.size != nsrc:
                 raise ValueError('fwhm_deg must have nsrc elements')
-        sky = PrisimSky(nsrc, _ptr(dc), _ptr(pb), 1 if is_f32 else 0, _ptr(pc), _ptr(fw))
-        return sky, (dc, pb, pc, fw)
+        fl = None
+        if fluxes is not None:
+            fl = NP.ascontiguousarray(fluxes, dtype=NP.float64)
+            if fl.size != nsrc * self.nchan:
+                raise ValueError('fluxes must have shape (nsrc, nchan)')
+        sky = PrisimSky(nsrc, _ptr(dc), _ptr(pb), 1 if is_f32 else 0, _ptr(pc), _ptr(fw), _ptr(fl))
+        return sky, (dc, pb, pc, fw, fl)
 
-    def set_sky(self, dircos, pbflux, pc_dircos, fwhm_deg=None):
-        sky, keep = self._sky_struct(dircos, pbflux, pc_dircos, fwhm_deg)
+    def set_sky(self, dircos, pbflux, pc_dircos, fwhm_deg=None, fluxes=None):
+        """pbflux: beam x flux (nsrc, nchan); or, with `fluxes` given, the beam alone (product formed on the device)."""
+        sky, keep = self._sky_struct(dircos, pbflux, pc_dircos, fwhm_deg, fluxes)
         self._check(self._lib.prisim_hip_set_sky(self._h, C.byref(sky)), 'prisim_hip_set_sky')
         self.nsrc = sky.nsrc
 
     def set_sky_analytic(self, dircos, flux_ref, spindex, ref_freq_hz, beam_kind, diameter_m, beam_pc_dircos,
-                         pc_dircos, fwhm_deg=None):
+                         pc_dircos, fwhm_deg=None, flux_spectrum=None):
+        """Fused beam x flux on the device.  Flux is the power law flux_ref*(f/ref)^spindex, or, when
+        flux_spectrum (nsrc, nchan) is given, that tabulated spectrum."""
         dc = NP.ascontiguousarray(dircos, dtype=NP.float64).reshape(-1, 3)
         nsrc = dc.shape[0]
-        fr = NP.ascontiguousarray(flux_ref, dtype=NP.float64).ravel()
-        sp = NP.ascontiguousarray(spindex, dtype=NP.float64).ravel()
-        if fr.size != nsrc or sp.size != nsrc:
-            raise ValueError('flux_ref and spindex must have nsrc elements')
+        fs = fr = sp = None
+        if flux_spectrum is not None:
+            fs = NP.ascontiguousarray(flux_spectrum, dtype=NP.float64)
+            if fs.size != nsrc * self.nchan:
+                raise ValueError('flux_spectrum must have shape (nsrc, nchan)')
+            ref_freq_hz = 1.0 if ref_freq_hz is None else ref_freq_hz
+        else:
+            fr = NP.ascontiguousarray(flux_ref, dtype=NP.float64).ravel()
+            sp = NP.ascontiguousarray(spindex, dtype=NP.float64).ravel()
+            if fr.size != nsrc or sp.size != nsrc:
+                raise ValueError('flux_ref and spindex must have nsrc elements')
         bpc = NP.ascontiguousarray(beam_pc_dircos, dtype=NP.float64).ravel()
         pc = NP.ascontiguousarray(pc_dircos, dtype=NP.float64).ravel()
         fw = None
@@ -196,7 +212,7 @@ class Context(object):
             fw = NP.ascontiguousarray(fwhm_deg, dtype=NP.float64).ravel()
             if fw.size != nsrc:
                 raise ValueError('fwhm_deg must have nsrc elements')
-        sky = PrisimBeamSky(nsrc, _ptr(dc), _ptr(fr), _ptr(sp), float(ref_freq_hz), int(beam_kind), float(diameter_m),
+        sky = PrisimBeamSky(nsrc, _ptr(dc), _ptr(fr), _ptr(sp), _ptr(fs), float(ref_freq_hz), int(beam_kind), float(diameter_m),
                             _ptr(bpc), _ptr(pc), _ptr(fw))
         self._check(self._lib.prisim_hip_set_sky_analytic(self._h, C.byref(sky)), 'prisim_hip_set_sky_analytic')
         self.nsrc = nsrc
@@ -220,9 +236,9 @@ class Context(object):
         return (vis, grad) if want_grad else vis
 
     def skyvis(self, dircos, pbflux, pc_dircos, fwhm_deg=None, precision=PRISIM_FP64, kernel=PRISIM_KERNEL_AUTO,
-               want_grad=False, complex64=False):
+               want_grad=False, complex64=False, fluxes=None):
         """One-shot drop-in for interferometry.py:6255-6376."""
-        sky, keep = self._sky_struct(dircos, pbflux, pc_dircos, fwhm_deg)
+        sky, keep = self._sky_struct(dircos, pbflux, pc_dircos, fwhm_deg, fluxes)
         ctype = NP.complex64 if complex64 else NP.complex128
         vis = NP.empty((self.nbl, self.nchan), dtype=ctype)
         grad = NP.empty((3, self.nbl, self.nchan), dtype=ctype) if want_grad else None
@@ -246,6 +262,18 @@ class Context(object):
         self._check(self._lib.prisim_hip_delay_transform(self._h, int(nt), _ptr(w), pad, _ptr(out), _ptr(lags), _ptr(pw),
                                                          float(power_scale)), 'prisim_hip_delay_transform')
         return out, lags, pw
+
+    def set_vis(self, vis, slot=0):
+        v = NP.ascontiguousarray(vis, dtype=NP.complex128)
+        if v.shape != (self.nbl, self.nchan):
+            raise ValueError('vis must have shape (nbl, nchan)')
+        self._check(self._lib.prisim_hip_set_vis(self._h, int(slot), _ptr(v)), 'prisim_hip_set_vis')
+
+    def delay_transform_host(self, vis, bpwts, pad):
+        """Delay-transform one host snapshot (nbl, nchan): upload into slot 0, transform, download."""
+        self.set_vis(vis, 0)
+        out, lags, pw = self.delay_transform(1, bpwts=bpwts, pad=pad)
+        return out[0], lags, pw
 
     # ---- multi-GPU ----
     @staticmethod

@@ -54,7 +54,7 @@ void k_beam_flux(const BeamParams p) {
     } else {
       pb = 1.0;
     }
-    const double flux = p.flux_ref[s] * pow(f / p.ref_freq, p.spindex[s]);
+    const double flux = p.flux_spec ? p.flux_spec[i] : p.flux_ref[s] * pow(f / p.ref_freq, p.spindex[s]);
     p.pb_out[i] = pb * flux;
   }
 }
@@ -65,6 +65,18 @@ hipError_t launch_beam_flux(const BeamParams& p, hipStream_t stream) {
   int64_t g = (total + 255) / 256;
   if (g > 16384) g = 16384;
   hipLaunchKernelGGL(k_beam_flux, dim3((unsigned)g), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+__global__ void k_mul_inplace(double* __restrict__ a, const double* __restrict__ b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] *= b[i];
+}
+
+hipError_t launch_mul_inplace(double* a, const double* b, int64_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  int64_t g = (n + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(k_mul_inplace, dim3((unsigned)g), dim3(256), 0, stream, a, b, n);
   return hipGetLastError();
 }
 

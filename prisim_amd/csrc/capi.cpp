@@ -412,6 +412,15 @@ int prisim_hip_set_sky(prisim_ctx* ctx, const prisim_sky* sky) {
       HIPCHK(ctx, hipMemcpyAsync(ctx->pb.p, sky->pbflux, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (sky->fluxes) {   // pbfluxes = pb * fluxes (:6254) on the device
+      DevBuf tmp;
+      if ((rc = ensure(ctx, tmp, (size_t)n * sizeof(double)))) return rc;
+      hipError_t e = hipMemcpyAsync(tmp.p, sky->fluxes, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = launch_mul_inplace((double*)ctx->pb.p, (const double*)tmp.p, n, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      release(tmp);
+      HIPCHK(ctx, e);
+    }
   }
   ctx->sky_set = true;
   return PRISIM_OK;
@@ -423,8 +432,10 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_analytic");
   if (sky->beam_kind < PRISIM_BEAM_DELTA || sky->beam_kind > PRISIM_BEAM_AIRY)
     return fail(ctx, PRISIM_EINVAL, "unknown beam_kind");
-  if (sky->nsrc > 0 && (!sky->flux_ref || !sky->spindex)) return fail(ctx, PRISIM_EINVAL, "flux_ref / spindex is NULL");
-  if (!(sky->ref_freq_hz > 0.0)) return fail(ctx, PRISIM_EINVAL, "ref_freq_hz must be positive");
+  const bool have_spec = sky->flux_spectrum != nullptr;
+  if (sky->nsrc > 0 && !have_spec && (!sky->flux_ref || !sky->spindex))
+    return fail(ctx, PRISIM_EINVAL, "flux_ref / spindex is NULL and no flux_spectrum given");
+  if (!have_spec && !(sky->ref_freq_hz > 0.0)) return fail(ctx, PRISIM_EINVAL, "ref_freq_hz must be positive");
   if (sky->beam_kind != PRISIM_BEAM_DELTA && !(sky->diameter_m > 0.0))
     return fail(ctx, PRISIM_EINVAL, "diameter_m must be positive");
   if (!sky->beam_pc_dircos) return fail(ctx, PRISIM_EINVAL, "beam_pc_dircos is NULL");
@@ -437,19 +448,22 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
   if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (ns > 0) {
     DevBuf fr, sp;
-    if ((rc = ensure(ctx, fr, (size_t)ns * sizeof(double))) || (rc = ensure(ctx, sp, (size_t)ns * sizeof(double)))) {
+    const size_t frb = have_spec ? (size_t)n * sizeof(double) : (size_t)ns * sizeof(double);
+    if ((rc = ensure(ctx, fr, frb)) || (rc = ensure(ctx, sp, (size_t)ns * sizeof(double)))) {
       release(fr); release(sp);
       return rc;
     }
-    hipError_t e = hipMemcpyAsync(fr.p, sky->flux_ref, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(sp.p, sky->spindex, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipMemcpyAsync(fr.p, have_spec ? sky->flux_spectrum : sky->flux_ref, frb, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && !have_spec)
+      e = hipMemcpyAsync(sp.p, sky->spindex, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
       BeamParams bp{};
       bp.dirs = (const double*)ctx->dirs.p;
-      bp.flux_ref = (const double*)fr.p;
-      bp.spindex = (const double*)sp.p;
+      bp.flux_ref = have_spec ? nullptr : (const double*)fr.p;
+      bp.spindex = have_spec ? nullptr : (const double*)sp.p;
+      bp.flux_spec = have_spec ? (const double*)fr.p : nullptr;
       bp.freqs = (const double*)ctx->freqs.p;
-      bp.ref_freq = sky->ref_freq_hz;
+      bp.ref_freq = have_spec ? 1.0 : sky->ref_freq_hz;
       bp.beam_kind = sky->beam_kind;
       bp.diameter = sky->diameter_m;
       bp.bpc_x = sky->beam_pc_dircos[0]; bp.bpc_y = sky->beam_pc_dircos[1]; bp.bpc_z = sky->beam_pc_dircos[2];
@@ -595,6 +609,19 @@ int prisim_hip_get_vis(prisim_ctx* ctx, int64_t slot, void* vis, void* grad, int
       to_c64(tmp.data(), (float*)grad, 3 * slot_elems);
     }
   }
+  return PRISIM_OK;
+}
+
+int prisim_hip_set_vis(prisim_ctx* ctx, int64_t slot, const double* vis) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (slot < 0 || slot >= ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "slot out of range");
+  if (!vis) return fail(ctx, PRISIM_EINVAL, "vis is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t slot_elems = (size_t)ctx->nbl * ctx->nchan * 2;
+  HIPCHK(ctx, hipMemcpyAsync((double*)ctx->cube.p + (size_t)slot * slot_elems, vis, slot_elems * sizeof(double),
+                             hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return PRISIM_OK;
 }
 

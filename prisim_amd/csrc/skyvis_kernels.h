@@ -56,6 +56,7 @@ struct BeamParams {
   const double* dirs;        // [nsrc][4]
   const double* flux_ref;    // [nsrc]
   const double* spindex;     // [nsrc]
+  const double* flux_spec;   // [nsrc][nchan] or nullptr (then power law)
   const double* freqs;       // [nchan]
   double ref_freq;
   int32_t beam_kind;
@@ -65,6 +66,7 @@ struct BeamParams {
   double* pb_out;            // [nsrc][nchan]
 };
 hipError_t launch_beam_flux(const BeamParams& p, hipStream_t stream);
+hipError_t launch_mul_inplace(double* a, const double* b, int64_t n, hipStream_t stream);
 
 // delay transform helpers (delay_kernels.hip)
 hipError_t launch_dt_prepare(const double* cube, const double* bpwts, double* work, int64_t nrows, int64_t nbl,

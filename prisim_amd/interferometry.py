@@ -1,0 +1,582 @@
+"""Host-side mirror of the reference's ``InterferometerArray`` for the sky-sum path.
+
+Same class / method / keyword names, argument meaning and exception types as
+prisim/interferometry.py of nithyanandan/PRISim (constructor :5140-5145, 5665-5870; observe
+:5874-6410; observing_run :6414-6657; delay_transform :8052-8137) so that a PRISim user can switch
+to ``prisim_amd.interferometry.InterferometerArray`` for this path.  Everything numerical on the
+path -- tau, the source-shape taper, the DFT sum, the baseline gradient, pb*flux, the analytic
+beams in scope, the delay transform -- runs in HIP kernels behind include/prisim_hip.h.  There is
+NO CPU fallback: without libprisim_hip.so or a GPU the constructor raises ``PrisimHipError``.
+
+Differences kept on purpose:
+  Q1  ``timeobj`` may be an astropy-``Time``-like object (``.jd``, ``.sidereal_time('apparent').deg``),
+      or a ``(jd, lst_deg)`` tuple, or a float jd with the ``lst`` keyword; astropy is not required.
+  Q2  ``observing_run`` works (the reference's passes a str as timeobj and cannot run).
+  Q4  baseline gradients work for shapeless sky models too.
+  Q5  ``memsave`` reduces the phase in fp64 before the fp32 recurrence (more accurate than the reference's
+      all-fp32 phase); results are complex64 like the reference's.
+  Q7  the visibility cube is grown without O(nt^2) recopy; same logical shape (nbl, nchan, n_acc).
+  Q20 delay_transform transforms whichever of the three cubes exist.
+  sky coordinates 'radec' are converted with HA = LST - RA (no precession / nutation / aberration;
+  astropy's FK5->AltAz is outside the boundary, SURVEY.md 7 "Hard parts").
+Out of scope here: init_file (HDF5/FITS persistence), gains, noise, uvfits.
+"""
+import warnings
+
+import numpy as NP
+
+from . import _abi
+from . import baseline_delay_horizon as DLY
+from . import geometry as GEOM
+from . import primary_beams as PB
+
+C_LIGHT = 299792458.0
+SIDEREAL_RATE = 1.00273790935    # sidereal seconds per solar second
+
+
+class LazyGeometricDelays(object):
+    """Stand-in for one entry of ``InterferometerArray.geometric_delays`` (the reference stores the full
+    nsrc x nbl matrix per snapshot, interferometry.py:6287-6291 -- 4.9 GB at HERA-350 x 1e4 sources).
+    Materialised on demand by ``numpy.asarray(obj)``: tau = dc . bl^T / c."""
+
+    def __init__(self, baselines, dircos, dtype):
+        self._bl, self._dc, self._dtype = baselines, dircos, dtype
+        self.shape = (dircos.shape[0], baselines.shape[0])
+
+    def __array__(self, dtype=None, copy=None):
+        out = DLY.geometric_delay(self._bl, self._dc, altaz=False, hadec=False, dircos=True).astype(self._dtype)
+        return out if dtype is None else out.astype(dtype)
+
+
+def _lst_and_jd(timeobj, lst):
+    """Resolve (jd, lst_deg) from the accepted forms of ``timeobj`` (interferometry.py:6113, 6395)."""
+    if hasattr(timeobj, 'sidereal_time'):
+        st = timeobj.sidereal_time('apparent')
+        lst_deg = float(getattr(st, 'deg', st))
+        return float(timeobj.jd), lst_deg       # the lst kwarg is overwritten, as in the reference (:6113)
+    if isinstance(timeobj, (tuple, list)) and len(timeobj) == 2:
+        return float(timeobj[0]), float(timeobj[1])
+    if isinstance(timeobj, dict) and 'jd' in timeobj and 'lst' in timeobj:
+        return float(timeobj['jd']), float(timeobj['lst'])
+    if isinstance(timeobj, (int, float, NP.floating, NP.integer)):
+        if lst is None:
+            raise ValueError('LST must be provided when timeobj is a bare Julian date.')
+        return float(timeobj), float(lst)
+    raise TypeError('timeobj must be a Time-like object, a (jd, lst_deg) pair, or a Julian date with lst given.')
+
+
+class InterferometerArray(object):
+    """Interferometer array whose snapshots are simulated on one MI355X (see module docstring).
+
+    Attributes touched by observe() keep the reference's names and shapes:
+    bp, bp_wts, Tsys, Tsysinfo, pointing_center, phase_center, geometric_delays, obs_catalog_indices,
+    skyvis_freq, gradient, gradient_mode, timestamp, t_acc, t_obs, n_acc, lst.
+    """
+
+    def __init__(self, labels, baselines, channels, telescope=None, eff_Q=0.89,
+                 latitude=34.0790, longitude=0.0, altitude=0.0, skycoords='radec',
+                 A_eff=NP.pi * (25.0 / 2) ** 2, pointing_coords='hadec', layout=None,
+                 blgroupinfo=None, baseline_coords='localenu', freq_scale=None,
+                 gaininfo=None, init_file=None, simparms_file=None, device=0):
+        if init_file is not None:
+            raise NotImplementedError('init_file (HDF5/FITS persistence, interferometry.py:5184-5658) is outside the '
+                                      'sky-sum path this package accelerates')
+        if gaininfo is not None:
+            raise NotImplementedError('gaininfo (instrument gains) is outside the sky-sum path')
+
+        self.baselines = NP.asarray(baselines, dtype=NP.float64)                      # :5668-5682
+        if self.baselines.ndim == 1:
+            if self.baselines.size == 2:
+                self.baselines = NP.hstack((self.baselines.reshape(1, -1), NP.zeros((1, 1))))
+            elif self.baselines.size == 3:
+                self.baselines = self.baselines.reshape(1, -1)
+            else:
+                raise ValueError('Baseline(s) must be a 2- or 3-column array.')
+        elif self.baselines.ndim == 2:
+            if self.baselines.shape[1] == 2:
+                self.baselines = NP.hstack((self.baselines, NP.zeros((self.baselines.shape[0], 1))))
+            elif self.baselines.shape[1] != 3:
+                raise ValueError('Baseline(s) must be a 2- or 3-column array')
+        else:
+            raise ValueError('Baseline(s) array contains more than 2 dimensions.')
+        self.baseline_lengths = NP.sqrt(NP.sum(self.baselines ** 2, axis=1))         # :5684
+        self.baseline_orientations = NP.angle(self.baselines[:, 0] + 1j * self.baselines[:, 1])
+        self.projected_baselines = None
+
+        if not isinstance(labels, (list, tuple, NP.ndarray)):                         # :5688-5693
+            raise TypeError('Interferometer array labels must be a list or tuple of unique identifiers')
+        elif len(labels) != self.baselines.shape[0]:
+            raise ValueError('Number of labels do not match the number of baselines specified.')
+        self.labels = labels
+        self.simparms_file = simparms_file if isinstance(simparms_file, str) else None
+
+        if isinstance(telescope, dict):                                               # :5701-5710
+            self.telescope = telescope
+        else:
+            self.telescope = {'id': 'vla', 'shape': 'dish', 'size': 25.0, 'ocoords': 'altaz',
+                              'orientation': NP.asarray([90.0, 270.0]).reshape(1, -1), 'groundplane': None}
+        self.layout = {}
+        if isinstance(layout, dict):                                                  # :5713-5751
+            for key in ('positions', 'coords', 'labels', 'ids'):
+                if key not in layout:
+                    raise KeyError('Array layout {0} missing'.format(key))
+            self.layout = dict(layout)
+        self.blgroups = None
+        self.bl_reversemap = None
+        if blgroupinfo is not None:
+            if not isinstance(blgroupinfo, dict):
+                raise TypeError('Input blgroupinfo must be a dictionary')
+            self.blgroups = blgroupinfo['groups']
+            self.bl_reversemap = blgroupinfo['reversemap']
+
+        self.latitude, self.longitude, self.altitude = latitude, longitude, altitude
+        self.vis_freq = None
+        self.skyvis_freq = None
+        self.vis_noise_freq = None
+        self.gradient_mode = None
+        self.gradient = {}
+        self.gaininfo = None
+
+        ch = NP.asarray(channels, dtype=NP.float64).ravel()                           # :5779-5788
+        if (freq_scale is None) or (freq_scale in ('Hz', 'hz')):
+            self.channels = ch
+        elif freq_scale in ('GHz', 'ghz'):
+            self.channels = ch * 1.0e9
+        elif freq_scale in ('MHz', 'mhz'):
+            self.channels = ch * 1.0e6
+        elif freq_scale in ('kHz', 'khz'):
+            self.channels = ch * 1.0e3
+        else:
+            raise ValueError('Frequency units must be "GHz", "MHz", "kHz" or "Hz". If not set, it defaults to "Hz"')
+
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        self.bp = NP.ones((nbl, nchan))                                               # :5790-5791
+        self.bp_wts = NP.ones((nbl, nchan))
+        self.lag_kernel = None
+        self.Tsys = NP.zeros((nbl, nchan))
+        self.Tsysinfo = []
+        self.flux_unit = 'JY'
+        self.timestamp = []
+        self.t_acc = []
+        self.t_obs = 0.0
+        self.n_acc = 0
+        self.pointing_center = NP.empty([1, 2])
+        self.phase_center = NP.empty([1, 2])
+        self.lst = []
+
+        self.eff_Q = self._broadcast_bl_chan(eff_Q, 'Efficiency', lo=0.0, hi=1.0)      # :5806-5824
+        self.A_eff = self._broadcast_bl_chan(A_eff, 'Effective area', lo=0.0, hi=None)  # :5826-5844
+
+        self.vis_rms_freq = None
+        self.freq_resolution = self.channels[1] - self.channels[0] if nchan > 1 else 0.0   # :5847
+        self.lags = None
+        self.skyvis_lag = None
+        self.vis_noise_lag = None
+        self.vis_lag = None
+        self.obs_catalog_indices = []
+        self.geometric_delays = []
+
+        if pointing_coords in ('radec', 'hadec', 'altaz'):                            # :5856-5860
+            self.pointing_coords = pointing_coords
+            self.phase_center_coords = pointing_coords
+        else:
+            raise ValueError('Pointing center of the interferometer must be "radec", "hadec" or "altaz". Check inputs.')
+        if skycoords in ('radec', 'hadec', 'altaz'):                                  # :5862-5865
+            self.skycoords = skycoords
+        else:
+            raise ValueError('Sky coordinates must be "radec", "hadec" or "altaz". Check inputs.')
+        if baseline_coords in ('equatorial', 'localenu'):                             # :5867-5870
+            self.baseline_coords = baseline_coords
+        else:
+            raise ValueError('Baseline coordinates must be "equatorial" or "local". Check inputs.')
+        if baseline_coords == 'equatorial':
+            raise NotImplementedError('equatorial baselines (GEOM.xyz2enu, interferometry.py:6153) are not on the accelerated path')
+
+        # GPU context: fails loudly when the HIP library or a device is missing
+        self._ctx = _abi.Context(device)
+        self._ctx.set_array(self.baselines, self.channels, nt_max=1)
+        self._cube = []        # per-snapshot (nbl, nchan) visibilities, stacked lazily into skyvis_freq
+        self._grad = []
+
+    # ------------------------------------------------------------------------------------------
+    def _broadcast_bl_chan(self, value, what, lo, hi):
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        if isinstance(value, (int, float)):
+            if value < lo or (hi is not None and value > hi):
+                raise ValueError('{0} value of interferometer is invalid.'.format(what))
+            return value * NP.ones((nbl, nchan))
+        elif isinstance(value, (list, tuple, NP.ndarray)):
+            value = NP.asarray(value)
+            if NP.any(value < lo) or (hi is not None and NP.any(value > hi)):
+                raise ValueError('One or more values of {0} found to be outside the valid range.'.format(what))
+            if value.size == nbl:
+                return NP.repeat(value.reshape(-1, 1), nchan, axis=1)
+            elif value.size == nchan:
+                return NP.repeat(value.reshape(1, -1), nbl, axis=0)
+            elif value.size == nbl * nchan:
+                return value.reshape(-1, nchan)
+            raise ValueError('{0} values of interferometers incompatible with the number of interferometers and/or '
+                             'frequency channels.'.format(what))
+        raise TypeError('{0} values of interferometers must be provided as a scalar, list, tuple or numpy array.'.format(what))
+
+    # ------------------------------------------------------------------------------------------
+    def _stack_bandpass(self, bandpass):
+        """interferometry.py:5993-6024."""
+        bandpass = NP.asarray(bandpass)
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        if bandpass.ndim == 1:
+            if bandpass.size != nchan:
+                raise ValueError('Specified bandpass incompatible with the number of frequency channels')
+            layer = NP.repeat(bandpass.reshape(1, -1), nbl, axis=0)[:, :, NP.newaxis]
+        elif bandpass.ndim == 2:
+            if bandpass.shape[1] != nchan:
+                raise ValueError('Specified bandpass incompatible with the number of frequency channels')
+            elif bandpass.shape[0] != nbl:
+                raise ValueError('Specified bandpass incompatible with the number of interferometers')
+            layer = bandpass[:, :, NP.newaxis]
+        elif bandpass.ndim == 3:
+            if bandpass.shape[1] != nchan:
+                raise ValueError('Specified bandpass incompatible with the number of frequency channels')
+            elif bandpass.shape[0] != nbl:
+                raise ValueError('Specified bandpass incompatible with the number of interferometers')
+            elif bandpass.shape[2] != 1:
+                raise ValueError('Bandpass can have only one layer for this instance of accumulation.')
+            layer = bandpass
+        else:
+            raise ValueError('Specified bandpass has too many dimensions')
+        self.bp = layer if self.bp.ndim == 2 else NP.dstack((self.bp, layer))
+        self.bp_wts = NP.ones_like(self.bp)
+
+    def _stack_tsys(self, Tsysinfo, bpcorrect):
+        """interferometry.py:6026-6086."""
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        if not isinstance(Tsysinfo, dict):
+            raise TypeError('Input Tsysinfo must be a dictionary')
+        Tsys = None
+        if Tsysinfo.get('Tnet', None) is not None:
+            Tsys = Tsysinfo['Tnet']
+        else:
+            try:
+                Tsys = Tsysinfo['Trx'] + Tsysinfo['Tant']['T0'] * (self.channels / Tsysinfo['Tant']['f0']) ** Tsysinfo['Tant']['spindex']
+            except KeyError:
+                raise KeyError('One or more keys not found in input Tsysinfo')
+            Tsys = Tsys.reshape(1, -1) + NP.zeros(nbl).reshape(-1, 1)
+        self.Tsysinfo += [Tsysinfo]
+        if bpcorrect is not None:
+            if not isinstance(bpcorrect, NP.ndarray):
+                raise TypeError('Input specifying bandpass correction must be a numpy array')
+            if bpcorrect.size == nchan:
+                bpcorrect = bpcorrect.reshape(1, -1)
+            elif bpcorrect.size == nbl:
+                bpcorrect = bpcorrect.reshape(-1, 1)
+            elif bpcorrect.size == nbl * nchan:
+                bpcorrect = bpcorrect.reshape(-1, nchan)
+            else:
+                raise ValueError('Input bpcorrect has dimensions incompatible with the number of baselines and frequencies')
+            Tsys = Tsys * bpcorrect
+        if isinstance(Tsys, (int, float)):
+            if Tsys < 0.0:
+                raise ValueError('Tsys found to be negative.')
+            layer = Tsys + NP.zeros((nbl, nchan, 1))
+        elif isinstance(Tsys, (list, tuple, NP.ndarray)):
+            Tsys = NP.asarray(Tsys)
+            if NP.any(Tsys < 0.0):
+                raise ValueError('Tsys should be non-negative.')
+            if Tsys.size == 1:
+                layer = float(Tsys.ravel()[0]) + NP.zeros((nbl, nchan, 1))
+            elif Tsys.size == nbl:
+                layer = NP.repeat(Tsys.reshape(-1, 1), nchan, axis=1)[:, :, NP.newaxis]
+            elif Tsys.size == nchan:
+                layer = NP.repeat(Tsys.reshape(1, -1), nbl, axis=0)[:, :, NP.newaxis]
+            elif Tsys.size == nbl * nchan:
+                layer = Tsys.reshape(-1, nchan)[:, :, NP.newaxis]
+            else:
+                raise ValueError('Specified Tsys has incompatible dimensions with the number of baselines and/or number of frequency channels.')
+        else:
+            raise TypeError('Tsys should be a scalar, list, tuple, or numpy array')
+        self.Tsys = layer if self.Tsys.ndim == 2 else NP.dstack((self.Tsys, layer))
+
+    # ------------------------------------------------------------------------------------------
+    def observe(self, timeobj, Tsysinfo, bandpass, pointing_center, skymodel,
+                t_acc, pb_info=None, brightness_units=None, bpcorrect=None,
+                roi_info=None, roi_radius=None, roi_center=None, lst=None,
+                gradient_mode=None, memsave=False, vmemavail=None,
+                store_prev_skymodel_file=None):
+        """Simulate one snapshot (interferometry.py:5874-6410).  See the reference docstring for the
+        argument meaning; vmemavail and store_prev_skymodel_file are accepted and ignored (the GPU kernel
+        never materialises the nsrc x nbl x nchan matrix, so there is no memory-shortage path)."""
+        self._stack_bandpass(bandpass)
+        self._stack_tsys(Tsysinfo, bpcorrect)
+
+        pc = NP.asarray(pointing_center, dtype=NP.float64).reshape(1, -1)             # :6103-6108
+        if pc.size != 2:
+            raise ValueError('pointing_center must be a 2-element vector')
+        if not self.timestamp:
+            self.pointing_center = pc
+            self.phase_center = pc.copy()
+        else:
+            self.pointing_center = NP.vstack((self.pointing_center, pc))
+            self.phase_center = NP.vstack((self.phase_center, pc))
+
+        jd, lst = _lst_and_jd(timeobj, lst)                                           # :6113
+
+        pc_altaz = self.pointing_center[-1, :]                                        # :6155-6162
+        if self.pointing_coords == 'hadec':
+            pc_altaz = GEOM.hadec2altaz(self.pointing_center[-1, :], self.latitude, units='degrees')
+        elif self.pointing_coords == 'radec':
+            pc_altaz = GEOM.hadec2altaz(NP.asarray([lst - self.pointing_center[-1, 0], self.pointing_center[-1, 1]]),
+                                        self.latitude, units='degrees')
+        pc_dircos = GEOM.altaz2dircos(pc_altaz, 'degrees').ravel()                    # :6164
+
+        for attr in ('location', 'generate_spectrum'):                                 # :6171 (duck-typed SkyModel)
+            if not hasattr(skymodel, attr):
+                raise TypeError('skymodel should be an instance of class SkyModel.')
+        location = NP.asarray(skymodel.location, dtype=NP.float64).reshape(-1, 2)
+        if self.skycoords == 'hadec':                                                 # :6176-6180
+            skypos_altaz = GEOM.hadec2altaz(location, self.latitude, units='degrees')
+        elif self.skycoords == 'radec':
+            hadec = NP.stack((lst - location[:, 0], location[:, 1]), axis=1)
+            skypos_altaz = GEOM.hadec2altaz(hadec, self.latitude, units='degrees')
+        else:
+            skypos_altaz = location
+
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        datatype = NP.complex64 if memsave else NP.complex128                         # :6182-6185
+
+        if gradient_mode is not None:                                                 # :6306-6311
+            if not isinstance(gradient_mode, str):
+                raise TypeError('Input gradient_mode must be a string')
+            if gradient_mode.lower() not in ['baseline', 'skypos', 'frequency']:
+                raise ValueError('Invalid value specified in input gradient_mode')
+            if gradient_mode.lower() != 'baseline':
+                raise NotImplementedError('only gradient_mode="baseline" is computed (as in the reference)')
+            if self.gradient_mode is None:
+                self.gradient_mode = gradient_mode
+        want_grad = gradient_mode is not None
+
+        pb = None
+        if roi_info is not None:                                                      # :6189-6202
+            if ('ind' not in roi_info) or ('pbeam' not in roi_info):
+                raise KeyError('Both "ind" and "pbeam" keys must be present in dictionary roi_info')
+            m2 = NP.arange(0)
+            if (roi_info['ind'] is not None) and (roi_info['pbeam'] is not None):
+                m2 = NP.asarray(roi_info['ind']).ravel()
+                if m2.size > 0:
+                    try:
+                        pb = NP.asarray(roi_info['pbeam']).reshape(-1, nchan)
+                    except ValueError:
+                        raise ValueError('Number of columns of primary beam in key "pbeam" of dictionary roi_info must be equal to number of frequency channels.')
+                    if m2.size != pb.shape[0]:
+                        raise ValueError('Values in keys ind and pbeam in must carry same number of elements.')
+        else:                                                                         # :6204-6216
+            if roi_radius is None:
+                roi_radius = 90.0
+            if roi_center is None:
+                roi_center = 'zenith'
+            elif (roi_center != 'zenith') and (roi_center != 'pointing_center'):
+                raise ValueError('Center of region of interest, roi_center, must be set to "zenith" or "pointing_center".')
+            if roi_center == 'pointing_center':
+                dc_all = GEOM.altaz2dircos(skypos_altaz, 'degrees')
+                cosd = NP.clip(NP.dot(dc_all, pc_dircos), -1.0, 1.0)
+                m2 = NP.where(NP.degrees(NP.arccos(cosd)) <= roi_radius)[0]
+            else:
+                m2 = NP.arange(skypos_altaz.shape[0])
+                m2 = m2[NP.where(skypos_altaz[:, 0] >= 90.0 - roi_radius)]
+
+        if len(m2) > 0:
+            skypos_altaz_roi = skypos_altaz[m2, :]                                    # :6219
+            dircos_roi = GEOM.altaz2dircos(skypos_altaz_roi, 'degrees')               # :6263 (unconditional, Q4)
+            fluxes = NP.asarray(skymodel.generate_spectrum(ind=m2, frequency=self.channels, interp_method='pchip'),
+                                dtype=NP.float64).reshape(-1, nchan)                  # :6249
+            fwhm = None
+            src_shape = getattr(skymodel, 'src_shape', None)
+            if src_shape is not None:                                                 # :6258, 6267
+                src_shape = NP.asarray(src_shape, dtype=NP.float64)
+                fwhm = NP.sqrt(src_shape[m2, 0] * src_shape[m2, 1])
+            prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
+            if pb is not None:
+                # supplied beam (ROI_parameters path): pbfluxes = pb * fluxes on the device (:6254)
+                self._ctx.set_sky(dircos_roi, pb, pc_dircos, fwhm_deg=fwhm, fluxes=fluxes)
+            else:
+                kind, dia, bpc = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz)  # :6252
+                self._ctx.set_sky_analytic(dircos_roi, None, None, None, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,
+                                           flux_spectrum=fluxes)
+            self._ctx.compute(precision=prec, want_grad=want_grad, slot=0)
+            res = self._ctx.get_vis(slot=0, want_grad=want_grad, complex64=memsave)
+            skyvis, skyvis_gradient = res if want_grad else (res, None)
+            self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(self.baselines, dircos_roi,
+                                                                                 NP.float32 if memsave else NP.float64)]   # :6287-6291
+            self.obs_catalog_indices = self.obs_catalog_indices + [m2]                # :6377
+        else:                                                                         # :6378-6382
+            warnings.warn('No sources found in the catalog within matching radius. Simply populating the observed visibilities and/or gradients with noise.')
+            skyvis = NP.zeros((nbl, nchan), dtype=datatype)
+            skyvis_gradient = NP.zeros((3, nbl, nchan), dtype=datatype) if want_grad else None
+
+        self._cube.append(skyvis)                                                     # :6384-6393
+        self._skyvis_cache = None
+        if want_grad:
+            self._grad.append(skyvis_gradient)
+            self.gradient[gradient_mode] = NP.stack(self._grad, axis=3)
+
+        self.timestamp = self.timestamp + [jd]                                        # :6395-6399
+        self.t_acc = self.t_acc + [t_acc]
+        self.t_obs += t_acc
+        self.n_acc += 1
+        self.lst = self.lst + [lst]
+
+    # skyvis_freq: (nbl, nchan, n_acc), time fastest, like the reference (:6385-6390)
+    @property
+    def skyvis_freq(self):
+        if not getattr(self, '_cube', None):
+            return self._skyvis_override
+        if getattr(self, '_skyvis_cache', None) is None:
+            self._skyvis_cache = NP.stack(self._cube, axis=2)
+        return self._skyvis_cache
+
+    @skyvis_freq.setter
+    def skyvis_freq(self, value):
+        self._skyvis_override = value
+        if value is not None:
+            value = NP.asarray(value)
+            self._cube = [value[:, :, i] for i in range(value.shape[2])]
+            self._skyvis_cache = value
+
+    # ------------------------------------------------------------------------------------------
+    def observing_run(self, pointing_init, skymodel, t_acc, duration, channels,
+                      bpass, Tsys, lst_init, roi_radius=None, roi_center=None,
+                      mode='track', pointing_coords=None, freq_scale=None,
+                      brightness_units=None, verbose=True, memsave=False):
+        """Extended observing run in 'track' or 'drift' mode built from snapshots
+        (interferometry.py:6414-6657; argument checks :6510-6601, LST ramp :6607, pointing :6611-6633).
+        lst_init is in HOURS, as the reference's LST ramp (:6607) treats it."""
+        if isinstance(pointing_init, list):
+            pointing_init = NP.asarray(pointing_init)
+        elif not isinstance(pointing_init, NP.ndarray):
+            raise TypeError('pointing_init must be a list or numpy array.')
+        if pointing_init.size != 2:
+            raise ValueError('pointing_init must be a 2-element vector.')
+        pointing_init = pointing_init.ravel().astype(NP.float64)
+        if not isinstance(t_acc, (int, float)):
+            raise TypeError('t_acc must be a scalar integer or float.')
+        if t_acc <= 0.0:
+            raise ValueError('t_acc must be positive.')
+        if not isinstance(duration, (int, float)):
+            raise TypeError('duration must be a scalar integer or float.')
+        if duration <= t_acc:
+            if verbose:
+                warnings.warn('\t\tDuration specified to be shorter than t_acc. Will set it equal to t_acc')
+            duration = t_acc
+        n_acc = int(duration / t_acc)                                                  # :6536
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        if not isinstance(bpass, (list, tuple, NP.ndarray)):
+            raise TypeError('bpass must be a list, tuple or numpy array')
+        bpass = NP.asarray(bpass)
+        if bpass.size == nchan:                                                        # :6561-6572
+            bpass = NP.expand_dims(NP.repeat(bpass.reshape(1, -1), nbl, axis=0), axis=2)
+        elif bpass.size == nbl * nchan:
+            bpass = NP.expand_dims(bpass.reshape(-1, nchan), axis=2)
+        elif bpass.size == nbl * nchan * n_acc:
+            bpass = bpass.reshape(-1, nchan, n_acc)
+        else:
+            raise ValueError('Dimensions of bpass incompatible with the number of frequency channels, baselines and number of accumulations.')
+        if not isinstance(Tsys, (int, float, list, tuple, NP.ndarray)):
+            raise TypeError('Tsys must be a scalar, list, tuple or numpy array')
+        Tsys = NP.asarray(Tsys, dtype=NP.float64).reshape(-1)                          # :6574-6598
+        if Tsys.size == 1:
+            Tsys = Tsys + NP.zeros((nbl, nchan, 1))
+        elif Tsys.size == nchan:
+            Tsys = NP.expand_dims(NP.repeat(Tsys.reshape(1, -1), nbl, axis=0), axis=2)
+        elif Tsys.size == nbl:
+            Tsys = NP.expand_dims(NP.repeat(Tsys.reshape(-1, 1), nchan, axis=1), axis=2)
+        elif Tsys.size == nbl * nchan:
+            Tsys = NP.expand_dims(Tsys.reshape(-1, nchan), axis=2)
+        elif Tsys.size == nbl * nchan * n_acc:
+            Tsys = Tsys.reshape(-1, nchan, n_acc)
+        else:
+            raise ValueError('Dimensions of Tsys incompatible with the number of frequency channels, baselines and number of accumulations.')
+        if not isinstance(lst_init, (int, float)):
+            raise TypeError('Starting LST should be a scalar')
+
+        lst = (lst_init + (t_acc / 3.6e3) * NP.arange(n_acc)) * 15.0                   # :6607 (degrees)
+        lst_init_deg = lst_init * 15.0
+        if mode == 'track':                                                            # :6611-6622
+            if pointing_coords == 'hadec':
+                pointing = NP.asarray([lst_init_deg - pointing_init[0], pointing_init[1]])
+            elif (pointing_coords == 'radec') or (pointing_coords is None):
+                pointing = pointing_init
+            elif pointing_coords == 'altaz':
+                hadec = GEOM.altaz2hadec(pointing_init, self.latitude, units='degrees')
+                pointing = NP.asarray([lst_init_deg - hadec[0], hadec[1]])
+            else:
+                raise ValueError('pointing_coords can only be set to "hadec", "radec" or "altaz".')
+            self.pointing_coords = 'radec'
+            self.phase_center_coords = 'radec'
+        elif mode == 'drift':                                                          # :6623-6633
+            if pointing_coords == 'radec':
+                pointing = NP.asarray([lst_init_deg - pointing_init[0], pointing_init[1]])
+            elif (pointing_coords == 'hadec') or (pointing_coords is None):
+                pointing = pointing_init
+            elif pointing_coords == 'altaz':
+                pointing = GEOM.altaz2hadec(pointing_init, self.latitude, units='degrees')
+            else:
+                raise ValueError('pointing_coords can only be set to "hadec", "radec" or "altaz".')
+            self.pointing_coords = 'hadec'
+            self.phase_center_coords = 'hadec'
+        else:
+            raise ValueError('mode must be "track" or "drift"')
+
+        jd0 = 2451545.0
+        for i in range(n_acc):                                                         # :6641-6647
+            jd = jd0 + i * t_acc / 86400.0
+            self.observe((jd, float(lst[i])), {'Tnet': Tsys[:, :, i % Tsys.shape[2]]}, bpass[:, :, i % bpass.shape[2]],
+                         pointing, skymodel, t_acc, brightness_units=brightness_units, roi_radius=roi_radius,
+                         roi_center=roi_center, memsave=memsave)
+        self.t_obs = duration                                                          # :6654-6655
+        self.n_acc = n_acc
+
+    # ------------------------------------------------------------------------------------------
+    def delay_transform(self, pad=1.0, freq_wts=None, verbose=True):
+        """Frequency -> delay transform on the GPU (rocFFT) of whichever visibility cubes exist
+        (interferometry.py:8052-8137; Q20).  Sets lags, skyvis_lag (vis_lag, vis_noise_lag when their
+        frequency cubes exist) and lag_kernel."""
+        if not isinstance(pad, (int, float)):
+            raise TypeError('pad fraction must be a scalar value.')
+        if pad < 0.0:
+            pad = 0.0
+            if verbose:
+                warnings.warn('\tPad fraction found to be negative. Resetting to 0.0 (no padding will be applied).')
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        if freq_wts is not None:                                                       # :8096-8107
+            freq_wts = NP.asarray(freq_wts)
+            if freq_wts.size == nchan:
+                freq_wts = NP.repeat(NP.expand_dims(NP.repeat(freq_wts.reshape(1, -1), nbl, axis=0), axis=2), self.n_acc, axis=2)
+            elif freq_wts.size == nchan * self.n_acc:
+                freq_wts = NP.repeat(NP.expand_dims(freq_wts.reshape(nchan, -1), axis=0), nbl, axis=0)
+            elif freq_wts.size == nchan * nbl:
+                freq_wts = NP.repeat(NP.expand_dims(freq_wts.reshape(-1, nchan), axis=2), self.n_acc, axis=2)
+            elif freq_wts.size == nchan * nbl * self.n_acc:
+                freq_wts = freq_wts.reshape(nbl, nchan, self.n_acc)
+            else:
+                raise ValueError('window shape dimensions incompatible with number of channels and/or number of tiemstamps.')
+            self.bp_wts = freq_wts
+        if self.skyvis_freq is None:
+            raise ValueError('no visibilities to transform: call observe() first')
+
+        def transform(cube):
+            # cube (nbl, nchan, nt) times bp*bp_wts, one snapshot at a time through the device cube slot 0
+            nt = cube.shape[2]
+            wts = NP.broadcast_to((self.bp * self.bp_wts).reshape(nbl, nchan, -1), (nbl, nchan, nt)) \
+                if self.bp.ndim == 3 else NP.broadcast_to((self.bp * self.bp_wts)[:, :, None], (nbl, nchan, nt))
+            outs = []
+            for t in range(nt):
+                out, lags, _ = self._ctx.delay_transform_host(cube[:, :, t], wts[:, :, t], pad)
+                outs.append(out)
+            return NP.stack(outs, axis=2), lags
+
+        self.skyvis_lag, self.lags = transform(NP.asarray(self.skyvis_freq, dtype=NP.complex128))
+        if self.vis_freq is not None:
+            self.vis_lag, _ = transform(NP.asarray(self.vis_freq, dtype=NP.complex128))
+        if self.vis_noise_freq is not None:
+            self.vis_noise_lag, _ = transform(NP.asarray(self.vis_noise_freq, dtype=NP.complex128))
+        ones = NP.ones((nbl, nchan, self.skyvis_freq.shape[2]), dtype=NP.complex128)
+        self.lag_kernel, _ = transform(ones)                                           # :8119 / :8127

@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library loads and exports every symbol include/prisim_hip.h declares; the ctypes
+structures match the header; the product path fails loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from prisim_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'prisim_hip.h')
+
+
+def _declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(prisim_hip_\w+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _abi.load_library()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), 'libprisim_hip.so does not export ' + name
+    assert sorted(_abi.EXPORTS) == names
+
+
+def test_version_and_error_string_without_context():
+    lib = _abi.load_library()
+    assert lib.prisim_hip_version().decode().startswith('prisim_hip ')
+    assert isinstance(lib.prisim_hip_last_error(None), bytes)
+
+
+def test_struct_layouts_match_header():
+    # prisim_sky: int64, 2 ptr, int32 (+pad), 3 ptr  -> 56 bytes on LP64
+    assert C.sizeof(_abi.PrisimSky) == 56
+    assert _abi.PrisimSky.pbflux_is_f32.offset == 24 and _abi.PrisimSky.fluxes.offset == 48
+    # prisim_beam_sky: int64, 4 ptr, double, int32 (+pad), double, 3 ptr -> 88 bytes
+    assert C.sizeof(_abi.PrisimBeamSky) == 88
+    assert _abi.PrisimBeamSky.beam_kind.offset == 48 and _abi.PrisimBeamSky.diameter_m.offset == 56
+    # prisim_timing: 3 double, 2 int64, 4 int32 -> 56 bytes
+    assert C.sizeof(_abi.PrisimTiming) == 56
+
+
+def test_null_context_is_rejected_not_crashing():
+    lib = _abi.load_library()
+    assert lib.prisim_hip_sync(None) == _abi.PRISIM_EINVAL
+    assert lib.prisim_hip_compute(None, 0, 0, 0, 0) == _abi.PRISIM_EINVAL
+    assert lib.prisim_hip_create(0, None) == _abi.PRISIM_EINVAL
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU, creating a context raises PrisimHipError (on a GPU box it simply succeeds)."""
+    try:
+        ctx = _abi.Context(0)
+    except _abi.PrisimHipError as exc:
+        assert 'no HIP device' in str(exc) or 'HIP' in str(exc)
+    else:
+        ctx.close()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_abi, '_lib', None)
+    monkeypatch.setattr(_abi, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_abi.PrisimHipError):
+        _abi.load_library()

@@ -1,0 +1,214 @@
+"""GPU (-m gpu): fused device beams, rocFFT delay transform, single-rank all-gather, and the
+InterferometerArray drop-in -- all through the C-ABI."""
+import numpy as NP
+import pytest
+
+from oracle import skyvis_oracle as O, beams_oracle as BO, delay_oracle as DO
+from prisim_amd import _abi, workloads as W
+from prisim_amd import interferometry as RI, skymodel as SM, primary_beams as PB
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_beams_match_golden_reference_functions(ctx, golden_beams):
+    g = golden_beams
+    sp, f = g['skypos_altaz'], g['freq_hz']
+    dc = O.altaz2dircos(sp)
+    zen = NP.array([0.0, 0.0, 1.0])
+    ctx.set_array(NP.zeros((1, 3)), f)
+    n = sp.shape[0]
+    for kind, key in ((_abi.PRISIM_BEAM_AIRY, 'airy_power_d14'), (_abi.PRISIM_BEAM_GAUSSIAN, 'gauss_power_d14'),
+                      (_abi.PRISIM_BEAM_DELTA, 'pbg_delta')):
+        ctx.set_sky_analytic(dc, NP.ones(n), NP.zeros(n), 150e6, kind, 14.0, zen, zen)
+        pb = ctx.get_pbflux()
+        assert NP.max(NP.abs(pb - g[key])) <= 1e-12, key
+    # host dispatcher mirror (primary_beam_generator) evaluates on the GPU as well
+    pb = PB.primary_beam_generator(sp, f / 1e9, {'shape': 'dish', 'size': 14.0}, freq_scale='GHz', skyunits='altaz')
+    assert NP.max(NP.abs(pb - g['pbg_dish_d14'])) <= 1e-12
+    pb = PB.primary_beam_generator(sp, f / 1e9, {'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'},
+                                   freq_scale='GHz', skyunits='altaz')
+    assert NP.max(NP.abs(pb - g['airy_power_d14'])) <= 1e-12
+
+
+def test_device_beam_times_power_law_and_offzenith_pointing(ctx):
+    cfg = W.config1()
+    ch, sky = cfg['channels'], cfg['sky']
+    ctx.set_array(cfg['baselines'], ch)
+    pc_altaz = NP.array([75.0, 200.0])
+    bpc = O.altaz2dircos(pc_altaz[None, :])[0]
+    zen = NP.array([0.0, 0.0, 1.0])
+    flux = sky['flux_ref'][:, None] * (ch[None, :] / sky['ref_freq']) ** sky['spindex'][:, None]
+    for kind, fn in ((_abi.PRISIM_BEAM_GAUSSIAN, BO.gaussian_beam), (_abi.PRISIM_BEAM_AIRY, BO.airy_disk_pattern)):
+        ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], kind, 14.0, bpc, zen)
+        ref = fn(14.0, sky['altaz'], ch, pointing_altaz=pc_altaz) * flux
+        assert NP.max(NP.abs(ctx.get_pbflux() - ref)) <= 1e-11 * NP.max(ref)
+        # tabulated spectra instead of the power law
+        ctx.set_sky_analytic(sky['dircos'], None, None, None, kind, 14.0, bpc, zen, flux_spectrum=flux)
+        assert NP.max(NP.abs(ctx.get_pbflux() - ref)) <= 1e-11 * NP.max(ref)
+
+
+@pytest.mark.parametrize('pad', [0.0, 1.0, 0.5])
+def test_delay_transform_matches_numpy_restatement(ctx, pad):
+    rng = NP.random.default_rng(12)
+    nbl, nchan, nt = 13, 64, 3
+    ch = 150e6 + NP.arange(nchan) * 1.0e5
+    ctx.set_array(rng.uniform(-100, 100, (nbl, 3)), ch, nt_max=nt)
+    cube = rng.normal(size=(nt, nbl, nchan)) + 1j * rng.normal(size=(nt, nbl, nchan))
+    for t in range(nt):
+        ctx.set_vis(cube[t], slot=t)
+    wts = rng.uniform(0.5, 1.0, (nbl, nchan))
+    out, lags, pw = ctx.delay_transform(nt, bpwts=wts, pad=pad, want_power=True, power_scale=2.5)
+    vis_bft = NP.transpose(cube, (1, 2, 0))                                    # (nbl, nchan, nt)
+    ref, ref_lags = DO.delay_transform(vis_bft, wts[:, :, None], NP.ones((nbl, nchan, 1)), 1.0e5, pad=pad)
+    ref = NP.transpose(ref, (2, 0, 1))
+    assert out.shape == ref.shape
+    assert NP.max(NP.abs(out - ref)) <= 1e-10 * NP.max(NP.abs(ref))            # delay spectra <= 1e-10 rel
+    assert NP.allclose(lags, ref_lags, rtol=0, atol=1e-18)
+    assert NP.max(NP.abs(pw - DO.delay_power(ref, 2.5))) <= 1e-9 * NP.max(NP.abs(ref)) ** 2 * 2.5
+
+
+def test_delay_transform_single_tone_kat8(ctx):
+    nchan, df = 128, 97656.25
+    ch = 150e6 + NP.arange(nchan) * df
+    ctx.set_array(NP.zeros((1, 3)), ch)
+    k0 = -9
+    tau0 = k0 / (nchan * df)
+    ctx.set_vis((3.0 * NP.exp(-2j * NP.pi * (ch - ch[0]) * tau0))[None, :])
+    out, lags, _ = ctx.delay_transform(1, pad=1.0)
+    ipk = int(NP.argmax(NP.abs(out[0, 0])))
+    assert abs(lags[ipk] - tau0) <= 1e-15 and abs(abs(out[0, 0, ipk]) - 3.0 * nchan * df) <= 1e-6 * nchan * df
+
+
+def test_single_rank_allgather_and_checksum(ctx):
+    rng = NP.random.default_rng(3)
+    nbl, nchan, nt = 17, 40, 2
+    ch = 150e6 + NP.arange(nchan) * 1.0e5
+    ctx.set_array(rng.uniform(-100, 100, (nbl, 3)), ch, nt_max=nt)
+    cube = rng.normal(size=(nt, nbl, nchan)) + 1j * rng.normal(size=(nt, nbl, nchan))
+    for t in range(nt):
+        ctx.set_vis(cube[t], slot=t)
+    ctx.allgather(nt)
+    g = ctx.get_gathered(nt, 1)
+    assert NP.array_equal(g[0], cube)
+    assert abs(ctx.gathered_checksum(nt) - (cube.real.sum() + cube.imag.sum())) <= 1e-9
+    ctx.allgather(nt, complex64=True)
+    g = ctx.get_gathered(nt, 1)
+    assert g.dtype == NP.complex64 and NP.array_equal(g[0], cube.astype(NP.complex64))
+
+
+def test_rccl_communicator_of_one_rank(ctx):
+    """RCCL itself (dlopen + ncclCommInitRank + ncclAllGather) on the one GPU of the box."""
+    rng = NP.random.default_rng(4)
+    ch = 150e6 + NP.arange(16) * 1.0e5
+    c = _abi.Context(0)
+    try:
+        c.set_array(rng.uniform(-100, 100, (5, 3)), ch, nt_max=1)
+        v = rng.normal(size=(5, 16)) + 1j * rng.normal(size=(5, 16))
+        c.set_vis(v)
+        c.comm_init(_abi.Context.comm_unique_id(), 1, 0)
+        c.allgather(1)
+        assert NP.array_equal(c.get_gathered(1, 1)[0, 0], v)
+    finally:
+        c.close()
+
+
+# ---------------------------------------------------------------- InterferometerArray drop-in
+class FakeTime(object):
+    """astropy.time.Time-like: observe() only needs .jd and .sidereal_time('apparent').deg (:6113, :6395)."""
+    def __init__(self, jd, lst_deg):
+        self.jd, self._lst = jd, lst_deg
+
+    def sidereal_time(self, kind):
+        class _A(object):
+            pass
+        a = _A()
+        a.deg = self._lst
+        return a
+
+
+def test_interferometer_array_observe_matches_oracle():
+    cfg = W.config2()
+    bl, ch, sky = cfg['baselines'][::3], cfg['channels'][:64], cfg['sky']
+    lat = -30.7224
+    n = sky['dircos'].shape[0]
+    skymod = SM.SkyModel(location=sky['altaz'], flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
+                         src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1))
+    labels = ['b%d' % i for i in range(bl.shape[0])]
+    ia = RI.InterferometerArray(labels, bl, ch, telescope={'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'},
+                                latitude=lat, skycoords='altaz', pointing_coords='hadec')
+    tsys = {'Trx': 100.0, 'Tant': {'f0': 150e6, 'T0': 200.0, 'spindex': -2.5}, 'Tnet': None}
+    for j, memsave in enumerate((False, True)):
+        ia2 = ia if j == 0 else RI.InterferometerArray(labels, bl, ch, telescope=ia.telescope, latitude=lat, skycoords='altaz')
+        ia2.observe(FakeTime(2457000.5 + j, 30.0), tsys, NP.ones(ch.size), [0.0, lat], skymod, 10.0, gradient_mode='baseline',
+                    memsave=memsave, roi_radius=90.0)
+        pb = BO.airy_disk_pattern(14.0, sky['altaz'], ch, pointing_altaz=[90.0, 270.0]) \
+            * skymod.generate_spectrum(frequency=ch)
+        zen = O.altaz2dircos(NP.array([[90.0, 0.0]]))[0]
+        ref, gref = O.skyvis(bl, ch, sky['dircos'], pb, zen, fwhm_deg=sky['fwhm_deg'], gradient=True)
+        tol = 5e-6 if memsave else 1e-11
+        scale = O.abs_flux_sum(pb)[None, :]
+        assert ia2.skyvis_freq.shape == (bl.shape[0], ch.size, 1)
+        assert ia2.skyvis_freq.dtype == (NP.complex64 if memsave else NP.complex128)
+        assert NP.max(NP.abs(ia2.skyvis_freq[:, :, 0] - ref) / scale) <= tol
+        assert NP.max(NP.abs(ia2.gradient['baseline'][:, :, :, 0] - gref) / scale[None]) <= tol
+        assert ia2.n_acc == 1 and ia2.t_obs == 10.0 and ia2.lst == [30.0] and ia2.timestamp == [2457000.5 + j]
+        assert ia2.bp.shape == (bl.shape[0], ch.size, 1) and ia2.Tsys.shape == (bl.shape[0], ch.size, 1)
+        assert NP.asarray(ia2.geometric_delays[0]).shape == (n, bl.shape[0])
+        assert NP.array_equal(ia2.obs_catalog_indices[0], NP.arange(n))
+    # second snapshot appends along the last (time) axis; roi_info path with a supplied float32 beam
+    pb32 = BO.airy_disk_pattern(14.0, sky['altaz'], ch).astype(NP.float32)
+    ia.observe((2457000.6, 31.0), tsys, NP.ones(ch.size), [0.0, lat], skymod, 10.0,
+               roi_info={'ind': NP.arange(n), 'pbeam': pb32})
+    assert ia.skyvis_freq.shape == (bl.shape[0], ch.size, 2) and ia.n_acc == 2
+    ref2 = O.skyvis(bl, ch, sky['dircos'], pb32.astype(NP.float64) * skymod.generate_spectrum(frequency=ch), zen,
+                    fwhm_deg=sky['fwhm_deg'])
+    assert NP.max(NP.abs(ia.skyvis_freq[:, :, 1] - ref2) / O.abs_flux_sum(pb)[None, :]) <= 1e-11
+    # delay transform of the accumulated cube on the GPU
+    ia.delay_transform(pad=1.0, verbose=False)
+    ref_lag, ref_lags = DO.delay_transform(ia.skyvis_freq, ia.bp, ia.bp_wts, ia.freq_resolution, pad=1.0)
+    assert ia.skyvis_lag.shape == ref_lag.shape
+    assert NP.max(NP.abs(ia.skyvis_lag - ref_lag)) <= 1e-10 * NP.max(NP.abs(ref_lag))
+    assert NP.allclose(ia.lags, ref_lags)
+
+
+def test_interferometer_array_validation_and_empty_sky():
+    ch = 150e6 + NP.arange(8) * 1e5
+    with pytest.raises(ValueError):
+        RI.InterferometerArray(['a'], NP.zeros((2, 3)), ch)
+    with pytest.raises(TypeError):
+        RI.InterferometerArray('a', NP.zeros((1, 3)), ch)
+    with pytest.raises(ValueError):
+        RI.InterferometerArray(['a'], NP.zeros((1, 3)), ch, freq_scale='THz')
+    with pytest.raises(ValueError):
+        RI.InterferometerArray(['a'], NP.zeros((1, 3)), ch, skycoords='galactic')
+    ia = RI.InterferometerArray(['a'], NP.array([[10.0, 0.0]]), ch / 1e6, freq_scale='MHz', skycoords='altaz',
+                                telescope={'shape': 'delta'})
+    assert ia.baselines.shape == (1, 3) and NP.allclose(ia.channels, ch)
+    skymod = SM.SkyModel(location=[[-10.0, 0.0]], flux_ref=[1.0], spindex=[0.0], ref_freq=150e6)   # below the horizon
+    with pytest.warns(UserWarning):
+        ia.observe((2457000.5, 0.0), {'Tnet': 50.0}, NP.ones(8), [0.0, 34.079], skymod, 1.0)
+    assert NP.all(ia.skyvis_freq == 0) and ia.skyvis_freq.shape == (1, 8, 1)
+    with pytest.raises(ValueError):
+        ia.observe((2457000.5, 0.0), {'Tnet': 50.0}, NP.ones(7), [0.0, 34.079], skymod, 1.0)
+    with pytest.raises(TypeError):
+        ia.observe((2457000.5, 0.0), 50.0, NP.ones(8), [0.0, 34.079], skymod, 1.0)
+    with pytest.raises(KeyError):
+        ia.observe((2457000.5, 0.0), {'Tnet': 50.0}, NP.ones(8), [0.0, 34.079], skymod, 1.0, roi_info={'ind': None})
+
+
+def test_observing_run_drift():
+    ch = 150e6 + NP.arange(16) * 1e5
+    bl = NP.array([[14.6, 0.0, 0.0], [0.0, 14.6, 0.0]])
+    lat = -30.7224
+    skymod = SM.SkyModel(location=[[10.0, lat], [355.0, lat + 5.0]], flux_ref=[1.0, 2.0], spindex=[0.0, -0.7], ref_freq=150e6)
+    ia = RI.InterferometerArray(['a', 'b'], bl, ch, telescope={'shape': 'gaussian', 'size': 14.0}, latitude=lat, skycoords='radec')
+    ia.observing_run([0.0, lat], skymod, 60.0, 180.0, ch, NP.ones(16), 100.0, 0.5, mode='drift', verbose=False)
+    assert ia.skyvis_freq.shape == (2, 16, 3) and ia.n_acc == 3 and ia.t_obs == 180.0
+    assert NP.allclose(ia.lst, (0.5 + 60.0 / 3600 * NP.arange(3)) * 15.0)
+    # snapshot 1 against the oracle: HA = LST - RA, zenith phase centre
+    lst1 = ia.lst[1]
+    hadec = NP.stack((lst1 - skymod.location[:, 0], skymod.location[:, 1]), 1)
+    altaz = O.hadec2altaz(hadec, lat)
+    pb = BO.gaussian_beam(14.0, altaz, ch, pointing_altaz=O.hadec2altaz([[0.0, lat]], lat)[0]) * skymod.generate_spectrum(frequency=ch)
+    ref = O.skyvis(bl, ch, O.altaz2dircos(altaz), pb, O.altaz2dircos(O.hadec2altaz([[0.0, lat]], lat))[0])
+    assert NP.max(NP.abs(ia.skyvis_freq[:, :, 1] - ref)) <= 1e-10

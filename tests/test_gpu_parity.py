@@ -1,0 +1,281 @@
+"""GPU (-m gpu): parity of the HIP sky-sum, called through the C-ABI, against the golden vectors
+(reference statements), the oracle on seeded inputs, analytic KATs, and size-independent properties at
+BASELINE.json's full headline size.
+
+Tolerances (stated relative to S_f = sum_s |pbflux[s,f]|):
+    fp64:  max |dV| <= 1e-11 * S_f        fp32:  max |dV| <= 5e-6 * S_f
+"""
+import numpy as NP
+import pytest
+
+from oracle import skyvis_oracle as O, c_oracle as CO
+from prisim_amd import _abi, workloads as W
+
+pytestmark = pytest.mark.gpu
+
+TOL = {_abi.PRISIM_FP64: 1e-11, _abi.PRISIM_FP32: 5e-6}
+C = 299792458.0
+
+
+def relerr(v, ref, pb):
+    return float(NP.max(NP.abs(v - ref) / O.abs_flux_sum(pb)[None, :]))
+
+
+def _fwhm(g):
+    return NP.sqrt(g['src_shape'][:, 0] * g['src_shape'][:, 1])
+
+
+# ---------------------------------------------------------------- golden vectors (reference statements)
+@pytest.mark.parametrize('prec', [_abi.PRISIM_FP64, _abi.PRISIM_FP32])
+@pytest.mark.parametrize('kernel', [_abi.PRISIM_KERNEL_RECURRENCE, _abi.PRISIM_KERNEL_DIRECT])
+def test_golden_fp64_reference_path(ctx, golden_skyvis, prec, kernel):
+    g = golden_skyvis
+    ctx.set_array(g['baselines'], g['channels'])
+    ctx.set_tuning(0, 0, 0)
+    v, gr = ctx.skyvis(g['dircos'], g['pbfluxes'], g['pc_dircos'], precision=prec, kernel=kernel, want_grad=True)
+    assert relerr(v, g['skyvis_f64'], g['pbfluxes']) <= TOL[prec]
+    assert max(relerr(gr[k], g['grad_f64'][k], g['pbfluxes']) for k in range(3)) <= TOL[prec]
+    v, gr = ctx.skyvis(g['dircos'], g['pbfluxes'], g['pc_dircos'], fwhm_deg=_fwhm(g), precision=prec, kernel=kernel, want_grad=True)
+    assert relerr(v, g['skyvis_f64_taper'], g['pbfluxes']) <= TOL[prec]
+    assert max(relerr(gr[k], g['grad_f64_taper'][k], g['pbfluxes']) for k in range(3)) <= TOL[prec]
+
+
+def test_golden_memsave_reference_path(ctx, golden_skyvis):
+    """The reference's own fp32 path (:6323) forms the phase in fp32 and is ~1e-5 S_f away from its fp64 path;
+    our fp32 mode must be at least as close to the reference fp32 result as that intrinsic error."""
+    g = golden_skyvis
+    ctx.set_array(g['baselines'], g['channels'])
+    v = ctx.skyvis(g['dircos'], g['pbfluxes'], g['pc_dircos'], precision=_abi.PRISIM_FP32, complex64=True)
+    assert v.dtype == NP.complex64
+    ref_gap = relerr(g['skyvis_f32'], g['skyvis_f64'], g['pbfluxes'])
+    assert relerr(v, g['skyvis_f32'], g['pbfluxes']) <= ref_gap + 5e-6
+    assert relerr(v, g['skyvis_f64'], g['pbfluxes']) <= 5e-6
+
+
+# ---------------------------------------------------------------- oracle on seeded inputs, all kernel variants
+def _random_case(seed, nbl, nchan, nsrc, taper, maxbl=300.0, df=97656.25):
+    rng = NP.random.default_rng(seed)
+    bl = rng.uniform(-maxbl, maxbl, size=(nbl, 3))
+    bl[:, 2] *= 0.01
+    ch = 100e6 + NP.arange(nchan) * df
+    alt = NP.degrees(NP.arcsin(rng.uniform(NP.sin(NP.radians(5.0)), 1.0, nsrc)))
+    dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, nsrc)), axis=1))
+    pb = rng.uniform(0.0, 10.0, size=(nsrc, 1)) * (ch / 150e6).reshape(1, -1) ** -0.8 * rng.uniform(0.2, 1.0, size=(nsrc, nchan))
+    pc = O.altaz2dircos(NP.array([[80.0, 30.0]]))[0]
+    fw = None
+    if taper:
+        fw = rng.uniform(0.0, 1.5, nsrc)
+        fw[::5] = 0.0
+    return bl, ch, dc, pb, pc, fw
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 100), (171, 256, 600), (300, 100, 777), (1, 1, 1), (65, 9, 2), (257, 33, 65)])
+@pytest.mark.parametrize('taper', [False, True])
+def test_oracle_parity_all_variants(ctx, shape, taper):
+    nbl, nchan, nsrc = shape
+    bl, ch, dc, pb, pc, fw = _random_case(11, nbl, nchan, nsrc, taper)
+    ref = O.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw)
+    ctx.set_array(bl, ch)
+    ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
+    for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):
+        cts = [0, 8, 16, 32] + ([64] if prec == _abi.PRISIM_FP32 else [])
+        for ct in cts:
+            for nsplit in (0, 1, 3):
+                ctx.set_tuning(ct, 0, nsplit)
+                ctx.compute(precision=prec, kernel=_abi.PRISIM_KERNEL_RECURRENCE)
+                assert relerr(ctx.get_vis(), ref, pb) <= TOL[prec], (shape, taper, prec, ct, nsplit)
+        for chunk in (1, 7, 64, 256):
+            ctx.set_tuning(0, chunk, 0)
+            ctx.compute(precision=prec, kernel=_abi.PRISIM_KERNEL_RECURRENCE)
+            assert relerr(ctx.get_vis(), ref, pb) <= TOL[prec], (shape, taper, prec, 'chunk', chunk)
+    ctx.set_tuning(0, 0, 0)
+    ctx.compute(precision=_abi.PRISIM_FP64, kernel=_abi.PRISIM_KERNEL_DIRECT)
+    assert relerr(ctx.get_vis(), ref, pb) <= TOL[_abi.PRISIM_FP64]
+
+
+def test_config2_fp64_full(ctx):
+    """BASELINE config 2: HERA-19 x 256 ch x nside-16 diffuse sky, Airy beam, taper ON, fp64 -- full size."""
+    cfg = W.config2()
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    zen = NP.array([0.0, 0.0, 1.0])
+    ctx.set_array(bl, ch)
+    ctx.set_tuning(0, 0, 0)
+    ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, 14.0, zen, zen,
+                         fwhm_deg=sky['fwhm_deg'])
+    pb = ctx.get_pbflux()
+    ref = CO.skyvis(bl, ch, sky['dircos'], pb, zen, fwhm_deg=sky['fwhm_deg'])
+    for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):
+        ctx.compute(precision=prec)
+        assert relerr(ctx.get_vis(), ref, pb) <= TOL[prec]
+
+
+def test_config3_subsample_fp32_and_fp64(ctx):
+    """1/64 sub-sample of the headline config 3 (every 8th baseline, every 8th source... of HERA-350 x 1024 ch)."""
+    cfg = W.subsample(W.config3(), bl_stride=64, src_stride=8)
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    zen = NP.array([0.0, 0.0, 1.0])
+    ctx.set_array(bl, ch)
+    ctx.set_tuning(0, 0, 0)
+    ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, 14.0, zen, zen)
+    pb = ctx.get_pbflux()
+    ref = CO.skyvis(bl, ch, sky['dircos'], pb, zen)
+    for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):
+        ctx.compute(precision=prec)
+        assert relerr(ctx.get_vis(), ref, pb) <= TOL[prec]
+
+
+# ---------------------------------------------------------------- analytic known answers on the GPU
+BL = NP.array([[14.6, 0.0, 0.0], [7.3, 12.644, 0.0], [-250.0, 120.0, 1.5], [0.0, 0.0, 0.0]])
+CH = 150e6 + (NP.arange(48) - 24) * 390625.0
+
+
+@pytest.mark.parametrize('prec', [_abi.PRISIM_FP64, _abi.PRISIM_FP32])
+def test_kat_phase_centre_and_closed_form(ctx, prec):
+    ctx.set_array(BL, CH)
+    ctx.set_tuning(0, 0, 0)
+    pc = O.altaz2dircos([[70.0, 123.0]])[0]
+    p = NP.linspace(1.0, 2.0, CH.size)[None, :]
+    v = ctx.skyvis(pc[None, :], p, pc, precision=prec)
+    assert relerr(v, NP.broadcast_to(p, v.shape), p) <= TOL[prec]                     # KAT-1
+    s = O.altaz2dircos([[40.0, 250.0]])[0]
+    zen = NP.array([0.0, 0.0, 1.0])
+    p3 = NP.full((1, CH.size), 3.0)
+    v = ctx.skyvis(s[None, :], p3, zen, precision=prec)
+    expected = 3.0 * NP.exp(-2j * NP.pi * CH[None, :] * (BL @ (s - zen))[:, None] / C)
+    assert relerr(v, expected, p3) <= TOL[prec]                                       # KAT-2
+
+
+@pytest.mark.parametrize('prec', [_abi.PRISIM_FP64, _abi.PRISIM_FP32])
+def test_kat_hermitian_linearity_additivity(ctx, prec):
+    rng = NP.random.default_rng(5)
+    s = O.altaz2dircos(NP.stack((rng.uniform(10, 90, 300), rng.uniform(0, 360, 300)), 1))
+    p = rng.uniform(0, 5, (300, CH.size))
+    pc = O.altaz2dircos([[85.0, 0.0]])[0]
+    ctx.set_array(BL, CH)
+    ctx.set_tuning(0, 0, 0)
+    full = ctx.skyvis(s, p, pc, precision=prec)
+    ctx.set_array(-BL, CH)
+    assert relerr(ctx.skyvis(s, p, pc, precision=prec), NP.conj(full), p) <= 2 * TOL[prec]        # KAT-4
+    ctx.set_array(BL, CH)
+    assert relerr(ctx.skyvis(s, 2.5 * p, pc, precision=prec), 2.5 * full, 2.5 * p) <= 2 * TOL[prec]   # KAT-5 linear
+    parts = ctx.skyvis(s[:101], p[:101], pc, precision=prec) + ctx.skyvis(s[101:], p[101:], pc, precision=prec)
+    assert relerr(parts, full, p) <= 2 * TOL[prec]                                    # KAT-5 additive (slab invariance)
+    # zero baseline sees the total flux
+    assert NP.max(NP.abs(full[3] - p.sum(0)) / p.sum(0)) <= TOL[prec]
+
+
+def test_kat_taper_limits(ctx):
+    zen = NP.array([0.0, 0.0, 1.0])
+    s = O.altaz2dircos([[50.0, 90.0]])
+    p = NP.ones((1, CH.size))
+    ctx.set_array(BL, CH)
+    ctx.set_tuning(0, 0, 0)
+    a = ctx.skyvis(s, p, zen, fwhm_deg=[0.0])
+    b = ctx.skyvis(s, p, zen)
+    assert NP.max(NP.abs(a - b)) <= 1e-13                                             # FWHM = 0 -> w = 1
+    ctx.set_array(NP.vstack((100.0 * s, BL[:1])), CH)
+    v = ctx.skyvis(s, p, zen, fwhm_deg=[1.0])
+    assert NP.max(NP.abs(NP.abs(v[0]) - 1.0)) <= 1e-9                                 # b || s -> u_perp = 0 -> w = 1
+    assert NP.all(NP.abs(v[1]) < 1.0)
+
+
+# ---------------------------------------------------------------- edge cases
+def test_empty_sky_gives_zeros(ctx):
+    ctx.set_array(BL, CH)
+    v, g = ctx.skyvis(NP.zeros((0, 3)), NP.zeros((0, CH.size)), [0, 0, 1.0], want_grad=True)
+    assert v.shape == (4, CH.size) and NP.all(v == 0) and NP.all(g == 0)
+
+
+def test_nonuniform_channels_use_direct_kernel(ctx):
+    rng = NP.random.default_rng(9)
+    ch = NP.sort(rng.uniform(100e6, 200e6, 37))
+    bl, _, dc, pb, pc, fw = _random_case(3, 70, 37, 90, True)
+    pb = pb[:, :37]
+    ctx.set_array(bl, ch)
+    ctx.set_tuning(0, 0, 0)
+    v = ctx.skyvis(dc, pb, pc, fwhm_deg=fw)
+    assert ctx.timing()['last_kernel_id'] == _abi.PRISIM_KERNEL_DIRECT
+    assert relerr(v, O.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw), pb) <= 1e-11
+    with pytest.raises(ValueError):
+        ctx.compute(kernel=_abi.PRISIM_KERNEL_RECURRENCE)
+
+
+def test_float32_pbflux_and_device_side_product(ctx):
+    bl, ch, dc, pb, pc, fw = _random_case(21, 40, 64, 120, False)
+    ctx.set_array(bl, ch)
+    ctx.set_tuning(0, 0, 0)
+    pb32 = pb.astype(NP.float32)                         # external beams are stored float32 (interferometry.py:4466)
+    v = ctx.skyvis(dc, pb32, pc)
+    assert relerr(v, O.skyvis(bl, ch, dc, pb32.astype(NP.float64), pc), pb) <= 1e-11
+    beam = NP.random.default_rng(2).uniform(0, 1, pb.shape)
+    v = ctx.skyvis(dc, beam, pc, fluxes=pb)              # pbfluxes = pb * fluxes formed on the device (:6254)
+    assert relerr(v, O.skyvis(bl, ch, dc, beam * pb, pc), beam * pb) <= 1e-11
+    v = ctx.skyvis(dc, beam.astype(NP.float32), pc, fluxes=pb)
+    assert relerr(v, O.skyvis(bl, ch, dc, beam.astype(NP.float32).astype(NP.float64) * pb, pc), beam * pb) <= 1e-11
+
+
+def test_argument_errors_map_to_reference_exception_types(ctx):
+    with pytest.raises(ValueError):
+        ctx.set_array(NP.zeros((0, 3)), CH)
+    ctx.set_array(BL, CH, nt_max=2)
+    with pytest.raises(ValueError):
+        ctx.set_sky(NP.zeros((2, 3)), NP.zeros((2, 5)), [0, 0, 1.0])                  # wrong nchan
+    with pytest.raises(ValueError):
+        ctx.set_sky(NP.full((2, 3), NP.nan), NP.zeros((2, CH.size)), [0, 0, 1.0])
+    with pytest.raises(ValueError):
+        ctx.set_sky(NP.zeros((2, 3)), NP.zeros((2, CH.size)), [0, 0, 1.0], fwhm_deg=[-1.0, 0.0])
+    ctx.set_sky(O.altaz2dircos([[50.0, 0.0]]), NP.ones((1, CH.size)), [0, 0, 1.0])
+    with pytest.raises(ValueError):
+        ctx.compute(slot=2)
+    with pytest.raises(ValueError):
+        ctx.compute(precision=7)
+    with pytest.raises(ValueError):
+        ctx.set_tuning(12, 0, 0)
+    fresh = _abi.Context(0)
+    with pytest.raises(RuntimeError):
+        fresh.compute()                                                               # compute before set_array
+    fresh.close()
+
+
+def test_snapshot_slots_are_independent(ctx):
+    bl, ch, dc, pb, pc, fw = _random_case(31, 50, 32, 64, False)
+    ctx.set_array(bl, ch, nt_max=3)
+    ctx.set_tuning(0, 0, 0)
+    refs = []
+    for t in range(3):
+        ctx.set_sky(dc, pb * (t + 1), pc)
+        ctx.compute(slot=t)
+        refs.append(O.skyvis(bl, ch, dc, pb * (t + 1), pc))
+    for t in range(3):
+        assert relerr(ctx.get_vis(slot=t), refs[t], pb * (t + 1)) <= 1e-11
+
+
+# ---------------------------------------------------------------- full headline size: size-independent properties
+def test_full_size_headline_properties(ctx):
+    """HERA-350 x 1024 ch x 1e4 sources (6.25e11 terms per pass), fp32: the oracle cannot run this size in
+    seconds, so check (i) a 1/977 baseline sample against the C oracle, (ii) additivity over two disjoint source
+    halves, (iii) the zero-spacing identity sum_b... (b = 0 is not in the array, so use V(-b) = conj V(b))."""
+    cfg = W.config3()
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    zen = NP.array([0.0, 0.0, 1.0])
+    ctx.set_array(bl, ch)
+    ctx.set_tuning(0, 0, 0)
+    ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, 14.0, zen, zen)
+    pb = ctx.get_pbflux()
+    ctx.compute(precision=_abi.PRISIM_FP32)
+    full = ctx.get_vis()
+    assert NP.all(NP.isfinite(full.view(NP.float64)))
+    sel = NP.arange(0, bl.shape[0], 977)
+    ref = CO.skyvis(bl[sel], ch, sky['dircos'], pb, zen)
+    assert relerr(full[sel], ref, pb) <= 5e-6
+    half = pb.shape[0] // 2
+    acc = NP.zeros_like(full)
+    for lo, hi in ((0, half), (half, pb.shape[0])):
+        ctx.set_sky(sky['dircos'][lo:hi], pb[lo:hi], zen)
+        ctx.compute(precision=_abi.PRISIM_FP32)
+        acc += ctx.get_vis()
+    assert relerr(acc, full, pb) <= 1e-5
+    ctx.set_array(-bl[::61], ch)
+    ctx.set_sky(sky['dircos'], pb, zen)
+    ctx.compute(precision=_abi.PRISIM_FP32)
+    assert relerr(ctx.get_vis(), NP.conj(full[::61]), pb) <= 1e-5

@@ -1,0 +1,161 @@
+"""CPU: host-side logic -- layouts, channel grid, HEALPix, geometry, workloads, sharding, sky model,
+beam dispatch, argument validation of the reference-mirroring interface."""
+import numpy as NP
+import pytest
+
+from prisim_amd import geometry as GEOM, layouts as LAY, workloads as W, skymodel as SM, primary_beams as PB
+from prisim_amd import baseline_delay_horizon as DLY, _abi
+import bench
+
+
+def test_hexagon_generator_hera19():
+    xy, labels = LAY.hexagon_generator(14.6, n_total=19)
+    assert xy.shape == (19, 2) and labels == [str(i) for i in range(19)]
+    assert NP.allclose(xy.mean(axis=0), 0.0, atol=1e-12)
+    d = NP.sqrt(((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1))
+    d[NP.diag_indices(19)] = NP.inf
+    assert NP.allclose(d.min(axis=1), 14.6)              # nearest neighbour = spacing
+    assert NP.isclose(d[NP.isfinite(d)].max(), 4 * 14.6)  # corner to corner of a side-3 hexagon
+    with pytest.raises(ValueError):
+        LAY.hexagon_generator(14.6, n_total=20)
+    with pytest.raises(ValueError):
+        LAY.hexagon_generator(14.6, n_total=19, n_side=3)
+    with pytest.raises(NameError):
+        LAY.hexagon_generator(14.6)
+    with pytest.raises(TypeError):
+        LAY.hexagon_generator('a', n_total=19)
+    xy2, _ = LAY.hexagon_generator(14.6, n_side=3)
+    assert NP.array_equal(xy, xy2)
+
+
+def test_baselines_fold_and_sort():
+    bl, ids = LAY.layout_baselines('HERA-19')
+    assert bl.shape == (171, 3) and ids.shape == (171, 2)
+    length = NP.sqrt((bl ** 2).sum(1))
+    assert NP.all(NP.diff(length) >= -1e-12)
+    ang = NP.degrees(NP.angle(bl[:, 0] + 1j * bl[:, 1]))
+    assert NP.all(ang >= -67.5 - 1e-9) and NP.all(ang <= 112.5 + 1e-9)
+    pos = LAY.array_layout('HERA-19')
+    assert NP.allclose(pos[ids[:, 0]] - pos[ids[:, 1]], bl)    # ids stay consistent with the fold
+    assert NP.isclose(length[0], 14.6)
+    assert LAY.layout_baselines('HERA-350')[0].shape == (61075, 3)
+    bla, _ = LAY.baseline_generator(pos, auto=True)
+    assert bla.shape[0] == 171 + 19
+    blc, _ = LAY.baseline_generator(pos, conjugate=True)
+    assert blc.shape[0] == 2 * 171
+
+
+def test_channel_grid_centre():
+    ch = W.channel_grid(150e6, 390625.0, 256)
+    assert ch[128] == 150e6 and NP.allclose(NP.diff(ch), 390625.0)
+
+
+def test_healpix_ring_pixel_centres():
+    th, ph = GEOM.healpix_pix2ang_ring(1)
+    assert NP.allclose(th[:4], NP.arccos(2 / 3.0)) and NP.allclose(ph[:4], NP.pi / 4 + NP.arange(4) * NP.pi / 2)
+    assert NP.allclose(th[4:8], NP.pi / 2) and NP.allclose(th[8:], NP.pi - NP.arccos(2 / 3.0))
+    for nside in (2, 8, 32):
+        th, ph = GEOM.healpix_pix2ang_ring(nside)
+        assert th.size == 12 * nside * nside
+        assert NP.all(NP.diff(th) >= -1e-15)                   # RING order: colatitude never decreases
+        v = NP.stack((NP.sin(th) * NP.cos(ph), NP.sin(th) * NP.sin(ph), NP.cos(th)), 1)
+        assert NP.abs(v.mean(0)).max() < 1e-12                 # equal-area pixels: centroid at the origin
+        assert NP.allclose(th + th[::-1], NP.pi)               # north/south mirror symmetry
+        assert NP.isclose(NP.cos(th[0]), 1 - 1.0 / (3 * nside ** 2))
+    assert NP.isclose(GEOM.nside2resol(16), NP.sqrt(4 * NP.pi / 3072))
+    with pytest.raises(ValueError):
+        GEOM.healpix_pix2ang_ring(4, ipix=[192])
+
+
+def test_geometry_conventions():
+    assert NP.allclose(GEOM.altaz2dircos([0.0, 90.0]), [[1, 0, 0]], atol=1e-15)      # East
+    assert NP.allclose(GEOM.altaz2dircos([0.0, 0.0]), [[0, 1, 0]], atol=1e-15)       # North
+    assert NP.allclose(GEOM.altaz2dircos([90.0, 270.0]), [[0, 0, 1]], atol=1e-15)    # zenith
+    aa = NP.array([[10.0, 20.0], [80.0, 200.0], [45.0, 359.0]])
+    assert NP.allclose(GEOM.dircos2altaz(GEOM.altaz2dircos(aa)), aa)
+    # a source on the meridian (HA=0) at Dec = latitude is at the zenith
+    assert NP.isclose(GEOM.hadec2altaz([0.0, -30.72], -30.72)[0], 90.0)
+    hd = NP.array([[10.0, -30.0], [-60.0, 20.0]])
+    assert NP.allclose(GEOM.altaz2hadec(GEOM.hadec2altaz(hd, -30.7), -30.7), hd)
+    with pytest.raises(ValueError):
+        GEOM.altaz2dircos([1.0, 2.0, 3.0])
+
+
+def test_geometric_delay_api():
+    bl = NP.array([[100.0, 0.0, 0.0], [0.0, 50.0, 0.0]])
+    tau = DLY.geometric_delay(bl, NP.array([[0.0, 90.0]]), altaz=True, hadec=False)
+    assert tau.shape == (1, 2) and NP.isclose(tau[0, 0], 100.0 / 299792458.0) and abs(tau[0, 1]) < 1e-20
+    with pytest.raises(ValueError):
+        DLY.geometric_delay(bl, NP.zeros((1, 2)), altaz=True, hadec=True)
+    with pytest.raises(ValueError):
+        DLY.geometric_delay(bl, NP.zeros((1, 2)))            # hadec without latitude
+    with pytest.raises(TypeError):
+        DLY.geometric_delay([[1, 2, 3]], NP.zeros((1, 3)), dircos=True, hadec=False)
+
+
+def test_workload_shapes():
+    c1, c2 = W.config1(), W.config2()
+    assert c1['baselines'].shape == (3, 3) and c1['channels'].size == 64 and c1['sky']['dircos'].shape == (100, 3)
+    assert c2['baselines'].shape == (171, 3) and c2['channels'].size == 256
+    n2 = c2['sky']['dircos'].shape[0]
+    assert n2 == 1504 and NP.all(c2['sky']['dircos'][:, 2] > 0)
+    assert NP.allclose(c2['sky']['fwhm_deg'], NP.degrees(NP.sqrt(4 * NP.pi / 3072)))
+    assert NP.allclose(NP.linalg.norm(c1['sky']['dircos'], axis=1), 1.0)
+    sub = W.subsample(c2, bl_stride=10, ch_count=16, src_stride=7)
+    assert sub['baselines'].shape[0] == 18 and sub['channels'].size == 16 and sub['sky']['flux_ref'].size == 215
+
+
+@pytest.mark.parametrize('nbl,world', [(61075, 1), (61075, 2), (61075, 8), (171, 4), (3, 8)])
+def test_baseline_sharding_covers_everything_once(nbl, world):
+    bl = NP.arange(nbl * 3, dtype=float).reshape(nbl, 3)
+    seen = []
+    per0 = None
+    for rank in range(world):
+        per, lo, hi = bench.shard_range(nbl, world, rank)
+        per0 = per if per0 is None else per0
+        assert per == per0
+        mine, n_real = bench.shard_baselines(bl, world, rank)
+        assert mine.shape == (per, 3) and n_real == hi - lo
+        seen.append(mine[:n_real])
+    assert NP.array_equal(NP.vstack(seen), bl)
+
+
+def test_skymodel_spectra():
+    loc = NP.array([[10.0, 20.0], [30.0, 40.0], [50.0, 60.0]])
+    sm = SM.SkyModel(location=loc, flux_ref=[1.0, 2.0, 3.0], spindex=-0.8, ref_freq=150e6)
+    f = NP.array([100e6, 150e6, 200e6])
+    sp = sm.generate_spectrum(ind=[2, 0], frequency=f, interp_method='pchip')
+    assert sp.shape == (2, 3) and NP.allclose(sp[:, 1], [3.0, 1.0]) and NP.isclose(sp[0, 0], 3.0 * (100 / 150.0) ** -0.8)
+    tab = SM.SkyModel(location=loc, frequency=f, spectrum=NP.arange(9.0).reshape(3, 3))
+    assert NP.allclose(tab.generate_spectrum(ind=[1], frequency=f), [[3.0, 4.0, 5.0]])
+    assert NP.allclose(tab.generate_spectrum(ind=[1], frequency=[125e6]), [[3.5]])
+    sub = sm.subset([1])
+    assert sub.location.shape == (1, 2) and sub.flux_ref[0] == 2.0
+
+
+def test_device_beam_spec_dispatch():
+    k, d, p = PB.device_beam_spec({'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'})
+    assert k == _abi.PRISIM_BEAM_AIRY and d == 14.0 and NP.allclose(p, [0, 0, 1], atol=1e-12)
+    assert PB.device_beam_spec({'id': 'hirax'})[1] == 6.0
+    assert PB.device_beam_spec({'shape': 'gaussian', 'size': 5.0})[:2] == (_abi.PRISIM_BEAM_GAUSSIAN, 5.0)
+    assert PB.device_beam_spec({'shape': 'dish', 'size': 25.0})[0] == _abi.PRISIM_BEAM_AIRY
+    assert PB.device_beam_spec({})[0] == _abi.PRISIM_BEAM_DELTA
+    k, d, p = PB.device_beam_spec({'shape': 'dish', 'size': 14.0}, pointing_center=[0.0, 90.0])
+    assert NP.allclose(p, [1, 0, 0], atol=1e-12)
+    with pytest.raises(TypeError):
+        PB.device_beam_spec(None)
+    with pytest.raises(ValueError):
+        PB.device_beam_spec({'shape': 'banana'})
+    with pytest.raises(NotImplementedError):
+        PB.device_beam_spec({'id': 'mwa'})
+
+
+def test_error_code_mapping():
+    with pytest.raises(ValueError):
+        _abi._raise(_abi.PRISIM_EINVAL, 'x')
+    with pytest.raises(MemoryError):
+        _abi._raise(_abi.PRISIM_ENOMEM, 'x')
+    with pytest.raises(RuntimeError):
+        _abi._raise(_abi.PRISIM_ESTATE, 'x')
+    with pytest.raises(_abi.PrisimHipError):
+        _abi._raise(_abi.PRISIM_ENODEV, 'x')

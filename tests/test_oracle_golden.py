@@ -1,0 +1,96 @@
+"""CPU: the oracle (numpy and C restatements) against the golden vectors produced by executing the
+reference's own statements (tests/golden/make_golden.py)."""
+import numpy as NP
+import pytest
+
+from oracle import skyvis_oracle as O, beams_oracle as BO, c_oracle as CO
+
+# the oracle restates the same numpy expressions: agreement is at rounding level
+TOL64 = 1e-14
+TOL32 = 2e-7
+
+
+def _fwhm(g):
+    return NP.sqrt(g['src_shape'][:, 0] * g['src_shape'][:, 1])      # interferometry.py:6267
+
+
+def _scale(g):
+    return O.abs_flux_sum(g['pbfluxes'])[None, :]
+
+
+def test_geometric_delay_matches_reference_function(golden_skyvis):
+    g = golden_skyvis
+    assert NP.array_equal(O.geometric_delay(g['baselines'], g['dircos']), g['geometric_delays'])
+    assert NP.array_equal(O.geometric_delay(g['baselines'], g['pc_dircos']), g['pc_delay_offsets'])
+
+
+def test_taper_weights_match_reference_statements(golden_skyvis):
+    g = golden_skyvis
+    w = O.taper_weights(g['baselines'], g['geometric_delays'], g['channels'], _fwhm(g))
+    assert NP.max(NP.abs(w - g['vis_wts'])) <= 1e-15
+    # zero-size sources (every 6th) give w == 1 exactly
+    assert NP.all(g['vis_wts'][::6] == 1.0)
+
+
+def test_fp64_sum(golden_skyvis):
+    g = golden_skyvis
+    v = O.skyvis(g['baselines'], g['channels'], g['dircos'], g['pbfluxes'], g['pc_dircos'])
+    assert v.dtype == NP.complex128
+    assert NP.max(NP.abs(v - g['skyvis_f64']) / _scale(g)) <= TOL64
+
+
+def test_fp64_sum_taper_and_gradient(golden_skyvis):
+    g = golden_skyvis
+    v, gr = O.skyvis(g['baselines'], g['channels'], g['dircos'], g['pbfluxes'], g['pc_dircos'], fwhm_deg=_fwhm(g), gradient=True)
+    assert NP.max(NP.abs(v - g['skyvis_f64_taper']) / _scale(g)) <= TOL64
+    assert NP.max(NP.abs(gr - g['grad_f64_taper']) / _scale(g)[None]) <= TOL64
+    v, gr = O.skyvis(g['baselines'], g['channels'], g['dircos'], g['pbfluxes'], g['pc_dircos'], gradient=True)
+    assert NP.max(NP.abs(gr - g['grad_f64']) / _scale(g)[None]) <= TOL64
+
+
+def test_fp32_memsave_sum(golden_skyvis):
+    g = golden_skyvis
+    v, gr = O.skyvis(g['baselines'], g['channels'], g['dircos'], g['pbfluxes'], g['pc_dircos'], gradient=True, memsave=True)
+    assert v.dtype == NP.complex64
+    assert NP.max(NP.abs(v - g['skyvis_f32']) / _scale(g)) <= TOL32
+    assert NP.max(NP.abs(gr - g['grad_f32']) / _scale(g)[None]) <= TOL32
+    v = O.skyvis(g['baselines'], g['channels'], g['dircos'], g['pbfluxes'], g['pc_dircos'], fwhm_deg=_fwhm(g), memsave=True)
+    assert NP.max(NP.abs(v - g['skyvis_f32_taper']) / _scale(g)) <= TOL32
+
+
+@pytest.mark.parametrize('slab_bytes', [1, 4096, 10 ** 6])
+def test_slab_invariance(golden_skyvis, slab_bytes):
+    """Serialising over source slabs (interferometry.py:6348-6376) does not change the sum beyond rounding."""
+    g = golden_skyvis
+    v = O.skyvis(g['baselines'], g['channels'], g['dircos'], g['pbfluxes'], g['pc_dircos'], fwhm_deg=_fwhm(g),
+                 slab_bytes=slab_bytes)
+    assert NP.max(NP.abs(v - g['skyvis_f64_taper']) / _scale(g)) <= 1e-13
+
+
+def test_c_oracle(golden_skyvis):
+    g = golden_skyvis
+    v = CO.skyvis(g['baselines'], g['channels'], g['dircos'], g['pbfluxes'], g['pc_dircos'])
+    assert NP.max(NP.abs(v - g['skyvis_f64']) / _scale(g)) <= 1e-12
+    v = CO.skyvis(g['baselines'], g['channels'], g['dircos'], g['pbfluxes'], g['pc_dircos'], fwhm_deg=_fwhm(g), nthreads=2)
+    assert NP.max(NP.abs(v - g['skyvis_f64_taper']) / _scale(g)) <= 1e-12
+
+
+def test_empty_sky_is_zero(golden_skyvis):
+    g = golden_skyvis
+    v = O.skyvis(g['baselines'], g['channels'], NP.zeros((0, 3)), NP.zeros((0, g['channels'].size)), g['pc_dircos'])
+    assert v.shape == (g['baselines'].shape[0], g['channels'].size) and NP.all(v == 0)
+
+
+def test_beams_match_reference_functions(golden_beams):
+    g = golden_beams
+    sp, f = g['skypos_altaz'], g['freq_hz']
+    with NP.errstate(all='ignore'):
+        assert NP.max(NP.abs(BO.airy_disk_pattern(14.0, sp, f) - g['airy_power_d14'])) <= 1e-15
+        assert NP.max(NP.abs(BO.gaussian_beam(14.0, sp, f) - g['gauss_power_d14'])) <= 1e-15
+        assert NP.max(NP.abs(BO.primary_beam_generator(sp, f, {'shape': 'gaussian', 'size': 14.0}) - g['pbg_gaussian_d14'])) <= 1e-15
+        assert NP.max(NP.abs(BO.primary_beam_generator(sp, f, {'shape': 'dish', 'size': 14.0}) - g['pbg_dish_d14'])) <= 1e-14
+        assert NP.array_equal(BO.primary_beam_generator(sp, f, {'shape': 'delta'}), g['pbg_delta'])
+        # explicit zenith pointing centre == pointing_center None
+        assert NP.max(NP.abs(BO.airy_disk_pattern(14.0, sp, f, pointing_altaz=[90.0, 270.0]) - g['airy_power_d14'])) <= 1e-12
+    # rows 2 and 3 of the fixture are on / below the horizon: blanked
+    assert NP.all(g['airy_power_d14'][2:4] == 0) and NP.all(g['gauss_power_d14'][2:4] == 0)
