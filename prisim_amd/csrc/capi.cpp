@@ -110,7 +110,7 @@ struct prisim_ctx {
   // array
   bool array_set = false;
   int64_t nbl = 0, nchan = 0, nt_max = 0;
-  DevBuf blx, bly, blz, freqs, fsq, cube, grad;
+  DevBuf blx, bly, blz, freqs, fsq, fsq_pairs, cube, grad;
   std::vector<double> h_freqs;
   bool uniform = false;
   double f0 = 0.0, df = 0.0;
@@ -204,6 +204,7 @@ struct Plan {
   int64_t nsrc_pad;
   int ntiles;
   int nbgroups;
+  bool pk;         // packed-fp32 kernel (k_skyvis_rec_f32pk) with interleaved pbflux pairs
 };
 
 Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
@@ -214,7 +215,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   const int64_t nbl = ctx->nbl, nchan = ctx->nchan, nsrc = ctx->nsrc;
   pl.nbgroups = (int)((nbl + kBlockThreads - 1) / kBlockThreads);
   // channel tile: largest tile that still yields enough blocks to fill 256 CUs x 4 blocks
-  const int max_ct = pl.f32 ? 32 : 16;
+  const int max_ct = pl.f32 ? 64 : 32;
   int ct = ctx->tune_ct;
   if (ct == 0) {
     ct = max_ct;
@@ -227,6 +228,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
     }
   }
   pl.ct = ct;
+  pl.pk = pl.f32 && (ct == 32 || ct == 64) && pl.kernel == PRISIM_KERNEL_RECURRENCE;
   pl.ntiles = (int)((nchan + ct - 1) / ct);
   // LDS chunk: <= 16 KiB of pbflux per chunk (4 x 16-byte pieces per thread)
   const int esz = pl.f32 ? 4 : 8;
@@ -243,8 +245,23 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   if (nsplit == 0) {
     const int64_t base = (int64_t)pl.ntiles * pl.nbgroups;
     nsplit = 1;
-    if (base < 1024) nsplit = (int)std::min<int64_t>((1024 + base - 1) / base, nchunks);
-    if (nsplit > 64) nsplit = 64;
+    if (base < 1024) {
+      nsplit = (int)std::min<int64_t>((1024 + base - 1) / base, nchunks);
+      if (nsplit > 64) nsplit = 64;
+    } else {
+      // Large problems: the grid runs in rounds of (CUs x resident blocks per CU) blocks; a partly
+      // filled last round idles the chip (3824 blocks on 512 slots = 7.47 rounds -> 6.6 % lost).
+      // Splitting the sources 2-4 ways multiplies the number of (shorter) blocks, which shrinks the
+      // tail; the partial cubes are reduced afterwards (k_reduce_partials).
+      const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * (pl.pk ? 2 : (pl.f32 ? 4 : 2));
+      double best_eff = 0.0;
+      for (int cand = 1; cand <= 4; ++cand) {
+        if (cand > nchunks) break;
+        const double rounds = (double)(base * cand) / (double)slots;
+        const double eff = rounds / std::ceil(rounds) - 0.004 * (cand - 1);   // small penalty: partial-cube traffic
+        if (eff > best_eff + 1e-9) { best_eff = eff; nsplit = cand; }
+      }
+    }
   }
   if (nsplit > nchunks) nsplit = (int)nchunks;
   if (nsplit < 1) nsplit = 1;
@@ -298,7 +315,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
   if (ctx->fft_plan && g_rocfft.plan_destroy) g_rocfft.plan_destroy(ctx->fft_plan);
   if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
-  for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->cube, &ctx->grad, &ctx->dirs,
+  for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->dirs_prep, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf,
                     &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts})
     release(*b);
@@ -499,13 +516,14 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   p.dirs_prep = (const double*)ctx->dirs_prep.p;
   p.pb_packed = ctx->packed.p;
   p.fsq = (const float*)ctx->fsq.p;
+  p.fsq_pairs = (const float*)ctx->fsq_pairs.p;
   p.fsq_scale = 1e16;
   p.nsrc = ctx->nsrc; p.nsrc_pad = pl.nsrc_pad;
   p.pc_x = ctx->pc[0]; p.pc_y = ctx->pc[1]; p.pc_z = ctx->pc[2];
   p.taper = ctx->taper ? 1 : 0;
   p.ntiles = pl.ntiles; p.nbgroups = pl.nbgroups; p.nsplit = pl.nsplit; p.src_per_split = pl.src_per_split;
   p.src_chunk = pl.chunk;
-  p.flush_src = 1024;
+  p.flush_src = 4096;
   p.scale_comp = scale_comp;
   if (pl.kernel == PRISIM_KERNEL_DIRECT) {
     p.out = dst;
@@ -516,10 +534,13 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     return PRISIM_OK;
   }
   HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
-                          pl.ntiles, (const double*)ctx->dirs.p, scale_comp, ctx->stream));
+                          pl.ntiles, (const double*)ctx->dirs.p, scale_comp, pl.pk ? 1 : 0, ctx->stream));
   p.out = pl.nsplit > 1 ? (double*)ctx->partial.p : dst;
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-  HIPCHK(ctx, launch_skyvis_rec(p, pl.f32, pl.ct, ctx->stream));
+  if (pl.pk)
+    HIPCHK(ctx, launch_skyvis_rec_f32pk(p, pl.ct, ctx->stream));
+  else
+    HIPCHK(ctx, launch_skyvis_rec(p, pl.f32, pl.ct, ctx->stream));
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   if (pl.nsplit > 1)
     HIPCHK(ctx, launch_reduce_partials((const double*)ctx->partial.p, dst, ctx->nbl * ctx->nchan * 2, pl.nsplit, ctx->stream));
@@ -559,6 +580,10 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;
     if ((rc = ensure(ctx, ctx->dirs_prep, (size_t)pl.nsrc_pad * 4 * sizeof(double)))) return rc;
     if (pl.nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)pl.nsplit * slot_elems * sizeof(double)))) return rc;
+    if (pl.pk && ctx->taper) {
+      if ((rc = ensure(ctx, ctx->fsq_pairs, (size_t)pl.ntiles * pl.ct * sizeof(float)))) return rc;
+      HIPCHK(ctx, launch_fsq_pairs((const float*)ctx->fsq.p, (float*)ctx->fsq_pairs.p, pl.ct, pl.ntiles, ctx->stream));
+    }
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE)

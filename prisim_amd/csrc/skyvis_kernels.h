@@ -23,6 +23,7 @@ struct SkyvisParams {
   const double* dirs_prep;   // [nsrc_pad][4]: (l-lpc)/c, (m-mpc)/c, (n-npc)/c, kappa; zero rows past nsrc
   const void* pb_packed;     // [ntiles][nsrc_pad][CT] of T, zero rows past nsrc
   const float* fsq;          // [npad] (f_k*1e-8)^2*log2(e) (fp32 taper)
+  const float* fsq_pairs;    // [ntiles][CT] the same, in the (up,down) pair order of k_skyvis_rec_f32pk
   double fsq_scale;          // 1e16
   int64_t nsrc;
   int64_t nsrc_pad;          // nsrc rounded up to a multiple of src_chunk
@@ -41,10 +42,12 @@ struct SkyvisParams {
 };
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);
+hipError_t launch_skyvis_rec_f32pk(const SkyvisParams& p, int ct, hipStream_t stream);
+hipError_t launch_fsq_pairs(const float* fsq, float* pairs, int ct, int ntiles, hipStream_t stream);
 hipError_t launch_skyvis_direct(const SkyvisParams& p, const double* freqs, const double* pb, const double* scale,
                                 hipStream_t stream);
 hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct,
-                       int ntiles, const double* dirs, int scale_comp, hipStream_t stream);
+                       int ntiles, const double* dirs, int scale_comp, int interleave, hipStream_t stream);
 hipError_t launch_prep_dirs(const double* dirs, double* prep, int64_t nsrc, int64_t nsrc_pad, double pcx, double pcy,
                             double pcz, double inv_c, hipStream_t stream);
 hipError_t launch_reduce_partials(const double* part, double* out, int64_t n2, int nsplit, hipStream_t stream);

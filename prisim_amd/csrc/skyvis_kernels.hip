@@ -31,21 +31,22 @@ __device__ __forceinline__ float fma_(float a, float b, float c) { return __buil
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // ------------------------------------------------------------------------------------------
-// sincos of an angle given in CYCLES, |x| <= 0.5 (double), result in T.
-// returns (cos 2 pi x, sin 2 pi x)
+// sincos of an angle given in QUARTER CYCLES (a4 = 4 * phase[cycles], any magnitude < 2^31):
+// returns (cos, sin) of 2 pi * phase.  The quadrant q = rint(a4) and the residual
+// y = (a4 - q)/4 in [-1/8, 1/8] cycle are formed in fp64 (exact), so no separate reduction modulo
+// one cycle is needed: q mod 4 selects the quadrant.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sincos_cycles(double x, float& c, float& s) {
-  // quadrant reduction in fp64 (exact), polynomial in fp32 on |y| <= 1/8 cycle
-  double q = __builtin_rint(4.0 * x);
-  float y = (float)__builtin_fma(-0.25, q, x);
-  int qi = (int)q;
-  float y2 = y * y;
+__device__ __forceinline__ void sincos_qcycles(double a4, float& c, float& s) {
+  const double q = __builtin_rint(a4);
+  const float y = (float)((a4 - q) * 0.25);
+  const int qi = (int)q;
+  const float y2 = y * y;
   // sin(2 pi y) = y * (2pi + y^2 * (-(2pi)^3/3! + y^2 * ((2pi)^5/5! + y^2 * (-(2pi)^7/7! + y^2 * (2pi)^9/9!))))
-  float ps = 42.058693944897655f;                          // (2pi)^9/9! = 42.0586939...
+  float ps = 42.058693944897655f;                          // (2pi)^9/9!
   ps = __builtin_fmaf(ps, y2, -76.70585975306136f);        // -(2pi)^7/7!
   ps = __builtin_fmaf(ps, y2, 81.60524927607504f);         // (2pi)^5/5!
   ps = __builtin_fmaf(ps, y2, -41.341702240399755f);       // -(2pi)^3/3!
-  float sy = __builtin_fmaf(y * y2, ps, y * 6.2831855f);   // 2pi rounded to f32: 6.28318548
+  float sy = __builtin_fmaf(y * y2, ps, y * 6.2831855f);   // fl32(2pi) = 6.28318548
   sy = __builtin_fmaf(y, -1.7484555e-7f, sy);              // + y * (2pi - fl32(2pi))
   // cos(2 pi y) = 1 + y^2 * (-(2pi)^2/2 + y^2 * ((2pi)^4/4! + y^2 * (-(2pi)^6/6! + y^2 * ((2pi)^8/8! - y^2 (2pi)^10/10!))))
   float pc = -26.42625678337438f;                          // -(2pi)^10/10!
@@ -53,20 +54,40 @@ __device__ __forceinline__ void sincos_cycles(double x, float& c, float& s) {
   pc = __builtin_fmaf(pc, y2, -85.45681720669373f);        // -(2pi)^6/6!
   pc = __builtin_fmaf(pc, y2, 64.93939402266829f);         // (2pi)^4/4!
   pc = __builtin_fmaf(pc, y2, -19.739208802178716f);       // -(2pi)^2/2
-  float cy = __builtin_fmaf(pc, y2, 1.0f);
+  const float cy = __builtin_fmaf(pc, y2, 1.0f);
   // rotate by q quarter turns: q=0:(c,s) 1:(-s,c) 2:(-c,-s) 3:(s,-c)
-  bool swap = (qi & 1) != 0;
-  float cc = swap ? sy : cy;
-  float ss = swap ? cy : sy;
-  bool negc = ((qi + 1) & 2) != 0;   // q mod 4 in {1,2}
-  bool negs = (qi & 2) != 0;         // q mod 4 in {2,3}
-  c = negc ? -cc : cc;
-  s = negs ? -ss : ss;
+  const bool swap = (qi & 1) != 0;
+  const float cc = swap ? sy : cy;
+  const float ss = swap ? cy : sy;
+  c = (((qi + 1) & 2) != 0) ? -cc : cc;    // q mod 4 in {1,2}
+  s = ((qi & 2) != 0) ? -ss : ss;          // q mod 4 in {2,3}
 }
 
-__device__ __forceinline__ void sincos_cycles(double x, double& c, double& s) {
-  // ocml sincospi: sin(pi*a), cos(pi*a)
-  sincospi(2.0 * x, &s, &c);
+__device__ __forceinline__ void sincos_qcycles(double a4, double& c, double& s) {
+  // fp64: residual angle t = 2 pi y, |t| <= pi/4; fdlibm __kernel_sin/__kernel_cos minimax coefficients
+  const double q = __builtin_rint(a4);
+  const double t = (a4 - q) * 1.5707963267948966192;       // (a4-q)/4 * 2pi
+  const int qi = (int)q;
+  const double z = t * t;
+  double ps = 1.58969099521155010221e-10;
+  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  const double sy = __builtin_fma(t * z, ps, t);
+  double pc = -1.13596475577881948265e-11;
+  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  const double cy = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+  const bool swap = (qi & 1) != 0;
+  const double cc = swap ? sy : cy;
+  const double ss = swap ? cy : sy;
+  c = (((qi + 1) & 2) != 0) ? -cc : cc;
+  s = ((qi & 2) != 0) ? -ss : ss;
 }
 
 template <typename T> struct Vec4;
@@ -122,6 +143,7 @@ void k_skyvis_rec(const SkyvisParams p) {
   const int k0 = tile * CT;
   const double fc = p.f0 + (double)(k0 + HC) * p.df;   // frequency of the seed (centre) channel
   const double df = p.df;
+  const double fc4 = 4.0 * fc, df4 = 4.0 * df;         // quarter-cycle scaling for sincos_qcycles
 
   // taper per-lane constants
   double bl2_c2 = 0.0, bpc = 0.0;
@@ -193,13 +215,9 @@ void k_skyvis_rec(const SkyvisParams p) {
       for (int s = 0; s < ns; ++s) {
         const double4 sv = ld[s];                                  // LDS broadcast
         const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));   // seconds
-        double phc = d * fc;                                       // cycles at the centre channel
-        double th = d * df;                                        // cycles per channel step
-        phc -= __builtin_rint(phc);
-        th -= __builtin_rint(th);
         T zc, zs, rc, rs;
-        sincos_cycles(phc, zc, zs);
-        sincos_cycles(th, rc, rs);
+        sincos_qcycles(d * fc4, zc, zs);                           // phase at the centre channel
+        sincos_qcycles(d * df4, rc, rs);                           // phase step per channel
         // exp(-2 pi i phi): z = (cos, -sin)
         T ur = zc, ui = -zs;            // up chain: channel HC + jj
         const T rr = rc, ri = -rs;      // step forward; step backward is conj(r)
@@ -305,6 +323,193 @@ void k_skyvis_rec(const SkyvisParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Packed-fp32 recurrence kernel (the headline fp32 path).
+//
+// Same mapping as k_skyvis_rec, but every inner-loop instruction is a packed v_pk_{mul,fma}_f32
+// on an (up-chain, down-chain) pair: lane register pair .x = channel HC+j, .y = channel HC-1-j.
+// A packed instruction occupies the SIMD for 4 cycles and does two lanes' worth of work, so the
+// fp32 peak is reached from one or two waves per SIMD (tools/microbench_valu.hip: v_pk_fma_f32
+// 97 TFLOP/s at 1 wave/SIMD, v_fma_f32 only 50) -- which is what lets a thread own CT = 64
+// channels (128 accumulator VGPRs) and halves the per-(source,baseline,tile) seed overhead.
+// pbflux rows are stored interleaved by k_pack (up_0, down_0, up_1, down_1, ...) so that one
+// ds_read_b128 broadcast delivers two ready-made operand pairs.
+// Per pair of terms: 2 pk_fma (accumulate) + 2 pk_mul + 2 pk_fma (rotate up by r, down by conj r).
+// ------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int CT, bool TAPER>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_skyvis_rec_f32pk(const SkyvisParams p) {
+  static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
+  constexpr int HC = CT / 2;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int S = p.src_chunk;
+  float* const lds_p = reinterpret_cast<float*>(smem_raw);                                   // [S][CT] interleaved pairs
+  double4* const lds_d = reinterpret_cast<double4*>(smem_raw + (size_t)S * CT * sizeof(float));   // [S]
+
+  const int xcd = blockIdx.x & 7;
+  const int jblk = blockIdx.x >> 3;
+  const int slab = xcd + 8 * (jblk / p.nbgroups);
+  const int bg = jblk % p.nbgroups;
+  if (slab >= p.ntiles * p.nsplit) return;
+  const int tile = slab % p.ntiles;
+  const int split = slab / p.ntiles;
+
+  const int64_t s_begin = (int64_t)split * p.src_per_split;
+  int64_t s_end = s_begin + p.src_per_split;
+  if (s_end > p.nsrc) s_end = p.nsrc;
+
+  const int tid = threadIdx.x;
+  const int64_t b_raw = (int64_t)bg * kBlockThreads + tid;
+  const bool b_valid = b_raw < p.nbl;
+  const int64_t b = b_valid ? b_raw : (p.nbl - 1);
+  const bool wave_active = ((int64_t)bg * kBlockThreads + (tid & ~63)) < p.nbl;
+
+  const double bx = p.bl_x[b], by = p.bl_y[b], bz = p.bl_z[b];
+  const int k0 = tile * CT;
+  const double fc4 = 4.0 * (p.f0 + (double)(k0 + HC) * p.df);
+  const double df4 = 4.0 * p.df;
+
+  double bl2_c2 = 0.0, bpc = 0.0;
+  if (TAPER) {
+    bl2_c2 = (bx * bx + by * by + bz * bz) * (p.inv_c * p.inv_c);
+    bpc = (bx * p.pc_x + by * p.pc_y + bz * p.pc_z) * p.inv_c;
+  }
+
+  f32x2 acc_re[HC], acc_im[HC];
+#pragma unroll
+  for (int j = 0; j < HC; ++j) { acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f); }
+
+  const float* const gp = reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT;
+  const double4* const gd = reinterpret_cast<const double4*>(p.dirs_prep);
+  const int npieces = S * CT / 4;
+  constexpr int kMaxPiecesPerThread = 4;
+
+  double2* const orow = reinterpret_cast<double2*>(p.out) + ((size_t)split * p.nbl + (size_t)b) * p.nchan + k0;
+  bool first_flush = true;
+  int since_flush = 0;
+
+  const int64_t nsrc_local = s_end - s_begin;
+  const int nchunks = (int)((nsrc_local + S - 1) / S);
+
+  for (int ci = 0; ci < nchunks; ++ci) {
+    const int64_t s0 = s_begin + (int64_t)ci * S;
+    const bool more = (ci + 1) < nchunks;
+    __syncthreads();
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(gp + (size_t)s0 * CT);
+#pragma unroll
+      for (int u = 0; u < kMaxPiecesPerThread; ++u) {
+        const int i = tid + u * kBlockThreads;
+        if (i < npieces) reinterpret_cast<uint4*>(lds_p)[i] = src[i];
+      }
+      if (tid < S) lds_d[tid] = gd[s0 + tid];
+      if (tid == S) lds_d[S] = make_double4(0, 0, 0, 0);      // read one past the chunk by the pipeline
+    }
+    __syncthreads();
+
+    const int ns = (int)((s_end - s0) < S ? (s_end - s0) : S);
+    if (wave_active) {
+      // Software pipeline over sources.  LDS broadcast reads have ~100+ cycles of latency and only two
+      // waves share a SIMD, so every operand is requested one phase before it is used:
+      //   phase A (seed arithmetic of source s)   covers the first half row of pbflux pairs of s
+      //   phase B (first 16 pairs)                covers the second half row of s and the direction of s+1
+      double4 sv = lds_d[0];
+      for (int s = 0; s < ns; ++s) {
+        constexpr int NQ = CT / 8;                       // float4 per half row
+        const float4* prow4 = reinterpret_cast<const float4*>(lds_p + (size_t)s * CT);
+        float4 pa[NQ], pb[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) pa[i] = prow4[i];
+        __builtin_amdgcn_sched_barrier(0);
+
+        const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));
+        float zc, zs, rc, rs;
+        sincos_qcycles(d * fc4, zc, zs);
+        sincos_qcycles(d * df4, rc, rs);
+        const float ur0 = zc, ui0 = -zs, rr = rc, ri = -rs;     // z = exp(-2 pi i phi), r likewise
+        const float dr0 = __builtin_fmaf(ur0, rr, ui0 * ri);    // down chain starts at z * conj(r)
+        const float di0 = __builtin_fmaf(ui0, rr, -(ur0 * ri));
+        f32x2 zre = {ur0, dr0};
+        f32x2 zim = {ui0, di0};
+        const f32x2 RR = {rr, rr};
+        const f32x2 RI = {-ri, ri};        // re' = re*rr + im*RI ;  im' = im*rr - re*RI
+        float g2 = 0.f;
+        if (TAPER) {
+          const double tau = d + bpc;
+          double gq = sv.w * (bl2_c2 - tau * tau);
+          gq = gq > 0.0 ? gq : 0.0;
+          g2 = -(float)(gq * p.fsq_scale);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) pb[i] = prow4[NQ + i];
+        sv = lds_d[s + 1];                               // lds_d has S+1 entries
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int j = 0; j < HC; j += 2) {
+          const float4 pv = (j < HC / 2) ? pa[j / 2] : pb[j / 2 - NQ];   // (up_j, down_j, up_j+1, down_j+1)
+          f32x2 p0 = {pv.x, pv.y};
+          f32x2 p1 = {pv.z, pv.w};
+          if (TAPER) {
+            // w = exp2(-g f^2 log2 e): direct v_exp_f32 per term, fsq pairs interleaved like pbflux
+            const float4 fq = *reinterpret_cast<const float4*>(p.fsq_pairs + (size_t)tile * CT + 2 * j);
+            p0.x *= __builtin_amdgcn_exp2f(g2 * fq.x);
+            p0.y *= __builtin_amdgcn_exp2f(g2 * fq.y);
+            p1.x *= __builtin_amdgcn_exp2f(g2 * fq.z);
+            p1.y *= __builtin_amdgcn_exp2f(g2 * fq.w);
+          }
+          acc_re[j] = pkfma(p0, zre, acc_re[j]);
+          acc_im[j] = pkfma(p0, zim, acc_im[j]);
+          f32x2 t0 = zim * RI;
+          f32x2 t1 = zre * RI;
+          f32x2 nre = pkfma(zre, RR, t0);
+          f32x2 nim = pkfma(zim, RR, -t1);
+          acc_re[j + 1] = pkfma(p1, nre, acc_re[j + 1]);
+          acc_im[j + 1] = pkfma(p1, nim, acc_im[j + 1]);
+          t0 = nim * RI;
+          t1 = nre * RI;
+          zre = pkfma(nre, RR, t0);
+          zim = pkfma(nim, RR, -t1);
+        }
+      }
+    }
+    since_flush += ns;
+    if ((since_flush >= p.flush_src && more) || !more) {
+      // accumulate the fp32 partial sums into the fp64 cube (read-modify-write after the first flush)
+      if (b_valid) {
+#pragma unroll
+        for (int j = 0; j < HC; ++j) {
+          const int ku = HC + j, kd = HC - 1 - j;
+          if (k0 + ku < p.nchan) {
+            double2 v = make_double2((double)acc_re[j].x, (double)acc_im[j].x);
+            if (!first_flush) { const double2 o = orow[ku]; v.x += o.x; v.y += o.y; }
+            orow[ku] = v;
+          }
+          if (k0 + kd < p.nchan) {
+            double2 v = make_double2((double)acc_re[j].y, (double)acc_im[j].y);
+            if (!first_flush) { const double2 o = orow[kd]; v.x += o.x; v.y += o.y; }
+            orow[kd] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < HC; ++j) { acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f); }
+      first_flush = false;
+      since_flush = 0;
+    }
+  }
+  if (nchunks == 0 && b_valid) {
+    for (int k = 0; k < CT; ++k)
+      if (k0 + k < p.nchan) orow[k] = make_double2(0.0, 0.0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Direct kernel: one (baseline, channel) output per thread, one sincospi per term, fp64 only.
 // Works for any channel grid (no uniform-spacing assumption).  Slow; used as the on-device
 // cross-check and as the fallback for non-uniform channel arrays.
@@ -382,12 +587,16 @@ void k_skyvis_direct(const SkyvisParams p, const double* __restrict__ freqs,
 // (gradient passes multiply the rows by a direction-cosine component, interferometry.py:6338).
 // Channels beyond nchan in the last tile are zero-filled.
 // ------------------------------------------------------------------------------------------
+// interleave != 0: element 2j of a row holds channel HC+j, element 2j+1 channel HC-1-j (HC = ct/2),
+// the (up, down) operand pairs of k_skyvis_rec_f32pk.
 template <typename T>
 __global__ void k_pack(const double* __restrict__ pb, T* __restrict__ packed, int64_t nsrc, int64_t nsrc_pad,
-                       int64_t nchan, int ct, int ntiles, const double* __restrict__ dirs, int scale_comp) {
+                       int64_t nchan, int ct, int ntiles, const double* __restrict__ dirs, int scale_comp,
+                       int interleave) {
   const int64_t total = (int64_t)ntiles * nsrc_pad * ct;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % ct);
+    int c = (int)(i % ct);
+    if (interleave) c = (c & 1) ? (ct / 2 - 1 - (c >> 1)) : (ct / 2 + (c >> 1));
     const int64_t s = (i / ct) % nsrc_pad;
     const int tile = (int)(i / ((int64_t)ct * nsrc_pad));
     const int64_t k = (int64_t)tile * ct + c;
@@ -452,6 +661,27 @@ static hipError_t launch_rec_ct(const SkyvisParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
+template <int CT>
+static hipError_t launch_rec_pk_ct(const SkyvisParams& p, hipStream_t stream) {
+  const int nslabs = p.ntiles * p.nsplit;
+  const int slabs_per_xcd = (nslabs + 7) / 8;
+  const unsigned grid = 8u * (unsigned)slabs_per_xcd * (unsigned)p.nbgroups;
+  const size_t lds = (size_t)p.src_chunk * CT * sizeof(float) + (size_t)(p.src_chunk + 1) * sizeof(double4);
+  if (p.taper)
+    hipLaunchKernelGGL((k_skyvis_rec_f32pk<CT, true>), dim3(grid), dim3(kBlockThreads), lds, stream, p);
+  else
+    hipLaunchKernelGGL((k_skyvis_rec_f32pk<CT, false>), dim3(grid), dim3(kBlockThreads), lds, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_skyvis_rec_f32pk(const SkyvisParams& p, int ct, hipStream_t stream) {
+  switch (ct) {
+    case 32: return launch_rec_pk_ct<32>(p, stream);
+    case 64: return launch_rec_pk_ct<64>(p, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream) {
   if (f32) {
     switch (ct) {
@@ -488,15 +718,15 @@ static unsigned grid_for(int64_t n) {
 }
 
 hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct,
-                       int ntiles, const double* dirs, int scale_comp, hipStream_t stream) {
+                       int ntiles, const double* dirs, int scale_comp, int interleave, hipStream_t stream) {
   const int64_t total = (int64_t)ntiles * nsrc_pad * ct;
   if (total == 0) return hipSuccess;
   if (f32)
     hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(total)), dim3(256), 0, stream, pb, (float*)packed, nsrc, nsrc_pad,
-                       nchan, ct, ntiles, dirs, scale_comp);
+                       nchan, ct, ntiles, dirs, scale_comp, interleave);
   else
     hipLaunchKernelGGL(k_pack<double>, dim3(grid_for(total)), dim3(256), 0, stream, pb, (double*)packed, nsrc, nsrc_pad,
-                       nchan, ct, ntiles, dirs, scale_comp);
+                       nchan, ct, ntiles, dirs, scale_comp, interleave);
   return hipGetLastError();
 }
 
@@ -508,6 +738,21 @@ hipError_t launch_reduce_partials(const double* part, double* out, int64_t n2, i
 hipError_t launch_f32_to_f64(const float* in, double* out, int64_t n, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_f32_to_f64, dim3(grid_for(n)), dim3(256), 0, stream, in, out, n);
+  return hipGetLastError();
+}
+
+// fsq_pairs[tile][2j], [2j+1] = fsq of channels tile*ct+HC+j, tile*ct+HC-1-j (operand order of the packed kernel)
+__global__ void k_fsq_pairs(const float* __restrict__ fsq, float* __restrict__ pairs, int ct, int ntiles) {
+  const int total = ct * ntiles;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int tile = i / ct, c = i % ct;
+    const int k = (c & 1) ? (ct / 2 - 1 - (c >> 1)) : (ct / 2 + (c >> 1));
+    pairs[i] = fsq[tile * ct + k];
+  }
+}
+
+hipError_t launch_fsq_pairs(const float* fsq, float* pairs, int ct, int ntiles, hipStream_t stream) {
+  hipLaunchKernelGGL(k_fsq_pairs, dim3(grid_for((int64_t)ct * ntiles)), dim3(256), 0, stream, fsq, pairs, ct, ntiles);
   return hipGetLastError();
 }
 
