@@ -534,7 +534,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     return PRISIM_OK;
   }
   HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
-                          pl.ntiles, (const double*)ctx->dirs.p, scale_comp, pl.pk ? 1 : 0, ctx->stream));
+                          pl.ntiles, (const double*)ctx->dirs.p, scale_comp, 1, ctx->stream));
   p.out = pl.nsplit > 1 ? (double*)ctx->partial.p : dst;
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   if (pl.pk)
@@ -580,7 +580,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;
     if ((rc = ensure(ctx, ctx->dirs_prep, (size_t)pl.nsrc_pad * 4 * sizeof(double)))) return rc;
     if (pl.nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)pl.nsplit * slot_elems * sizeof(double)))) return rc;
-    if (pl.pk && ctx->taper) {
+    if (pl.f32 && ctx->taper) {
       if ((rc = ensure(ctx, ctx->fsq_pairs, (size_t)pl.ntiles * pl.ct * sizeof(float)))) return rc;
       HIPCHK(ctx, launch_fsq_pairs((const float*)ctx->fsq.p, (float*)ctx->fsq_pairs.p, pl.ct, pl.ntiles, ctx->stream));
     }

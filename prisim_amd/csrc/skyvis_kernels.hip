@@ -90,9 +90,11 @@ __device__ __forceinline__ void sincos_qcycles(double a4, double& c, double& s) 
   s = ((qi & 2) != 0) ? -ss : ss;
 }
 
-template <typename T> struct Vec4;
-template <> struct Vec4<float> { using type = float4; };
-template <> struct Vec4<double> { using type = double4; };
+template <typename T> struct Vec16;               // 16-byte LDS/global access unit
+template <> struct Vec16<float> { using type = float4; };
+template <> struct Vec16<double> { using type = double2; };
+__device__ __forceinline__ void unpack16(const float4 v, float* d) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+__device__ __forceinline__ void unpack16(const double2 v, double* d) { d[0] = v.x; d[1] = v.y; }
 
 // ------------------------------------------------------------------------------------------
 // Recurrence kernel
@@ -174,6 +176,7 @@ void k_skyvis_rec(const SkyvisParams p) {
       if (i < npieces) reinterpret_cast<uint4*>(lp)[i] = src[i];
     }
     if (tid < S) lds_d[tid] = gd[s0 + tid];
+    if (tid == (S < kBlockThreads ? S : 0)) lds_d[S] = make_double4(0, 0, 0, 0);   // read one past the chunk by the pipeline
   };
 
   double* const out = p.out + ((size_t)split * p.nbl * p.nchan) * 2;   // partial buffer of this split
@@ -210,109 +213,88 @@ void k_skyvis_rec(const SkyvisParams p) {
 
     int ns = (int)((s_end - s0) < S ? (s_end - s0) : S);
     if (wave_active) {
-      const T* lp = lds_p;
-      const double4* ld = lds_d;
+      // Software pipeline over sources (LDS broadcast reads are requested one phase before use):
+      //   seed arithmetic of source s   covers the first half row of (up,down) pbflux pairs of s
+      //   first half of the pairs       covers the second half row of s and the direction of s+1
+      constexpr int NH = CT / 2;                     // elements per half row
+      constexpr int VE16 = 16 / (int)sizeof(T);
+      using V16 = typename Vec16<T>::type;
+      double4 sv = lds_d[0];
       for (int s = 0; s < ns; ++s) {
-        const double4 sv = ld[s];                                  // LDS broadcast
+        const T* prow = lds_p + (size_t)s * CT;      // [2j] = channel HC+j (up), [2j+1] = channel HC-1-j (down)
+        T pa[NH], pb[NH];
+#pragma unroll
+        for (int i = 0; i < NH / VE16; ++i) {
+          const V16 v = reinterpret_cast<const V16*>(prow)[i];
+          unpack16(v, &pa[i * VE16]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
         const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));   // seconds
         T zc, zs, rc, rs;
         sincos_qcycles(d * fc4, zc, zs);                           // phase at the centre channel
         sincos_qcycles(d * df4, rc, rs);                           // phase step per channel
         // exp(-2 pi i phi): z = (cos, -sin)
-        T ur = zc, ui = -zs;            // up chain: channel HC + jj
+        T ur = zc, ui = -zs;            // up chain: channel HC + j
         const T rr = rc, ri = -rs;      // step forward; step backward is conj(r)
         T dr = fma_(ur, rr, ui * ri);        // z * conj(r): channel HC-1
         T di = fma_(ui, rr, -(ur * ri));
-        const T* prow = lp + (size_t)s * CT;
-
-        if constexpr (!TAPER) {
-#pragma unroll
-          for (int jj = 0; jj < HC; jj += 4) {
-            // 4 channels up [HC+jj .. HC+jj+3], 4 channels down [HC-1-jj .. HC-4-jj]
-            const typename Vec4<T>::type pu = *reinterpret_cast<const typename Vec4<T>::type*>(prow + HC + jj);
-            const typename Vec4<T>::type pd = *reinterpret_cast<const typename Vec4<T>::type*>(prow + HC - 4 - jj);
-            const T pus[4] = {pu.x, pu.y, pu.z, pu.w};
-            const T pds[4] = {pd.w, pd.z, pd.y, pd.x};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int ku = HC + jj + e, kd = HC - 1 - jj - e;
-              acc_re[ku] = fma_(pus[e], ur, acc_re[ku]);
-              acc_im[ku] = fma_(pus[e], ui, acc_im[ku]);
-              acc_re[kd] = fma_(pds[e], dr, acc_re[kd]);
-              acc_im[kd] = fma_(pds[e], di, acc_im[kd]);
-              const T nur = fma_(ur, rr, -(ui * ri));
-              const T nui = fma_(ur, ri, ui * rr);
-              const T ndr = fma_(dr, rr, di * ri);
-              const T ndi = fma_(di, rr, -(dr * ri));
-              ur = nur; ui = nui; dr = ndr; di = ndi;
-            }
-          }
-        } else {
-          // source-shape taper  w = exp(-g f^2),  g = kappa_s * (|b|^2/c^2 - tau^2),  tau = d + b.s_pc/c
+        // source-shape taper  w = exp(-g f^2),  g = kappa_s * (|b|^2/c^2 - tau^2),  tau = d + b.s_pc/c
+        double gq = 0.0;
+        float g2 = 0.f;
+        double wu = 1.0, wd = 1.0, qu = 1.0, qd = 1.0, h = 1.0;
+        if constexpr (TAPER) {
           const double tau = d + bpc;
-          double gq = sv.w * (bl2_c2 - tau * tau);
+          gq = sv.w * (bl2_c2 - tau * tau);
           gq = gq > 0.0 ? gq : 0.0;      // |b|^2 >= (b.s)^2 up to rounding
           if constexpr (sizeof(T) == 4) {
-            // fp32: direct exp2 per term (no error accumulation); f_k^2 * log2(e) staged per tile in p.fsq
-            const float g2 = (float)(gq * p.fsq_scale);
-#pragma unroll
-            for (int jj = 0; jj < HC; jj += 4) {
-              const float4 pu = *reinterpret_cast<const float4*>(prow + HC + jj);
-              const float4 pd = *reinterpret_cast<const float4*>(prow + HC - 4 - jj);
-              const float pus[4] = {pu.x, pu.y, pu.z, pu.w};
-              const float pds[4] = {pd.w, pd.z, pd.y, pd.x};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int ku = HC + jj + e, kd = HC - 1 - jj - e;
-                const float wu = __builtin_amdgcn_exp2f(-g2 * p.fsq[k0 + ku]);
-                const float wd = __builtin_amdgcn_exp2f(-g2 * p.fsq[k0 + kd]);
-                const float au = pus[e] * wu, ad = pds[e] * wd;
-                acc_re[ku] = __builtin_fmaf(au, ur, acc_re[ku]);
-                acc_im[ku] = __builtin_fmaf(au, ui, acc_im[ku]);
-                acc_re[kd] = __builtin_fmaf(ad, dr, acc_re[kd]);
-                acc_im[kd] = __builtin_fmaf(ad, di, acc_im[kd]);
-                const float nur = __builtin_fmaf(ur, rr, -(ui * ri));
-                const float nui = __builtin_fmaf(ur, ri, ui * rr);
-                const float ndr = __builtin_fmaf(dr, rr, di * ri);
-                const float ndi = __builtin_fmaf(di, rr, -(dr * ri));
-                ur = nur; ui = nui; dr = ndr; di = ndi;
-              }
-            }
+            g2 = -(float)(gq * p.fsq_scale);   // fp32: direct exp2 per term (no error accumulation)
           } else {
             // fp64: second-order multiplicative recurrence of the Gaussian in frequency:
-            //   w_{k+1} = w_k q_k,  q_{k+1} = q_k h,   h = exp(-2 g df^2)
-            //   w_{k-1} = w_k q'_k, q'_{k-1} = q'_k h
+            //   w_{k+1} = w_k q_k,  q_{k+1} = q_k h,   h = exp(-2 g df^2);   w_{k-1} = w_k q'_k, q'_{k-1} = q'_k h
             const double e1 = exp(-2.0 * gq * fc * df);
             const double e2 = exp(-gq * df * df);
-            const double h = e2 * e2;
-            double wu = exp(-gq * fc * fc);           // channel HC
-            double qu = e1 * e2;                      // w_{HC+1}/w_{HC}
-            double qd = e2 / e1;                      // w_{HC-1}/w_{HC}
-            double wd = wu * qd;                      // channel HC-1
+            h = e2 * e2;
+            wu = exp(-gq * fc * fc);                  // channel HC
+            qu = e1 * e2;                             // w_{HC+1}/w_{HC}
+            qd = e2 / e1;                             // w_{HC-1}/w_{HC}
+            wd = wu * qd;                             // channel HC-1
             qd *= h;                                  // w_{HC-2}/w_{HC-1}
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int jj = 0; jj < HC; jj += 2) {
-              const double2 pu = *reinterpret_cast<const double2*>(prow + HC + jj);
-              const double2 pd = *reinterpret_cast<const double2*>(prow + HC - 2 - jj);
-              const double pus[2] = {pu.x, pu.y};
-              const double pds[2] = {pd.y, pd.x};
+        for (int i = 0; i < NH / VE16; ++i) {
+          const V16 v = reinterpret_cast<const V16*>(prow + NH)[i];
+          unpack16(v, &pb[i * VE16]);
+        }
+        sv = lds_d[s + 1];                           // lds_d has S+1 entries
+        __builtin_amdgcn_sched_barrier(0);
+
 #pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                const int ku = HC + jj + e, kd = HC - 1 - jj - e;
-                const double au = pus[e] * wu, ad = pds[e] * wd;
-                acc_re[ku] = fma_(au, ur, acc_re[ku]);
-                acc_im[ku] = fma_(au, ui, acc_im[ku]);
-                acc_re[kd] = fma_(ad, dr, acc_re[kd]);
-                acc_im[kd] = fma_(ad, di, acc_im[kd]);
-                const double nur = fma_(ur, rr, -(ui * ri));
-                const double nui = fma_(ur, ri, ui * rr);
-                const double ndr = fma_(dr, rr, di * ri);
-                const double ndi = fma_(di, rr, -(dr * ri));
-                ur = nur; ui = nui; dr = ndr; di = ndi;
-                wu *= qu; qu *= h; wd *= qd; qd *= h;
-              }
+        for (int j = 0; j < HC; ++j) {
+          const int ku = HC + j, kd = HC - 1 - j;
+          T pu = (2 * j < NH) ? pa[(2 * j) % NH] : pb[(2 * j) % NH];
+          T pd = (2 * j < NH) ? pa[(2 * j + 1) % NH] : pb[(2 * j + 1) % NH];
+          if constexpr (TAPER) {
+            if constexpr (sizeof(T) == 4) {
+              const float* fq = p.fsq_pairs + (size_t)tile * CT + 2 * j;
+              pu *= __builtin_amdgcn_exp2f(g2 * fq[0]);
+              pd *= __builtin_amdgcn_exp2f(g2 * fq[1]);
+            } else {
+              pu *= wu; pd *= wd;
+              wu *= qu; qu *= h; wd *= qd; qd *= h;
             }
           }
+          acc_re[ku] = fma_(pu, ur, acc_re[ku]);
+          acc_im[ku] = fma_(pu, ui, acc_im[ku]);
+          acc_re[kd] = fma_(pd, dr, acc_re[kd]);
+          acc_im[kd] = fma_(pd, di, acc_im[kd]);
+          const T nur = fma_(ur, rr, -(ui * ri));
+          const T nui = fma_(ur, ri, ui * rr);
+          const T ndr = fma_(dr, rr, di * ri);
+          const T ndi = fma_(di, rr, -(dr * ri));
+          ur = nur; ui = nui; dr = ndr; di = ndi;
         }
       }
     }
@@ -407,7 +389,7 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
         if (i < npieces) reinterpret_cast<uint4*>(lds_p)[i] = src[i];
       }
       if (tid < S) lds_d[tid] = gd[s0 + tid];
-      if (tid == S) lds_d[S] = make_double4(0, 0, 0, 0);      // read one past the chunk by the pipeline
+      if (tid == (S < kBlockThreads ? S : 0)) lds_d[S] = make_double4(0, 0, 0, 0);   // read one past the chunk by the pipeline
     }
     __syncthreads();
 
@@ -653,7 +635,7 @@ static hipError_t launch_rec_ct(const SkyvisParams& p, hipStream_t stream) {
   const int nslabs = p.ntiles * p.nsplit;
   const int slabs_per_xcd = (nslabs + 7) / 8;
   const unsigned grid = 8u * (unsigned)slabs_per_xcd * (unsigned)p.nbgroups;
-  const size_t lds = (size_t)p.src_chunk * CT * sizeof(T) + (size_t)p.src_chunk * sizeof(double4);
+  const size_t lds = (size_t)p.src_chunk * CT * sizeof(T) + (size_t)(p.src_chunk + 1) * sizeof(double4);
   if (p.taper)
     hipLaunchKernelGGL((k_skyvis_rec<T, CT, true>), dim3(grid), dim3(kBlockThreads), lds, stream, p);
   else
@@ -687,8 +669,7 @@ hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_
     switch (ct) {
       case 8: return launch_rec_ct<float, 8>(p, stream);
       case 16: return launch_rec_ct<float, 16>(p, stream);
-      case 32: return launch_rec_ct<float, 32>(p, stream);
-      case 64: return launch_rec_ct<float, 64>(p, stream);
+      case 32: case 64: return launch_skyvis_rec_f32pk(p, ct, stream);   // packed kernel owns the wide tiles
     }
   } else {
     switch (ct) {
