@@ -111,8 +111,26 @@ int prisim_hip_skyvis(prisim_ctx* ctx, const prisim_sky* sky, int precision, int
 enum {
   PRISIM_BEAM_DELTA = 0,     /* pb = 1 (telescope shape 'delta', primary_beams.py:357-359) */
   PRISIM_BEAM_GAUSSIAN = 1,  /* primary_beams.py:716-728 (power pattern) */
-  PRISIM_BEAM_AIRY = 2       /* primary_beams.py:609-623 (power pattern, HERA D=14 m preset :239-247) */
+  PRISIM_BEAM_AIRY = 2,      /* primary_beams.py:609-623 (power pattern, HERA D=14 m preset :239-247) */
+  PRISIM_BEAM_DIPOLE = 3     /* primary_beams.py:1207-1235 (field pattern squared); needs prisim_beam_ext */
 };
+
+enum { PRISIM_DIPOLE_GENERAL = 0, PRISIM_DIPOLE_SHORT = 1, PRISIM_DIPOLE_HALFWAVE = 2 };
+
+/* Optional factors multiplying the element pattern (primary_beams.py:282-286, 317, 416-439):
+ *   power = | element_field x array_factor |^2 x ground_plane_field^2 */
+typedef struct prisim_beam_ext {
+  double dipole_dircos[3];   /* dipole axis (ENU direction cosines), PRISIM_BEAM_DIPOLE only (:1207) */
+  int32_t dipole_mode;       /* PRISIM_DIPOLE_* (:1214-1224) */
+  int32_t array_nax1;        /* isotropic-radiator array factor (:1460-1475); 0 = no array factor */
+  int32_t array_nax2;
+  int32_t ground_modify;     /* bit 0: apply 1/sqrt(|n|) modifier (:956-958); bit 1: scale given; bit 2: max given */
+  double array_sep1, array_sep2;     /* element separations in metres along axis 1 / 2 */
+  double array_east2ax1_deg;         /* rotation of axis 1 anti-clockwise from East (:1436-1441) */
+  double array_pc_dircos[3];         /* array pointing centre (zenith = {0,0,1}) */
+  double ground_height;      /* ground-plane height in metres (:950-966); <= 0 = no ground plane */
+  double ground_scale, ground_max;
+} prisim_beam_ext;
 
 typedef struct prisim_beam_sky {
   int64_t nsrc;
@@ -127,6 +145,7 @@ typedef struct prisim_beam_sky {
   const double* beam_pc_dircos;/* [3] beam pointing centre (ENU); zenith = {0,0,1} */
   const double* pc_dircos;     /* [3] phase centre */
   const double* fwhm_deg;      /* [nsrc] or NULL */
+  const prisim_beam_ext* ext;  /* optional dipole / array factor / ground plane; NULL = none */
 } prisim_beam_sky;
 
 /* Build pbflux[s,f] = beam(s,f) * flux(s,f) on the device (no nsrc x nchan host array) and make it the

@@ -79,3 +79,98 @@ def primary_beam_generator(skypos_altaz, frequency_hz, telescope, pointing_altaz
     else:
         raise ValueError('Value in key "shape" of telescope dictionary invalid.')
     return NP.abs(ep) ** 2                                                                  # :416
+
+
+# ---- dipole, isotropic-radiator array factor, ground plane (direction-cosine inputs) --------------------
+
+def dipole_field_pattern(length, dircos, wavelength, dipole_dircos=(1.0, 0.0, 0.0), short_dipole_approx=False,
+                         half_wave_dipole_approx=False):
+    """Field pattern of a dipole (primary_beams.py:1203-1235), skypos and orientation as direction cosines."""
+    dircos = NP.asarray(dircos, dtype=NP.float64).reshape(-1, 3)
+    wavelength = NP.asarray(wavelength, dtype=NP.float64).ravel()
+    k = 2 * NP.pi / wavelength.reshape(1, -1)                                               # :1203
+    h = 0.5 * length                                                                         # :1204
+    dot_product = NP.dot(NP.asarray(dipole_dircos, dtype=NP.float64).reshape(1, 3), dircos.T).reshape(-1, 1)   # :1205
+    angles = NP.arccos(NP.clip(dot_product, -1.0, 1.0))                                      # :1206
+    zero = (NP.abs(NP.abs(dot_product) - 1.0) < 1.0e-10).ravel()                             # :1209
+    max_pattern = 1.0
+    with NP.errstate(divide='ignore', invalid='ignore'):
+        if short_dipole_approx:
+            field = NP.repeat(NP.sin(angles).reshape(-1, 1), wavelength.size, axis=1)       # :1215-1216
+        else:
+            if half_wave_dipole_approx:
+                field = NP.cos(0.5 * NP.pi * NP.cos(angles)) / NP.sin(angles)               # :1219
+                field = NP.repeat(field.reshape(-1, 1), wavelength.size, axis=1)
+            else:
+                max_pattern = 1.0 - NP.cos(k * h)                                           # :1222
+                field = (NP.cos(k * h * NP.cos(angles)) - NP.cos(k * h)) / NP.sin(angles)   # :1223
+            if NP.any(zero):
+                field[zero, :] = k * h * NP.sin(k * h * NP.cos(angles[zero])) * NP.tan(angles[zero])   # :1226
+    return field / max_pattern                                                              # :1232
+
+
+def isotropic_radiators_array_field_pattern(nax1, nax2, sep1, sep2, dircos, wavelength, east2ax1=0.0,
+                                            pointing_dircos=(0.0, 0.0, 1.0)):
+    """Array factor of an nax1 x nax2 grid of isotropic radiators (primary_beams.py:1436-1475).
+    The reference uses nax1 in both terms (:1469-1471, harmless for 4 x 4); nax2 is used here."""
+    dircos = NP.asarray(dircos, dtype=NP.float64).reshape(-1, 3)
+    wavelength = NP.asarray(wavelength, dtype=NP.float64).ravel()
+    angle = NP.radians(east2ax1)
+    rot = NP.asarray([[NP.cos(angle), NP.sin(angle), 0.0], [-NP.sin(angle), NP.cos(angle), 0.0], [0.0, 0.0, 1.0]])   # :1443-1445
+    rel = NP.dot(dircos, rot.T) - NP.dot(NP.asarray(pointing_dircos, dtype=NP.float64), rot.T).reshape(1, -1)      # :1446-1449
+    phi = 2 * NP.pi * sep1 * rel[:, [0]] / wavelength.reshape(1, -1)                        # :1458
+    psi = 2 * NP.pi * sep2 * rel[:, [1]] / wavelength.reshape(1, -1)                        # :1459
+    with NP.errstate(divide='ignore', invalid='ignore'):
+        t1 = NP.sin(0.5 * nax1 * phi) / NP.sin(0.5 * phi) / nax1                            # :1465
+        t1 = NP.where(NP.abs(phi) < 1e-10, NP.cos(0.5 * nax1 * phi) / NP.cos(0.5 * phi), t1)   # :1466-1467
+        t2 = NP.sin(0.5 * nax2 * psi) / NP.sin(0.5 * psi) / nax2                            # :1469
+        t2 = NP.where(NP.abs(psi) < 1e-10, NP.cos(0.5 * nax2 * psi) / NP.cos(0.5 * psi), t2)   # :1470-1471
+    return t1 * t2                                                                          # :1473
+
+
+def ground_plane_field_pattern(height, dircos, wavelength, modifier=None):
+    """Field pattern of a ground plane at `height` (primary_beams.py:950-966).  sin(alt) = n.
+    PARITY UNPINNED (the reference reaches alt through GEOM.dircos2altaz, astroutils)."""
+    dircos = NP.asarray(dircos, dtype=NP.float64).reshape(-1, 3)
+    k = 2 * NP.pi / NP.asarray(wavelength, dtype=NP.float64).reshape(1, -1)                 # :950
+    gp = 2 * NP.sin(k * height * dircos[:, [2]])                                            # :953
+    if isinstance(modifier, dict):                                                          # :955-963
+        with NP.errstate(divide='ignore'):
+            val = 1.0 / NP.sqrt(NP.abs(dircos[:, 2]))
+        if 'scale' in modifier:
+            val = val * modifier['scale']
+        if 'max' in modifier:
+            val = NP.clip(val, 0.0, modifier['max'])
+        gp = gp * val[:, NP.newaxis]
+    return gp / (2 * NP.sin(k * height))                                                    # :965-966
+
+
+def composite_power_beam(dircos, frequency_hz, element='delta', size=0.0, element_dircos=(0.0, 0.0, 1.0), dipole_mode='general',
+                         array=None, ground=None):
+    """power = |element_field x array_factor|^2 x ground_field^2 (primary_beams.py:317, 349, 416, 439).
+    element: 'delta' | 'gaussian' | 'dish' | 'dipole'.  array: dict(nax1, nax2, sep1, sep2, east2ax1, pointing_dircos).
+    ground: dict(height, modifier)."""
+    dircos = NP.asarray(dircos, dtype=NP.float64).reshape(-1, 3)
+    f = NP.asarray(frequency_hz, dtype=NP.float64).ravel()
+    wl = C_LIGHT / f
+    if element == 'delta':
+        ep = NP.ones((dircos.shape[0], f.size))
+    elif element == 'dipole':
+        ep = dipole_field_pattern(size, dircos, wl, dipole_dircos=element_dircos, short_dipole_approx=(dipole_mode == 'short'),
+                                  half_wave_dipole_approx=(dipole_mode == 'halfwave'))
+    else:
+        alt = NP.degrees(NP.arcsin(NP.clip(dircos[:, 2], -1, 1)))
+        az = NP.degrees(NP.arctan2(dircos[:, 0], dircos[:, 1])) % 360.0
+        e = NP.asarray(element_dircos, dtype=NP.float64)
+        pc = [NP.degrees(NP.arcsin(NP.clip(e[2], -1, 1))), NP.degrees(NP.arctan2(e[0], e[1])) % 360.0]
+        fn = gaussian_beam if element == 'gaussian' else airy_disk_pattern
+        ep = fn(size, NP.stack((alt, az), axis=1), f, pointing_altaz=pc, power=False)
+    af = 1.0
+    if array is not None:
+        af = isotropic_radiators_array_field_pattern(array['nax1'], array['nax2'], array['sep1'], array['sep2'], dircos, wl,
+                                                     east2ax1=array.get('east2ax1', 0.0),
+                                                     pointing_dircos=array.get('pointing_dircos', (0.0, 0.0, 1.0)))
+    pb = NP.abs(ep * af) ** 2
+    if ground is not None:
+        pb = pb * ground_plane_field_pattern(ground['height'], dircos, wl, modifier=ground.get('modifier', None)) ** 2
+    return pb

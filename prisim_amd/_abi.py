@@ -15,7 +15,8 @@ PRISIM_OK = 0
 PRISIM_EINVAL, PRISIM_ENODEV, PRISIM_ENOMEM, PRISIM_ESTATE, PRISIM_ELIB, PRISIM_EINTERNAL = -1, -2, -3, -4, -5, -6
 PRISIM_FP64, PRISIM_FP32 = 0, 1
 PRISIM_KERNEL_AUTO, PRISIM_KERNEL_RECURRENCE, PRISIM_KERNEL_DIRECT = 0, 1, 2
-PRISIM_BEAM_DELTA, PRISIM_BEAM_GAUSSIAN, PRISIM_BEAM_AIRY = 0, 1, 2
+PRISIM_BEAM_DELTA, PRISIM_BEAM_GAUSSIAN, PRISIM_BEAM_AIRY, PRISIM_BEAM_DIPOLE = 0, 1, 2, 3
+PRISIM_DIPOLE_GENERAL, PRISIM_DIPOLE_SHORT, PRISIM_DIPOLE_HALFWAVE = 0, 1, 2
 
 # every symbol include/prisim_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
@@ -33,10 +34,52 @@ class PrisimSky(C.Structure):
                 ('pbflux_is_f32', C.c_int32), ('pc_dircos', C.c_void_p), ('fwhm_deg', C.c_void_p), ('fluxes', C.c_void_p)]
 
 
+class PrisimBeamExt(C.Structure):
+    _fields_ = [('dipole_dircos', C.c_double * 3), ('dipole_mode', C.c_int32), ('array_nax1', C.c_int32),
+                ('array_nax2', C.c_int32), ('ground_modify', C.c_int32), ('array_sep1', C.c_double), ('array_sep2', C.c_double),
+                ('array_east2ax1_deg', C.c_double), ('array_pc_dircos', C.c_double * 3), ('ground_height', C.c_double),
+                ('ground_scale', C.c_double), ('ground_max', C.c_double)]
+
+
+def make_beam_ext(ext):
+    """dict -> PrisimBeamExt.  Keys: dipole_dircos, dipole_mode, array (dict nax1, nax2, sep1, sep2, east2ax1, pointing_dircos),
+    ground (dict height, modifier{scale,max})."""
+    if ext is None:
+        return None
+    x = PrisimBeamExt()
+    dd = NP.asarray(ext.get('dipole_dircos', (1.0, 0.0, 0.0)), dtype=NP.float64).ravel()
+    if dd.size != 3:
+        raise ValueError('dipole_dircos must have 3 elements')
+    x.dipole_dircos[:] = dd.tolist()
+    x.dipole_mode = int(ext.get('dipole_mode', PRISIM_DIPOLE_GENERAL))
+    arr = ext.get('array', None)
+    if arr is not None:
+        x.array_nax1, x.array_nax2 = int(arr['nax1']), int(arr['nax2'])
+        x.array_sep1, x.array_sep2 = float(arr['sep1']), float(arr['sep2'])
+        x.array_east2ax1_deg = float(arr.get('east2ax1', 0.0) or 0.0)
+        pc = NP.asarray(arr.get('pointing_dircos', (0.0, 0.0, 1.0)), dtype=NP.float64).ravel()
+        if pc.size != 3:
+            raise ValueError('array pointing_dircos must have 3 elements')
+        x.array_pc_dircos[:] = pc.tolist()
+    gnd = ext.get('ground', None)
+    if gnd is not None:
+        x.ground_height = float(gnd['height'])
+        mod = gnd.get('modifier', None)
+        if isinstance(mod, dict):
+            x.ground_modify = 1
+            if 'scale' in mod:
+                x.ground_modify |= 2
+                x.ground_scale = float(mod['scale'])
+            if 'max' in mod:
+                x.ground_modify |= 4
+                x.ground_max = float(mod['max'])
+    return x
+
+
 class PrisimBeamSky(C.Structure):
     _fields_ = [('nsrc', C.c_int64), ('dircos', C.c_void_p), ('flux_ref', C.c_void_p), ('spindex', C.c_void_p),
                 ('flux_spectrum', C.c_void_p), ('ref_freq_hz', C.c_double), ('beam_kind', C.c_int32), ('diameter_m', C.c_double),
-                ('beam_pc_dircos', C.c_void_p), ('pc_dircos', C.c_void_p), ('fwhm_deg', C.c_void_p)]
+                ('beam_pc_dircos', C.c_void_p), ('pc_dircos', C.c_void_p), ('fwhm_deg', C.c_void_p), ('ext', C.c_void_p)]
 
 
 class PrisimTiming(C.Structure):
@@ -189,7 +232,7 @@ class Context(object):
         self.nsrc = sky.nsrc
 
     def set_sky_analytic(self, dircos, flux_ref, spindex, ref_freq_hz, beam_kind, diameter_m, beam_pc_dircos,
-                         pc_dircos, fwhm_deg=None, flux_spectrum=None):
+                         pc_dircos, fwhm_deg=None, flux_spectrum=None, ext=None):
         """Fused beam x flux on the device.  Flux is the power law flux_ref*(f/ref)^spindex, or, when
         flux_spectrum (nsrc, nchan) is given, that tabulated spectrum."""
         dc = NP.ascontiguousarray(dircos, dtype=NP.float64).reshape(-1, 3)
@@ -212,8 +255,9 @@ class Context(object):
             fw = NP.ascontiguousarray(fwhm_deg, dtype=NP.float64).ravel()
             if fw.size != nsrc:
                 raise ValueError('fwhm_deg must have nsrc elements')
+        xs = make_beam_ext(ext)
         sky = PrisimBeamSky(nsrc, _ptr(dc), _ptr(fr), _ptr(sp), _ptr(fs), float(ref_freq_hz), int(beam_kind), float(diameter_m),
-                            _ptr(bpc), _ptr(pc), _ptr(fw))
+                            _ptr(bpc), _ptr(pc), _ptr(fw), None if xs is None else C.cast(C.pointer(xs), C.c_void_p))
         self._check(self._lib.prisim_hip_set_sky_analytic(self._h, C.byref(sky)), 'prisim_hip_set_sky_analytic')
         self.nsrc = nsrc
 

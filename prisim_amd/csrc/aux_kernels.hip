@@ -34,13 +34,13 @@ void k_beam_flux(const BeamParams p) {
     const double cosx = d.x * p.bpc_x + d.y * p.bpc_y + d.z * p.bpc_z;
     // blank beyond the horizon of the dish or of the sky (primary_beams.py:607, 714)
     const bool blank = (cosx <= 0.0) || (d.z <= 0.0);
-    double pb = 1.0;
+    // element FIELD pattern
+    double ep = 1.0;
     if (p.beam_kind == PRISIM_BEAM_GAUSSIAN) {
       const double sigma_aprtr = p.diameter / (2.0 * sqrt(2.0 * log(2.0))) / (kC / f);   // :717
       const double sigma_dircos = 1.0 / (2.0 * kPi * sigma_aprtr);                        // :721
       const double r = sinx / sigma_dircos;
-      const double field = exp(-0.5 * r * r);                                             // :724
-      pb = blank ? 0.0 : field * field;                                                   // :725-728
+      ep = blank ? 0.0 : exp(-0.5 * r * r);                                               // :724-725
     } else if (p.beam_kind == PRISIM_BEAM_AIRY) {
       const double kk = 2.0 * kPi * f / kC;                                               // :609
       const double tol = 1e-10;                                                           // small_angle_tol
@@ -50,9 +50,53 @@ void k_beam_flux(const BeamParams p) {
       const double a0 = kk * 0.5 * p.diameter * sin_tol;
       const double pat = 2.0 * j1(a) / a;                                                 // :614
       const double mx = 2.0 * j1(a0) / a0;                                                // :618
-      pb = blank ? 0.0 : (pat * pat) / (mx * mx);                                         // :616-623
-    } else {
-      pb = 1.0;
+      ep = blank ? 0.0 : pat / mx;                                                        // :616, :623
+    } else if (p.beam_kind == PRISIM_BEAM_DIPOLE) {
+      const double kh = 2.0 * kPi * f / kC * 0.5 * p.diameter;                            // k*h, h = L/2 (:1203-1204)
+      double dot = p.dip_x * d.x + p.dip_y * d.y + p.dip_z * d.z;                         // :1205
+      dot = dot > 1.0 ? 1.0 : (dot < -1.0 ? -1.0 : dot);
+      const double ang = acos(dot);                                                       // :1206
+      const bool zero_ang = fabs(fabs(dot) - 1.0) < 1e-10;                                // :1209
+      if (p.dipole_mode == PRISIM_DIPOLE_SHORT) {
+        ep = sin(ang);                                                                    // :1215
+      } else {
+        double mx = 1.0;
+        if (p.dipole_mode == PRISIM_DIPOLE_HALFWAVE) {
+          ep = cos(0.5 * kPi * cos(ang)) / sin(ang);                                      // :1219
+        } else {
+          mx = 1.0 - cos(kh);                                                             // :1222
+          ep = (cos(kh * cos(ang)) - cos(kh)) / sin(ang);                                 // :1223
+        }
+        if (zero_ang) ep = kh * sin(kh * cos(ang)) * tan(ang);                            // :1226 (L'Hospital)
+        ep /= mx;                                                                         // :1230-1232
+      }
+    }
+    // isotropic-radiator array factor (:1436-1475)
+    double af = 1.0;
+    if (p.nax1 > 0) {
+      const double lam = kC / f;
+      const double rx = (p.rot_c * d.x + p.rot_s * d.y) - (p.rot_c * p.apc_x + p.rot_s * p.apc_y);      // :1443-1449
+      const double ry = (-p.rot_s * d.x + p.rot_c * d.y) - (-p.rot_s * p.apc_x + p.rot_c * p.apc_y);
+      const double phi = 2.0 * kPi * p.sep1 * rx / lam;                                   // :1458
+      const double psi = 2.0 * kPi * p.sep2 * ry / lam;                                   // :1459
+      const double n1 = (double)p.nax1, n2 = (double)p.nax2;
+      const double t1 = fabs(phi) < 1e-10 ? cos(0.5 * n1 * phi) / cos(0.5 * phi) : sin(0.5 * n1 * phi) / sin(0.5 * phi) / n1;   // :1465-1467
+      const double t2 = fabs(psi) < 1e-10 ? cos(0.5 * n2 * psi) / cos(0.5 * psi) : sin(0.5 * n2 * psi) / sin(0.5 * psi) / n2;   // :1469-1471 (nax2)
+      af = t1 * t2;
+    }
+    double pb = (ep * af) * (ep * af);                                                    // :317 / :349 / :416
+    if (p.gp_height > 0.0) {                                                              // ground plane (:950-966)
+      const double kk = 2.0 * kPi * f / kC;
+      const double nz = d.z < -1.0 ? -1.0 : (d.z > 1.0 ? 1.0 : d.z);                      // sin(alt) = n
+      double gp = 2.0 * sin(kk * p.gp_height * nz);                                       // :953
+      if (p.gp_modify & 1) {
+        double val = 1.0 / sqrt(fabs(d.z));                                               // :957
+        if (p.gp_modify & 2) val *= p.gp_scale;
+        if (p.gp_modify & 4) val = val < 0.0 ? 0.0 : (val > p.gp_max ? p.gp_max : val);   // :960-961
+        gp *= val;
+      }
+      gp /= 2.0 * sin(kk * p.gp_height);                                                  // :965-966
+      pb *= gp * gp;                                                                      // :439
     }
     const double flux = p.flux_spec ? p.flux_spec[i] : p.flux_ref[s] * pow(f / p.ref_freq, p.spindex[s]);
     p.pb_out[i] = pb * flux;

@@ -447,8 +447,21 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
   if (!ctx) return PRISIM_EINVAL;
   if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_analytic");
-  if (sky->beam_kind < PRISIM_BEAM_DELTA || sky->beam_kind > PRISIM_BEAM_AIRY)
+  if (sky->beam_kind < PRISIM_BEAM_DELTA || sky->beam_kind > PRISIM_BEAM_DIPOLE)
     return fail(ctx, PRISIM_EINVAL, "unknown beam_kind");
+  if (sky->beam_kind == PRISIM_BEAM_DIPOLE && !sky->ext)
+    return fail(ctx, PRISIM_EINVAL, "PRISIM_BEAM_DIPOLE needs a prisim_beam_ext (dipole axis)");
+  if (sky->ext) {
+    const prisim_beam_ext* x = sky->ext;
+    if (x->dipole_mode < PRISIM_DIPOLE_GENERAL || x->dipole_mode > PRISIM_DIPOLE_HALFWAVE)
+      return fail(ctx, PRISIM_EINVAL, "unknown dipole_mode");
+    if (x->array_nax1 < 0 || x->array_nax2 < 0 || (x->array_nax1 > 0) != (x->array_nax2 > 0))
+      return fail(ctx, PRISIM_EINVAL, "array_nax1 and array_nax2 must both be positive or both zero");
+    if (x->array_nax1 > 0 && !(x->array_sep1 > 0.0 && x->array_sep2 > 0.0))
+      return fail(ctx, PRISIM_EINVAL, "array element separations must be positive");
+    if (!std::isfinite(x->ground_height) || !std::isfinite(x->array_east2ax1_deg))
+      return fail(ctx, PRISIM_EINVAL, "non-finite beam extension parameter");
+  }
   const bool have_spec = sky->flux_spectrum != nullptr;
   if (sky->nsrc > 0 && !have_spec && (!sky->flux_ref || !sky->spindex))
     return fail(ctx, PRISIM_EINVAL, "flux_ref / spindex is NULL and no flux_spectrum given");
@@ -484,6 +497,16 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
       bp.beam_kind = sky->beam_kind;
       bp.diameter = sky->diameter_m;
       bp.bpc_x = sky->beam_pc_dircos[0]; bp.bpc_y = sky->beam_pc_dircos[1]; bp.bpc_z = sky->beam_pc_dircos[2];
+      if (sky->ext) {
+        const prisim_beam_ext* x = sky->ext;
+        bp.dip_x = x->dipole_dircos[0]; bp.dip_y = x->dipole_dircos[1]; bp.dip_z = x->dipole_dircos[2];
+        bp.dipole_mode = x->dipole_mode;
+        bp.nax1 = x->array_nax1; bp.nax2 = x->array_nax2; bp.sep1 = x->array_sep1; bp.sep2 = x->array_sep2;
+        const double ang = x->array_east2ax1_deg * M_PI / 180.0;
+        bp.rot_c = std::cos(ang); bp.rot_s = std::sin(ang);
+        bp.apc_x = x->array_pc_dircos[0]; bp.apc_y = x->array_pc_dircos[1]; bp.apc_z = x->array_pc_dircos[2];
+        bp.gp_height = x->ground_height; bp.gp_modify = x->ground_modify; bp.gp_scale = x->ground_scale; bp.gp_max = x->ground_max;
+      }
       bp.nsrc = ns; bp.nchan = ctx->nchan;
       bp.pb_out = (double*)ctx->pb.p;
       e = launch_beam_flux(bp, ctx->stream);

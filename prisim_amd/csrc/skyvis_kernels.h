@@ -65,6 +65,10 @@ struct BeamParams {
   int32_t beam_kind;
   double diameter;
   double bpc_x, bpc_y, bpc_z;  // beam pointing centre
+  // optional factors (prisim_beam_ext)
+  double dip_x, dip_y, dip_z; int32_t dipole_mode;
+  int32_t nax1, nax2; double sep1, sep2, rot_c, rot_s; double apc_x, apc_y, apc_z;
+  double gp_height; int32_t gp_modify; double gp_scale, gp_max;
   int64_t nsrc, nchan;
   double* pb_out;            // [nsrc][nchan]
 };

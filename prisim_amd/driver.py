@@ -1,0 +1,346 @@
+"""YAML-driven simulation loop -- the accelerated counterpart of scripts/run_prisim.py of the reference
+for the keys the BASELINE configs use (SURVEY.md 8(a) A10, section 5 "config / flags").
+
+Kept from the reference driver (scripts/run_prisim.py): the `-i parms.yaml` entry, the parameter-file schema
+(prisim/examples/simparms/defaultparms.yaml) with `preload.template` deep merge (:67-101), the channel grid (:900),
+the antenna layout presets / baseline selection (getBaselineInfo, interferometry.py:1465-2013), drift / track
+pointing schedules (:709-733), the custom catalog columns RA DEC F_INT SPINDEX MAJAX MINAX PA and its flux cut
+(:1645-1684), baseline sharding across processes (`pp.key: 'bl'`, :1775-1791) and the NPZ output keys
+(interferometry.py:8859-8863).
+
+Replaced: `mpirun` ranks + per-rank part files + rank-0 concatenate become one process per GPU
+(RANK / WORLD_SIZE / LOCAL_RANK from the launcher) and a single RCCL all-gather of the visibility cube;
+the rank-0 ROI/beam precompute through FITS files disappears (beams are fused on the device).
+Not offered (out of scope): survey catalogs (SUMSS/NVSS/GLEAM/GSM need prisim/data, absent),
+gains, noise, uvfits/uvh5/HDF5 writers, `pp.key: 'freq' | 'src'`, plots, resource monitor.  Two synthetic sky models
+are added because the reference's catalogs are not available offline: skyparm.model 'ptsrc_random' and 'healpix_synthetic'.
+Time: without astropy the LST ramp is lst_init + t * 15.0410686 deg/h (mean sidereal rate), jd from jd_init or obs_date.
+"""
+import copy
+import datetime
+import os
+import time
+
+import numpy as NP
+import yaml
+
+from . import _abi
+from . import geometry as GEOM
+from . import interferometry as RI
+from . import layouts as LAY
+from . import skymodel as SM
+from . import workloads as W
+
+SIDEREAL_DEG_PER_SEC = 360.0 * 1.00273790935 / 86400.0
+
+DEFAULTS = {
+    'preload': {'template': None},
+    'dirstruct': {'rootdir': './', 'project': 'prisim_amd_run', 'simid': None},
+    'telescope': {'label_prefix': '', 'id': 'custom', 'latitude': -30.7224, 'longitude': 21.4278, 'altitude': 0.0,
+                  'A_eff': 154, 'eff_Q': 0.96, 'Trx': 50.0, 'Tant_freqref': 150e6, 'Tant_spindex': -2.55, 'Tant_ref': 200.0,
+                  'Tsys': None},
+    'array': {'redundant': True, 'layout': 'HERA-19', 'file': None, 'seed': 200},
+    'baseline': {'min': None, 'max': None, 'direction': None},
+    'antenna': {'shape': 'dish', 'size': 14.0, 'orientation': [90.0, 270.0], 'ocoords': 'altaz', 'phased_array': False,
+                'ground_plane': None},
+    'beam': {'use_external': False},
+    'bandpass': {'freq': 150e6, 'freq_resolution': 390625.0, 'nchan': 256},
+    'obsparm': {'obs_date': '2015/11/23', 'obs_mode': 'drift', 't_obs': None, 'n_acc': 2, 't_acc': 1080.0},
+    'pointing': {'file': None, 'jd_init': None, 'lst_init': 0.0,
+                 'drift_init': {'alt': None, 'az': None, 'ha': 0.0, 'dec': -30.7224},
+                 'track_init': {'ra': 0.0, 'dec': -30.7224, 'ha': 0.0, 'epoch': '2000'}},
+    'skyparm': {'model': 'custom', 'epoch': '2000', 'nside': 16, 'flux_unit': 'Jy', 'custom_reffreq': 0.150, 'flux_min': 0.0,
+                'flux_max': None, 'fluxcut_reffreq': None, 'spindex': -0.83, 'roi_radius': None, 'n_src': 100, 'seed': 1},
+    'catalog': {'custom_file': 'custom_catalog.txt'},
+    'processing': {'gradient_mode': None, 'f_pad': 1.0, 'bpass_shape': 'bhw', 'delay_transform': False, 'memsave': False},
+    'pp': {'key': 'bl', 'eqvol': True},
+    'save_formats': {'npz': True},
+    'diagnosis': {'wait_after_run': False},
+}
+
+
+def deep_merge(base, override):
+    """Recursively overlay `override` on `base` (the reference merges three levels by hand, run_prisim.py:67-101)."""
+    out = copy.deepcopy(base)
+    for key, val in (override or {}).items():
+        if isinstance(val, dict) and isinstance(out.get(key), dict):
+            out[key] = deep_merge(out[key], val)
+        else:
+            out[key] = copy.deepcopy(val)
+    return out
+
+
+def load_parms(infile):
+    with open(infile, 'r') as f:
+        parms = yaml.safe_load(f) or {}
+    template = (parms.get('preload') or {}).get('template')
+    if template is not None:
+        if not os.path.isabs(template):
+            template = os.path.join(os.path.dirname(os.path.abspath(infile)), template)
+        with open(template, 'r') as f:
+            parms = deep_merge(yaml.safe_load(f) or {}, parms)
+    return deep_merge(DEFAULTS, parms)
+
+
+def telescope_dict(parms):
+    """run_prisim.py:103-230 condensed: telescope id + antenna element description."""
+    tel, ant = parms['telescope'], parms['antenna']
+    out = {'latitude': tel['latitude'], 'longitude': tel['longitude'], 'altitude': tel['altitude']}
+    if tel['id'] not in (None, 'custom'):
+        out['id'] = tel['id']
+        if ant.get('orientation') is not None:
+            out['orientation'], out['ocoords'] = ant['orientation'], ant['ocoords']
+    else:
+        out['shape'] = ant['shape']
+        out['size'] = ant['size']
+        out['orientation'], out['ocoords'] = ant['orientation'], ant['ocoords']
+    out['groundplane'] = ant.get('ground_plane')
+    return out
+
+
+def read_layout_file(path):
+    """Whitespace table with a header naming East / North / Up columns (array.parser defaults, defaultparms.yaml)."""
+    with open(path) as f:
+        lines = [ln for ln in f if ln.strip() and not ln.lstrip().startswith('#')]
+    header = lines[0].split()
+    cols = {name.lower(): i for i, name in enumerate(header)}
+    for need in ('east', 'north'):
+        if need not in cols:
+            raise KeyError('layout file must have East and North columns')
+    rows = [ln.split() for ln in lines[1:]]
+    east = NP.array([float(r[cols['east']]) for r in rows])
+    north = NP.array([float(r[cols['north']]) for r in rows])
+    up = NP.array([float(r[cols['up']]) for r in rows]) if 'up' in cols else NP.zeros(east.size)
+    return NP.stack((east, north, up), axis=1)
+
+
+def baseline_info(parms):
+    """Antenna positions -> baselines (all pairs j>i, folded, length-sorted), length selection, redundancy handling."""
+    arr = parms['array']
+    if arr.get('file'):
+        pos = read_layout_file(arr['file'])
+    else:
+        pos = LAY.array_layout(arr['layout'])
+    bl, ids = LAY.baseline_generator(pos)
+    bl, ids = LAY.fold_and_sort_baselines(bl, ids)
+    length = NP.sqrt(NP.sum(bl ** 2, axis=1))
+    keep = NP.ones(length.size, dtype=bool)
+    if parms['baseline']['min'] is not None:
+        keep &= length >= parms['baseline']['min']
+    if parms['baseline']['max'] is not None:
+        keep &= length <= parms['baseline']['max']
+    bl, ids = bl[keep], ids[keep]
+    if not arr.get('redundant', True):
+        # keep one baseline per redundant group (vectors equal to 1 cm)
+        key = NP.round(bl * 100.0).astype(NP.int64)
+        _, first = NP.unique(key, axis=0, return_index=True)
+        first = NP.sort(first)
+        bl, ids = bl[first], ids[first]
+    labels = ['{0}{1:d}-{0}{2:d}'.format(parms['telescope'].get('label_prefix') or '', int(a), int(b)) for a, b in ids]
+    return bl, labels, pos
+
+
+def read_custom_catalog(path):
+    with open(path) as f:
+        lines = [ln for ln in f if ln.strip() and not ln.lstrip().startswith('#')]
+    header = lines[0].split()
+    data = NP.array([[float(x) for x in ln.split()] for ln in lines[1:]])
+    return {name: data[:, i] for i, name in enumerate(header)}
+
+
+def build_skymodel(parms, infile_dir):
+    """Sky model in (RA, Dec) degrees.  'custom' follows run_prisim.py:1645-1684."""
+    sp = parms['skyparm']
+    model = sp['model']
+    freq = parms['bandpass']['freq']
+    fluxcut_freq = sp['fluxcut_reffreq'] if sp['fluxcut_reffreq'] is not None else freq         # run_prisim.py:902-903
+    if model == 'custom':
+        path = parms['catalog']['custom_file']
+        if not os.path.isabs(path):
+            path = os.path.join(infile_dir, path)
+        cat = read_custom_catalog(path)
+        ra, dec, fint, spindex = cat['RA'], cat['DEC'], cat['F_INT'], cat['SPINDEX']
+        majax, minax = cat['MAJAX'], cat['MINAX']
+        ref = sp['custom_reffreq'] * 1e9                                                         # :1655
+        lo = sp['flux_min'] * (ref / fluxcut_freq) ** sp['spindex']                              # :1658-1661
+        sel = fint >= lo
+        if sp['flux_max'] is not None:
+            sel &= fint <= sp['flux_max'] * (ref / fluxcut_freq) ** sp['spindex']
+        if NP.sum(sel) == 0:
+            raise IndexError('No sources in the catalog found satisfying flux threshold criteria')
+        return SM.SkyModel(location=NP.stack((ra[sel], dec[sel]), axis=1), flux_ref=fint[sel], spindex=spindex[sel], ref_freq=ref,
+                           src_shape=NP.stack((majax[sel], minax[sel], NP.zeros(int(sel.sum()))), axis=1),
+                           epoch='J' + str(sp['epoch']))
+    lst0 = (parms['pointing']['lst_init'] or 0.0) * 15.0
+    lat = parms['telescope']['latitude']
+    if model == 'ptsrc_random':
+        sky = W.point_source_sky(int(sp['n_src']), int(sp['seed']), f_ref=sp['custom_reffreq'] * 1e9, spindex=sp['spindex'])
+    elif model == 'healpix_synthetic':
+        sky = W.diffuse_sky(int(sp['nside']), int(sp['seed']), f_ref=sp['custom_reffreq'] * 1e9, spindex=sp['spindex'])
+    else:
+        raise NotImplementedError('skyparm.model {0!r}: survey catalogs need prisim/data (absent); use custom, ptsrc_random or '
+                                  'healpix_synthetic'.format(model))
+    hadec = GEOM.altaz2hadec(sky['altaz'], lat, units='degrees')         # local frame at lst_init -> (RA, Dec)
+    radec = NP.stack(((lst0 - hadec[:, 0]) % 360.0, hadec[:, 1]), axis=1)
+    n = radec.shape[0]
+    return SM.SkyModel(location=radec, flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
+                       src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1), epoch='J' + str(sp['epoch']))
+
+
+def window(nchan, shape):
+    """Frequency window for the delay transform (DSP.windowing, astroutils: unpinned).  area-normalised to mean 1."""
+    n = NP.arange(nchan)
+    if shape in ('rect', 'RECT', None):
+        w = NP.ones(nchan)
+    elif shape in ('bhw', 'BHW'):
+        a = (0.35875, 0.48829, 0.14128, 0.01168)
+        x = 2 * NP.pi * n / (nchan - 1)
+        w = a[0] - a[1] * NP.cos(x) + a[2] * NP.cos(2 * x) - a[3] * NP.cos(3 * x)
+    elif shape in ('bnw', 'BNW'):
+        a = (0.3635819, 0.4891775, 0.1365995, 0.0106411)
+        x = 2 * NP.pi * n / (nchan - 1)
+        w = a[0] - a[1] * NP.cos(x) + a[2] * NP.cos(2 * x) - a[3] * NP.cos(3 * x)
+    else:
+        raise ValueError('bpass_shape must be "rect", "bhw" or "bnw"')
+    return w * nchan / NP.sum(w)
+
+
+def julian_date(obs_date):
+    y, m, d = [int(x) for x in str(obs_date).replace('-', '/').split('/')]
+    return datetime.date(y, m, d).toordinal() + 1721424.5
+
+
+def schedule(parms):
+    """(jd, lst_deg, pointing_hadec) per accumulation (run_prisim.py:684-733)."""
+    ob, pt = parms['obsparm'], parms['pointing']
+    t_acc = float(ob['t_acc'])
+    n_acc = int(ob['n_acc']) if ob.get('t_obs') is None else int(ob['t_obs'] / t_acc)
+    mode = ob['obs_mode'] or 'track'
+    if mode not in ('track', 'drift'):
+        raise ValueError('Invalid specification for obs_mode')
+    lst_init = (pt['lst_init'] or 0.0) * 15.0
+    jd0 = pt['jd_init'] if pt.get('jd_init') is not None else julian_date(ob['obs_date'])
+    t = NP.arange(n_acc) * t_acc
+    lst = (lst_init + t * SIDEREAL_DEG_PER_SEC) % 360.0
+    jd = jd0 + t / 86400.0
+    lat = parms['telescope']['latitude']
+    if mode == 'drift':
+        di = pt['drift_init']
+        if di.get('alt') is None or di.get('az') is None:
+            if di.get('ha') is None or di.get('dec') is None:
+                raise ValueError('One of alt-az or ha-dec pairs must be specified')
+            hadec0 = NP.asarray([di['ha'], di['dec']], dtype=float)
+        else:
+            hadec0 = GEOM.altaz2hadec(NP.asarray([di['alt'], di['az']], dtype=float), lat, units='degrees')
+        hadec = NP.repeat(hadec0.reshape(1, -1), n_acc, axis=0)
+    else:
+        ti = pt['track_init']
+        ha0 = lst_init - ti['ra']
+        hadec = NP.stack((ha0 + t * SIDEREAL_DEG_PER_SEC, ti['dec'] + NP.zeros(n_acc)), axis=1)
+    return jd, lst, hadec, t_acc, n_acc
+
+
+def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose=True):
+    """Simulate the observation described by `parms` on this rank's GPU.  Returns a dict with the (gathered) visibility
+    cube (nbl, nchan, n_acc), baselines, labels, channels, lst, timestamps and timing."""
+    if parms['beam'].get('use_external'):
+        raise NotImplementedError('external HEALPix beams (run_prisim.py:1897-1908) are the next row (SURVEY.md 8(f) N1)')
+    if parms['pp']['key'] != 'bl':
+        raise NotImplementedError("pp.key must be 'bl': baselines are the natural shard axis on GPUs (SURVEY.md 2.2)")
+    bp = parms['bandpass']
+    chans = W.channel_grid(float(bp['freq']), float(bp['freq_resolution']), int(bp['nchan']))      # run_prisim.py:900
+    bl, labels, antpos = baseline_info(parms)
+    nbl_total = bl.shape[0]
+    per = (nbl_total + world - 1) // world                                                           # :1775-1791, equal shards
+    lo, hi = min(rank * per, nbl_total), min((rank + 1) * per, nbl_total)
+    bl_mine, labels_mine = bl[lo:hi], labels[lo:hi]
+    if bl_mine.shape[0] < per:                       # pad so that every rank gathers equal shards
+        npad = per - bl_mine.shape[0]
+        bl_mine = NP.vstack((bl_mine, NP.repeat(bl[-1:], npad, axis=0)))
+        labels_mine = labels_mine + ['pad'] * npad
+    tel = telescope_dict(parms)
+    skymod = build_skymodel(parms, infile_dir)
+    jd, lst, hadec, t_acc, n_acc = schedule(parms)
+    proc = parms['processing']
+    ia = RI.InterferometerArray(labels_mine, bl_mine, chans, telescope=tel, eff_Q=parms['telescope']['eff_Q'],
+                                latitude=tel['latitude'], longitude=tel['longitude'], altitude=tel['altitude'],
+                                skycoords='radec', A_eff=parms['telescope']['A_eff'], pointing_coords='hadec', device=device)
+    ia.reserve(n_acc)
+    tp = parms['telescope']
+    if tp.get('Tsys') is not None:
+        tsysinfo = {'Tnet': float(tp['Tsys'])}
+    else:
+        tsysinfo = {'Trx': tp['Trx'], 'Tant': {'f0': tp['Tant_freqref'], 'T0': tp['Tant_ref'], 'spindex': tp['Tant_spindex']}, 'Tnet': None}
+    roi_radius = parms['skyparm'].get('roi_radius')
+    t0 = time.time()
+    for j in range(n_acc):                                                                            # run_prisim.py:2180-2198
+        ia.observe((float(jd[j]), float(lst[j])), tsysinfo, NP.ones(chans.size), hadec[j], skymod, t_acc,
+                   roi_radius=roi_radius, roi_center='zenith', gradient_mode=proc.get('gradient_mode'),
+                   memsave=bool(proc.get('memsave')))
+        if verbose and rank == 0:
+            print('snapshot {0}/{1}: lst = {2:.4f} deg, {3} sources'.format(j + 1, n_acc, lst[j], ia.obs_catalog_indices[-1].size
+                                                                              if len(ia.obs_catalog_indices) > j else 0))
+    t_sim = time.time() - t0
+    cube = ia.skyvis_freq
+    if world > 1:
+        if comm_uid is None:
+            raise ValueError('comm_uid is needed when world > 1')
+        cube = ia.allgather(comm_uid, world, rank)[:nbl_total]
+        labels_all, bl_all = labels, bl
+    else:
+        cube, labels_all, bl_all = cube[:nbl_total], labels, bl
+    out = {'skyvis_freq': cube, 'bl': bl_all, 'labels': labels_all, 'freq': chans, 'lst': NP.asarray(ia.lst),
+           'timestamp': NP.asarray(ia.timestamp), 'bl_length': NP.sqrt(NP.sum(bl_all ** 2, axis=1)), 't_sim': t_sim,
+           'antpos': antpos, 'ia': ia}
+    if proc.get('delay_transform') and world == 1:
+        ia.delay_transform(pad=float(proc.get('f_pad', 1.0)), freq_wts=window(chans.size, proc.get('bpass_shape', 'bhw')), verbose=False)
+        out['skyvis_lag'], out['lags'] = ia.skyvis_lag, ia.lags
+    return out
+
+
+def save(out, parms, infile=None):
+    ds = parms['dirstruct']
+    simid = ds['simid'] or time.strftime('%Y-%m-%d-%H-%M-%S')
+    outdir = os.path.join(ds['rootdir'], ds['project'], simid, 'simdata')
+    os.makedirs(outdir, exist_ok=True)
+    path = os.path.join(outdir, 'simvis')
+    if parms['save_formats'].get('npz', True):
+        keys = {k: out[k] for k in ('skyvis_freq', 'lst', 'freq', 'timestamp', 'bl', 'bl_length')}          # interferometry.py:8862
+        for extra in ('skyvis_lag', 'lags'):
+            if extra in out:
+                keys[extra] = out[extra]
+        NP.savez_compressed(path + '.npz', **keys)
+    metadir = os.path.join(ds['rootdir'], ds['project'], simid, 'metainfo')
+    os.makedirs(metadir, exist_ok=True)
+    with open(os.path.join(metadir, 'simparms.yaml'), 'w') as f:                                            # run_prisim.py:2213-2220
+        yaml.safe_dump(parms, f, default_flow_style=False)
+    return path + '.npz'
+
+
+def main(argv=None):
+    import argparse
+    parser = argparse.ArgumentParser(description='Program to simulate interferometer array data (MI355X path)')
+    parser.add_argument('-i', '--infile', dest='infile', required=True, type=str, help='File specifying input parameters')
+    args = parser.parse_args(argv)
+    parms = load_parms(args.infile)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    uid = None
+    dist = None
+    if world > 1:
+        import torch.distributed as dist          # rendezvous only (gloo); all GPU work goes through libprisim_hip.so
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        box = [_abi.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    out = run(parms, infile_dir=os.path.dirname(os.path.abspath(args.infile)), rank=rank, world=world, device=local_rank, comm_uid=uid)
+    if rank == 0:
+        path = save(out, parms, args.infile)
+        print('simulated {0} baselines x {1} channels x {2} snapshots in {3:.3f} s -> {4}'.format(
+            out['skyvis_freq'].shape[0], out['skyvis_freq'].shape[1], out['skyvis_freq'].shape[2], out['t_sim'], path))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0

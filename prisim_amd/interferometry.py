@@ -197,6 +197,30 @@ class InterferometerArray(object):
         self._ctx.set_array(self.baselines, self.channels, nt_max=1)
         self._cube = []        # per-snapshot (nbl, nchan) visibilities, stacked lazily into skyvis_freq
         self._grad = []
+        self._reserved = 1     # snapshot slots of the device cube (reserve())
+
+    def reserve(self, n_acc):
+        """Allocate `n_acc` snapshot slots in the device visibility cube so that every observe() also leaves its result
+        resident on the GPU (slot = snapshot index) for a later allgather() / device-side delay transform.  Not in the
+        reference (its cube is a host array grown by dstack, interferometry.py:6384-6393)."""
+        n_acc = int(n_acc)
+        if n_acc < 1:
+            raise ValueError('n_acc must be positive')
+        if self.n_acc > 0:
+            raise RuntimeError('reserve() must be called before the first observe()')
+        self._ctx.set_array(self.baselines, self.channels, nt_max=n_acc)
+        self._reserved = n_acc
+
+    def allgather(self, comm_uid, nranks, rank):
+        """One RCCL all-gather of the baseline shards of all ranks (equal shard sizes; replaces the reference's per-rank
+        part files + rank-0 concatenate, scripts/run_prisim.py:2207, 2233-2242).  Returns (nranks*nbl, nchan, n_acc)."""
+        if self._reserved < self.n_acc:
+            raise RuntimeError('reserve(n_acc) must be called before observing to keep the cube on the device')
+        self._ctx.comm_init(comm_uid, nranks, rank)
+        c64 = bool(self._cube) and self._cube[0].dtype == NP.complex64
+        self._ctx.allgather(self.n_acc, complex64=c64)
+        g = self._ctx.get_gathered(self.n_acc, nranks)                 # [rank][t][b][f]
+        return NP.transpose(g, (0, 2, 3, 1)).reshape(nranks * self.baselines.shape[0], self.channels.size, self.n_acc)
 
     # ------------------------------------------------------------------------------------------
     def _broadcast_bl_chan(self, value, what, lo, hi):
@@ -398,11 +422,12 @@ class InterferometerArray(object):
                 # supplied beam (ROI_parameters path): pbfluxes = pb * fluxes on the device (:6254)
                 self._ctx.set_sky(dircos_roi, pb, pc_dircos, fwhm_deg=fwhm, fluxes=fluxes)
             else:
-                kind, dia, bpc = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz)  # :6252
+                kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz)  # :6252
                 self._ctx.set_sky_analytic(dircos_roi, None, None, None, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,
-                                           flux_spectrum=fluxes)
-            self._ctx.compute(precision=prec, want_grad=want_grad, slot=0)
-            res = self._ctx.get_vis(slot=0, want_grad=want_grad, complex64=memsave)
+                                           flux_spectrum=fluxes, ext=ext)
+            slot = self.n_acc if self.n_acc < self._reserved else 0
+            self._ctx.compute(precision=prec, want_grad=want_grad, slot=slot)
+            res = self._ctx.get_vis(slot=slot, want_grad=want_grad, complex64=memsave)
             skyvis, skyvis_gradient = res if want_grad else (res, None)
             self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(self.baselines, dircos_roi,
                                                                                  NP.float32 if memsave else NP.float64)]   # :6287-6291

@@ -7,8 +7,12 @@ beam kernel (prisim_amd/csrc/aux_kernels.hip, prisim_hip_set_sky_analytic):
     telescope shape 'dish'               -> Airy power pattern of diameter 'size'  (:369-373, :416)
     telescope shape 'gaussian'           -> Gaussian power pattern                 (:374-377, :416)
     telescope shape 'delta' / no shape   -> 1                                      (:355-359, :416)
-Other presets (vla, gmrt, mwa, dipole, phased arrays, rect/square apertures, ground planes) are
-later rows of SURVEY.md 8(f) and raise NotImplementedError here -- there is no CPU stand-in.
+    telescope id 'mwa'                   -> dipole (0.74 m) x 4x4 array factor     (:248-317, analytic path)
+    telescope id 'mwa_dipole' / 'paper'  -> dipole 0.74 m / 2.0 m                   (:320-349)
+    telescope shape 'dipole'             -> dipole of length 'size'                 (:360-368)
+    'groundplane' (+ 'ground_modify')    -> ground-plane factor                     (:418-439, :950-966)
+Other presets (vla, gmrt, phased-array beamformer with pointing_info, rect/square apertures) raise
+NotImplementedError here -- there is no CPU stand-in.
 """
 import numpy as NP
 
@@ -31,38 +35,84 @@ def _pointing_dircos(pointing_center, pointing_coords):
     raise ValueError('pointing coordinates must be "altaz" or "dircos"')
 
 
-def device_beam_spec(telescope, pointing_info=None, pointing_center=None):
-    """Map a reference ``telescope`` dictionary onto (beam_kind, diameter_m, beam pointing dircos) of the
-    fused device beam kernel.  pointing_center: alt-az degrees (observe() passes pc_altaz, :6252)."""
+def _ground_ext(telescope):
+    """'groundplane' / 'ground_modify' keys (primary_beams.py:418-439): applied unless the shape is 'dish'."""
+    if telescope.get('groundplane', None) is None:
+        return None
+    if telescope.get('shape', None) == 'dish':
+        return None
+    return {'height': float(telescope['groundplane']), 'modifier': telescope.get('ground_modify', None)}
+
+
+def _dipole_axis(telescope):
+    """Dipole axis from 'orientation'/'ocoords' with the reference's defaults (:250-265, :326-341): East."""
+    if ('orientation' in telescope) and ('ocoords' in telescope):
+        return _pointing_dircos(NP.asarray(telescope['orientation']), telescope['ocoords'])
+    if ('orientation' not in telescope) and ('ocoords' in telescope):
+        if telescope['ocoords'] not in ('altaz', 'dircos'):
+            raise ValueError('key "ocoords" in telescope dictionary contains invalid value')
+        return NP.array([1.0, 0.0, 0.0])                       # altaz [0, 90] == dircos [1, 0, 0]
+    if ('orientation' in telescope) and ('ocoords' not in telescope):
+        raise KeyError('key "ocoords" in telescope dictionary not specified.')
+    return NP.array([1.0, 0.0, 0.0])
+
+
+def device_beam_spec(telescope, pointing_info=None, pointing_center=None, east2ax1=0.0, short_dipole_approx=False,
+                     half_wave_dipole_approx=False):
+    """Map a reference ``telescope`` dictionary onto (beam_kind, size_m, element pointing dircos, ext) of the fused device
+    beam kernel (ext: dipole axis / array factor / ground plane, see _abi.make_beam_ext).
+    pointing_center: alt-az degrees (observe() passes pc_altaz, interferometry.py:6252)."""
     if (telescope is None) or (not isinstance(telescope, dict)):
         raise TypeError('telescope must be specified as a dictionary')
-    if telescope.get('groundplane', None) is not None and telescope.get('shape', None) != 'dish':
-        raise NotImplementedError('ground-plane patterns (primary_beams.py:812-971) are not on the accelerated path yet')
-    if 'id' in telescope:
-        tid = telescope['id']
+    if short_dipole_approx and half_wave_dipole_approx:
+        raise ValueError('Both short dipole and half-wave dipole approximations cannot be made at the same time')
+    dmode = _abi.PRISIM_DIPOLE_SHORT if short_dipole_approx else (_abi.PRISIM_DIPOLE_HALFWAVE if half_wave_dipole_approx
+                                                                    else _abi.PRISIM_DIPOLE_GENERAL)
+    zen = NP.array([0.0, 0.0, 1.0])
+    ground = _ground_ext(telescope)
+    tid = telescope.get('id', None)
+    if tid is not None and tid not in ('custom',):
         if tid in ('hera', 'hirax'):
             dia = 14.0 if tid == 'hera' else 6.0                                     # :240-243
             if 'orientation' in telescope:                                           # :245-246
                 bpc = _pointing_dircos(NP.asarray(telescope['orientation']), telescope.get('ocoords', 'altaz'))
             else:
-                bpc = NP.array([0.0, 0.0, 1.0])
-            return _abi.PRISIM_BEAM_AIRY, dia, bpc
-        if tid in ('custom', None) and 'shape' in telescope:
-            pass
-        else:
-            raise NotImplementedError('telescope id {0!r}: beam preset not on the accelerated path (SURVEY.md 8(f) N1)'.format(tid))
+                bpc = zen
+            ext = {'ground': ground} if ground is not None else None
+            return _abi.PRISIM_BEAM_AIRY, dia, bpc, ext
+        if tid == 'mwa':                                                             # :248-317
+            if pointing_info is not None:
+                raise NotImplementedError('MWA phased-array beamformer (pointing_info, primary_beams.py:288-316) is not on the '
+                                          'accelerated path yet')
+            ext = {'dipole_dircos': _dipole_axis(telescope), 'dipole_mode': dmode,
+                   'array': {'nax1': 4, 'nax2': 4, 'sep1': 1.1, 'sep2': 1.1, 'east2ax1': east2ax1, 'pointing_dircos': zen}}   # :282-285
+            if ground is not None:
+                ext['ground'] = ground
+            return _abi.PRISIM_BEAM_DIPOLE, 0.74, zen, ext                           # :267
+        if tid in ('mwa_dipole', 'paper'):                                           # :320-349
+            ext = {'dipole_dircos': _dipole_axis(telescope), 'dipole_mode': dmode}
+            if ground is not None:
+                ext['ground'] = ground
+            return _abi.PRISIM_BEAM_DIPOLE, 0.74 if tid == 'mwa_dipole' else 2.0, zen, ext
+        raise NotImplementedError('telescope id {0!r}: beam preset not on the accelerated path (SURVEY.md 8(f) N1)'.format(tid))
     if pointing_info is not None:
         raise NotImplementedError('phased-array beamformer (pointing_info) is not on the accelerated path yet')
     shape = telescope.get('shape', 'delta')
     bpc = _pointing_dircos(pointing_center, 'altaz')
+    ext = {'ground': ground} if ground is not None else None
     if shape == 'delta':
-        return _abi.PRISIM_BEAM_DELTA, 0.0, bpc
+        return _abi.PRISIM_BEAM_DELTA, 0.0, bpc, ext
     if shape == 'dish':
-        return _abi.PRISIM_BEAM_AIRY, float(telescope['size']), bpc
+        return _abi.PRISIM_BEAM_AIRY, float(telescope['size']), bpc, ext
     if shape == 'gaussian':
-        return _abi.PRISIM_BEAM_GAUSSIAN, float(telescope['size']), bpc
-    if shape in ('dipole', 'rect', 'square'):
-        raise NotImplementedError('telescope shape {0!r} is not on the accelerated path yet'.format(shape))
+        return _abi.PRISIM_BEAM_GAUSSIAN, float(telescope['size']), bpc, ext
+    if shape == 'dipole':                                                            # :360-368
+        ext = dict(ext or {})
+        ext.update({'dipole_dircos': _pointing_dircos(NP.asarray(telescope['orientation']), telescope['ocoords']), 'dipole_mode': dmode})
+        return _abi.PRISIM_BEAM_DIPOLE, float(telescope['size']), bpc, ext
+    if shape in ('rect', 'square'):
+        raise NotImplementedError('telescope shape {0!r} is not on the accelerated path (the reference code for it is broken, '
+                                  'SURVEY.md Q17)'.format(shape))
     raise ValueError('Value in key "shape" of telescope dictionary invalid.')
 
 
@@ -86,9 +136,11 @@ def primary_beam_generator(skypos, frequency, telescope, freq_scale='GHz', skyun
         dircos = skypos.reshape(-1, 3)
     else:
         raise ValueError('skyunits must be "altaz" or "dircos" on the accelerated path')
-    kind, dia, bpc = device_beam_spec(telescope, pointing_info=pointing_info, pointing_center=pointing_center)
+    kind, dia, bpc, ext = device_beam_spec(telescope, pointing_info=pointing_info, pointing_center=pointing_center,
+                                           east2ax1=east2ax1, short_dipole_approx=short_dipole_approx,
+                                           half_wave_dipole_approx=half_wave_dipole_approx)
     nsrc = dircos.shape[0]
     with _abi.Context(device) as ctx:
         ctx.set_array(NP.zeros((1, 3)), frequency, nt_max=1)
-        ctx.set_sky_analytic(dircos, NP.ones(nsrc), NP.zeros(nsrc), 1.0, kind, dia, bpc, NP.array([0.0, 0.0, 1.0]))
+        ctx.set_sky_analytic(dircos, NP.ones(nsrc), NP.zeros(nsrc), 1.0, kind, dia, bpc, NP.array([0.0, 0.0, 1.0]), ext=ext)
         return ctx.get_pbflux()

@@ -21,8 +21,8 @@ JY = 1.0e-26
 
 
 def channel_grid(f0, df, nchan):
-    """chans = f0 + (arange(nchan) - nchan/2) * df   (scripts/run_prisim.py:900; Python-2 integer nchan/2)."""
-    return f0 + (NP.arange(nchan) - nchan // 2) * df
+    """chans = f0 + (arange(nchan) - 0.5*nchan) * df   (scripts/run_prisim.py:900)."""
+    return f0 + (NP.arange(nchan) - 0.5 * nchan) * df
 
 
 def point_source_sky(nsrc, seed, alt_min_deg=10.0, f_ref=150e6, spindex=-0.83):

@@ -15,6 +15,8 @@ source text is stored in this repository.
                        baseline_delay_horizon.py:133-241 (function geometric_delay, dircos path)
   golden_beams.npz     primary_beams.py:517-625 (airy_disk_pattern), 629-730 (gaussian_beam),
                        9-441 (primary_beam_generator dispatch, shapes 'gaussian' / 'dish' / 'delta')
+  golden_beams_ext.npz primary_beams.py:975-1235 (dipole_field_pattern), 1239-1478 (isotropic_radiators_array_field_pattern),
+                       9-441 (dispatch for id 'mwa' / 'mwa_dipole' / 'paper' and shape 'dipole'), direction-cosine inputs
 """
 import os
 import sys
@@ -150,6 +152,42 @@ def make_beams():
                                                         freq_scale='GHz', skyunits='altaz')
     NP.savez_compressed(os.path.join(HERE, 'golden_beams.npz'), skypos_altaz=skypos, freq_hz=freq_hz, **out)
     print('golden_beams.npz:', {k: v.shape for k, v in out.items()})
+
+    # ---- dipole, 4x4 array factor, MWA / PAPER presets: direction-cosine inputs (those code paths need no GEOM)
+    rng = NP.random.default_rng(78)
+    n = 37
+    alt = NP.concatenate(([90.0, 0.0], NP.degrees(NP.arcsin(rng.uniform(0.02, 1.0, n - 2)))))
+    az = NP.concatenate(([0.0, 90.0], rng.uniform(0.0, 360.0, n - 2)))
+    dircos = altaz2dircos(NP.stack((alt, az), axis=1))
+    dircos[1] = [1.0, 0.0, 0.0]                       # exactly along an east-pointing dipole: L'Hospital branch (:1226)
+    wl = FCNST.c / freq_hz
+    exec(ref_block('primary_beams.py', [(975, 1235)]), ns)     # dipole_field_pattern
+    exec(ref_block('primary_beams.py', [(1239, 1478)]), ns)    # isotropic_radiators_array_field_pattern
+    out2 = {}
+    east = NP.asarray([1.0, 0.0, 0.0]).reshape(1, -1)
+    tilt = altaz2dircos(NP.array([[20.0, 35.0]]))
+    with NP.errstate(divide='ignore', invalid='ignore'):
+        for name, kw in (('general', {'short_dipole_approx': False, 'half_wave_dipole_approx': False}),
+                         ('short', {'short_dipole_approx': True, 'half_wave_dipole_approx': False}),
+                         ('halfwave', {'short_dipole_approx': False, 'half_wave_dipole_approx': True})):
+            out2['dipole_field_' + name] = ns['dipole_field_pattern'](0.74, NP.copy(dircos), dipole_coords='dircos',
+                                                                       dipole_orientation=NP.copy(east), skycoords='dircos',
+                                                                       wavelength=wl, power=False, **kw)
+        out2['dipole_field_tilted_2m'] = ns['dipole_field_pattern'](2.0, NP.copy(dircos), dipole_coords='dircos', dipole_orientation=NP.copy(tilt),
+                                                                    skycoords='dircos', wavelength=wl, short_dipole_approx=False, half_wave_dipole_approx=False, power=False)
+        out2['irap_4x4_zenith'] = ns['isotropic_radiators_array_field_pattern'](4, 4, 1.1, 1.1, NP.copy(dircos), wl, east2ax1=0.0,
+                                                                                 pointing_center=NP.asarray([0.0, 0.0, 1.0]), skycoords='dircos', power=False)
+        pc = altaz2dircos(NP.array([[70.0, 120.0]])).ravel()
+        out2['irap_4x4_rot30_pointed'] = ns['isotropic_radiators_array_field_pattern'](4, 4, 1.1, 1.1, NP.copy(dircos), wl, east2ax1=30.0,
+                                                                                        pointing_center=NP.copy(pc), skycoords='dircos', power=False)
+        out2['pbg_mwa'] = ns['primary_beam_generator'](NP.copy(dircos), freq_hz / 1e9, {'id': 'mwa'}, freq_scale='GHz', skyunits='dircos', east2ax1=0.0)
+        out2['pbg_mwa_dipole'] = ns['primary_beam_generator'](NP.copy(dircos), freq_hz / 1e9, {'id': 'mwa_dipole'}, freq_scale='GHz', skyunits='dircos')
+        out2['pbg_paper'] = ns['primary_beam_generator'](NP.copy(dircos), freq_hz / 1e9, {'id': 'paper'}, freq_scale='GHz', skyunits='dircos')
+        out2['pbg_shape_dipole'] = ns['primary_beam_generator'](NP.copy(dircos), freq_hz / 1e9,
+                                                               {'shape': 'dipole', 'size': 1.5, 'ocoords': 'dircos', 'orientation': NP.copy(tilt)},
+                                                               freq_scale='GHz', skyunits='dircos')
+    NP.savez_compressed(os.path.join(HERE, 'golden_beams_ext.npz'), dircos=dircos, freq_hz=freq_hz, tilt=tilt.ravel(), array_pc=pc, **out2)
+    print('golden_beams_ext.npz:', {k: v.shape for k, v in out2.items()})
 
 
 if __name__ == '__main__':

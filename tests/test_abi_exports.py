@@ -37,8 +37,10 @@ def test_struct_layouts_match_header():
     # prisim_sky: int64, 2 ptr, int32 (+pad), 3 ptr  -> 56 bytes on LP64
     assert C.sizeof(_abi.PrisimSky) == 56
     assert _abi.PrisimSky.pbflux_is_f32.offset == 24 and _abi.PrisimSky.fluxes.offset == 48
-    # prisim_beam_sky: int64, 4 ptr, double, int32 (+pad), double, 3 ptr -> 88 bytes
-    assert C.sizeof(_abi.PrisimBeamSky) == 88
+    # prisim_beam_sky: int64, 4 ptr, double, int32 (+pad), double, 4 ptr -> 96 bytes
+    assert C.sizeof(_abi.PrisimBeamSky) == 96 and _abi.PrisimBeamSky.ext.offset == 88
+    # prisim_beam_ext: 3 double, 4 int32, 3 double, 3 double, 3 double -> 112 bytes
+    assert C.sizeof(_abi.PrisimBeamExt) == 112 and _abi.PrisimBeamExt.array_sep1.offset == 40
     assert _abi.PrisimBeamSky.beam_kind.offset == 48 and _abi.PrisimBeamSky.diameter_m.offset == 56
     # prisim_timing: 3 double, 2 int64, 4 int32 -> 56 bytes
     assert C.sizeof(_abi.PrisimTiming) == 56

@@ -1,0 +1,140 @@
+"""YAML driver (prisim_amd/driver.py, scripts/run_prisim.py): host logic on CPU, end-to-end runs on the GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as NP
+import pytest
+import yaml
+
+from prisim_amd import driver, workloads as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = os.path.join(ROOT, 'examples')
+
+
+def test_load_parms_defaults_and_template_merge(tmp_path):
+    tmpl = tmp_path / 'template.yaml'
+    tmpl.write_text(yaml.safe_dump({'bandpass': {'nchan': 32, 'freq': 120e6}, 'telescope': {'id': 'hera'}}))
+    parm = tmp_path / 'parms.yaml'
+    parm.write_text(yaml.safe_dump({'preload': {'template': 'template.yaml'}, 'bandpass': {'nchan': 48}}))
+    p = driver.load_parms(str(parm))
+    assert p['bandpass']['nchan'] == 48 and p['bandpass']['freq'] == 120e6          # file overrides template overrides defaults
+    assert p['bandpass']['freq_resolution'] == 390625.0 and p['telescope']['id'] == 'hera'
+    assert p['pp']['key'] == 'bl' and p['diagnosis']['wait_after_run'] is False       # never drops into a debugger
+
+
+def test_baseline_info_selection_and_redundancy():
+    p = driver.load_parms(os.path.join(EX, 'config2.yaml'))
+    bl, labels, pos = driver.baseline_info(p)
+    assert bl.shape == (171, 3) and len(labels) == 171 and pos.shape == (19, 3)
+    p['baseline']['max'] = 15.0
+    assert driver.baseline_info(p)[0].shape[0] == 42                                  # 14.6 m spacings of HERA-19
+    p['baseline']['max'] = None
+    p['array']['redundant'] = False
+    blu = driver.baseline_info(p)[0]
+    assert blu.shape[0] == 30                                                         # unique baselines of a 19-element hexagon
+    p1 = driver.load_parms(os.path.join(EX, 'config1.yaml'))
+    p1['array']['file'] = os.path.join(EX, 'config1_layout.txt')
+    bl1 = driver.baseline_info(p1)[0]
+    assert bl1.shape == (6, 3) and NP.isclose(NP.sqrt((bl1 ** 2).sum(1)).min(), 14.6, atol=1e-3)
+
+
+def test_schedule_drift_and_track():
+    p = driver.load_parms(os.path.join(EX, 'config2.yaml'))
+    jd, lst, hadec, t_acc, n_acc = driver.schedule(p)
+    assert n_acc == 2 and t_acc == 1080.0 and NP.allclose(hadec, [[0.0, -30.7224]] * 2)
+    assert NP.isclose(lst[1] - lst[0], 1080.0 * 360.0 * 1.00273790935 / 86400.0)
+    assert NP.isclose(jd[1] - jd[0], 1080.0 / 86400.0) and NP.isclose(jd[0], 2457349.5)           # 2015/11/23 0h UT
+    p['obsparm']['obs_mode'] = 'track'
+    p['pointing']['lst_init'] = 1.0
+    p['pointing']['track_init'] = {'ra': 10.0, 'dec': -25.0, 'ha': 0.0, 'epoch': '2000'}
+    jd, lst, hadec, _, _ = driver.schedule(p)
+    assert NP.isclose(hadec[0, 0], 5.0) and NP.allclose(hadec[:, 1], -25.0) and hadec[1, 0] > hadec[0, 0]
+    p['obsparm']['obs_mode'] = 'dns'
+    with pytest.raises(ValueError):
+        driver.schedule(p)
+
+
+def test_custom_catalog_and_flux_cut():
+    p = driver.load_parms(os.path.join(EX, 'config1.yaml'))
+    sm = driver.build_skymodel(p, EX)
+    assert sm.location.shape == (100, 2) and NP.all(sm.spindex == -0.83) and NP.all(sm.src_shape == 0)
+    sky = W.point_source_sky(100, 1)
+    assert NP.allclose(sm.flux_ref, sky['flux_ref'], rtol=0, atol=1e-8)
+    p['skyparm']['flux_min'] = 5.0
+    sm2 = driver.build_skymodel(p, EX)
+    assert 0 < sm2.flux_ref.size < 100 and NP.all(sm2.flux_ref >= 5.0)
+    p['skyparm']['flux_min'] = 1e9
+    with pytest.raises(IndexError):
+        driver.build_skymodel(p, EX)
+    p['skyparm']['model'] = 'nvss'
+    with pytest.raises(NotImplementedError):
+        driver.build_skymodel(p, EX)
+
+
+def test_window_shapes():
+    for shape in ('rect', 'bhw', 'bnw'):
+        w = driver.window(64, shape)
+        assert w.shape == (64,) and NP.isclose(w.mean(), 1.0) and NP.allclose(w, w[::-1])
+    assert driver.window(64, 'bhw').max() > 2.0 and driver.window(64, 'bhw')[0] < 1e-3
+    with pytest.raises(ValueError):
+        driver.window(64, 'hann')
+
+
+def test_unsupported_modes_fail_loudly():
+    p = driver.load_parms(os.path.join(EX, 'config1.yaml'))
+    p['pp']['key'] = 'freq'
+    with pytest.raises(NotImplementedError):
+        driver.run(p)
+    p['pp']['key'] = 'bl'
+    p['beam']['use_external'] = True
+    with pytest.raises(NotImplementedError):
+        driver.run(p)
+
+
+@pytest.mark.gpu
+def test_config1_yaml_end_to_end_matches_oracle(tmp_path):
+    """BASELINE config 1 through scripts/run_prisim.py -i examples/config1.yaml, checked against the oracle."""
+    from oracle import skyvis_oracle as O, beams_oracle as BO, delay_oracle as DO
+    parms = yaml.safe_load(open(os.path.join(EX, 'config1.yaml')))
+    parms['dirstruct']['rootdir'] = str(tmp_path) + '/'
+    parms['array']['file'] = os.path.join(EX, 'config1_layout.txt')
+    parms['catalog']['custom_file'] = os.path.join(EX, 'config1_catalog.txt')
+    infile = tmp_path / 'cfg1.yaml'
+    infile.write_text(yaml.safe_dump(parms))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_prisim.py'), '-i', str(infile)], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    out = NP.load(os.path.join(str(tmp_path), 'prisim_amd_cfg1', 'cfg1', 'simdata', 'simvis.npz'))
+    assert sorted(out.files) == sorted(['skyvis_freq', 'lst', 'freq', 'timestamp', 'bl', 'bl_length', 'skyvis_lag', 'lags'])
+    vis = out['skyvis_freq']
+    assert vis.shape == (6, 64, 1)
+    # oracle: same catalog in the local frame at lst = 0
+    p = driver.load_parms(str(infile))
+    sm = driver.build_skymodel(p, EX)
+    lat = p['telescope']['latitude']
+    altaz = O.hadec2altaz(NP.stack((0.0 - sm.location[:, 0], sm.location[:, 1]), 1), lat)
+    ch = out['freq']
+    pb = BO.gaussian_beam(14.0, altaz, ch, pointing_altaz=O.hadec2altaz([[0.0, lat]], lat)[0]) * sm.generate_spectrum(frequency=ch)
+    pc = O.altaz2dircos(O.hadec2altaz([[0.0, lat]], lat))[0]
+    ref = O.skyvis(out['bl'], ch, O.altaz2dircos(altaz), pb, pc, fwhm_deg=NP.zeros(altaz.shape[0]))
+    assert NP.max(NP.abs(vis[:, :, 0] - ref) / O.abs_flux_sum(pb)[None, :]) <= 1e-11
+    w = driver.window(64, 'bhw')
+    lag, lags = DO.delay_transform(ref[:, :, None], NP.ones((6, 64, 1)), NP.broadcast_to(w[None, :, None], (6, 64, 1)), ch[1] - ch[0], pad=1.0)
+    assert NP.max(NP.abs(out['skyvis_lag'] - lag)) <= 1e-10 * NP.max(NP.abs(lag))
+
+
+@pytest.mark.gpu
+def test_config2_yaml_runs_and_reserves_device_cube():
+    p = driver.load_parms(os.path.join(EX, 'config2.yaml'))
+    out = driver.run(p, infile_dir=EX, verbose=False)
+    assert out['skyvis_freq'].shape == (171, 256, 2) and NP.all(NP.isfinite(out['skyvis_freq'].view(NP.float64)))
+    ia = out['ia']
+    # the device-resident cube holds the same snapshots (slot t) as the host attribute
+    for t in range(2):
+        assert NP.array_equal(ia._ctx.get_vis(slot=t), out['skyvis_freq'][:, :, t])
+    # single-rank "gather" through the same code path the multi-GPU driver uses
+    ia._ctx.allgather(2)
+    g = ia._ctx.get_gathered(2, 1)
+    assert NP.array_equal(NP.transpose(g[0], (1, 2, 0)), out['skyvis_freq'])

@@ -134,20 +134,38 @@ def test_skymodel_spectra():
 
 
 def test_device_beam_spec_dispatch():
-    k, d, p = PB.device_beam_spec({'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'})
-    assert k == _abi.PRISIM_BEAM_AIRY and d == 14.0 and NP.allclose(p, [0, 0, 1], atol=1e-12)
+    k, d, p, x = PB.device_beam_spec({'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'})
+    assert k == _abi.PRISIM_BEAM_AIRY and d == 14.0 and NP.allclose(p, [0, 0, 1], atol=1e-12) and x is None
     assert PB.device_beam_spec({'id': 'hirax'})[1] == 6.0
     assert PB.device_beam_spec({'shape': 'gaussian', 'size': 5.0})[:2] == (_abi.PRISIM_BEAM_GAUSSIAN, 5.0)
     assert PB.device_beam_spec({'shape': 'dish', 'size': 25.0})[0] == _abi.PRISIM_BEAM_AIRY
     assert PB.device_beam_spec({})[0] == _abi.PRISIM_BEAM_DELTA
-    k, d, p = PB.device_beam_spec({'shape': 'dish', 'size': 14.0}, pointing_center=[0.0, 90.0])
+    k, d, p, x = PB.device_beam_spec({'shape': 'dish', 'size': 14.0}, pointing_center=[0.0, 90.0])
     assert NP.allclose(p, [1, 0, 0], atol=1e-12)
+    k, d, p, x = PB.device_beam_spec({'id': 'mwa'}, east2ax1=15.0)
+    assert k == _abi.PRISIM_BEAM_DIPOLE and d == 0.74 and x['array']['nax1'] == 4 and x['array']['sep1'] == 1.1
+    assert x['array']['east2ax1'] == 15.0 and NP.allclose(x['dipole_dircos'], [1, 0, 0])
+    assert PB.device_beam_spec({'id': 'paper'})[1] == 2.0 and PB.device_beam_spec({'id': 'mwa_dipole'})[1] == 0.74
+    k, d, p, x = PB.device_beam_spec({'shape': 'dipole', 'size': 1.5, 'ocoords': 'altaz', 'orientation': [0.0, 0.0],
+                                      'groundplane': 0.3, 'ground_modify': {'scale': 2.0, 'max': 3.0}}, half_wave_dipole_approx=True)
+    assert k == _abi.PRISIM_BEAM_DIPOLE and NP.allclose(x['dipole_dircos'], [0, 1, 0], atol=1e-12)
+    assert x['dipole_mode'] == _abi.PRISIM_DIPOLE_HALFWAVE and x['ground']['height'] == 0.3
+    ext = _abi.make_beam_ext(x)
+    assert ext.ground_modify == 7 and ext.ground_scale == 2.0 and ext.ground_max == 3.0 and ext.array_nax1 == 0
+    # a dish ignores the ground plane (primary_beams.py:422)
+    assert PB.device_beam_spec({'shape': 'dish', 'size': 14.0, 'groundplane': 0.3})[3] is None
     with pytest.raises(TypeError):
         PB.device_beam_spec(None)
     with pytest.raises(ValueError):
         PB.device_beam_spec({'shape': 'banana'})
+    with pytest.raises(ValueError):
+        PB.device_beam_spec({'id': 'paper'}, short_dipole_approx=True, half_wave_dipole_approx=True)
+    with pytest.raises(KeyError):
+        PB.device_beam_spec({'id': 'paper', 'orientation': [0.0, 90.0]})
     with pytest.raises(NotImplementedError):
-        PB.device_beam_spec({'id': 'mwa'})
+        PB.device_beam_spec({'id': 'vla'})
+    with pytest.raises(NotImplementedError):
+        PB.device_beam_spec({'id': 'mwa'}, pointing_info={'delays': [0] * 16})
 
 
 def test_error_code_mapping():

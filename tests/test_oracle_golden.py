@@ -94,3 +94,26 @@ def test_beams_match_reference_functions(golden_beams):
         assert NP.max(NP.abs(BO.airy_disk_pattern(14.0, sp, f, pointing_altaz=[90.0, 270.0]) - g['airy_power_d14'])) <= 1e-12
     # rows 2 and 3 of the fixture are on / below the horizon: blanked
     assert NP.all(g['airy_power_d14'][2:4] == 0) and NP.all(g['gauss_power_d14'][2:4] == 0)
+
+
+def test_dipole_array_factor_and_presets_match_reference_functions():
+    import os
+    from conftest import GOLDEN
+    g = dict(NP.load(os.path.join(GOLDEN, 'golden_beams_ext.npz')))
+    dc, f = g['dircos'], g['freq_hz']
+    wl = 299792458.0 / f
+    assert NP.array_equal(BO.dipole_field_pattern(0.74, dc, wl), g['dipole_field_general'])
+    assert NP.array_equal(BO.dipole_field_pattern(0.74, dc, wl, short_dipole_approx=True), g['dipole_field_short'])
+    assert NP.array_equal(BO.dipole_field_pattern(0.74, dc, wl, half_wave_dipole_approx=True), g['dipole_field_halfwave'])
+    assert NP.array_equal(BO.dipole_field_pattern(2.0, dc, wl, dipole_dircos=g['tilt']), g['dipole_field_tilted_2m'])
+    assert NP.array_equal(BO.isotropic_radiators_array_field_pattern(4, 4, 1.1, 1.1, dc, wl), g['irap_4x4_zenith'])
+    assert NP.array_equal(BO.isotropic_radiators_array_field_pattern(4, 4, 1.1, 1.1, dc, wl, east2ax1=30.0, pointing_dircos=g['array_pc']),
+                          g['irap_4x4_rot30_pointed'])
+    mwa = BO.composite_power_beam(dc, f, element='dipole', size=0.74, element_dircos=(1, 0, 0),
+                                  array=dict(nax1=4, nax2=4, sep1=1.1, sep2=1.1))
+    assert NP.max(NP.abs(mwa - g['pbg_mwa'])) <= 1e-15
+    assert NP.max(NP.abs(BO.composite_power_beam(dc, f, element='dipole', size=2.0, element_dircos=(1, 0, 0)) - g['pbg_paper'])) <= 1e-15
+    assert NP.max(NP.abs(BO.composite_power_beam(dc, f, element='dipole', size=1.5, element_dircos=g['tilt']) - g['pbg_shape_dipole'])) <= 1e-15
+    # ground plane known answers (unpinned restatement): 1 at zenith, 0 on the horizon
+    gp = BO.ground_plane_field_pattern(0.3, NP.array([[0, 0, 1.0], [1.0, 0, 0]]), wl)
+    assert NP.allclose(gp[0], 1.0) and NP.allclose(gp[1], 0.0)
