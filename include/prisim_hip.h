@@ -152,6 +152,20 @@ typedef struct prisim_beam_sky {
  * current sky.  Replaces primary_beam_generator + generate_spectrum(power law) + :6254 for these leaves. */
 int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky);
 
+/* External (tabulated) primary beam, resident across snapshots (scripts/run_prisim.py:489-494, 2091-2103).
+ * beam: [npix][nfreq] > 0, HEALPix RING in the local frame (theta = zenith angle, phi = azimuth N->E).
+ * interp_matrix: [nchan][nfreq] linear operator of the spectral interpolation onto the channel grid
+ * (scipy interp1d of kind beam.spec_interp applied to unit vectors; one row with a single 1 = achromatic
+ * nearest-frequency selection, :2096-2097).  The device forms table[p][c] = sum_j M[c][j] log10(beam[p][j]). */
+int prisim_hip_set_external_beam(prisim_ctx* ctx, const double* beam, int64_t npix, int64_t nfreq,
+                                 const double* interp_matrix);
+
+/* Sky for one snapshot with the external beam: sky->pbflux must be NULL and sky->fluxes [nsrc][nchan] given.
+ * On the device: bilinear HEALPix interpolation of the table at each source (healpy get_interp_val),
+ * subtraction of max(per-channel maximum over the sources, 0) (:2098-2101), 10**, rounding to float32
+ * (the reference stores supplied beams as float32, interferometry.py:4466), times fluxes (:6254). */
+int prisim_hip_set_sky_external(prisim_ctx* ctx, const prisim_sky* sky);
+
 /* Read back the device pbflux (float64 [nsrc][nchan]) -- for parity tests of the fused beams. */
 int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out);
 

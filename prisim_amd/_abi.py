@@ -22,7 +22,8 @@ PRISIM_DIPOLE_GENERAL, PRISIM_DIPOLE_SHORT, PRISIM_DIPOLE_HALFWAVE = 0, 1, 2
 EXPORTS = (
     'prisim_hip_create', 'prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version',
     'prisim_hip_set_array', 'prisim_hip_set_sky', 'prisim_hip_compute', 'prisim_hip_get_vis',
-    'prisim_hip_skyvis', 'prisim_hip_set_vis', 'prisim_hip_set_sky_analytic', 'prisim_hip_get_pbflux',
+    'prisim_hip_skyvis', 'prisim_hip_set_vis', 'prisim_hip_set_sky_analytic',
+    'prisim_hip_set_external_beam', 'prisim_hip_set_sky_external', 'prisim_hip_get_pbflux',
     'prisim_hip_delay_transform', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
     'prisim_hip_allgather', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
@@ -122,6 +123,8 @@ def load_library():
     lib.prisim_hip_set_vis.argtypes = [vp, i64, vp]
     lib.prisim_hip_skyvis.argtypes = [vp, C.POINTER(PrisimSky), i32, i32, vp, vp, i32]
     lib.prisim_hip_set_sky_analytic.argtypes = [vp, C.POINTER(PrisimBeamSky)]
+    lib.prisim_hip_set_external_beam.argtypes = [vp, vp, i64, i64, vp]
+    lib.prisim_hip_set_sky_external.argtypes = [vp, C.POINTER(PrisimSky)]
     lib.prisim_hip_get_pbflux.argtypes = [vp, vp]
     lib.prisim_hip_delay_transform.argtypes = [vp, i64, vp, dbl, vp, vp, vp, dbl]
     lib.prisim_hip_comm_unique_id.argtypes = [C.c_char_p]
@@ -259,6 +262,35 @@ class Context(object):
         sky = PrisimBeamSky(nsrc, _ptr(dc), _ptr(fr), _ptr(sp), _ptr(fs), float(ref_freq_hz), int(beam_kind), float(diameter_m),
                             _ptr(bpc), _ptr(pc), _ptr(fw), None if xs is None else C.cast(C.pointer(xs), C.c_void_p))
         self._check(self._lib.prisim_hip_set_sky_analytic(self._h, C.byref(sky)), 'prisim_hip_set_sky_analytic')
+        self.nsrc = nsrc
+
+    def set_external_beam(self, beam, interp_matrix):
+        """beam (npix, nfreq) HEALPix RING, local frame; interp_matrix (nchan, nfreq) spectral interpolation operator."""
+        b = NP.ascontiguousarray(beam, dtype=NP.float64)
+        if b.ndim != 2:
+            raise ValueError('beam must be a (npix, nfreq) array')
+        m = NP.ascontiguousarray(interp_matrix, dtype=NP.float64)
+        if m.shape != (self.nchan, b.shape[1]):
+            raise ValueError('interp_matrix must have shape (nchan, nfreq) = ({0}, {1})'.format(self.nchan, b.shape[1]))
+        self._check(self._lib.prisim_hip_set_external_beam(self._h, _ptr(b), b.shape[0], b.shape[1], _ptr(m)),
+                    'prisim_hip_set_external_beam')
+
+    def set_sky_external(self, dircos, fluxes, pc_dircos, fwhm_deg=None):
+        dc = NP.ascontiguousarray(dircos, dtype=NP.float64).reshape(-1, 3)
+        nsrc = dc.shape[0]
+        fl = NP.ascontiguousarray(fluxes, dtype=NP.float64)
+        if fl.size != nsrc * self.nchan:
+            raise ValueError('fluxes must have shape (nsrc, nchan)')
+        pc = NP.ascontiguousarray(pc_dircos, dtype=NP.float64).ravel()
+        if pc.size != 3:
+            raise ValueError('pc_dircos must have 3 elements')
+        fw = None
+        if fwhm_deg is not None:
+            fw = NP.ascontiguousarray(fwhm_deg, dtype=NP.float64).ravel()
+            if fw.size != nsrc:
+                raise ValueError('fwhm_deg must have nsrc elements')
+        sky = PrisimSky(nsrc, _ptr(dc), None, 0, _ptr(pc), _ptr(fw), _ptr(fl))
+        self._check(self._lib.prisim_hip_set_sky_external(self._h, C.byref(sky)), 'prisim_hip_set_sky_external')
         self.nsrc = nsrc
 
     def get_pbflux(self):

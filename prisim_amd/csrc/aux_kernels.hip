@@ -124,6 +124,191 @@ hipError_t launch_mul_inplace(double* a, const double* b, int64_t n, hipStream_t
   return hipGetLastError();
 }
 
+// ---- external HEALPix beam (scripts/run_prisim.py:2091-2103) ---------------------------------------------
+// table[p][c] = sum_j M[c][j] * log10(beam[p][j])
+__global__ void k_extbeam_table(const double* __restrict__ beam, const double* __restrict__ interp, double* __restrict__ table,
+                                int64_t npix, int64_t nfreq, int64_t nchan) {
+  const int64_t total = npix * nchan;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i / nchan, c = i - pix * nchan;
+    double a = 0.0;
+    for (int64_t j = 0; j < nfreq; ++j) {
+      const double m = interp[c * nfreq + j];
+      if (m != 0.0) a = fma(m, log10(beam[pix * nfreq + j]), a);
+    }
+    table[i] = a;
+  }
+}
+
+struct RingInfo { int64_t start; int64_t nr; double theta; int shift; };
+
+// HEALPix RING: start pixel, pixels in ring, colatitude and phi-shift flag of ring ir in [1, 4 nside - 1]
+// (Healpix_Base::get_ring_info2)
+__device__ __forceinline__ RingInfo ring_info(int64_t nside, int64_t ir) {
+  const int64_t npix = 12 * nside * nside, ncap = 2 * nside * (nside - 1);
+  const double fact2 = 4.0 / (double)npix, fact1 = (double)(2 * nside) * fact2;
+  const bool south = ir > 2 * nside;
+  const int64_t north = south ? 4 * nside - ir : ir;
+  RingInfo r;
+  if (north < nside) {
+    const double tmp = (double)(north * north) * fact2;
+    r.theta = atan2(sqrt(tmp * (2.0 - tmp)), 1.0 - tmp);
+    r.nr = 4 * north;
+    r.start = 2 * north * (north - 1);
+    r.shift = 1;
+  } else {
+    double ct = (double)(2 * nside - north) * fact1;
+    ct = ct > 1.0 ? 1.0 : (ct < -1.0 ? -1.0 : ct);
+    r.theta = acos(ct);
+    r.nr = 4 * nside;
+    r.start = ncap + (north - nside) * 4 * nside;
+    r.shift = (((north - nside) & 1) == 0) ? 1 : 0;
+  }
+  if (south) { r.theta = kPi - r.theta; r.start = npix - r.start - r.nr; }
+  return r;
+}
+
+// work[s][c] = bilinear HEALPix interpolation of table[.][c] at the direction of source s
+// (Healpix_Base::get_interpol / healpy.get_interp_val).  One block per source; thread 0 forms the 4 pixels + weights.
+__global__ __launch_bounds__(256)
+void k_extbeam_gather(const double* __restrict__ table, int nside_i, const double* __restrict__ dirs, double* __restrict__ work,
+                      int64_t nsrc, int64_t nchan) {
+  __shared__ int64_t spix[4];
+  __shared__ double swgt[4];
+  const int64_t nside = nside_i;
+  for (int64_t s = blockIdx.x; s < nsrc; s += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double4 d = reinterpret_cast<const double4*>(dirs)[s];
+      double z = d.z;                                   // cos(theta), theta = zenith angle
+      z = z > 1.0 ? 1.0 : (z < -1.0 ? -1.0 : z);
+      const double theta = acos(z);
+      double phi = atan2(d.x, d.y);                     // azimuth from North through East
+      if (phi < 0.0) phi += 2.0 * kPi;
+      const int64_t npix = 12 * nside * nside;
+      const double az = fabs(z);
+      int64_t ir1;
+      if (az <= 2.0 / 3.0) ir1 = (int64_t)((double)nside * (2.0 - 1.5 * z));
+      else { const int64_t irr = (int64_t)((double)nside * sqrt(3.0 * (1.0 - az))); ir1 = z > 0.0 ? irr : 4 * nside - irr - 1; }
+      const int64_t ir2 = ir1 + 1;
+      int64_t pix[4] = {0, 0, 0, 0};
+      double wgt[4] = {0, 0, 0, 0};
+      double theta1 = 0.0, theta2 = 0.0;
+      if (ir1 > 0) {
+        const RingInfo r = ring_info(nside, ir1);
+        const double dphi = 2.0 * kPi / (double)r.nr;
+        const double tmp = phi / dphi - 0.5 * r.shift;
+        int64_t i1 = tmp < 0.0 ? (int64_t)tmp - 1 : (int64_t)tmp;
+        const double w1 = (phi - ((double)i1 + 0.5 * r.shift) * dphi) / dphi;
+        int64_t i2 = i1 + 1;
+        if (i1 < 0) i1 += r.nr;
+        if (i2 >= r.nr) i2 -= r.nr;
+        pix[0] = r.start + i1; pix[1] = r.start + i2; wgt[0] = 1.0 - w1; wgt[1] = w1; theta1 = r.theta;
+      }
+      if (ir2 < 4 * nside) {
+        const RingInfo r = ring_info(nside, ir2);
+        const double dphi = 2.0 * kPi / (double)r.nr;
+        const double tmp = phi / dphi - 0.5 * r.shift;
+        int64_t i1 = tmp < 0.0 ? (int64_t)tmp - 1 : (int64_t)tmp;
+        const double w1 = (phi - ((double)i1 + 0.5 * r.shift) * dphi) / dphi;
+        int64_t i2 = i1 + 1;
+        if (i1 < 0) i1 += r.nr;
+        if (i2 >= r.nr) i2 -= r.nr;
+        pix[2] = r.start + i1; pix[3] = r.start + i2; wgt[2] = 1.0 - w1; wgt[3] = w1; theta2 = r.theta;
+      }
+      if (ir1 == 0) {                                   // north polar cap
+        const double wth = theta / theta2;
+        wgt[2] *= wth; wgt[3] *= wth;
+        const double fac = (1.0 - wth) * 0.25;
+        wgt[0] = fac; wgt[1] = fac; wgt[2] += fac; wgt[3] += fac;
+        pix[0] = (pix[2] + 2) & 3; pix[1] = (pix[3] + 2) & 3;
+      } else if (ir2 == 4 * nside) {                    // south polar cap
+        const double wth = (theta - theta1) / (kPi - theta1);
+        wgt[0] *= (1.0 - wth); wgt[1] *= (1.0 - wth);
+        const double fac = wth * 0.25;
+        wgt[0] += fac; wgt[1] += fac; wgt[2] = fac; wgt[3] = fac;
+        pix[2] = ((pix[0] + 2) & 3) + npix - 4; pix[3] = ((pix[1] + 2) & 3) + npix - 4;
+      } else {
+        const double wth = (theta - theta1) / (theta2 - theta1);
+        wgt[0] *= (1.0 - wth); wgt[1] *= (1.0 - wth); wgt[2] *= wth; wgt[3] *= wth;
+      }
+      for (int k = 0; k < 4; ++k) { spix[k] = pix[k]; swgt[k] = wgt[k]; }
+    }
+    __syncthreads();
+    for (int64_t c = threadIdx.x; c < nchan; c += blockDim.x) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a += table[spix[k] * nchan + c] * swgt[k];      // same summation order as the restatement
+      work[s * nchan + c] = a;
+    }
+  }
+}
+
+// partial[blk][c] = nan-ignoring max over the sources handled by block blk; fixed block count => deterministic
+__global__ __launch_bounds__(256)
+void k_colmax_partial(const double* __restrict__ work, double* __restrict__ partial, int64_t nsrc, int64_t nchan) {
+  for (int64_t c = threadIdx.x; c < nchan; c += blockDim.x) {
+    double m = -INFINITY;
+    bool any = false;
+    for (int64_t s = blockIdx.x; s < nsrc; s += gridDim.x) {
+      const double v = work[s * nchan + c];
+      if (!isnan(v)) { m = any ? (v > m ? v : m) : v; any = true; }
+    }
+    partial[(int64_t)blockIdx.x * nchan + c] = any ? m : NAN;
+  }
+}
+
+__global__ void k_colmax_final(const double* __restrict__ partial, double* __restrict__ colmax, int nblk, int64_t nchan) {
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchan; c += (int64_t)gridDim.x * blockDim.x) {
+    double m = -INFINITY;
+    bool any = false;
+    for (int b = 0; b < nblk; ++b) {
+      const double v = partial[(int64_t)b * nchan + c];
+      if (!isnan(v)) { m = any ? (v > m ? v : m) : v; any = true; }
+    }
+    m = any ? m : NAN;
+    colmax[c] = (m <= 0.0) ? 0.0 : m;                   // run_prisim.py:2099-2100 (NaN stays NaN, as numpy's comparison leaves it)
+  }
+}
+
+// pb_out[s][c] = float32( 10 ** (work - colmax[c]) ) * fluxes[s][c]
+__global__ void k_extbeam_finish(const double* __restrict__ work, const double* __restrict__ colmax, const double* __restrict__ fluxes,
+                                 double* __restrict__ pb_out, int64_t nsrc, int64_t nchan) {
+  const int64_t total = nsrc * nchan;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i % nchan;
+    const double pb = (double)(float)exp10(work[i] - colmax[c]);      // :2101-2102 ; interferometry.py:4466 (float32 storage)
+    pb_out[i] = pb * fluxes[i];                                        // interferometry.py:6254
+  }
+}
+
+static unsigned grid_for_(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+hipError_t launch_extbeam_table(const double* beam, const double* interp, double* table, int64_t npix, int64_t nfreq,
+                                int64_t nchan, hipStream_t stream) {
+  hipLaunchKernelGGL(k_extbeam_table, dim3(grid_for_(npix * nchan)), dim3(256), 0, stream, beam, interp, table, npix, nfreq, nchan);
+  return hipGetLastError();
+}
+
+hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs, const double* fluxes, double* work,
+                              double* colmax_scratch, double* pb_out, int64_t nsrc, int64_t nchan, hipStream_t stream) {
+  if (nsrc == 0) return hipSuccess;
+  const unsigned gs = (unsigned)(nsrc < 16384 ? nsrc : 16384);
+  hipLaunchKernelGGL(k_extbeam_gather, dim3(gs), dim3(256), 0, stream, table, nside, dirs, work, nsrc, nchan);
+  const int nblk = (int)(nsrc < 1024 ? nsrc : 1024);
+  double* partial = colmax_scratch;
+  double* colmax = colmax_scratch + (size_t)1024 * nchan;
+  hipLaunchKernelGGL(k_colmax_partial, dim3(nblk), dim3(256), 0, stream, work, partial, nsrc, nchan);
+  hipLaunchKernelGGL(k_colmax_final, dim3(grid_for_(nchan)), dim3(256), 0, stream, partial, colmax, nblk, nchan);
+  hipLaunchKernelGGL(k_extbeam_finish, dim3(grid_for_(nsrc * nchan)), dim3(256), 0, stream, work, colmax, fluxes, pb_out, nsrc, nchan);
+  return hipGetLastError();
+}
+
 // ---- delay transform -----------------------------------------------------------------------
 // work[row][n] (complex128, nfft per row) = cube[row][n] * w[b][n] for n < nchan, else 0.
 __global__ void k_dt_prepare(const double2* __restrict__ cube, const double* __restrict__ bpwts,

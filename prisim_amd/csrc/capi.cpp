@@ -122,6 +122,9 @@ struct prisim_ctx {
   bool taper = false;
   double pc[3] = {0, 0, 1};
   DevBuf dirs, dirs_prep, pb, packed, partial, scratch;
+  // external beam
+  DevBuf ext_table, ext_work, ext_colmax;
+  int ext_nside = 0;
 
   // events / timing
   hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
@@ -316,7 +319,8 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->fft_plan && g_rocfft.plan_destroy) g_rocfft.plan_destroy(ctx->fft_plan);
   if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->cube, &ctx->grad, &ctx->dirs,
-                    &ctx->dirs_prep, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf,
+                    &ctx->dirs_prep, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
+                    &ctx->ext_work, &ctx->ext_colmax,
                     &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts})
     release(*b);
   for (hipEvent_t ev : {ctx->ev_c0, ctx->ev_c1, ctx->ev_k0, ctx->ev_k1})
@@ -337,6 +341,7 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->array_set = false;
   ctx->sky_set = false;
+  ctx->ext_nside = 0;   // the external-beam table is per channel grid
   std::vector<double> x(nbl), y(nbl), z(nbl);
   for (int64_t b = 0; b < nbl; ++b) {
     x[b] = bl_enu[3 * b]; y[b] = bl_enu[3 * b + 1]; z[b] = bl_enu[3 * b + 2];
@@ -513,6 +518,69 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     release(fr); release(sp);
+    HIPCHK(ctx, e);
+  }
+  ctx->sky_set = true;
+  return PRISIM_OK;
+}
+
+int prisim_hip_set_external_beam(prisim_ctx* ctx, const double* beam, int64_t npix, int64_t nfreq, const double* interp_matrix) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_external_beam");
+  if (!beam || !interp_matrix) return fail(ctx, PRISIM_EINVAL, "beam / interp_matrix is NULL");
+  if (npix < 12 || nfreq < 1) return fail(ctx, PRISIM_EINVAL, "npix must be 12*nside^2 and nfreq >= 1");
+  const int64_t nside = (int64_t)std::llround(std::sqrt((double)npix / 12.0));
+  if (12 * nside * nside != npix || nside > (1 << 13)) return fail(ctx, PRISIM_EINVAL, "npix is not 12*nside^2");
+  for (int64_t i = 0; i < npix * nfreq; ++i)
+    if (!(beam[i] > 0.0) || !std::isfinite(beam[i]))
+      return fail(ctx, PRISIM_EINVAL, "external beam values must be finite and > 0 (log10 is interpolated, run_prisim.py:2094)");
+  for (int64_t i = 0; i < ctx->nchan * nfreq; ++i)
+    if (!std::isfinite(interp_matrix[i])) return fail(ctx, PRISIM_EINVAL, "non-finite spectral interpolation weight");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->ext_nside = 0;
+  DevBuf dbeam, dm;
+  int rc;
+  if ((rc = ensure(ctx, dbeam, (size_t)npix * nfreq * sizeof(double))) || (rc = ensure(ctx, dm, (size_t)ctx->nchan * nfreq * sizeof(double))) ||
+      (rc = ensure(ctx, ctx->ext_table, (size_t)npix * ctx->nchan * sizeof(double)))) {
+    release(dbeam); release(dm);
+    return rc;
+  }
+  hipError_t e = hipMemcpyAsync(dbeam.p, beam, (size_t)npix * nfreq * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dm.p, interp_matrix, (size_t)ctx->nchan * nfreq * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = launch_extbeam_table((const double*)dbeam.p, (const double*)dm.p, (double*)ctx->ext_table.p, npix, nfreq, ctx->nchan, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  release(dbeam); release(dm);
+  HIPCHK(ctx, e);
+  ctx->ext_nside = (int)nside;
+  return PRISIM_OK;
+}
+
+int prisim_hip_set_sky_external(prisim_ctx* ctx, const prisim_sky* sky) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_external");
+  if (ctx->ext_nside <= 0) return fail(ctx, PRISIM_ESTATE, "set_external_beam must be called before set_sky_external");
+  if (sky->pbflux) return fail(ctx, PRISIM_EINVAL, "pbflux must be NULL: the beam comes from the external table");
+  if (sky->nsrc > 0 && !sky->fluxes) return fail(ctx, PRISIM_EINVAL, "fluxes is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->sky_set = false;
+  int rc = upload_common(ctx, sky->nsrc, sky->dircos, sky->pc_dircos, sky->fwhm_deg);
+  if (rc) return rc;
+  const int64_t n = sky->nsrc * ctx->nchan;
+  if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+  if (n > 0) {
+    DevBuf fl;
+    if ((rc = ensure(ctx, fl, (size_t)n * sizeof(double))) || (rc = ensure(ctx, ctx->ext_work, (size_t)n * sizeof(double))) ||
+        (rc = ensure(ctx, ctx->ext_colmax, (size_t)1025 * ctx->nchan * sizeof(double)))) {
+      release(fl);
+      return rc;
+    }
+    hipError_t e = hipMemcpyAsync(fl.p, sky->fluxes, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+      e = launch_extbeam_sky((const double*)ctx->ext_table.p, ctx->ext_nside, (const double*)ctx->dirs.p, (const double*)fl.p,
+                             (double*)ctx->ext_work.p, (double*)ctx->ext_colmax.p, (double*)ctx->pb.p, sky->nsrc, ctx->nchan, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release(fl);
     HIPCHK(ctx, e);
   }
   ctx->sky_set = true;

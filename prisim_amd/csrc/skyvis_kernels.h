@@ -74,6 +74,12 @@ struct BeamParams {
 };
 hipError_t launch_beam_flux(const BeamParams& p, hipStream_t stream);
 hipError_t launch_mul_inplace(double* a, const double* b, int64_t n, hipStream_t stream);
+// external HEALPix beam (aux_kernels.hip)
+hipError_t launch_extbeam_table(const double* beam, const double* interp, double* table, int64_t npix, int64_t nfreq,
+                                int64_t nchan, hipStream_t stream);
+hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs, const double* fluxes, double* work /*[nsrc][nchan]*/,
+                              double* colmax_scratch /*[1024*nchan + nchan]*/, double* pb_out, int64_t nsrc, int64_t nchan,
+                              hipStream_t stream);
 
 // delay transform helpers (delay_kernels.hip)
 hipError_t launch_dt_prepare(const double* cube, const double* bpwts, double* work, int64_t nrows, int64_t nbl,

@@ -43,7 +43,7 @@ DEFAULTS = {
     'baseline': {'min': None, 'max': None, 'direction': None},
     'antenna': {'shape': 'dish', 'size': 14.0, 'orientation': [90.0, 270.0], 'ocoords': 'altaz', 'phased_array': False,
                 'ground_plane': None},
-    'beam': {'use_external': False},
+    'beam': {'use_external': False, 'file': None, 'filefmt': 'npz', 'chromatic': True, 'select_freq': None, 'spec_interp': 'cubic'},
     'bandpass': {'freq': 150e6, 'freq_resolution': 390625.0, 'nchan': 256},
     'obsparm': {'obs_date': '2015/11/23', 'obs_mode': 'drift', 't_obs': None, 'n_acc': 2, 't_acc': 1080.0},
     'pointing': {'file': None, 'jd_init': None, 'lst_init': 0.0,
@@ -187,6 +187,25 @@ def build_skymodel(parms, infile_dir):
                        src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1), epoch='J' + str(sp['epoch']))
 
 
+def load_external_beam(parms, infile_dir):
+    """External beam file -> (beam [npix, nfreq], freqs_hz).  The reference reads FITS / HDF5 / UVBeam files
+    (run_prisim.py:489-520; astropy / h5py / pyuvdata, none of which exist offline); the layout kept here is the HDF5
+    one (gain_info/<pol> = nfreq x npix, spectral_info/freqs in Hz, FEKO_beam_to_healpix.py:161-198) stored as .npz:
+    keys 'beam' (npix, nfreq) or 'gain_info' (nfreq, npix), and 'freqs' (Hz)."""
+    bm = parms['beam']
+    if str(bm.get('filefmt', 'npz')).lower() != 'npz':
+        raise NotImplementedError('beam.filefmt {0!r}: only the npz container can be read without astropy/h5py/pyuvdata'.format(bm.get('filefmt')))
+    path = bm['file']
+    if path is None:
+        raise ValueError('beam.file must be given when beam.use_external is true')
+    if not os.path.isabs(path):
+        path = os.path.join(infile_dir, path)
+    with NP.load(path) as f:
+        beam = f['beam'] if 'beam' in f.files else f['gain_info'].T
+        freqs = f['freqs']
+    return NP.asarray(beam, dtype=NP.float64), NP.asarray(freqs, dtype=NP.float64)
+
+
 def window(nchan, shape):
     """Frequency window for the delay transform (DSP.windowing, astroutils: unpinned).  area-normalised to mean 1."""
     n = NP.arange(nchan)
@@ -243,8 +262,9 @@ def schedule(parms):
 def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose=True):
     """Simulate the observation described by `parms` on this rank's GPU.  Returns a dict with the (gathered) visibility
     cube (nbl, nchan, n_acc), baselines, labels, channels, lst, timestamps and timing."""
+    extbeam = None
     if parms['beam'].get('use_external'):
-        raise NotImplementedError('external HEALPix beams (run_prisim.py:1897-1908) are the next row (SURVEY.md 8(f) N1)')
+        extbeam = load_external_beam(parms, infile_dir)
     if parms['pp']['key'] != 'bl':
         raise NotImplementedError("pp.key must be 'bl': baselines are the natural shard axis on GPUs (SURVEY.md 2.2)")
     bp = parms['bandpass']
@@ -266,6 +286,10 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
                                 latitude=tel['latitude'], longitude=tel['longitude'], altitude=tel['altitude'],
                                 skycoords='radec', A_eff=parms['telescope']['A_eff'], pointing_coords='hadec', device=device)
     ia.reserve(n_acc)
+    if extbeam is not None:
+        bm = parms['beam']
+        ia.set_external_beam(extbeam[0], extbeam[1], spec_interp=bm.get('spec_interp', 'cubic'), chromatic=bool(bm.get('chromatic', True)),
+                             select_freq=bm.get('select_freq'))
     tp = parms['telescope']
     if tp.get('Tsys') is not None:
         tsysinfo = {'Tnet': float(tp['Tsys'])}

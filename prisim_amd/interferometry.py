@@ -210,6 +210,19 @@ class InterferometerArray(object):
             raise RuntimeError('reserve() must be called before the first observe()')
         self._ctx.set_array(self.baselines, self.channels, nt_max=n_acc)
         self._reserved = n_acc
+        self._restore_external_beam()
+
+    def set_external_beam(self, beam, beam_freqs_hz, spec_interp='cubic', chromatic=True, select_freq=None):
+        """Use a tabulated HEALPix (RING, local zenith-angle/azimuth frame) power beam [npix, nfreq] for all following
+        observe() calls that do not pass roi_info (scripts/run_prisim.py:489-494, 2091-2103: interpolation of log10(beam) in
+        frequency and on the sphere, per-channel peak normalisation, float32 storage) -- evaluated on the GPU per snapshot."""
+        m = PB.spectral_interp_matrix(beam_freqs_hz, self.channels, kind=spec_interp, chromatic=chromatic, select_freq=select_freq)
+        self._ctx.set_external_beam(beam, m)
+        self._extbeam = (NP.asarray(beam), m)
+
+    def _restore_external_beam(self):
+        if getattr(self, '_extbeam', None) is not None:
+            self._ctx.set_external_beam(*self._extbeam)
 
     def allgather(self, comm_uid, nranks, rank):
         """One RCCL all-gather of the baseline shards of all ranks (equal shard sizes; replaces the reference's per-rank
@@ -421,6 +434,8 @@ class InterferometerArray(object):
             if pb is not None:
                 # supplied beam (ROI_parameters path): pbfluxes = pb * fluxes on the device (:6254)
                 self._ctx.set_sky(dircos_roi, pb, pc_dircos, fwhm_deg=fwhm, fluxes=fluxes)
+            elif getattr(self, '_extbeam', None) is not None:
+                self._ctx.set_sky_external(dircos_roi, fluxes, pc_dircos, fwhm_deg=fwhm)
             else:
                 kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz)  # :6252
                 self._ctx.set_sky_analytic(dircos_roi, None, None, None, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,

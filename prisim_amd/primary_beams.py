@@ -144,3 +144,27 @@ def primary_beam_generator(skypos, frequency, telescope, freq_scale='GHz', skyun
         ctx.set_array(NP.zeros((1, 3)), frequency, nt_max=1)
         ctx.set_sky_analytic(dircos, NP.ones(nsrc), NP.zeros(nsrc), 1.0, kind, dia, bpc, NP.array([0.0, 0.0, 1.0]), ext=ext)
         return ctx.get_pbflux()
+
+
+def spectral_interp_matrix(beam_freqs_hz, chans_hz, kind='cubic', chromatic=True, select_freq=None):
+    """(nchan, nfreq) linear operator that resamples an external beam's frequency axis onto the channel grid, to be applied
+    on the device to log10(beam) (prisim_hip_set_external_beam).  chromatic: scipy interp1d of the given kind applied to unit
+    vectors (the interpolation is linear in the data; scripts/run_prisim.py:2094); achromatic: the single tabulated
+    frequency nearest to select_freq is used for every channel (:2096-2097)."""
+    bf = NP.asarray(beam_freqs_hz, dtype=NP.float64).ravel()
+    ch = NP.asarray(chans_hz, dtype=NP.float64).ravel()
+    if not chromatic:
+        if select_freq is None:
+            raise ValueError('select_freq is needed for an achromatic external beam')
+        m = NP.zeros((ch.size, bf.size))
+        m[:, int(NP.argmin(NP.abs(bf - select_freq)))] = 1.0
+        return m
+    if bf.size == 1:
+        return NP.ones((ch.size, 1))
+    if NP.any(NP.diff(bf) <= 0):
+        raise ValueError('external beam frequencies must be strictly increasing')
+    need = {'linear': 2, 'quadratic': 3, 'cubic': 4}.get(kind, 2)
+    if bf.size < need:
+        kind = 'linear'
+    from scipy.interpolate import interp1d
+    return interp1d(bf, NP.eye(bf.size), kind=kind, axis=0, bounds_error=False, fill_value='extrapolate', assume_sorted=True)(ch)

@@ -89,6 +89,7 @@ def test_unsupported_modes_fail_loudly():
         driver.run(p)
     p['pp']['key'] = 'bl'
     p['beam']['use_external'] = True
+    p['beam']['filefmt'] = 'uvbeam'
     with pytest.raises(NotImplementedError):
         driver.run(p)
 

@@ -244,3 +244,60 @@ def test_device_dipole_array_ground_beams_match_reference_golden(ctx):
         ctx.set_sky_analytic(dc, one, zero, 150e6, _abi.PRISIM_BEAM_DIPOLE, 0.74, zen, zen)       # dipole without ext
     with pytest.raises(ValueError):
         ctx.set_sky_analytic(dc, one, zero, 150e6, _abi.PRISIM_BEAM_DELTA, 0.0, zen, zen, ext={'array': {'nax1': 4, 'nax2': 0, 'sep1': 1.1, 'sep2': 1.1}})
+
+
+def _synthetic_external_beam(nside, bf):
+    from prisim_amd import geometry as GEOM
+    th, ph = GEOM.healpix_pix2ang_ring(nside)
+    rng = NP.random.default_rng(40)
+    base = NP.cos(NP.clip(th, 0, NP.pi / 2)) ** 2 * (1 + 0.2 * NP.cos(2 * ph)) + 1e-4
+    return base[:, None] * (1 + 0.3 * (bf[None, :] / 150e6 - 1)) * NP.exp(0.05 * rng.normal(size=(th.size, bf.size)))
+
+
+@pytest.mark.parametrize('kind,chromatic', [('cubic', True), ('linear', True), ('cubic', False)])
+def test_device_external_healpix_beam_matches_restatement(ctx, kind, chromatic):
+    from oracle import healpix_oracle as H
+    cfg = W.config2()
+    ch, sky = cfg['channels'][::4], cfg['sky']
+    bf = NP.linspace(100e6, 200e6, 21)
+    beam = _synthetic_external_beam(8, bf)
+    theta = NP.pi / 2 - NP.radians(sky['altaz'][:, 0])
+    phi = NP.radians(sky['altaz'][:, 1])
+    flux = sky['flux_ref'][:, None] * (ch[None, :] / sky['ref_freq']) ** sky['spindex'][:, None]
+    ctx.set_array(cfg['baselines'], ch)
+    ctx.set_external_beam(beam, PB.spectral_interp_matrix(bf, ch, kind=kind, chromatic=chromatic, select_freq=152e6))
+    zen = NP.array([0.0, 0.0, 1.0])
+    ctx.set_sky_external(sky['dircos'], flux, zen, fwhm_deg=sky['fwhm_deg'])
+    pb_ref = H.external_beam(beam, bf, theta, phi, ch, kind=kind, chromatic=chromatic, select_freq=152e6)
+    got = ctx.get_pbflux()
+    # float32 quantisation of the beam (interferometry.py:4466): values within one float32 ulp of the restatement
+    assert NP.max(NP.abs(got - pb_ref * flux) / (pb_ref * flux + 1e-300)) <= 1.3e-7
+    ctx.compute()
+    ref = O.skyvis(cfg['baselines'], ch, sky['dircos'], got, zen, fwhm_deg=sky['fwhm_deg'])
+    assert NP.max(NP.abs(ctx.get_vis() - ref) / O.abs_flux_sum(got)[None, :]) <= 1e-11
+    with pytest.raises(ValueError):
+        ctx.set_external_beam(-beam, NP.zeros((ch.size, bf.size)))
+    with pytest.raises(ValueError):
+        ctx.set_external_beam(beam[:100], NP.zeros((ch.size, bf.size)))
+
+
+def test_interferometer_array_with_external_beam():
+    from oracle import healpix_oracle as H
+    cfg = W.config2()
+    bl, ch, sky = cfg['baselines'][::5], cfg['channels'][:32], cfg['sky']
+    n = sky['dircos'].shape[0]
+    bf = NP.linspace(120e6, 180e6, 13)
+    beam = _synthetic_external_beam(8, bf)
+    skymod = SM.SkyModel(location=sky['altaz'], flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'])
+    ia = RI.InterferometerArray(['b%d' % i for i in range(bl.shape[0])], bl, ch, telescope={'id': 'mwa'}, latitude=-26.7, skycoords='altaz')
+    ia.reserve(2)
+    ia.set_external_beam(beam, bf, spec_interp='cubic')
+    for j in range(2):
+        ia.observe((2457000.5 + j, 10.0 * j), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, -26.7], skymod, 112.0)
+    pb = H.external_beam(beam, bf, NP.pi / 2 - NP.radians(sky['altaz'][:, 0]), NP.radians(sky['altaz'][:, 1]), ch) * skymod.generate_spectrum(frequency=ch)
+    ref = O.skyvis(bl, ch, sky['dircos'], pb, NP.array([0.0, 0.0, 1.0]))
+    scale = O.abs_flux_sum(pb)[None, :]
+    assert ia.skyvis_freq.shape == (bl.shape[0], 32, 2)
+    # the float32-rounded beam differs from the double restatement by <= 6e-8 relative per source
+    assert NP.max(NP.abs(ia.skyvis_freq[:, :, 0] - ref) / scale) <= 2e-7
+    assert NP.array_equal(ia.skyvis_freq[:, :, 0], ia.skyvis_freq[:, :, 1])          # sky fixed in the local frame (skycoords='altaz')

@@ -100,3 +100,47 @@ def test_kat8_delay_transform_tone():
         assert abs(abs(lag[0, ipk, 0]) - 2.0 * nchan * df) <= 1e-6 * nchan * df
     # lags are fftshift(fftfreq)
     assert NP.allclose(lags, NP.fft.fftshift(NP.fft.fftfreq(nchan, df)))
+
+
+def test_kat9_healpix_bilinear_interpolation():
+    """healpy.get_interp_val restatement: exact at pixel centres, partition of unity, second-order convergence, poles."""
+    from oracle import healpix_oracle as H
+    from prisim_amd import geometry as GEOM
+    rng = NP.random.default_rng(9)
+    t = NP.arccos(rng.uniform(-1, 1, 3000))
+    p = rng.uniform(0, 2 * NP.pi, 3000)
+    f = lambda th, ph: 1 + 0.5 * NP.cos(th) + 0.3 * NP.sin(th) * NP.cos(ph)
+    errs = []
+    for nside in (2, 4, 8, 16, 32):
+        th, ph = GEOM.healpix_pix2ang_ring(nside)
+        m = rng.normal(size=th.size)
+        assert NP.max(NP.abs(H.get_interp_val(m, th, ph) - m)) <= 1e-10          # pixel centres reproduce the map
+        pix, w = H.get_interp_weights(nside, t, p)
+        assert NP.max(NP.abs(w.sum(0) - 1)) <= 1e-14 and w.min() >= -1e-15 and pix.min() >= 0 and pix.max() < th.size
+        assert NP.max(NP.abs(H.get_interp_val(NP.full(th.size, 3.5), t, p) - 3.5)) <= 1e-14
+        errs.append(NP.max(NP.abs(H.get_interp_val(f(th, ph), t, p) - f(t, p))))
+    assert all(e2 < 0.6 * e1 for e1, e2 in zip(errs, errs[1:])) and errs[-1] < errs[0] / 40   # ~ h^2
+    pix, w = H.get_interp_weights(4, [0.0, NP.pi], [0.3, 0.3])
+    assert sorted(pix[:, 0]) == [0, 1, 2, 3] and sorted(pix[:, 1]) == [188, 189, 190, 191] and NP.allclose(w, 0.25)
+
+
+def test_kat10_external_beam_normalisation_and_spectral_matrix():
+    from oracle import healpix_oracle as H
+    from prisim_amd import geometry as GEOM, primary_beams as PB
+    nside = 8
+    th, ph = GEOM.healpix_pix2ang_ring(nside)
+    bf = NP.linspace(100e6, 200e6, 11)
+    beam = (NP.cos(th / 2)[:, None] ** 4 + 1e-3) * (1 + 0.3 * (bf[None, :] / 150e6 - 1)) * 7.0      # peak 7 at the zenith pixel ring
+    ch = 150e6 + (NP.arange(16) - 8) * 1e6
+    srct = NP.radians([0.0, 10.0, 45.0, 80.0]); srcp = NP.radians([0.0, 33.0, 120.0, 300.0])
+    pb = H.external_beam(beam, bf, srct, srcp, ch, kind='cubic')
+    assert pb.shape == (4, 16) and NP.allclose(pb[0], 1.0, atol=1e-6)           # peak-normalised per channel over the sources
+    assert NP.all(NP.diff(pb[:, 3]) < 0)                                        # falls with zenith angle
+    m = PB.spectral_interp_matrix(bf, ch, kind='cubic')
+    from scipy.interpolate import interp1d
+    y = NP.log10(beam[5])
+    assert NP.max(NP.abs(m @ y - interp1d(bf, y, kind='cubic')(ch))) <= 1e-13
+    ma = PB.spectral_interp_matrix(bf, ch, chromatic=False, select_freq=151e6)
+    assert NP.all(ma.sum(1) == 1) and NP.all(ma[:, 5] == 1)
+    pba = H.external_beam(beam, bf, srct, srcp, ch, chromatic=False, select_freq=151e6)
+    assert NP.allclose(pba, pba[:, [0]])                                        # achromatic: same in every channel
