@@ -11,8 +11,9 @@ HERA-350 x 1024-channel x 1e4-source workload (SURVEY.md 8(d) config 3, fp32 wit
 A "step" is one snapshot: one pass of the hot path (prep + pack + sky-sum kernel) over the whole
 sky with all inputs already resident in HBM.  With N > 1 the baselines are sharded in contiguous
 blocks (one process per GPU, the reference's pp.key='bl' model, scripts/run_prisim.py:1775-1791),
-each rank writes snapshot t into slot t of its shard of the visibility cube, and the single
-RCCL all-gather of the cube at the end of the run is INSIDE the timed region.  The total workload is
+each rank writes snapshot t into slot t of its shard of the visibility cube, and the RCCL all-gather
+of the cube (issued per snapshot on a second HIP stream so that it overlaps the next snapshot's compute) is
+INSIDE the timed region.  The total workload is
 fixed as N grows ("scaling": "strong").  torch is used only for the multi-process rendezvous
 (gloo barrier / max-reduce / unique-id broadcast); all GPU work goes through libprisim_hip.so.
 
@@ -98,6 +99,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')      # single node: RCCL bootstraps over loopback
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
 
     def barrier():
@@ -124,10 +126,11 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], world, rank)
 
+    c64 = (prec == _abi.PRISIM_FP32)
     for i in range(Wm):
         ctx.compute(precision=prec, slot=i % K)
-    if world > 1 and Wm > 0:
-        ctx.allgather(K, complex64=(prec == _abi.PRISIM_FP32))
+        if world > 1:
+            ctx.allgather_slot_async(i % K, complex64=c64)
     ctx.sync()
     ctx.timing(reset=True)
 
@@ -136,8 +139,10 @@ def main():
     t0 = time.perf_counter()
     for t in range(K):
         ctx.compute(precision=prec, slot=t)
-    if world > 1:
-        ctx.allgather(K, complex64=(prec == _abi.PRISIM_FP32))
+        if world > 1:
+            # RCCL all-gather of snapshot t on the communication stream, overlapped with the sky-sum of snapshot t+1;
+            # only the last snapshot's exchange is exposed.  Still inside the timed region.
+            ctx.allgather_slot_async(t, complex64=c64)
     ctx.sync()
     barrier()
     t1 = time.perf_counter()
@@ -152,7 +157,7 @@ def main():
     gather_ok = None
     if world > 1:
         # every rank must hold the same gathered cube: compare device checksums
-        cs = ctx.gathered_checksum(K, complex64=(prec == _abi.PRISIM_FP32))
+        cs = ctx.gathered_checksum(K, complex64=c64)
         import torch
         allcs = [None] * world
         dist.all_gather_object(allcs, cs)

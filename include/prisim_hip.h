@@ -186,12 +186,17 @@ int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts,
 int prisim_hip_comm_unique_id(char id[128]);
 int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int rank);
 /* All-gather the local cube (equal-sized baseline shards, [nt][nbl_shard][nchan]) into a device cube
- * [nranks][nt][nbl_shard][nchan] held by the context.  as_c64 = 0: complex128 on the wire; 1: the
+ * [nt][nranks][nbl_shard][nchan] held by the context (snapshot-major: every snapshot's full baseline set is
+ * contiguous, rank blocks in rank order).  as_c64 = 0: complex128 on the wire; 1: the
  * shard is first rounded to complex64 on the device (the reference's memsave dtype, :6183) and
  * half the bytes cross xGMI.  Replaces the reference's per-rank _part_i.hdf5 files + rank-0
  * concatenate (scripts/run_prisim.py:2207, 2233-2242).  Asynchronous on the context stream. */
 int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt, int as_c64);
-/* Copy the gathered cube to the host: out [nranks][nt][nbl_shard][nchan], complex128 or complex64
+/* Same exchange for ONE snapshot slot, enqueued on a second HIP stream behind everything issued so far on the
+ * compute stream: the RCCL transfer of snapshot t overlaps the sky-sum of snapshot t+1 (xGMI copies beside VALU work).
+ * prisim_hip_sync / _get_gathered / _gathered_checksum wait for it. */
+int prisim_hip_allgather_slot_async(prisim_ctx* ctx, int64_t slot, int as_c64);
+/* Copy the gathered cube to the host: out [nt][nranks][nbl_shard][nchan], complex128 or complex64
  * according to the as_c64 of the last allgather. */
 int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out);
 /* Checksum (sum of all re,im accumulated in double, fixed reduction order) of the gathered cube,

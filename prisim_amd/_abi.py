@@ -25,7 +25,7 @@ EXPORTS = (
     'prisim_hip_skyvis', 'prisim_hip_set_vis', 'prisim_hip_set_sky_analytic',
     'prisim_hip_set_external_beam', 'prisim_hip_set_sky_external', 'prisim_hip_get_pbflux',
     'prisim_hip_delay_transform', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
-    'prisim_hip_allgather', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
+    'prisim_hip_allgather', 'prisim_hip_allgather_slot_async', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
 )
 
@@ -130,6 +130,7 @@ def load_library():
     lib.prisim_hip_comm_unique_id.argtypes = [C.c_char_p]
     lib.prisim_hip_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     lib.prisim_hip_allgather.argtypes = [vp, i64, i32]
+    lib.prisim_hip_allgather_slot_async.argtypes = [vp, i64, i32]
     lib.prisim_hip_get_gathered.argtypes = [vp, i64, vp]
     lib.prisim_hip_gathered_checksum.argtypes = [vp, i64, C.POINTER(dbl)]
     lib.prisim_hip_sync.argtypes = [vp]
@@ -371,9 +372,16 @@ class Context(object):
         self._check(self._lib.prisim_hip_allgather(self._h, int(nt), 1 if complex64 else 0), 'prisim_hip_allgather')
         self._gathered_c64 = bool(complex64)
 
+    def allgather_slot_async(self, slot, complex64=False):
+        """Gather one snapshot on the communication stream, overlapping later compute() calls."""
+        self._check(self._lib.prisim_hip_allgather_slot_async(self._h, int(slot), 1 if complex64 else 0),
+                    'prisim_hip_allgather_slot_async')
+        self._gathered_c64 = bool(complex64)
+
     def get_gathered(self, nt, nranks=None):
+        """(nt, nranks, nbl_shard, nchan): snapshot-major, rank blocks in rank order."""
         nranks = getattr(self, 'nranks', 1) if nranks is None else nranks
-        out = NP.empty((nranks, nt, self.nbl, self.nchan), dtype=NP.complex64 if getattr(self, '_gathered_c64', False) else NP.complex128)
+        out = NP.empty((nt, nranks, self.nbl, self.nchan), dtype=NP.complex64 if getattr(self, '_gathered_c64', False) else NP.complex128)
         self._check(self._lib.prisim_hip_get_gathered(self._h, int(nt), _ptr(out)), 'prisim_hip_get_gathered')
         return out
 

@@ -136,6 +136,9 @@ struct prisim_ctx {
 
   // comm
   ncclComm_t comm = nullptr;
+  hipStream_t comm_stream = nullptr;     // all-gathers overlapped with the next snapshot's compute
+  hipEvent_t ev_slot_done = nullptr;
+  bool comm_pending = false;
   int nranks = 1, rank = 0;
   DevBuf gathered, sendbuf;
   bool gathered_c64 = false;
@@ -251,20 +254,10 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
     if (base < 1024) {
       nsplit = (int)std::min<int64_t>((1024 + base - 1) / base, nchunks);
       if (nsplit > 64) nsplit = 64;
-    } else {
-      // Large problems: the grid runs in rounds of (CUs x resident blocks per CU) blocks; a partly
-      // filled last round idles the chip (3824 blocks on 512 slots = 7.47 rounds -> 6.6 % lost).
-      // Splitting the sources 2-4 ways multiplies the number of (shorter) blocks, which shrinks the
-      // tail; the partial cubes are reduced afterwards (k_reduce_partials).
-      const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * (pl.pk ? 2 : (pl.f32 ? 4 : 2));
-      double best_eff = 0.0;
-      for (int cand = 1; cand <= 4; ++cand) {
-        if (cand > nchunks) break;
-        const double rounds = (double)(base * cand) / (double)slots;
-        const double eff = rounds / std::ceil(rounds) - 0.004 * (cand - 1);   // small penalty: partial-cube traffic
-        if (eff > best_eff + 1e-9) { best_eff = eff; nsplit = cand; }
-      }
     }
+    // Large problems keep nsplit = 1: splitting the sources to shorten the last, partly filled round of blocks
+    // (3824 blocks on 512 slots = 7.47 rounds) was measured at +1.5 % only and costs two extra passes over the
+    // cube (partial slabs + reduce), i.e. 3x the algorithmic HBM traffic.
   }
   if (nsplit > nchunks) nsplit = (int)nchunks;
   if (nsplit < 1) nsplit = 1;
@@ -315,7 +308,10 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+  if (ctx->ev_slot_done) (void)hipEventDestroy(ctx->ev_slot_done);
+  if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
   if (ctx->fft_plan && g_rocfft.plan_destroy) g_rocfft.plan_destroy(ctx->fft_plan);
   if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->cube, &ctx->grad, &ctx->dirs,
@@ -372,6 +368,8 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   for (int64_t k = 0; k < nchan; ++k)
     if (std::fabs(freqs_hz[k] - (ctx->f0 + (double)k * ctx->df)) > 1e-7) { ctx->uniform = false; break; }
   release(ctx->grad);
+  release(ctx->gathered);
+  release(ctx->sendbuf);
   ctx->array_set = true;
   return PRISIM_OK;
 }
@@ -614,7 +612,10 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   p.taper = ctx->taper ? 1 : 0;
   p.ntiles = pl.ntiles; p.nbgroups = pl.nbgroups; p.nsplit = pl.nsplit; p.src_per_split = pl.src_per_split;
   p.src_chunk = pl.chunk;
-  p.flush_src = 4096;
+  // fp32 accumulators are flushed into the fp64 cube every flush_src sources: the rounding error of a sequential
+  // fp32 sum grows like eps/2*sqrt(n/3) relative to sum|pbflux| in the fully coherent worst case (1.1e-6 at n = 16384,
+  // tolerance 5e-6), and every flush is a read-modify-write pass over the whole cube, so flush as rarely as that allows.
+  p.flush_src = 16384;
   p.scale_comp = scale_comp;
   if (pl.kernel == PRISIM_KERNEL_DIRECT) {
     p.out = dst;
@@ -753,6 +754,7 @@ int prisim_hip_sync(prisim_ctx* ctx) {
   if (!ctx) return PRISIM_EINVAL;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream && ctx->comm_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
   harvest_timing(ctx);
   return PRISIM_OK;
 }
@@ -896,29 +898,72 @@ int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int ra
   return PRISIM_OK;
 }
 
+// Gather cube slot `slot` of every rank into gathered[slot][rank][b][f] on stream `st`.
+static int gather_one_slot(prisim_ctx* ctx, int64_t slot, int as_c64, hipStream_t st) {
+  const size_t shard = (size_t)ctx->nbl * ctx->nchan * 2;   // reals per snapshot shard
+  const size_t esz = as_c64 ? sizeof(float) : sizeof(double);
+  const double* src = (const double*)ctx->cube.p + (size_t)slot * shard;
+  const void* send = src;
+  if (as_c64) {
+    float* sb = (float*)ctx->sendbuf.p + (size_t)slot * shard;
+    HIPCHK(ctx, launch_f64_to_f32(src, sb, (int64_t)shard, st));
+    send = sb;
+  }
+  char* dst = (char*)ctx->gathered.p + (size_t)slot * shard * (size_t)ctx->nranks * esz;
+  if (ctx->nranks == 1 && !ctx->comm) {
+    HIPCHK(ctx, hipMemcpyAsync(dst, send, shard * esz, hipMemcpyDeviceToDevice, st));
+    return PRISIM_OK;
+  }
+  if (!ctx->comm) return fail(ctx, PRISIM_ESTATE, "comm_init has not been called");
+  ncclResult_t r = g_rccl.AllGather(send, dst, shard, as_c64 ? ncclFloat : ncclDouble, ctx->comm, st);
+  if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+  return PRISIM_OK;
+}
+
+static int ensure_gather_buffers(prisim_ctx* ctx, int as_c64) {
+  const size_t shard = (size_t)ctx->nbl * ctx->nchan * 2;
+  const size_t esz = as_c64 ? sizeof(float) : sizeof(double);
+  int rc;
+  if (ctx->gathered.p && ctx->gathered_c64 != (as_c64 != 0)) release(ctx->gathered);
+  if ((rc = ensure(ctx, ctx->gathered, shard * (size_t)ctx->nt_max * (size_t)ctx->nranks * esz))) return rc;
+  if (as_c64 && (rc = ensure(ctx, ctx->sendbuf, shard * (size_t)ctx->nt_max * sizeof(float)))) return rc;
+  ctx->gathered_c64 = as_c64 != 0;
+  return PRISIM_OK;
+}
+
 int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt, int as_c64) {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
   if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  const size_t shard = (size_t)nt * ctx->nbl * ctx->nchan * 2;   // reals
-  const size_t esz = as_c64 ? sizeof(float) : sizeof(double);
   int rc;
-  if ((rc = ensure(ctx, ctx->gathered, shard * (size_t)ctx->nranks * esz))) return rc;
-  const void* send = ctx->cube.p;
-  if (as_c64) {
-    if ((rc = ensure(ctx, ctx->sendbuf, shard * sizeof(float)))) return rc;
-    HIPCHK(ctx, launch_f64_to_f32((const double*)ctx->cube.p, (float*)ctx->sendbuf.p, (int64_t)shard, ctx->stream));
-    send = ctx->sendbuf.p;
+  if ((rc = ensure_gather_buffers(ctx, as_c64))) return rc;
+  for (int64_t t = 0; t < nt; ++t)
+    if ((rc = gather_one_slot(ctx, t, as_c64, ctx->stream))) return rc;
+  return PRISIM_OK;
+}
+
+int prisim_hip_allgather_slot_async(prisim_ctx* ctx, int64_t slot, int as_c64) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (slot < 0 || slot >= ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "slot out of range");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if (!ctx->comm_stream) {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_slot_done, hipEventDisableTiming));
   }
-  ctx->gathered_c64 = as_c64 != 0;
-  if (ctx->nranks == 1 && !ctx->comm) {
-    HIPCHK(ctx, hipMemcpyAsync(ctx->gathered.p, send, shard * esz, hipMemcpyDeviceToDevice, ctx->stream));
-    return PRISIM_OK;
+  if (!ctx->gathered.p || ctx->gathered_c64 != (as_c64 != 0)) {
+    // (re)allocation must not race with gathers in flight
+    HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream));
+    if ((rc = ensure_gather_buffers(ctx, as_c64))) return rc;
   }
-  if (!ctx->comm) return fail(ctx, PRISIM_ESTATE, "comm_init has not been called");
-  ncclResult_t r = g_rccl.AllGather(send, ctx->gathered.p, shard, as_c64 ? ncclFloat : ncclDouble, ctx->comm, ctx->stream);
-  if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+  // the gather of slot t waits for everything enqueued so far on the compute stream (i.e. compute(slot t)) ...
+  HIPCHK(ctx, hipEventRecord(ctx->ev_slot_done, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_slot_done, 0));
+  // ... and runs on the communication stream, overlapping the next snapshot's compute
+  if ((rc = gather_one_slot(ctx, slot, as_c64, ctx->comm_stream))) return rc;
+  ctx->comm_pending = true;
   return PRISIM_OK;
 }
 
@@ -931,6 +976,7 @@ int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out) {
   const size_t bytes = (size_t)nt * ctx->nbl * ctx->nchan * 2 * (size_t)ctx->nranks * esz;
   if (nt <= 0 || bytes > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt does not match the gathered cube");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
   HIPCHK(ctx, hipMemcpy(out, ctx->gathered.p, bytes, hipMemcpyDeviceToHost));
   return PRISIM_OK;
 }
@@ -945,6 +991,7 @@ int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out) {
   if (nt <= 0 || (size_t)n * esz > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt does not match the gathered cube");
   int rc;
   if ((rc = ensure(ctx, ctx->scratch, 1025 * sizeof(double)))) return rc;
+  if (ctx->comm_stream) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
   HIPCHK(ctx, launch_checksum(ctx->gathered.p, ctx->gathered_c64, n, (double*)ctx->scratch.p, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(out, ctx->scratch.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

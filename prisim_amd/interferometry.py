@@ -232,8 +232,8 @@ class InterferometerArray(object):
         self._ctx.comm_init(comm_uid, nranks, rank)
         c64 = bool(self._cube) and self._cube[0].dtype == NP.complex64
         self._ctx.allgather(self.n_acc, complex64=c64)
-        g = self._ctx.get_gathered(self.n_acc, nranks)                 # [rank][t][b][f]
-        return NP.transpose(g, (0, 2, 3, 1)).reshape(nranks * self.baselines.shape[0], self.channels.size, self.n_acc)
+        g = self._ctx.get_gathered(self.n_acc, nranks)                 # [t][rank][b][f]
+        return NP.transpose(g.reshape(self.n_acc, nranks * self.baselines.shape[0], self.channels.size), (1, 2, 0))
 
     # ------------------------------------------------------------------------------------------
     def _broadcast_bl_chan(self, value, what, lo, hi):

@@ -138,4 +138,4 @@ def test_config2_yaml_runs_and_reserves_device_cube():
     # single-rank "gather" through the same code path the multi-GPU driver uses
     ia._ctx.allgather(2)
     g = ia._ctx.get_gathered(2, 1)
-    assert NP.array_equal(NP.transpose(g[0], (1, 2, 0)), out['skyvis_freq'])
+    assert NP.array_equal(NP.transpose(g[:, 0], (1, 2, 0)), out['skyvis_freq'])

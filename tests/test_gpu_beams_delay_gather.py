@@ -88,12 +88,17 @@ def test_single_rank_allgather_and_checksum(ctx):
     for t in range(nt):
         ctx.set_vis(cube[t], slot=t)
     ctx.allgather(nt)
-    g = ctx.get_gathered(nt, 1)
-    assert NP.array_equal(g[0], cube)
+    g = ctx.get_gathered(nt, 1)                                    # [t][rank][b][f]
+    assert g.shape == (nt, 1, nbl, nchan) and NP.array_equal(g[:, 0], cube)
     assert abs(ctx.gathered_checksum(nt) - (cube.real.sum() + cube.imag.sum())) <= 1e-9
     ctx.allgather(nt, complex64=True)
     g = ctx.get_gathered(nt, 1)
-    assert g.dtype == NP.complex64 and NP.array_equal(g[0], cube.astype(NP.complex64))
+    assert g.dtype == NP.complex64 and NP.array_equal(g[:, 0], cube.astype(NP.complex64))
+    # per-slot gathers on the communication stream
+    for t in range(nt):
+        ctx.allgather_slot_async(t)
+    ctx.sync()
+    assert NP.array_equal(ctx.get_gathered(nt, 1)[:, 0], cube)
 
 
 def test_rccl_communicator_of_one_rank(ctx):
@@ -108,6 +113,9 @@ def test_rccl_communicator_of_one_rank(ctx):
         c.comm_init(_abi.Context.comm_unique_id(), 1, 0)
         c.allgather(1)
         assert NP.array_equal(c.get_gathered(1, 1)[0, 0], v)
+        c.allgather_slot_async(0, complex64=True)
+        c.sync()
+        assert NP.array_equal(c.get_gathered(1, 1)[0, 0], v.astype(NP.complex64))
     finally:
         c.close()
 
