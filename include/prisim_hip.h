@@ -180,6 +180,12 @@ int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out);
 int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts, double pad,
                                double* out, double* lags_out, double* out_power, double power_scale);
 
+/* ---- phase-centre rotation (interferometry.py:7871-7877) --------------------------- */
+
+/* For slots [0, nt): V[t][b][f] *= exp(-2 pi i f (b . diff_dircos[t]) / c), diff = current - new phase-centre
+ * direction cosines per snapshot ([nt][3]).  In place on the device cube. */
+int prisim_hip_phase_rotate(prisim_ctx* ctx, int64_t nt, const double* diff_dircos);
+
 /* ---- multi-GPU: baseline shards + one RCCL all-gather ---------------------- */
 
 /* 128-byte RCCL unique id; rank 0 creates it, the launcher distributes it out of band. */

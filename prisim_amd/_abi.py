@@ -24,7 +24,7 @@ EXPORTS = (
     'prisim_hip_set_array', 'prisim_hip_set_sky', 'prisim_hip_compute', 'prisim_hip_get_vis',
     'prisim_hip_skyvis', 'prisim_hip_set_vis', 'prisim_hip_set_sky_analytic',
     'prisim_hip_set_external_beam', 'prisim_hip_set_sky_external', 'prisim_hip_get_pbflux',
-    'prisim_hip_delay_transform', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
+    'prisim_hip_delay_transform', 'prisim_hip_phase_rotate', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
     'prisim_hip_allgather', 'prisim_hip_allgather_slot_async', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
 )
@@ -127,6 +127,7 @@ def load_library():
     lib.prisim_hip_set_sky_external.argtypes = [vp, C.POINTER(PrisimSky)]
     lib.prisim_hip_get_pbflux.argtypes = [vp, vp]
     lib.prisim_hip_delay_transform.argtypes = [vp, i64, vp, dbl, vp, vp, vp, dbl]
+    lib.prisim_hip_phase_rotate.argtypes = [vp, i64, vp]
     lib.prisim_hip_comm_unique_id.argtypes = [C.c_char_p]
     lib.prisim_hip_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     lib.prisim_hip_allgather.argtypes = [vp, i64, i32]
@@ -351,6 +352,13 @@ class Context(object):
         self.set_vis(vis, 0)
         out, lags, pw = self.delay_transform(1, bpwts=bpwts, pad=pad)
         return out[0], lags, pw
+
+    def phase_rotate(self, nt, diff_dircos):
+        """cube[t] *= exp(-2 pi i f (b . diff[t])/c) for t < nt, in place on the device (interferometry.py:7871-7877)."""
+        d = NP.ascontiguousarray(diff_dircos, dtype=NP.float64).reshape(-1, 3)
+        if d.shape[0] != nt:
+            raise ValueError('diff_dircos must have one row per snapshot')
+        self._check(self._lib.prisim_hip_phase_rotate(self._h, int(nt), _ptr(d)), 'prisim_hip_phase_rotate')
 
     # ---- multi-GPU ----
     @staticmethod

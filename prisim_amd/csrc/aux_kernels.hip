@@ -380,6 +380,32 @@ hipError_t launch_dt_finish(const double* work, double* out, double* out_power, 
   return hipGetLastError();
 }
 
+// ---- phase-centre rotation: V *= exp(-2 pi i f (b . diff_t)/c)   (interferometry.py:7871-7877) ------------
+__global__ void k_phase_rotate(double2* __restrict__ cube, const double* __restrict__ blx, const double* __restrict__ bly,
+                               const double* __restrict__ blz, const double* __restrict__ freqs, const double* __restrict__ diff,
+                               int64_t nt, int64_t nbl, int64_t nchan) {
+  const int64_t total = nt * nbl * nchan;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = i % nchan;
+    const int64_t b = (i / nchan) % nbl;
+    const int64_t t = i / (nchan * nbl);
+    const double bdl = blx[b] * diff[3 * t] + bly[b] * diff[3 * t + 1] + blz[b] * diff[3 * t + 2];   // :7872
+    double ph = bdl / kC * freqs[f];                    // cycles
+    ph -= rint(ph);
+    double sn, cs;
+    sincospi(2.0 * ph, &sn, &cs);
+    const double2 v = cube[i];
+    cube[i] = make_double2(v.x * cs + v.y * sn, v.y * cs - v.x * sn);                                 // v * exp(-i phi), :7877
+  }
+}
+
+hipError_t launch_phase_rotate(double* cube, const double* blx, const double* bly, const double* blz, const double* freqs,
+                               const double* diff, int64_t nt, int64_t nbl, int64_t nchan, hipStream_t stream) {
+  hipLaunchKernelGGL(k_phase_rotate, dim3(grid_for(nt * nbl * nchan)), dim3(256), 0, stream, reinterpret_cast<double2*>(cube), blx,
+                     bly, blz, freqs, diff, nt, nbl, nchan);
+  return hipGetLastError();
+}
+
 // ---- deterministic checksum: fixed 1024-block partial sums, then one block ------------------
 template <typename T>
 __global__ __launch_bounds__(256)

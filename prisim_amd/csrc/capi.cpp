@@ -866,6 +866,23 @@ int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts,
   return PRISIM_OK;
 }
 
+int prisim_hip_phase_rotate(prisim_ctx* ctx, int64_t nt, const double* diff_dircos) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
+  if (!diff_dircos) return fail(ctx, PRISIM_EINVAL, "diff_dircos is NULL");
+  for (int64_t i = 0; i < 3 * nt; ++i)
+    if (!std::isfinite(diff_dircos[i])) return fail(ctx, PRISIM_EINVAL, "non-finite phase-centre offset");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->scratch, std::max<size_t>(1025, (size_t)3 * nt) * sizeof(double)))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->scratch.p, diff_dircos, (size_t)3 * nt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, launch_phase_rotate((double*)ctx->cube.p, (const double*)ctx->blx.p, (const double*)ctx->bly.p, (const double*)ctx->blz.p,
+                                  (const double*)ctx->freqs.p, (const double*)ctx->scratch.p, nt, ctx->nbl, ctx->nchan, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // diff_dircos is caller-owned
+  return PRISIM_OK;
+}
+
 // ---- multi-GPU ------------------------------------------------------------------------------
 
 int prisim_hip_comm_unique_id(char id[128]) {

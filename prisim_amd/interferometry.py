@@ -575,6 +575,166 @@ class InterferometerArray(object):
         self.n_acc = n_acc
 
     # ------------------------------------------------------------------------------------------
+    def _pc_dircos(self, pc, coords):
+        """Phase centres (n_acc, 2|3) in `coords` -> ENU direction cosines, per snapshot (uses self.lst)."""
+        pc = NP.asarray(pc, dtype=NP.float64)
+        lst = NP.asarray(self.lst, dtype=NP.float64)
+        if coords == 'dircos':
+            if (pc.shape[1] < 2) or (pc.shape[1] > 3):
+                raise ValueError('Dimensions incompatible for direction cosine positions')
+            if NP.any(NP.sqrt(NP.sum(pc ** 2, axis=1)) > 1.0 + 1e-12):
+                raise ValueError('direction cosines found to be exceeding unit magnitude.')
+            if pc.shape[1] == 2:
+                pc = NP.hstack((pc, NP.sqrt(NP.maximum(0.0, 1.0 - NP.sum(pc ** 2, axis=1))).reshape(-1, 1)))
+            return pc
+        if coords == 'altaz':
+            return GEOM.altaz2dircos(pc, 'degrees')
+        if coords == 'hadec':
+            return GEOM.altaz2dircos(GEOM.hadec2altaz(pc, self.latitude, units='degrees'), 'degrees')
+        if coords == 'radec':
+            hadec = NP.stack((lst - pc[:, 0], pc[:, 1]), axis=1)
+            return GEOM.altaz2dircos(GEOM.hadec2altaz(hadec, self.latitude, units='degrees'), 'degrees')
+        raise ValueError('Invalid phase center coordinate system specified')
+
+    def _convert_pc(self, dircos, coords):
+        """ENU direction cosines -> phase-centre coordinates in `coords` (for the phase_center attribute)."""
+        if coords == 'dircos':
+            return dircos
+        altaz = GEOM.dircos2altaz(dircos, units='degrees')
+        if coords == 'altaz':
+            return altaz
+        hadec = GEOM.altaz2hadec(altaz, self.latitude, units='degrees')
+        if coords == 'hadec':
+            return hadec
+        return NP.stack((NP.asarray(self.lst) - hadec[:, 0], hadec[:, 1]), axis=1)
+
+    def phase_centering(self, phase_center=None, phase_center_coords=None, do_delay_transform=False, verbose=True):
+        """Re-centre the visibility phases on new phase centre(s): V *= exp(-2 pi i f b.(s_cur - s_new)/c)
+        (interferometry.py:7735-7886; arithmetic :7871-7877) on the GPU.  phase_center: (1|n_acc, 2|3) array in
+        phase_center_coords ('radec', 'hadec', 'altaz', 'dircos'); None uses the pointing centres."""
+        if phase_center is None:
+            phase_center = self.pointing_center
+            phase_center_coords = self.pointing_coords
+        elif not isinstance(phase_center, NP.ndarray):
+            raise TypeError('Phase center must be a numpy array')
+        if phase_center_coords is None:
+            raise NameError('Coordinates of phase center not provided.')
+        phase_center = NP.asarray(phase_center, dtype=NP.float64)
+        if phase_center.ndim == 1:
+            phase_center = phase_center.reshape(1, -1)
+        if phase_center.ndim != 2:
+            raise ValueError('Phase center has invalid dimensions')
+        n_acc = len(self.lst)
+        if phase_center.shape[0] == 1:
+            phase_center = NP.repeat(phase_center, n_acc, axis=0)
+        elif phase_center.shape[0] != n_acc:
+            raise ValueError('One phase center must be provided for every timestamp.')
+        if self.skyvis_freq is None:
+            raise ValueError('no visibilities to rotate: call observe() first')
+        cur = self._pc_dircos(self.phase_center, self.phase_center_coords)
+        new = self._pc_dircos(phase_center, phase_center_coords)
+        diff = cur - new                                                               # :7871
+
+        def rotate(cube):
+            cube = NP.asarray(cube, dtype=NP.complex128)
+            out = NP.empty_like(cube)
+            for t in range(cube.shape[2]):                 # through device cube slot 0 (host-resident cubes)
+                self._ctx.set_vis(cube[:, :, t], slot=0)
+                self._ctx.phase_rotate(1, diff[[t]])
+                out[:, :, t] = self._ctx.get_vis(slot=0)
+            return out
+
+        dtype = self.skyvis_freq.dtype
+        self.skyvis_freq = rotate(self.skyvis_freq).astype(dtype)                      # :7877
+        if self.vis_freq is not None:
+            self.vis_freq = rotate(self.vis_freq)
+        if self.vis_noise_freq is not None:
+            self.vis_noise_freq = rotate(self.vis_noise_freq)
+        if self._reserved >= n_acc:                        # keep the device-resident cube in step
+            for t in range(n_acc):
+                self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
+        self.phase_center = self._convert_pc(new, self.phase_center_coords)            # :7874-7875
+        if do_delay_transform:
+            self.delay_transform(verbose=verbose)
+
+    def project_baselines(self, ref_point):
+        """Baselines projected on the (u, v, w) frame of a reference direction per snapshot
+        (interferometry.py:7890-7985; rotation matrix :7979-7981).  Host side: O(nbl * n_acc)."""
+        if not isinstance(ref_point, dict):
+            raise TypeError('Input ref_point must be a dictionary')
+        if ('location' not in ref_point) or ('coords' not in ref_point):
+            raise KeyError('Both keys "location" and "coords" must be specified in input dictionary ref_point')
+        pc, coords = ref_point['location'], ref_point['coords']
+        if not isinstance(pc, NP.ndarray):
+            raise TypeError('The specified reference point must be a numpy array')
+        if not isinstance(coords, str):
+            raise TypeError('The specified coordinates of the reference point must be a string')
+        if coords not in ['radec', 'hadec', 'altaz', 'dircos']:
+            raise ValueError('Specified coordinates of reference point invalid')
+        pc = pc.reshape(1, -1) if pc.ndim == 1 else pc
+        if pc.ndim > 2:
+            raise ValueError('Reference point has invalid dimensions')
+        if (pc.shape[0] != self.n_acc) and (pc.shape[0] != 1):
+            raise ValueError('Reference point has dimensions incompatible with the number of timestamps')
+        if pc.shape[0] == 1:
+            pc = NP.repeat(pc, self.n_acc, axis=0)
+        dc = self._pc_dircos(pc, coords)
+        hadec = GEOM.altaz2hadec(GEOM.dircos2altaz(dc, units='degrees'), self.latitude, units='degrees')
+        ha, dec = NP.radians(hadec[:, 0]), NP.radians(hadec[:, 1])
+        lat = NP.radians(self.latitude)
+        e, n, u = self.baselines[:, 0], self.baselines[:, 1], self.baselines[:, 2]
+        eq = NP.stack((-NP.sin(lat) * n + NP.cos(lat) * u, e, NP.cos(lat) * n + NP.sin(lat) * u), axis=1)   # GEOM.enu2xyz (:7977)
+        rot = NP.asarray([[NP.sin(ha), NP.cos(ha), NP.zeros(ha.size)],
+                          [-NP.sin(dec) * NP.cos(ha), NP.sin(dec) * NP.sin(ha), NP.cos(dec)],
+                          [NP.cos(dec) * NP.cos(ha), -NP.cos(dec) * NP.sin(ha), NP.sin(dec)]])            # :7979-7981
+        self.projected_baselines = NP.einsum('bk,jkt->bjt', eq, rot)                                      # :7985 (nbl, 3, n_acc)
+
+    def rotate_visibilities(self, ref_point, do_delay_transform=False, verbose=True):
+        """phase_centering + project_baselines about one reference point (interferometry.py:7655-7733)."""
+        if not isinstance(ref_point, dict):
+            raise TypeError('Input ref_point must be a dictionary')
+        if ('location' not in ref_point) or ('coords' not in ref_point):
+            raise KeyError('Both keys "location" and "coords" must be specified in input dictionary ref_point')
+        self.phase_centering(phase_center=ref_point['location'], phase_center_coords=ref_point['coords'],
+                             do_delay_transform=do_delay_transform, verbose=verbose)
+        self.project_baselines(ref_point)
+
+    def conjugate(self, ind=None, verbose=True):
+        """Flip the selected baselines and conjugate their visibilities (interferometry.py:7989-8048)."""
+        if ind is None:
+            return
+        if isinstance(ind, str):
+            if ind != 'all':
+                raise ValueError('Value of ind must be "all" if set to string')
+            ind = NP.arange(self.baselines.shape[0])
+        elif isinstance(ind, (int, NP.integer)):
+            ind = [ind]
+        elif not isinstance(ind, (list, NP.ndarray)):
+            raise TypeError('ind must be string "all", scalar interger, list or numpy array')
+        ind = NP.asarray(ind)
+        if NP.any(ind >= self.baselines.shape[0]):
+            raise IndexError('Out of range indices found.')
+        self.labels = [tuple(reversed(self.labels[i])) if (i in ind and isinstance(self.labels[i], tuple)) else self.labels[i]
+                       for i in range(len(self.labels))]
+        self.baselines[ind, :] = -self.baselines[ind, :]
+        self.baseline_orientations = NP.angle(self.baselines[:, 0] + 1j * self.baselines[:, 1])
+        if self.skyvis_freq is not None:
+            cube = NP.array(self.skyvis_freq)
+            cube[ind, :, :] = cube[ind, :, :].conj()
+            self.skyvis_freq = cube
+        for name in ('vis_freq', 'vis_noise_freq'):
+            arr = getattr(self, name)
+            if arr is not None:
+                arr[ind, :, :] = arr[ind, :, :].conj()
+        if self.projected_baselines is not None:
+            self.projected_baselines[ind, :, :] = -self.projected_baselines[ind, :, :]
+        self._ctx.set_array(self.baselines, self.channels, nt_max=self._reserved)      # the resident array follows the flip
+        self._restore_external_beam()
+        if self._reserved >= self.n_acc and self.skyvis_freq is not None:
+            for t in range(self.n_acc):
+                self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
+
+    # ------------------------------------------------------------------------------------------
     def delay_transform(self, pad=1.0, freq_wts=None, verbose=True):
         """Frequency -> delay transform on the GPU (rocFFT) of whichever visibility cubes exist
         (interferometry.py:8052-8137; Q20).  Sets lags, skyvis_lag (vis_lag, vis_noise_lag when their

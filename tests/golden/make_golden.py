@@ -12,7 +12,8 @@ source text is stored in this repository.
 
   golden_skyvis.npz    interferometry.py:6332,6340 (fp64), 6335 (+taper), 6338/6343 (gradient),
                        6323,6326,6327,6330 (fp32 "memsave"), taper 6259-6262,6265-6270,6281-6283,
-                       baseline_delay_horizon.py:133-241 (function geometric_delay, dircos path)
+                       baseline_delay_horizon.py:133-241 (function geometric_delay, dircos path),
+                       phase_centering :7871-7872, 7877
   golden_beams.npz     primary_beams.py:517-625 (airy_disk_pattern), 629-730 (gaussian_beam),
                        9-441 (primary_beam_generator dispatch, shapes 'gaussian' / 'dish' / 'delta')
   golden_beams_ext.npz primary_beams.py:975-1235 (dipole_field_pattern), 1239-1478 (isotropic_radiators_array_field_pattern),
@@ -119,6 +120,19 @@ def make_skyvis():
     e['vis_wts'] = vis_wts.astype(NP.float32)                                     # :6289
     exec(ref_stmts('interferometry.py', [(6323, 6323), (6326, 6327)]), e)
     out['skyvis_f32_taper'] = e['skyvis']
+
+    # ---- phase centering (rotate visibilities to a new phase centre): :7871-7872, :7877
+    n_t = 3
+    cube = (rng.normal(size=(nbl, nchan, n_t)) + 1j * rng.normal(size=(nbl, nchan, n_t)))
+    pc_cur = altaz2dircos(NP.stack((rng.uniform(60, 90, n_t), rng.uniform(0, 360, n_t)), axis=1))
+    pc_new = altaz2dircos(NP.stack((rng.uniform(60, 90, n_t), rng.uniform(0, 360, n_t)), axis=1))
+    e = {'NP': NP, 'FCNST': FCNST, 'phase_center_current_temp': pc_cur, 'phase_center_new': pc_new,
+         'self': types.SimpleNamespace(baselines=baselines, channels=channels, skyvis_freq=cube.copy())}
+    exec(ref_stmts('interferometry.py', [(7871, 7872), (7877, 7877)]), e)
+    out['phase_cube_in'] = cube
+    out['phase_pc_cur'] = pc_cur
+    out['phase_pc_new'] = pc_new
+    out['phase_cube_out'] = e['self'].skyvis_freq
 
     NP.savez_compressed(os.path.join(HERE, 'golden_skyvis.npz'),
                         baselines=baselines, channels=channels, dircos=skypos_dircos_roi, pbfluxes=pbfluxes,

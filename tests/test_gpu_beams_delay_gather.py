@@ -309,3 +309,53 @@ def test_interferometer_array_with_external_beam():
     # the float32-rounded beam differs from the double restatement by <= 6e-8 relative per source
     assert NP.max(NP.abs(ia.skyvis_freq[:, :, 0] - ref) / scale) <= 2e-7
     assert NP.array_equal(ia.skyvis_freq[:, :, 0], ia.skyvis_freq[:, :, 1])          # sky fixed in the local frame (skycoords='altaz')
+
+
+def test_phase_rotate_matches_reference_statements(ctx, golden_skyvis):
+    g = golden_skyvis
+    cube = g['phase_cube_in']                           # (nbl, nchan, nt)
+    nt = cube.shape[2]
+    ctx.set_array(g['baselines'], g['channels'], nt_max=nt)
+    for t in range(nt):
+        ctx.set_vis(cube[:, :, t], slot=t)
+    ctx.phase_rotate(nt, g['phase_pc_cur'] - g['phase_pc_new'])
+    out = NP.stack([ctx.get_vis(slot=t) for t in range(nt)], axis=2)
+    assert NP.max(NP.abs(out - g['phase_cube_out'])) <= 1e-11 * NP.max(NP.abs(cube))
+    with pytest.raises(ValueError):
+        ctx.phase_rotate(nt + 1, NP.zeros((nt + 1, 3)))
+
+
+def test_interferometer_array_phase_centering_project_conjugate():
+    ch = 150e6 + NP.arange(16) * 1e5
+    bl = NP.array([[14.6, 0.0, 0.0], [0.0, 29.2, 0.0], [-50.0, 20.0, 1.0]])
+    lat = -30.7224
+    skymod = SM.SkyModel(location=[[80.0, 100.0], [60.0, 250.0]], flux_ref=[1.0, 2.0], spindex=[0.0, -0.7], ref_freq=150e6)
+    ia = RI.InterferometerArray([('a', 'b'), ('a', 'c'), ('b', 'c')], bl, ch, telescope={'shape': 'delta'}, latitude=lat, skycoords='altaz',
+                                pointing_coords='altaz')
+    ia.reserve(2)
+    for j in range(2):
+        ia.observe((2457000.5 + j, 15.0 * j), {'Tnet': 100.0}, NP.ones(16), [90.0, 270.0], skymod, 10.0)
+    before = NP.array(ia.skyvis_freq)
+    # re-centre on source 0: its contribution becomes a real constant (flux) on every baseline / channel
+    ia.phase_centering(phase_center=NP.array([[80.0, 100.0]]), phase_center_coords='altaz')
+    dc = O.altaz2dircos(skymod.location)
+    pb = skymod.generate_spectrum(frequency=ch)
+    ref = O.skyvis(bl, ch, dc, pb, dc[0])
+    assert NP.max(NP.abs(ia.skyvis_freq[:, :, 0] - ref)) <= 1e-10
+    assert NP.allclose(ia.phase_center, [[80.0, 100.0]] * 2) and ia.phase_center_coords == 'altaz'
+    assert NP.array_equal(ia._ctx.get_vis(slot=1), ia.skyvis_freq[:, :, 1])            # device cube follows
+    # rotating back restores the original
+    ia.phase_centering(phase_center=NP.array([[90.0, 270.0]]), phase_center_coords='altaz')
+    assert NP.max(NP.abs(ia.skyvis_freq - before)) <= 1e-10
+    # projected baselines toward the zenith: w = Up component, |uvw| = |b|
+    ia.project_baselines({'location': NP.array([90.0, 270.0]), 'coords': 'altaz'})
+    assert ia.projected_baselines.shape == (3, 3, 2)
+    assert NP.allclose(NP.linalg.norm(ia.projected_baselines[:, :, 0], axis=1), NP.linalg.norm(bl, axis=1))
+    assert NP.allclose(ia.projected_baselines[:, 2, 0], bl[:, 2], atol=1e-9)
+    ia.conjugate(ind=[2])
+    assert NP.allclose(ia.baselines[2], [50.0, -20.0, -1.0]) and NP.allclose(ia.skyvis_freq[2], before[2].conj())
+    assert ia.labels[2] == ('c', 'b')
+    with pytest.raises(IndexError):
+        ia.conjugate(ind=[7])
+    with pytest.raises(KeyError):
+        ia.rotate_visibilities({'location': NP.array([90.0, 270.0])})
