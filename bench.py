@@ -78,6 +78,25 @@ def cpu_baseline(cfg, pbflux_sample_fn, target_terms=1.0e10):
                       'interferometry.py:6332-6340' % (bls.shape[0], bl.shape[0], stride, nchan, nsrc, terms, dt)}, bls, ref, stride
 
 
+def profiled_traffic(kernel_tag):
+    """HBM bytes per launch of the dominant kernel, from the newest committed rocprofv3 PMC summary
+    (profiles/*/pmc_summary.json: separate --pmc passes of this same command, 2*FETCH_SIZE + WRITE_SIZE in KiB with the
+    gfx950 FETCH correction of MI355X_MICROARCH.md).  Counters cannot be read inside an ordinary run, so this is the
+    committed measurement for the same kernel/workload, or None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'pmc_summary.json'))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if kernel_tag in d.get('_kernel', {}).get('Kernel_Name', '') and 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+                best = ((2.0 * d['FETCH_SIZE']['mean_per_launch'] + d['WRITE_SIZE']['mean_per_launch']) * 1024.0,
+                        os.path.relpath(path, ROOT))
+        except Exception:
+            pass
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -173,6 +192,11 @@ def main():
         wp = 4 if prec == _abi.PRISIM_FP32 else 8
         alg_bytes = nsrc * nchan * wp + 24 * nsrc + 24 * bl_mine.shape[0] + 8 * nchan + 2 * 8 * bl_mine.shape[0] * nchan
         ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = traffic_src = None
+        if world == 1 and nsrc == 10000:
+            tr = profiled_traffic('f32pk<64, false>' if dtype == 'f32' else 'k_skyvis_rec<double, 32, false>')
+            if tr is not None:
+                traffic, traffic_src = tr
         out = {
             'metric': 'visibility-terms/sec', 'value': value, 'unit': 'terms/s', 'n_gpus': world, 'steps': K, 'warmup': Wm,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
@@ -181,11 +205,13 @@ def main():
                        'beam': 'airy D=14 m fused on device', 'sharding': 'baselines/%d + 1 RCCL all-gather' % world,
                        'kernel': 'recurrence ct=%d nsplit=%d' % (tm['last_chan_tile'], tm['last_nsplit'])},
             'roofline': {'bound': 'valu', 'achieved': ach_tflops, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
-                         'frac': ach_tflops / PEAK_TFLOPS[dtype], 'traffic': None,
+                         'frac': ach_tflops / PEAK_TFLOPS[dtype], 'traffic': traffic, 'traffic_unit': 'bytes/launch',
+                         'traffic_source': traffic_src,
                          'kernel': 'k_skyvis_rec', 'avg_kernel_ms': kern_ms, 'flops_per_term': FLOPS_PER_TERM,
                          'terms_per_launch': terms_launch},
             'roofline_hbm': {'bound': 'hbm', 'achieved': ach_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'frac': ach_gbs / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes_per_launch': alg_bytes},
+                             'frac': ach_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
+                             'algorithmic_bytes_per_launch': alg_bytes},
         }
         if gather_ok is not None:
             out['gather_ok'] = gather_ok
