@@ -352,7 +352,8 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
 
   const double bx = p.bl_x[b], by = p.bl_y[b], bz = p.bl_z[b];
   const int k0 = tile * CT;
-  const double fc4 = 4.0 * (p.f0 + (double)(k0 + HC) * p.df);
+  const double fc_hz = p.f0 + (double)(k0 + HC) * p.df;
+  const double fc4 = 4.0 * fc_hz;
   const double df4 = 4.0 * p.df;
 
   double bl2_c2 = 0.0, bpc = 0.0;
@@ -419,12 +420,28 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
         f32x2 zim = {ui0, di0};
         const f32x2 RR = {rr, rr};
         const f32x2 RI = {-ri, ri};        // re' = re*rr + im*RI ;  im' = im*rr - re*RI
-        float g2 = 0.f;
+        // Source-shape taper folded into the recurrence.  log2 w at channel HC+j is L(j) = A + B j + C j^2 with
+        //   A = -G fc^2, B = -2 G fc df, C = -G df^2, G = kappa_s (|b|^2/c^2 - tau^2) log2(e)     (interferometry.py:6265-6283)
+        // so zeta_j = w_j z_j advances by the complex factor rho_j = r * exp2(L(j+1)-L(j)) (up) / conj(r) * exp2(L(-2-j)-L(-1-j))
+        // (down), and rho_{j+1} = rho_j * exp2(2C): 2 more packed instructions per pair of terms instead of two v_exp_f32.
+        // rho is re-formed exactly every RESEED steps so that its rounding error cannot random-walk into zeta's phase.
+        f32x2 rho_re = RR, rho_im = {ri, -ri}, HM = {0.f, 0.f};
+        float tB = 0.f, tC = 0.f;
         if (TAPER) {
           const double tau = d + bpc;
           double gq = sv.w * (bl2_c2 - tau * tau);
-          gq = gq > 0.0 ? gq : 0.0;
-          g2 = -(float)(gq * p.fsq_scale);
+          gq = gq > 0.0 ? gq : 0.0;                       // |b|^2 >= (b.s)^2 up to rounding
+          const double G = gq * 1.4426950408889634;
+          const float tA = (float)(-G * fc_hz * fc_hz);
+          tB = (float)(-2.0 * G * fc_hz * p.df);
+          tC = (float)(-G * p.df * p.df);
+          const float w_u0 = __builtin_amdgcn_exp2f(tA);                 // channel HC
+          const float w_d0 = __builtin_amdgcn_exp2f(tA - tB + tC);       // channel HC-1
+          zre = zre * (f32x2){w_u0, w_d0};
+          zim = zim * (f32x2){w_u0, w_d0};
+          const float th = 2.0f * tC * 0.6931471805599453f;              // exp2(2C) - 1 = th + th^2/2 + ...
+          const float hm = __builtin_fmaf(0.5f * th, th, th);
+          HM = (f32x2){hm, hm};
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -432,31 +449,46 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
         sv = lds_d[s + 1];                               // lds_d has S+1 entries
         __builtin_amdgcn_sched_barrier(0);
 
+        constexpr int RESEED = 8;
 #pragma unroll
         for (int j = 0; j < HC; j += 2) {
           const float4 pv = (j < HC / 2) ? pa[j / 2] : pb[j / 2 - NQ];   // (up_j, down_j, up_j+1, down_j+1)
-          f32x2 p0 = {pv.x, pv.y};
-          f32x2 p1 = {pv.z, pv.w};
-          if (TAPER) {
-            // w = exp2(-g f^2 log2 e): direct v_exp_f32 per term, fsq pairs interleaved like pbflux
-            const float4 fq = *reinterpret_cast<const float4*>(p.fsq_pairs + (size_t)tile * CT + 2 * j);
-            p0.x *= __builtin_amdgcn_exp2f(g2 * fq.x);
-            p0.y *= __builtin_amdgcn_exp2f(g2 * fq.y);
-            p1.x *= __builtin_amdgcn_exp2f(g2 * fq.z);
-            p1.y *= __builtin_amdgcn_exp2f(g2 * fq.w);
+          const f32x2 p0 = {pv.x, pv.y};
+          const f32x2 p1 = {pv.z, pv.w};
+          if (!TAPER) {
+            acc_re[j] = pkfma(p0, zre, acc_re[j]);
+            acc_im[j] = pkfma(p0, zim, acc_im[j]);
+            f32x2 t0 = zim * RI;
+            f32x2 t1 = zre * RI;
+            const f32x2 nre = pkfma(zre, RR, t0);
+            const f32x2 nim = pkfma(zim, RR, -t1);
+            acc_re[j + 1] = pkfma(p1, nre, acc_re[j + 1]);
+            acc_im[j + 1] = pkfma(p1, nim, acc_im[j + 1]);
+            t0 = nim * RI;
+            t1 = nre * RI;
+            zre = pkfma(nre, RR, t0);
+            zim = pkfma(nim, RR, -t1);
+          } else {
+            if ((j % RESEED) == 0) {
+              const float qu = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(2 * j + 1), tB));     // L(j+1) - L(j)
+              const float qd = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(2 * j + 3), -tB));    // L(-2-j) - L(-1-j)
+              rho_re = (f32x2){qu * rr, qd * rr};
+              rho_im = (f32x2){qu * ri, -(qd * ri)};
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const f32x2 pp = e == 0 ? p0 : p1;
+              acc_re[j + e] = pkfma(pp, zre, acc_re[j + e]);
+              acc_im[j + e] = pkfma(pp, zim, acc_im[j + e]);
+              const f32x2 t0 = zim * rho_im;
+              const f32x2 t1 = zre * rho_im;
+              const f32x2 nre = pkfma(zre, rho_re, -t0);
+              const f32x2 nim = pkfma(zim, rho_re, t1);
+              zre = nre; zim = nim;
+              rho_re = pkfma(rho_re, HM, rho_re);
+              rho_im = pkfma(rho_im, HM, rho_im);
+            }
           }
-          acc_re[j] = pkfma(p0, zre, acc_re[j]);
-          acc_im[j] = pkfma(p0, zim, acc_im[j]);
-          f32x2 t0 = zim * RI;
-          f32x2 t1 = zre * RI;
-          f32x2 nre = pkfma(zre, RR, t0);
-          f32x2 nim = pkfma(zim, RR, -t1);
-          acc_re[j + 1] = pkfma(p1, nre, acc_re[j + 1]);
-          acc_im[j + 1] = pkfma(p1, nim, acc_im[j + 1]);
-          t0 = nim * RI;
-          t1 = nre * RI;
-          zre = pkfma(nre, RR, t0);
-          zim = pkfma(nim, RR, -t1);
         }
       }
     }
