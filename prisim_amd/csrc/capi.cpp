@@ -252,7 +252,20 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
     const int64_t base = (int64_t)pl.ntiles * pl.nbgroups;
     nsplit = 1;
     if (base < 1024) {
-      nsplit = (int)std::min<int64_t>((1024 + base - 1) / base, nchunks);
+      // Small / mid-size problems: split the sources so that the grid has >= 2 rounds of blocks, and among the
+      // candidates pick the smallest split whose last round is (nearly) full: the grid runs in rounds of
+      // slots = CUs x resident blocks per CU, and e.g. 1152 blocks on 512 slots = 2.25 rounds waste a quarter of the
+      // third round, while 1536 = 3.0 rounds waste nothing.
+      const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * (pl.pk ? 2 : (pl.f32 ? 4 : 2));
+      const int lo = (int)std::min<int64_t>((1024 + base - 1) / base, nchunks);
+      const int hi = (int)std::min<int64_t>(std::min<int64_t>(4 * (int64_t)lo, 64), nchunks);
+      nsplit = std::max(lo, 1);
+      double best_eff = -1.0;
+      for (int cand = std::max(lo, 1); cand <= std::max(hi, 1); ++cand) {
+        const double rounds = (double)(base * cand) / (double)slots;
+        const double eff = rounds >= 1.0 ? rounds / std::ceil(rounds) : rounds;
+        if (eff > best_eff + 0.03) { best_eff = eff; nsplit = cand; }     // prefer the smaller split unless clearly better
+      }
       if (nsplit > 64) nsplit = 64;
     }
     // Large problems keep nsplit = 1: splitting the sources to shorten the last, partly filled round of blocks
@@ -812,50 +825,68 @@ int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts,
   const int64_t nfft = nchan + npad;
   const double factor = 1.0 + pad;                                      // :8131
   const int64_t nout = (int64_t)std::ceil((double)nfft / factor - 1e-12);   // len(arange(0, nfft, factor))
-  const int64_t nrows = nt * nbl;
+  // Snapshots are transformed in batches so that the padded work buffer stays <= 4 GiB whatever nt is
+  // (config 5: 120 x 61075 rows of 2048 would be 240 GB at once).
+  const int64_t row_bytes = nfft * 2 * (int64_t)sizeof(double);
+  int64_t budget = (int64_t)4 << 30;
+  if (const char* env = getenv("PRISIM_HIP_DT_BATCH_BYTES")) {   // test hook: force several batches on small cubes
+    const long long v = atoll(env);
+    if (v > 0) budget = v;
+  }
+  int64_t nt_b = std::max<int64_t>(1, budget / (nbl * row_bytes));
+  if (nt_b > nt) nt_b = nt;
   int rc;
-  if ((rc = ensure(ctx, ctx->fft_buf, (size_t)nrows * nfft * 2 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->fft_buf, (size_t)(nt_b * nbl) * row_bytes))) return rc;
   if (bpwts) {
     if ((rc = ensure(ctx, ctx->dt_wts, (size_t)nbl * nchan * sizeof(double)))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->dt_wts.p, bpwts, (size_t)nbl * nchan * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   }
-  if (!ctx->fft_plan || ctx->fft_len != (size_t)nfft || ctx->fft_batch != (size_t)nrows) {
-    if (ctx->fft_plan) { F.plan_destroy(ctx->fft_plan); ctx->fft_plan = nullptr; }
-    size_t len = (size_t)nfft;
-    if (F.plan_create(&ctx->fft_plan, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
-                      rocfft_precision_double, 1, &len, (size_t)nrows, nullptr) != rocfft_status_success) {
-      ctx->fft_plan = nullptr;
-      return fail(ctx, PRISIM_ELIB, "rocfft_plan_create failed");
-    }
-    ctx->fft_len = (size_t)nfft; ctx->fft_batch = (size_t)nrows;
-    if (!ctx->fft_info && F.execution_info_create(&ctx->fft_info) != rocfft_status_success)
-      return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_create failed");
-    if (F.execution_info_set_stream(ctx->fft_info, ctx->stream) != rocfft_status_success)
-      return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_stream failed");
-    size_t wbytes = 0;
-    F.plan_get_work_buffer_size(ctx->fft_plan, &wbytes);
-    if (wbytes) {
-      if ((rc = ensure(ctx, ctx->fft_work, wbytes))) return rc;
-      if (F.execution_info_set_work_buffer(ctx->fft_info, ctx->fft_work.p, wbytes) != rocfft_status_success)
-        return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_work_buffer failed");
-    }
-  }
-  HIPCHK(ctx, launch_dt_prepare((const double*)ctx->cube.p, bpwts ? (const double*)ctx->dt_wts.p : nullptr,
-                                (double*)ctx->fft_buf.p, nrows, nbl, nchan, nfft, ctx->stream));
-  void* bufs[1] = {ctx->fft_buf.p};
-  if (F.execute(ctx->fft_plan, bufs, nullptr, ctx->fft_info) != rocfft_status_success)
-    return fail(ctx, PRISIM_ELIB, "rocfft_execute failed");
+  if (out && (rc = ensure(ctx, ctx->dt_out, (size_t)(nt_b * nbl) * nout * 2 * sizeof(double)))) return rc;
+  if (out_power && (rc = ensure(ctx, ctx->dt_pow, (size_t)(nt_b * nbl) * nout * sizeof(double)))) return rc;
   // rocFFT's inverse is unnormalised: sum_n x[n] e^{+2 pi i k n / N'}.  The reference forms
   // ifft(x) * N' * df (:8125) = that sum times df.
   const double scale = ctx->df;
-  if (out && (rc = ensure(ctx, ctx->dt_out, (size_t)nrows * nout * 2 * sizeof(double)))) return rc;
-  if (out_power && (rc = ensure(ctx, ctx->dt_pow, (size_t)nrows * nout * sizeof(double)))) return rc;
-  HIPCHK(ctx, launch_dt_finish((const double*)ctx->fft_buf.p, out ? (double*)ctx->dt_out.p : nullptr,
-                               out_power ? (double*)ctx->dt_pow.p : nullptr, nrows, nfft, nout, factor, scale, power_scale,
-                               ctx->stream));
-  if (out) HIPCHK(ctx, hipMemcpyAsync(out, ctx->dt_out.p, (size_t)nrows * nout * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (out_power) HIPCHK(ctx, hipMemcpyAsync(out_power, ctx->dt_pow.p, (size_t)nrows * nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t slot_elems = (size_t)nbl * nchan * 2;
+  for (int64_t t0 = 0; t0 < nt; t0 += nt_b) {
+    const int64_t ntc = std::min(nt_b, nt - t0);
+    const int64_t nrows = ntc * nbl;
+    if (!ctx->fft_plan || ctx->fft_len != (size_t)nfft || ctx->fft_batch != (size_t)nrows) {
+      if (ctx->fft_plan) { F.plan_destroy(ctx->fft_plan); ctx->fft_plan = nullptr; }
+      size_t len = (size_t)nfft;
+      if (F.plan_create(&ctx->fft_plan, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                        rocfft_precision_double, 1, &len, (size_t)nrows, nullptr) != rocfft_status_success) {
+        ctx->fft_plan = nullptr;
+        return fail(ctx, PRISIM_ELIB, "rocfft_plan_create failed");
+      }
+      ctx->fft_len = (size_t)nfft; ctx->fft_batch = (size_t)nrows;
+      if (!ctx->fft_info && F.execution_info_create(&ctx->fft_info) != rocfft_status_success)
+        return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_create failed");
+      if (F.execution_info_set_stream(ctx->fft_info, ctx->stream) != rocfft_status_success)
+        return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_stream failed");
+      size_t wbytes = 0;
+      F.plan_get_work_buffer_size(ctx->fft_plan, &wbytes);
+      if (wbytes) {
+        if ((rc = ensure(ctx, ctx->fft_work, wbytes))) return rc;
+        if (F.execution_info_set_work_buffer(ctx->fft_info, ctx->fft_work.p, wbytes) != rocfft_status_success)
+          return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_work_buffer failed");
+      }
+    }
+    HIPCHK(ctx, launch_dt_prepare((const double*)ctx->cube.p + (size_t)t0 * slot_elems, bpwts ? (const double*)ctx->dt_wts.p : nullptr,
+                                  (double*)ctx->fft_buf.p, nrows, nbl, nchan, nfft, ctx->stream));
+    void* bufs[1] = {ctx->fft_buf.p};
+    if (F.execute(ctx->fft_plan, bufs, nullptr, ctx->fft_info) != rocfft_status_success)
+      return fail(ctx, PRISIM_ELIB, "rocfft_execute failed");
+    HIPCHK(ctx, launch_dt_finish((const double*)ctx->fft_buf.p, out ? (double*)ctx->dt_out.p : nullptr,
+                                 out_power ? (double*)ctx->dt_pow.p : nullptr, nrows, nfft, nout, factor, scale, power_scale,
+                                 ctx->stream));
+    if (out)
+      HIPCHK(ctx, hipMemcpyAsync(out + (size_t)t0 * nbl * nout * 2, ctx->dt_out.p, (size_t)nrows * nout * 2 * sizeof(double),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    if (out_power)
+      HIPCHK(ctx, hipMemcpyAsync(out_power + (size_t)t0 * nbl * nout, ctx->dt_pow.p, (size_t)nrows * nout * sizeof(double),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // the staging buffers are reused by the next batch
+  }
   if (lags_out) {
     // DSP.spectral_axis(nchan, delx=df, shift=True) (:8114) == fftshift(fftfreq(nchan, df))
     for (int64_t i = 0; i < nchan; ++i) {

@@ -114,3 +114,62 @@ def subsample(cfg, bl_stride=1, ch_count=None, src_stride=1):
     sky = cfg['sky']
     out['sky'] = {k: (v[::src_stride] if isinstance(v, NP.ndarray) else v) for k, v in sky.items()}
     return out
+
+
+def mwa128_layout(seed=4, sigma_m=400.0, n_tiles=128):
+    """Synthetic MWA-128T: the real tile file (prisim/data/array_layouts/MWA-I-128T_tile_coordinates.txt,
+    interferometry.py:1801) is not in the reference tree; 128 tiles drawn from a 2-D Gaussian."""
+    rng = NP.random.default_rng(seed)
+    xy = rng.normal(0.0, sigma_m, size=(n_tiles, 2))
+    return NP.hstack((xy, NP.zeros((n_tiles, 1))))
+
+
+def synthetic_healpix_beam(nside, freqs_hz, tile=True):
+    """External power beam [npix, nfreq] in the local (zenith angle, azimuth) frame: cos^2(theta) envelope times a 4x4
+    array factor of 1.1 m spacing (MWA-tile-like), strictly positive (log10 is interpolated, run_prisim.py:2094)."""
+    theta, phi = GEOM.healpix_pix2ang_ring(nside)
+    freqs_hz = NP.asarray(freqs_hz, dtype=float)
+    ct = NP.cos(NP.clip(theta, 0.0, NP.pi / 2))
+    env = (ct ** 2)[:, None]
+    if tile:
+        l = NP.sin(theta) * NP.sin(phi)
+        m = NP.sin(theta) * NP.cos(phi)
+        lam = C_LIGHT / freqs_hz
+        with NP.errstate(divide='ignore', invalid='ignore'):
+            def af(x):
+                ph = 2 * NP.pi * 1.1 * x[:, None] / lam[None, :]
+                out = NP.sin(2.0 * ph) / NP.sin(0.5 * ph) / 4.0
+                return NP.where(NP.abs(ph) < 1e-10, 1.0, out)
+            env = env * (af(l) * af(m)) ** 2
+    return env + 1e-6
+
+
+def config4(n_acc=32):
+    """MWA-128T (8128 bl), 768 channels, nside=64 diffuse sky (taper ON), external HEALPix beam nside=32, drift scan."""
+    pos = mwa128_layout()
+    bl, _ = LAY.baseline_generator(pos)
+    bl = LAY.fold_and_sort_baselines(bl)
+    ch = channel_grid(185e6, 40e3, 768)
+    beam_freqs = NP.linspace(165e6, 205e6, 21)
+    sky = diffuse_sky(64, 44, f_ref=185e6)
+    return {'name': 'cfg4: MWA-128T (8128 bl) x 768 ch x nside64 diffuse x %d acc, external HEALPix beam nside32' % n_acc,
+            'baselines': bl, 'channels': ch, 'sky': sky, 'beam': 'external', 'beam_table': synthetic_healpix_beam(32, beam_freqs),
+            'beam_freqs': beam_freqs, 'taper': True, 'precision': 'fp32', 'n_acc': n_acc, 't_acc': 112.0, 'latitude': -26.701}
+
+
+def config5(n_acc=120, nside=256):
+    """HERA-350, 1024 channels, nside=256 diffuse sky (taper ON), Airy 14 m, 120 LSTs + delay transform."""
+    bl, _ = LAY.layout_baselines('HERA-350')
+    return {'name': 'cfg5: HERA-350 (61075 bl) x 1024 ch x nside%d diffuse x %d LST, Airy 14 m' % (nside, n_acc), 'baselines': bl,
+            'channels': channel_grid(150e6, 97656.25, 1024), 'sky': diffuse_sky(nside, 55), 'beam': 'airy', 'diameter': 14.0,
+            'taper': True, 'precision': 'fp32', 'n_acc': n_acc, 't_acc': 10.7, 'latitude': -30.7224}
+
+
+def drift_snapshot_directions(sky, latitude, lst_offset_deg):
+    """Directions of a sky that is fixed in (HA, Dec) at lst offset 0 after the sidereal sphere has turned by lst_offset_deg:
+    returns (dircos, altaz, keep) with keep = above-horizon mask (the ROI selection of interferometry.py:6215-6216)."""
+    hadec = GEOM.altaz2hadec(sky['altaz'], latitude, units='degrees')
+    hadec = NP.stack((hadec[:, 0] + lst_offset_deg, hadec[:, 1]), axis=1)
+    altaz = GEOM.hadec2altaz(hadec, latitude, units='degrees')
+    keep = altaz[:, 0] > 0.0
+    return GEOM.altaz2dircos(altaz[keep], 'degrees'), altaz[keep], keep

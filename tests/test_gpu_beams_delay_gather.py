@@ -67,6 +67,21 @@ def test_delay_transform_matches_numpy_restatement(ctx, pad):
     assert NP.max(NP.abs(pw - DO.delay_power(ref, 2.5))) <= 1e-9 * NP.max(NP.abs(ref)) ** 2 * 2.5
 
 
+def test_delay_transform_in_snapshot_batches(ctx, monkeypatch):
+    """Large cubes are transformed a few snapshots at a time (4 GiB work buffer); force 1-snapshot batches here."""
+    rng = NP.random.default_rng(13)
+    nbl, nchan, nt = 7, 32, 5
+    ch = 150e6 + NP.arange(nchan) * 1.0e5
+    ctx.set_array(rng.uniform(-100, 100, (nbl, 3)), ch, nt_max=nt)
+    cube = rng.normal(size=(nt, nbl, nchan)) + 1j * rng.normal(size=(nt, nbl, nchan))
+    for t in range(nt):
+        ctx.set_vis(cube[t], slot=t)
+    ref, _, refp = ctx.delay_transform(nt, pad=1.0, want_power=True)
+    monkeypatch.setenv('PRISIM_HIP_DT_BATCH_BYTES', str(2 * nbl * 2 * nchan * 16))      # two snapshots per batch -> 3 batches
+    out, _, pw = ctx.delay_transform(nt, pad=1.0, want_power=True)
+    assert NP.array_equal(out, ref) and NP.array_equal(pw, refp)
+
+
 def test_delay_transform_single_tone_kat8(ctx):
     nchan, df = 128, 97656.25
     ch = 150e6 + NP.arange(nchan) * df

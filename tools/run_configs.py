@@ -1,0 +1,92 @@
+"""Run the five BASELINE.json configurations through the C-ABI on one MI355X and print one JSON line
+per configuration: sizes, terms, kernel time, terms/s, wall time including sky staging, and a parity spot check of a few
+baselines against the C oracle.  Config 5 is run for `--lst5` of its 120 LSTs (the full run is 2.95e15 terms)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as NP
+
+from prisim_amd import _abi, workloads as W, primary_beams as PB
+from oracle import c_oracle as CO
+
+
+def run(cfg, ctx, n_acc, spot=6, delay=False):
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    prec = _abi.PRISIM_FP32 if cfg['precision'] == 'fp32' else _abi.PRISIM_FP64
+    zen = NP.array([0.0, 0.0, 1.0])
+    ctx.set_array(bl, ch, nt_max=n_acc)
+    ctx.set_tuning(0, 0, 0)
+    if cfg['beam'] == 'external':
+        ctx.set_external_beam(cfg['beam_table'], PB.spectral_interp_matrix(cfg['beam_freqs'], ch, kind='cubic'))
+    kinds = {'gaussian': _abi.PRISIM_BEAM_GAUSSIAN, 'airy': _abi.PRISIM_BEAM_AIRY}
+    kern_ms = 0.0
+    terms = 0
+    ctx.timing(reset=True)
+    t0 = time.perf_counter()
+    worst = 0.0
+    for j in range(n_acc):
+        if n_acc > 1:
+            dc, altaz, keep = W.drift_snapshot_directions(sky, cfg['latitude'], j * cfg['t_acc'] * 360.0 * 1.00273790935 / 86400.0)
+            fr, sp, fw = sky['flux_ref'][keep], sky['spindex'][keep], sky['fwhm_deg'][keep]
+        else:
+            dc, fr, sp, fw = sky['dircos'], sky['flux_ref'], sky['spindex'], sky['fwhm_deg']
+        fwhm = fw if cfg['taper'] else None
+        if cfg['beam'] == 'external':
+            flux = fr[:, None] * (ch[None, :] / sky['ref_freq']) ** sp[:, None]
+            ctx.set_sky_external(dc, flux, zen, fwhm_deg=fwhm)
+        else:
+            ctx.set_sky_analytic(dc, fr, sp, sky['ref_freq'], kinds[cfg['beam']], cfg['diameter'], zen, zen, fwhm_deg=fwhm)
+        ctx.compute(precision=prec, slot=j)
+        terms += bl.shape[0] * ch.size * dc.shape[0]
+        if j == n_acc - 1 and spot:
+            ctx.sync()
+            pb = ctx.get_pbflux()
+            sel = NP.linspace(0, bl.shape[0] - 1, spot).astype(int)
+            ref = CO.skyvis(bl[sel], ch, dc, pb, zen, fwhm_deg=fwhm)
+            vis = ctx.get_vis(slot=j)[sel]
+            worst = float(NP.max(NP.abs(vis - ref) / NP.sum(NP.abs(pb), axis=0)[None, :]))
+    ctx.sync()
+    wall = time.perf_counter() - t0
+    tm = ctx.timing()
+    kern_ms = tm['sum_kernel_ms']
+    out = {'config': cfg['name'], 'nbl': int(bl.shape[0]), 'nchan': int(ch.size), 'nsrc_catalog': int(sky['dircos'].shape[0]),
+           'n_acc': n_acc, 'precision': cfg['precision'], 'taper': bool(cfg['taper']), 'terms': float(terms),
+           'kernel_ms_total': kern_ms, 'terms_per_s_kernel': terms / (kern_ms * 1e-3) if kern_ms > 0 else None,
+           'wall_s_incl_sky_staging_and_spot_check': wall, 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
+           'parity_spot_max_err_rel_sumflux': worst, 'tolerance': 5e-6 if cfg['precision'] == 'fp32' else 1e-11}
+    if delay:
+        t1 = time.perf_counter()
+        _, lags, pw = ctx.delay_transform(n_acc, pad=1.0, want_power=True, power_scale=1.0, want_lag=False)
+        out['delay_power_spectrum_s'] = time.perf_counter() - t1
+        out['delay_ffts'] = int(n_acc * bl.shape[0])
+        out['delay_fft_length'] = int(2 * ch.size)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--lst5', type=int, default=2)
+    ap.add_argument('--nside5', type=int, default=256)
+    ap.add_argument('--configs', default='1,2,3,4,5')
+    args = ap.parse_args()
+    ctx = _abi.Context(0)
+    which = [int(x) for x in args.configs.split(',')]
+    if 1 in which:
+        print(json.dumps(run(W.config1(), ctx, 1)), flush=True)
+    if 2 in which:
+        print(json.dumps(run(W.config2(), ctx, 1)), flush=True)
+    if 3 in which:
+        print(json.dumps(run(W.config3(), ctx, 1)), flush=True)
+    if 4 in which:
+        print(json.dumps(run(W.config4(), ctx, 32)), flush=True)
+    if 5 in which:
+        print(json.dumps(run(W.config5(n_acc=args.lst5, nside=args.nside5), ctx, args.lst5, delay=True)), flush=True)
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()
