@@ -59,6 +59,7 @@ def cpu_baseline(cfg, pbflux_sample_fn, target_terms=1.0e10):
     """Time the C oracle (oracle/skyvis_oracle.c, the checker) on a bounded baseline sample of the same
     workload, on this box's host cores.  Reported baseline only -- never the thing measured above."""
     from oracle import c_oracle as CO
+    CO.use_native_build()          # -march=native for THIS host's cores (falls back to the shipped portable build)
     threads = max(1, min(16, os.cpu_count() or 1, CO.max_threads()))
     bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
     nsrc, nchan = sky['dircos'].shape[0], ch.size
@@ -75,7 +76,7 @@ def cpu_baseline(cfg, pbflux_sample_fn, target_terms=1.0e10):
     terms = float(bls.shape[0]) * nchan * nsrc
     return {'value': terms / dt, 'unit': 'terms/s', 'cores': threads, 'kind': 'port',
             'sample': '%d of %d baselines (every %d-th) x %d ch x %d src = %.3g terms in %.1f s, C/OpenMP libm-sincos port of '
-                      'interferometry.py:6332-6340' % (bls.shape[0], bl.shape[0], stride, nchan, nsrc, terms, dt)}, bls, ref, stride
+                      'interferometry.py:6332-6340, %s' % (bls.shape[0], bl.shape[0], stride, nchan, nsrc, terms, dt, CO.flavour)}, bls, ref, stride
 
 
 def profiled_traffic(kernel_tag):

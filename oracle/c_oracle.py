@@ -7,11 +7,37 @@ import numpy as NP
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, 'liboracle_skyvis.so')
+_LIB_NATIVE = os.path.join(_HERE, 'liboracle_skyvis_native.so')
 _lib = None
+flavour = 'portable (x86-64-v3)'
 
 
 def build():
     subprocess.check_call(['make', '-s', '-C', _HERE])
+
+
+def use_native_build():
+    """Compile the oracle with -march=native on THIS machine and switch to it (bench.py's cpu_baseline leg: the baseline is
+    timed on the host cores of the GPU box, so it gets that CPU's full instruction set).  Falls back silently to the
+    portable build that ships with the snapshot."""
+    global _lib, flavour
+    try:
+        subprocess.check_call(['make', '-s', '-B', '-C', _HERE, 'native'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = C.CDLL(_LIB_NATIVE)
+    except Exception:
+        return False
+    _lib = None
+    _declare(lib)
+    _lib = lib
+    flavour = 'native (-march=native on this host)'
+    return True
+
+
+def _declare(lib):
+    lib.oracle_skyvis_f64.restype = C.c_int
+    lib.oracle_skyvis_f64.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.oracle_max_threads.restype = C.c_int
 
 
 def _load():
@@ -19,11 +45,9 @@ def _load():
     if _lib is None:
         if not os.path.exists(_LIB):
             build()
-        _lib = C.CDLL(_LIB)
-        _lib.oracle_skyvis_f64.restype = C.c_int
-        _lib.oracle_skyvis_f64.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        _lib.oracle_max_threads.restype = C.c_int
+        lib = C.CDLL(_LIB)
+        _declare(lib)
+        _lib = lib
     return _lib
 
 
