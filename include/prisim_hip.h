@@ -220,7 +220,7 @@ typedef struct prisim_timing {
   int32_t last_kernel_id;    /* PRISIM_KERNEL_* actually used */
   int32_t last_chan_tile;    /* channels per thread of the recurrence kernel */
   int32_t last_nsplit;       /* source split factor */
-  int32_t reserved;
+  int32_t last_lift_groups;  /* baseline groups (of 256) that ran the 5-instruction lifting rotation (fp32, no taper) */
 } prisim_timing;
 
 int prisim_hip_sync(prisim_ctx* ctx);

@@ -110,7 +110,9 @@ struct prisim_ctx {
   // array
   bool array_set = false;
   int64_t nbl = 0, nchan = 0, nt_max = 0;
-  DevBuf blx, bly, blz, freqs, fsq, fsq_pairs, cube, grad;
+  DevBuf blx, bly, blz, freqs, fsq, fsq_pairs, cube, grad, lift_flags;
+  std::vector<double> grp_maxlen;     // max |b| per group of kBlockThreads baselines (lifting-rotation guarantee)
+  double dmax = 2.0;                  // max_s |s - s_pc| of the current sky
   std::vector<double> h_freqs;
   bool uniform = false;
   double f0 = 0.0, df = 0.0;
@@ -327,7 +329,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
   if (ctx->fft_plan && g_rocfft.plan_destroy) g_rocfft.plan_destroy(ctx->fft_plan);
   if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
-  for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->cube, &ctx->grad, &ctx->dirs,
+  for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->dirs_prep, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax,
                     &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts})
@@ -373,6 +375,12 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   HIPCHK(ctx, launch_fsq((const double*)ctx->freqs.p, (float*)ctx->fsq.p, nchan, ctx->nchan_pad, 1e-8, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->h_freqs.assign(freqs_hz, freqs_hz + nchan);
+  ctx->grp_maxlen.assign((size_t)((nbl + kBlockThreads - 1) / kBlockThreads), 0.0);
+  for (int64_t b = 0; b < nbl; ++b) {
+    const double len = std::sqrt(x[b] * x[b] + y[b] * y[b] + z[b] * z[b]);
+    double& m = ctx->grp_maxlen[(size_t)(b / kBlockThreads)];
+    if (len > m) m = len;
+  }
   ctx->nbl = nbl; ctx->nchan = nchan; ctx->nt_max = nt_max;
   // uniform channel grid?  f_k = f0 + k*df to within 1e-7 Hz (phase error <= 1e-13 cycles at 1 us delay)
   ctx->f0 = freqs_hz[0];
@@ -395,7 +403,13 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
   for (int i = 0; i < 3; ++i)
     if (!std::isfinite(pc_dircos[i])) return fail(ctx, PRISIM_EINVAL, "non-finite pc_dircos");
   std::vector<double> d4((size_t)std::max<int64_t>(nsrc, 1) * 4, 0.0);
+  double dmax2 = 0.0;
   for (int64_t s = 0; s < nsrc; ++s) {
+    {
+      const double ex = dircos[3 * s] - pc_dircos[0], ey = dircos[3 * s + 1] - pc_dircos[1], ez = dircos[3 * s + 2] - pc_dircos[2];
+      const double e2 = ex * ex + ey * ey + ez * ez;
+      if (e2 > dmax2) dmax2 = e2;
+    }
     for (int i = 0; i < 3; ++i) {
       const double v = dircos[3 * s + i];
       if (!std::isfinite(v)) return fail(ctx, PRISIM_EINVAL, "non-finite direction cosine");
@@ -416,6 +430,7 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
   HIPCHK(ctx, hipMemcpyAsync(ctx->dirs.p, d4.data(), d4.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // d4 is a local
   ctx->nsrc = nsrc;
+  ctx->dmax = std::sqrt(dmax2);
   ctx->taper = fwhm_deg != nullptr;
   for (int i = 0; i < 3; ++i) ctx->pc[i] = pc_dircos[i];
   return PRISIM_OK;
@@ -619,6 +634,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   p.pb_packed = ctx->packed.p;
   p.fsq = (const float*)ctx->fsq.p;
   p.fsq_pairs = (const float*)ctx->fsq_pairs.p;
+  p.lift_flags = (pl.pk && !ctx->taper && ctx->lift_flags.p) ? (const int32_t*)ctx->lift_flags.p : nullptr;
   p.fsq_scale = 1e16;
   p.nsrc = ctx->nsrc; p.nsrc_pad = pl.nsrc_pad;
   p.pc_x = ctx->pc[0]; p.pc_y = ctx->pc[1]; p.pc_z = ctx->pc[2];
@@ -680,11 +696,27 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     return PRISIM_OK;
   }
   const Plan pl = make_plan(ctx, precision, kernel);
+  ctx->timing.last_lift_groups = 0;
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE) {
     const size_t pbytes = (size_t)pl.ntiles * pl.nsrc_pad * pl.ct * (pl.f32 ? 4 : 8);
     if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;
     if ((rc = ensure(ctx, ctx->dirs_prep, (size_t)pl.nsrc_pad * 4 * sizeof(double)))) return rc;
     if (pl.nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)pl.nsplit * slot_elems * sizeof(double)))) return rc;
+    if (pl.pk && !ctx->taper) {
+      // lifting rotation is used for a baseline group only when |step phase| <= 1/8 cycle is guaranteed for every source:
+      // |theta| = |b . (s - s_pc)| |df| / c <= max|b| * max_s|s - s_pc| * |df| / c
+      std::vector<int32_t> flags((size_t)pl.nbgroups, 0);
+      const double k = ctx->dmax * std::fabs(ctx->df) / kC;
+      int nlift = 0;
+      for (int g = 0; g < pl.nbgroups; ++g) {
+        flags[(size_t)g] = (ctx->grp_maxlen[(size_t)g] * k <= 0.125 * (1.0 - 1e-9)) ? 1 : 0;
+        nlift += flags[(size_t)g];
+      }
+      ctx->timing.last_lift_groups = nlift;
+      if ((rc = ensure(ctx, ctx->lift_flags, flags.size() * sizeof(int32_t)))) return rc;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->lift_flags.p, flags.data(), flags.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // flags is a local
+    }
     if (pl.f32 && ctx->taper) {
       if ((rc = ensure(ctx, ctx->fsq_pairs, (size_t)pl.ntiles * pl.ct * sizeof(float)))) return rc;
       HIPCHK(ctx, launch_fsq_pairs((const float*)ctx->fsq.p, (float*)ctx->fsq_pairs.p, pl.ct, pl.ntiles, ctx->stream));

@@ -24,6 +24,7 @@ struct SkyvisParams {
   const void* pb_packed;     // [ntiles][nsrc_pad][CT] of T, zero rows past nsrc
   const float* fsq;          // [npad] (f_k*1e-8)^2*log2(e) (fp32 taper)
   const float* fsq_pairs;    // [ntiles][CT] the same, in the (up,down) pair order of k_skyvis_rec_f32pk
+  const int32_t* lift_flags; // [nbgroups] 1: the lifting rotation is safe for this baseline group (or nullptr)
   double fsq_scale;          // 1e16
   int64_t nsrc;
   int64_t nsrc_pad;          // nsrc rounded up to a multiple of src_chunk

@@ -63,6 +63,17 @@ __device__ __forceinline__ void sincos_qcycles(double a4, float& c, float& s) {
   s = ((qi & 2) != 0) ? -ss : ss;          // q mod 4 in {2,3}
 }
 
+// tan(pi y) for |y| <= 1/8 cycle, ~1 ulp: y*pi (hi + lo) + y^3 * P(y^2), P = least-squares fit of (tan(pi y)/y - pi)/y^2
+__device__ __forceinline__ float tan_pi_y(float y) {
+  const float u = y * y;
+  float pt = 764.9256591796875f;
+  pt = __builtin_fmaf(pt, u, 161.4058837890625f);
+  pt = __builtin_fmaf(pt, u, 40.8116340637207f);
+  pt = __builtin_fmaf(pt, u, 10.335408210754395f);
+  const float t = __builtin_fmaf(y * u, pt, y * 3.1415927410125732f);   // fl32(pi)
+  return __builtin_fmaf(y, -8.742278e-8f, t);                           // + y * (pi - fl32(pi))
+}
+
 __device__ __forceinline__ void sincos_qcycles(double a4, double& c, double& s) {
   // fp64: residual angle t = 2 pi y, |t| <= pi/4; fdlibm __kernel_sin/__kernel_cos minimax coefficients
   const double q = __builtin_rint(a4);
@@ -321,10 +332,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <int CT, bool TAPER>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_skyvis_rec_f32pk(const SkyvisParams p) {
+// LIFT: the step rotation uses the lifting (three-shear) form
+//     x1 = x - t y,  y1 = y + s x1,  x2 = x1 - t y1,   t = tan(alpha/2), s = sin(alpha)
+// = 3 dependent packed FMAs instead of 2 mul + 2 fma, i.e. 5 instead of 6 packed instructions per pair of terms
+// (tools/microbench_inner.hip: 12.5e12 vs 11.1e12 terms/s for the bare loop).  With inexact (t, s) the map is still
+// area-preserving and advances the phase by beta with cos(beta) = 1 - t s, so the angle error per step is ~ alpha * eps:
+// it is only used where |alpha| <= pi/4 is GUARANTEED for every source (the host sets lift_flags[bg] when
+// max|b| * max_s|s - s_pc| * |df| / c <= 1/8 cycle for the baseline group), all other groups take the 4-instruction rotation.
+template <int CT, bool TAPER, bool LIFT>
+__device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p) {
   static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
+  static_assert(!(TAPER && LIFT), "the taper-folded recurrence is a scaled rotation: no lifting form");
   constexpr int HC = CT / 2;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -412,8 +430,13 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
         const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));
         float zc, zs, rc, rs;
         sincos_qcycles(d * fc4, zc, zs);
-        sincos_qcycles(d * df4, rc, rs);
+        const double th4 = d * df4;
+        sincos_qcycles(th4, rc, rs);
         const float ur0 = zc, ui0 = -zs, rr = rc, ri = -rs;     // z = exp(-2 pi i phi), r likewise
+        // lifting operands: alpha = -2 pi theta, |theta| <= 1/8 cycle guaranteed by the host for LIFT groups
+        const float tpy = LIFT ? tan_pi_y((float)(0.25 * th4)) : 0.f;     // tan(pi theta) = -tan(alpha/2)
+        const f32x2 NT = {tpy, -tpy};                    // (-t_up, -t_down)
+        const f32x2 SS = {ri, -ri};                      // (sin alpha_up, sin alpha_down)
         const float dr0 = __builtin_fmaf(ur0, rr, ui0 * ri);    // down chain starts at z * conj(r)
         const float di0 = __builtin_fmaf(ui0, rr, -(ur0 * ri));
         f32x2 zre = {ur0, dr0};
@@ -455,7 +478,20 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
           const float4 pv = (j < HC / 2) ? pa[j / 2] : pb[j / 2 - NQ];   // (up_j, down_j, up_j+1, down_j+1)
           const f32x2 p0 = {pv.x, pv.y};
           const f32x2 p1 = {pv.z, pv.w};
-          if (!TAPER) {
+          if (LIFT) {
+            acc_re[j] = pkfma(p0, zre, acc_re[j]);
+            acc_im[j] = pkfma(p0, zim, acc_im[j]);
+            f32x2 x1 = pkfma(NT, zim, zre);
+            f32x2 y1 = pkfma(SS, x1, zim);
+            zre = pkfma(NT, y1, x1);
+            zim = y1;
+            acc_re[j + 1] = pkfma(p1, zre, acc_re[j + 1]);
+            acc_im[j + 1] = pkfma(p1, zim, acc_im[j + 1]);
+            x1 = pkfma(NT, zim, zre);
+            y1 = pkfma(SS, x1, zim);
+            zre = pkfma(NT, y1, x1);
+            zim = y1;
+          } else if (!TAPER) {
             acc_re[j] = pkfma(p0, zre, acc_re[j]);
             acc_im[j] = pkfma(p0, zim, acc_im[j]);
             f32x2 t0 = zim * RI;
@@ -521,6 +557,21 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
     for (int k = 0; k < CT; ++k)
       if (k0 + k < p.nchan) orow[k] = make_double2(0.0, 0.0);
   }
+}
+
+template <int CT, bool TAPER>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_skyvis_rec_f32pk(const SkyvisParams p) {
+  if constexpr (!TAPER) {
+    // block-uniform choice made by the host per baseline group; the two bodies share no live state
+    const int jblk = blockIdx.x >> 3;
+    const int bg = jblk % p.nbgroups;
+    if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {
+      skyvis_rec_f32pk_body<CT, false, true>(p);
+      return;
+    }
+  }
+  skyvis_rec_f32pk_body<CT, TAPER, false>(p);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -124,6 +124,44 @@ def test_config3_subsample_fp32_and_fp64(ctx):
         assert relerr(ctx.get_vis(), ref, pb) <= TOL[prec]
 
 
+def test_lifting_rotation_groups_and_fallback(ctx):
+    """fp32 / no taper: baseline groups whose step phase is guaranteed within +-1/8 cycle use the 5-instruction lifting
+    rotation, the others the 4-instruction one; both must meet the tolerance, also inside one launch."""
+    rng = NP.random.default_rng(77)
+    nchan, nsrc = 128, 500
+    ch = 150e6 + NP.arange(nchan) * 97656.25
+    alt = NP.degrees(NP.arcsin(rng.uniform(NP.sin(NP.radians(10.0)), 1.0, nsrc)))
+    dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, nsrc)), axis=1))
+    pb = rng.uniform(0.0, 5.0, (nsrc, nchan))
+    zen = NP.array([0.0, 0.0, 1.0])
+    ang = rng.uniform(0, 2 * NP.pi, 768)
+    length = NP.concatenate((rng.uniform(5.0, 250.0, 512), rng.uniform(400.0, 3000.0, 256)))     # 2 short groups + 1 long group
+    bl = NP.stack((length * NP.cos(ang), length * NP.sin(ang), NP.zeros(768)), axis=1)
+    ref = CO.skyvis(bl, ch, dc, pb, zen)
+    ctx.set_array(bl, ch)
+    ctx.set_sky(dc, pb, zen)
+    for ct in (64, 32):
+        ctx.set_tuning(ct, 0, 1)
+        ctx.compute(precision=_abi.PRISIM_FP32)
+        vis = ctx.get_vis()
+        assert ctx.timing()['last_lift_groups'] == 2
+        assert relerr(vis[:512], ref[:512], pb) <= 5e-6          # lifting groups
+        assert relerr(vis[512:], ref[512:], pb) <= 5e-6          # step phase up to ~1 cycle: standard rotation
+    # single bright source at the edge of the lifting range, worst case for the per-step angle error
+    s1 = O.altaz2dircos(NP.array([[10.0, 45.0]]))
+    p1 = NP.ones((1, nchan))
+    ctx.set_sky(s1, p1, zen)
+    ctx.set_tuning(64, 0, 1)
+    ctx.compute(precision=_abi.PRISIM_FP32)
+    assert ctx.timing()['last_lift_groups'] == 2
+    assert relerr(ctx.get_vis()[:512], CO.skyvis(bl[:512], ch, s1, p1, zen), p1) <= 5e-6
+    # taper on: no lifting
+    ctx.set_sky(dc, pb, zen, fwhm_deg=NP.full(nsrc, 0.3))
+    ctx.compute(precision=_abi.PRISIM_FP32)
+    assert ctx.timing()['last_lift_groups'] == 0
+    ctx.set_tuning(0, 0, 0)
+
+
 # ---------------------------------------------------------------- analytic known answers on the GPU
 BL = NP.array([[14.6, 0.0, 0.0], [7.3, 12.644, 0.0], [-250.0, 120.0, 1.5], [0.0, 0.0, 0.0]])
 CH = 150e6 + (NP.arange(48) - 24) * 390625.0
