@@ -634,7 +634,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   p.pb_packed = ctx->packed.p;
   p.fsq = (const float*)ctx->fsq.p;
   p.fsq_pairs = (const float*)ctx->fsq_pairs.p;
-  p.lift_flags = (pl.pk && !ctx->taper && ctx->lift_flags.p) ? (const int32_t*)ctx->lift_flags.p : nullptr;
+  p.lift_flags = (!ctx->taper && ctx->lift_flags.p) ? (const int32_t*)ctx->lift_flags.p : nullptr;
   p.fsq_scale = 1e16;
   p.nsrc = ctx->nsrc; p.nsrc_pad = pl.nsrc_pad;
   p.pc_x = ctx->pc[0]; p.pc_y = ctx->pc[1]; p.pc_z = ctx->pc[2];
@@ -702,14 +702,15 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;
     if ((rc = ensure(ctx, ctx->dirs_prep, (size_t)pl.nsrc_pad * 4 * sizeof(double)))) return rc;
     if (pl.nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)pl.nsplit * slot_elems * sizeof(double)))) return rc;
-    if (pl.pk && !ctx->taper) {
-      // lifting rotation is used for a baseline group only when |step phase| <= 1/8 cycle is guaranteed for every source:
+    if (!ctx->taper) {
+      // lifting rotation is used for a baseline group only when |step phase| <= 1/8 cycle (fp32; 1/4 cycle in fp64, where the
+      // angle error alpha*eps is irrelevant and only tan(alpha/2) must stay bounded) is guaranteed for every source:
       // |theta| = |b . (s - s_pc)| |df| / c <= max|b| * max_s|s - s_pc| * |df| / c
       std::vector<int32_t> flags((size_t)pl.nbgroups, 0);
       const double k = ctx->dmax * std::fabs(ctx->df) / kC;
       int nlift = 0;
       for (int g = 0; g < pl.nbgroups; ++g) {
-        flags[(size_t)g] = (ctx->grp_maxlen[(size_t)g] * k <= 0.125 * (1.0 - 1e-9)) ? 1 : 0;
+        flags[(size_t)g] = (ctx->grp_maxlen[(size_t)g] * k <= (pl.f32 ? 0.125 : 0.25) * (1.0 - 1e-9)) ? 1 : 0;
         nlift += flags[(size_t)g];
       }
       ctx->timing.last_lift_groups = nlift;

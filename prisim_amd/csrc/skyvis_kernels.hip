@@ -63,6 +63,17 @@ __device__ __forceinline__ void sincos_qcycles(double a4, float& c, float& s) {
   s = ((qi & 2) != 0) ? -ss : ss;          // q mod 4 in {2,3}
 }
 
+// sin(2 pi y) for |y| <= 1/8 cycle (the polynomial of sincos_qcycles without the quadrant logic)
+__device__ __forceinline__ float sin_2pi_y(float y) {
+  const float y2 = y * y;
+  float ps = 42.058693944897655f;
+  ps = __builtin_fmaf(ps, y2, -76.70585975306136f);
+  ps = __builtin_fmaf(ps, y2, 81.60524927607504f);
+  ps = __builtin_fmaf(ps, y2, -41.341702240399755f);
+  const float sy = __builtin_fmaf(y * y2, ps, y * 6.2831855f);
+  return __builtin_fmaf(y, -1.7484555e-7f, sy);
+}
+
 // tan(pi y) for |y| <= 1/8 cycle, ~1 ulp: y*pi (hi + lo) + y^3 * P(y^2), P = least-squares fit of (tan(pi y)/y - pi)/y^2
 __device__ __forceinline__ float tan_pi_y(float y) {
   const float u = y * y;
@@ -117,10 +128,11 @@ template <typename T, int CT> struct WavesPerEU {
   static constexpr int value = (sizeof(T) == 4) ? (CT <= 32 ? 4 : 2) : (CT <= 8 ? 4 : (CT <= 16 ? 3 : 2));
 };
 
-template <typename T, int CT, bool TAPER>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(WavesPerEU<T, CT>::value)))
-void k_skyvis_rec(const SkyvisParams p) {
+// LIFT: lifting (three-shear) form of the step rotation, see skyvis_rec_f32pk_body below; chosen per baseline group by the host.
+template <typename T, int CT, bool TAPER, bool LIFT>
+__device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p) {
   static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
+  static_assert(!(TAPER && LIFT), "no lifting form with the taper");
   constexpr int HC = CT / 2;                       // channels per chain
   constexpr int VE = 16 / (int)sizeof(T);           // elements per 16-byte piece
 
@@ -244,12 +256,18 @@ void k_skyvis_rec(const SkyvisParams p) {
         const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));   // seconds
         T zc, zs, rc, rs;
         sincos_qcycles(d * fc4, zc, zs);                           // phase at the centre channel
-        sincos_qcycles(d * df4, rc, rs);                           // phase step per channel
+        const double th4 = d * df4;
+        sincos_qcycles(th4, rc, rs);                               // phase step per channel
         // exp(-2 pi i phi): z = (cos, -sin)
         T ur = zc, ui = -zs;            // up chain: channel HC + j
         const T rr = rc, ri = -rs;      // step forward; step backward is conj(r)
         T dr = fma_(ur, rr, ui * ri);        // z * conj(r): channel HC-1
         T di = fma_(ui, rr, -(ur * ri));
+        T tl = (T)0;                         // tan(alpha/2), alpha = -2 pi theta the step angle (LIFT groups only)
+        if constexpr (LIFT) {
+          if constexpr (sizeof(T) == 4) tl = -tan_pi_y((float)(0.25 * th4));      // |theta| <= 1/8 cycle guaranteed
+          else tl = ri / ((T)1 + rr);                                             // |theta| <= 1/4 cycle guaranteed: 1 + cos >= 1
+        }
         // source-shape taper  w = exp(-g f^2),  g = kappa_s * (|b|^2/c^2 - tau^2),  tau = d + b.s_pc/c
         double gq = 0.0;
         float g2 = 0.f;
@@ -301,11 +319,21 @@ void k_skyvis_rec(const SkyvisParams p) {
           acc_im[ku] = fma_(pu, ui, acc_im[ku]);
           acc_re[kd] = fma_(pd, dr, acc_re[kd]);
           acc_im[kd] = fma_(pd, di, acc_im[kd]);
-          const T nur = fma_(ur, rr, -(ui * ri));
-          const T nui = fma_(ur, ri, ui * rr);
-          const T ndr = fma_(dr, rr, di * ri);
-          const T ndi = fma_(di, rr, -(dr * ri));
-          ur = nur; ui = nui; dr = ndr; di = ndi;
+          if constexpr (LIFT) {
+            // x1 = x - t y, y1 = y + s x1, x2 = x1 - t y1 with t = tan(alpha/2), s = sin(alpha) = ri (up), -t, -s (down)
+            const T xu = fma_(-tl, ui, ur);
+            const T yu = fma_(ri, xu, ui);
+            ur = fma_(-tl, yu, xu); ui = yu;
+            const T xd = fma_(tl, di, dr);
+            const T yd = fma_(-ri, xd, di);
+            dr = fma_(tl, yd, xd); di = yd;
+          } else {
+            const T nur = fma_(ur, rr, -(ui * ri));
+            const T nui = fma_(ur, ri, ui * rr);
+            const T ndr = fma_(dr, rr, di * ri);
+            const T ndi = fma_(di, rr, -(dr * ri));
+            ur = nur; ui = nui; dr = ndr; di = ndi;
+          }
         }
       }
     }
@@ -313,6 +341,19 @@ void k_skyvis_rec(const SkyvisParams p) {
     if (sizeof(T) == 4 && since_flush >= p.flush_src && more) flush();
   }
   flush();
+}
+
+template <typename T, int CT, bool TAPER>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(WavesPerEU<T, CT>::value)))
+void k_skyvis_rec(const SkyvisParams p) {
+  if constexpr (!TAPER) {
+    const int bg = (blockIdx.x >> 3) % p.nbgroups;
+    if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {      // block-uniform; the two bodies share no live state
+      skyvis_rec_body<T, CT, false, true>(p);
+      return;
+    }
+  }
+  skyvis_rec_body<T, CT, TAPER, false>(p);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -428,17 +469,30 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p) {
         __builtin_amdgcn_sched_barrier(0);
 
         const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));
-        float zc, zs, rc, rs;
+        float zc, zs;
         sincos_qcycles(d * fc4, zc, zs);
+        const float ur0 = zc, ui0 = -zs;                 // z = exp(-2 pi i phi) at channel HC
         const double th4 = d * df4;
-        sincos_qcycles(th4, rc, rs);
-        const float ur0 = zc, ui0 = -zs, rr = rc, ri = -rs;     // z = exp(-2 pi i phi), r likewise
-        // lifting operands: alpha = -2 pi theta, |theta| <= 1/8 cycle guaranteed by the host for LIFT groups
-        const float tpy = LIFT ? tan_pi_y((float)(0.25 * th4)) : 0.f;     // tan(pi theta) = -tan(alpha/2)
+        float rr = 1.f, ri, tpy = 0.f, dr0, di0;
+        if (LIFT) {
+          // |theta| <= 1/8 cycle is guaranteed for this baseline group: no quadrant reduction, no cosine.  alpha = -2 pi theta:
+          // s = sin(alpha) = ri, t = tan(alpha/2) = -tan(pi theta)
+          const float yth = (float)(0.25 * th4);
+          ri = -sin_2pi_y(yth);
+          tpy = tan_pi_y(yth);
+          // down chain starts one channel below: rotate z by -alpha with the same three shears (t -> -t, s -> -s)
+          const float x1 = __builtin_fmaf(-tpy, ui0, ur0);
+          di0 = __builtin_fmaf(-ri, x1, ui0);
+          dr0 = __builtin_fmaf(-tpy, di0, x1);
+        } else {
+          float rc, rs;
+          sincos_qcycles(th4, rc, rs);
+          rr = rc; ri = -rs;                             // r = exp(-2 pi i theta)
+          dr0 = __builtin_fmaf(ur0, rr, ui0 * ri);       // down chain starts at z * conj(r)
+          di0 = __builtin_fmaf(ui0, rr, -(ur0 * ri));
+        }
         const f32x2 NT = {tpy, -tpy};                    // (-t_up, -t_down)
         const f32x2 SS = {ri, -ri};                      // (sin alpha_up, sin alpha_down)
-        const float dr0 = __builtin_fmaf(ur0, rr, ui0 * ri);    // down chain starts at z * conj(r)
-        const float di0 = __builtin_fmaf(ui0, rr, -(ur0 * ri));
         f32x2 zre = {ur0, dr0};
         f32x2 zim = {ui0, di0};
         const f32x2 RR = {rr, rr};
