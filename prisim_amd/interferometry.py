@@ -773,10 +773,21 @@ class InterferometerArray(object):
                 outs.append(out)
             return NP.stack(outs, axis=2), lags
 
-        self.skyvis_lag, self.lags = transform(NP.asarray(self.skyvis_freq, dtype=NP.complex128))
+        nt_all = self.skyvis_freq.shape[2]
+        wall = (self.bp * self.bp_wts).reshape(nbl, nchan, -1)
+        same_wts = wall.shape[2] == 1 or bool(NP.all(wall == wall[:, :, [0]]))
+        if self._reserved >= nt_all and self.n_acc == nt_all and same_wts and self.skyvis_freq.dtype == NP.complex128:
+            # the cube is resident on the GPU (reserve()): transform all snapshots in place, no re-upload
+            out, self.lags, _ = self._ctx.delay_transform(nt_all, bpwts=wall[:, :, 0], pad=pad)
+            self.skyvis_lag = NP.transpose(out, (1, 2, 0))
+        else:
+            self.skyvis_lag, self.lags = transform(NP.asarray(self.skyvis_freq, dtype=NP.complex128))
         if self.vis_freq is not None:
             self.vis_lag, _ = transform(NP.asarray(self.vis_freq, dtype=NP.complex128))
         if self.vis_noise_freq is not None:
             self.vis_noise_lag, _ = transform(NP.asarray(self.vis_noise_freq, dtype=NP.complex128))
         ones = NP.ones((nbl, nchan, self.skyvis_freq.shape[2]), dtype=NP.complex128)
         self.lag_kernel, _ = transform(ones)                                           # :8119 / :8127
+        if self._reserved >= self.n_acc and self._cube:
+            # the host-cube transforms above went through device slot 0: put the resident snapshot back
+            self._ctx.set_vis(NP.asarray(self.skyvis_freq[:, :, 0], dtype=NP.complex128), slot=0)

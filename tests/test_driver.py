@@ -135,6 +135,11 @@ def test_config2_yaml_runs_and_reserves_device_cube():
     # the device-resident cube holds the same snapshots (slot t) as the host attribute
     for t in range(2):
         assert NP.array_equal(ia._ctx.get_vis(slot=t), out['skyvis_freq'][:, :, t])
+    # device-resident delay transform (no re-upload) equals the per-snapshot host path
+    from oracle import delay_oracle as DO
+    ia.delay_transform(pad=1.0, verbose=False)
+    ref_lag, ref_lags = DO.delay_transform(out['skyvis_freq'], ia.bp, ia.bp_wts, ia.freq_resolution, pad=1.0)
+    assert NP.max(NP.abs(ia.skyvis_lag - ref_lag)) <= 1e-10 * NP.max(NP.abs(ref_lag)) and NP.allclose(ia.lags, ref_lags)
     # single-rank "gather" through the same code path the multi-GPU driver uses
     ia._ctx.allgather(2)
     g = ia._ctx.get_gathered(2, 1)

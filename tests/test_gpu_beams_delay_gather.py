@@ -374,3 +374,35 @@ def test_interferometer_array_phase_centering_project_conjugate():
         ia.conjugate(ind=[7])
     with pytest.raises(KeyError):
         ia.rotate_visibilities({'location': NP.array([90.0, 270.0])})
+
+
+def test_observe_radec_sky_and_roi_selection():
+    """skycoords='radec' (HA = LST - RA), pointing_coords='radec', roi_center='pointing_center' with a finite radius."""
+    rng = NP.random.default_rng(21)
+    lat, lst = -30.7224, 47.0
+    nsrc = 400
+    ra = rng.uniform(0, 360, nsrc)
+    dec = NP.degrees(NP.arcsin(rng.uniform(-1, 0.6, nsrc)))
+    skymod = SM.SkyModel(location=NP.stack((ra, dec), 1), flux_ref=rng.uniform(1, 5, nsrc), spindex=rng.uniform(-1, 0, nsrc), ref_freq=150e6)
+    ch = 150e6 + (NP.arange(24) - 12) * 2e5
+    bl = rng.uniform(-100, 100, (11, 3)); bl[:, 2] = 0
+    ia = RI.InterferometerArray(list(range(11)), bl, ch, telescope={'shape': 'dish', 'size': 14.0}, latitude=lat, skycoords='radec',
+                                pointing_coords='radec')
+    pc_radec = [lst - 20.0, lat + 10.0]                    # HA = 20 deg, Dec = lat + 10
+    ia.observe((2457000.5, lst), {'Tnet': 100.0}, NP.ones(24), pc_radec, skymod, 10.0, roi_radius=40.0, roi_center='pointing_center')
+    altaz = O.hadec2altaz(NP.stack((lst - ra, dec), 1), lat)
+    dc = O.altaz2dircos(altaz)
+    pc_altaz = O.hadec2altaz([[20.0, lat + 10.0]], lat)[0]
+    pc_dc = O.altaz2dircos(pc_altaz[None, :])[0]
+    sel = NP.where(NP.degrees(NP.arccos(NP.clip(dc @ pc_dc, -1, 1))) <= 40.0)[0]
+    assert NP.array_equal(ia.obs_catalog_indices[0], sel) and 0 < sel.size < nsrc
+    pb = BO.airy_disk_pattern(14.0, altaz[sel], ch, pointing_altaz=pc_altaz) * skymod.generate_spectrum(ind=sel, frequency=ch)
+    ref = O.skyvis(bl, ch, dc[sel], pb, pc_dc)
+    assert NP.max(NP.abs(ia.skyvis_freq[:, :, 0] - ref) / O.abs_flux_sum(pb)[None, :]) <= 1e-11
+    # default region of interest: the visible hemisphere (alt >= 0)
+    ia2 = RI.InterferometerArray(list(range(11)), bl, ch, telescope={'shape': 'delta'}, latitude=lat, skycoords='radec', pointing_coords='radec')
+    ia2.observe((2457000.5, lst), {'Tnet': 100.0}, NP.ones(24), pc_radec, skymod, 10.0)
+    up = NP.where(altaz[:, 0] >= 0.0)[0]
+    assert NP.array_equal(ia2.obs_catalog_indices[0], up)
+    ref2 = O.skyvis(bl, ch, dc[up], skymod.generate_spectrum(ind=up, frequency=ch), pc_dc)
+    assert NP.max(NP.abs(ia2.skyvis_freq[:, :, 0] - ref2)) <= 1e-10
