@@ -73,11 +73,6 @@ def concat_skies(*skies):
     return out
 
 
-CONFIGS = {
-    # name: (description, builder)
-}
-
-
 def config1():
     """3 baselines, 64 channels, 100 point sources, 1 snapshot, Gaussian D=14 m beam."""
     bl = NP.array([[14.6, 0.0, 0.0], [7.3, 12.644, 0.0], [29.2, 0.0, 0.0]])
