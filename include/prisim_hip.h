@@ -186,6 +186,14 @@ int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts,
  * direction cosines per snapshot ([nt][3]).  In place on the device cube. */
 int prisim_hip_phase_rotate(prisim_ctx* ctx, int64_t nt, const double* diff_dircos);
 
+/* ---- thermal noise (interferometry.py:6661-6693) ----------------------------------- */
+
+/* noise[t][b][f] = rms[t][b][f] / sqrt(2) * (n1 + i n2), n1, n2 ~ N(0,1) (interferometry.py:6692).  The normals come from
+ * a counter-based generator (Philox-4x32-10 keyed by `seed`, counter = (t, bl_offset + b, f)), so a baseline-sharded run
+ * draws exactly the numbers of the unsharded run.  rms: host [nt][nbl][nchan] float64 (vis_rms_freq, :6685-6689);
+ * out: host complex128 [nt][nbl][nchan]. */
+int prisim_hip_noise(prisim_ctx* ctx, int64_t nt, const double* rms, uint64_t seed, int64_t bl_offset, double* out);
+
 /* ---- multi-GPU: baseline shards + one RCCL all-gather ---------------------- */
 
 /* 128-byte RCCL unique id; rank 0 creates it, the launcher distributes it out of band. */

@@ -24,7 +24,7 @@ EXPORTS = (
     'prisim_hip_set_array', 'prisim_hip_set_sky', 'prisim_hip_compute', 'prisim_hip_get_vis',
     'prisim_hip_skyvis', 'prisim_hip_set_vis', 'prisim_hip_set_sky_analytic',
     'prisim_hip_set_external_beam', 'prisim_hip_set_sky_external', 'prisim_hip_get_pbflux',
-    'prisim_hip_delay_transform', 'prisim_hip_phase_rotate', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
+    'prisim_hip_delay_transform', 'prisim_hip_phase_rotate', 'prisim_hip_noise', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
     'prisim_hip_allgather', 'prisim_hip_allgather_slot_async', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
 )
@@ -128,6 +128,7 @@ def load_library():
     lib.prisim_hip_get_pbflux.argtypes = [vp, vp]
     lib.prisim_hip_delay_transform.argtypes = [vp, i64, vp, dbl, vp, vp, vp, dbl]
     lib.prisim_hip_phase_rotate.argtypes = [vp, i64, vp]
+    lib.prisim_hip_noise.argtypes = [vp, i64, vp, C.c_uint64, i64, vp]
     lib.prisim_hip_comm_unique_id.argtypes = [C.c_char_p]
     lib.prisim_hip_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     lib.prisim_hip_allgather.argtypes = [vp, i64, i32]
@@ -359,6 +360,17 @@ class Context(object):
         if d.shape[0] != nt:
             raise ValueError('diff_dircos must have one row per snapshot')
         self._check(self._lib.prisim_hip_phase_rotate(self._h, int(nt), _ptr(d)), 'prisim_hip_phase_rotate')
+
+    def noise(self, rms, seed, bl_offset=0):
+        """Complex Gaussian noise (nt, nbl, nchan) with per-element rms (interferometry.py:6692), Philox counter-based draws
+        on the device: identical for sharded and unsharded runs when bl_offset is the shard's first global baseline."""
+        r = NP.ascontiguousarray(rms, dtype=NP.float64)
+        if r.ndim != 3 or r.shape[1:] != (self.nbl, self.nchan):
+            raise ValueError('rms must have shape (nt, nbl, nchan)')
+        out = NP.empty(r.shape, dtype=NP.complex128)
+        self._check(self._lib.prisim_hip_noise(self._h, r.shape[0], _ptr(r), int(seed) & 0xFFFFFFFFFFFFFFFF, int(bl_offset), _ptr(out)),
+                    'prisim_hip_noise')
+        return out
 
     # ---- multi-GPU ----
     @staticmethod

@@ -406,6 +406,50 @@ hipError_t launch_phase_rotate(double* cube, const double* blx, const double* bl
   return hipGetLastError();
 }
 
+// ---- thermal noise: Philox-4x32-10 counter-based normals (Salmon et al. 2011) ---------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// one snapshot: out[b][f] = rms[b][f]/sqrt(2) * (n1 + i n2); counter = (f, global baseline, snapshot, 0)
+__global__ void k_noise(const double* __restrict__ rms, double2* __restrict__ out, int64_t nbl, int64_t nchan, int64_t t,
+                        int64_t bl_offset, uint64_t seed) {
+  const int64_t total = nbl * nchan;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / nchan, f = i - b * nchan;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)f, (uint32_t)(bl_offset + b), (uint32_t)t, (uint32_t)((uint64_t)(bl_offset + b) >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    // two 52-bit uniforms in (0,1], Box-Muller
+    const double u1 = ((double)(((uint64_t)r[0] << 20) | (r[1] >> 12)) + 1.0) * (1.0 / 4503599627370496.0);
+    const double u2 = ((double)(((uint64_t)r[2] << 20) | (r[3] >> 12))) * (1.0 / 4503599627370496.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    const double sc = rms[i] * 0.70710678118654752440;                      // :6692 sqrt(2) split
+    out[i] = make_double2(sc * rad * cs, sc * rad * sn);
+  }
+}
+
+hipError_t launch_noise(const double* rms, double* out, int64_t nbl, int64_t nchan, int64_t t, int64_t bl_offset, uint64_t seed,
+                        hipStream_t stream) {
+  hipLaunchKernelGGL(k_noise, dim3(grid_for(nbl * nchan)), dim3(256), 0, stream, rms, reinterpret_cast<double2*>(out), nbl, nchan, t,
+                     bl_offset, seed);
+  return hipGetLastError();
+}
+
 // ---- deterministic checksum: fixed 1024-block partial sums, then one block ------------------
 template <typename T>
 __global__ __launch_bounds__(256)

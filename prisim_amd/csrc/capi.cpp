@@ -947,6 +947,32 @@ int prisim_hip_phase_rotate(prisim_ctx* ctx, int64_t nt, const double* diff_dirc
   return PRISIM_OK;
 }
 
+int prisim_hip_noise(prisim_ctx* ctx, int64_t nt, const double* rms, uint64_t seed, int64_t bl_offset, double* out) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (nt <= 0 || !rms || !out || bl_offset < 0) return fail(ctx, PRISIM_EINVAL, "bad noise arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->nbl * ctx->nchan;
+  for (size_t i = 0; i < n * (size_t)nt; ++i)
+    if (!(rms[i] >= 0.0) || !std::isfinite(rms[i])) return fail(ctx, PRISIM_EINVAL, "noise rms must be finite and non-negative");
+  DevBuf drms, dout;
+  int rc;
+  if ((rc = ensure(ctx, drms, n * sizeof(double))) || (rc = ensure(ctx, dout, n * 2 * sizeof(double)))) {
+    release(drms); release(dout);
+    return rc;
+  }
+  hipError_t e = hipSuccess;
+  for (int64_t t = 0; t < nt && e == hipSuccess; ++t) {
+    e = hipMemcpyAsync(drms.p, rms + (size_t)t * n, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = launch_noise((const double*)drms.p, (double*)dout.p, ctx->nbl, ctx->nchan, t, bl_offset, seed, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out + (size_t)t * n * 2, dout.p, n * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  release(drms); release(dout);
+  HIPCHK(ctx, e);
+  return PRISIM_OK;
+}
+
 // ---- multi-GPU ------------------------------------------------------------------------------
 
 int prisim_hip_comm_unique_id(char id[128]) {

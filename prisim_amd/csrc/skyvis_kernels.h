@@ -89,6 +89,8 @@ hipError_t launch_dt_finish(const double* work, double* out, double* out_power, 
                             int64_t nout, double factor, double scale, double power_scale, hipStream_t stream);
 hipError_t launch_phase_rotate(double* cube, const double* blx, const double* bly, const double* blz, const double* freqs,
                                const double* diff /*[nt][3] device*/, int64_t nt, int64_t nbl, int64_t nchan, hipStream_t stream);
+hipError_t launch_noise(const double* rms, double* out, int64_t nbl, int64_t nchan, int64_t t, int64_t bl_offset, uint64_t seed,
+                        hipStream_t stream);
 hipError_t launch_checksum(const void* data, bool is_f32, int64_t n, double* out, hipStream_t stream);
 hipError_t launch_f64_to_f32(const double* in, float* out, int64_t n, hipStream_t stream);
 

@@ -575,6 +575,40 @@ class InterferometerArray(object):
         self.n_acc = n_acc
 
     # ------------------------------------------------------------------------------------------
+    def generate_noise(self, seed=None, bl_offset=0):
+        """Thermal noise for every (baseline, channel, snapshot) from the system parameters (interferometry.py:6661-6693):
+        vis_rms_freq = 2 k / sqrt(t_acc df) * Tsys / (A_eff eff_Q) / Jy (flux_unit 'JY') or Tsys / eff_Q / sqrt(t_acc df) ('K');
+        vis_noise_freq = vis_rms_freq / sqrt(2) * (randn + 1j randn).  The normals are drawn on the GPU (counter-based Philox),
+        reproducibly for a given `seed` (None: a fresh random seed, like the reference's global numpy RNG)."""
+        if not self.timestamp:
+            raise ValueError('no snapshots: call observe() first')
+        eff_Q = self.eff_Q if self.eff_Q.ndim == 3 else self.eff_Q[:, :, NP.newaxis]
+        A_eff = self.A_eff if self.A_eff.ndim == 3 else self.A_eff[:, :, NP.newaxis]
+        t_acc = NP.asarray(self.t_acc, dtype=NP.float64)[NP.newaxis, NP.newaxis, :]
+        Tsys = self.Tsys if self.Tsys.ndim == 3 else self.Tsys[:, :, NP.newaxis]
+        if self.flux_unit in ('JY', 'jy', 'Jy'):
+            self.vis_rms_freq = 2.0 * 1.380649e-23 / NP.sqrt(t_acc * self.freq_resolution) * (Tsys / A_eff / eff_Q) / 1.0e-26   # :6685
+        elif self.flux_unit in ('K', 'k'):
+            self.vis_rms_freq = 1.0 / NP.sqrt(t_acc * self.freq_resolution) * Tsys / eff_Q                                  # :6687
+        else:
+            raise ValueError('Flux density units can only be in Jy or K.')
+        if seed is None:
+            seed = int(NP.random.SeedSequence().generate_state(2, dtype=NP.uint32).astype(NP.uint64) @ NP.array([1, 1 << 32], dtype=NP.uint64))
+        rms_tbf = NP.ascontiguousarray(NP.transpose(NP.broadcast_to(self.vis_rms_freq, (self.baselines.shape[0], self.channels.size,
+                                                                                          len(self.timestamp))), (2, 0, 1)))
+        noise = self._ctx.noise(rms_tbf, seed, bl_offset=bl_offset)                     # (nt, nbl, nchan)
+        self.vis_noise_freq = NP.transpose(noise, (1, 2, 0))                             # :6692
+        self.noise_seed = seed
+
+    def add_noise(self):
+        """vis_freq = gains * skyvis_freq + vis_noise_freq with unity gains (interferometry.py:6697-6722; gain tables are out of scope)."""
+        if self.vis_noise_freq is None:
+            raise ValueError('generate_noise() must be called first')
+        if self.gaininfo is None:
+            warnings.warn('Gain table absent. Proceeding with default unity gains')
+        self.vis_freq = self.skyvis_freq + self.vis_noise_freq
+
+    # ------------------------------------------------------------------------------------------
     def _pc_dircos(self, pc, coords):
         """Phase centres (n_acc, 2|3) in `coords` -> ENU direction cosines, per snapshot (uses self.lst)."""
         pc = NP.asarray(pc, dtype=NP.float64)

@@ -406,3 +406,49 @@ def test_observe_radec_sky_and_roi_selection():
     assert NP.array_equal(ia2.obs_catalog_indices[0], up)
     ref2 = O.skyvis(bl, ch, dc[up], skymod.generate_spectrum(ind=up, frequency=ch), pc_dc)
     assert NP.max(NP.abs(ia2.skyvis_freq[:, :, 0] - ref2)) <= 1e-10
+
+
+def test_device_noise_statistics_determinism_and_sharding(ctx):
+    rng = NP.random.default_rng(5)
+    nbl, nchan, nt = 96, 128, 4
+    ch = 150e6 + NP.arange(nchan) * 1e5
+    bl = rng.uniform(-100, 100, (nbl, 3))
+    ctx.set_array(bl, ch, nt_max=1)
+    rms = rng.uniform(0.5, 2.0, (nt, nbl, nchan))
+    a = ctx.noise(rms, seed=1234)
+    assert a.shape == (nt, nbl, nchan) and NP.array_equal(a, ctx.noise(rms, seed=1234))        # deterministic for a seed
+    assert not NP.array_equal(a, ctx.noise(rms, seed=1235))
+    z = a / rms                                                   # unit-variance complex normals: var(re) = var(im) = 1/2
+    n = z.size
+    assert abs(z.real.mean()) < 4 / NP.sqrt(2 * n) and abs(z.imag.mean()) < 4 / NP.sqrt(2 * n)
+    assert abs(z.real.var() - 0.5) < 0.02 and abs(z.imag.var() - 0.5) < 0.02
+    assert abs(NP.mean(z.real * z.imag)) < 4 / NP.sqrt(n) / 2                                   # re, im uncorrelated
+    assert abs(NP.mean(z[:, :, 1:].real * z[:, :, :-1].real)) < 0.01                            # adjacent channels uncorrelated
+    assert abs(NP.mean(NP.abs(z) ** 4) - 2.0) < 0.1                                             # Gaussian kurtosis: E|z|^4 = 2 for CN(0,1)
+    # a baseline-sharded run draws exactly the numbers of the unsharded run
+    ctx.set_array(bl[40:], ch, nt_max=1)
+    assert NP.array_equal(ctx.noise(rms[:, 40:], seed=1234, bl_offset=40), a[:, 40:])
+    with pytest.raises(ValueError):
+        ctx.noise(-rms[:, 40:], seed=1)
+
+
+def test_interferometer_array_generate_and_add_noise():
+    ch = 150e6 + NP.arange(32) * 1e5
+    bl = NP.array([[14.6, 0.0, 0.0], [0.0, 29.2, 0.0]])
+    skymod = SM.SkyModel(location=[[80.0, 100.0]], flux_ref=[1.0], spindex=[0.0], ref_freq=150e6)
+    ia = RI.InterferometerArray(['a', 'b'], bl, ch, telescope={'shape': 'delta'}, skycoords='altaz', pointing_coords='altaz', A_eff=154.0, eff_Q=0.96)
+    for j in range(3):
+        ia.observe((2457000.5 + j, 0.0), {'Tnet': 300.0}, NP.ones(32), [90.0, 270.0], skymod, 60.0)
+    ia.generate_noise(seed=99)
+    rms = 2.0 * 1.380649e-23 / NP.sqrt(60.0 * 1e5) * 300.0 / 154.0 / 0.96 / 1e-26               # interferometry.py:6685
+    assert ia.vis_rms_freq.shape[:2] == (2, 32) and NP.allclose(ia.vis_rms_freq, rms)
+    assert ia.vis_noise_freq.shape == (2, 32, 3)
+    assert abs(NP.std(ia.vis_noise_freq.real) / (rms / NP.sqrt(2)) - 1.0) < 0.2
+    with pytest.warns(UserWarning):
+        ia.add_noise()
+    assert NP.array_equal(ia.vis_freq, ia.skyvis_freq + ia.vis_noise_freq)
+    first = ia.vis_noise_freq.copy()
+    ia.generate_noise(seed=99)
+    assert NP.array_equal(first, ia.vis_noise_freq)
+    ia.delay_transform(pad=0.0, verbose=False)                     # all three cubes are transformed now (Q20)
+    assert ia.vis_lag.shape == ia.skyvis_lag.shape == ia.vis_noise_lag.shape == (2, 32, 3)
