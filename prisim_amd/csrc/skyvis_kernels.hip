@@ -63,26 +63,36 @@ __device__ __forceinline__ void sincos_qcycles(double a4, float& c, float& s) {
   s = ((qi & 2) != 0) ? -ss : ss;          // q mod 4 in {2,3}
 }
 
-// sin(2 pi y) for |y| <= 1/8 cycle (the polynomial of sincos_qcycles without the quadrant logic)
-__device__ __forceinline__ float sin_2pi_y(float y) {
-  const float y2 = y * y;
-  float ps = 42.058693944897655f;
-  ps = __builtin_fmaf(ps, y2, -76.70585975306136f);
-  ps = __builtin_fmaf(ps, y2, 81.60524927607504f);
-  ps = __builtin_fmaf(ps, y2, -41.341702240399755f);
-  const float sy = __builtin_fmaf(y * y2, ps, y * 6.2831855f);
-  return __builtin_fmaf(y, -1.7484555e-7f, sy);
+// (cos, sin) of 2 pi a for a phase in CYCLES of any magnitude: fp64 reduction to [-1/2, 1/2] cycle, then the hardware
+// v_cos_f32 / v_sin_f32 (input in revolutions; measured max abs error 1.25e-7 on [-1/2, 1/2], tools/microbench_trig.hip).
+// Two quarter-rate instructions instead of ~25 for the polynomial + quadrant logic.  Only for phasors that are used once
+// (the seed at the tile centre); the step phasor, whose error is multiplied by the chain length, keeps the polynomial.
+__device__ __forceinline__ void sincos_cycles_hw(double a, float& c, float& s) {
+  const float y = (float)(a - __builtin_rint(a));
+  c = __builtin_amdgcn_cosf(y);
+  s = __builtin_amdgcn_sinf(y);
 }
 
-// tan(pi y) for |y| <= 1/8 cycle, ~1 ulp: y*pi (hi + lo) + y^3 * P(y^2), P = least-squares fit of (tan(pi y)/y - pi)/y^2
+// sin(2 pi y) for |y| <= 1/8 cycle: y * (2pi_hi + (2pi_lo + y^2 P(y^2))), P = degree-2 minimax fit (1.8e-9 abs), so the
+// result is within ~1 ulp in 6 instructions.  This is the lifting step's s = sin(alpha): its error is multiplied by the chain length.
+__device__ __forceinline__ float sin_2pi_y(float y) {
+  const float y2 = y * y;
+  float ps = -75.36964416503906f;
+  ps = __builtin_fmaf(ps, y2, 81.59197998046875f);
+  ps = __builtin_fmaf(ps, y2, -41.3416633605957f);
+  const float q = __builtin_fmaf(ps, y2, -1.7484555e-7f);               // + (2pi - fl32(2pi))
+  return __builtin_fmaf(y, q, y * 6.2831855f);
+}
+
+// tan(pi y) for |y| <= 1/8 cycle, ~1 ulp: y * (pi_hi + (pi_lo + y^2 P(y^2))), P = degree-3 fit of (tan(pi y)/y - pi)/y^2
 __device__ __forceinline__ float tan_pi_y(float y) {
   const float u = y * y;
-  float pt = 764.9256591796875f;
-  pt = __builtin_fmaf(pt, u, 161.4058837890625f);
-  pt = __builtin_fmaf(pt, u, 40.8116340637207f);
-  pt = __builtin_fmaf(pt, u, 10.335408210754395f);
-  const float t = __builtin_fmaf(y * u, pt, y * 3.1415927410125732f);   // fl32(pi)
-  return __builtin_fmaf(y, -8.742278e-8f, t);                           // + y * (pi - fl32(pi))
+  float pt = 769.7825317382812f;
+  pt = __builtin_fmaf(pt, u, 161.2586212158203f);
+  pt = __builtin_fmaf(pt, u, 40.81293869018555f);
+  pt = __builtin_fmaf(pt, u, 10.335405349731445f);
+  const float q = __builtin_fmaf(pt, u, -8.742278e-8f);                 // + (pi - fl32(pi))
+  return __builtin_fmaf(y, q, y * 3.1415927410125732f);
 }
 
 __device__ __forceinline__ void sincos_qcycles(double a4, double& c, double& s) {
@@ -134,13 +144,10 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p) {
   static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
   static_assert(!(TAPER && LIFT), "no lifting form with the taper");
   constexpr int HC = CT / 2;                       // channels per chain
-  constexpr int VE = 16 / (int)sizeof(T);           // elements per 16-byte piece
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int S = p.src_chunk;
-  // layout: [S][CT] T  |  [S] double4 = (s - s_pc)/c, kappa   (prepared by k_prep_dirs)
-  T* const lds_p = reinterpret_cast<T*>(smem_raw);
-  double4* const lds_d = reinterpret_cast<double4*>(smem_raw + (size_t)S * CT * sizeof(T));
+  constexpr int NH = CT / 2;                       // elements per half row
+  typedef const __attribute__((address_space(4))) T* crow_p;
+  typedef const __attribute__((address_space(4))) double* cdir_p;
+  typedef const __attribute__((address_space(4))) float* cfsq_p;
 
   // ---- XCD-aware block -> (slab, baseline group) map ------------------------------------
   // Blocks are dealt round-robin to the 8 XCDs (blockIdx % 8 shares an XCD), so slab ids that
@@ -181,26 +188,10 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p) {
 #pragma unroll
   for (int k = 0; k < CT; ++k) { acc_re[k] = (T)0; acc_im[k] = (T)0; }
 
-  const T* const gp = reinterpret_cast<const T*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT;
-  const double4* const gd = reinterpret_cast<const double4*>(p.dirs_prep);
-
-  const int npieces = S * CT / VE;                 // 16-byte pieces of pbflux per chunk
-  constexpr int kMaxPiecesPerThread = 4;           // S*CT*sizeof(T) <= 16 KiB  (host enforces)
-
-  // global -> VGPR -> LDS staging of one chunk of sources.  The packed pbflux and the direction
-  // table are zero-padded by the host layer to a multiple of S sources past nsrc, and split
-  // ranges are multiples of S, so no bounds checks are needed here.
-  auto stage_chunk = [&](int64_t s0) {
-    T* lp = lds_p;
-    const uint4* src = reinterpret_cast<const uint4*>(gp + (size_t)s0 * CT);
-#pragma unroll
-    for (int u = 0; u < kMaxPiecesPerThread; ++u) {
-      const int i = tid + u * kBlockThreads;
-      if (i < npieces) reinterpret_cast<uint4*>(lp)[i] = src[i];
-    }
-    if (tid < S) lds_d[tid] = gd[s0 + tid];
-    if (tid == (S < kBlockThreads ? S : 0)) lds_d[S] = make_double4(0, 0, 0, 0);   // read one past the chunk by the pipeline
-  };
+  // pbflux rows and directions are wave-uniform: scalar loads into SGPRs (see k_skyvis_rec_f32pk for the pipeline)
+  const crow_p gp = (crow_p)(uintptr_t)(reinterpret_cast<const T*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT);
+  const cdir_p gd = (cdir_p)(uintptr_t)p.dirs_prep;
+  const cfsq_p gfq = (cfsq_p)(uintptr_t)(p.fsq_pairs ? p.fsq_pairs + (size_t)tile * CT : nullptr);   // fp32 taper only
 
   double* const out = p.out + ((size_t)split * p.nbl * p.nchan) * 2;   // partial buffer of this split
   bool first_flush = true;
@@ -224,92 +215,75 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p) {
     since_flush = 0;
   };
 
-  const int64_t nsrc_local = s_end - s_begin;
-  const int nchunks = (int)((nsrc_local + S - 1) / S);
-
-  for (int ci = 0; ci < nchunks; ++ci) {
-    const int64_t s0 = s_begin + (int64_t)ci * S;
-    const bool more = (ci + 1) < nchunks;
-    __syncthreads();                 // everyone is done reading the previous chunk
-    stage_chunk(s0);
-    __syncthreads();
-
-    int ns = (int)((s_end - s0) < S ? (s_end - s0) : S);
-    if (wave_active) {
-      // Software pipeline over sources (LDS broadcast reads are requested one phase before use):
-      //   seed arithmetic of source s   covers the first half row of (up,down) pbflux pairs of s
-      //   first half of the pairs       covers the second half row of s and the direction of s+1
-      constexpr int NH = CT / 2;                     // elements per half row
-      constexpr int VE16 = 16 / (int)sizeof(T);
-      using V16 = typename Vec16<T>::type;
-      double4 sv = lds_d[0];
-      for (int s = 0; s < ns; ++s) {
-        const T* prow = lds_p + (size_t)s * CT;      // [2j] = channel HC+j (up), [2j+1] = channel HC-1-j (down)
-        T pa[NH], pb[NH];
+  if (wave_active && s_end > s_begin) {
+    T ra[NH], rb[NH];                                  // [2j] = channel HC+j (up), [2j+1] = channel HC-1-j (down)
+    double sv[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+      const crow_p r0 = gp + (size_t)s_begin * CT;
 #pragma unroll
-        for (int i = 0; i < NH / VE16; ++i) {
-          const V16 v = reinterpret_cast<const V16*>(prow)[i];
-          unpack16(v, &pa[i * VE16]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));   // seconds
-        T zc, zs, rc, rs;
-        sincos_qcycles(d * fc4, zc, zs);                           // phase at the centre channel
-        const double th4 = d * df4;
-        sincos_qcycles(th4, rc, rs);                               // phase step per channel
-        // exp(-2 pi i phi): z = (cos, -sin)
-        T ur = zc, ui = -zs;            // up chain: channel HC + j
-        const T rr = rc, ri = -rs;      // step forward; step backward is conj(r)
-        T dr = fma_(ur, rr, ui * ri);        // z * conj(r): channel HC-1
-        T di = fma_(ui, rr, -(ur * ri));
-        T tl = (T)0;                         // tan(alpha/2), alpha = -2 pi theta the step angle (LIFT groups only)
-        if constexpr (LIFT) {
-          if constexpr (sizeof(T) == 4) tl = -tan_pi_y((float)(0.25 * th4));      // |theta| <= 1/8 cycle guaranteed
-          else tl = ri / ((T)1 + rr);                                             // |theta| <= 1/4 cycle guaranteed: 1 + cos >= 1
-        }
-        // source-shape taper  w = exp(-g f^2),  g = kappa_s * (|b|^2/c^2 - tau^2),  tau = d + b.s_pc/c
-        double gq = 0.0;
-        float g2 = 0.f;
-        double wu = 1.0, wd = 1.0, qu = 1.0, qd = 1.0, h = 1.0;
-        if constexpr (TAPER) {
-          const double tau = d + bpc;
-          gq = sv.w * (bl2_c2 - tau * tau);
-          gq = gq > 0.0 ? gq : 0.0;      // |b|^2 >= (b.s)^2 up to rounding
-          if constexpr (sizeof(T) == 4) {
-            g2 = -(float)(gq * p.fsq_scale);   // fp32: direct exp2 per term (no error accumulation)
-          } else {
-            // fp64: second-order multiplicative recurrence of the Gaussian in frequency:
-            //   w_{k+1} = w_k q_k,  q_{k+1} = q_k h,   h = exp(-2 g df^2);   w_{k-1} = w_k q'_k, q'_{k-1} = q'_k h
-            const double e1 = exp(-2.0 * gq * fc * df);
-            const double e2 = exp(-gq * df * df);
-            h = e2 * e2;
-            wu = exp(-gq * fc * fc);                  // channel HC
-            qu = e1 * e2;                             // w_{HC+1}/w_{HC}
-            qd = e2 / e1;                             // w_{HC-1}/w_{HC}
-            wd = wu * qd;                             // channel HC-1
-            qd *= h;                                  // w_{HC-2}/w_{HC-1}
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < NH; ++i) ra[i] = r0[i];
+      const cdir_p d0 = gd + (size_t)s_begin * 4;
+      sv[0] = d0[0]; sv[1] = d0[1]; sv[2] = d0[2];
+      if (TAPER) sv[3] = d0[3];
+    }
+    for (int64_t s = s_begin; s < s_end; ++s) {
+      const crow_p row = gp + (size_t)s * CT;
+      const int64_t sn = (s + 1 < s_end) ? s + 1 : s;               // the last source is simply fetched again
+      // the first use of sv waits for everything in flight (first half row + direction); only then ask for the second half
+      const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));   // seconds
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < NH / VE16; ++i) {
-          const V16 v = reinterpret_cast<const V16*>(prow + NH)[i];
-          unpack16(v, &pb[i * VE16]);
-        }
-        sv = lds_d[s + 1];                           // lds_d has S+1 entries
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < NH; ++i) rb[i] = row[NH + i];
+      __builtin_amdgcn_sched_barrier(0);
 
+      T zc, zs, rc, rs;
+      sincos_qcycles(d * fc4, zc, zs);                           // phase at the centre channel
+      const double th4 = d * df4;
+      sincos_qcycles(th4, rc, rs);                               // phase step per channel
+      // exp(-2 pi i phi): z = (cos, -sin)
+      T ur = zc, ui = -zs;            // up chain: channel HC + j
+      const T rr = rc, ri = -rs;      // step forward; step backward is conj(r)
+      T dr = fma_(ur, rr, ui * ri);        // z * conj(r): channel HC-1
+      T di = fma_(ui, rr, -(ur * ri));
+      T tl = (T)0;                         // tan(alpha/2), alpha = -2 pi theta the step angle (LIFT groups only)
+      if constexpr (LIFT) {
+        if constexpr (sizeof(T) == 4) tl = -tan_pi_y((float)(0.25 * th4));      // |theta| <= 1/8 cycle guaranteed
+        else tl = ri / ((T)1 + rr);                                             // |theta| <= 1/4 cycle guaranteed: 1 + cos >= 1
+      }
+      // source-shape taper  w = exp(-g f^2),  g = kappa_s * (|b|^2/c^2 - tau^2),  tau = d + b.s_pc/c
+      double gq = 0.0;
+      float g2 = 0.f;
+      double wu = 1.0, wd = 1.0, qu = 1.0, qd = 1.0, h = 1.0;
+      if constexpr (TAPER) {
+        const double tau = d + bpc;
+        gq = sv[3] * (bl2_c2 - tau * tau);
+        gq = gq > 0.0 ? gq : 0.0;      // |b|^2 >= (b.s)^2 up to rounding
+        if constexpr (sizeof(T) == 4) {
+          g2 = -(float)(gq * p.fsq_scale);   // fp32: direct exp2 per term (no error accumulation)
+        } else {
+          // fp64: second-order multiplicative recurrence of the Gaussian in frequency:
+          //   w_{k+1} = w_k q_k,  q_{k+1} = q_k h,   h = exp(-2 g df^2);   w_{k-1} = w_k q'_k, q'_{k-1} = q'_k h
+          const double e1 = exp(-2.0 * gq * fc * df);
+          const double e2 = exp(-gq * df * df);
+          h = e2 * e2;
+          wu = exp(-gq * fc * fc);                  // channel HC
+          qu = e1 * e2;                             // w_{HC+1}/w_{HC}
+          qd = e2 / e1;                             // w_{HC-1}/w_{HC}
+          wd = wu * qd;                             // channel HC-1
+          qd *= h;                                  // w_{HC-2}/w_{HC-1}
+        }
+      }
+
+      auto pairs = [&](const T (&r)[NH], int jbase) {
 #pragma unroll
-        for (int j = 0; j < HC; ++j) {
+        for (int jj = 0; jj < NH / 2; ++jj) {
+          const int j = jbase + jj;
           const int ku = HC + j, kd = HC - 1 - j;
-          T pu = (2 * j < NH) ? pa[(2 * j) % NH] : pb[(2 * j) % NH];
-          T pd = (2 * j < NH) ? pa[(2 * j + 1) % NH] : pb[(2 * j + 1) % NH];
+          T pu = r[2 * jj], pd = r[2 * jj + 1];
           if constexpr (TAPER) {
             if constexpr (sizeof(T) == 4) {
-              const float* fq = p.fsq_pairs + (size_t)tile * CT + 2 * j;
-              pu *= __builtin_amdgcn_exp2f(g2 * fq[0]);
-              pd *= __builtin_amdgcn_exp2f(g2 * fq[1]);
+              pu *= __builtin_amdgcn_exp2f(g2 * gfq[2 * j]);
+              pd *= __builtin_amdgcn_exp2f(g2 * gfq[2 * j + 1]);
             } else {
               pu *= wu; pd *= wd;
               wu *= qu; qu *= h; wd *= qd; qd *= h;
@@ -335,10 +309,24 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p) {
             ur = nur; ui = nui; dr = ndr; di = ndi;
           }
         }
+      };
+      pairs(ra, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the second half row has landed before the next requests go out
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const crow_p rn = gp + (size_t)sn * CT;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) ra[i] = rn[i];
+        const cdir_p dn = gd + (size_t)sn * 4;
+        sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
+        if (TAPER) sv[3] = dn[3];
       }
+      __builtin_amdgcn_sched_barrier(0);
+      pairs(rb, NH / 2);
+
+      if (sizeof(T) == 4 && ++since_flush >= p.flush_src && s + 1 < s_end) flush();
     }
-    since_flush += ns;
-    if (sizeof(T) == 4 && since_flush >= p.flush_src && more) flush();
   }
   flush();
 }
@@ -359,20 +347,21 @@ void k_skyvis_rec(const SkyvisParams p) {
 // ------------------------------------------------------------------------------------------
 // Packed-fp32 recurrence kernel (the headline fp32 path).
 //
-// Same mapping as k_skyvis_rec, but every inner-loop instruction is a packed v_pk_{mul,fma}_f32
-// on an (up-chain, down-chain) pair: lane register pair .x = channel HC+j, .y = channel HC-1-j.
-// A packed instruction occupies the SIMD for 4 cycles and does two lanes' worth of work, so the
-// fp32 peak is reached from one or two waves per SIMD (tools/microbench_valu.hip: v_pk_fma_f32
-// 97 TFLOP/s at 1 wave/SIMD, v_fma_f32 only 50) -- which is what lets a thread own CT = 64
-// channels (128 accumulator VGPRs) and halves the per-(source,baseline,tile) seed overhead.
-// pbflux rows are stored interleaved by k_pack (up_0, down_0, up_1, down_1, ...) so that one
-// ds_read_b128 broadcast delivers two ready-made operand pairs.
-// Per pair of terms: 2 pk_fma (accumulate) + 2 pk_mul + 2 pk_fma (rotate up by r, down by conj r).
-// ------------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-
+// Same mapping as k_skyvis_rec (lanes = baselines, CT channels per thread, tile seeded at its centre), but
+//   * every inner-loop instruction is a packed v_pk_fma_f32 on an (up-chain, down-chain) pair: register pair .x = channel
+//     HC+j, .y = channel HC-1-j.  A packed instruction occupies the SIMD for 4 cycles and does two lanes' worth of work
+//     (tools/microbench_valu.hip), which is what lets a thread own CT = 64 channels (128 accumulator VGPRs);
+//   * pbflux rows are stored interleaved by k_pack (up_0, down_0, up_1, down_1, ...).  pbflux[s, tile] and the source
+//     direction are wave-uniform, so they are fetched with SCALAR loads (s_load_dwordx16 through the scalar cache) straight
+//     into SGPRs and used as the SGPR-pair operand of v_pk_fma_f32 (full rate, tools/microbench_trig.hip: 12.8e12 terms/s
+//     for the bare lifting loop against 11.1-12.5e12 with LDS broadcast reads).  No LDS, no barriers, no VGPR staging of
+//     the rows: waves run free and the no-taper kernel fits 3 waves per SIMD (157 VGPRs).
+// Scalar loads return out of order, so the only wait is lgkmcnt(0); the half rows are requested one phase ahead:
+//   top of source s:  wait (first half row + direction of s are there)  ->  request second half row of s
+//                     seed arithmetic, pairs 0..HC/2-1
+//   middle:           wait (second half row)                             ->  request first half row + direction of s+1
+//                     pairs HC/2..HC-1
+//
 // LIFT: the step rotation uses the lifting (three-shear) form
 //     x1 = x - t y,  y1 = y + s x1,  x2 = x1 - t y1,   t = tan(alpha/2), s = sin(alpha)
 // = 3 dependent packed FMAs instead of 2 mul + 2 fma, i.e. 5 instead of 6 packed instructions per pair of terms
@@ -380,16 +369,19 @@ __device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __bui
 // area-preserving and advances the phase by beta with cos(beta) = 1 - t s, so the angle error per step is ~ alpha * eps:
 // it is only used where |alpha| <= pi/4 is GUARANTEED for every source (the host sets lift_flags[bg] when
 // max|b| * max_s|s - s_pc| * |df| / c <= 1/8 cycle for the baseline group), all other groups take the 4-instruction rotation.
+// ------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+typedef const __attribute__((address_space(4))) float* cfloat_p;
+typedef const __attribute__((address_space(4))) double* cdouble_p;
+
 template <int CT, bool TAPER, bool LIFT>
 __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p) {
-  static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
   static_assert(!(TAPER && LIFT), "the taper-folded recurrence is a scaled rotation: no lifting form");
   constexpr int HC = CT / 2;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int S = p.src_chunk;
-  float* const lds_p = reinterpret_cast<float*>(smem_raw);                                   // [S][CT] interleaved pairs
-  double4* const lds_d = reinterpret_cast<double4*>(smem_raw + (size_t)S * CT * sizeof(float));   // [S]
+  constexpr int NH = CT / 2;                         // floats per half row
 
   const int xcd = blockIdx.x & 7;
   const int jblk = blockIdx.x >> 3;
@@ -412,9 +404,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p) {
   const double bx = p.bl_x[b], by = p.bl_y[b], bz = p.bl_z[b];
   const int k0 = tile * CT;
   const double fc_hz = p.f0 + (double)(k0 + HC) * p.df;
-  const double fc4 = 4.0 * fc_hz;
   const double df4 = 4.0 * p.df;
-
   double bl2_c2 = 0.0, bpc = 0.0;
   if (TAPER) {
     bl2_c2 = (bx * bx + by * by + bz * bz) * (p.inv_c * p.inv_c);
@@ -425,139 +415,100 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p) {
 #pragma unroll
   for (int j = 0; j < HC; ++j) { acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f); }
 
-  const float* const gp = reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT;
-  const double4* const gd = reinterpret_cast<const double4*>(p.dirs_prep);
-  const int npieces = S * CT / 4;
-  constexpr int kMaxPiecesPerThread = 4;
-
+  const cfloat_p gp = (cfloat_p)(uintptr_t)(reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT);
+  const cdouble_p gd = (cdouble_p)(uintptr_t)p.dirs_prep;
   double2* const orow = reinterpret_cast<double2*>(p.out) + ((size_t)split * p.nbl + (size_t)b) * p.nchan + k0;
   bool first_flush = true;
   int since_flush = 0;
 
-  const int64_t nsrc_local = s_end - s_begin;
-  const int nchunks = (int)((nsrc_local + S - 1) / S);
-
-  for (int ci = 0; ci < nchunks; ++ci) {
-    const int64_t s0 = s_begin + (int64_t)ci * S;
-    const bool more = (ci + 1) < nchunks;
-    __syncthreads();
+  if (wave_active && s_end > s_begin) {
+    float ra[NH], rb[NH];
+    double sv[4] = {0.0, 0.0, 0.0, 0.0};
     {
-      const uint4* src = reinterpret_cast<const uint4*>(gp + (size_t)s0 * CT);
+      const cfloat_p r0 = gp + (size_t)s_begin * CT;
 #pragma unroll
-      for (int u = 0; u < kMaxPiecesPerThread; ++u) {
-        const int i = tid + u * kBlockThreads;
-        if (i < npieces) reinterpret_cast<uint4*>(lds_p)[i] = src[i];
-      }
-      if (tid < S) lds_d[tid] = gd[s0 + tid];
-      if (tid == (S < kBlockThreads ? S : 0)) lds_d[S] = make_double4(0, 0, 0, 0);   // read one past the chunk by the pipeline
+      for (int i = 0; i < NH; ++i) ra[i] = r0[i];
+      const cdouble_p d0 = gd + (size_t)s_begin * 4;
+      sv[0] = d0[0]; sv[1] = d0[1]; sv[2] = d0[2];
+      if (TAPER) sv[3] = d0[3];
     }
-    __syncthreads();
-
-    const int ns = (int)((s_end - s0) < S ? (s_end - s0) : S);
-    if (wave_active) {
-      // Software pipeline over sources.  LDS broadcast reads have ~100+ cycles of latency and only two
-      // waves share a SIMD, so every operand is requested one phase before it is used:
-      //   phase A (seed arithmetic of source s)   covers the first half row of pbflux pairs of s
-      //   phase B (first 16 pairs)                covers the second half row of s and the direction of s+1
-      double4 sv = lds_d[0];
-      for (int s = 0; s < ns; ++s) {
-        constexpr int NQ = CT / 8;                       // float4 per half row
-        const float4* prow4 = reinterpret_cast<const float4*>(lds_p + (size_t)s * CT);
-        float4 pa[NQ], pb[NQ];
+    for (int64_t s = s_begin; s < s_end; ++s) {
+      const cfloat_p row = gp + (size_t)s * CT;
+      const int64_t sn = (s + 1 < s_end) ? s + 1 : s;               // the last source is simply fetched again
+      // the first use of sv waits for everything in flight (first half row + direction); only then ask for the second half
+      const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) pa[i] = prow4[i];
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < NH; ++i) rb[i] = row[NH + i];
+      __builtin_amdgcn_sched_barrier(0);
+      float zc, zs;
+      sincos_cycles_hw(d * fc_hz, zc, zs);
+      const float ur0 = zc, ui0 = -zs;
+      float rr = 1.f, ri, tpy = 0.f, dr0, di0;
+      if (LIFT) {
+        const float yth = (float)(d * p.df);
+        ri = -sin_2pi_y(yth);
+        tpy = tan_pi_y(yth);
+        const float x1 = __builtin_fmaf(-tpy, ui0, ur0);
+        di0 = __builtin_fmaf(-ri, x1, ui0);
+        dr0 = __builtin_fmaf(-tpy, di0, x1);
+      } else {
+        float rc, rs;
+        sincos_qcycles(d * df4, rc, rs);
+        rr = rc; ri = -rs;
+        dr0 = __builtin_fmaf(ur0, rr, ui0 * ri);
+        di0 = __builtin_fmaf(ui0, rr, -(ur0 * ri));
+      }
+      const f32x2 NT = {tpy, -tpy};                    // (-t_up, -t_down)
+      const f32x2 SS = {ri, -ri};                      // (sin alpha_up, sin alpha_down)
+      f32x2 zre = {ur0, dr0};
+      f32x2 zim = {ui0, di0};
+      const f32x2 RR = {rr, rr};
+      const f32x2 RI = {-ri, ri};                      // re' = re*rr + im*RI ;  im' = im*rr - re*RI
+      // Source-shape taper folded into the recurrence.  log2 w at channel HC+j is L(j) = A + B j + C j^2 with
+      //   A = -G fc^2, B = -2 G fc df, C = -G df^2, G = kappa_s (|b|^2/c^2 - tau^2) log2(e)     (interferometry.py:6265-6283)
+      // so zeta_j = w_j z_j advances by the complex factor rho_j = r * exp2(L(j+1)-L(j)) (up) / conj(r) * exp2(L(-2-j)-L(-1-j))
+      // (down), and rho_{j+1} = rho_j * exp2(2C): 2 more packed instructions per pair of terms instead of two v_exp_f32.
+      // rho is re-formed exactly every RESEED steps so that its rounding error cannot random-walk into zeta's phase.
+      f32x2 rho_re = RR, rho_im = {ri, -ri}, HM = {0.f, 0.f};
+      float tB = 0.f, tC = 0.f;
+      if (TAPER) {
+        const double tau = d + bpc;
+        double gq = sv[3] * (bl2_c2 - tau * tau);
+        gq = gq > 0.0 ? gq : 0.0;                       // |b|^2 >= (b.s)^2 up to rounding
+        const double G = gq * 1.4426950408889634;
+        const float tA = (float)(-G * fc_hz * fc_hz);
+        tB = (float)(-2.0 * G * fc_hz * p.df);
+        tC = (float)(-G * p.df * p.df);
+        const float w_u0 = __builtin_amdgcn_exp2f(tA);                 // channel HC
+        const float w_d0 = __builtin_amdgcn_exp2f(tA - tB + tC);       // channel HC-1
+        zre = zre * (f32x2){w_u0, w_d0};
+        zim = zim * (f32x2){w_u0, w_d0};
+        const float th = 2.0f * tC * 0.6931471805599453f;              // exp2(2C) - 1 = th + th^2/2 + ...
+        const float hm = __builtin_fmaf(0.5f * th, th, th);
+        HM = (f32x2){hm, hm};
+      }
+      constexpr int RESEED = 8;
 
-        const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));
-        float zc, zs;
-        sincos_qcycles(d * fc4, zc, zs);
-        const float ur0 = zc, ui0 = -zs;                 // z = exp(-2 pi i phi) at channel HC
-        const double th4 = d * df4;
-        float rr = 1.f, ri, tpy = 0.f, dr0, di0;
-        if (LIFT) {
-          // |theta| <= 1/8 cycle is guaranteed for this baseline group: no quadrant reduction, no cosine.  alpha = -2 pi theta:
-          // s = sin(alpha) = ri, t = tan(alpha/2) = -tan(pi theta)
-          const float yth = (float)(0.25 * th4);
-          ri = -sin_2pi_y(yth);
-          tpy = tan_pi_y(yth);
-          // down chain starts one channel below: rotate z by -alpha with the same three shears (t -> -t, s -> -s)
-          const float x1 = __builtin_fmaf(-tpy, ui0, ur0);
-          di0 = __builtin_fmaf(-ri, x1, ui0);
-          dr0 = __builtin_fmaf(-tpy, di0, x1);
-        } else {
-          float rc, rs;
-          sincos_qcycles(th4, rc, rs);
-          rr = rc; ri = -rs;                             // r = exp(-2 pi i theta)
-          dr0 = __builtin_fmaf(ur0, rr, ui0 * ri);       // down chain starts at z * conj(r)
-          di0 = __builtin_fmaf(ui0, rr, -(ur0 * ri));
-        }
-        const f32x2 NT = {tpy, -tpy};                    // (-t_up, -t_down)
-        const f32x2 SS = {ri, -ri};                      // (sin alpha_up, sin alpha_down)
-        f32x2 zre = {ur0, dr0};
-        f32x2 zim = {ui0, di0};
-        const f32x2 RR = {rr, rr};
-        const f32x2 RI = {-ri, ri};        // re' = re*rr + im*RI ;  im' = im*rr - re*RI
-        // Source-shape taper folded into the recurrence.  log2 w at channel HC+j is L(j) = A + B j + C j^2 with
-        //   A = -G fc^2, B = -2 G fc df, C = -G df^2, G = kappa_s (|b|^2/c^2 - tau^2) log2(e)     (interferometry.py:6265-6283)
-        // so zeta_j = w_j z_j advances by the complex factor rho_j = r * exp2(L(j+1)-L(j)) (up) / conj(r) * exp2(L(-2-j)-L(-1-j))
-        // (down), and rho_{j+1} = rho_j * exp2(2C): 2 more packed instructions per pair of terms instead of two v_exp_f32.
-        // rho is re-formed exactly every RESEED steps so that its rounding error cannot random-walk into zeta's phase.
-        f32x2 rho_re = RR, rho_im = {ri, -ri}, HM = {0.f, 0.f};
-        float tB = 0.f, tC = 0.f;
-        if (TAPER) {
-          const double tau = d + bpc;
-          double gq = sv.w * (bl2_c2 - tau * tau);
-          gq = gq > 0.0 ? gq : 0.0;                       // |b|^2 >= (b.s)^2 up to rounding
-          const double G = gq * 1.4426950408889634;
-          const float tA = (float)(-G * fc_hz * fc_hz);
-          tB = (float)(-2.0 * G * fc_hz * p.df);
-          tC = (float)(-G * p.df * p.df);
-          const float w_u0 = __builtin_amdgcn_exp2f(tA);                 // channel HC
-          const float w_d0 = __builtin_amdgcn_exp2f(tA - tB + tC);       // channel HC-1
-          zre = zre * (f32x2){w_u0, w_d0};
-          zim = zim * (f32x2){w_u0, w_d0};
-          const float th = 2.0f * tC * 0.6931471805599453f;              // exp2(2C) - 1 = th + th^2/2 + ...
-          const float hm = __builtin_fmaf(0.5f * th, th, th);
-          HM = (f32x2){hm, hm};
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      auto pairs = [&](const float (&r)[NH], int jbase) {
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) pb[i] = prow4[NQ + i];
-        sv = lds_d[s + 1];                               // lds_d has S+1 entries
-        __builtin_amdgcn_sched_barrier(0);
-
-        constexpr int RESEED = 8;
-#pragma unroll
-        for (int j = 0; j < HC; j += 2) {
-          const float4 pv = (j < HC / 2) ? pa[j / 2] : pb[j / 2 - NQ];   // (up_j, down_j, up_j+1, down_j+1)
-          const f32x2 p0 = {pv.x, pv.y};
-          const f32x2 p1 = {pv.z, pv.w};
+        for (int jj = 0; jj < NH / 2; ++jj) {
+          const int j = jbase + jj;
+          const f32x2 pp = {r[2 * jj], r[2 * jj + 1]};
+          acc_re[j] = pkfma(pp, zre, acc_re[j]);
+          acc_im[j] = pkfma(pp, zim, acc_im[j]);
           if (LIFT) {
-            acc_re[j] = pkfma(p0, zre, acc_re[j]);
-            acc_im[j] = pkfma(p0, zim, acc_im[j]);
-            f32x2 x1 = pkfma(NT, zim, zre);
-            f32x2 y1 = pkfma(SS, x1, zim);
-            zre = pkfma(NT, y1, x1);
-            zim = y1;
-            acc_re[j + 1] = pkfma(p1, zre, acc_re[j + 1]);
-            acc_im[j + 1] = pkfma(p1, zim, acc_im[j + 1]);
-            x1 = pkfma(NT, zim, zre);
-            y1 = pkfma(SS, x1, zim);
+            // x1 = x - t y, y1 = y + s x1, x2 = x1 - t y1
+            const f32x2 x1 = pkfma(NT, zim, zre);
+            const f32x2 y1 = pkfma(SS, x1, zim);
             zre = pkfma(NT, y1, x1);
             zim = y1;
           } else if (!TAPER) {
-            acc_re[j] = pkfma(p0, zre, acc_re[j]);
-            acc_im[j] = pkfma(p0, zim, acc_im[j]);
-            f32x2 t0 = zim * RI;
-            f32x2 t1 = zre * RI;
+            const f32x2 t0 = zim * RI;
+            const f32x2 t1 = zre * RI;
             const f32x2 nre = pkfma(zre, RR, t0);
             const f32x2 nim = pkfma(zim, RR, -t1);
-            acc_re[j + 1] = pkfma(p1, nre, acc_re[j + 1]);
-            acc_im[j + 1] = pkfma(p1, nim, acc_im[j + 1]);
-            t0 = nim * RI;
-            t1 = nre * RI;
-            zre = pkfma(nre, RR, t0);
-            zim = pkfma(nim, RR, -t1);
+            zre = nre; zim = nim;
           } else {
             if ((j % RESEED) == 0) {
               const float qu = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(2 * j + 1), tB));     // L(j+1) - L(j)
@@ -565,56 +516,75 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p) {
               rho_re = (f32x2){qu * rr, qd * rr};
               rho_im = (f32x2){qu * ri, -(qd * ri)};
             }
+            const f32x2 t0 = zim * rho_im;
+            const f32x2 t1 = zre * rho_im;
+            const f32x2 nre = pkfma(zre, rho_re, -t0);
+            const f32x2 nim = pkfma(zim, rho_re, t1);
+            zre = nre; zim = nim;
+            rho_re = pkfma(rho_re, HM, rho_re);
+            rho_im = pkfma(rho_im, HM, rho_im);
+          }
+        }
+      };
+      pairs(ra, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the second half row has landed before the next requests go out
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const cfloat_p rn = gp + (size_t)sn * CT;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const f32x2 pp = e == 0 ? p0 : p1;
-              acc_re[j + e] = pkfma(pp, zre, acc_re[j + e]);
-              acc_im[j + e] = pkfma(pp, zim, acc_im[j + e]);
-              const f32x2 t0 = zim * rho_im;
-              const f32x2 t1 = zre * rho_im;
-              const f32x2 nre = pkfma(zre, rho_re, -t0);
-              const f32x2 nim = pkfma(zim, rho_re, t1);
-              zre = nre; zim = nim;
-              rho_re = pkfma(rho_re, HM, rho_re);
-              rho_im = pkfma(rho_im, HM, rho_im);
+        for (int i = 0; i < NH; ++i) ra[i] = rn[i];
+        const cdouble_p dn = gd + (size_t)sn * 4;
+        sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
+        if (TAPER) sv[3] = dn[3];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      pairs(rb, NH / 2);
+
+      if (++since_flush >= p.flush_src && s + 1 < s_end) {
+        if (b_valid) {
+#pragma unroll
+          for (int j = 0; j < HC; ++j) {
+            const int ku = HC + j, kd = HC - 1 - j;
+            if (k0 + ku < p.nchan) {
+              double2 v = make_double2((double)acc_re[j].x, (double)acc_im[j].x);
+              if (!first_flush) { const double2 o = orow[ku]; v.x += o.x; v.y += o.y; }
+              orow[ku] = v;
+            }
+            if (k0 + kd < p.nchan) {
+              double2 v = make_double2((double)acc_re[j].y, (double)acc_im[j].y);
+              if (!first_flush) { const double2 o = orow[kd]; v.x += o.x; v.y += o.y; }
+              orow[kd] = v;
             }
           }
         }
-      }
-    }
-    since_flush += ns;
-    if ((since_flush >= p.flush_src && more) || !more) {
-      // accumulate the fp32 partial sums into the fp64 cube (read-modify-write after the first flush)
-      if (b_valid) {
 #pragma unroll
-        for (int j = 0; j < HC; ++j) {
-          const int ku = HC + j, kd = HC - 1 - j;
-          if (k0 + ku < p.nchan) {
-            double2 v = make_double2((double)acc_re[j].x, (double)acc_im[j].x);
-            if (!first_flush) { const double2 o = orow[ku]; v.x += o.x; v.y += o.y; }
-            orow[ku] = v;
-          }
-          if (k0 + kd < p.nchan) {
-            double2 v = make_double2((double)acc_re[j].y, (double)acc_im[j].y);
-            if (!first_flush) { const double2 o = orow[kd]; v.x += o.x; v.y += o.y; }
-            orow[kd] = v;
-          }
-        }
+        for (int j = 0; j < HC; ++j) { acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f); }
+        first_flush = false;
+        since_flush = 0;
       }
-#pragma unroll
-      for (int j = 0; j < HC; ++j) { acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f); }
-      first_flush = false;
-      since_flush = 0;
     }
   }
-  if (nchunks == 0 && b_valid) {
-    for (int k = 0; k < CT; ++k)
-      if (k0 + k < p.nchan) orow[k] = make_double2(0.0, 0.0);
+  if (b_valid) {
+#pragma unroll
+    for (int j = 0; j < HC; ++j) {
+      const int ku = HC + j, kd = HC - 1 - j;
+      if (k0 + ku < p.nchan) {
+        double2 v = make_double2((double)acc_re[j].x, (double)acc_im[j].x);
+        if (!first_flush) { const double2 o = orow[ku]; v.x += o.x; v.y += o.y; }
+        orow[ku] = v;
+      }
+      if (k0 + kd < p.nchan) {
+        double2 v = make_double2((double)acc_re[j].y, (double)acc_im[j].y);
+        if (!first_flush) { const double2 o = orow[kd]; v.x += o.x; v.y += o.y; }
+        orow[kd] = v;
+      }
+    }
   }
 }
 
 template <int CT, bool TAPER>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(TAPER ? 2 : 3, TAPER ? 2 : 3)))
 void k_skyvis_rec_f32pk(const SkyvisParams p) {
   if constexpr (!TAPER) {
     // block-uniform choice made by the host per baseline group; the two bodies share no live state
@@ -772,11 +742,10 @@ static hipError_t launch_rec_ct(const SkyvisParams& p, hipStream_t stream) {
   const int nslabs = p.ntiles * p.nsplit;
   const int slabs_per_xcd = (nslabs + 7) / 8;
   const unsigned grid = 8u * (unsigned)slabs_per_xcd * (unsigned)p.nbgroups;
-  const size_t lds = (size_t)p.src_chunk * CT * sizeof(T) + (size_t)(p.src_chunk + 1) * sizeof(double4);
   if (p.taper)
-    hipLaunchKernelGGL((k_skyvis_rec<T, CT, true>), dim3(grid), dim3(kBlockThreads), lds, stream, p);
+    hipLaunchKernelGGL((k_skyvis_rec<T, CT, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   else
-    hipLaunchKernelGGL((k_skyvis_rec<T, CT, false>), dim3(grid), dim3(kBlockThreads), lds, stream, p);
+    hipLaunchKernelGGL((k_skyvis_rec<T, CT, false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   return hipGetLastError();
 }
 
@@ -785,11 +754,10 @@ static hipError_t launch_rec_pk_ct(const SkyvisParams& p, hipStream_t stream) {
   const int nslabs = p.ntiles * p.nsplit;
   const int slabs_per_xcd = (nslabs + 7) / 8;
   const unsigned grid = 8u * (unsigned)slabs_per_xcd * (unsigned)p.nbgroups;
-  const size_t lds = (size_t)p.src_chunk * CT * sizeof(float) + (size_t)(p.src_chunk + 1) * sizeof(double4);
   if (p.taper)
-    hipLaunchKernelGGL((k_skyvis_rec_f32pk<CT, true>), dim3(grid), dim3(kBlockThreads), lds, stream, p);
+    hipLaunchKernelGGL((k_skyvis_rec_f32pk<CT, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   else
-    hipLaunchKernelGGL((k_skyvis_rec_f32pk<CT, false>), dim3(grid), dim3(kBlockThreads), lds, stream, p);
+    hipLaunchKernelGGL((k_skyvis_rec_f32pk<CT, false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   return hipGetLastError();
 }
 
