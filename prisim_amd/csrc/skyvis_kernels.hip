@@ -134,8 +134,8 @@ __device__ __forceinline__ void unpack16(const double2 v, double* d) { d[0] = v.
 // waves per SIMD the register allocator is asked to leave room for (hipcc otherwise spends
 // up to 256 VGPRs on scheduling freedom and drops to 1-2 waves/SIMD, too few to keep the
 // 2-cycle fp32 VALU issue slots filled -- see tools/microbench_valu.hip results).
-template <typename T, int CT> struct WavesPerEU {
-  static constexpr int value = (sizeof(T) == 4) ? (CT <= 32 ? 4 : 2) : (CT <= 8 ? 4 : (CT <= 16 ? 3 : 2));
+template <typename T, int CT, bool TAPER> struct WavesPerEU {
+  static constexpr int value = (sizeof(T) == 4) ? (CT <= 32 ? 4 : 2) : (CT <= 8 ? 4 : (CT <= 16 || !TAPER ? 3 : 2));
 };
 
 // LIFT: lifting (three-shear) form of the step rotation, see skyvis_rec_f32pk_body below; chosen per baseline group by the host.
@@ -332,7 +332,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p) {
 }
 
 template <typename T, int CT, bool TAPER>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(WavesPerEU<T, CT>::value)))
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(WavesPerEU<T, CT, TAPER>::value)))
 void k_skyvis_rec(const SkyvisParams p) {
   if constexpr (!TAPER) {
     const int bg = (blockIdx.x >> 3) % p.nbgroups;
@@ -584,7 +584,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p) {
 }
 
 template <int CT, bool TAPER>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(TAPER ? 2 : 3, TAPER ? 2 : 3)))
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_skyvis_rec_f32pk(const SkyvisParams p) {
   if constexpr (!TAPER) {
     // block-uniform choice made by the host per baseline group; the two bodies share no live state

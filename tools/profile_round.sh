@@ -1,0 +1,22 @@
+#!/bin/bash
+# rocprofv3 recipe behind profiles/<round>/ (run on the MI355X box through gpurun, from the repo root):
+#   tools/profile_round.sh r02      -> gpurun_out/prof_r02/{kernel_stats.csv, pmc_summary.json, bench_under_rocprof.json}
+# Kernel timing and every counter group are separate passes (gpurun refuses --pmc combined with API tracing).
+set -e
+ROUND=${1:-rXX}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$ROUND
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
+echo "trace done"
+i=0
+for group in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" \
+             "SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F32"; do
+  i=$((i+1))
+  rocprofv3 --pmc $group --output-format csv -d "$OUT/pmc$i" -- $BENCH > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err" || echo "pmc group $i failed: $group"
+  echo "pmc $i done"
+done
+cd "$REPO"
+python3 tools/summarize_pmc.py "$OUT"
