@@ -238,7 +238,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   pl.ct = ct;
   pl.pk = pl.f32 && (ct == 32 || ct == 64) && pl.kernel == PRISIM_KERNEL_RECURRENCE;
   pl.ntiles = (int)((nchan + ct - 1) / ct);
-  // LDS chunk: <= 16 KiB of pbflux per chunk (4 x 16-byte pieces per thread)
+  // source chunk: granularity of the zero padding and of the source split (the kernels stream rows through scalar loads)
   const int esz = pl.f32 ? 4 : 8;
   int chunk = ctx->tune_chunk ? ctx->tune_chunk : 64;
   const int max_chunk = 16384 / (ct * esz);
@@ -258,7 +258,9 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
       // candidates pick the smallest split whose last round is (nearly) full: the grid runs in rounds of
       // slots = CUs x resident blocks per CU, and e.g. 1152 blocks on 512 slots = 2.25 rounds waste a quarter of the
       // third round, while 1536 = 3.0 rounds waste nothing.
-      const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * (pl.pk ? 2 : (pl.f32 ? 4 : 2));
+      // resident blocks per CU = waves per SIMD the kernels are built for (WavesPerEU in skyvis_kernels.hip)
+      const int per_cu = pl.pk ? 3 : (pl.f32 ? 4 : (ct <= 8 ? 4 : ((ct <= 16 || !ctx->taper) ? 3 : 2)));
+      const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * per_cu;
       const int lo = (int)std::min<int64_t>((1024 + base - 1) / base, nchunks);
       const int hi = (int)std::min<int64_t>(std::min<int64_t>(4 * (int64_t)lo, 64), nchunks);
       nsplit = std::max(lo, 1);
@@ -271,7 +273,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
       if (nsplit > 64) nsplit = 64;
     }
     // Large problems keep nsplit = 1: splitting the sources to shorten the last, partly filled round of blocks
-    // (3824 blocks on 512 slots = 7.47 rounds) was measured at +1.5 % only and costs two extra passes over the
+    // (3824 blocks on 512 slots = 7.47 rounds at the time) was measured at +1.5 % only and costs two extra passes over the
     // cube (partial slabs + reduce), i.e. 3x the algorithmic HBM traffic.
   }
   if (nsplit > nchunks) nsplit = (int)nchunks;

@@ -138,9 +138,26 @@ template <typename T, int CT, bool TAPER> struct WavesPerEU {
   static constexpr int value = (sizeof(T) == 4) ? (CT <= 32 ? 4 : 2) : (CT <= 8 ? 4 : (CT <= 16 || !TAPER ? 3 : 2));
 };
 
+// Wave-local ordering point between LDS writes and LDS reads of other lanes of the same wave (DS operations of one wave
+// execute in order; this only stops the compiler from moving them across and makes it wait for the counters).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Rows of the per-wave transpose buffer used by the flush: a thread owns CT channels of ONE baseline, so storing straight
+// from registers writes 16-byte pieces 16 KiB apart (measured 0.5 TB/s: 2 ms of the 59 ms launch at config 3, 10 % of a
+// 1/8 baseline shard).  Instead each wave transposes kFlushCh channels at a time through LDS (unused otherwise) and writes
+// runs of 128 contiguous bytes per 8 lanes.
+template <typename T> struct FlushCfg;
+template <> struct FlushCfg<float> { static constexpr int ch = 16; using vec = float2; };     // 64 x 17 x 8 B = 8.5 KiB per wave
+template <> struct FlushCfg<double> { static constexpr int ch = 8; using vec = double2; };    // 64 x 9 x 16 B = 9 KiB per wave
+template <typename T> constexpr int flush_lds_bytes() { return (kBlockThreads / 64) * 64 * (FlushCfg<T>::ch + 1) * (int)sizeof(typename FlushCfg<T>::vec); }
+
 // LIFT: lifting (three-shear) form of the step rotation, see skyvis_rec_f32pk_body below; chosen per baseline group by the host.
 template <typename T, int CT, bool TAPER, bool LIFT>
-__device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p) {
+__device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned char* flush_lds) {
   static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
   static_assert(!(TAPER && LIFT), "no lifting form with the taper");
   constexpr int HC = CT / 2;                       // channels per chain
@@ -195,40 +212,72 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p) {
 
   double* const out = p.out + ((size_t)split * p.nbl * p.nchan) * 2;   // partial buffer of this split
   bool first_flush = true;
-  int since_flush = 0;
+
+  using FV = typename FlushCfg<T>::vec;
+  constexpr int FCH = FlushCfg<T>::ch < CT ? FlushCfg<T>::ch : CT;
+  FV* const wbuf = reinterpret_cast<FV*>(flush_lds) + (tid >> 6) * (64 * (FCH + 1));
+  const int lane = tid & 63;
+  const int64_t bw0 = (int64_t)bg * kBlockThreads + (tid & ~63);      // first baseline of this wave
 
   auto flush = [&]() {
-    if (b_valid) {
-      double2* orow = reinterpret_cast<double2*>(out) + (size_t)b * p.nchan + k0;
+    if (wave_active) {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));        // opaque: keeps the 64 store addresses from being hoisted out of the segment loop and spilled
 #pragma unroll
-      for (int k = 0; k < CT; ++k) {
-        if (k0 + k < p.nchan) {
-          double2 v = make_double2((double)acc_re[k], (double)acc_im[k]);
-          if (!first_flush) { double2 o = orow[k]; v.x += o.x; v.y += o.y; }
-          orow[k] = v;
+      for (int pz = 0; pz < CT / FCH; ++pz) {
+#pragma unroll
+        for (int c = 0; c < FCH; ++c) {
+          FV v; v.x = acc_re[pz * FCH + c]; v.y = acc_im[pz * FCH + c];
+          wbuf[lane * (FCH + 1) + c] = v;
+          acc_re[pz * FCH + c] = (T)0; acc_im[pz * FCH + c] = (T)0;     // dead during the stores below
         }
+        wave_lds_sync();
+        const int c = lane_o % FCH;
+        const int k = k0 + pz * FCH + c;
+#pragma unroll
+        for (int r = 0; r < FCH; ++r) {                          // 64 / FCH baselines per store instruction
+          const int bi = r * (64 / FCH) + lane_o / FCH;
+          const FV a = wbuf[bi * (FCH + 1) + c];
+          const int64_t bb = bw0 + bi;
+          if (bb < p.nbl && k < p.nchan) {
+            double2* o = reinterpret_cast<double2*>(out) + (size_t)bb * p.nchan + k;
+            double2 v = make_double2((double)a.x, (double)a.y);
+            if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
+            *o = v;
+          }
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the register footprint of the flush small
+        }
+        wave_lds_sync();
       }
     }
 #pragma unroll
     for (int k = 0; k < CT; ++k) { acc_re[k] = (T)0; acc_im[k] = (T)0; }
     first_flush = false;
-    since_flush = 0;
   };
 
-  if (wave_active && s_end > s_begin) {
+  // Sources are walked in segments of flush_src (fp32: the partial sums of a segment are then added into the fp64 cube;
+  // fp64: one segment).  One flush site, 32-bit source indices (the host keeps nsrc below 2^31).
+  const int n_loc = s_end > s_begin ? (int)(s_end - s_begin) : 0;
+  const int seg_len = (sizeof(T) == 4 && p.flush_src > 0) ? p.flush_src : 0x7fffffff;
+  const crow_p gps = gp + (size_t)s_begin * CT;
+  const cdir_p gds = gd + (size_t)s_begin * 4;
+  int seg0 = 0;
+  do {
+  const int seg1 = (n_loc - seg0 > seg_len) ? seg0 + seg_len : n_loc;
+  if (wave_active && seg1 > seg0) {
     T ra[NH], rb[NH];                                  // [2j] = channel HC+j (up), [2j+1] = channel HC-1-j (down)
     double sv[4] = {0.0, 0.0, 0.0, 0.0};
     {
-      const crow_p r0 = gp + (size_t)s_begin * CT;
+      const crow_p r0 = gps + (size_t)seg0 * CT;
 #pragma unroll
       for (int i = 0; i < NH; ++i) ra[i] = r0[i];
-      const cdir_p d0 = gd + (size_t)s_begin * 4;
+      const cdir_p d0 = gds + (size_t)seg0 * 4;
       sv[0] = d0[0]; sv[1] = d0[1]; sv[2] = d0[2];
       if (TAPER) sv[3] = d0[3];
     }
-    for (int64_t s = s_begin; s < s_end; ++s) {
-      const crow_p row = gp + (size_t)s * CT;
-      const int64_t sn = (s + 1 < s_end) ? s + 1 : s;               // the last source is simply fetched again
+    for (int s = seg0; s < seg1; ++s) {
+      const crow_p row = gps + (size_t)s * CT;
+      const int sn = (s + 1 < seg1) ? s + 1 : s;                    // the last source is simply fetched again
       // the first use of sv waits for everything in flight (first half row + direction); only then ask for the second half
       const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));   // seconds
       __builtin_amdgcn_sched_barrier(0);
@@ -315,33 +364,34 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p) {
       __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the second half row has landed before the next requests go out
       __builtin_amdgcn_sched_barrier(0);
       {
-        const crow_p rn = gp + (size_t)sn * CT;
+        const crow_p rn = gps + (size_t)sn * CT;
 #pragma unroll
         for (int i = 0; i < NH; ++i) ra[i] = rn[i];
-        const cdir_p dn = gd + (size_t)sn * 4;
+        const cdir_p dn = gds + (size_t)sn * 4;
         sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
         if (TAPER) sv[3] = dn[3];
       }
       __builtin_amdgcn_sched_barrier(0);
       pairs(rb, NH / 2);
-
-      if (sizeof(T) == 4 && ++since_flush >= p.flush_src && s + 1 < s_end) flush();
     }
   }
   flush();
+  seg0 = seg1;
+  } while (seg0 < n_loc);
 }
 
 template <typename T, int CT, bool TAPER>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(WavesPerEU<T, CT, TAPER>::value)))
 void k_skyvis_rec(const SkyvisParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<T>()];
   if constexpr (!TAPER) {
     const int bg = (blockIdx.x >> 3) % p.nbgroups;
     if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {      // block-uniform; the two bodies share no live state
-      skyvis_rec_body<T, CT, false, true>(p);
+      skyvis_rec_body<T, CT, false, true>(p, flush_lds);
       return;
     }
   }
-  skyvis_rec_body<T, CT, TAPER, false>(p);
+  skyvis_rec_body<T, CT, TAPER, false>(p, flush_lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -378,7 +428,7 @@ typedef const __attribute__((address_space(4))) float* cfloat_p;
 typedef const __attribute__((address_space(4))) double* cdouble_p;
 
 template <int CT, bool TAPER, bool LIFT>
-__device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p) {
+__device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, unsigned char* flush_lds) {
   static_assert(!(TAPER && LIFT), "the taper-folded recurrence is a scaled rotation: no lifting form");
   constexpr int HC = CT / 2;
   constexpr int NH = CT / 2;                         // floats per half row
@@ -417,24 +467,75 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p) {
 
   const cfloat_p gp = (cfloat_p)(uintptr_t)(reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT);
   const cdouble_p gd = (cdouble_p)(uintptr_t)p.dirs_prep;
-  double2* const orow = reinterpret_cast<double2*>(p.out) + ((size_t)split * p.nbl + (size_t)b) * p.nchan + k0;
+  double2* const out = reinterpret_cast<double2*>(p.out) + (size_t)split * p.nbl * p.nchan;
   bool first_flush = true;
-  int since_flush = 0;
+  float2* const wbuf = reinterpret_cast<float2*>(flush_lds) + (tid >> 6) * (64 * 17);
+  const int lane = tid & 63;
+  const int64_t bw0 = (int64_t)bg * kBlockThreads + (tid & ~63);      // first baseline of this wave
 
-  if (wave_active && s_end > s_begin) {
+  // fp32 partial sums -> fp64 cube (read-modify-write after the first flush), transposed through LDS 16 channels at a time:
+  // piece pz holds the pairs j = 8 pz .. 8 pz + 7, i.e. channels HC+8pz .. HC+8pz+7 (columns 0-7) and HC-1-8pz .. HC-8-8pz
+  // (columns 8-15); 16 lanes write the 2 x 128 contiguous bytes of one baseline, 4 baselines per store instruction.
+  auto flush = [&]() {
+    if (wave_active) {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));        // opaque: keeps the 64 store addresses from being hoisted out of the segment loop and spilled
+#pragma unroll
+      for (int pz = 0; pz < HC / 8; ++pz) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int j = 8 * pz + jj;
+          wbuf[lane * 17 + jj] = make_float2(acc_re[j].x, acc_im[j].x);
+          wbuf[lane * 17 + 8 + jj] = make_float2(acc_re[j].y, acc_im[j].y);
+          acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f);           // dead during the stores below
+        }
+        wave_lds_sync();
+        const int c = lane_o & 15;
+        const int k = k0 + ((c < 8) ? (HC + 8 * pz + c) : (HC - 1 - 8 * pz - (c - 8)));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int bi = r * 4 + (lane_o >> 4);
+          const float2 a = wbuf[bi * 17 + c];
+          const int64_t bb = bw0 + bi;
+          if (bb < p.nbl && k < p.nchan) {
+            double2* o = out + (size_t)bb * p.nchan + k;
+            double2 v = make_double2((double)a.x, (double)a.y);
+            if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
+            *o = v;
+          }
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the register footprint of the flush small
+        }
+        wave_lds_sync();
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < HC; ++j) { acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f); }
+    first_flush = false;
+  };
+
+  // Sources are walked in segments of flush_src: the fp32 partial sums of a segment are then added into the fp64 cube.
+  // One flush site, 32-bit source indices (the host keeps nsrc below 2^31).
+  const int n_loc = s_end > s_begin ? (int)(s_end - s_begin) : 0;
+  const int seg_len = p.flush_src > 0 ? p.flush_src : 0x7fffffff;
+  const cfloat_p gps = gp + (size_t)s_begin * CT;
+  const cdouble_p gds = gd + (size_t)s_begin * 4;
+  int seg0 = 0;
+  do {
+  const int seg1 = (n_loc - seg0 > seg_len) ? seg0 + seg_len : n_loc;
+  if (wave_active && seg1 > seg0) {
     float ra[NH], rb[NH];
     double sv[4] = {0.0, 0.0, 0.0, 0.0};
     {
-      const cfloat_p r0 = gp + (size_t)s_begin * CT;
+      const cfloat_p r0 = gps + (size_t)seg0 * CT;
 #pragma unroll
       for (int i = 0; i < NH; ++i) ra[i] = r0[i];
-      const cdouble_p d0 = gd + (size_t)s_begin * 4;
+      const cdouble_p d0 = gds + (size_t)seg0 * 4;
       sv[0] = d0[0]; sv[1] = d0[1]; sv[2] = d0[2];
       if (TAPER) sv[3] = d0[3];
     }
-    for (int64_t s = s_begin; s < s_end; ++s) {
-      const cfloat_p row = gp + (size_t)s * CT;
-      const int64_t sn = (s + 1 < s_end) ? s + 1 : s;               // the last source is simply fetched again
+    for (int s = seg0; s < seg1; ++s) {
+      const cfloat_p row = gps + (size_t)s * CT;
+      const int sn = (s + 1 < seg1) ? s + 1 : s;                    // the last source is simply fetched again
       // the first use of sv waits for everything in flight (first half row + direction); only then ask for the second half
       const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));
       __builtin_amdgcn_sched_barrier(0);
@@ -531,71 +632,36 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p) {
       __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the second half row has landed before the next requests go out
       __builtin_amdgcn_sched_barrier(0);
       {
-        const cfloat_p rn = gp + (size_t)sn * CT;
+        const cfloat_p rn = gps + (size_t)sn * CT;
 #pragma unroll
         for (int i = 0; i < NH; ++i) ra[i] = rn[i];
-        const cdouble_p dn = gd + (size_t)sn * 4;
+        const cdouble_p dn = gds + (size_t)sn * 4;
         sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
         if (TAPER) sv[3] = dn[3];
       }
       __builtin_amdgcn_sched_barrier(0);
       pairs(rb, NH / 2);
-
-      if (++since_flush >= p.flush_src && s + 1 < s_end) {
-        if (b_valid) {
-#pragma unroll
-          for (int j = 0; j < HC; ++j) {
-            const int ku = HC + j, kd = HC - 1 - j;
-            if (k0 + ku < p.nchan) {
-              double2 v = make_double2((double)acc_re[j].x, (double)acc_im[j].x);
-              if (!first_flush) { const double2 o = orow[ku]; v.x += o.x; v.y += o.y; }
-              orow[ku] = v;
-            }
-            if (k0 + kd < p.nchan) {
-              double2 v = make_double2((double)acc_re[j].y, (double)acc_im[j].y);
-              if (!first_flush) { const double2 o = orow[kd]; v.x += o.x; v.y += o.y; }
-              orow[kd] = v;
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < HC; ++j) { acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f); }
-        first_flush = false;
-        since_flush = 0;
-      }
     }
   }
-  if (b_valid) {
-#pragma unroll
-    for (int j = 0; j < HC; ++j) {
-      const int ku = HC + j, kd = HC - 1 - j;
-      if (k0 + ku < p.nchan) {
-        double2 v = make_double2((double)acc_re[j].x, (double)acc_im[j].x);
-        if (!first_flush) { const double2 o = orow[ku]; v.x += o.x; v.y += o.y; }
-        orow[ku] = v;
-      }
-      if (k0 + kd < p.nchan) {
-        double2 v = make_double2((double)acc_re[j].y, (double)acc_im[j].y);
-        if (!first_flush) { const double2 o = orow[kd]; v.x += o.x; v.y += o.y; }
-        orow[kd] = v;
-      }
-    }
-  }
+  flush();
+  seg0 = seg1;
+  } while (seg0 < n_loc);
 }
 
 template <int CT, bool TAPER>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_skyvis_rec_f32pk(const SkyvisParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>()];
   if constexpr (!TAPER) {
     // block-uniform choice made by the host per baseline group; the two bodies share no live state
     const int jblk = blockIdx.x >> 3;
     const int bg = jblk % p.nbgroups;
     if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {
-      skyvis_rec_f32pk_body<CT, false, true>(p);
+      skyvis_rec_f32pk_body<CT, false, true>(p, flush_lds);
       return;
     }
   }
-  skyvis_rec_f32pk_body<CT, TAPER, false>(p);
+  skyvis_rec_f32pk_body<CT, TAPER, false>(p, flush_lds);
 }
 
 // ------------------------------------------------------------------------------------------
