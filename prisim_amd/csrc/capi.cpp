@@ -647,6 +647,10 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   // fp32 sum grows like eps/2*sqrt(n/3) relative to sum|pbflux| in the fully coherent worst case (1.1e-6 at n = 16384,
   // tolerance 5e-6), and every flush is a read-modify-write pass over the whole cube, so flush as rarely as that allows.
   p.flush_src = 16384;
+  if (const char* env = getenv("PRISIM_HIP_FLUSH_SRC")) {        // test hook: exercise the read-modify-write flush on small skies
+    const long v = atol(env);
+    if (v > 0 && v < (1L << 30)) p.flush_src = (int32_t)v;
+  }
   p.scale_comp = scale_comp;
   if (pl.kernel == PRISIM_KERNEL_DIRECT) {
     p.out = dst;

@@ -93,6 +93,24 @@ def test_oracle_parity_all_variants(ctx, shape, taper):
     assert relerr(ctx.get_vis(), ref, pb) <= TOL[_abi.PRISIM_FP64]
 
 
+@pytest.mark.parametrize('taper', [False, True])
+def test_fp32_periodic_flush_read_modify_write(ctx, monkeypatch, taper):
+    """fp32 partial sums are added into the fp64 cube every flush_src sources (16384 in production, config 5 crosses it 24
+    times per launch); the test hook forces a flush every 37 sources so segments, the transposed stores and the
+    read-modify-write path are exercised on a sky the oracle finishes in seconds, for every fp32 tile width and a source split."""
+    bl, ch, dc, pb, pc, fw = _random_case(23, 300, 200, 500, taper)
+    ref = O.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw)
+    monkeypatch.setenv('PRISIM_HIP_FLUSH_SRC', '37')
+    ctx.set_array(bl, ch)
+    ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
+    for ct in (8, 16, 32, 64):
+        for nsplit in (1, 2):
+            ctx.set_tuning(ct, 0, nsplit)
+            ctx.compute(precision=_abi.PRISIM_FP32, kernel=_abi.PRISIM_KERNEL_RECURRENCE)
+            assert relerr(ctx.get_vis(), ref, pb) <= TOL[_abi.PRISIM_FP32], (taper, ct, nsplit)
+    ctx.set_tuning(0, 0, 0)
+
+
 def test_config2_fp64_full(ctx):
     """BASELINE config 2: HERA-19 x 256 ch x nside-16 diffuse sky, Airy beam, taper ON, fp64 -- full size."""
     cfg = W.config2()
