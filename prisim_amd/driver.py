@@ -54,6 +54,7 @@ DEFAULTS = {
     'catalog': {'custom_file': 'custom_catalog.txt'},
     'processing': {'gradient_mode': None, 'f_pad': 1.0, 'bpass_shape': 'bhw', 'delay_transform': False, 'memsave': False},
     'pp': {'key': 'bl', 'eqvol': True},
+    'save_redundant': True,
     'save_formats': {'npz': True},
     'diagnosis': {'wait_after_run': False},
 }
@@ -129,15 +130,21 @@ def baseline_info(parms):
         keep &= length >= parms['baseline']['min']
     if parms['baseline']['max'] is not None:
         keep &= length <= parms['baseline']['max']
-    bl, ids = bl[keep], ids[keep]
-    if not arr.get('redundant', True):
-        # keep one baseline per redundant group (vectors equal to 1 cm)
-        key = NP.round(bl * 100.0).astype(NP.int64)
-        _, first = NP.unique(key, axis=0, return_index=True)
-        first = NP.sort(first)
-        bl, ids = bl[first], ids[first]
-    labels = ['{0}{1:d}-{0}{2:d}'.format(parms['telescope'].get('label_prefix') or '', int(a), int(b)) for a, b in ids]
-    return bl, labels, pos
+    prefix = parms['telescope'].get('label_prefix') or ''
+    all_labels = NP.array(['{0}{1:d}-{0}{2:d}'.format(prefix, int(a), int(b)) for a, b in ids])
+    if arr.get('redundant', True):
+        # array.redundant (default true) = look for redundancy and simulate one baseline per redundant group
+        # (interferometry.py:1890-1891); the others are re-created at save time when save_redundant is set (:6823-6906)
+        ubl, first, counts, occ = LAY.uniq_baselines(bl)
+        order = NP.argsort(NP.sqrt(NP.sum(ubl ** 2, axis=1)), kind='mergesort')         # :1904-1905
+        ubl, first, counts, occ = ubl[order], first[order], counts[order], [occ[i] for i in order]
+    else:
+        ubl, first, counts, occ = bl, NP.arange(bl.shape[0]), NP.ones(bl.shape[0], dtype=int), [[i] for i in range(bl.shape[0])]
+    sel = keep[first]                                                                  # length selection, :1958
+    ubl, first, counts, occ = ubl[sel], first[sel], counts[sel], [occ[i] for i in NP.flatnonzero(sel)]
+    labels = all_labels[first].tolist()
+    groups = {labels[i]: all_labels[NP.asarray(occ[i])].tolist() for i in range(len(labels))}
+    return ubl, labels, pos, groups
 
 
 def read_custom_catalog(path):
@@ -269,7 +276,7 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         raise NotImplementedError("pp.key must be 'bl': baselines are the natural shard axis on GPUs (SURVEY.md 2.2)")
     bp = parms['bandpass']
     chans = W.channel_grid(float(bp['freq']), float(bp['freq_resolution']), int(bp['nchan']))      # run_prisim.py:900
-    bl, labels, antpos = baseline_info(parms)
+    bl, labels, antpos, blgroups = baseline_info(parms)
     nbl_total = bl.shape[0]
     per = (nbl_total + world - 1) // world                                                           # :1775-1791, equal shards
     lo, hi = min(rank * per, nbl_total), min((rank + 1) * per, nbl_total)
@@ -284,7 +291,8 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     proc = parms['processing']
     ia = RI.InterferometerArray(labels_mine, bl_mine, chans, telescope=tel, eff_Q=parms['telescope']['eff_Q'],
                                 latitude=tel['latitude'], longitude=tel['longitude'], altitude=tel['altitude'],
-                                skycoords='radec', A_eff=parms['telescope']['A_eff'], pointing_coords='hadec', device=device)
+                                skycoords='radec', A_eff=parms['telescope']['A_eff'], pointing_coords='hadec', device=device,
+                                blgroupinfo={'groups': blgroups, 'reversemap': {m: k for k, v in blgroups.items() for m in v}})
     ia.reserve(n_acc)
     if extbeam is not None:
         bm = parms['beam']
@@ -315,7 +323,7 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         cube, labels_all, bl_all = cube[:nbl_total], labels, bl
     out = {'skyvis_freq': cube, 'bl': bl_all, 'labels': labels_all, 'freq': chans, 'lst': NP.asarray(ia.lst),
            'timestamp': NP.asarray(ia.timestamp), 'bl_length': NP.sqrt(NP.sum(bl_all ** 2, axis=1)), 't_sim': t_sim,
-           'antpos': antpos, 'ia': ia}
+           'antpos': antpos, 'ia': ia, 'blgroups': blgroups}
     if proc.get('delay_transform') and world == 1:
         ia.delay_transform(pad=float(proc.get('f_pad', 1.0)), freq_wts=window(chans.size, proc.get('bpass_shape', 'bhw')), verbose=False)
         out['skyvis_lag'], out['lags'] = ia.skyvis_lag, ia.lags
@@ -328,8 +336,18 @@ def save(out, parms, infile=None):
     outdir = os.path.join(ds['rootdir'], ds['project'], simid, 'simdata')
     os.makedirs(outdir, exist_ok=True)
     path = os.path.join(outdir, 'simvis')
+    if parms.get('save_redundant', True) and out.get('blgroups'):
+        # re-create the redundant baselines from the simulated unique ones (run_prisim.py:2325-2326, interferometry.py:6889-6895)
+        counts = [len(out['blgroups'].get(lbl, [lbl])) for lbl in out['labels']]
+        if any(c > 1 for c in counts):
+            out = dict(out)
+            out['labels'] = [m for lbl in out['labels'] for m in out['blgroups'].get(lbl, [lbl])]
+            for key, axis in (('skyvis_freq', 0), ('bl', 0), ('bl_length', 0), ('skyvis_lag', 0)):
+                if key in out:
+                    out[key] = NP.repeat(out[key], counts, axis=axis)
     if parms['save_formats'].get('npz', True):
         keys = {k: out[k] for k in ('skyvis_freq', 'lst', 'freq', 'timestamp', 'bl', 'bl_length')}          # interferometry.py:8862
+        keys['labels'] = NP.asarray(out['labels'])
         for extra in ('skyvis_lag', 'lags'):
             if extra in out:
                 keys[extra] = out[extra]

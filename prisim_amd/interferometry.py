@@ -769,6 +769,62 @@ class InterferometerArray(object):
                 self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
 
     # ------------------------------------------------------------------------------------------
+    def duplicate_measurements(self, blgroups=None):
+        """Re-create the redundant baselines from the simulated unique ones (interferometry.py:6823-6906): every baseline whose
+        label is a key of `blgroups` is repeated once per member of its group (visibilities, gradient, baselines, per-baseline
+        system parameters), labels become the members' labels, then noise is regenerated for the expanded set.  The GPU computes
+        the unique baselines only; this is a host-side repeat."""
+        if blgroups is None:
+            blgroups = self.blgroups
+        if not isinstance(blgroups, dict):
+            raise TypeError('Input blgroups must be a dictionary')
+        nbl = sum(len(v) for v in blgroups.values()) if self.bl_reversemap is None else len(self.bl_reversemap)
+        if len(self.labels) >= nbl:
+            return
+        labels = [tuple(l) if isinstance(l, (list, NP.ndarray)) else l for l in self.labels]
+        groups = {}
+        for key, members in blgroups.items():
+            members = [tuple(m) if isinstance(m, (list, NP.ndarray)) else m for m in members]
+            if key not in labels:
+                rkey = tuple(reversed(key)) if isinstance(key, tuple) else key
+                if rkey not in labels:
+                    raise KeyError('Input label {0} not found in attribute labels'.format(key))
+                key = rkey
+            if key not in members:
+                members = [key] + members
+            groups[key] = members
+        new_labels, num_list = [], []
+        for label in labels:
+            members = groups.get(label, [label])
+            num_list.append(len(members))
+            for m in members:
+                if m in new_labels:
+                    raise ValueError('Label {0} repeated in more than one baseline group'.format(m))
+                new_labels.append(m)
+        if self.skyvis_freq is not None:
+            self.skyvis_freq = NP.repeat(self.skyvis_freq, num_list, axis=0)
+        if self.gradient_mode is not None and self.gradient.get(self.gradient_mode) is not None:
+            self.gradient[self.gradient_mode] = NP.repeat(self.gradient[self.gradient_mode], num_list, axis=1)
+        self.labels = new_labels
+        self.baselines = NP.repeat(self.baselines, num_list, axis=0)
+        if self.projected_baselines is not None:
+            self.projected_baselines = NP.repeat(self.projected_baselines, num_list, axis=0)
+        self.baseline_lengths = NP.repeat(self.baseline_lengths, num_list)
+        self.baseline_orientations = NP.repeat(self.baseline_orientations, num_list)
+        for name in ('Tsys', 'eff_Q', 'A_eff', 'bp', 'bp_wts'):
+            arr = getattr(self, name, None)
+            if isinstance(arr, NP.ndarray) and arr.ndim >= 1 and arr.shape[0] > 1:
+                setattr(self, name, NP.repeat(arr, num_list, axis=0))
+        # the resident device array follows the expanded baseline list (slots are re-uploaded on demand)
+        self._ctx.set_array(self.baselines, self.channels, nt_max=self._reserved)
+        self._restore_external_beam()
+        if self._reserved >= self.n_acc and self.skyvis_freq is not None:
+            for t in range(self.n_acc):
+                self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
+        self.generate_noise()                                                          # :6905-6906
+        self.add_noise()
+
+    # ------------------------------------------------------------------------------------------
     def delay_transform(self, pad=1.0, freq_wts=None, verbose=True):
         """Frequency -> delay transform on the GPU (rocFFT) of whichever visibility cubes exist
         (interferometry.py:8052-8137; Q20).  Sets lags, skyvis_lag (vis_lag, vis_noise_lag when their

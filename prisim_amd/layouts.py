@@ -113,6 +113,43 @@ def fold_and_sort_baselines(bl, ids=None):
     return bl[order]
 
 
+def uniq_baselines(baseline_locations, redundant=None):
+    """Unique / redundant / non-redundant baselines of a set (interferometry.py:1373-1461).
+
+    Two baselines are the same when their length (to 0.01 m), zenith angle and folded orientation in [0, 180) deg (both to
+    0.001 arcsec) agree -- the reference's string key '{len:.2f}_{za:.3f}_{orientation:.3f}', kept verbatim because the order
+    of the returned unique baselines is the lexicographic order of those keys.
+    redundant=None: every distinct baseline; True: only those occurring more than once; False: only those occurring once.
+    Returns (baselines [n,3], index of the first occurrence of each, counts, list of index lists of all occurrences).
+    """
+    if not isinstance(baseline_locations, NP.ndarray):
+        raise TypeError('baseline_locations must be a numpy array')
+    if redundant is not None and not isinstance(redundant, bool):
+        raise TypeError('keyword "redundant" must be set to None or a boolean value')
+    bl = NP.asarray(baseline_locations, dtype=float)
+    if bl.shape[1] > 3:
+        bl = bl[:, :3]
+    elif bl.shape[1] < 3:
+        bl = NP.hstack((bl, NP.zeros((bl.shape[0], 3 - bl.shape[1]))))
+    orient = NP.angle(bl[:, 0] + 1j * bl[:, 1], deg=True)
+    orient[orient >= 180.0] -= 180.0
+    orient[orient < 0.0] += 180.0
+    length = NP.sqrt(NP.sum(bl ** 2, axis=1))
+    za = NP.degrees(NP.arccos(bl[:, 2] / length))
+    keys = NP.array(['%.2f_%.3f_%.3f' % (l, 3.6e3 * z, 3.6e3 * o) for l, z, o in zip(length, za, orient)])
+    _, first, inverse, counts = NP.unique(keys, return_index=True, return_inverse=True, return_counts=True)
+    if redundant is None:
+        sel = NP.arange(first.size)
+    elif redundant:
+        sel = NP.flatnonzero(counts > 1)
+    else:
+        sel = NP.flatnonzero(counts == 1)
+    order = NP.argsort(inverse, kind='mergesort')
+    starts = NP.concatenate(([0], NP.cumsum(counts)))
+    occurrences = [order[starts[g]:starts[g + 1]].tolist() for g in sel]
+    return bl[first[sel], :], first[sel], counts[sel], occurrences
+
+
 _HERA_PRESETS = (7, 19, 37, 61, 91, 127, 169, 217, 271, 331)
 
 

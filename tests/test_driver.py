@@ -26,18 +26,39 @@ def test_load_parms_defaults_and_template_merge(tmp_path):
 
 def test_baseline_info_selection_and_redundancy():
     p = driver.load_parms(os.path.join(EX, 'config2.yaml'))
-    bl, labels, pos = driver.baseline_info(p)
-    assert bl.shape == (171, 3) and len(labels) == 171 and pos.shape == (19, 3)
+    bl, labels, pos, groups = driver.baseline_info(p)                                 # array.redundant: false -> every pair
+    assert bl.shape == (171, 3) and len(labels) == 171 and pos.shape == (19, 3) and all(len(v) == 1 for v in groups.values())
     p['baseline']['max'] = 15.0
     assert driver.baseline_info(p)[0].shape[0] == 42                                  # 14.6 m spacings of HERA-19
     p['baseline']['max'] = None
-    p['array']['redundant'] = False
-    blu = driver.baseline_info(p)[0]
-    assert blu.shape[0] == 30                                                         # unique baselines of a 19-element hexagon
+    p['array']['redundant'] = True                                                    # the reference's default: unique baselines only
+    blu, lblu, _, grp = driver.baseline_info(p)
+    assert blu.shape[0] == 30 and len(grp) == 30                                      # unique baselines of a 19-element hexagon
+    assert sum(len(v) for v in grp.values()) == 171 and max(len(v) for v in grp.values()) == 14
+    assert NP.all(NP.diff(NP.sqrt((blu ** 2).sum(1))) >= -1e-9) and all(lbl in grp[lbl] for lbl in lblu)
     p1 = driver.load_parms(os.path.join(EX, 'config1.yaml'))
     p1['array']['file'] = os.path.join(EX, 'config1_layout.txt')
     bl1 = driver.baseline_info(p1)[0]
     assert bl1.shape == (6, 3) and NP.isclose(NP.sqrt((bl1 ** 2).sum(1)).min(), 14.6, atol=1e-3)
+
+
+def test_uniq_baselines_modes():
+    """interferometry.py:1373-1461: None = all distinct, True = those seen more than once, False = those seen once."""
+    from prisim_amd import layouts as LAY
+    bl = NP.array([[14.6, 0, 0], [0, 14.6, 0], [14.6, 0, 0], [29.2, 0, 0], [-14.6, 0, 0], [7.3, 12.644, 0.0]])
+    ub, first, counts, occ = LAY.uniq_baselines(bl)
+    assert ub.shape == (4, 3) and sorted(counts.tolist()) == [1, 1, 1, 3]            # -b folds onto b (orientation modulo 180 deg)
+    assert sorted(map(sorted, occ)) == [[0, 2, 4], [1], [3], [5]]
+    assert all(first[i] == min(occ[i]) for i in range(4))
+    rb, rfirst, rcounts, rocc = LAY.uniq_baselines(bl, redundant=True)
+    assert rb.shape == (1, 3) and rcounts.tolist() == [3] and sorted(rocc[0]) == [0, 2, 4]
+    nb, _, ncounts, _ = LAY.uniq_baselines(bl, redundant=False)
+    assert nb.shape == (3, 3) and ncounts.tolist() == [1, 1, 1]
+    assert LAY.uniq_baselines(bl[:, :2])[0].shape == (4, 3)                           # 2-column input is padded with zeros
+    with pytest.raises(TypeError):
+        LAY.uniq_baselines(bl.tolist())
+    with pytest.raises(TypeError):
+        LAY.uniq_baselines(bl, redundant='yes')
 
 
 def test_schedule_drift_and_track():
@@ -108,7 +129,7 @@ def test_config1_yaml_end_to_end_matches_oracle(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     out = NP.load(os.path.join(str(tmp_path), 'prisim_amd_cfg1', 'cfg1', 'simdata', 'simvis.npz'))
-    assert sorted(out.files) == sorted(['skyvis_freq', 'lst', 'freq', 'timestamp', 'bl', 'bl_length', 'skyvis_lag', 'lags'])
+    assert sorted(out.files) == sorted(['skyvis_freq', 'lst', 'freq', 'timestamp', 'bl', 'bl_length', 'labels', 'skyvis_lag', 'lags'])
     vis = out['skyvis_freq']
     assert vis.shape == (6, 64, 1)
     # oracle: same catalog in the local frame at lst = 0
@@ -144,3 +165,32 @@ def test_config2_yaml_runs_and_reserves_device_cube():
     ia._ctx.allgather(2)
     g = ia._ctx.get_gathered(2, 1)
     assert NP.array_equal(NP.transpose(g[:, 0], (1, 2, 0)), out['skyvis_freq'])
+
+
+@pytest.mark.gpu
+def test_config2_unique_baselines_then_save_redundant(tmp_path):
+    """array.redundant: true (the reference's default) simulates the 30 unique baselines of HERA-19; save_redundant re-creates all
+    171 at save time (run_prisim.py:2325-2326).  The expanded file equals the all-baselines run to the 0.01 m / 0.001 arcsec at which
+    the reference calls baselines redundant."""
+    p_all = driver.load_parms(os.path.join(EX, 'config2.yaml'))
+    p_all['dirstruct']['rootdir'] = str(tmp_path) + '/'
+    p_all['dirstruct']['simid'] = 'all'
+    out_all = driver.run(p_all, infile_dir=EX, verbose=False)
+    f_all = NP.load(driver.save(out_all, p_all))
+    p_u = driver.load_parms(os.path.join(EX, 'config2.yaml'))
+    p_u['array']['redundant'] = True
+    p_u['dirstruct']['rootdir'] = str(tmp_path) + '/'
+    p_u['dirstruct']['simid'] = 'uniq'
+    out_u = driver.run(p_u, infile_dir=EX, verbose=False)
+    assert out_u['skyvis_freq'].shape == (30, 256, 2)
+    f_u = NP.load(driver.save(out_u, p_u))
+    assert f_u['skyvis_freq'].shape == (171, 256, 2) and f_u['bl'].shape == (171, 3) and f_u['labels'].shape == (171,)
+    assert sorted(f_u['labels'].tolist()) == sorted(f_all['labels'].tolist())
+    order_u = NP.argsort(f_u['labels'])
+    order_a = NP.argsort(f_all['labels'])
+    assert NP.allclose(f_u['bl'][order_u], f_all['bl'][order_a], atol=1e-2)
+    scale = NP.max(NP.abs(f_all['skyvis_freq']))
+    assert NP.max(NP.abs(f_u['skyvis_freq'][order_u] - f_all['skyvis_freq'][order_a])) <= 1e-9 * scale
+    p_u['save_redundant'] = False
+    p_u['dirstruct']['simid'] = 'uniq_only'
+    assert NP.load(driver.save(out_u, p_u))['skyvis_freq'].shape == (30, 256, 2)

@@ -452,3 +452,30 @@ def test_interferometer_array_generate_and_add_noise():
     assert NP.array_equal(first, ia.vis_noise_freq)
     ia.delay_transform(pad=0.0, verbose=False)                     # all three cubes are transformed now (Q20)
     assert ia.vis_lag.shape == ia.skyvis_lag.shape == ia.vis_noise_lag.shape == (2, 32, 3)
+
+
+def test_duplicate_measurements_expands_redundant_groups():
+    """interferometry.py:6823-6906: unique baselines are simulated, redundant ones re-created by repetition, noise regenerated."""
+    ch = 150e6 + NP.arange(16) * 1e5
+    bl = NP.array([[14.6, 0.0, 0.0], [0.0, 29.2, 0.0], [7.3, 12.644, 0.0]])
+    labels = [('a1', 'a0'), ('a2', 'a0'), ('a3', 'a0')]
+    groups = {('a1', 'a0'): [('a1', 'a0'), ('a5', 'a4'), ('a7', 'a6')], ('a3', 'a0'): [('a9', 'a8')]}      # key itself is added if missing
+    rev = {m: k for k, v in groups.items() for m in v}
+    rev[('a2', 'a0')] = ('a2', 'a0'); rev[('a3', 'a0')] = ('a3', 'a0')
+    skymod = SM.SkyModel(location=[[80.0, 100.0], [60.0, 200.0]], flux_ref=[1.0, 2.0], spindex=[0.0, -0.7], ref_freq=150e6)
+    ia = RI.InterferometerArray(labels, bl, ch, telescope={'shape': 'delta'}, skycoords='altaz', pointing_coords='altaz', A_eff=154.0,
+                                eff_Q=0.96, blgroupinfo={'groups': groups, 'reversemap': rev})
+    for j in range(2):
+        ia.observe((2457000.5 + j, 0.0), {'Tnet': 300.0}, NP.ones(16), [90.0, 270.0], skymod, 60.0)
+    before = ia.skyvis_freq.copy()
+    with pytest.warns(UserWarning):
+        ia.duplicate_measurements()
+    assert ia.labels == [('a1', 'a0'), ('a5', 'a4'), ('a7', 'a6'), ('a2', 'a0'), ('a3', 'a0'), ('a9', 'a8')]
+    assert ia.skyvis_freq.shape == (6, 16, 2) and ia.baselines.shape == (6, 3) and ia.baseline_lengths.shape == (6,)
+    assert NP.array_equal(ia.skyvis_freq, before[[0, 0, 0, 1, 2, 2]]) and NP.array_equal(ia.baselines, bl[[0, 0, 0, 1, 2, 2]])
+    assert ia.Tsys.shape[0] == 6 and ia.vis_noise_freq.shape == (6, 16, 2) and ia.vis_freq.shape == (6, 16, 2)
+    assert not NP.array_equal(ia.vis_noise_freq[0], ia.vis_noise_freq[1])            # redundant baselines get independent noise
+    ia.delay_transform(pad=0.0, verbose=False)                                        # device state follows the expanded list
+    assert ia.skyvis_lag.shape == (6, 16, 2) and NP.allclose(ia.skyvis_lag[0], ia.skyvis_lag[2])
+    with pytest.raises(TypeError):
+        ia.duplicate_measurements(blgroups=[1, 2])
