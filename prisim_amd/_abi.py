@@ -86,7 +86,8 @@ class PrisimBeamSky(C.Structure):
 class PrisimTiming(C.Structure):
     _fields_ = [('last_kernel_ms', C.c_double), ('last_compute_ms', C.c_double), ('sum_kernel_ms', C.c_double),
                 ('n_kernel', C.c_int64), ('last_terms', C.c_int64), ('last_kernel_id', C.c_int32),
-                ('last_chan_tile', C.c_int32), ('last_nsplit', C.c_int32), ('last_lift_groups', C.c_int32)]
+                ('last_chan_tile', C.c_int32), ('last_nsplit', C.c_int32), ('last_lift_groups', C.c_int32),
+                ('last_taper_group', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class PrisimHipError(RuntimeError):

@@ -259,7 +259,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
       // slots = CUs x resident blocks per CU, and e.g. 1152 blocks on 512 slots = 2.25 rounds waste a quarter of the
       // third round, while 1536 = 3.0 rounds waste nothing.
       // resident blocks per CU = waves per SIMD the kernels are built for (WavesPerEU in skyvis_kernels.hip)
-      const int per_cu = pl.pk ? 3 : (pl.f32 ? 4 : (ct <= 8 ? 4 : ((ct <= 16 || !ctx->taper) ? 3 : 2)));
+      const int per_cu = pl.pk ? 2 : (pl.f32 ? 4 : (ct <= 8 ? 4 : ((ct <= 16 || !ctx->taper) ? 3 : 2)));
       const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * per_cu;
       const int lo = (int)std::min<int64_t>((1024 + base - 1) / base, nchunks);
       const int hi = (int)std::min<int64_t>(std::min<int64_t>(4 * (int64_t)lo, 64), nchunks);
@@ -400,6 +400,7 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
 static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, const double* pc_dircos,
                          const double* fwhm_deg) {
   if (nsrc < 0) return fail(ctx, PRISIM_EINVAL, "nsrc must be non-negative");
+  if (nsrc > (int64_t)0x7fff0000) return fail(ctx, PRISIM_EINVAL, "nsrc must be below 2^31 (the kernels index sources with 32 bits)");
   if (nsrc > 0 && !dircos) return fail(ctx, PRISIM_EINVAL, "dircos is NULL");
   if (!pc_dircos) return fail(ctx, PRISIM_EINVAL, "pc_dircos is NULL");
   for (int i = 0; i < 3; ++i)
@@ -652,6 +653,13 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     if (v > 0 && v < (1L << 30)) p.flush_src = (int32_t)v;
   }
   p.scale_comp = scale_comp;
+  {
+    // grouped taper recurrence (skyvis_kernels.hip): second-order residual (11.09 (df/f)^2)^2 * 0.565 <= 1e-8 of sum|pbflux|
+    const double fmin = std::min(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
+    p.taper_group = (ctx->taper && fmin > 0.0 && std::fabs(ctx->df) <= 3.4e-3 * fmin) ? 1 : 0;
+    if (const char* env = getenv("PRISIM_HIP_TAPER_GROUP")) p.taper_group = (atoi(env) != 0 && ctx->taper) ? 1 : 0;   // A/B hook
+    ctx->timing.last_taper_group = (pl.pk && p.taper_group) ? 1 : 0;
+  }
   if (pl.kernel == PRISIM_KERNEL_DIRECT) {
     p.out = dst;
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
@@ -703,6 +711,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   }
   const Plan pl = make_plan(ctx, precision, kernel);
   ctx->timing.last_lift_groups = 0;
+  ctx->timing.last_taper_group = 0;
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE) {
     const size_t pbytes = (size_t)pl.ntiles * pl.nsrc_pad * pl.ct * (pl.f32 ? 4 : 8);
     if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;

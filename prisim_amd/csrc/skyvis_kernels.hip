@@ -245,7 +245,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
             if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
             *o = v;
           }
-          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the register footprint of the flush small
+          __builtin_amdgcn_sched_barrier(0);                       // one store at a time: the flush must fit beside 128 accumulators
         }
         wave_lds_sync();
       }
@@ -420,6 +420,11 @@ void k_skyvis_rec(const SkyvisParams p) {
 // it is only used where |alpha| <= pi/4 is GUARANTEED for every source (the host sets lift_flags[bg] when
 // max|b| * max_s|s - s_pc| * |df| / c <= 1/8 cycle for the baseline group), all other groups take the 4-instruction rotation.
 // ------------------------------------------------------------------------------------------
+// waves per SIMD the packed kernels are built for: at 3 (168 VGPRs) the compiler spills around the flush (and, with the taper,
+// inside the source loop); 2 waves measured 1-1.5 % faster on the same box and leave no scratch use at all
+#ifndef PK_WAVES
+#define PK_WAVES 2
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -427,11 +432,15 @@ __device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __bui
 typedef const __attribute__((address_space(4))) float* cfloat_p;
 typedef const __attribute__((address_space(4))) double* cdouble_p;
 
-template <int CT, bool TAPER, bool LIFT>
+template <int CT, bool TAPER, bool LIFT, bool TGROUP = false>
 __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, unsigned char* flush_lds) {
   static_assert(!(TAPER && LIFT), "the taper-folded recurrence is a scaled rotation: no lifting form");
+  static_assert(TAPER || !TGROUP, "TGROUP is a taper variant");
   constexpr int HC = CT / 2;
-  constexpr int NH = CT / 2;                         // floats per half row
+  // pieces per row: halves (2 x 32 SGPRs at CT = 64) without the taper; quarters with it, whose extra wave-uniform state would
+  // otherwise push the row buffers out of the ~100 SGPRs (48 v_readlane/v_writelane per source in the loop)
+  constexpr int NPART = (TAPER && CT >= 64) ? 4 : 2;
+  constexpr int NP = CT / NPART;                     // floats per piece
 
   const int xcd = blockIdx.x & 7;
   const int jblk = blockIdx.x >> 3;
@@ -460,6 +469,10 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
     bl2_c2 = (bx * bx + by * by + bz * bz) * (p.inv_c * p.inv_c);
     bpc = (bx * p.pc_x + by * p.pc_y + bz * p.pc_z) * p.inv_c;
   }
+  // log2 w = A + B j + C j^2 per (source, baseline): A = gq kA, B = gq kB, C = gq kC with gq = kappa (|b|^2/c^2 - tau^2)
+  const double kA = -1.4426950408889634 * fc_hz * fc_hz;
+  const float kBf = (float)(-2.0 * 1.4426950408889634 * fc_hz * p.df);
+  const float kCf = (float)(-1.4426950408889634 * p.df * p.df);
 
   f32x2 acc_re[HC], acc_im[HC];
 #pragma unroll
@@ -503,7 +516,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
             if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
             *o = v;
           }
-          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the register footprint of the flush small
+          __builtin_amdgcn_sched_barrier(0);                       // one store at a time: the flush must fit beside 128 accumulators
         }
         wave_lds_sync();
       }
@@ -523,12 +536,13 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   do {
   const int seg1 = (n_loc - seg0 > seg_len) ? seg0 + seg_len : n_loc;
   if (wave_active && seg1 > seg0) {
-    float ra[NH], rb[NH];
+    // the row is fetched in NPART pieces through two SGPR buffers (piece k in buffer k & 1), one piece ahead of its use
+    float ra[NP], rb[NP];
     double sv[4] = {0.0, 0.0, 0.0, 0.0};
     {
       const cfloat_p r0 = gps + (size_t)seg0 * CT;
 #pragma unroll
-      for (int i = 0; i < NH; ++i) ra[i] = r0[i];
+      for (int i = 0; i < NP; ++i) ra[i] = r0[i];
       const cdouble_p d0 = gds + (size_t)seg0 * 4;
       sv[0] = d0[0]; sv[1] = d0[1]; sv[2] = d0[2];
       if (TAPER) sv[3] = d0[3];
@@ -536,11 +550,11 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
     for (int s = seg0; s < seg1; ++s) {
       const cfloat_p row = gps + (size_t)s * CT;
       const int sn = (s + 1 < seg1) ? s + 1 : s;                    // the last source is simply fetched again
-      // the first use of sv waits for everything in flight (first half row + direction); only then ask for the second half
+      // the first use of sv waits for everything in flight (first piece + direction); only then ask for the second piece
       const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < NH; ++i) rb[i] = row[NH + i];
+      for (int i = 0; i < NP; ++i) rb[i] = row[NP + i];
       __builtin_amdgcn_sched_barrier(0);
       float zc, zs;
       sincos_cycles_hw(d * fc_hz, zc, zs);
@@ -568,34 +582,53 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       const f32x2 RI = {-ri, ri};                      // re' = re*rr + im*RI ;  im' = im*rr - re*RI
       // Source-shape taper folded into the recurrence.  log2 w at channel HC+j is L(j) = A + B j + C j^2 with
       //   A = -G fc^2, B = -2 G fc df, C = -G df^2, G = kappa_s (|b|^2/c^2 - tau^2) log2(e)     (interferometry.py:6265-6283)
-      // so zeta_j = w_j z_j advances by the complex factor rho_j = r * exp2(L(j+1)-L(j)) (up) / conj(r) * exp2(L(-2-j)-L(-1-j))
-      // (down), and rho_{j+1} = rho_j * exp2(2C): 2 more packed instructions per pair of terms instead of two v_exp_f32.
-      // rho is re-formed exactly every RESEED steps so that its rounding error cannot random-walk into zeta's phase.
+      // so zeta_j = w_j z_j advances by the complex factor rho_j = r * exp2(L(j+1)-L(j)) (up) / conj(r) * exp2(L(-2-j)-L(-1-j)) (down).
+      //  * exact form (TGROUP = false): rho_{j+1} = rho_j * exp2(2C), 2 more packed instructions per pair of terms instead of two
+      //    v_exp_f32; rho is re-formed exactly every RESEED steps so that its rounding error cannot random-walk into zeta's phase.
+      //  * grouped form (TGROUP): within a group of 8 steps rho is held at the group's geometric-mean ratio
+      //    rho_g = r * exp2(B + C (16 g + 8)) (up), conj(r) * exp2(-B + C (16 g + 10)) (down), which is exact at the group ends and
+      //    low by exp2(C m (8 - m)) at step m inside; that known parabola is put back on the (wave-uniform) pbflux operand,
+      //    p_eff = p + p * (-ln2 C m (8 - m)): 1 packed FMA on 7 of 8 steps instead of 2 on every step, and rho_g moves to the next
+      //    group with 2 (exact re-formation every 16 steps).  Residual: (ln2 C m(8-m))^2 / 2 relative to the term; the host only
+      //    selects this form when that is < 1e-8 of sum|pbflux| for every possible source (df / f_min <= 3.4e-3).
       f32x2 rho_re = RR, rho_im = {ri, -ri}, HM = {0.f, 0.f};
+      f32x2 EK[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
       float tB = 0.f, tC = 0.f;
       if (TAPER) {
         const double tau = d + bpc;
         double gq = sv[3] * (bl2_c2 - tau * tau);
         gq = gq > 0.0 ? gq : 0.0;                       // |b|^2 >= (b.s)^2 up to rounding
-        const double G = gq * 1.4426950408889634;
-        const float tA = (float)(-G * fc_hz * fc_hz);
-        tB = (float)(-2.0 * G * fc_hz * p.df);
-        tC = (float)(-G * p.df * p.df);
+        const float tA = (float)(gq * kA);               // |A| can reach tens of octaves: fp64 product; B and C are small
+        const float gqf = (float)gq;
+        tB = gqf * kBf;
+        tC = gqf * kCf;
         const float w_u0 = __builtin_amdgcn_exp2f(tA);                 // channel HC
         const float w_d0 = __builtin_amdgcn_exp2f(tA - tB + tC);       // channel HC-1
         zre = zre * (f32x2){w_u0, w_d0};
         zim = zim * (f32x2){w_u0, w_d0};
-        const float th = 2.0f * tC * 0.6931471805599453f;              // exp2(2C) - 1 = th + th^2/2 + ...
+        const float th = (TGROUP ? 16.0f : 2.0f) * tC * 0.6931471805599453f;   // exp2(2C) - 1 (exp2(16C) - 1) = th + th^2/2 + ...
         const float hm = __builtin_fmaf(0.5f * th, th, th);
         HM = (f32x2){hm, hm};
+        if (TGROUP) {
+          const float c = -0.6931471805599453f * tC;                     // >= 0
+          EK[0] = (f32x2){7.f * c, 7.f * c};
+          EK[1] = (f32x2){12.f * c, 12.f * c};
+          EK[2] = (f32x2){15.f * c, 15.f * c};
+          EK[3] = (f32x2){16.f * c, 16.f * c};
+        }
       }
-      constexpr int RESEED = 8;
+      constexpr int RESEED = TGROUP ? 16 : 8;
 
-      auto pairs = [&](const float (&r)[NH], int jbase) {
+      auto pairs = [&](const float (&r)[NP], int jbase) {
 #pragma unroll
-        for (int jj = 0; jj < NH / 2; ++jj) {
+        for (int jj = 0; jj < NP / 2; ++jj) {
           const int j = jbase + jj;
-          const f32x2 pp = {r[2 * jj], r[2 * jj + 1]};
+          f32x2 pp = {r[2 * jj], r[2 * jj + 1]};
+          if (TGROUP) {
+            constexpr int kmap[8] = {0, 0, 1, 2, 3, 2, 1, 0};          // m (8 - m) = 7, 12, 15, 16, 15, 12, 7 for m = 1..7
+            const int m = j % 8;
+            if (m != 0) pp = pkfma(pp, EK[kmap[m]], pp);
+          }
           acc_re[j] = pkfma(pp, zre, acc_re[j]);
           acc_im[j] = pkfma(pp, zim, acc_im[j]);
           if (LIFT) {
@@ -612,35 +645,53 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
             zre = nre; zim = nim;
           } else {
             if ((j % RESEED) == 0) {
-              const float qu = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(2 * j + 1), tB));     // L(j+1) - L(j)
-              const float qd = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(2 * j + 3), -tB));    // L(-2-j) - L(-1-j)
+              // exact: per-step ratio at step j, or the mean ratio of the group starting at j
+              const float qu = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(TGROUP ? 2 * j + 8 : 2 * j + 1), tB));
+              const float qd = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(TGROUP ? 2 * j + 10 : 2 * j + 3), -tB));
               rho_re = (f32x2){qu * rr, qd * rr};
               rho_im = (f32x2){qu * ri, -(qd * ri)};
+            } else if (TGROUP && (j % 8) == 0) {
+              rho_re = pkfma(rho_re, HM, rho_re);        // next group: mean ratio moves by exp2(16 C)
+              rho_im = pkfma(rho_im, HM, rho_im);
             }
             const f32x2 t0 = zim * rho_im;
             const f32x2 t1 = zre * rho_im;
             const f32x2 nre = pkfma(zre, rho_re, -t0);
             const f32x2 nim = pkfma(zim, rho_re, t1);
             zre = nre; zim = nim;
-            rho_re = pkfma(rho_re, HM, rho_re);
-            rho_im = pkfma(rho_im, HM, rho_im);
+            if (!TGROUP) {
+              rho_re = pkfma(rho_re, HM, rho_re);
+              rho_im = pkfma(rho_im, HM, rho_im);
+            }
           }
         }
       };
       pairs(ra, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the second half row has landed before the next requests go out
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const cfloat_p rn = gps + (size_t)sn * CT;
 #pragma unroll
-        for (int i = 0; i < NH; ++i) ra[i] = rn[i];
-        const cdouble_p dn = gds + (size_t)sn * 4;
-        sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
-        if (TAPER) sv[3] = dn[3];
+      for (int ph = 1; ph < NPART; ++ph) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): piece ph has landed before the next request goes out
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph + 1 < NPART) {
+          // piece ph + 1 of this source into the buffer piece ph - 1 has just left
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            if (ph & 1) ra[i] = row[(ph + 1) * NP + i];
+            else rb[i] = row[(ph + 1) * NP + i];
+          }
+        } else {
+          // first piece + direction of the next source (NPART is even: it goes to ra)
+          const cfloat_p rn = gps + (size_t)sn * CT;
+#pragma unroll
+          for (int i = 0; i < NP; ++i) ra[i] = rn[i];
+          const cdouble_p dn = gds + (size_t)sn * 4;
+          sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
+          if (TAPER) sv[3] = dn[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph & 1) pairs(rb, ph * (NP / 2));
+        else pairs(ra, ph * (NP / 2));
       }
-      __builtin_amdgcn_sched_barrier(0);
-      pairs(rb, NH / 2);
     }
   }
   flush();
@@ -649,7 +700,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
 }
 
 template <int CT, bool TAPER>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void k_skyvis_rec_f32pk(const SkyvisParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>()];
   if constexpr (!TAPER) {
@@ -658,6 +709,11 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
     const int bg = jblk % p.nbgroups;
     if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {
       skyvis_rec_f32pk_body<CT, false, true>(p, flush_lds);
+      return;
+    }
+  } else {
+    if (p.taper_group) {                      // launch-uniform, chosen by the host from df / f_min
+      skyvis_rec_f32pk_body<CT, true, false, true>(p, flush_lds);
       return;
     }
   }

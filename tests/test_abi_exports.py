@@ -42,8 +42,8 @@ def test_struct_layouts_match_header():
     # prisim_beam_ext: 3 double, 4 int32, 3 double, 3 double, 3 double -> 112 bytes
     assert C.sizeof(_abi.PrisimBeamExt) == 112 and _abi.PrisimBeamExt.array_sep1.offset == 40
     assert _abi.PrisimBeamSky.beam_kind.offset == 48 and _abi.PrisimBeamSky.diameter_m.offset == 56
-    # prisim_timing: 3 double, 2 int64, 4 int32 -> 56 bytes
-    assert C.sizeof(_abi.PrisimTiming) == 56
+    # prisim_timing: 3 double, 2 int64, 6 int32 -> 64 bytes
+    assert C.sizeof(_abi.PrisimTiming) == 64
 
 
 def test_null_context_is_rejected_not_crashing():
@@ -68,3 +68,31 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_abi, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_abi.PrisimHipError):
         _abi.load_library()
+
+
+def test_sky_sum_kernels_use_no_scratch(tmp_path):
+    """Build guard: every k_skyvis_rec* kernel must keep its accumulators in registers (no private segment).  A build of the packed
+    taper kernel that spilled inside the source loop (3 waves/SIMD, 168 VGPRs) produced NaNs on partly filled wavefronts; the
+    kernels are built for occupancies at which the compiler does not spill at all, and this test keeps it that way."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'prisim_amd', 'csrc', 'skyvis_kernels.hip')
+    out = tmp_path / 'skyvis_kernels.s'
+    res = subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-I/opt/rocm/include', '-S', '--cuda-device-only', src,
+                          '-o', str(out)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    text = out.read_text()
+    meta = text[text.index('amdhsa.kernels:'):]
+    found = 0
+    for block in meta.split('- .agpr_count:')[1:]:
+        name = re.search(r'\.name:\s+(\S+)', block).group(1)
+        if 'k_skyvis_rec' not in name:
+            continue
+        found += 1
+        assert int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', block).group(1)) == 0, name
+        assert int(re.search(r'\.vgpr_spill_count:\s+(\d+)', block).group(1)) == 0, name
+    assert found >= 14

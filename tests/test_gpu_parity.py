@@ -111,6 +111,48 @@ def test_fp32_periodic_flush_read_modify_write(ctx, monkeypatch, taper):
     ctx.set_tuning(0, 0, 0)
 
 
+def test_fp32_taper_grouped_and_exact_recurrences(ctx, monkeypatch):
+    """The packed fp32 taper kernel has two forms of the amplitude recurrence: exact per step, and grouped (8 steps at the group's
+    mean ratio + the known parabola put back on pbflux), which the host selects only when df/f_min <= 3.4e-3.  Strong taper
+    (degree-scale sources on km baselines: w spans 1 ... 1e-6 across a tile), both forms against the oracle and each other."""
+    rng = NP.random.default_rng(31)
+    nbl, nchan, nsrc = 256, 128, 300
+    bl = rng.uniform(-1200.0, 1200.0, size=(nbl, 3)); bl[:, 2] *= 0.01
+    bl[:8] *= 0.02                                                                     # a few short ones: w ~ 1
+    ch = 120e6 + NP.arange(nchan) * 97656.25
+    alt = NP.degrees(NP.arcsin(rng.uniform(NP.sin(NP.radians(8.0)), 1.0, nsrc)))
+    dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, nsrc)), axis=1))
+    pb = rng.uniform(0.5, 10.0, size=(nsrc, 1)) * rng.uniform(0.5, 1.0, size=(nsrc, nchan))
+    pc = NP.array([0.0, 0.0, 1.0])
+    fw = rng.uniform(0.02, 0.4, nsrc)
+    ref = O.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw)
+    ctx.set_array(bl, ch)
+    ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
+    res = {}
+    for ct in (32, 64):
+        ctx.set_tuning(ct, 0, 1)
+        for form in (0, 1):
+            monkeypatch.setenv('PRISIM_HIP_TAPER_GROUP', str(form))
+            ctx.compute(precision=_abi.PRISIM_FP32, kernel=_abi.PRISIM_KERNEL_RECURRENCE)
+            assert ctx.timing()['last_taper_group'] == form
+            res[(ct, form)] = ctx.get_vis()
+            assert relerr(res[(ct, form)], ref, pb) <= TOL[_abi.PRISIM_FP32], (ct, form)
+        assert relerr(res[(ct, 1)], res[(ct, 0)], pb) <= 1e-6
+    monkeypatch.delenv('PRISIM_HIP_TAPER_GROUP')
+    ctx.compute(precision=_abi.PRISIM_FP32, kernel=_abi.PRISIM_KERNEL_RECURRENCE)
+    assert ctx.timing()['last_taper_group'] == 1                                       # df/f_min = 8.1e-4: grouped form by default
+    # coarse channels (df/f_min = 1.3e-2): the host must fall back to the exact form
+    ch2 = 30e6 + NP.arange(nchan) * 390625.0
+    ref2 = O.skyvis(bl[:64], ch2, dc, pb, pc, fwhm_deg=fw)
+    ctx.set_array(bl[:64], ch2)
+    ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
+    ctx.set_tuning(64, 0, 1)
+    ctx.compute(precision=_abi.PRISIM_FP32, kernel=_abi.PRISIM_KERNEL_RECURRENCE)
+    assert ctx.timing()['last_taper_group'] == 0
+    assert relerr(ctx.get_vis(), ref2, pb) <= TOL[_abi.PRISIM_FP32]
+    ctx.set_tuning(0, 0, 0)
+
+
 def test_config2_fp64_full(ctx):
     """BASELINE config 2: HERA-19 x 256 ch x nside-16 diffuse sky, Airy beam, taper ON, fp64 -- full size."""
     cfg = W.config2()
