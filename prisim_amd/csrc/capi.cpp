@@ -259,7 +259,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
       // slots = CUs x resident blocks per CU, and e.g. 1152 blocks on 512 slots = 2.25 rounds waste a quarter of the
       // third round, while 1536 = 3.0 rounds waste nothing.
       // resident blocks per CU = waves per SIMD the kernels are built for (WavesPerEU in skyvis_kernels.hip)
-      const int per_cu = pl.pk ? 2 : (pl.f32 ? 4 : (ct <= 8 ? 4 : ((ct <= 16 || !ctx->taper) ? 3 : 2)));
+      const int per_cu = pl.pk ? 2 : (pl.f32 ? 4 : (ct <= 8 ? 4 : (ct <= 16 ? 3 : 2)));
       const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * per_cu;
       const int lo = (int)std::min<int64_t>((1024 + base - 1) / base, nchunks);
       const int hi = (int)std::min<int64_t>(std::min<int64_t>(4 * (int64_t)lo, 64), nchunks);

@@ -135,7 +135,7 @@ __device__ __forceinline__ void unpack16(const double2 v, double* d) { d[0] = v.
 // up to 256 VGPRs on scheduling freedom and drops to 1-2 waves/SIMD, too few to keep the
 // 2-cycle fp32 VALU issue slots filled -- see tools/microbench_valu.hip results).
 template <typename T, int CT, bool TAPER> struct WavesPerEU {
-  static constexpr int value = (sizeof(T) == 4) ? (CT <= 32 ? 4 : 2) : (CT <= 8 ? 4 : (CT <= 16 || !TAPER ? 3 : 2));
+  static constexpr int value = (sizeof(T) == 4) ? (CT <= 32 ? 4 : 2) : (CT <= 8 ? 4 : (CT <= 16 ? 3 : 2));
 };
 
 // Wave-local ordering point between LDS writes and LDS reads of other lanes of the same wave (DS operations of one wave
@@ -155,6 +155,17 @@ template <> struct FlushCfg<float> { static constexpr int ch = 16; using vec = f
 template <> struct FlushCfg<double> { static constexpr int ch = 8; using vec = double2; };    // 64 x 9 x 16 B = 9 KiB per wave
 template <typename T> constexpr int flush_lds_bytes() { return (kBlockThreads / 64) * 64 * (FlushCfg<T>::ch + 1) * (int)sizeof(typename FlushCfg<T>::vec); }
 
+// L2 warm-up for the scalar row stream.  A scalar load is requested one piece (~300 cycles) ahead of its use, which covers the
+// scalar cache and L2 but not HBM: when a tile's pbflux slab (nsrc x 256 B) outgrows the 4 MiB L2 (config 5: 100 MB) every row
+// would stall the wave.  So every 4th source each wave also touches 1 KiB of rows (4 rows of 256 B) and 8 directions
+// kPrefetchAhead sources ahead with LDS-DMA loads (no VGPR, never waited for) that land in a dummy area of LDS behind the flush buffer.
+constexpr int kPrefetchAhead = 12;
+constexpr int kPrefetchWaveBytes = 1024;
+constexpr int kPrefetchLdsBytes = (kBlockThreads / 64) * kPrefetchWaveBytes;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+
 // LIFT: lifting (three-shear) form of the step rotation, see skyvis_rec_f32pk_body below; chosen per baseline group by the host.
 template <typename T, int CT, bool TAPER, bool LIFT>
 __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned char* flush_lds) {
@@ -163,7 +174,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   constexpr int HC = CT / 2;                       // channels per chain
   constexpr int NH = CT / 2;                       // elements per half row
   typedef const __attribute__((address_space(4))) T* crow_p;
-  typedef const __attribute__((address_space(4))) double* cdir_p;
+  typedef const volatile __attribute__((address_space(4))) double* cdir_p;    // volatile: see the packed kernel (keeps the load where it is written)
   typedef const __attribute__((address_space(4))) float* cfsq_p;
 
   // ---- XCD-aware block -> (slab, baseline group) map ------------------------------------
@@ -261,6 +272,11 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   const int seg_len = (sizeof(T) == 4 && p.flush_src > 0) ? p.flush_src : 0x7fffffff;
   const crow_p gps = gp + (size_t)s_begin * CT;
   const cdir_p gds = gd + (size_t)s_begin * 4;
+  const float* const pf_rows = reinterpret_cast<const float*>(reinterpret_cast<const T*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT +
+                                                              (size_t)s_begin * CT);
+  const float* const pf_dirs = reinterpret_cast<const float*>(p.dirs_prep) + (size_t)s_begin * 8;
+  const lptr_t pf_lds = (lptr_t)(flush_lds + flush_lds_bytes<T>() + (tid >> 6) * kPrefetchWaveBytes);
+  const bool pf_on = n_loc >= 64;                    // 1 KiB = 4 ... 32 rows per request, clamped 32 rows before the end
   int seg0 = 0;
   do {
   const int seg1 = (n_loc - seg0 > seg_len) ? seg0 + seg_len : n_loc;
@@ -278,6 +294,13 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
     for (int s = seg0; s < seg1; ++s) {
       const crow_p row = gps + (size_t)s * CT;
       const int sn = (s + 1 < seg1) ? s + 1 : s;                    // the last source is simply fetched again
+      if (pf_on && ((s - seg0) & 3) == 0) {
+        // L2 warm-up, every 4th source: 1 KiB of rows and 8 directions kPrefetchAhead sources ahead (see k_skyvis_rec_f32pk)
+        constexpr int kRowDwords = CT * (int)sizeof(T) / 4;          // <= 64
+        const int spf = (s + kPrefetchAhead < n_loc - 32) ? s + kPrefetchAhead : n_loc - 32;
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * kRowDwords + lane * 4), pf_lds, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_dirs + (size_t)spf * 8 + lane), pf_lds, 4, 0, 0);
+      }
       // the first use of sv waits for everything in flight (first half row + direction); only then ask for the second half
       const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));   // seconds
       __builtin_amdgcn_sched_barrier(0);
@@ -383,7 +406,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
 template <typename T, int CT, bool TAPER>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(WavesPerEU<T, CT, TAPER>::value)))
 void k_skyvis_rec(const SkyvisParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<T>()];
+  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<T>() + kPrefetchLdsBytes];
   if constexpr (!TAPER) {
     const int bg = (blockIdx.x >> 3) % p.nbgroups;
     if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {      // block-uniform; the two bodies share no live state
@@ -431,6 +454,7 @@ __device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __bui
 
 typedef const __attribute__((address_space(4))) float* cfloat_p;
 typedef const __attribute__((address_space(4))) double* cdouble_p;
+typedef const volatile __attribute__((address_space(4))) double* cvdouble_p;
 
 template <int CT, bool TAPER, bool LIFT, bool TGROUP = false>
 __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, unsigned char* flush_lds) {
@@ -532,6 +556,10 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   const int seg_len = p.flush_src > 0 ? p.flush_src : 0x7fffffff;
   const cfloat_p gps = gp + (size_t)s_begin * CT;
   const cdouble_p gds = gd + (size_t)s_begin * 4;
+  const float* const pf_rows = reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT + (size_t)s_begin * CT;
+  const float* const pf_dirs = reinterpret_cast<const float*>(p.dirs_prep) + (size_t)s_begin * 8;
+  const lptr_t pf_lds = (lptr_t)(flush_lds + flush_lds_bytes<float>() + (tid >> 6) * kPrefetchWaveBytes);
+  const bool pf_on = n_loc >= 64;                    // 4 (CT = 64) or 8 rows per request, clamped 8 rows before the end
   int seg0 = 0;
   do {
   const int seg1 = (n_loc - seg0 > seg_len) ? seg0 + seg_len : n_loc;
@@ -543,13 +571,21 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       const cfloat_p r0 = gps + (size_t)seg0 * CT;
 #pragma unroll
       for (int i = 0; i < NP; ++i) ra[i] = r0[i];
-      const cdouble_p d0 = gds + (size_t)seg0 * 4;
+      // volatile: keeps instcombine from folding phi(load before the loop, load in the loop) into one load of a phi'd address at
+      // the loop TOP -- right before the seed that needs it, where every source would wait out a scalar-cache round trip
+      const cvdouble_p d0 = gds + (size_t)seg0 * 4;
       sv[0] = d0[0]; sv[1] = d0[1]; sv[2] = d0[2];
       if (TAPER) sv[3] = d0[3];
     }
     for (int s = seg0; s < seg1; ++s) {
       const cfloat_p row = gps + (size_t)s * CT;
       const int sn = (s + 1 < seg1) ? s + 1 : s;                    // the last source is simply fetched again
+      if (pf_on && ((s - seg0) & 3) == 0) {
+        // every 4th source: the next 4 rows (64 lanes x 16 B) and 8 directions (64 lanes x 4 B), kPrefetchAhead sources ahead
+        const int spf = (s + kPrefetchAhead < n_loc - 8) ? s + kPrefetchAhead : n_loc - 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * CT + lane * 4), pf_lds, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_dirs + (size_t)spf * 8 + lane), pf_lds, 4, 0, 0);
+      }
       // the first use of sv waits for everything in flight (first piece + direction); only then ask for the second piece
       const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));
       __builtin_amdgcn_sched_barrier(0);
@@ -684,7 +720,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           const cfloat_p rn = gps + (size_t)sn * CT;
 #pragma unroll
           for (int i = 0; i < NP; ++i) ra[i] = rn[i];
-          const cdouble_p dn = gds + (size_t)sn * 4;
+          const cvdouble_p dn = gds + (size_t)sn * 4;
           sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
           if (TAPER) sv[3] = dn[3];
         }
@@ -702,7 +738,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
 template <int CT, bool TAPER>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void k_skyvis_rec_f32pk(const SkyvisParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>()];
+  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>() + kPrefetchLdsBytes];
   if constexpr (!TAPER) {
     // block-uniform choice made by the host per baseline group; the two bodies share no live state
     const int jblk = blockIdx.x >> 3;
