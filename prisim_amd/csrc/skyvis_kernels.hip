@@ -298,8 +298,10 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
         // L2 warm-up, every 4th source: 1 KiB of rows and 8 directions kPrefetchAhead sources ahead (see k_skyvis_rec_f32pk)
         constexpr int kRowDwords = CT * (int)sizeof(T) / 4;          // <= 64
         const int spf = (s + kPrefetchAhead < n_loc - 32) ? s + kPrefetchAhead : n_loc - 32;
-        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * kRowDwords + lane * 4), pf_lds, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(pf_dirs + (size_t)spf * 8 + lane), pf_lds, 4, 0, 0);
+        int lane_pf = lane;
+        asm volatile("" : "+v"(lane_pf));                            // formed here from the lane id: no per-lane pointers kept live across the loop
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * kRowDwords + lane_pf * 4), pf_lds, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_dirs + (size_t)spf * 8 + lane_pf), pf_lds, 4, 0, 0);
       }
       // the first use of sv waits for everything in flight (first half row + direction); only then ask for the second half
       const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));   // seconds
@@ -583,8 +585,10 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       if (pf_on && ((s - seg0) & 3) == 0) {
         // every 4th source: the next 4 rows (64 lanes x 16 B) and 8 directions (64 lanes x 4 B), kPrefetchAhead sources ahead
         const int spf = (s + kPrefetchAhead < n_loc - 8) ? s + kPrefetchAhead : n_loc - 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * CT + lane * 4), pf_lds, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(pf_dirs + (size_t)spf * 8 + lane), pf_lds, 4, 0, 0);
+        int lane_pf = lane;
+        asm volatile("" : "+v"(lane_pf));                            // formed here from the lane id: no per-lane pointers kept live across the loop
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * CT + lane_pf * 4), pf_lds, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_dirs + (size_t)spf * 8 + lane_pf), pf_lds, 4, 0, 0);
       }
       // the first use of sv waits for everything in flight (first piece + direction); only then ask for the second piece
       const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));
