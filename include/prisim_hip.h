@@ -130,6 +130,16 @@ typedef struct prisim_beam_ext {
   double array_pc_dircos[3];         /* array pointing centre (zenith = {0,0,1}) */
   double ground_height;      /* ground-plane height in metres (:950-966); <= 0 = no ground plane */
   double ground_scale, ground_max;
+  /* Phased-array beamformer over isotropic elements (array_field_pattern, primary_beams.py:1482-1754, called from
+   * primary_beam_generator :288-317 and :385-416 when pointing_info is given).  bf_nelem = 0: none.  Otherwise
+   *   F[s,f,r] = 1/N sum_i g[i][r] exp(2 pi i f (-pos_i . s / c + delay[i][r])),  power *= mean_r |F[s,f,r]|^2   (:317, :416)
+   * and the analytic array_* factor above must be off.  Delays are the beamformer's compensation delays (seconds) including any
+   * jitter realisations, gains likewise: the host draws them (the reference uses numpy's global RNG, :1655, :1665). */
+  int32_t bf_nelem;          /* 0 ... 4096 */
+  int32_t bf_nrand;          /* realisations, 1 ... 256 */
+  const double* bf_pos;      /* host [bf_nelem][3] ENU metres */
+  const double* bf_delays;   /* host [bf_nelem][bf_nrand] seconds */
+  const double* bf_gains;    /* host [bf_nelem][bf_nrand] */
 } prisim_beam_ext;
 
 typedef struct prisim_beam_sky {

@@ -145,11 +145,73 @@ def ground_plane_field_pattern(height, dircos, wavelength, modifier=None):
     return gp / (2 * NP.sin(k * height))                                                    # :965-966
 
 
+def beamformer_settings(antpos, pointing_info):
+    """Element delays [nelem, nrand] (seconds) and gains [nelem, nrand] of the phased-array beamformer from a reference
+    ``pointing_info`` dictionary (primary_beams.py:1595-1668): explicit 'delays', or delay compensation towards
+    'pointing_center' (dircos; :1632), optional 'gains', and Gaussian jitter 'delayerr' (seconds) / 'gainerr' (dB) drawn from
+    numpy's GLOBAL generator in the reference's order (delays first, then gains; :1655, :1665) -- seed it to reproduce a draw."""
+    antpos = NP.asarray(antpos, dtype=NP.float64)
+    nel = antpos.shape[0]
+    if pointing_info is None:
+        return NP.zeros((nel, 1)), NP.ones((nel, 1))
+    nrand = pointing_info.get('nrand', 1) or 1
+    if pointing_info.get('delays', None) is not None:
+        delays = NP.asarray(pointing_info['delays'], dtype=NP.float64).ravel()
+    elif 'pointing_center' in pointing_info and 'delays' not in pointing_info:
+        pc = NP.asarray(pointing_info['pointing_center'], dtype=NP.float64).reshape(1, -1)
+        delays = (NP.dot(antpos, pc.T) / C_LIGHT).ravel()                                # :1632
+    else:
+        delays = NP.zeros(nel)
+    gains = pointing_info.get('gains', None)
+    gains = NP.ones(nel) if gains is None else NP.asarray(gains, dtype=NP.float64).ravel()
+    if pointing_info.get('delayerr', None) is not None:
+        delays = delays.reshape(nel, 1) + pointing_info['delayerr'] * NP.random.standard_normal((nel, nrand))      # :1655
+    if pointing_info.get('gainerr', None) is not None:
+        gains = gains.reshape(nel, 1) * 10 ** (pointing_info['gainerr'] / 10.0 * NP.random.standard_normal((nel, nrand)))   # :1664-1665
+    return NP.broadcast_to(delays.reshape(nel, -1), (nel, nrand)).copy(), NP.broadcast_to(gains.reshape(nel, -1), (nel, nrand)).copy()
+
+
+def array_field_pattern(antpos, dircos, wavelength, delays=None, gains=None, power=False, single=True):
+    """Field of an array of isotropic radiators with beamformer delays and gains (primary_beams.py:1670-1754):
+    F[s, f, r] = (1/N) sum_i g[i, r] exp(2 pi i c / lambda_f (-antpos_i . s / c + delay[i, r])).
+    single=True reproduces the reference's float32 / complex64 arithmetic statement by statement (:1670-1671, :1726, :1733-1746),
+    which is what tests/golden/golden_beamformer.npz pins; single=False is the same sum in float64 (what the device evaluates)."""
+    antpos = NP.asarray(antpos, dtype=NP.float64)
+    nel = antpos.shape[0]
+    delays = NP.zeros((nel, 1)) if delays is None else NP.asarray(delays, dtype=NP.float64).reshape(nel, -1)
+    gains = NP.ones((nel, 1)) if gains is None else NP.asarray(gains, dtype=NP.float64).reshape(nel, -1)
+    nrand = max(delays.shape[1], gains.shape[1])
+    delays = NP.broadcast_to(delays, (nel, nrand))
+    gains = NP.broadcast_to(gains, (nel, nrand))
+    dircos = NP.asarray(dircos, dtype=NP.float64).reshape(-1, 3)
+    wl = NP.asarray(wavelength, dtype=NP.float64).ravel()
+    if not single:
+        geo = -NP.dot(antpos, dircos.T) / C_LIGHT                                          # [nel, nsrc]
+        ph = (geo[:, :, None, None] + delays[:, None, None, :]) * (C_LIGHT / wl)[None, None, :, None]
+        field = NP.sum(gains[:, None, None, :] * NP.exp(2j * NP.pi * ph), axis=0) / nel
+    else:
+        g32 = gains.astype(NP.float32)                                                     # :1670
+        d32 = delays.astype(NP.float32)                                                    # :1671
+        sky32 = dircos.astype(NP.float32)                                                  # :1713
+        wl32 = wl.astype(NP.float32)                                                       # :1726
+        geo = -NP.dot(antpos, sky32.T) / C_LIGHT                                           # :1728
+        geo = geo[:, :, NP.newaxis, NP.newaxis].astype(NP.float32)                         # :1729
+        gc = g32.reshape(nel, 1, 1, nrand).astype(NP.complex64)                            # :1731
+        dd = d32.reshape(nel, 1, 1, nrand)                                                 # :1732
+        wlr = wl32.reshape(1, 1, -1, 1)                                                    # :1733
+        ret = (geo + dd).astype(NP.complex64)                                              # :1735-1736
+        ret = NP.exp(1j * 2 * NP.pi * C_LIGHT / wlr * ret).astype(NP.complex64)            # :1740
+        ret *= gc / nel                                                                    # :1741
+        field = NP.sum(ret.astype(NP.complex64), axis=0)                                   # :1742
+    return NP.abs(field) ** 2 if power else field
+
+
 def composite_power_beam(dircos, frequency_hz, element='delta', size=0.0, element_dircos=(0.0, 0.0, 1.0), dipole_mode='general',
-                         array=None, ground=None):
+                         array=None, ground=None, beamformer=None):
     """power = |element_field x array_factor|^2 x ground_field^2 (primary_beams.py:317, 349, 416, 439).
     element: 'delta' | 'gaussian' | 'dish' | 'dipole'.  array: dict(nax1, nax2, sep1, sep2, east2ax1, pointing_dircos).
-    ground: dict(height, modifier)."""
+    ground: dict(height, modifier).  beamformer: dict(positions [n,3], delays [n,nrand], gains [n,nrand], single) -- then the
+    power is the mean over realisations of |element field x beamformed field|^2 (:317, :416)."""
     dircos = NP.asarray(dircos, dtype=NP.float64).reshape(-1, 3)
     f = NP.asarray(frequency_hz, dtype=NP.float64).ravel()
     wl = C_LIGHT / f
@@ -170,7 +232,12 @@ def composite_power_beam(dircos, frequency_hz, element='delta', size=0.0, elemen
         af = isotropic_radiators_array_field_pattern(array['nax1'], array['nax2'], array['sep1'], array['sep2'], dircos, wl,
                                                      east2ax1=array.get('east2ax1', 0.0),
                                                      pointing_dircos=array.get('pointing_dircos', (0.0, 0.0, 1.0)))
-    pb = NP.abs(ep * af) ** 2
+    if beamformer is not None:
+        irap = array_field_pattern(beamformer['positions'], dircos, wl, delays=beamformer.get('delays'), gains=beamformer.get('gains'),
+                                   power=False, single=beamformer.get('single', False))
+        pb = NP.mean(NP.abs(NP.asarray(ep)[:, :, None] * irap) ** 2, axis=2) if NP.ndim(ep) == 2 else NP.mean(NP.abs(ep * irap) ** 2, axis=2)
+    else:
+        pb = NP.abs(ep * af) ** 2
     if ground is not None:
         pb = pb * ground_plane_field_pattern(ground['height'], dircos, wl, modifier=ground.get('modifier', None)) ** 2
     return pb

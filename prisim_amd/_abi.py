@@ -39,12 +39,14 @@ class PrisimBeamExt(C.Structure):
     _fields_ = [('dipole_dircos', C.c_double * 3), ('dipole_mode', C.c_int32), ('array_nax1', C.c_int32),
                 ('array_nax2', C.c_int32), ('ground_modify', C.c_int32), ('array_sep1', C.c_double), ('array_sep2', C.c_double),
                 ('array_east2ax1_deg', C.c_double), ('array_pc_dircos', C.c_double * 3), ('ground_height', C.c_double),
-                ('ground_scale', C.c_double), ('ground_max', C.c_double)]
+                ('ground_scale', C.c_double), ('ground_max', C.c_double), ('bf_nelem', C.c_int32), ('bf_nrand', C.c_int32),
+                ('bf_pos', C.c_void_p), ('bf_delays', C.c_void_p), ('bf_gains', C.c_void_p)]
 
 
 def make_beam_ext(ext):
     """dict -> PrisimBeamExt.  Keys: dipole_dircos, dipole_mode, array (dict nax1, nax2, sep1, sep2, east2ax1, pointing_dircos),
-    ground (dict height, modifier{scale,max})."""
+    ground (dict height, modifier{scale,max}), beamformer (dict positions [n,3], delays [n] or [n,nrand], gains likewise).
+    The returned struct keeps the beamformer arrays alive (attribute _keep)."""
     if ext is None:
         return None
     x = PrisimBeamExt()
@@ -74,6 +76,20 @@ def make_beam_ext(ext):
             if 'max' in mod:
                 x.ground_modify |= 4
                 x.ground_max = float(mod['max'])
+    bf = ext.get('beamformer', None)
+    if bf is not None:
+        pos = NP.ascontiguousarray(bf['positions'], dtype=NP.float64)
+        if pos.ndim != 2 or pos.shape[1] != 3:
+            raise ValueError('beamformer positions must have shape (nelem, 3)')
+        nel = pos.shape[0]
+        delays = NP.asarray(bf.get('delays', NP.zeros(nel)), dtype=NP.float64).reshape(nel, -1)
+        gains = NP.asarray(bf.get('gains', NP.ones(nel)), dtype=NP.float64).reshape(nel, -1)
+        nrand = max(delays.shape[1], gains.shape[1])
+        delays = NP.ascontiguousarray(NP.broadcast_to(delays, (nel, nrand)))
+        gains = NP.ascontiguousarray(NP.broadcast_to(gains, (nel, nrand)))
+        x.bf_nelem, x.bf_nrand = nel, nrand
+        x.bf_pos, x.bf_delays, x.bf_gains = pos.ctypes.data, delays.ctypes.data, gains.ctypes.data
+        x._keep = (pos, delays, gains)
     return x
 
 

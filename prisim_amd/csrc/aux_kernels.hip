@@ -85,6 +85,27 @@ void k_beam_flux(const BeamParams p) {
       af = t1 * t2;
     }
     double pb = (ep * af) * (ep * af);                                                    // :317 / :349 / :416
+    if (p.bf_nelem > 0) {
+      // phased-array beamformer (:1728-1746): field of the elements with compensation delays and gains, power averaged over the
+      // jitter realisations (:317, :416).  fp64 here; the reference forms the same sum in float32 / complex64.
+      double acc = 0.0;
+      for (int r = 0; r < p.bf_nrand; ++r) {
+        double fr = 0.0, fi = 0.0;
+        for (int e = 0; e < p.bf_nelem; ++e) {
+          const double geo = -(p.bf_pos[3 * e] * d.x + p.bf_pos[3 * e + 1] * d.y + p.bf_pos[3 * e + 2] * d.z) / kC;
+          double ph = f * (geo + p.bf_delays[(size_t)e * p.bf_nrand + r]);               // cycles
+          ph -= rint(ph);
+          double sn, cs;
+          sincospi(2.0 * ph, &sn, &cs);
+          const double g = p.bf_gains[(size_t)e * p.bf_nrand + r];
+          fr = fma(g, cs, fr);
+          fi = fma(g, sn, fi);
+        }
+        acc += fr * fr + fi * fi;
+      }
+      const double n2 = (double)p.bf_nelem * (double)p.bf_nelem;
+      pb = ep * ep * acc / (n2 * (double)p.bf_nrand);
+    }
     if (p.gp_height > 0.0) {                                                              // ground plane (:950-966)
       const double kk = 2.0 * kPi * f / kC;
       const double nz = d.z < -1.0 ? -1.0 : (d.z > 1.0 ? 1.0 : d.z);                      // sin(alt) = n

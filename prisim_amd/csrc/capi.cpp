@@ -495,6 +495,17 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
       return fail(ctx, PRISIM_EINVAL, "array element separations must be positive");
     if (!std::isfinite(x->ground_height) || !std::isfinite(x->array_east2ax1_deg))
       return fail(ctx, PRISIM_EINVAL, "non-finite beam extension parameter");
+    if (x->bf_nelem < 0 || x->bf_nelem > 4096) return fail(ctx, PRISIM_EINVAL, "bf_nelem must be in 0 ... 4096");
+    if (x->bf_nelem > 0) {
+      if (x->bf_nrand < 1 || x->bf_nrand > 256) return fail(ctx, PRISIM_EINVAL, "bf_nrand must be in 1 ... 256");
+      if (!x->bf_pos || !x->bf_delays || !x->bf_gains) return fail(ctx, PRISIM_EINVAL, "beamformer positions / delays / gains is NULL");
+      if (x->array_nax1 > 0) return fail(ctx, PRISIM_EINVAL, "the beamformer replaces the analytic array factor: set array_nax1 = array_nax2 = 0");
+      for (int64_t i = 0; i < (int64_t)x->bf_nelem * 3; ++i)
+        if (!std::isfinite(x->bf_pos[i])) return fail(ctx, PRISIM_EINVAL, "non-finite beamformer element position");
+      for (int64_t i = 0; i < (int64_t)x->bf_nelem * x->bf_nrand; ++i)
+        if (!std::isfinite(x->bf_delays[i]) || !std::isfinite(x->bf_gains[i]))
+          return fail(ctx, PRISIM_EINVAL, "non-finite beamformer delay / gain");
+    }
   }
   const bool have_spec = sky->flux_spectrum != nullptr;
   if (sky->nsrc > 0 && !have_spec && (!sky->flux_ref || !sky->spindex))
@@ -511,13 +522,22 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
   const int64_t n = ns * ctx->nchan;
   if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (ns > 0) {
-    DevBuf fr, sp;
+    DevBuf fr, sp, bf;
     const size_t frb = have_spec ? (size_t)n * sizeof(double) : (size_t)ns * sizeof(double);
-    if ((rc = ensure(ctx, fr, frb)) || (rc = ensure(ctx, sp, (size_t)ns * sizeof(double)))) {
-      release(fr); release(sp);
+    const int bf_n = sky->ext ? sky->ext->bf_nelem : 0, bf_r = bf_n > 0 ? sky->ext->bf_nrand : 0;
+    const size_t bf_doubles = (size_t)bf_n * 3 + 2 * (size_t)bf_n * bf_r;
+    if ((rc = ensure(ctx, fr, frb)) || (rc = ensure(ctx, sp, (size_t)ns * sizeof(double))) ||
+        (bf_n > 0 && (rc = ensure(ctx, bf, bf_doubles * sizeof(double))))) {
+      release(fr); release(sp); release(bf);
       return rc;
     }
     hipError_t e = hipMemcpyAsync(fr.p, have_spec ? sky->flux_spectrum : sky->flux_ref, frb, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && bf_n > 0) {
+      double* b = (double*)bf.p;
+      e = hipMemcpyAsync(b, sky->ext->bf_pos, (size_t)bf_n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(b + (size_t)bf_n * 3, sky->ext->bf_delays, (size_t)bf_n * bf_r * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(b + (size_t)bf_n * 3 + (size_t)bf_n * bf_r, sky->ext->bf_gains, (size_t)bf_n * bf_r * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    }
     if (e == hipSuccess && !have_spec)
       e = hipMemcpyAsync(sp.p, sky->spindex, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
@@ -540,13 +560,19 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
         bp.rot_c = std::cos(ang); bp.rot_s = std::sin(ang);
         bp.apc_x = x->array_pc_dircos[0]; bp.apc_y = x->array_pc_dircos[1]; bp.apc_z = x->array_pc_dircos[2];
         bp.gp_height = x->ground_height; bp.gp_modify = x->ground_modify; bp.gp_scale = x->ground_scale; bp.gp_max = x->ground_max;
+        if (bf_n > 0) {
+          bp.bf_nelem = bf_n; bp.bf_nrand = bf_r;
+          bp.bf_pos = (const double*)bf.p;
+          bp.bf_delays = bp.bf_pos + (size_t)bf_n * 3;
+          bp.bf_gains = bp.bf_delays + (size_t)bf_n * bf_r;
+        }
       }
       bp.nsrc = ns; bp.nchan = ctx->nchan;
       bp.pb_out = (double*)ctx->pb.p;
       e = launch_beam_flux(bp, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    release(fr); release(sp);
+    release(fr); release(sp); release(bf);
     HIPCHK(ctx, e);
   }
   ctx->sky_set = true;

@@ -70,6 +70,8 @@ struct BeamParams {
   double dip_x, dip_y, dip_z; int32_t dipole_mode;
   int32_t nax1, nax2; double sep1, sep2, rot_c, rot_s; double apc_x, apc_y, apc_z;
   double gp_height; int32_t gp_modify; double gp_scale, gp_max;
+  int32_t bf_nelem, bf_nrand;  // beamformer (device arrays): positions [n][3], delays [n][nrand], gains [n][nrand]
+  const double* bf_pos; const double* bf_delays; const double* bf_gains;
   int64_t nsrc, nchan;
   double* pb_out;            // [nsrc][nchan]
 };

@@ -11,8 +11,9 @@ beam kernel (prisim_amd/csrc/aux_kernels.hip, prisim_hip_set_sky_analytic):
     telescope id 'mwa_dipole' / 'paper'  -> dipole 0.74 m / 2.0 m                   (:320-349)
     telescope shape 'dipole'             -> dipole of length 'size'                 (:360-368)
     'groundplane' (+ 'ground_modify')    -> ground-plane factor                     (:418-439, :950-966)
-Other presets (vla, gmrt, phased-array beamformer with pointing_info, rect/square apertures) raise
-NotImplementedError here -- there is no CPU stand-in.
+The phased-array beamformer (pointing_info: delays / gains / pointing centre / delay and gain jitter, array_field_pattern
+:1482-1754) is evaluated on the device too; its settings (and the random draws of the jitter) are formed here on the host.
+Other presets (vla, gmrt, rect/square apertures) raise NotImplementedError here -- there is no CPU stand-in.
 """
 import numpy as NP
 
@@ -57,6 +58,83 @@ def _dipole_axis(telescope):
     return NP.array([1.0, 0.0, 0.0])
 
 
+def mwa_tile_element_locs():
+    """The 4 x 4 dipole grid of an MWA tile at 1.1 m spacing, ENU metres, row-major from the north-west corner (:289-292)."""
+    x, y = NP.meshgrid(1.1 * NP.linspace(-1.5, 1.5, 4), 1.1 * NP.linspace(1.5, -1.5, 4))
+    return NP.stack((x.ravel(), y.ravel(), NP.zeros(x.size)), axis=1)
+
+
+def beamformer_settings(element_locs, pointing_info):
+    """Per-element compensation delays (seconds) and gains, shape (nelem, nrand), from a reference pointing_info dictionary
+    (array_field_pattern, primary_beams.py:1595-1668).  Keys: 'delays' (nelem,) | 'pointing_center' + 'pointing_coords'
+    ('altaz' degrees or 'dircos'; delay = element . pointing / c, :1632), 'gains' (nelem,), 'delayerr' (s), 'gainerr' (dB),
+    'nrand'.  Jitter is drawn from numpy's global generator, delays before gains, like the reference (:1655, :1665)."""
+    pos = NP.asarray(element_locs, dtype=NP.float64)
+    if pos.ndim != 2 or pos.shape[1] != 3:
+        raise ValueError('element_locs must be an Nx3 array (ENU metres)')
+    nel = pos.shape[0]
+    if pointing_info is None:
+        return NP.zeros((nel, 1)), NP.ones((nel, 1))
+    if not isinstance(pointing_info, dict):
+        raise TypeError('pointing_info must be a dictionary')
+    nrand = pointing_info.get('nrand', 1)
+    if nrand is None:
+        nrand = 1
+    elif not isinstance(nrand, (int, NP.integer)):
+        raise TypeError('nrand must be an integer')
+    elif nrand < 1:
+        raise ValueError('nrand must be positive')
+    if 'delays' in pointing_info:
+        delays = pointing_info['delays']
+        if delays is None:
+            delays = NP.zeros(nel)
+        elif not isinstance(delays, NP.ndarray):
+            raise TypeError('delays must be a numpy array')
+        elif delays.size != nel:
+            raise ValueError('size of delays must be equal to the number of antennas')
+        delays = NP.asarray(delays, dtype=NP.float64).ravel()
+    elif 'pointing_center' in pointing_info:
+        if 'pointing_coords' not in pointing_info:
+            raise KeyError('pointing_coords not specified.')
+        pc = NP.asarray(pointing_info['pointing_center'], dtype=NP.float64)
+        if pointing_info['pointing_coords'] == 'altaz':
+            pc = GEOM.altaz2dircos(pc.reshape(1, -1), 'degrees')
+        elif pointing_info['pointing_coords'] == 'dircos':
+            if NP.sum(pc ** 2) > 1.0 + 1e-9:
+                raise ValueError('Invalid direction cosines specified in pointing_center')
+            pc = pc.reshape(1, -1)
+        else:
+            raise ValueError('pointing_coords must be set to "dircos" or "altaz"')
+        delays = (NP.dot(pos, pc.T) / 299792458.0).ravel()      # delay compensation: opposite sign to the geometric delay
+    else:
+        delays = NP.zeros(nel)
+    gains = pointing_info.get('gains', None)
+    if gains is None:
+        gains = NP.ones(nel)
+    elif not isinstance(gains, NP.ndarray):
+        raise TypeError('gains must be a numpy array')
+    elif gains.size != nel:
+        raise ValueError('size of gains must be equal to the number of antennas')
+    gains = NP.asarray(gains, dtype=NP.float64).ravel()
+    delayerr = pointing_info.get('delayerr', None)
+    if delayerr is not None:
+        if not isinstance(delayerr, (int, float)):
+            raise TypeError('delayerr must be an integer or float')
+        if delayerr < 0.0:
+            raise ValueError('delayerr must be non-negative')
+        delays = delays.reshape(nel, 1) + delayerr * NP.random.standard_normal((nel, nrand))
+    gainerr = pointing_info.get('gainerr', None)
+    if gainerr is not None:
+        if not isinstance(gainerr, (int, float)):
+            raise TypeError('gainerr must be an integer or float')
+        if gainerr < 0.0:
+            raise ValueError('gainerr must be non-negative')
+        gains = gains.reshape(nel, 1) * 10 ** (gainerr / 10.0 * NP.random.standard_normal((nel, nrand)))
+    delays = NP.broadcast_to(delays.reshape(nel, -1), (nel, nrand)).copy()
+    gains = NP.broadcast_to(gains.reshape(nel, -1), (nel, nrand)).copy()
+    return delays, gains
+
+
 def device_beam_spec(telescope, pointing_info=None, pointing_center=None, east2ax1=0.0, short_dipole_approx=False,
                      half_wave_dipole_approx=False):
     """Map a reference ``telescope`` dictionary onto (beam_kind, size_m, element pointing dircos, ext) of the fused device
@@ -81,11 +159,14 @@ def device_beam_spec(telescope, pointing_info=None, pointing_center=None, east2a
             ext = {'ground': ground} if ground is not None else None
             return _abi.PRISIM_BEAM_AIRY, dia, bpc, ext
         if tid == 'mwa':                                                             # :248-317
-            if pointing_info is not None:
-                raise NotImplementedError('MWA phased-array beamformer (pointing_info, primary_beams.py:288-316) is not on the '
-                                          'accelerated path yet')
-            ext = {'dipole_dircos': _dipole_axis(telescope), 'dipole_mode': dmode,
-                   'array': {'nax1': 4, 'nax2': 4, 'sep1': 1.1, 'sep2': 1.1, 'east2ax1': east2ax1, 'pointing_dircos': zen}}   # :282-285
+            if pointing_info is not None:                                            # :288-316: beamformer over the tile's dipoles
+                locs = NP.asarray(telescope['element_locs'], dtype=NP.float64) if 'element_locs' in telescope else mwa_tile_element_locs()
+                delays, gains = beamformer_settings(locs, pointing_info)
+                ext = {'dipole_dircos': _dipole_axis(telescope), 'dipole_mode': dmode,
+                       'beamformer': {'positions': locs, 'delays': delays, 'gains': gains}}
+            else:
+                ext = {'dipole_dircos': _dipole_axis(telescope), 'dipole_mode': dmode,
+                       'array': {'nax1': 4, 'nax2': 4, 'sep1': 1.1, 'sep2': 1.1, 'east2ax1': east2ax1, 'pointing_dircos': zen}}   # :282-285
             if ground is not None:
                 ext['ground'] = ground
             return _abi.PRISIM_BEAM_DIPOLE, 0.74, zen, ext                           # :267
@@ -95,11 +176,14 @@ def device_beam_spec(telescope, pointing_info=None, pointing_center=None, east2a
                 ext['ground'] = ground
             return _abi.PRISIM_BEAM_DIPOLE, 0.74 if tid == 'mwa_dipole' else 2.0, zen, ext
         raise NotImplementedError('telescope id {0!r}: beam preset not on the accelerated path (SURVEY.md 8(f) N1)'.format(tid))
-    if pointing_info is not None:
-        raise NotImplementedError('phased-array beamformer (pointing_info) is not on the accelerated path yet')
     shape = telescope.get('shape', 'delta')
     bpc = _pointing_dircos(pointing_center, 'altaz')
     ext = {'ground': ground} if ground is not None else None
+    if pointing_info is not None and 'element_locs' in telescope:                    # :385-410 (no element_locs: factor 1, :387-389)
+        locs = NP.asarray(telescope['element_locs'], dtype=NP.float64)
+        delays, gains = beamformer_settings(locs, pointing_info)
+        ext = dict(ext or {})
+        ext['beamformer'] = {'positions': locs, 'delays': delays, 'gains': gains}
     if shape == 'delta':
         return _abi.PRISIM_BEAM_DELTA, 0.0, bpc, ext
     if shape == 'dish':

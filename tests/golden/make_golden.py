@@ -18,6 +18,8 @@ source text is stored in this repository.
                        9-441 (primary_beam_generator dispatch, shapes 'gaussian' / 'dish' / 'delta')
   golden_beams_ext.npz primary_beams.py:975-1235 (dipole_field_pattern), 1239-1478 (isotropic_radiators_array_field_pattern),
                        9-441 (dispatch for id 'mwa' / 'mwa_dipole' / 'paper' and shape 'dipole'), direction-cosine inputs
+  golden_beamformer.npz primary_beams.py:1482-1754 (array_field_pattern: beamformer delays / gains / pointing centre / seeded
+                       delay and gain jitter, complex64 arithmetic), 9-441 (id 'mwa' and shape 'dipole' with pointing_info)
 """
 import os
 import sys
@@ -204,8 +206,56 @@ def make_beams():
     print('golden_beams_ext.npz:', {k: v.shape for k, v in out2.items()})
 
 
+def make_beamformer():
+    """Phased-array beamformer (primary_beams.py:1482-1754) and its callers in primary_beam_generator (:288-317, :385-416)."""
+    rng = NP.random.default_rng(79)
+    n, nchan = 29, 7
+    alt = NP.concatenate(([90.0], NP.degrees(NP.arcsin(rng.uniform(0.05, 1.0, n - 1)))))
+    az = NP.concatenate(([0.0], rng.uniform(0.0, 360.0, n - 1)))
+    dircos = altaz2dircos(NP.stack((alt, az), axis=1))
+    freq_hz = 185e6 + (NP.arange(nchan) - nchan // 2) * 2.56e6
+    wl = FCNST.c / freq_hz
+    ns = {'NP': NP, 'FCNST': FCNST, 'SPS': SPS, 'GEOM': None}
+    exec(ref_block('primary_beams.py', [(975, 1235)]), ns)     # dipole_field_pattern
+    exec(ref_block('primary_beams.py', [(1239, 1478)]), ns)    # isotropic_radiators_array_field_pattern
+    exec(ref_block('primary_beams.py', [(1482, 1754)]), ns)    # array_field_pattern
+    exec(ref_block('primary_beams.py', [(9, 441)]), ns)        # primary_beam_generator
+    afp = ns['array_field_pattern']
+    xl, yl = NP.meshgrid(1.1 * NP.linspace(-1.5, 1.5, 4), 1.1 * NP.linspace(1.5, -1.5, 4))           # the MWA tile of :290-291
+    tile = NP.hstack((xl.reshape(-1, 1), yl.reshape(-1, 1), NP.zeros(xl.size).reshape(-1, 1)))
+    irregular = NP.hstack((rng.uniform(-3.0, 3.0, (11, 2)), rng.uniform(-0.1, 0.1, (11, 1))))
+    delays = rng.uniform(-4e-9, 4e-9, 16)
+    gains = rng.uniform(0.7, 1.2, 16)
+    pc = altaz2dircos(NP.array([[72.0, 140.0]])).ravel()
+    out = {}
+    with NP.errstate(divide='ignore', invalid='ignore'):
+        out['field_delays_gains'] = afp(NP.copy(tile), NP.copy(dircos), skycoords='dircos', pointing_info={'delays': NP.copy(delays), 'gains': NP.copy(gains)},
+                                        wavelength=NP.copy(wl), power=False)
+        out['power_pointed'] = afp(NP.copy(tile), NP.copy(dircos), skycoords='dircos',
+                                   pointing_info={'pointing_center': NP.copy(pc), 'pointing_coords': 'dircos'}, wavelength=NP.copy(wl), power=True)
+        out['field_irregular_none'] = afp(NP.copy(irregular), NP.copy(dircos), skycoords='dircos', pointing_info=None, wavelength=NP.copy(wl), power=False)
+        NP.random.seed(5)
+        out['field_jitter_seed5'] = afp(NP.copy(tile), NP.copy(dircos), skycoords='dircos',
+                                        pointing_info={'pointing_center': NP.copy(pc), 'pointing_coords': 'dircos', 'delayerr': 0.3e-9, 'gainerr': 0.5, 'nrand': 3},
+                                        wavelength=NP.copy(wl), power=False)
+        out['pbg_mwa_delays'] = ns['primary_beam_generator'](NP.copy(dircos), freq_hz / 1e9, {'id': 'mwa'}, freq_scale='GHz', skyunits='dircos',
+                                                             pointing_info={'delays': NP.copy(delays), 'gains': NP.copy(gains)})
+        NP.random.seed(6)
+        out['pbg_mwa_jitter_seed6'] = ns['primary_beam_generator'](NP.copy(dircos), freq_hz / 1e9, {'id': 'mwa'}, freq_scale='GHz', skyunits='dircos',
+                                                                   pointing_info={'pointing_center': NP.copy(pc), 'pointing_coords': 'dircos', 'delayerr': 0.2e-9,
+                                                                                  'gainerr': 0.3, 'nrand': 4})
+        tilt = altaz2dircos(NP.array([[20.0, 35.0]]))
+        out['pbg_dipole_elements_pointed'] = ns['primary_beam_generator'](
+            NP.copy(dircos), freq_hz / 1e9, {'shape': 'dipole', 'size': 1.5, 'ocoords': 'dircos', 'orientation': NP.copy(tilt), 'element_locs': NP.copy(irregular)},
+            freq_scale='GHz', skyunits='dircos', pointing_info={'pointing_center': NP.copy(pc), 'pointing_coords': 'dircos'})
+    NP.savez_compressed(os.path.join(HERE, 'golden_beamformer.npz'), dircos=dircos, freq_hz=freq_hz, tile=tile, irregular=irregular, delays=delays,
+                        gains=gains, pc=pc, tilt=tilt.ravel(), **out)
+    print('golden_beamformer.npz:', {k: (v.shape, v.dtype) for k, v in out.items()})
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree not available: golden vectors can only be regenerated in the build container')
     make_skyvis()
     make_beams()
+    make_beamformer()

@@ -479,3 +479,74 @@ def test_duplicate_measurements_expands_redundant_groups():
     assert ia.skyvis_lag.shape == (6, 16, 2) and NP.allclose(ia.skyvis_lag[0], ia.skyvis_lag[2])
     with pytest.raises(TypeError):
         ia.duplicate_measurements(blgroups=[1, 2])
+
+
+def test_device_beamformer_matches_reference_golden_and_oracle(ctx):
+    """Phased-array beamformer on the device (primary_beams.py:1482-1754 via :288-317 and :385-416): fp64 on the GPU against the
+    fp64 form of the oracle (tight) and against the reference's own complex64 output (float32-level)."""
+    import os
+    from conftest import GOLDEN
+    g = dict(NP.load(os.path.join(GOLDEN, 'golden_beamformer.npz')))
+    dc, f, tile, irr = g['dircos'], g['freq_hz'], g['tile'], g['irregular']
+    n = dc.shape[0]
+    zen = NP.array([0.0, 0.0, 1.0])
+    one, zero = NP.ones(n), NP.zeros(n)
+    ctx.set_array(NP.zeros((1, 3)), f)
+    # field level through the C-ABI: delta element x beamformer -> |F|^2, one realisation and several
+    NP.random.seed(5)
+    cases = [({'delays': g['delays'], 'gains': g['gains']}, tile, 'field_delays_gains'),
+             (None, irr, 'field_irregular_none'),
+             ({'pointing_center': g['pc'], 'pointing_coords': 'dircos', 'delayerr': 0.3e-9, 'gainerr': 0.5, 'nrand': 3}, tile, 'field_jitter_seed5')]
+    for info, locs, key in cases:
+        d, gn = PB.beamformer_settings(locs, info)
+        ctx.set_sky_analytic(dc, one, zero, 150e6, _abi.PRISIM_BEAM_DELTA, 0.0, zen, zen, ext={'beamformer': {'positions': locs, 'delays': d, 'gains': gn}})
+        got = ctx.get_pbflux()
+        ref64 = NP.mean(NP.abs(BO.array_field_pattern(locs, dc, 299792458.0 / f, d, gn, single=False)) ** 2, axis=2)
+        assert NP.max(NP.abs(got - ref64)) <= 1e-12, key
+        assert NP.max(NP.abs(got - NP.mean(NP.abs(g[key]) ** 2, axis=2))) <= 2e-6, key
+    # through the host dispatcher mirror: MWA tile with explicit delays, seeded jitter, custom dipole elements with a pointing centre
+    pb = PB.primary_beam_generator(dc, f / 1e9, {'id': 'mwa'}, freq_scale='GHz', skyunits='dircos', pointing_info={'delays': g['delays'], 'gains': g['gains']})
+    assert NP.max(NP.abs(pb - g['pbg_mwa_delays'])) <= 1e-6
+    NP.random.seed(6)
+    pb = PB.primary_beam_generator(dc, f / 1e9, {'id': 'mwa'}, freq_scale='GHz', skyunits='dircos',
+                                   pointing_info={'pointing_center': g['pc'], 'pointing_coords': 'dircos', 'delayerr': 0.2e-9, 'gainerr': 0.3, 'nrand': 4})
+    assert NP.max(NP.abs(pb - g['pbg_mwa_jitter_seed6'])) <= 1e-6
+    tel = {'shape': 'dipole', 'size': 1.5, 'ocoords': 'dircos', 'orientation': g['tilt'], 'element_locs': irr}
+    pb = PB.primary_beam_generator(dc, f / 1e9, tel, freq_scale='GHz', skyunits='dircos', pointing_info={'pointing_center': g['pc'], 'pointing_coords': 'dircos'})
+    assert NP.max(NP.abs(pb - g['pbg_dipole_elements_pointed'])) <= 1e-6
+    # zero delays on the regular tile = the analytic 4x4 array factor pointed at the zenith
+    pb_bf = PB.primary_beam_generator(dc, f / 1e9, {'id': 'mwa'}, freq_scale='GHz', skyunits='dircos', pointing_info={'delays': NP.zeros(16)})
+    pb_af = PB.primary_beam_generator(dc, f / 1e9, {'id': 'mwa'}, freq_scale='GHz', skyunits='dircos')
+    assert NP.max(NP.abs(pb_bf - pb_af)) <= 1e-12
+    # argument checks at the ABI
+    with pytest.raises(ValueError):
+        ctx.set_sky_analytic(dc, one, zero, 150e6, _abi.PRISIM_BEAM_DELTA, 0.0, zen, zen,
+                             ext={'beamformer': {'positions': tile, 'delays': NP.full(16, NP.nan)}})
+    with pytest.raises(ValueError):
+        ctx.set_sky_analytic(dc, one, zero, 150e6, _abi.PRISIM_BEAM_DELTA, 0.0, zen, zen,
+                             ext={'array': {'nax1': 4, 'nax2': 4, 'sep1': 1.1, 'sep2': 1.1}, 'beamformer': {'positions': tile}})
+
+
+def test_observe_with_mwa_beamformer_pointing():
+    """observe(pb_info=...) with the MWA tile beamformer steered off zenith: the visibilities equal the oracle's sky-sum of
+    (dipole x beamformed tile) beam x flux (interferometry.py:6252-6254)."""
+    ch = 170e6 + NP.arange(24) * 1.28e6
+    bl = NP.array([[30.0, 5.0, 0.0], [-120.0, 80.0, 0.5], [400.0, -310.0, 1.0]])
+    rng = NP.random.default_rng(12)
+    alt = NP.degrees(NP.arcsin(rng.uniform(0.2, 1.0, 40)))
+    altaz = NP.stack((alt, rng.uniform(0, 360, 40)), axis=1)
+    skymod = SM.SkyModel(location=altaz, flux_ref=rng.uniform(1, 5, 40), spindex=NP.full(40, -0.8), ref_freq=185e6)
+    pinfo = {'pointing_center': NP.array([75.0, 150.0]), 'pointing_coords': 'altaz'}
+    ia = RI.InterferometerArray(['a', 'b', 'c'], bl, ch, telescope={'id': 'mwa'}, skycoords='altaz', pointing_coords='altaz')
+    ia.observe((2457000.5, 0.0), {'Tnet': 200.0}, NP.ones(24), [90.0, 270.0], skymod, 112.0, pb_info=pinfo)
+    dc = O.altaz2dircos(altaz)
+    tile = PB.mwa_tile_element_locs()
+    d, gn = BO.beamformer_settings(tile, {'pointing_center': O.altaz2dircos(pinfo['pointing_center'].reshape(1, 2))[0], 'pointing_coords': 'dircos'})
+    pb = BO.composite_power_beam(dc, ch, element='dipole', size=0.74, element_dircos=(1, 0, 0), beamformer={'positions': tile, 'delays': d, 'gains': gn})
+    pbflux = pb * skymod.generate_spectrum(frequency=ch)
+    ref = O.skyvis(bl, ch, dc, pbflux, NP.array([0.0, 0.0, 1.0]))
+    assert NP.max(NP.abs(ia.skyvis_freq[:, :, 0] - ref) / O.abs_flux_sum(pbflux)[None, :]) <= 1e-11
+    # the steered tile is brighter towards the pointing centre than the zenith-pointed one
+    ia0 = RI.InterferometerArray(['a', 'b', 'c'], bl, ch, telescope={'id': 'mwa'}, skycoords='altaz', pointing_coords='altaz')
+    ia0.observe((2457000.5, 0.0), {'Tnet': 200.0}, NP.ones(24), [90.0, 270.0], skymod, 112.0)
+    assert not NP.allclose(ia0.skyvis_freq, ia.skyvis_freq)

@@ -164,7 +164,7 @@ def test_device_beam_spec_dispatch():
         PB.device_beam_spec({'id': 'paper', 'orientation': [0.0, 90.0]})
     with pytest.raises(NotImplementedError):
         PB.device_beam_spec({'id': 'vla'})
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):                                               # the reference wants a numpy array (:1616-1617)
         PB.device_beam_spec({'id': 'mwa'}, pointing_info={'delays': [0] * 16})
 
 
@@ -177,3 +177,40 @@ def test_error_code_mapping():
         _abi._raise(_abi.PRISIM_ESTATE, 'x')
     with pytest.raises(_abi.PrisimHipError):
         _abi._raise(_abi.PRISIM_ENODEV, 'x')
+
+
+def test_beamformer_settings_follow_the_reference_draw_order_and_checks():
+    """Host side of the phased-array beamformer (primary_beams.py:1595-1668): delays from a pointing centre, explicit delays and
+    gains, jitter drawn delays-first from numpy's global generator (the oracle restates the same rule independently)."""
+    from oracle import beams_oracle as BO
+    from prisim_amd import primary_beams as PB
+    tile = PB.mwa_tile_element_locs()
+    assert tile.shape == (16, 3) and NP.allclose(tile[0], [-1.65, 1.65, 0.0]) and NP.allclose(tile[-1], [1.65, -1.65, 0.0])
+    pc = NP.array([0.3, -0.2, NP.sqrt(1 - 0.13)])
+    info = {'pointing_center': pc, 'pointing_coords': 'dircos', 'delayerr': 0.25e-9, 'gainerr': 0.4, 'nrand': 5}
+    NP.random.seed(11)
+    d1, g1 = PB.beamformer_settings(tile, info)
+    NP.random.seed(11)
+    d2, g2 = BO.beamformer_settings(tile, info)
+    assert d1.shape == (16, 5) and NP.array_equal(d1, d2) and NP.array_equal(g1, g2)
+    d, g = PB.beamformer_settings(tile, {'pointing_center': NP.array([90.0, 0.0]), 'pointing_coords': 'altaz'})
+    assert d.shape == (16, 1) and NP.allclose(d, 0.0, atol=1e-24) and NP.all(g == 1.0)      # zenith: no compensation needed
+    d, g = PB.beamformer_settings(tile, None)
+    assert NP.all(d == 0.0) and NP.all(g == 1.0)
+    with pytest.raises(KeyError):
+        PB.beamformer_settings(tile, {'pointing_center': pc})
+    with pytest.raises(ValueError):
+        PB.beamformer_settings(tile, {'delays': NP.zeros(3)})
+    with pytest.raises(TypeError):
+        PB.beamformer_settings(tile, {'delays': [0.0] * 16})
+    with pytest.raises(ValueError):
+        PB.beamformer_settings(tile, {'delayerr': -1.0})
+    with pytest.raises(TypeError):
+        PB.beamformer_settings(tile, {'nrand': 2.5})
+    # telescope dictionary -> device beam spec
+    kind, size, bpc, ext = PB.device_beam_spec({'id': 'mwa'}, pointing_info={'delays': NP.zeros(16)})
+    assert 'beamformer' in ext and 'array' not in ext and ext['beamformer']['positions'].shape == (16, 3)
+    kind, size, bpc, ext = PB.device_beam_spec({'id': 'mwa'})
+    assert 'array' in ext and 'beamformer' not in ext
+    kind, size, bpc, ext = PB.device_beam_spec({'shape': 'delta'}, pointing_info={'delays': NP.zeros(16)})     # no element_locs: factor 1 (:387-389)
+    assert ext is None

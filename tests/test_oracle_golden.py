@@ -117,3 +117,41 @@ def test_dipole_array_factor_and_presets_match_reference_functions():
     # ground plane known answers (unpinned restatement): 1 at zenith, 0 on the horizon
     gp = BO.ground_plane_field_pattern(0.3, NP.array([[0, 0, 1.0], [1.0, 0, 0]]), wl)
     assert NP.allclose(gp[0], 1.0) and NP.allclose(gp[1], 0.0)
+
+
+def test_beamformer_matches_reference_function():
+    """array_field_pattern (primary_beams.py:1482-1754) and its callers (:288-317, :385-416): the restatement in the reference's
+    float32 / complex64 arithmetic against the reference function executed on seeded inputs, including the seeded jitter draws."""
+    import os
+    from conftest import GOLDEN
+    g = dict(NP.load(os.path.join(GOLDEN, 'golden_beamformer.npz')))
+    dc, f, tile, irr = g['dircos'], g['freq_hz'], g['tile'], g['irregular']
+    wl = 299792458.0 / f
+    tol = 1e-6                                                        # complex64: a few float32 ulps of a unit-scale field
+    d, gn = BO.beamformer_settings(tile, {'delays': g['delays'], 'gains': g['gains']})
+    a = BO.array_field_pattern(tile, dc, wl, d, gn)
+    assert a.dtype == NP.complex64 and a.shape == (29, 7, 1) and NP.max(NP.abs(a - g['field_delays_gains'])) <= tol
+    d, gn = BO.beamformer_settings(tile, {'pointing_center': g['pc'], 'pointing_coords': 'dircos'})
+    p = BO.array_field_pattern(tile, dc, wl, d, gn, power=True)
+    assert NP.max(NP.abs(p - g['power_pointed'])) <= tol
+    ipc = NP.argmax(dc @ g['pc'])
+    assert NP.all(p <= 1.0 + 1e-6) and p[ipc].min() > 0.5           # coherent towards the pointing centre
+    assert NP.max(NP.abs(BO.array_field_pattern(irr, dc, wl) - g['field_irregular_none'])) <= tol
+    NP.random.seed(5)
+    d, gn = BO.beamformer_settings(tile, {'pointing_center': g['pc'], 'pointing_coords': 'dircos', 'delayerr': 0.3e-9, 'gainerr': 0.5, 'nrand': 3})
+    assert d.shape == (16, 3) and gn.shape == (16, 3)
+    assert NP.max(NP.abs(BO.array_field_pattern(tile, dc, wl, d, gn) - g['field_jitter_seed5'])) <= tol
+    assert NP.max(NP.abs(BO.array_field_pattern(tile, dc, wl, d, gn, single=False) - g['field_jitter_seed5'])) <= tol    # fp64 form
+    d, gn = BO.beamformer_settings(tile, {'delays': g['delays'], 'gains': g['gains']})
+    bf = {'positions': tile, 'delays': d, 'gains': gn, 'single': True}
+    pb = BO.composite_power_beam(dc, f, element='dipole', size=0.74, element_dircos=(1, 0, 0), beamformer=bf)
+    assert NP.max(NP.abs(pb - g['pbg_mwa_delays'])) <= tol
+    NP.random.seed(6)
+    d, gn = BO.beamformer_settings(tile, {'pointing_center': g['pc'], 'pointing_coords': 'dircos', 'delayerr': 0.2e-9, 'gainerr': 0.3, 'nrand': 4})
+    pb = BO.composite_power_beam(dc, f, element='dipole', size=0.74, element_dircos=(1, 0, 0),
+                                 beamformer={'positions': tile, 'delays': d, 'gains': gn, 'single': True})
+    assert NP.max(NP.abs(pb - g['pbg_mwa_jitter_seed6'])) <= tol
+    d, gn = BO.beamformer_settings(irr, {'pointing_center': g['pc'], 'pointing_coords': 'dircos'})
+    pb = BO.composite_power_beam(dc, f, element='dipole', size=1.5, element_dircos=g['tilt'],
+                                 beamformer={'positions': irr, 'delays': d, 'gains': gn, 'single': True})
+    assert NP.max(NP.abs(pb - g['pbg_dipole_elements_pointed'])) <= tol
