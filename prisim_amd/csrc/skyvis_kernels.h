@@ -35,7 +35,7 @@ struct SkyvisParams {
   int32_t nbgroups;          // baseline groups of kBlockThreads
   int32_t nsplit;            // source split factor (partials reduced afterwards)
   int64_t src_per_split;
-  int32_t src_chunk;         // sources per LDS chunk
+  int32_t src_chunk;         // granularity of the zero padding / of the source split (host side; the kernels do not use it)
   int32_t flush_src;         // fp32: flush accumulators into the fp64 cube every this many sources
   int32_t scale_comp;        // direct kernel: gradient component or -1
   int32_t taper_group;       // packed fp32 taper: 1 = grouped recurrence (valid when df/f_min <= 3.4e-3), 0 = exact per-step form

@@ -7,19 +7,22 @@
 //
 // MI355X mapping:
 //   * lanes = baselines (64 consecutive baselines per wavefront), so pbflux[s,f] and the source
-//     direction are wave-uniform and are served by LDS broadcast reads; no cross-lane reduction is
-//     needed on the main path.
+//     direction are wave-uniform: they are fetched with scalar loads and used as SGPR operands
+//     (no LDS, no barriers in the source loop); no cross-lane reduction is needed.
 //   * each thread owns CT consecutive channels of one baseline: 2*CT accumulators in VGPRs.
 //   * the nsrc x nbl x nchan phase matrix of the reference is never materialised: per (source,
 //     baseline, channel tile) one range-reduced seed phasor and one step phasor are formed
 //     (fp64 phase reduction), then the phasor is advanced along frequency by a complex rotation
-//     (4 VALU) and accumulated (2 FMA): 6 VALU slots / term.  The tile is seeded at its centre
-//     channel and walked in both directions (two independent dependency chains, half the drift).
-//   * sources are streamed through a double-buffered LDS ring in chunks (global -> VGPR -> LDS).
+//     (3-4 VALU) and accumulated (2 FMA).  The tile is seeded at its centre channel and walked in
+//     both directions (two independent dependency chains, half the drift).
+//   * rows of the packed pbflux ([tile][source][CT]) stream through the scalar cache, requested
+//     one piece ahead of their use; an LDS-DMA touch 12 sources ahead keeps L2 warm for skies
+//     whose slab outgrows it.
 //   * block id -> (pbflux slab, baseline group) is XCD-aware: all blocks resident on one XCD
 //     read the same pbflux slab, which therefore stays in that XCD's 4 MiB L2.
-//   * fp32 mode accumulates in fp32 registers and flushes into the fp64 cube every
-//     FLUSH_SRC sources, so the summation error does not grow with nsrc.
+//   * fp32 mode accumulates in fp32 registers and adds them into the fp64 cube every flush_src
+//     sources (transposed through LDS so the stores are coalesced), so the summation error
+//     does not grow with nsrc.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "skyvis_kernels.h"
@@ -122,11 +125,6 @@ __device__ __forceinline__ void sincos_qcycles(double a4, double& c, double& s) 
   s = ((qi & 2) != 0) ? -ss : ss;
 }
 
-template <typename T> struct Vec16;               // 16-byte LDS/global access unit
-template <> struct Vec16<float> { using type = float4; };
-template <> struct Vec16<double> { using type = double2; };
-__device__ __forceinline__ void unpack16(const float4 v, float* d) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
-__device__ __forceinline__ void unpack16(const double2 v, double* d) { d[0] = v.x; d[1] = v.y; }
 
 // ------------------------------------------------------------------------------------------
 // Recurrence kernel
