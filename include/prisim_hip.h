@@ -247,7 +247,7 @@ int prisim_hip_sync(prisim_ctx* ctx);
 int prisim_hip_get_timing(prisim_ctx* ctx, prisim_timing* out, int reset);
 /* Device properties: CU count and clock (kHz) used to re-derive the VALU peak on the box. */
 int prisim_hip_device_info(prisim_ctx* ctx, int* cu_count, int* clock_khz, char name[64]);
-/* Tuning knobs (0 = library default): channels per thread, sources per LDS chunk, split factor. */
+/* Tuning knobs (0 = library default): channels per thread, source padding / split granularity, source split factor. */
 int prisim_hip_set_tuning(prisim_ctx* ctx, int chan_tile, int src_chunk, int nsplit);
 
 #ifdef __cplusplus
