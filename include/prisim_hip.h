@@ -112,7 +112,8 @@ enum {
   PRISIM_BEAM_DELTA = 0,     /* pb = 1 (telescope shape 'delta', primary_beams.py:357-359) */
   PRISIM_BEAM_GAUSSIAN = 1,  /* primary_beams.py:716-728 (power pattern) */
   PRISIM_BEAM_AIRY = 2,      /* primary_beams.py:609-623 (power pattern, HERA D=14 m preset :239-247) */
-  PRISIM_BEAM_DIPOLE = 3     /* primary_beams.py:1207-1235 (field pattern squared); needs prisim_beam_ext */
+  PRISIM_BEAM_DIPOLE = 3,    /* primary_beams.py:1207-1235 (field pattern squared); needs prisim_beam_ext */
+  PRISIM_BEAM_POLY = 4       /* VLA / GMRT polynomial power beams (:445-513, :734-808); needs prisim_beam_ext.poly_coef */
 };
 
 enum { PRISIM_DIPOLE_GENERAL = 0, PRISIM_DIPOLE_SHORT = 1, PRISIM_DIPOLE_HALFWAVE = 2 };
@@ -140,6 +141,9 @@ typedef struct prisim_beam_ext {
   const double* bf_pos;      /* host [bf_nelem][3] ENU metres */
   const double* bf_delays;   /* host [bf_nelem][bf_nrand] seconds */
   const double* bf_gains;    /* host [bf_nelem][bf_nrand] */
+  /* PRISIM_BEAM_POLY: power = 1 + c0 x/1e3 + c1 x^2/1e7 + c2 x^3/1e10 + c3 x^4/1e13 with x = (zenith angle [deg] * 60 * f [GHz])^2
+   * (:508-509, :801); like the reference the call fails (PRISIM_EINVAL) if any value is NaN or >= 1.01 (:510-512, :802-807). */
+  double poly_coef[4];
 } prisim_beam_ext;
 
 typedef struct prisim_beam_sky {

@@ -145,6 +145,16 @@ def ground_plane_field_pattern(height, dircos, wavelength, modifier=None):
     return gp / (2 * NP.sin(k * height))                                                    # :965-966
 
 
+def polynomial_beam(coef, zenith_angle_deg, frequency_hz):
+    """VLA / GMRT polynomial power beam (primary_beams.py:503-509 / :796-801): x = (angle [deg] * 60 * f [GHz])^2,
+    1 + c0 x/1e3 + c1 x^2/1e7 + c2 x^3/1e10 (+ c3 x^4/1e13)."""
+    th = NP.asarray(zenith_angle_deg, dtype=NP.float64).reshape(-1, 1)
+    f = NP.asarray(frequency_hz, dtype=NP.float64).reshape(1, -1) / 1e9
+    x = (th * 60.0 * f) ** 2
+    c = list(coef) + [0.0] * (4 - len(coef))
+    return 1.0 + c[0] * x / 1e3 + c[1] * (x ** 2) / 1e7 + c[2] * (x ** 3) / 1e10 + c[3] * (x ** 4) / 1e13
+
+
 def beamformer_settings(antpos, pointing_info):
     """Element delays [nelem, nrand] (seconds) and gains [nelem, nrand] of the phased-array beamformer from a reference
     ``pointing_info`` dictionary (primary_beams.py:1595-1668): explicit 'delays', or delay compensation towards

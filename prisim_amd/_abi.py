@@ -15,7 +15,7 @@ PRISIM_OK = 0
 PRISIM_EINVAL, PRISIM_ENODEV, PRISIM_ENOMEM, PRISIM_ESTATE, PRISIM_ELIB, PRISIM_EINTERNAL = -1, -2, -3, -4, -5, -6
 PRISIM_FP64, PRISIM_FP32 = 0, 1
 PRISIM_KERNEL_AUTO, PRISIM_KERNEL_RECURRENCE, PRISIM_KERNEL_DIRECT = 0, 1, 2
-PRISIM_BEAM_DELTA, PRISIM_BEAM_GAUSSIAN, PRISIM_BEAM_AIRY, PRISIM_BEAM_DIPOLE = 0, 1, 2, 3
+PRISIM_BEAM_DELTA, PRISIM_BEAM_GAUSSIAN, PRISIM_BEAM_AIRY, PRISIM_BEAM_DIPOLE, PRISIM_BEAM_POLY = 0, 1, 2, 3, 4
 PRISIM_DIPOLE_GENERAL, PRISIM_DIPOLE_SHORT, PRISIM_DIPOLE_HALFWAVE = 0, 1, 2
 
 # every symbol include/prisim_hip.h declares (tests check the library exports all of them)
@@ -40,7 +40,7 @@ class PrisimBeamExt(C.Structure):
                 ('array_nax2', C.c_int32), ('ground_modify', C.c_int32), ('array_sep1', C.c_double), ('array_sep2', C.c_double),
                 ('array_east2ax1_deg', C.c_double), ('array_pc_dircos', C.c_double * 3), ('ground_height', C.c_double),
                 ('ground_scale', C.c_double), ('ground_max', C.c_double), ('bf_nelem', C.c_int32), ('bf_nrand', C.c_int32),
-                ('bf_pos', C.c_void_p), ('bf_delays', C.c_void_p), ('bf_gains', C.c_void_p)]
+                ('bf_pos', C.c_void_p), ('bf_delays', C.c_void_p), ('bf_gains', C.c_void_p), ('poly_coef', C.c_double * 4)]
 
 
 def make_beam_ext(ext):
@@ -90,6 +90,14 @@ def make_beam_ext(ext):
         x.bf_nelem, x.bf_nrand = nel, nrand
         x.bf_pos, x.bf_delays, x.bf_gains = pos.ctypes.data, delays.ctypes.data, gains.ctypes.data
         x._keep = (pos, delays, gains)
+    poly = ext.get('poly', None)
+    if poly is not None:
+        c = NP.zeros(4)
+        pc = NP.asarray(poly, dtype=NP.float64).ravel()
+        if pc.size < 1 or pc.size > 4:
+            raise ValueError('poly must have 1 to 4 coefficients')
+        c[:pc.size] = pc
+        x.poly_coef[:] = c.tolist()
     return x
 
 

@@ -106,6 +106,15 @@ void k_beam_flux(const BeamParams p) {
       const double n2 = (double)p.bf_nelem * (double)p.bf_nelem;
       pb = ep * ep * acc / (n2 * (double)p.bf_nrand);
     }
+    if (p.beam_kind == PRISIM_BEAM_POLY) {
+      // VLA / GMRT polynomial in x = (zenith angle [deg] * 60 * f [GHz])^2 (:503, :508-509 / :796, :801); no blanking, no pointing
+      const double th = atan2(sqrt(d.x * d.x + d.y * d.y), d.z) * (180.0 / kPi);      // zenith angle; well conditioned near the axis
+      const double u = th * 60.0 * (f * 1e-9);
+      const double x = u * u;
+      pb = 1.0 + p.poly[0] * x / 1e3 + p.poly[1] * (x * x) / 1e7 + p.poly[2] * (x * x * x) / 1e10 + p.poly[3] * (x * x * x * x) / 1e13;
+      if (pb != pb) atomicOr(p.flag, 2);
+      else if (pb >= 1.01) atomicOr(p.flag, 1);
+    }
     if (p.gp_height > 0.0) {                                                              // ground plane (:950-966)
       const double kk = 2.0 * kPi * f / kC;
       const double nz = d.z < -1.0 ? -1.0 : (d.z > 1.0 ? 1.0 : d.z);                      // sin(alt) = n

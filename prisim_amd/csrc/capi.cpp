@@ -481,10 +481,12 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
   if (!ctx) return PRISIM_EINVAL;
   if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_analytic");
-  if (sky->beam_kind < PRISIM_BEAM_DELTA || sky->beam_kind > PRISIM_BEAM_DIPOLE)
+  if (sky->beam_kind < PRISIM_BEAM_DELTA || sky->beam_kind > PRISIM_BEAM_POLY)
     return fail(ctx, PRISIM_EINVAL, "unknown beam_kind");
   if (sky->beam_kind == PRISIM_BEAM_DIPOLE && !sky->ext)
     return fail(ctx, PRISIM_EINVAL, "PRISIM_BEAM_DIPOLE needs a prisim_beam_ext (dipole axis)");
+  if (sky->beam_kind == PRISIM_BEAM_POLY && !sky->ext)
+    return fail(ctx, PRISIM_EINVAL, "PRISIM_BEAM_POLY needs a prisim_beam_ext (poly_coef)");
   if (sky->ext) {
     const prisim_beam_ext* x = sky->ext;
     if (x->dipole_mode < PRISIM_DIPOLE_GENERAL || x->dipole_mode > PRISIM_DIPOLE_HALFWAVE)
@@ -511,7 +513,7 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
   if (sky->nsrc > 0 && !have_spec && (!sky->flux_ref || !sky->spindex))
     return fail(ctx, PRISIM_EINVAL, "flux_ref / spindex is NULL and no flux_spectrum given");
   if (!have_spec && !(sky->ref_freq_hz > 0.0)) return fail(ctx, PRISIM_EINVAL, "ref_freq_hz must be positive");
-  if (sky->beam_kind != PRISIM_BEAM_DELTA && !(sky->diameter_m > 0.0))
+  if (sky->beam_kind != PRISIM_BEAM_DELTA && sky->beam_kind != PRISIM_BEAM_POLY && !(sky->diameter_m > 0.0))
     return fail(ctx, PRISIM_EINVAL, "diameter_m must be positive");
   if (!sky->beam_pc_dircos) return fail(ctx, PRISIM_EINVAL, "beam_pc_dircos is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -522,15 +524,16 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
   const int64_t n = ns * ctx->nchan;
   if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (ns > 0) {
-    DevBuf fr, sp, bf;
+    DevBuf fr, sp, bf, flag;
     const size_t frb = have_spec ? (size_t)n * sizeof(double) : (size_t)ns * sizeof(double);
     const int bf_n = sky->ext ? sky->ext->bf_nelem : 0, bf_r = bf_n > 0 ? sky->ext->bf_nrand : 0;
     const size_t bf_doubles = (size_t)bf_n * 3 + 2 * (size_t)bf_n * bf_r;
     if ((rc = ensure(ctx, fr, frb)) || (rc = ensure(ctx, sp, (size_t)ns * sizeof(double))) ||
-        (bf_n > 0 && (rc = ensure(ctx, bf, bf_doubles * sizeof(double))))) {
-      release(fr); release(sp); release(bf);
+        (bf_n > 0 && (rc = ensure(ctx, bf, bf_doubles * sizeof(double)))) || (rc = ensure(ctx, flag, sizeof(int32_t)))) {
+      release(fr); release(sp); release(bf); release(flag);
       return rc;
     }
+    int32_t hflag = 0;
     hipError_t e = hipMemcpyAsync(fr.p, have_spec ? sky->flux_spectrum : sky->flux_ref, frb, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && bf_n > 0) {
       double* b = (double*)bf.p;
@@ -567,13 +570,22 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
           bp.bf_gains = bp.bf_delays + (size_t)bf_n * bf_r;
         }
       }
+      if (sky->beam_kind == PRISIM_BEAM_POLY)
+        for (int i = 0; i < 4; ++i) bp.poly[i] = sky->ext->poly_coef[i];
+      bp.flag = (int32_t*)flag.p;
       bp.nsrc = ns; bp.nchan = ctx->nchan;
       bp.pb_out = (double*)ctx->pb.p;
-      e = launch_beam_flux(bp, ctx->stream);
+      e = hipMemsetAsync(flag.p, 0, sizeof(int32_t), ctx->stream);
+      if (e == hipSuccess) e = launch_beam_flux(bp, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(&hflag, flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    release(fr); release(sp); release(bf);
+    release(fr); release(sp); release(bf); release(flag);
     HIPCHK(ctx, e);
+    if (hflag & 2)
+      return fail(ctx, PRISIM_EINVAL, "Primary beam values were found to be NaN in some case(s). Check if the polynomial equations are valid for the frequencies specified.");
+    if (hflag & 1)
+      return fail(ctx, PRISIM_EINVAL, "Primary beam exceeds unity by a significant amount. Check the validity of the Primary beam equation for the angles specified.");
   }
   ctx->sky_set = true;
   return PRISIM_OK;

@@ -72,6 +72,7 @@ struct BeamParams {
   double gp_height; int32_t gp_modify; double gp_scale, gp_max;
   int32_t bf_nelem, bf_nrand;  // beamformer (device arrays): positions [n][3], delays [n][nrand], gains [n][nrand]
   const double* bf_pos; const double* bf_delays; const double* bf_gains;
+  double poly[4]; int32_t* flag;   // PRISIM_BEAM_POLY coefficients; flag bit 0: value >= 1.01, bit 1: NaN
   int64_t nsrc, nchan;
   double* pb_out;            // [nsrc][nchan]
 };

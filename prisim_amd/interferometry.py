@@ -437,7 +437,8 @@ class InterferometerArray(object):
             elif getattr(self, '_extbeam', None) is not None:
                 self._ctx.set_sky_external(dircos_roi, fluxes, pc_dircos, fwhm_deg=fwhm)
             else:
-                kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz)  # :6252
+                kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz,
+                                                          first_frequency_hz=float(self.channels[0]))                   # :6252
                 self._ctx.set_sky_analytic(dircos_roi, None, None, None, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,
                                            flux_spectrum=fluxes, ext=ext)
             slot = self.n_acc if self.n_acc < self._reserved else 0

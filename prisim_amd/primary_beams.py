@@ -13,7 +13,8 @@ beam kernel (prisim_amd/csrc/aux_kernels.hip, prisim_hip_set_sky_analytic):
     'groundplane' (+ 'ground_modify')    -> ground-plane factor                     (:418-439, :950-966)
 The phased-array beamformer (pointing_info: delays / gains / pointing centre / delay and gain jitter, array_field_pattern
 :1482-1754) is evaluated on the device too; its settings (and the random draws of the jitter) are formed here on the host.
-Other presets (vla, gmrt, rect/square apertures) raise NotImplementedError here -- there is no CPU stand-in.
+The VLA / GMRT polynomial beams (:445-513, :734-808) are a fifth device beam kind.  rect/square apertures raise
+NotImplementedError here (the reference code for them is broken) -- there is no CPU stand-in.
 """
 import numpy as NP
 
@@ -135,8 +136,35 @@ def beamformer_settings(element_locs, pointing_info):
     return delays, gains
 
 
+# Polynomial power beams 1 + c0 x/1e3 + c1 x^2/1e7 + c2 x^3/1e10 [+ c3 x^4/1e13], x = (angle [arcmin] * f [GHz])^2:
+# reference bands (GHz) and coefficients of the VLA (:491-499) and of the GMRT / upgraded GMRT (:781-790)
+_POLY_BANDS = {
+    'vla': ((0.0738, 0.3275, 1.465, 4.885, 8.435, 14.965, 22.485, 43.315),
+            ((-0.897, 2.71, -0.242), (-0.935, 3.23, -0.378), (-1.343, 6.579, -1.186), (-1.372, 6.940, -1.309),
+             (-1.306, 6.253, -1.100), (-1.305, 6.155, -1.030), (-1.417, 7.332, -1.352), (-1.321, 6.185, -0.983))),
+    'gmrt': ((0.235, 0.325, 0.610, 1.420),
+             ((-3.366, 46.159, -29.963, 7.529), (-3.397, 47.192, -30.931, 7.803), (-3.486, 47.749, -35.203, 10.399),
+              (-2.27961, 21.4611, -9.7929, 1.80153))),
+    'ugmrt': ((0.235, 0.325, 0.610, 1.420),
+              ((NP.nan, NP.nan, NP.nan, NP.nan), (-2.939, 33.312, -16.659, 3.006), (-3.190, 38.642, -20.471, 3.964),
+               (-2.608, 27.357, -13.091, 2.365))),
+}
+
+
+def poly_beam_coefficients(telescope_id, first_frequency_hz):
+    """Coefficients of the band nearest to the FIRST frequency of the run (:500, :791), padded to 4."""
+    key = 'vla' if telescope_id == 'vla' else telescope_id
+    if key not in _POLY_BANDS:
+        raise KeyError('no polynomial beam for instrument {0!r}'.format(telescope_id))     # the reference's parms_ref[instrument] lookup
+    bands, coef = _POLY_BANDS[key]
+    idx = int(NP.argmin(NP.abs(NP.asarray(bands) - first_frequency_hz / 1e9)))
+    c = NP.zeros(4)
+    c[:len(coef[idx])] = coef[idx]
+    return c
+
+
 def device_beam_spec(telescope, pointing_info=None, pointing_center=None, east2ax1=0.0, short_dipole_approx=False,
-                     half_wave_dipole_approx=False):
+                     half_wave_dipole_approx=False, first_frequency_hz=None):
     """Map a reference ``telescope`` dictionary onto (beam_kind, size_m, element pointing dircos, ext) of the fused device
     beam kernel (ext: dipole axis / array factor / ground plane, see _abi.make_beam_ext).
     pointing_center: alt-az degrees (observe() passes pc_altaz, interferometry.py:6252)."""
@@ -150,6 +178,13 @@ def device_beam_spec(telescope, pointing_info=None, pointing_center=None, east2a
     ground = _ground_ext(telescope)
     tid = telescope.get('id', None)
     if tid is not None and tid not in ('custom',):
+        if tid == 'vla' or 'gmrt' in tid:                                            # :225-238: angle from the zenith, no pointing
+            if first_frequency_hz is None:
+                raise ValueError('the polynomial beams select their band from the first frequency: first_frequency_hz is needed')
+            ext = {'poly': poly_beam_coefficients(tid, first_frequency_hz)}
+            if ground is not None:
+                ext['ground'] = ground
+            return _abi.PRISIM_BEAM_POLY, 0.0, zen, ext
         if tid in ('hera', 'hirax'):
             dia = 14.0 if tid == 'hera' else 6.0                                     # :240-243
             if 'orientation' in telescope:                                           # :245-246
@@ -222,7 +257,7 @@ def primary_beam_generator(skypos, frequency, telescope, freq_scale='GHz', skyun
         raise ValueError('skyunits must be "altaz" or "dircos" on the accelerated path')
     kind, dia, bpc, ext = device_beam_spec(telescope, pointing_info=pointing_info, pointing_center=pointing_center,
                                            east2ax1=east2ax1, short_dipole_approx=short_dipole_approx,
-                                           half_wave_dipole_approx=half_wave_dipole_approx)
+                                           half_wave_dipole_approx=half_wave_dipole_approx, first_frequency_hz=float(frequency[0]))
     nsrc = dircos.shape[0]
     with _abi.Context(device) as ctx:
         ctx.set_array(NP.zeros((1, 3)), frequency, nt_max=1)

@@ -18,6 +18,7 @@ source text is stored in this repository.
                        9-441 (primary_beam_generator dispatch, shapes 'gaussian' / 'dish' / 'delta')
   golden_beams_ext.npz primary_beams.py:975-1235 (dipole_field_pattern), 1239-1478 (isotropic_radiators_array_field_pattern),
                        9-441 (dispatch for id 'mwa' / 'mwa_dipole' / 'paper' and shape 'dipole'), direction-cosine inputs
+  golden_polybeams.npz primary_beams.py:445-513 (VLA_primary_beam_PBCOR), 734-808 (GMRT_primary_beam), 9-441 (id 'vla' / 'gmrt' / 'ugmrt')
   golden_beamformer.npz primary_beams.py:1482-1754 (array_field_pattern: beamformer delays / gains / pointing centre / seeded
                        delay and gain jitter, complex64 arithmetic), 9-441 (id 'mwa' and shape 'dipole' with pointing_info)
 """
@@ -253,9 +254,32 @@ def make_beamformer():
     print('golden_beamformer.npz:', {k: (v.shape, v.dtype) for k, v in out.items()})
 
 
+def make_polybeams():
+    """Polynomial (PBCOR-style) dish beams of the VLA and the GMRT (primary_beams.py:445-513, 734-808) and their dispatch (:225-238)."""
+    rng = NP.random.default_rng(80)
+    ns = {'NP': NP, 'FCNST': FCNST, 'SPS': SPS, 'GEOM': None}
+    exec(ref_block('primary_beams.py', [(445, 513)]), ns)
+    exec(ref_block('primary_beams.py', [(734, 808)]), ns)
+    exec(ref_block('primary_beams.py', [(9, 441)]), ns)
+    out = {}
+    n = 33
+    for name, tel, f0 in (('vla_L', {'id': 'vla'}, 1.4e9), ('vla_P', {'id': 'vla'}, 0.33e9), ('gmrt_610', {'id': 'gmrt'}, 0.6e9), ('ugmrt_325', {'id': 'ugmrt'}, 0.32e9)):
+        freq_hz = f0 + NP.arange(5) * 2e6
+        # zenith angles where the polynomial is a beam (first-null radius ~ 45' * 1.4 GHz / f for a 25 m dish, 1.8x that for 45 m)
+        theta_max = (0.55 if 'vla' in name else 0.3) * 1.4e9 / f0
+        alt = 90.0 - NP.concatenate(([0.0], rng.uniform(0.0, theta_max, n - 1)))
+        skypos = NP.stack((alt, rng.uniform(0.0, 360.0, n)), axis=1)
+        out['pbg_' + name] = ns['primary_beam_generator'](NP.copy(skypos), freq_hz / 1e9, dict(tel), freq_scale='GHz', skyunits='altaz')
+        out['altaz_' + name] = skypos
+        out['freq_' + name] = freq_hz
+    NP.savez_compressed(os.path.join(HERE, 'golden_polybeams.npz'), **out)
+    print('golden_polybeams.npz:', {k: v.shape for k, v in out.items() if k.startswith('pbg')}, {k: (float(v.min()), float(v.max())) for k, v in out.items() if k.startswith('pbg')})
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree not available: golden vectors can only be regenerated in the build container')
     make_skyvis()
     make_beams()
     make_beamformer()
+    make_polybeams()

@@ -39,8 +39,8 @@ def test_struct_layouts_match_header():
     assert _abi.PrisimSky.pbflux_is_f32.offset == 24 and _abi.PrisimSky.fluxes.offset == 48
     # prisim_beam_sky: int64, 4 ptr, double, int32 (+pad), double, 4 ptr -> 96 bytes
     assert C.sizeof(_abi.PrisimBeamSky) == 96 and _abi.PrisimBeamSky.ext.offset == 88
-    # prisim_beam_ext: 3 double, 4 int32, 3 double, 3 double, 3 double, 2 int32, 3 pointers -> 144 bytes
-    assert C.sizeof(_abi.PrisimBeamExt) == 144 and _abi.PrisimBeamExt.array_sep1.offset == 40 and _abi.PrisimBeamExt.bf_pos.offset == 120
+    # prisim_beam_ext: 3 double, 4 int32, 3 double, 3 double, 3 double, 2 int32, 3 pointers, 4 double -> 176 bytes
+    assert C.sizeof(_abi.PrisimBeamExt) == 176 and _abi.PrisimBeamExt.array_sep1.offset == 40 and _abi.PrisimBeamExt.bf_pos.offset == 120
     assert _abi.PrisimBeamSky.beam_kind.offset == 48 and _abi.PrisimBeamSky.diameter_m.offset == 56
     # prisim_timing: 3 double, 2 int64, 6 int32 -> 64 bytes
     assert C.sizeof(_abi.PrisimTiming) == 64

@@ -550,3 +550,19 @@ def test_observe_with_mwa_beamformer_pointing():
     ia0 = RI.InterferometerArray(['a', 'b', 'c'], bl, ch, telescope={'id': 'mwa'}, skycoords='altaz', pointing_coords='altaz')
     ia0.observe((2457000.5, 0.0), {'Tnet': 200.0}, NP.ones(24), [90.0, 270.0], skymod, 112.0)
     assert not NP.allclose(ia0.skyvis_freq, ia.skyvis_freq)
+
+
+def test_device_polynomial_dish_beams_match_reference_golden():
+    """id 'vla' / 'gmrt' / 'ugmrt' on the device (PRISIM_BEAM_POLY) against the reference functions' output, and the reference's
+    ValueError when the polynomial leaves its range of validity (:510-512) or has no coefficients (:802-803)."""
+    import os
+    from conftest import GOLDEN
+    g = dict(NP.load(os.path.join(GOLDEN, 'golden_polybeams.npz')))
+    for name, tid in (('vla_L', 'vla'), ('vla_P', 'vla'), ('gmrt_610', 'gmrt'), ('ugmrt_325', 'ugmrt')):
+        pb = PB.primary_beam_generator(g['altaz_' + name], g['freq_' + name] / 1e9, {'id': tid}, freq_scale='GHz', skyunits='altaz')
+        assert NP.max(NP.abs(pb - g['pbg_' + name])) <= 1e-11, name       # the angle goes alt -> direction cosines -> angle
+    far = NP.array([[90.0, 0.0], [87.0, 10.0]])                    # 3 deg off axis at 610 MHz: the quartic term has taken over (1.6e4)
+    with pytest.raises(ValueError, match='exceeds unity'):
+        PB.primary_beam_generator(far, NP.array([0.61]), {'id': 'gmrt'}, freq_scale='GHz', skyunits='altaz')
+    with pytest.raises(ValueError, match='NaN'):
+        PB.primary_beam_generator(NP.array([[89.9, 0.0]]), NP.array([0.235]), {'id': 'ugmrt'}, freq_scale='GHz', skyunits='altaz')

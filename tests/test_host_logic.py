@@ -162,8 +162,17 @@ def test_device_beam_spec_dispatch():
         PB.device_beam_spec({'id': 'paper'}, short_dipole_approx=True, half_wave_dipole_approx=True)
     with pytest.raises(KeyError):
         PB.device_beam_spec({'id': 'paper', 'orientation': [0.0, 90.0]})
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                                              # the band is chosen from the first frequency
         PB.device_beam_spec({'id': 'vla'})
+    kind, size, bpc, ext = PB.device_beam_spec({'id': 'vla'}, first_frequency_hz=1.4e9)
+    assert kind == _abi.PRISIM_BEAM_POLY and NP.allclose(ext['poly'], [-1.343, 6.579, -1.186, 0.0])      # 1.465 GHz band (:494)
+    kind, size, bpc, ext = PB.device_beam_spec({'id': 'ugmrt'}, first_frequency_hz=0.61e9)
+    assert NP.allclose(ext['poly'], [-3.190, 38.642, -20.471, 3.964])
+    assert NP.all(NP.isnan(PB.poly_beam_coefficients('ugmrt', 0.2e9)))           # no uGMRT polynomial at 235 MHz (:786)
+    with pytest.raises(KeyError):
+        PB.device_beam_spec({'id': 'gmrt_x'}, first_frequency_hz=0.61e9)
+    with pytest.raises(NotImplementedError):
+        PB.device_beam_spec({'shape': 'rect', 'size': [3.0, 4.0]})
     with pytest.raises(TypeError):                                               # the reference wants a numpy array (:1616-1617)
         PB.device_beam_spec({'id': 'mwa'}, pointing_info={'delays': [0] * 16})
 

@@ -155,3 +155,17 @@ def test_beamformer_matches_reference_function():
     pb = BO.composite_power_beam(dc, f, element='dipole', size=1.5, element_dircos=g['tilt'],
                                  beamformer={'positions': irr, 'delays': d, 'gains': gn, 'single': True})
     assert NP.max(NP.abs(pb - g['pbg_dipole_elements_pointed'])) <= tol
+
+
+def test_polynomial_dish_beams_match_reference_functions():
+    """VLA_primary_beam_PBCOR / GMRT_primary_beam through primary_beam_generator (primary_beams.py:445-513, 734-808, 225-238)."""
+    import os
+    from conftest import GOLDEN
+    from prisim_amd import primary_beams as PB
+    g = dict(NP.load(os.path.join(GOLDEN, 'golden_polybeams.npz')))
+    for name, tid in (('vla_L', 'vla'), ('vla_P', 'vla'), ('gmrt_610', 'gmrt'), ('ugmrt_325', 'ugmrt')):
+        f = g['freq_' + name]
+        coef = PB.poly_beam_coefficients(tid, f[0])
+        pb = BO.polynomial_beam(coef, 90.0 - g['altaz_' + name][:, 0], f)
+        assert NP.max(NP.abs(pb - g['pbg_' + name])) <= 1e-13, name
+        assert pb[0, 0] == 1.0
