@@ -55,7 +55,7 @@ DEFAULTS = {
     'processing': {'gradient_mode': None, 'f_pad': 1.0, 'bpass_shape': 'bhw', 'delay_transform': False, 'memsave': False},
     'pp': {'key': 'bl', 'eqvol': True},
     'save_redundant': True,
-    'save_formats': {'npz': True},
+    'save_formats': {'npz': True, 'hdf5': False},
     'diagnosis': {'wait_after_run': False},
 }
 
@@ -352,6 +352,15 @@ def save(out, parms, infile=None):
             if extra in out:
                 keys[extra] = out[extra]
         NP.savez_compressed(path + '.npz', **keys)
+    if parms['save_formats'].get('hdf5', False) and out.get('ia') is not None:
+        # PRISim's HDF5 layout (interferometry.py:8717-8846) of this process's InterferometerArray, redundant baselines re-created
+        # first when asked for (run_prisim.py:2325-2326).  Single-process runs only: a sharded run gathers the cube, not the object.
+        ia = out['ia']
+        if len(ia.labels) != len(out['labels']) and not parms.get('save_redundant', True):
+            raise NotImplementedError('HDF5 output of a baseline-sharded run is not supported; use the gathered npz')
+        if parms.get('save_redundant', True) and ia.blgroups and len(ia.labels) < sum(len(v) for v in ia.blgroups.values()):
+            ia.duplicate_measurements()
+        ia.save(path, fmt='HDF5', npz=False, overwrite=True, verbose=False)
     metadir = os.path.join(ds['rootdir'], ds['project'], simid, 'metainfo')
     os.makedirs(metadir, exist_ok=True)
     with open(os.path.join(metadir, 'simparms.yaml'), 'w') as f:                                            # run_prisim.py:2213-2220

@@ -770,6 +770,120 @@ class InterferometerArray(object):
                 self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
 
     # ------------------------------------------------------------------------------------------
+    def save(self, outfile, fmt='HDF5', tabtype='BinTableHDU', npz=True, overwrite=False, uvfits_parms=None, verbose=True):
+        """Write the object to disk in PRISim's HDF5 layout (interferometry.py:8393-8863; groups and dataset names of
+        :8723-8846) and, with npz, the reference's NPZ summary (:8854-8857).  HDF5 goes through the HDF5 C library
+        (prisim_amd/hdf5io.py; no h5py here); FITS and UVFITS need astropy / pyuvdata and are not written."""
+        if not isinstance(outfile, str):
+            raise TypeError('outfile must be a string')
+        if fmt.lower() not in ('hdf5', 'fits'):
+            raise ValueError('Invalid output file format specified')
+        if fmt.lower() == 'fits':
+            raise NotImplementedError('FITS output needs astropy, which this build does not carry; use fmt="HDF5"')
+        if uvfits_parms is not None:
+            raise NotImplementedError('UVFITS output needs pyuvdata / astropy, which this build does not carry')
+        from . import hdf5io
+        filename = outfile + '.hdf5'
+        if verbose:
+            print('\nSaving information about interferometer...')
+        tel = self.telescope
+        with hdf5io.File(filename, 'w' if overwrite else 'w-') as f:
+            f.create_group('header')
+            f.write('header/AstroUtils#', 'none (prisim_amd)')
+            f.write('header/PRISim#', 'prisim_amd')
+            f.write('header/flux_unit', self.flux_unit)
+            f.write('telescope_parms/latitude', float(self.latitude), attrs={'units': 'deg'})
+            f.write('telescope_parms/longitude', float(self.longitude), attrs={'units': 'deg'})
+            f.write('telescope_parms/altitude', float(self.altitude), attrs={'units': 'm'})
+            if 'id' in tel:
+                f.write('telescope_parms/id', str(tel['id']))
+            f.write('spectral_info/freq_resolution', float(self.freq_resolution), attrs={'units': 'Hz'})
+            f.write('spectral_info/freqs', self.channels, attrs={'units': 'Hz'})
+            if self.lags is not None:
+                f.write('spectral_info/lags', self.lags, attrs={'units': 's'})
+            f.write('spectral_info/bp', self.bp)
+            f.write('spectral_info/bp_wts', self.bp_wts)
+            if self.simparms_file is not None:
+                f.write('simparms/simfile', self.simparms_file)
+            f.create_group('antenna_element')
+            for key in ('shape', 'ocoords'):
+                if tel.get(key) is not None:
+                    f.write('antenna_element/' + key, str(tel[key]))
+            if tel.get('size') is not None:
+                f.write('antenna_element/size', NP.asarray(tel['size'], dtype=NP.float64), attrs={'units': 'm'})
+            if tel.get('orientation') is not None:
+                f.write('antenna_element/orientation', NP.asarray(tel['orientation'], dtype=NP.float64),
+                        attrs=({'units': 'deg'} if tel.get('ocoords') != 'dircos' else None))
+            if tel.get('groundplane') is not None:
+                f.write('antenna_element/groundplane', float(tel['groundplane']))
+            if self.layout:
+                f.write('layout/positions', NP.asarray(self.layout['positions'], dtype=NP.float64),
+                        attrs={'units': 'm', 'coords': str(self.layout['coords'])})
+                f.write('layout/labels', NP.asarray(self.layout['labels']))
+                f.write('layout/ids', NP.asarray(self.layout['ids']))
+            f.write('timing/t_obs', float(self.t_obs))
+            f.write('timing/n_acc', int(self.n_acc))
+            if self.t_acc:
+                f.write('timing/t_acc', NP.asarray(self.t_acc, dtype=NP.float64))
+            f.write('timing/timestamps', NP.asarray(self.timestamp))
+            f.write('skyparms/pointing_coords', str(self.pointing_coords))
+            f.write('skyparms/phase_center_coords', str(self.phase_center_coords))
+            f.write('skyparms/skycoords', str(self.skycoords))
+            f.write('skyparms/LST', NP.asarray(self.lst, dtype=NP.float64).ravel(), attrs={'units': 'deg'})
+            f.write('skyparms/pointing_center', NP.asarray(self.pointing_center, dtype=NP.float64))
+            f.write('skyparms/phase_center', NP.asarray(self.phase_center, dtype=NP.float64))
+            labels = self.labels
+            if len(labels) and isinstance(labels[0], (tuple, list)):                    # (A2, A1) antenna-pair records like the reference's
+                width = max(max(len(str(a)), len(str(b))) for a, b in labels)
+                labels = NP.asarray([(str(a).encode(), str(b).encode()) for a, b in labels], dtype=[('A2', 'S%d' % width), ('A1', 'S%d' % width)])
+            else:
+                labels = NP.asarray([str(l) for l in labels])
+            f.write('array/labels', labels)
+            f.write('array/baselines', self.baselines, attrs={'coords': 'local-ENU', 'units': 'm'})
+            f.write('array/baseline_coords', str(self.baseline_coords))
+            if self.projected_baselines is not None:
+                f.write('array/projected_baselines', self.projected_baselines, attrs={'coords': 'eq-XYZ', 'units': 'm'})
+            f.write('instrument/effective_area', self.A_eff, attrs={'units': 'm^2'})
+            f.write('instrument/efficiency', self.eff_Q)
+            if self.Tsysinfo:
+                def col(get):
+                    return NP.asarray([get(elem) for elem in self.Tsysinfo], dtype=NP.float64)
+                nan = float('nan')
+                f.write('instrument/Trx', col(lambda e: e.get('Trx') if e.get('Trx') is not None else nan), attrs={'units': 'K'})
+                f.write('instrument/Tant0', col(lambda e: (e.get('Tant') or {}).get('T0', nan)), attrs={'units': 'K'})
+                f.write('instrument/f0', col(lambda e: (e.get('Tant') or {}).get('f0', nan)), attrs={'units': 'Hz'})
+                f.write('instrument/spindex', col(lambda e: (e.get('Tant') or {}).get('spindex', nan)))
+                f.write('instrument/Tnet', col(lambda e: e['Tnet'] if e.get('Tnet') is not None else -999), attrs={'units': 'K'})
+            f.write('instrument/Tsys', self.Tsys, attrs={'units': 'K'})
+            f.create_group('visibilities/freq_spectrum')
+            for name, arr in (('rms', self.vis_rms_freq), ('vis', self.vis_freq), ('skyvis', self.skyvis_freq), ('noise', self.vis_noise_freq)):
+                if arr is not None:
+                    f.write('visibilities/freq_spectrum/' + name, arr, attrs={'units': 'Jy'})
+            f.create_group('visibilities/delay_spectrum')
+            for name, arr in (('vis', self.vis_lag), ('skyvis', self.skyvis_lag), ('noise', self.vis_noise_lag)):
+                if arr is not None:
+                    f.write('visibilities/delay_spectrum/' + name, arr, attrs={'units': 'Jy Hz'})
+            if self.gradient_mode is not None:
+                for key, arr in self.gradient.items():
+                    f.write('gradients/' + str(key), arr)
+            if self.blgroups is not None:
+                f.create_group('blgroupinfo/groups')
+                f.create_group('blgroupinfo/reversemap')
+                for key, members in self.blgroups.items():
+                    f.write('blgroupinfo/groups/' + str(key).replace('/', '|'), NP.asarray([str(m) for m in members]))
+                for key, val in (self.bl_reversemap or {}).items():
+                    f.write('blgroupinfo/reversemap/' + str(key).replace('/', '|'), NP.asarray([str(val)]))
+        if verbose:
+            print('\tInterferometer array information written successfully to file on disk:\n\t\t{0}\n'.format(filename))
+        if npz:
+            keys = {'skyvis_freq': self.skyvis_freq, 'lst': self.lst, 'freq': self.channels, 'timestamp': self.timestamp,
+                    'bl': self.baselines, 'bl_length': self.baseline_lengths}                              # :8857
+            if (self.vis_freq is not None) and (self.vis_noise_freq is not None):                         # :8855
+                keys.update({'vis_freq': self.vis_freq, 'vis_noise_freq': self.vis_noise_freq})
+            NP.savez_compressed(outfile + '.npz', **keys)
+        return filename
+
+    # ------------------------------------------------------------------------------------------
     def duplicate_measurements(self, blgroups=None):
         """Re-create the redundant baselines from the simulated unique ones (interferometry.py:6823-6906): every baseline whose
         label is a key of `blgroups` is repeated once per member of its group (visibilities, gradient, baselines, per-baseline

@@ -194,3 +194,19 @@ def test_config2_unique_baselines_then_save_redundant(tmp_path):
     p_u['save_redundant'] = False
     p_u['dirstruct']['simid'] = 'uniq_only'
     assert NP.load(driver.save(out_u, p_u))['skyvis_freq'].shape == (30, 256, 2)
+    # PRISim's HDF5 file of the same run, redundant baselines re-created by InterferometerArray.duplicate_measurements
+    from prisim_amd import hdf5io
+    try:
+        hdf5io._load()
+    except hdf5io.HDF5Unavailable:
+        return
+    p_u['save_redundant'] = True
+    p_u['save_formats']['hdf5'] = True
+    p_u['dirstruct']['simid'] = 'uniq_hdf5'
+    with pytest.warns(UserWarning):
+        npz = driver.save(out_u, p_u)
+    with hdf5io.File(npz[:-4] + '.hdf5', 'r') as f:
+        cube = f.read('visibilities/freq_spectrum/skyvis')
+        assert cube.shape == (171, 256, 2) and f.read('array/baselines').shape == (171, 3) and f.read('array/labels').shape == (171,)
+        assert f.exists('blgroupinfo/groups') and f.read('visibilities/freq_spectrum/noise').shape == (171, 256, 2)
+    assert NP.array_equal(NP.sort_complex(cube[:, 0, 0]), NP.sort_complex(f_u['skyvis_freq'][:, 0, 0]))

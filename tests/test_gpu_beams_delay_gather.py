@@ -1,5 +1,7 @@
 """GPU (-m gpu): fused device beams, rocFFT delay transform, single-rank all-gather, and the
 InterferometerArray drop-in -- all through the C-ABI."""
+import os
+
 import numpy as NP
 import pytest
 
@@ -566,3 +568,48 @@ def test_device_polynomial_dish_beams_match_reference_golden():
         PB.primary_beam_generator(far, NP.array([0.61]), {'id': 'gmrt'}, freq_scale='GHz', skyunits='altaz')
     with pytest.raises(ValueError, match='NaN'):
         PB.primary_beam_generator(NP.array([[89.9, 0.0]]), NP.array([0.235]), {'id': 'ugmrt'}, freq_scale='GHz', skyunits='altaz')
+
+
+def test_interferometer_array_save_hdf5_layout(tmp_path):
+    """InterferometerArray.save: PRISim's HDF5 groups / datasets (interferometry.py:8723-8846) through the ctypes HDF5 writer."""
+    from prisim_amd import hdf5io
+    try:
+        hdf5io._load()
+    except hdf5io.HDF5Unavailable:
+        pytest.skip('the HDF5 C library is not installed')
+    ch = 150e6 + NP.arange(16) * 1e5
+    bl = NP.array([[14.6, 0.0, 0.0], [0.0, 29.2, 0.0]])
+    skymod = SM.SkyModel(location=[[80.0, 100.0], [50.0, 10.0]], flux_ref=[1.0, 3.0], spindex=[0.0, -0.7], ref_freq=150e6)
+    ia = RI.InterferometerArray([('a1', 'a0'), ('a2', 'a0')], bl, ch, telescope={'id': 'hera', 'shape': 'dish', 'size': 14.0, 'orientation': [90.0, 270.0], 'ocoords': 'altaz'},
+                                skycoords='altaz', pointing_coords='altaz', A_eff=154.0, eff_Q=0.96, latitude=-30.72)
+    for j in range(2):
+        ia.observe((2457000.5 + j, 15.0 * j), {'Tnet': 300.0}, NP.ones(16), [90.0, 270.0], skymod, 60.0)
+    ia.generate_noise(seed=3)
+    with pytest.warns(UserWarning):
+        ia.add_noise()
+    ia.delay_transform(pad=0.0, verbose=False)
+    out = str(tmp_path / 'simvis')
+    fname = ia.save(out, fmt='HDF5', npz=True, overwrite=False, verbose=False)
+    assert fname == out + '.hdf5' and os.path.exists(out + '.npz')
+    with hdf5io.File(fname, 'r') as f:
+        assert f.read('header/flux_unit') == 'JY' and f.read('telescope_parms/id') == 'hera'
+        assert f.read('telescope_parms/latitude') == -30.72 and f.read_attr('telescope_parms/latitude', 'units') == 'deg'
+        assert NP.array_equal(f.read('spectral_info/freqs'), ch) and NP.array_equal(f.read('spectral_info/lags'), ia.lags)
+        assert f.read('timing/n_acc') == 2 and NP.array_equal(f.read('timing/t_acc'), [60.0, 60.0])
+        assert NP.array_equal(f.read('skyparms/LST'), [0.0, 15.0]) and f.read('skyparms/skycoords') == 'altaz'
+        lab = f.read('array/labels')
+        assert lab.dtype.names == ('A2', 'A1') and lab[1][0] == b'a2'
+        assert NP.array_equal(f.read('array/baselines'), bl) and f.read_attr('array/baselines', 'units') == 'm'
+        for name, arr in (('skyvis', ia.skyvis_freq), ('vis', ia.vis_freq), ('noise', ia.vis_noise_freq), ('rms', ia.vis_rms_freq)):
+            assert NP.array_equal(f.read('visibilities/freq_spectrum/' + name), arr), name
+        assert NP.array_equal(f.read('visibilities/delay_spectrum/skyvis'), ia.skyvis_lag)
+        assert f.read_attr('visibilities/delay_spectrum/skyvis', 'units') == 'Jy Hz'
+        assert NP.array_equal(f.read('instrument/Tnet'), [300.0, 300.0]) and f.read('instrument/Tsys').shape == ia.Tsys.shape
+    z = NP.load(out + '.npz')
+    assert NP.array_equal(z['skyvis_freq'], ia.skyvis_freq) and NP.array_equal(z['vis_freq'], ia.vis_freq)
+    with pytest.raises(IOError):
+        ia.save(out, fmt='HDF5', npz=False, overwrite=False, verbose=False)          # exists
+    with pytest.raises(NotImplementedError):
+        ia.save(out, fmt='FITS', verbose=False)
+    with pytest.raises(ValueError):
+        ia.save(out, fmt='CSV', verbose=False)
