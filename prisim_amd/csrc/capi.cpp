@@ -252,29 +252,20 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   const int64_t nchunks = pl.nsrc_pad / chunk;
   if (nsplit == 0) {
     const int64_t base = (int64_t)pl.ntiles * pl.nbgroups;
+    // resident blocks per CU = waves per SIMD the kernels are built for (PK_WAVES / WavesPerEU in skyvis_kernels.hip)
+    const int per_cu = pl.pk ? 2 : (pl.f32 ? 4 : (ct <= 8 ? 4 : (ct <= 16 ? 3 : 2)));
+    const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * per_cu;
+    // The grid runs in rounds of `slots` resident blocks.  Measured on 1/2, 1/4 and 1/8 baseline shards of config 3
+    // (tools/shard_nsplit_sweep.py): the step time is lowest when the sources are split so that the grid is again about
+    // 7.5 rounds deep, like the unsplit full problem (nsplit = 2 / 4 / 8: 98 / 98 / 96 % of ideal against 96 / 90 / 85 %
+    // unsplit) -- blocks then start and finish out of step and the tail is short; each extra split costs ~0.5 % in partial-cube
+    // traffic, so deeper grids lose again.  Problems that are already >= 6 rounds deep keep nsplit = 1.
     nsplit = 1;
-    if (base < 1024) {
-      // Small / mid-size problems: split the sources so that the grid has >= 2 rounds of blocks, and among the
-      // candidates pick the smallest split whose last round is (nearly) full: the grid runs in rounds of
-      // slots = CUs x resident blocks per CU, and e.g. 1152 blocks on 512 slots = 2.25 rounds waste a quarter of the
-      // third round, while 1536 = 3.0 rounds waste nothing.
-      // resident blocks per CU = waves per SIMD the kernels are built for (WavesPerEU in skyvis_kernels.hip)
-      const int per_cu = pl.pk ? 2 : (pl.f32 ? 4 : (ct <= 8 ? 4 : (ct <= 16 ? 3 : 2)));
-      const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * per_cu;
-      const int lo = (int)std::min<int64_t>((1024 + base - 1) / base, nchunks);
-      const int hi = (int)std::min<int64_t>(std::min<int64_t>(4 * (int64_t)lo, 64), nchunks);
-      nsplit = std::max(lo, 1);
-      double best_eff = -1.0;
-      for (int cand = std::max(lo, 1); cand <= std::max(hi, 1); ++cand) {
-        const double rounds = (double)(base * cand) / (double)slots;
-        const double eff = rounds >= 1.0 ? rounds / std::ceil(rounds) : rounds;
-        if (eff > best_eff + 0.03) { best_eff = eff; nsplit = cand; }     // prefer the smaller split unless clearly better
-      }
-      if (nsplit > 64) nsplit = 64;
+    if (base * 10 < slots * 60) {
+      int64_t want = (slots * 15 / 2 + base / 2) / base;                 // round(7.5 * slots / base)
+      want = std::min<int64_t>(want, std::max<int64_t>(1, nsrc / 32));     // keep >= 32 sources per split
+      nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, 64));
     }
-    // Large problems keep nsplit = 1: splitting the sources to shorten the last, partly filled round of blocks
-    // (3824 blocks on 512 slots = 7.47 rounds at the time) was measured at +1.5 % only and costs two extra passes over the
-    // cube (partial slabs + reduce), i.e. 3x the algorithmic HBM traffic.
   }
   if (nsplit > nchunks) nsplit = (int)nchunks;
   if (nsplit < 1) nsplit = 1;
