@@ -627,7 +627,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       //    rho_g = r * exp2(B + C (16 g + 8)) (up), conj(r) * exp2(-B + C (16 g + 10)) (down), which is exact at the group ends and
       //    low by exp2(C m (8 - m)) at step m inside; that known parabola is put back on the (wave-uniform) pbflux operand,
       //    p_eff = p + p * (-ln2 C m (8 - m)): 1 packed FMA on 7 of 8 steps instead of 2 on every step, and rho_g moves to the next
-      //    group with 2 (exact re-formation every 16 steps).  Residual: (ln2 C m(8-m))^2 / 2 relative to the term; the host only
+      //    group with 2.  Residual: (ln2 C m(8-m))^2 / 2 relative to the term; the host only
       //    selects this form when that is < 1e-8 of sum|pbflux| for every possible source (df / f_min <= 3.4e-3).
       f32x2 rho_re = RR, rho_im = {ri, -ri}, HM = {0.f, 0.f};
       f32x2 EK[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -655,7 +655,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           EK[3] = (f32x2){16.f * c, 16.f * c};
         }
       }
-      constexpr int RESEED = TGROUP ? 16 : 8;
+      constexpr int RESEED = TGROUP ? HC : 8;             // grouped form: rho_0 exact, the (at most 3) later groups by multiplication
 
       auto pairs = [&](const float (&r)[NP], int jbase) {
 #pragma unroll
