@@ -129,8 +129,16 @@ struct prisim_ctx {
   int ext_nside = 0;
 
   // events / timing
-  hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
-  bool timing_pending = false;
+  // hipEvent timing of compute(): a ring of event quadruples so that back-to-back compute() calls queue on the stream without
+  // a host synchronisation; completed entries are harvested in order (lazily, or at sync / get_timing)
+  static constexpr int kTimingRing = 16;
+  hipEvent_t ev_c0[kTimingRing] = {}, ev_c1[kTimingRing] = {}, ev_k0[kTimingRing] = {}, ev_k1[kTimingRing] = {};
+  int ring_head = 0;            // next entry to record
+  int ring_pending = 0;         // recorded, not yet harvested (oldest = head - pending)
+  // lifting flags of the last compute (host copy stays alive for the asynchronous upload) and what they were computed for
+  std::vector<int32_t> lift_host;
+  double lift_key_k = -1.0;
+  int lift_key_f32 = -1;
   prisim_timing timing{};
 
   // tuning overrides
@@ -189,17 +197,24 @@ void release(DevBuf& b) {
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-// Collect the pending hipEvent timings of the last compute() (requires the stream to be idle).
-void harvest_timing(prisim_ctx* ctx) {
-  if (!ctx->timing_pending) return;
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, ctx->ev_c0, ctx->ev_c1) == hipSuccess) ctx->timing.last_compute_ms = ms;
-  if (hipEventElapsedTime(&ms, ctx->ev_k0, ctx->ev_k1) == hipSuccess) {
-    ctx->timing.last_kernel_ms = ms;
-    ctx->timing.sum_kernel_ms += ms;
-    ctx->timing.n_kernel += 1;
+// Collect the hipEvent timings of finished compute() calls, oldest first.  wait = true: block until every recorded entry is done.
+void harvest_timing(prisim_ctx* ctx, bool wait = true) {
+  while (ctx->ring_pending > 0) {
+    const int i = (ctx->ring_head - ctx->ring_pending + 2 * prisim_ctx::kTimingRing) % prisim_ctx::kTimingRing;
+    if (wait) {
+      if (hipEventSynchronize(ctx->ev_c1[i]) != hipSuccess) { ctx->ring_pending = 0; return; }
+    } else if (hipEventQuery(ctx->ev_c1[i]) != hipSuccess) {
+      return;
+    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_c0[i], ctx->ev_c1[i]) == hipSuccess) ctx->timing.last_compute_ms = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev_k0[i], ctx->ev_k1[i]) == hipSuccess) {
+      ctx->timing.last_kernel_ms = ms;
+      ctx->timing.sum_kernel_ms += ms;
+      ctx->timing.n_kernel += 1;
+    }
+    ctx->ring_pending -= 1;
   }
-  ctx->timing_pending = false;
 }
 
 struct Plan {
@@ -295,11 +310,16 @@ int prisim_hip_create(int device, prisim_ctx** out) {
   prisim_ctx* ctx = new (std::nothrow) prisim_ctx();
   if (!ctx) return fail(nullptr, PRISIM_ENOMEM, "out of host memory");
   ctx->device = device;
-  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-      (e = hipEventCreate(&ctx->ev_c0)) != hipSuccess || (e = hipEventCreate(&ctx->ev_c1)) != hipSuccess ||
-      (e = hipEventCreate(&ctx->ev_k0)) != hipSuccess || (e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) {
+  e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreate(&ctx->stream);
+  for (int i = 0; i < prisim_ctx::kTimingRing && e == hipSuccess; ++i) {
+    if ((e = hipEventCreate(&ctx->ev_c0[i])) != hipSuccess || (e = hipEventCreate(&ctx->ev_c1[i])) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_k0[i])) != hipSuccess || (e = hipEventCreate(&ctx->ev_k1[i])) != hipSuccess)
+      break;
+  }
+  if (e != hipSuccess) {
     std::string m = std::string("HIP context setup failed: ") + hipGetErrorString(e);
-    delete ctx;
+    prisim_hip_destroy(ctx);
     return fail(nullptr, PRISIM_ENODEV, m);
   }
   hipDeviceProp_t prop;
@@ -327,8 +347,9 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
                     &ctx->ext_work, &ctx->ext_colmax,
                     &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts})
     release(*b);
-  for (hipEvent_t ev : {ctx->ev_c0, ctx->ev_c1, ctx->ev_k0, ctx->ev_k1})
-    if (ev) (void)hipEventDestroy(ev);
+  for (int i = 0; i < prisim_ctx::kTimingRing; ++i)
+    for (hipEvent_t ev : {ctx->ev_c0[i], ctx->ev_c1[i], ctx->ev_k0[i], ctx->ev_k1[i]})
+      if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -369,6 +390,7 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->h_freqs.assign(freqs_hz, freqs_hz + nchan);
   ctx->grp_maxlen.assign((size_t)((nbl + kBlockThreads - 1) / kBlockThreads), 0.0);
+  ctx->lift_key_k = -1.0;                                  // the cached lifting flags belong to the previous array
   for (int64_t b = 0; b < nbl; ++b) {
     const double len = std::sqrt(x[b] * x[b] + y[b] * y[b] + z[b] * z[b]);
     double& m = ctx->grp_maxlen[(size_t)(b / kBlockThreads)];
@@ -691,21 +713,21 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   }
   if (pl.kernel == PRISIM_KERNEL_DIRECT) {
     p.out = dst;
-    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
     HIPCHK(ctx, launch_skyvis_direct(p, (const double*)ctx->freqs.p, (const double*)ctx->pb.p,
                                      scale_comp >= 0 ? (const double*)ctx->dirs.p : nullptr, ctx->stream));
-    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
     return PRISIM_OK;
   }
   HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
                           pl.ntiles, (const double*)ctx->dirs.p, scale_comp, 1, ctx->stream));
   p.out = pl.nsplit > 1 ? (double*)ctx->partial.p : dst;
-  if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+  if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
   if (pl.pk)
     HIPCHK(ctx, launch_skyvis_rec_f32pk(p, pl.ct, ctx->stream));
   else
     HIPCHK(ctx, launch_skyvis_rec(p, pl.f32, pl.ct, ctx->stream));
-  if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
   if (pl.nsplit > 1)
     HIPCHK(ctx, launch_reduce_partials((const double*)ctx->partial.p, dst, ctx->nbl * ctx->nchan * 2, pl.nsplit, ctx->stream));
   return PRISIM_OK;
@@ -720,7 +742,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   if (kernel == PRISIM_KERNEL_RECURRENCE && !ctx->uniform)
     return fail(ctx, PRISIM_EINVAL, "recurrence kernel needs a uniform channel grid");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (ctx->timing_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); harvest_timing(ctx); }
+  harvest_timing(ctx, /*wait=*/ctx->ring_pending >= prisim_ctx::kTimingRing);     // frees the oldest entry only when the ring is full
   const size_t slot_elems = (size_t)ctx->nbl * ctx->nchan * 2;
   double* dst = (double*)ctx->cube.p + (size_t)slot * slot_elems;
   int rc;
@@ -750,24 +772,29 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
       // lifting rotation is used for a baseline group only when |step phase| <= 1/8 cycle (fp32; 1/4 cycle in fp64, where the
       // angle error alpha*eps is irrelevant and only tan(alpha/2) must stay bounded) is guaranteed for every source:
       // |theta| = |b . (s - s_pc)| |df| / c <= max|b| * max_s|s - s_pc| * |df| / c
-      std::vector<int32_t> flags((size_t)pl.nbgroups, 0);
       const double k = ctx->dmax * std::fabs(ctx->df) / kC;
-      int nlift = 0;
-      for (int g = 0; g < pl.nbgroups; ++g) {
-        flags[(size_t)g] = (ctx->grp_maxlen[(size_t)g] * k <= (pl.f32 ? 0.125 : 0.25) * (1.0 - 1e-9)) ? 1 : 0;
-        nlift += flags[(size_t)g];
+      if (k != ctx->lift_key_k || (int)pl.f32 != ctx->lift_key_f32 || ctx->lift_host.size() != (size_t)pl.nbgroups) {
+        // the host copy is rewritten: an upload of the previous flags may still be reading it
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->lift_host.assign((size_t)pl.nbgroups, 0);
+        for (int g = 0; g < pl.nbgroups; ++g)
+          ctx->lift_host[(size_t)g] = (ctx->grp_maxlen[(size_t)g] * k <= (pl.f32 ? 0.125 : 0.25) * (1.0 - 1e-9)) ? 1 : 0;
+        if ((rc = ensure(ctx, ctx->lift_flags, ctx->lift_host.size() * sizeof(int32_t)))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->lift_flags.p, ctx->lift_host.data(), ctx->lift_host.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        ctx->lift_key_k = k;
+        ctx->lift_key_f32 = (int)pl.f32;
       }
+      int nlift = 0;
+      for (int32_t v : ctx->lift_host) nlift += v;
       ctx->timing.last_lift_groups = nlift;
-      if ((rc = ensure(ctx, ctx->lift_flags, flags.size() * sizeof(int32_t)))) return rc;
-      HIPCHK(ctx, hipMemcpyAsync(ctx->lift_flags.p, flags.data(), flags.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // flags is a local
     }
     if (pl.f32 && ctx->taper) {
       if ((rc = ensure(ctx, ctx->fsq_pairs, (size_t)pl.ntiles * pl.ct * sizeof(float)))) return rc;
       HIPCHK(ctx, launch_fsq_pairs((const float*)ctx->fsq.p, (float*)ctx->fsq_pairs.p, pl.ct, pl.ntiles, ctx->stream));
     }
   }
-  HIPCHK(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_c0[ctx->ring_head], ctx->stream));
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE)
     HIPCHK(ctx, launch_prep_dirs((const double*)ctx->dirs.p, (double*)ctx->dirs_prep.p, ctx->nsrc, pl.nsrc_pad, ctx->pc[0],
                                  ctx->pc[1], ctx->pc[2], 1.0 / kC, ctx->stream));
@@ -778,8 +805,9 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
       if ((rc = run_pass(ctx, pl, gdst, comp, false))) return rc;
     }
   }
-  HIPCHK(ctx, hipEventRecord(ctx->ev_c1, ctx->stream));
-  ctx->timing_pending = true;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_c1[ctx->ring_head], ctx->stream));
+  ctx->ring_head = (ctx->ring_head + 1) % prisim_ctx::kTimingRing;
+  ctx->ring_pending += 1;
   ctx->timing.last_terms = ctx->nbl * ctx->nchan * ctx->nsrc;
   ctx->timing.last_kernel_id = pl.kernel;
   ctx->timing.last_chan_tile = pl.kernel == PRISIM_KERNEL_RECURRENCE ? pl.ct : 1;
@@ -852,9 +880,8 @@ int prisim_hip_sync(prisim_ctx* ctx) {
 int prisim_hip_get_timing(prisim_ctx* ctx, prisim_timing* out, int reset) {
   if (!ctx) return PRISIM_EINVAL;
   if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
-  if (ctx->timing_pending) {
+  if (ctx->ring_pending > 0) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     harvest_timing(ctx);
   }
   *out = ctx->timing;
