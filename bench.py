@@ -108,6 +108,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    # Libraries loaded later (RCCL prints a version banner on its first communicator) write to fd 1: keep the real stdout for
+    # the ONE JSON line of the contract and send everything else to stderr.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -260,7 +266,8 @@ def main():
                 out['parity_max_err_rel_sumflux'] = float(NP.max(NP.abs(gpu - ref) / scale))
             except Exception as exc:   # the baseline is a report, never a reason to lose the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'terms/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
     ctx.close()
     if dist is not None:
         dist.barrier()
