@@ -274,13 +274,14 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
     // (tools/shard_nsplit_sweep.py): the step time is lowest when the sources are split so that the grid is again about
     // 7.5 rounds deep, like the unsplit full problem (nsplit = 2 / 4 / 8: 98 / 98 / 96 % of ideal against 96 / 90 / 85 %
     // unsplit) -- blocks then start and finish out of step and the tail is short; each extra split costs ~0.5 % in partial-cube
-    // traffic, so deeper grids lose again.  Problems that are already >= 6 rounds deep keep nsplit = 1.
+    // traffic, so deeper grids lose again.  A grid that is 6 ... 12 rounds deep unsplit (the full config 3: 7.5) still gains 2 %
+    // from two splits (its blocks then finish out of step; 58.7 -> 57.5 ms, tools/full_nsplit.py); deeper ones keep nsplit = 1.
     nsplit = 1;
-    if (base * 10 < slots * 60) {
-      int64_t want = (slots * 15 / 2 + base / 2) / base;                 // round(7.5 * slots / base)
-      want = std::min<int64_t>(want, std::max<int64_t>(1, nsrc / 32));     // keep >= 32 sources per split
-      nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, 64));
-    }
+    int64_t want = 1;
+    if (base * 10 < slots * 60) want = (slots * 15 / 2 + base / 2) / base;       // round(7.5 * slots / base)
+    else if (base * 10 < slots * 120) want = 2;
+    want = std::min<int64_t>(want, std::max<int64_t>(1, nsrc / 32));             // keep >= 32 sources per split
+    nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, 64));
   }
   if (nsplit > nchunks) nsplit = (int)nchunks;
   if (nsplit < 1) nsplit = 1;
@@ -722,6 +723,9 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
                           pl.ntiles, (const double*)ctx->dirs.p, scale_comp, 1, ctx->stream));
   p.out = pl.nsplit > 1 ? (double*)ctx->partial.p : dst;
+  // fp32 kernels whose splits each flush exactly once store their partial sums as complex64: half the partial traffic
+  const bool part_f32 = pl.nsplit > 1 && pl.f32 && pl.kernel == PRISIM_KERNEL_RECURRENCE && pl.src_per_split <= (int64_t)p.flush_src;
+  p.out_f32 = part_f32 ? 1 : 0;
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
   if (pl.pk)
     HIPCHK(ctx, launch_skyvis_rec_f32pk(p, pl.ct, ctx->stream));
@@ -729,7 +733,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     HIPCHK(ctx, launch_skyvis_rec(p, pl.f32, pl.ct, ctx->stream));
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
   if (pl.nsplit > 1)
-    HIPCHK(ctx, launch_reduce_partials((const double*)ctx->partial.p, dst, ctx->nbl * ctx->nchan * 2, pl.nsplit, ctx->stream));
+    HIPCHK(ctx, launch_reduce_partials(ctx->partial.p, part_f32, dst, ctx->nbl * ctx->nchan * 2, pl.nsplit, ctx->stream));
   return PRISIM_OK;
 }
 

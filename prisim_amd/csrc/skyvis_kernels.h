@@ -40,6 +40,8 @@ struct SkyvisParams {
   int32_t scale_comp;        // direct kernel: gradient component or -1
   int32_t taper_group;       // packed fp32 taper: 1 = grouped recurrence (valid when df/f_min <= 3.4e-3), 0 = exact per-step form
   double* out;               // [nsplit][nbl][nchan] complex128 (nsplit==1: the cube slot itself)
+  int32_t out_f32;           // 1: out is [nsplit][nbl][nchan] complex64 partial sums (fp32 run, every split flushes exactly once)
+  int32_t pad2_;
 };
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);
@@ -51,7 +53,7 @@ hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, i
                        int ntiles, const double* dirs, int scale_comp, int interleave, hipStream_t stream);
 hipError_t launch_prep_dirs(const double* dirs, double* prep, int64_t nsrc, int64_t nsrc_pad, double pcx, double pcy,
                             double pcz, double inv_c, hipStream_t stream);
-hipError_t launch_reduce_partials(const double* part, double* out, int64_t n2, int nsplit, hipStream_t stream);
+hipError_t launch_reduce_partials(const void* part, bool part_f32, double* out, int64_t n2, int nsplit, hipStream_t stream);
 hipError_t launch_f32_to_f64(const float* in, double* out, int64_t n, hipStream_t stream);
 hipError_t launch_fsq(const double* freqs, float* fsq, int64_t nchan, int64_t npad, double scale, hipStream_t stream);
 

@@ -249,10 +249,14 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
           const FV a = wbuf[bi * (FCH + 1) + c];
           const int64_t bb = bw0 + bi;
           if (bb < p.nbl && k < p.nchan) {
-            double2* o = reinterpret_cast<double2*>(out) + (size_t)bb * p.nchan + k;
-            double2 v = make_double2((double)a.x, (double)a.y);
-            if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
-            *o = v;
+            if (sizeof(T) == 4 && p.out_f32) {                     // complex64 partial of a source split: written once, no read-modify-write
+              reinterpret_cast<float2*>(p.out)[((size_t)split * p.nbl + (size_t)bb) * p.nchan + k] = make_float2((float)a.x, (float)a.y);
+            } else {
+              double2* o = reinterpret_cast<double2*>(out) + (size_t)bb * p.nchan + k;
+              double2 v = make_double2((double)a.x, (double)a.y);
+              if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
+              *o = v;
+            }
           }
           __builtin_amdgcn_sched_barrier(0);                       // one store at a time: the flush must fit beside 128 accumulators
         }
@@ -535,10 +539,14 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           const float2 a = wbuf[bi * 17 + c];
           const int64_t bb = bw0 + bi;
           if (bb < p.nbl && k < p.nchan) {
-            double2* o = out + (size_t)bb * p.nchan + k;
-            double2 v = make_double2((double)a.x, (double)a.y);
-            if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
-            *o = v;
+            if (p.out_f32) {                                       // complex64 partial of a source split: written once, no read-modify-write
+              reinterpret_cast<float2*>(p.out)[((size_t)split * p.nbl + (size_t)bb) * p.nchan + k] = a;
+            } else {
+              double2* o = out + (size_t)bb * p.nchan + k;
+              double2 v = make_double2((double)a.x, (double)a.y);
+              if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
+              *o = v;
+            }
           }
           __builtin_amdgcn_sched_barrier(0);                       // one store at a time: the flush must fit beside 128 accumulators
         }
@@ -871,11 +879,13 @@ __global__ void k_prep_dirs(const double* __restrict__ dirs, double* __restrict_
   }
 }
 
-// sum nsplit partial cubes [nsplit][n] (complex as 2 doubles) -> out[n]; deterministic order.
-__global__ void k_reduce_partials(const double* __restrict__ part, double* __restrict__ out, int64_t n2, int nsplit) {
+// sum nsplit partial cubes [nsplit][n] (complex as 2 doubles, or 2 floats for the fp32 kernels' single-flush partials) -> out[n];
+// deterministic order, fp64 sum.
+template <typename TP>
+__global__ void k_reduce_partials(const TP* __restrict__ part, double* __restrict__ out, int64_t n2, int nsplit) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
     double a = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) a += part[(size_t)sp * n2 + i];
+    for (int sp = 0; sp < nsplit; ++sp) a += (double)part[(size_t)sp * n2 + i];
     out[i] = a;
   }
 }
@@ -976,8 +986,11 @@ hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, i
   return hipGetLastError();
 }
 
-hipError_t launch_reduce_partials(const double* part, double* out, int64_t n2, int nsplit, hipStream_t stream) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(grid_for(n2)), dim3(256), 0, stream, part, out, n2, nsplit);
+hipError_t launch_reduce_partials(const void* part, bool part_f32, double* out, int64_t n2, int nsplit, hipStream_t stream) {
+  if (part_f32)
+    hipLaunchKernelGGL(k_reduce_partials<float>, dim3(grid_for(n2)), dim3(256), 0, stream, (const float*)part, out, n2, nsplit);
+  else
+    hipLaunchKernelGGL(k_reduce_partials<double>, dim3(grid_for(n2)), dim3(256), 0, stream, (const double*)part, out, n2, nsplit);
   return hipGetLastError();
 }
 
