@@ -274,12 +274,11 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
     // (tools/shard_nsplit_sweep.py): the step time is lowest when the sources are split so that the grid is again about
     // 7.5 rounds deep, like the unsplit full problem (nsplit = 2 / 4 / 8: 98 / 98 / 96 % of ideal against 96 / 90 / 85 %
     // unsplit) -- blocks then start and finish out of step and the tail is short; each extra split costs ~0.5 % in partial-cube
-    // traffic, so deeper grids lose again.  A grid that is 6 ... 12 rounds deep unsplit (the full config 3: 7.5) still gains 2 %
-    // from two splits (its blocks then finish out of step; 58.7 -> 57.5 ms, tools/full_nsplit.py); deeper ones keep nsplit = 1.
+    // traffic, so deeper grids lose again.  Problems that are already >= 6 rounds deep keep nsplit = 1 (alternating A/B on the
+    // full config 3, tools/full_nsplit.py: 1 / 2 / 4 splits within 0.4 % of each other).
     nsplit = 1;
     int64_t want = 1;
     if (base * 10 < slots * 60) want = (slots * 15 / 2 + base / 2) / base;       // round(7.5 * slots / base)
-    else if (base * 10 < slots * 120) want = 2;
     want = std::min<int64_t>(want, std::max<int64_t>(1, nsrc / 32));             // keep >= 32 sources per split
     nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, 64));
   }
