@@ -271,11 +271,11 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
     const int per_cu = pl.pk ? 2 : (pl.f32 ? 4 : (ct <= 8 ? 4 : (ct <= 16 ? 3 : 2)));
     const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * per_cu;
     // The grid runs in rounds of `slots` resident blocks.  Measured on 1/2, 1/4 and 1/8 baseline shards of config 3
-    // (tools/shard_nsplit_sweep.py): the step time is lowest when the sources are split so that the grid is again about
-    // 7.5 rounds deep, like the unsplit full problem (nsplit = 2 / 4 / 8: 98 / 98 / 96 % of ideal against 96 / 90 / 85 %
-    // unsplit) -- blocks then start and finish out of step and the tail is short; each extra split costs ~0.5 % in partial-cube
-    // traffic, so deeper grids lose again.  Problems that are already >= 6 rounds deep keep nsplit = 1 (alternating A/B on the
-    // full config 3, tools/full_nsplit.py: 1 / 2 / 4 splits within 0.4 % of each other).
+    // (tools/shard_nsplit_sweep.py, candidates alternating): the step time is lowest when the sources are split so that the grid
+    // is again about 7.5 rounds deep, like the unsplit full problem (nsplit = 2 / 4 / 8: 1.00 / 1.02 / 1.03 x the ideal T1/N
+    // against 1.03 / 1.06 / 1.10 x unsplit) -- blocks then start and finish out of step and the tail is short; every extra split
+    // costs partial-cube traffic, so much deeper grids lose again.  Problems that are already >= 6 rounds deep keep nsplit = 1
+    // (alternating A/B on the full config 3, tools/full_nsplit.py: 1 / 2 / 4 splits within 0.4 % of each other).
     nsplit = 1;
     int64_t want = 1;
     if (base * 10 < slots * 60) want = (slots * 15 / 2 + base / 2) / base;       // round(7.5 * slots / base)
