@@ -238,7 +238,14 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   const int64_t nbl = ctx->nbl, nchan = ctx->nchan, nsrc = ctx->nsrc;
   pl.nbgroups = (int)((nbl + kBlockThreads - 1) / kBlockThreads);
   // channel tile: largest tile that still yields enough blocks to fill 256 CUs x 4 blocks
-  const int max_ct = pl.f32 ? 64 : 32;
+  int max_ct = pl.f32 ? 64 : 32;
+  {
+    // coarse channel grids with the taper run the exact per-step amplitude recurrence (the grouped form needs df/f_min <= 3.4e-3,
+    // run_pass): its rounding grows with the chain length (5.8e-6 of one term at 32 steps and df/f = 3 %, tools/fuzz_parity.py),
+    // so such runs use 32-channel tiles (16 steps from the seed)
+    const double fmin = std::min(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
+    if (pl.f32 && ctx->taper && !(fmin > 0.0 && std::fabs(ctx->df) <= 3.4e-3 * fmin)) max_ct = 32;
+  }
   int ct = ctx->tune_ct;
   if (ct == 0) {
     ct = max_ct;
@@ -688,7 +695,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   p.pb_packed = ctx->packed.p;
   p.fsq = (const float*)ctx->fsq.p;
   p.fsq_pairs = (const float*)ctx->fsq_pairs.p;
-  p.lift_flags = (!ctx->taper && ctx->lift_flags.p) ? (const int32_t*)ctx->lift_flags.p : nullptr;
+  p.lift_flags = ctx->lift_flags.p ? (const int32_t*)ctx->lift_flags.p : nullptr;   // taper kernels: which groups need no re-anchoring
   p.fsq_scale = 1e16;
   p.nsrc = ctx->nsrc; p.nsrc_pad = pl.nsrc_pad;
   p.pc_x = ctx->pc[0]; p.pc_y = ctx->pc[1]; p.pc_z = ctx->pc[2];
@@ -771,7 +778,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;
     if ((rc = ensure(ctx, ctx->dirs_prep, (size_t)pl.nsrc_pad * 4 * sizeof(double)))) return rc;
     if (pl.nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)pl.nsplit * slot_elems * sizeof(double)))) return rc;
-    if (!ctx->taper) {
+    {
       // lifting rotation is used for a baseline group only when |step phase| <= 1/8 cycle (fp32; 1/4 cycle in fp64, where the
       // angle error alpha*eps is irrelevant and only tan(alpha/2) must stay bounded) is guaranteed for every source:
       // |theta| = |b . (s - s_pc)| |df| / c <= max|b| * max_s|s - s_pc| * |df| / c
@@ -790,7 +797,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
       }
       int nlift = 0;
       for (int32_t v : ctx->lift_host) nlift += v;
-      ctx->timing.last_lift_groups = nlift;
+      ctx->timing.last_lift_groups = ctx->taper ? 0 : nlift;       // with the taper the flags only select the re-anchored body
     }
     if (pl.f32 && ctx->taper) {
       if ((rc = ensure(ctx, ctx->fsq_pairs, (size_t)pl.ntiles * pl.ct * sizeof(float)))) return rc;

@@ -460,10 +460,30 @@ typedef const __attribute__((address_space(4))) float* cfloat_p;
 typedef const __attribute__((address_space(4))) double* cdouble_p;
 typedef const volatile __attribute__((address_space(4))) double* cvdouble_p;
 
-template <int CT, bool TAPER, bool LIFT, bool TGROUP = false>
+// exp2(D) - 1 to ~1e-8 absolute for the small per-step taper exponents of the grouped form: 5-term series in x = D ln2, clamped
+// to |x| <= 1.  The host selects the grouped form only for df/f_min <= 3.4e-3, where |x| >= 1/8 implies a taper weight below
+// 1.5e-8 on every channel of the tile, so the loss of accuracy (and the clamp) out there is immaterial.
+__device__ __forceinline__ float exp2m1_small(float D) {
+  const float x = __builtin_fminf(__builtin_fmaxf(D * 0.6931471805599453f, -1.0f), 1.0f);
+  float e = __builtin_fmaf(x, 8.3333333e-3f, 4.1666668e-2f);
+  e = __builtin_fmaf(e, x, 0.16666667f);
+  e = __builtin_fmaf(e, x, 0.5f);
+  e = __builtin_fmaf(e, x, 1.0f);
+  return e * x;
+}
+
+// REANCHOR (taper bodies): the rounding of the step factor rho is the same at every step of a chain, so the error of zeta grows
+// linearly with the step count.  Measured per term at the chain ends (32 steps, one source, tools/fuzz_parity.py and a single-source
+// sweep on HERA-350 baselines): 3.0e-6 on the up chain but 5.0-6.9e-6 on the down chain, whose amplitude ratio is > 1 (floats just
+// above 1 carry half the relative precision of floats just below), and more where the step angle is large (|alpha| ~ 1 rad on long
+// baselines).  5e-6 is the tolerance and a sky may be dominated by one source, so the chains are re-formed exactly at their
+// midpoint (hardware sin/cos of the fp64-reduced phase + one exp2): 1 = the down chain only (every taper run, ~4 % of its time),
+// 2 = both chains (baseline groups whose step angle is not guaranteed <= pi/4).
+template <int CT, bool TAPER, bool LIFT, bool TGROUP = false, int REANCHOR = 0>
 __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, unsigned char* flush_lds) {
   static_assert(!(TAPER && LIFT), "the taper-folded recurrence is a scaled rotation: no lifting form");
   static_assert(TAPER || !TGROUP, "TGROUP is a taper variant");
+  static_assert(TAPER || REANCHOR == 0, "REANCHOR is a taper variant");
   constexpr int HC = CT / 2;
   // pieces per row: halves (2 x 32 SGPRs at CT = 64) without the taper; quarters with it, whose extra wave-uniform state would
   // otherwise push the row buffers out of the ~100 SGPRs (48 v_readlane/v_writelane per source in the loop)
@@ -637,9 +657,10 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       //    p_eff = p + p * (-ln2 C m (8 - m)): 1 packed FMA on 7 of 8 steps instead of 2 on every step, and rho_g moves to the next
       //    group with 2.  Residual: (ln2 C m(8-m))^2 / 2 relative to the term; the host only
       //    selects this form when that is < 1e-8 of sum|pbflux| for every possible source (df / f_min <= 3.4e-3).
-      f32x2 rho_re = RR, rho_im = {ri, -ri}, HM = {0.f, 0.f};
+      const f32x2 RIC = {ri, -ri};                     // imaginary part of (r, conj r)
+      f32x2 rho_re = RR, rho_im = RIC, HM = {0.f, 0.f}, EQ = {0.f, 0.f};
       f32x2 EK[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-      float tB = 0.f, tC = 0.f;
+      float tB = 0.f, tC = 0.f, tA_keep = 0.f;
       if (TAPER) {
         const double tau = d + bpc;
         double gq = sv[3] * (bl2_c2 - tau * tau);
@@ -648,6 +669,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
         const float gqf = (float)gq;
         tB = gqf * kBf;
         tC = gqf * kCf;
+        tA_keep = tA;
         const float w_u0 = __builtin_amdgcn_exp2f(tA);                 // channel HC
         const float w_d0 = __builtin_amdgcn_exp2f(tA - tB + tC);       // channel HC-1
         zre = zre * (f32x2){w_u0, w_d0};
@@ -663,13 +685,28 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           EK[3] = (f32x2){16.f * c, 16.f * c};
         }
       }
-      constexpr int RESEED = TGROUP ? HC : 8;             // grouped form: rho_0 exact, the (at most 3) later groups by multiplication
+      constexpr int RESEED = 8;
 
       auto pairs = [&](const float (&r)[NP], int jbase) {
 #pragma unroll
         for (int jj = 0; jj < NP / 2; ++jj) {
           const int j = jbase + jj;
           f32x2 pp = {r[2 * jj], r[2 * jj + 1]};
+          if (REANCHOR != 0 && HC >= 32 && j == HC / 2) {
+            // exact zeta at channel HC - 1 - j (down) and, REANCHOR == 2, HC + j (up): phase d f, amplitude exp2(L(-1-j)) / exp2(L(j))
+            float cd, sd;
+            sincos_cycles_hw(d * (fc_hz - (double)(j + 1) * p.df), cd, sd);
+            const float wd = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)((j + 1) * (j + 1)), __builtin_fmaf(tB, -(float)(j + 1), tA_keep)));
+            zre.y = cd * wd;
+            zim.y = -(sd * wd);
+            if (REANCHOR == 2) {
+              float cu, su;
+              sincos_cycles_hw(d * (fc_hz + (double)j * p.df), cu, su);
+              const float wu = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(j * j), __builtin_fmaf(tB, (float)j, tA_keep)));
+              zre.x = cu * wu;
+              zim.x = -(su * wu);
+            }
+          }
           if (TGROUP) {
             constexpr int kmap[8] = {0, 0, 1, 2, 3, 2, 1, 0};          // m (8 - m) = 7, 12, 15, 16, 15, 12, 7 for m = 1..7
             const int m = j % 8;
@@ -690,15 +727,26 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
             const f32x2 nim = pkfma(zim, RR, -t1);
             zre = nre; zim = nim;
           } else {
-            if ((j % RESEED) == 0) {
-              // exact: per-step ratio at step j, or the mean ratio of the group starting at j
-              const float qu = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(TGROUP ? 2 * j + 8 : 2 * j + 1), tB));
-              const float qd = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(TGROUP ? 2 * j + 10 : 2 * j + 3), -tB));
+            if (TGROUP) {
+              // rho_g = r * q_g is applied 8 times with the SAME rounding error, and v_exp_f32's 1 ulp (6e-8 of a number just below
+              // 1, 1.2e-7 just above) plus a product rounding per group put 3.7e-6 / 5.0e-6 of one term on the ends of the up / down
+              // chains.  So q_g - 1 =: e_g is carried instead (accurate to ~1e-8: series at the first group, e_{g+1} = e_g + h + e_g h
+              // after that) and rho_g = r + r e_g is one FMA: what is left is the rounding of r and of rho itself.
+              if (j == 0) {
+                EQ = (f32x2){exp2m1_small(__builtin_fmaf(tC, 8.f, tB)), exp2m1_small(__builtin_fmaf(tC, 10.f, -tB))};
+              } else if ((j % 8) == 0) {
+                EQ = pkfma(EQ, HM, EQ + HM);                 // mean ratio of the next group: (1 + e)(1 + h) - 1, h = exp2(16 C) - 1
+              }
+              if ((j % 8) == 0) {
+                rho_re = pkfma(RR, EQ, RR);
+                rho_im = pkfma(RIC, EQ, RIC);
+              }
+            } else if ((j % RESEED) == 0) {
+              // exact per-step ratio at step j
+              const float qu = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(2 * j + 1), tB));
+              const float qd = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(2 * j + 3), -tB));
               rho_re = (f32x2){qu * rr, qd * rr};
               rho_im = (f32x2){qu * ri, -(qd * ri)};
-            } else if (TGROUP && (j % 8) == 0) {
-              rho_re = pkfma(rho_re, HM, rho_re);        // next group: mean ratio moves by exp2(16 C)
-              rho_im = pkfma(rho_im, HM, rho_im);
             }
             const f32x2 t0 = zim * rho_im;
             const f32x2 t1 = zre * rho_im;
@@ -758,10 +806,18 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
       return;
     }
   } else {
+    // lift_flags[bg] = 1: |step angle| <= pi/4 for every source of this baseline group; 0: re-anchor the chains at their midpoint
+    const int jblk = blockIdx.x >> 3;
+    const int bg = jblk % p.nbgroups;
+    const bool small_step = p.lift_flags != nullptr && p.lift_flags[bg] != 0;
     if (p.taper_group) {                      // launch-uniform, chosen by the host from df / f_min
-      skyvis_rec_f32pk_body<CT, true, false, true>(p, flush_lds);
-      return;
+      if (small_step) skyvis_rec_f32pk_body<CT, true, false, true, 0>(p, flush_lds);
+      else skyvis_rec_f32pk_body<CT, true, false, true, 2>(p, flush_lds);
+    } else {
+      if (small_step) skyvis_rec_f32pk_body<CT, true, false, false, 1>(p, flush_lds);
+      else skyvis_rec_f32pk_body<CT, true, false, false, 2>(p, flush_lds);
     }
+    return;
   }
   skyvis_rec_f32pk_body<CT, TAPER, false>(p, flush_lds);
 }

@@ -153,6 +153,32 @@ def test_fp32_taper_grouped_and_exact_recurrences(ctx, monkeypatch):
     ctx.set_tuning(0, 0, 0)
 
 
+@pytest.mark.parametrize('taper', [False, True])
+def test_fp32_single_source_worst_case_per_term(ctx, taper):
+    """One source, so nothing averages: the error of every (baseline, channel) term against the fp64 oracle must stay inside the
+    5e-6 tolerance on its own, on short (lifting / small-step) and long (re-anchored) HERA-350 baselines, at the ends of the
+    64-channel chains.  The recurrences' systematic per-step rounding is what this pins (3.0e-6 measured; 6.9e-6 before the
+    amplitude ratio of the taper was carried as q - 1 and long-baseline chains were re-anchored at their midpoint)."""
+    cfg = W.config3()
+    bl = NP.vstack((cfg['baselines'][::37][-600:], cfg['baselines'][-200:]))
+    ch = cfg['channels']
+    rng = NP.random.default_rng(3)
+    ctx.set_array(bl, ch)
+    ctx.set_tuning(64, 0, 1)                       # the tile width the full array runs with (a small array would get 8)
+    worst = 0.0
+    for trial in range(6):
+        dc = O.altaz2dircos(NP.array([[rng.uniform(8, 80), rng.uniform(0, 360)]]))
+        pb = rng.uniform(0.5, 2.0, size=(1, ch.size))
+        fw = NP.array([rng.uniform(0.05, 0.3)]) if taper else None
+        ref = CO.skyvis(bl, ch, dc, pb, NP.array([0.0, 0.0, 1.0]), fwhm_deg=fw)
+        ctx.set_sky(dc, pb, NP.array([0.0, 0.0, 1.0]), fwhm_deg=fw)
+        ctx.compute(precision=_abi.PRISIM_FP32)
+        assert ctx.timing()['last_chan_tile'] == 64
+        worst = max(worst, float(NP.max(NP.abs(ctx.get_vis() - ref) / NP.abs(pb))))
+    ctx.set_tuning(0, 0, 0)
+    assert worst <= 4.0e-6, worst
+
+
 def test_config2_fp64_full(ctx):
     """BASELINE config 2: HERA-19 x 256 ch x nside-16 diffuse sky, Airy beam, taper ON, fp64 -- full size."""
     cfg = W.config2()
