@@ -98,6 +98,17 @@ __device__ __forceinline__ float tan_pi_y(float y) {
   return __builtin_fmaf(y, q, y * 3.1415927410125732f);
 }
 
+// cos(2 pi y) for |y| <= 1/8 cycle (the cosine polynomial of sincos_qcycles without the quadrant logic)
+__device__ __forceinline__ float cos_2pi_y(float y) {
+  const float y2 = y * y;
+  float pc = -26.42625678337438f;
+  pc = __builtin_fmaf(pc, y2, 60.24464137187666f);
+  pc = __builtin_fmaf(pc, y2, -85.45681720669373f);
+  pc = __builtin_fmaf(pc, y2, 64.93939402266829f);
+  pc = __builtin_fmaf(pc, y2, -19.739208802178716f);
+  return __builtin_fmaf(pc, y2, 1.0f);
+}
+
 __device__ __forceinline__ void sincos_qcycles(double a4, double& c, double& s) {
   // fp64: residual angle t = 2 pi y, |t| <= pi/4; fdlibm __kernel_sin/__kernel_cos minimax coefficients
   const double q = __builtin_rint(a4);
@@ -634,9 +645,16 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
         di0 = __builtin_fmaf(-ri, x1, ui0);
         dr0 = __builtin_fmaf(-tpy, di0, x1);
       } else {
-        float rc, rs;
-        sincos_qcycles(d * df4, rc, rs);
-        rr = rc; ri = -rs;
+        if (TAPER && REANCHOR != 2) {
+          // taper bodies of baseline groups whose |theta| <= 1/8 cycle is guaranteed (the host's lift flag): no quadrant logic
+          const float yth = (float)(d * p.df);
+          rr = cos_2pi_y(yth);
+          ri = -sin_2pi_y(yth);
+        } else {
+          float rc, rs;
+          sincos_qcycles(d * df4, rc, rs);
+          rr = rc; ri = -rs;
+        }
         dr0 = __builtin_fmaf(ur0, rr, ui0 * ri);
         di0 = __builtin_fmaf(ui0, rr, -(ur0 * ri));
       }
