@@ -14,7 +14,9 @@ t0 = time.time()
 for case in range(ncase):
     nbl = int(rng.choice([1, 2, 63, 64, 65, 200, 256, 257, 511, 700]))
     nchan = int(rng.choice([1, 7, 8, 16, 31, 33, 64, 65, 100, 128, 200]))
-    nsrc = int(rng.choice([0, 1, 5, 31, 63, 64, 65, 71, 72, 100, 127, 500, 1500, 3000]))
+    nsrc = int(rng.choice([0, 1, 5, 31, 63, 64, 65, 71, 72, 100, 127, 500, 1500, 3000, 17000, 40000]))
+    if nsrc > 3000:
+        pass
     taper = bool(rng.integers(0, 2))
     maxbl = float(rng.choice([20.0, 300.0, 1500.0]))
     df = float(rng.choice([24414.0625, 97656.25, 390625.0, 1.5e6]))
@@ -37,8 +39,17 @@ for case in range(ncase):
         if flush: os.environ['PRISIM_HIP_FLUSH_SRC'] = str(flush)
         else: os.environ.pop('PRISIM_HIP_FLUSH_SRC', None)
         ctx.set_tuning(ct, chunk, nsplit)
-        ctx.compute(precision=prec)
-        v = ctx.get_vis()
+        grad = bool(rng.integers(0, 4) == 0) and nsrc > 0
+        ctx.compute(precision=prec, want_grad=grad)
+        v = ctx.get_vis(want_grad=grad)
+        if grad:
+            v, g = v
+            for k in range(3):
+                gref = CO.skyvis(bl, ch, dc, pb * dc[:, k:k + 1], pc, fwhm_deg=fw)
+                gerr = float(NP.max(NP.abs(g[k] - gref) / scale))
+                if not (NP.all(NP.isfinite(g[k])) and gerr <= TOL[prec]):
+                    fails += 1
+                    print('FAIL-GRAD k=%d nbl=%d nchan=%d nsrc=%d taper=%d prec=%d ct=%d nsplit=%d flush=%d err=%.3e' % (k, nbl, nchan, nsrc, taper, prec, ct, nsplit, flush, gerr), flush=True)
         err = float(NP.max(NP.abs(v - ref) / scale)) if nsrc else float(NP.max(NP.abs(v)))
         ok = NP.all(NP.isfinite(v)) and err <= TOL[prec]
         if not ok:
