@@ -21,6 +21,7 @@ Differences kept on purpose:
   astropy's FK5->AltAz is outside the boundary, SURVEY.md 7 "Hard parts").
 Out of scope here: init_file (HDF5/FITS persistence), gains, noise, uvfits.
 """
+import os
 import warnings
 
 import numpy as NP
@@ -79,8 +80,13 @@ class InterferometerArray(object):
                  blgroupinfo=None, baseline_coords='localenu', freq_scale=None,
                  gaininfo=None, init_file=None, simparms_file=None, device=0):
         if init_file is not None:
-            raise NotImplementedError('init_file (HDF5/FITS persistence, interferometry.py:5184-5658) is outside the '
-                                      'sky-sum path this package accelerates')
+            # interferometry.py:5184-5658: initialise from <init_file>.hdf5; if it cannot be opened, fall back to the arguments
+            try:
+                self._init_from_hdf5(init_file, device)
+                return
+            except (IOError, OSError) as exc:
+                warnings.warn('\tinit_file provided but could not open the initialization file ({0}). Attempting to initialize '
+                              'with input parameters...'.format(exc))
         if gaininfo is not None:
             raise NotImplementedError('gaininfo (instrument gains) is outside the sky-sum path')
 
@@ -198,6 +204,116 @@ class InterferometerArray(object):
         self._cube = []        # per-snapshot (nbl, nchan) visibilities, stacked lazily into skyvis_freq
         self._grad = []
         self._reserved = 1     # snapshot slots of the device cube (reserve())
+
+    def _init_from_hdf5(self, init_file, device):
+        """Attributes from a file written by save() / by PRISim (interferometry.py:5186-5657; same group and dataset names,
+        same KeyErrors for what is mandatory there).  The visibility cube goes back onto the device, snapshot t in slot t."""
+        from . import hdf5io
+        fname = init_file if init_file.endswith('.hdf5') else init_file + '.hdf5'
+        if not os.path.exists(fname):
+            raise IOError('no such file: ' + fname)
+        try:
+            f = hdf5io.File(fname, 'r')
+        except hdf5io.HDF5Unavailable as exc:
+            raise IOError(str(exc))
+        def text(v):
+            return v.decode() if isinstance(v, bytes) else str(v)
+        with f:
+            def get(path, default=None, required=None):
+                if f.exists(path):
+                    return f.read(path)
+                if required:
+                    raise KeyError(required)
+                return default
+            for key in ('header', 'telescope_parms', 'spectral_info', 'antenna_element', 'timing', 'skyparms', 'array', 'instrument',
+                        'visibilities'):
+                if not f.exists(key):
+                    raise KeyError('Key {0} not found in init_file'.format(key))
+            self.simparms_file = get('simparms/simfile')
+            self.flux_unit = text(get('header/flux_unit', 'JY'))
+            self.latitude = float(get('telescope_parms/latitude', 0.0))
+            self.longitude = float(get('telescope_parms/longitude', 0.0))
+            self.altitude = float(get('telescope_parms/altitude', 0.0))
+            self.telescope = {'shape': 'delta', 'size': 1.0, 'groundplane': None}
+            if f.exists('telescope_parms/id'):
+                self.telescope['id'] = text(f.read('telescope_parms/id'))
+            if f.exists('antenna_element/shape'):
+                self.telescope['shape'] = text(f.read('antenna_element/shape'))
+            if f.exists('antenna_element/size'):
+                size = NP.asarray(f.read('antenna_element/size'), dtype=NP.float64)
+                self.telescope['size'] = float(size) if size.ndim == 0 else size
+            self.telescope['ocoords'] = text(get('antenna_element/ocoords', required='Keyword "ocoords" not found in init_file'))
+            self.telescope['orientation'] = NP.asarray(get('antenna_element/orientation', required='Key "orientation" not found in init_file'),
+                                                       dtype=NP.float64).reshape(1, -1)
+            if f.exists('antenna_element/groundplane'):
+                self.telescope['groundplane'] = float(f.read('antenna_element/groundplane'))
+            self.layout = {}
+            if f.exists('layout'):
+                self.layout = {'positions': get('layout/positions', required='Antenna layout positions is missing'),
+                               'coords': text(f.read_attr('layout/positions', 'coords')),
+                               'labels': get('layout/labels', required='Layout antenna labels is missing'),
+                               'ids': get('layout/ids', required='Layout antenna ids is missing')}
+            self.freq_resolution = float(f.read('spectral_info/freq_resolution'))
+            self.channels = NP.asarray(f.read('spectral_info/freqs'), dtype=NP.float64)
+            self.lags = get('spectral_info/lags')
+            self.bp = NP.asarray(get('spectral_info/bp', required='Key "bp" not found in init_file'))
+            self.bp_wts = NP.asarray(get('spectral_info/bp_wts', NP.ones_like(self.bp)))
+            self.pointing_coords = text(get('skyparms/pointing_coords', 'hadec'))
+            self.phase_center_coords = text(get('skyparms/phase_center_coords', self.pointing_coords))
+            self.skycoords = text(get('skyparms/skycoords', 'radec'))
+            self.lst = NP.asarray(f.read('skyparms/LST')).ravel().tolist()
+            self.pointing_center = NP.asarray(f.read('skyparms/pointing_center'))
+            self.phase_center = NP.asarray(f.read('skyparms/phase_center'))
+            self.timestamp = NP.asarray(get('timing/timestamps', required='Key "timestamps" not found in init_file')).tolist()
+            self.t_acc = NP.asarray(get('timing/t_acc', required='Key "t_acc" not found in init_file')).ravel().tolist()
+            self.t_obs = float(f.read('timing/t_obs'))
+            self.n_acc = int(f.read('timing/n_acc'))
+            labels = get('array/labels', required='Key "labels" not found in init_file')
+            if labels.dtype.names:
+                self.labels = [tuple(text(x) for x in rec) for rec in labels.tolist()]
+            else:
+                self.labels = [text(x) for x in labels.tolist()]
+            self.baselines = NP.asarray(get('array/baselines', required='Key "baselines" not found in init_file'), dtype=NP.float64)
+            self.baseline_coords = text(get('array/baseline_coords', 'localenu'))
+            self.projected_baselines = get('array/projected_baselines')
+            self.baseline_lengths = NP.sqrt(NP.sum(self.baselines ** 2, axis=1))
+            self.baseline_orientations = NP.angle(self.baselines[:, 0] + 1j * self.baselines[:, 1])
+            self.A_eff = NP.asarray(f.read('instrument/effective_area'))
+            self.eff_Q = NP.asarray(f.read('instrument/efficiency'))
+            self.Tsysinfo = []
+            if f.exists('instrument/Trx'):
+                trx, t0, f0, sp = (NP.asarray(f.read('instrument/' + k)).ravel() for k in ('Trx', 'Tant0', 'f0', 'spindex'))
+                tnet = NP.asarray(get('instrument/Tnet', NP.full(trx.size, -999.0))).ravel()
+                for i in range(trx.size):
+                    self.Tsysinfo += [{'Trx': float(trx[i]), 'Tant': {'T0': float(t0[i]), 'f0': float(f0[i]), 'spindex': float(sp[i])},
+                                       'Tnet': float(tnet[i]) if tnet[i] > 0 else None}]
+            self.Tsys = NP.asarray(get('instrument/Tsys', NP.zeros((self.baselines.shape[0], self.channels.size))))
+            self.vis_rms_freq = get('visibilities/freq_spectrum/rms')
+            self.vis_freq = get('visibilities/freq_spectrum/vis')
+            skyvis = get('visibilities/freq_spectrum/skyvis', required='Key "skyvis" not found in init_file')
+            self.vis_noise_freq = get('visibilities/freq_spectrum/noise')
+            self.vis_lag = get('visibilities/delay_spectrum/vis')
+            self.skyvis_lag = get('visibilities/delay_spectrum/skyvis')
+            self.vis_noise_lag = get('visibilities/delay_spectrum/noise')
+            self.gradient_mode, self.gradient = None, {}
+            if f.exists('gradients/baseline'):
+                self.gradient_mode = 'baseline'
+                self.gradient = {'baseline': f.read('gradients/baseline')}
+        self.gaininfo = None
+        self.blgroups = None
+        self.bl_reversemap = None
+        self.lag_kernel = None
+        self.obs_catalog_indices = []
+        self.geometric_delays = []
+        if self.baseline_coords == 'equatorial':
+            raise NotImplementedError('equatorial baselines (GEOM.xyz2enu, interferometry.py:6153) are not on the accelerated path')
+        self._cube, self._grad = [], []
+        self._reserved = max(int(self.n_acc), 1)
+        self._ctx = _abi.Context(device)
+        self._ctx.set_array(self.baselines, self.channels, nt_max=self._reserved)
+        self.skyvis_freq = skyvis
+        for t in range(skyvis.shape[2]):
+            self._ctx.set_vis(NP.ascontiguousarray(skyvis[:, :, t], dtype=NP.complex128), slot=t)
 
     def reserve(self, n_acc):
         """Allocate `n_acc` snapshot slots in the device visibility cube so that every observe() also leaves its result
@@ -806,14 +922,13 @@ class InterferometerArray(object):
             if self.simparms_file is not None:
                 f.write('simparms/simfile', self.simparms_file)
             f.create_group('antenna_element')
-            for key in ('shape', 'ocoords'):
-                if tel.get(key) is not None:
-                    f.write('antenna_element/' + key, str(tel[key]))
-            if tel.get('size') is not None:
-                f.write('antenna_element/size', NP.asarray(tel['size'], dtype=NP.float64), attrs={'units': 'm'})
-            if tel.get('orientation') is not None:
-                f.write('antenna_element/orientation', NP.asarray(tel['orientation'], dtype=NP.float64),
-                        attrs=({'units': 'deg'} if tel.get('ocoords') != 'dircos' else None))
+            # the reference's reader insists on ocoords and orientation (:5261-5266): defaults of its constructor (:5703-5709)
+            ocoords = str(tel.get('ocoords', 'altaz'))
+            f.write('antenna_element/shape', str(tel.get('shape', 'delta')))
+            f.write('antenna_element/ocoords', ocoords)
+            f.write('antenna_element/size', NP.asarray(tel.get('size', 1.0), dtype=NP.float64), attrs={'units': 'm'})
+            f.write('antenna_element/orientation', NP.asarray(tel.get('orientation', [90.0, 270.0]), dtype=NP.float64).ravel(),
+                    attrs=({'units': 'deg'} if ocoords != 'dircos' else None))
             if tel.get('groundplane') is not None:
                 f.write('antenna_element/groundplane', float(tel['groundplane']))
             if self.layout:

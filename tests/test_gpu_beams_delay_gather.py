@@ -607,6 +607,20 @@ def test_interferometer_array_save_hdf5_layout(tmp_path):
         assert NP.array_equal(f.read('instrument/Tnet'), [300.0, 300.0]) and f.read('instrument/Tsys').shape == ia.Tsys.shape
     z = NP.load(out + '.npz')
     assert NP.array_equal(z['skyvis_freq'], ia.skyvis_freq) and NP.array_equal(z['vis_freq'], ia.vis_freq)
+    # init_file: the object comes back (interferometry.py:5184-5658) with its cube resident on the device again
+    ib = RI.InterferometerArray(None, None, None, init_file=out)
+    assert ib.labels == [('a1', 'a0'), ('a2', 'a0')] and NP.array_equal(ib.baselines, bl) and NP.array_equal(ib.channels, ch)
+    assert ib.n_acc == 2 and ib.t_acc == [60.0, 60.0] and ib.lst == [0.0, 15.0] and ib.telescope['id'] == 'hera'
+    assert ib.skycoords == 'altaz' and ib.flux_unit == 'JY' and ib.Tsysinfo[0]['Tnet'] == 300.0 and ib.latitude == -30.72
+    assert NP.array_equal(ib.skyvis_freq, ia.skyvis_freq) and NP.array_equal(ib.vis_noise_freq, ia.vis_noise_freq)
+    assert NP.array_equal(ib._ctx.get_vis(slot=1), ia.skyvis_freq[:, :, 1])
+    ib.delay_transform(pad=0.0, verbose=False)                                     # device-side work on the reloaded cube
+    assert NP.allclose(ib.skyvis_lag, ia.skyvis_lag, rtol=0, atol=1e-12 * NP.abs(ia.skyvis_lag).max())
+    ib.observe((2457002.5, 30.0), {'Tnet': 300.0}, NP.ones(16), [90.0, 270.0], skymod, 60.0)     # and it keeps observing
+    assert ib.skyvis_freq.shape == (2, 16, 3) and ib.n_acc == 3
+    with pytest.warns(UserWarning, match='could not open'):
+        ic = RI.InterferometerArray(['x'], [[1.0, 2.0, 0.0]], ch, init_file=str(tmp_path / 'missing'), skycoords='altaz', pointing_coords='altaz')
+    assert ic.n_acc == 0 and ic.labels == ['x']
     with pytest.raises(IOError):
         ia.save(out, fmt='HDF5', npz=False, overwrite=False, verbose=False)          # exists
     with pytest.raises(NotImplementedError):
