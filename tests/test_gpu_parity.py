@@ -403,3 +403,35 @@ def test_full_size_headline_properties(ctx):
     ctx.set_sky(sky['dircos'], pb, zen)
     ctx.compute(precision=_abi.PRISIM_FP32)
     assert relerr(ctx.get_vis(), NP.conj(full[::61]), pb) <= 1e-5
+
+
+def test_full_size_config5_snapshot_properties(ctx):
+    """One snapshot of BASELINE config 5 (HERA-350 x 1024 ch x nside-256 diffuse sky above the horizon = 392 704 sources, taper ON,
+    fp32: 2.46e13 terms).  The sky is 24 flush intervals long and its pbflux slab is 100 MB per channel tile (25x the L2), so this
+    is the size at which the periodic fp32 -> fp64 flush, the L2 warm-up and the grouped taper recurrence all work for a living.
+    Checks: finite; 4 baselines against the C oracle; additivity over two disjoint source sets (slab invariance, :6348-6376)."""
+    cfg = W.config5(n_acc=1)
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    zen = NP.array([0.0, 0.0, 1.0])
+    n = sky['dircos'].shape[0]
+    assert n > 390000
+    ctx.set_array(bl, ch)
+    ctx.set_tuning(0, 0, 0)
+
+    def run(sel):
+        ctx.set_sky_analytic(sky['dircos'][sel], sky['flux_ref'][sel], sky['spindex'][sel], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, 14.0,
+                             zen, zen, fwhm_deg=sky['fwhm_deg'][sel])
+        ctx.compute(precision=_abi.PRISIM_FP32)
+        return ctx.get_vis()
+
+    full = run(slice(None))
+    tm = ctx.timing()
+    assert tm['last_chan_tile'] == 64 and tm['last_taper_group'] == 1
+    assert NP.all(NP.isfinite(full.view(NP.float64)))
+    pb = ctx.get_pbflux()
+    sel_bl = NP.array([0, 20000, 45000, bl.shape[0] - 1])
+    ref = CO.skyvis(bl[sel_bl], ch, sky['dircos'], pb, zen, fwhm_deg=sky['fwhm_deg'])
+    assert relerr(full[sel_bl], ref, pb) <= 5e-6
+    odd = NP.arange(n) % 3 == 1
+    parts = run(odd) + run(~odd)
+    assert relerr(parts, full, pb) <= 1e-5
