@@ -66,6 +66,35 @@ __device__ __forceinline__ void sincos_qcycles(double a4, float& c, float& s) {
   s = ((qi & 2) != 0) ? -ss : ss;          // q mod 4 in {2,3}
 }
 
+// fp64 (sin x, cos x) for |x| <= pi/4 (fdlibm __kernel_sin / __kernel_cos minimax coefficients), no reduction, no quadrant logic
+__device__ __forceinline__ void sincos_kernel_f64(double x, double& sn, double& cs) {
+  const double z = x * x;
+  double ps = 1.58969099521155010221e-10;
+  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  sn = __builtin_fma(x * z, ps, x);
+  double pc = -1.13596475577881948265e-11;
+  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+}
+
+// a / c for c in [0.7, 1]: v_rcp_f64 seed + two Newton steps + one residual correction (the generic fp64 division is ~14 instructions
+// of scaling and fix-up that this range does not need)
+__device__ __forceinline__ double div_unit_range_f64(double a, double c) {
+  double r = __builtin_amdgcn_rcp(c);
+  r = __builtin_fma(r, __builtin_fma(-c, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-c, r, 1.0), r);
+  const double q = a * r;
+  return __builtin_fma(r, __builtin_fma(-c, q, a), q);
+}
+
 // (cos, sin) of 2 pi a for a phase in CYCLES of any magnitude: fp64 reduction to [-1/2, 1/2] cycle, then the hardware
 // v_cos_f32 / v_sin_f32 (input in revolutions; measured max abs error 1.25e-7 on [-1/2, 1/2], tools/microbench_trig.hip).
 // Two quarter-rate instructions instead of ~25 for the polynomial + quadrant logic.  Only for phasors that are used once
@@ -326,17 +355,24 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
       T zc, zs, rc, rs;
       sincos_qcycles(d * fc4, zc, zs);                           // phase at the centre channel
       const double th4 = d * df4;
-      sincos_qcycles(th4, rc, rs);                               // phase step per channel
+      T tl = (T)0;                         // tan(alpha/2), alpha = -2 pi theta the step angle (LIFT groups only)
+      if constexpr (LIFT && sizeof(T) == 8) {
+        // |theta| <= 1/4 cycle is guaranteed for this baseline group: half angle beta = pi theta in [-pi/4, pi/4] straight into the
+        // polynomial kernels (no reduction, no quadrant logic), tan(beta) by a short reciprocal; sin/cos of the step by doubling
+        double sb, cb;
+        sincos_kernel_f64(th4 * 0.78539816339744830962, sb, cb);                  // beta = (th4 / 4) * pi
+        rc = __builtin_fma(-2.0 * sb, sb, 1.0);                                   // cos 2 beta
+        rs = 2.0 * sb * cb;                                                       // sin 2 beta
+        tl = -div_unit_range_f64(sb, cb);                                         // alpha = -2 beta
+      } else {
+        sincos_qcycles(th4, rc, rs);                             // phase step per channel
+      }
       // exp(-2 pi i phi): z = (cos, -sin)
       T ur = zc, ui = -zs;            // up chain: channel HC + j
       const T rr = rc, ri = -rs;      // step forward; step backward is conj(r)
       T dr = fma_(ur, rr, ui * ri);        // z * conj(r): channel HC-1
       T di = fma_(ui, rr, -(ur * ri));
-      T tl = (T)0;                         // tan(alpha/2), alpha = -2 pi theta the step angle (LIFT groups only)
-      if constexpr (LIFT) {
-        if constexpr (sizeof(T) == 4) tl = -tan_pi_y((float)(0.25 * th4));      // |theta| <= 1/8 cycle guaranteed
-        else tl = ri / ((T)1 + rr);                                             // |theta| <= 1/4 cycle guaranteed: 1 + cos >= 1
-      }
+      if constexpr (LIFT && sizeof(T) == 4) tl = -tan_pi_y((float)(0.25 * th4));      // |theta| <= 1/8 cycle guaranteed
       // source-shape taper  w = exp(-g f^2),  g = kappa_s * (|b|^2/c^2 - tau^2),  tau = d + b.s_pc/c
       double gq = 0.0;
       float g2 = 0.f;

@@ -16,7 +16,7 @@ for taper in (False, True):
                          fwhm_deg=(NP.full(sky['dircos'].shape[0], 0.46) if taper else None))
     best = 1e9
     for rep in range(3):
-        ctx.compute(precision=_abi.PRISIM_FP32); ctx.sync(); best = min(best, ctx.timing()['last_kernel_ms'])
+        ctx.compute(precision=(_abi.PRISIM_FP64 if os.environ.get('AB_PREC') == 'fp64' else _abi.PRISIM_FP32)); ctx.sync(); best = min(best, ctx.timing()['last_kernel_ms'])
     print(os.path.basename(sys.argv[1]), 'taper=%%d kern_ms=%%.2f' %% (taper, best), flush=True)
 ''' % root
 for rnd in range(2):
