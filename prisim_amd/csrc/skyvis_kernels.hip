@@ -386,12 +386,38 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
         } else {
           // fp64: second-order multiplicative recurrence of the Gaussian in frequency:
           //   w_{k+1} = w_k q_k,  q_{k+1} = q_k h,   h = exp(-2 g df^2);   w_{k-1} = w_k q'_k, q'_{k-1} = q'_k h
-          const double e1 = exp(-2.0 * gq * fc * df);
-          const double e2 = exp(-gq * df * df);
+          const double x1 = -2.0 * gq * fc * df, x2 = -gq * df * df;
+          double e1, e1inv, e2;
+          if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(x1) < 0.1 && __builtin_fabs(x2) < 1e-3)) == 0) {
+            // the usual case (df << f): exp(+-x1) from the even and odd series to x^9 (next term 3e-17 at |x1| = 0.1) and
+            // exp(x2) from five terms, instead of two library exponentials and an fp64 division -- wave-uniform choice
+            const double z = x1 * x1;
+            double ce = 2.48015873015873015873e-05;                                    // 1/8!
+            ce = __builtin_fma(ce, z, 1.38888888888888888889e-03);
+            ce = __builtin_fma(ce, z, 4.16666666666666666667e-02);
+            ce = __builtin_fma(ce, z, 0.5);
+            ce = __builtin_fma(ce, z, 1.0);
+            double so = 2.75573192239858906526e-06;                                    // 1/9!
+            so = __builtin_fma(so, z, 1.98412698412698412698e-04);
+            so = __builtin_fma(so, z, 8.33333333333333333333e-03);
+            so = __builtin_fma(so, z, 1.66666666666666666667e-01);
+            so = __builtin_fma(so, z, 1.0) * x1;
+            e1 = ce + so;
+            e1inv = ce - so;
+            double p2 = 4.16666666666666666667e-02;
+            p2 = __builtin_fma(p2, x2, 1.66666666666666666667e-01);
+            p2 = __builtin_fma(p2, x2, 0.5);
+            p2 = __builtin_fma(p2, x2, 1.0);
+            e2 = __builtin_fma(p2, x2, 1.0);
+          } else {
+            e1 = exp(x1);
+            e1inv = 1.0 / e1;
+            e2 = exp(x2);
+          }
           h = e2 * e2;
           wu = exp(-gq * fc * fc);                  // channel HC
           qu = e1 * e2;                             // w_{HC+1}/w_{HC}
-          qd = e2 / e1;                             // w_{HC-1}/w_{HC}
+          qd = e2 * e1inv;                          // w_{HC-1}/w_{HC}
           wd = wu * qd;                             // channel HC-1
           qd *= h;                                  // w_{HC-2}/w_{HC-1}
         }
