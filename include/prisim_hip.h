@@ -242,7 +242,7 @@ typedef struct prisim_timing {
   int32_t last_kernel_id;    /* PRISIM_KERNEL_* actually used */
   int32_t last_chan_tile;    /* channels per thread of the recurrence kernel */
   int32_t last_nsplit;       /* source split factor */
-  int32_t last_lift_groups;  /* baseline groups (of 256) that ran the 5-instruction lifting rotation (fp32, no taper) */
+  int32_t last_lift_groups;  /* baseline groups (of 256) that ran the lifting (three-shear) rotation; 0 for the packed fp32 taper kernel */
   int32_t last_taper_group;  /* 1: the packed fp32 taper kernel ran its grouped recurrence (df/f_min <= 3.4e-3), 0: exact per-step form */
   int32_t reserved_;
 } prisim_timing;

@@ -797,7 +797,9 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
       }
       int nlift = 0;
       for (int32_t v : ctx->lift_host) nlift += v;
-      ctx->timing.last_lift_groups = ctx->taper ? 0 : nlift;       // with the taper the flags only select the re-anchored body
+      // the packed taper kernel folds the amplitude into the phasor (a scaled rotation: no lifting there, the flags only select its
+      // re-anchored body); every other kernel lifts the flagged groups
+      ctx->timing.last_lift_groups = (ctx->taper && pl.pk) ? 0 : nlift;
     }
     if (pl.f32 && ctx->taper) {
       if ((rc = ensure(ctx, ctx->fsq_pairs, (size_t)pl.ntiles * pl.ct * sizeof(float)))) return rc;

@@ -208,8 +208,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <typename T, int CT, bool TAPER, bool LIFT>
 __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned char* flush_lds) {
   static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
-  static_assert(!(TAPER && LIFT), "no lifting form with the taper");
-  constexpr int HC = CT / 2;                       // channels per chain
+  constexpr int HC = CT / 2;                       // channels per chain (here the taper multiplies pbflux, so z stays a pure rotation
+                                                   // and the lifting form applies with or without it)
   constexpr int NH = CT / 2;                       // elements per half row
   typedef const __attribute__((address_space(4))) T* crow_p;
   typedef const volatile __attribute__((address_space(4))) double* cdir_p;    // volatile: see the packed kernel (keeps the load where it is written)
@@ -484,12 +484,10 @@ template <typename T, int CT, bool TAPER>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(WavesPerEU<T, CT, TAPER>::value)))
 void k_skyvis_rec(const SkyvisParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<T>() + kPrefetchLdsBytes];
-  if constexpr (!TAPER) {
-    const int bg = (blockIdx.x >> 3) % p.nbgroups;
-    if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {      // block-uniform; the two bodies share no live state
-      skyvis_rec_body<T, CT, false, true>(p, flush_lds);
-      return;
-    }
+  const int bg = (blockIdx.x >> 3) % p.nbgroups;
+  if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {        // block-uniform; the two bodies share no live state
+    skyvis_rec_body<T, CT, TAPER, true>(p, flush_lds);
+    return;
   }
   skyvis_rec_body<T, CT, TAPER, false>(p, flush_lds);
 }

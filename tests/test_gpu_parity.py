@@ -241,10 +241,19 @@ def test_lifting_rotation_groups_and_fallback(ctx):
     ctx.compute(precision=_abi.PRISIM_FP32)
     assert ctx.timing()['last_lift_groups'] == 2
     assert relerr(ctx.get_vis()[:512], CO.skyvis(bl[:512], ch, s1, p1, zen), p1) <= 5e-6
-    # taper on: no lifting
-    ctx.set_sky(dc, pb, zen, fwhm_deg=NP.full(nsrc, 0.3))
+    # taper on: the packed fp32 kernel folds the amplitude into the phasor (a scaled rotation, no lifting); the generic kernels
+    # (fp64, narrow fp32 tiles) put the taper on pbflux, so their phasor is still a pure rotation and the flagged groups lift
+    fw = NP.full(nsrc, 0.3)
+    reft = CO.skyvis(bl, ch, dc, pb, zen, fwhm_deg=fw)
+    ctx.set_sky(dc, pb, zen, fwhm_deg=fw)
     ctx.compute(precision=_abi.PRISIM_FP32)
-    assert ctx.timing()['last_lift_groups'] == 0
+    assert ctx.timing()['last_lift_groups'] == 0 and ctx.timing()['last_chan_tile'] == 64
+    assert relerr(ctx.get_vis(), reft, pb) <= 5e-6
+    for prec, ct, tol in ((_abi.PRISIM_FP64, 32, 1e-11), (_abi.PRISIM_FP64, 16, 1e-11), (_abi.PRISIM_FP32, 16, 5e-6)):
+        ctx.set_tuning(ct, 0, 1)
+        ctx.compute(precision=prec)
+        assert ctx.timing()['last_lift_groups'] == 2
+        assert relerr(ctx.get_vis(), reft, pb) <= tol, (prec, ct)
     ctx.set_tuning(0, 0, 0)
 
 
