@@ -15,10 +15,16 @@ Pinning status (see DESIGN.md, section "Oracle"):
       - source-shape taper                    interferometry.py:6259-6283
       - baseline gradient                     interferometry.py:6338, 6343
       - Gaussian / Airy beams (zenith)        primary_beams.py:609-623, 716-728
+      - dipole, 4x4 array factor, presets     primary_beams.py:975-1235, 1239-1478, 9-441
+      - VLA / GMRT polynomial beams           primary_beams.py:445-513, 734-808
+      - phased-array beamformer               primary_beams.py:1482-1754 (seeded jitter draws included)
+      - phase-centre rotation                 interferometry.py:7871-7877
   * PARITY UNPINNED (un-vendored, un-pinned third-party dependency
     ``astroutils``; the reference has no tests or golden vectors for them):
       - altaz<->dircos / hadec->altaz geometry (convention taken from in-tree
         docstrings, primary_beams.py:122-123, 255-258, 275-278)
       - DSP.FT1D / DSP.downsampler / DSP.spectral_axis (delay transform)
+      - OPS.healpix_interp_along_axis (external HEALPix beams; restated from the published HEALPix algorithm)
+      - GEOM.sphdist / dircos2altaz (off-zenith pointing, ground plane)
       - SkyModel.generate_spectrum
 """
