@@ -35,6 +35,15 @@ C_LIGHT = 299792458.0
 SIDEREAL_RATE = 1.00273790935    # sidereal seconds per solar second
 
 
+class _DeviceSlot(object):
+    """Placeholder in InterferometerArray._cube for a snapshot that so far lives only in slot `slot` of the device cube (after
+    reserve()); the host copy is fetched the first time skyvis_freq is read.  Runs that gather on the device never fetch it."""
+    __slots__ = ('slot', 'dtype')
+
+    def __init__(self, slot, dtype):
+        self.slot, self.dtype = slot, NP.dtype(dtype)
+
+
 class LazyGeometricDelays(object):
     """Stand-in for one entry of ``InterferometerArray.geometric_delays`` (the reference stores the full
     nsrc x nbl matrix per snapshot, interferometry.py:6287-6291 -- 4.9 GB at HERA-350 x 1e4 sources).
@@ -346,7 +355,7 @@ class InterferometerArray(object):
         if self._reserved < self.n_acc:
             raise RuntimeError('reserve(n_acc) must be called before observing to keep the cube on the device')
         self._ctx.comm_init(comm_uid, nranks, rank)
-        c64 = bool(self._cube) and self._cube[0].dtype == NP.complex64
+        c64 = bool(self._cube) and self._cube[0].dtype == NP.complex64           # works for host arrays and _DeviceSlot placeholders
         self._ctx.allgather(self.n_acc, complex64=c64)
         g = self._ctx.get_gathered(self.n_acc, nranks)                 # [t][rank][b][f]
         return NP.transpose(g.reshape(self.n_acc, nranks * self.baselines.shape[0], self.channels.size), (1, 2, 0))
@@ -558,9 +567,16 @@ class InterferometerArray(object):
                 self._ctx.set_sky_analytic(dircos_roi, None, None, None, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,
                                            flux_spectrum=fluxes, ext=ext)
             slot = self.n_acc if self.n_acc < self._reserved else 0
+            for i, snap in enumerate(self._cube):                       # a snapshot still parked in the slot about to be overwritten
+                if isinstance(snap, _DeviceSlot) and snap.slot == slot:
+                    self._cube[i] = self._ctx.get_vis(slot=slot, complex64=(snap.dtype == NP.complex64))
             self._ctx.compute(precision=prec, want_grad=want_grad, slot=slot)
-            res = self._ctx.get_vis(slot=slot, want_grad=want_grad, complex64=memsave)
-            skyvis, skyvis_gradient = res if want_grad else (res, None)
+            if slot == self.n_acc and not want_grad:
+                # the snapshot stays in its own slot of the device cube: no download now (1 GB and 20 ms per HERA-350 snapshot)
+                skyvis, skyvis_gradient = _DeviceSlot(slot, datatype), None
+            else:
+                res = self._ctx.get_vis(slot=slot, want_grad=want_grad, complex64=memsave)
+                skyvis, skyvis_gradient = res if want_grad else (res, None)
             self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(self.baselines, dircos_roi,
                                                                                  NP.float32 if memsave else NP.float64)]   # :6287-6291
             self.obs_catalog_indices = self.obs_catalog_indices + [m2]                # :6377
@@ -587,6 +603,9 @@ class InterferometerArray(object):
         if not getattr(self, '_cube', None):
             return self._skyvis_override
         if getattr(self, '_skyvis_cache', None) is None:
+            for i, snap in enumerate(self._cube):
+                if isinstance(snap, _DeviceSlot):                       # first read: fetch the device-resident snapshots
+                    self._cube[i] = self._ctx.get_vis(slot=snap.slot, complex64=(snap.dtype == NP.complex64))
             self._skyvis_cache = NP.stack(self._cube, axis=2)
         return self._skyvis_cache
 

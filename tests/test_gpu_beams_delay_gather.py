@@ -627,3 +627,29 @@ def test_interferometer_array_save_hdf5_layout(tmp_path):
         ia.save(out, fmt='FITS', verbose=False)
     with pytest.raises(ValueError):
         ia.save(out, fmt='CSV', verbose=False)
+
+
+def test_observe_keeps_reserved_snapshots_on_the_device_until_read():
+    """After reserve(n) every snapshot stays in its own slot of the device cube and the host copy is only made when
+    skyvis_freq is first read (a sharded run that gathers on the device never makes it); without reserve() the single slot
+    is reused, so a parked snapshot is fetched before the next one overwrites it."""
+    ch = 150e6 + NP.arange(16) * 1e5
+    bl = NP.array([[14.6, 0.0, 0.0], [0.0, 29.2, 0.0], [100.0, -40.0, 0.0]])
+    skymod = SM.SkyModel(location=[[80.0, 100.0], [50.0, 10.0], [30.0, 250.0]], flux_ref=[1.0, 3.0, 2.0], spindex=[0.0, -0.7, -1.0], ref_freq=150e6)
+    def run(reserve):
+        ia = RI.InterferometerArray(['a', 'b', 'c'], bl, ch, telescope={'shape': 'delta'}, skycoords='altaz', pointing_coords='altaz')
+        if reserve:
+            ia.reserve(3)
+        for j in range(3):
+            ia.observe((2457000.5 + j, 20.0 * j), {'Tnet': 100.0}, NP.ones(16), [90.0 - 5.0 * j, 270.0], skymod, 60.0)
+        return ia
+    ia = run(True)
+    assert all(isinstance(s, RI._DeviceSlot) for s in ia._cube)                    # nothing downloaded yet
+    for t in range(3):
+        assert ia._ctx.get_vis(slot=t).shape == (3, 16)
+    cube = ia.skyvis_freq                                                          # first read fetches the three slots
+    assert cube.shape == (3, 16, 3) and not any(isinstance(s, RI._DeviceSlot) for s in ia._cube)
+    ib = run(False)                                                                # one slot, reused: same numbers
+    assert not any(isinstance(s, RI._DeviceSlot) for s in ib._cube)                # the parked first one was fetched before its slot was reused
+    assert NP.array_equal(ib.skyvis_freq, cube)
+    assert NP.abs(cube[:, :, 0] - cube[:, :, 1]).max() > 0                         # the snapshots do differ
