@@ -313,14 +313,13 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
             print('snapshot {0}/{1}: lst = {2:.4f} deg, {3} sources'.format(j + 1, n_acc, lst[j], ia.obs_catalog_indices[-1].size
                                                                               if len(ia.obs_catalog_indices) > j else 0))
     t_sim = time.time() - t0
-    cube = ia.skyvis_freq
     if world > 1:
         if comm_uid is None:
             raise ValueError('comm_uid is needed when world > 1')
-        cube = ia.allgather(comm_uid, world, rank)[:nbl_total]
+        cube = ia.allgather(comm_uid, world, rank)[:nbl_total]          # shards go GPU -> GPU; the host never sees this rank's own cube
         labels_all, bl_all = labels, bl
     else:
-        cube, labels_all, bl_all = cube[:nbl_total], labels, bl
+        cube, labels_all, bl_all = ia.skyvis_freq[:nbl_total], labels, bl
     out = {'skyvis_freq': cube, 'bl': bl_all, 'labels': labels_all, 'freq': chans, 'lst': NP.asarray(ia.lst),
            'timestamp': NP.asarray(ia.timestamp), 'bl_length': NP.sqrt(NP.sum(bl_all ** 2, axis=1)), 't_sim': t_sim,
            'antpos': antpos, 'ia': ia, 'blgroups': blgroups}
