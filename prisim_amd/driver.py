@@ -323,9 +323,11 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     out = {'skyvis_freq': cube, 'bl': bl_all, 'labels': labels_all, 'freq': chans, 'lst': NP.asarray(ia.lst),
            'timestamp': NP.asarray(ia.timestamp), 'bl_length': NP.sqrt(NP.sum(bl_all ** 2, axis=1)), 't_sim': t_sim,
            'antpos': antpos, 'ia': ia, 'blgroups': blgroups}
-    if proc.get('delay_transform') and world == 1:
+    if proc.get('delay_transform'):
+        # every rank transforms its own shard on its GPU (the FFT runs along frequency); sharded runs then exchange the spectra
         ia.delay_transform(pad=float(proc.get('f_pad', 1.0)), freq_wts=window(chans.size, proc.get('bpass_shape', 'bhw')), verbose=False)
-        out['skyvis_lag'], out['lags'] = ia.skyvis_lag, ia.lags
+        out['skyvis_lag'] = ia.allgather_lags(world)[:nbl_total] if world > 1 else ia.skyvis_lag
+        out['lags'] = ia.lags
     return out
 
 

@@ -354,10 +354,31 @@ class InterferometerArray(object):
         part files + rank-0 concatenate, scripts/run_prisim.py:2207, 2233-2242).  Returns (nranks*nbl, nchan, n_acc)."""
         if self._reserved < self.n_acc:
             raise RuntimeError('reserve(n_acc) must be called before observing to keep the cube on the device')
-        self._ctx.comm_init(comm_uid, nranks, rank)
+        if not getattr(self, '_comm_ready', False):
+            self._ctx.comm_init(comm_uid, nranks, rank)
+            self._comm_ready = True
         c64 = bool(self._cube) and self._cube[0].dtype == NP.complex64           # works for host arrays and _DeviceSlot placeholders
         self._ctx.allgather(self.n_acc, complex64=c64)
         g = self._ctx.get_gathered(self.n_acc, nranks)                 # [t][rank][b][f]
+        return NP.transpose(g.reshape(self.n_acc, nranks * self.baselines.shape[0], self.channels.size), (1, 2, 0))
+
+    def allgather_lags(self, nranks):
+        """All-gather of the delay spectra of the baseline shards (the FFT is along frequency, so every rank transforms
+        its own shard and the spectra are exchanged like the visibilities).  Call after allgather() and delay_transform(); the lag
+        spectra take the place of the visibilities in the device cube slots for the exchange.  Returns (nranks*nbl, nlag, n_acc)."""
+        if not getattr(self, '_comm_ready', False):
+            raise RuntimeError('allgather() must be called first (it sets up the communicator)')
+        if self.skyvis_lag is None:
+            raise RuntimeError('delay_transform() must be called first')
+        if self.skyvis_lag.shape != (self.baselines.shape[0], self.channels.size, self.n_acc):
+            raise NotImplementedError('the delay spectra are exchanged through the visibility slots: this needs nlag == nchan (pad = 0, 1, 2, ...)')
+        _ = self.skyvis_freq                                           # make sure the host owns the visibilities before their slots are reused
+        for t in range(self.n_acc):
+            self._ctx.set_vis(NP.ascontiguousarray(self.skyvis_lag[:, :, t], dtype=NP.complex128), slot=t)
+        self._ctx.allgather(self.n_acc, complex64=False)
+        g = self._ctx.get_gathered(self.n_acc, nranks)
+        for t in range(self.n_acc):                                    # and the visibilities go back into their slots
+            self._ctx.set_vis(NP.asarray(self.skyvis_freq[:, :, t], dtype=NP.complex128), slot=t)
         return NP.transpose(g.reshape(self.n_acc, nranks * self.baselines.shape[0], self.channels.size), (1, 2, 0))
 
     # ------------------------------------------------------------------------------------------
@@ -1098,35 +1119,44 @@ class InterferometerArray(object):
             else:
                 raise ValueError('window shape dimensions incompatible with number of channels and/or number of tiemstamps.')
             self.bp_wts = freq_wts
-        if self.skyvis_freq is None:
+        if not self._cube and self._skyvis_override is None:
             raise ValueError('no visibilities to transform: call observe() first')
 
         def transform(cube):
             # cube (nbl, nchan, nt) times bp*bp_wts, one snapshot at a time through the device cube slot 0
             nt = cube.shape[2]
-            wts = NP.broadcast_to((self.bp * self.bp_wts).reshape(nbl, nchan, -1), (nbl, nchan, nt)) \
-                if self.bp.ndim == 3 else NP.broadcast_to((self.bp * self.bp_wts)[:, :, None], (nbl, nchan, nt))
+            w3 = (self.bp * self.bp_wts).reshape(nbl, nchan, -1)
+            wts = w3 if w3.shape[2] == nt else NP.broadcast_to(w3[:, :, :1], (nbl, nchan, nt))   # per-snapshot weights, or one set for all
             outs = []
             for t in range(nt):
                 out, lags, _ = self._ctx.delay_transform_host(cube[:, :, t], wts[:, :, t], pad)
                 outs.append(out)
             return NP.stack(outs, axis=2), lags
 
-        nt_all = self.skyvis_freq.shape[2]
+        # number and type of the snapshots without forcing device-resident ones onto the host (_DeviceSlot placeholders)
+        nt_all = len(self._cube) if self._cube else self._skyvis_override.shape[2]
+        dtype0 = self._cube[0].dtype if self._cube else self._skyvis_override.dtype
         wall = (self.bp * self.bp_wts).reshape(nbl, nchan, -1)
         same_wts = wall.shape[2] == 1 or bool(NP.all(wall == wall[:, :, [0]]))
-        if self._reserved >= nt_all and self.n_acc == nt_all and same_wts and self.skyvis_freq.dtype == NP.complex128:
+        resident = self._reserved >= self.n_acc and bool(self._cube)     # device slots hold the snapshots: slot 0 must survive
+        if resident and self._reserved >= nt_all and self.n_acc == nt_all and same_wts and dtype0 == NP.complex128:
             # the cube is resident on the GPU (reserve()): transform all snapshots in place, no re-upload
             out, self.lags, _ = self._ctx.delay_transform(nt_all, bpwts=wall[:, :, 0], pad=pad)
             self.skyvis_lag = NP.transpose(out, (1, 2, 0))
+            saved0 = self._ctx.get_vis(slot=0)
         else:
-            self.skyvis_lag, self.lags = transform(NP.asarray(self.skyvis_freq, dtype=NP.complex128))
+            host_cube = NP.asarray(self.skyvis_freq, dtype=NP.complex128)
+            saved0 = self._ctx.get_vis(slot=0) if resident else None       # the host-side transforms run through slot 0
+            self.skyvis_lag, self.lags = transform(host_cube)
         if self.vis_freq is not None:
             self.vis_lag, _ = transform(NP.asarray(self.vis_freq, dtype=NP.complex128))
         if self.vis_noise_freq is not None:
             self.vis_noise_lag, _ = transform(NP.asarray(self.vis_noise_freq, dtype=NP.complex128))
-        ones = NP.ones((nbl, nchan, self.skyvis_freq.shape[2]), dtype=NP.complex128)
-        self.lag_kernel, _ = transform(ones)                                           # :8119 / :8127
-        if self._reserved >= self.n_acc and self._cube:
-            # the host-cube transforms above went through device slot 0: put the resident snapshot back
-            self._ctx.set_vis(NP.asarray(self.skyvis_freq[:, :, 0], dtype=NP.complex128), slot=0)
+        if same_wts:
+            # the transform of bp * bp_wts (:8119 / :8127) is the same for every snapshot then: one FFT batch, repeated
+            kern, _ = transform(NP.ones((nbl, nchan, 1), dtype=NP.complex128))
+            self.lag_kernel = NP.repeat(kern, nt_all, axis=2)
+        else:
+            self.lag_kernel, _ = transform(NP.ones((nbl, nchan, nt_all), dtype=NP.complex128))
+        if saved0 is not None:
+            self._ctx.set_vis(saved0, slot=0)                              # put the resident snapshot back

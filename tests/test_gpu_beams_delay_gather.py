@@ -653,3 +653,28 @@ def test_observe_keeps_reserved_snapshots_on_the_device_until_read():
     assert not any(isinstance(s, RI._DeviceSlot) for s in ib._cube)                # the parked first one was fetched before its slot was reused
     assert NP.array_equal(ib.skyvis_freq, cube)
     assert NP.abs(cube[:, :, 0] - cube[:, :, 1]).max() > 0                         # the snapshots do differ
+
+
+def test_sharded_run_gathers_visibilities_then_delay_spectra():
+    """The multi-GPU driver's sequence on a one-rank RCCL communicator: observe into reserved device slots (nothing downloaded),
+    all-gather the shards, delay-transform the local shard on the device, all-gather the delay spectra through the same slots."""
+    ch = 150e6 + NP.arange(32) * 1e5
+    bl = NP.array([[14.6, 0.0, 0.0], [0.0, 29.2, 0.0], [100.0, -40.0, 0.0], [55.0, 60.0, 0.0]])
+    skymod = SM.SkyModel(location=[[80.0, 100.0], [50.0, 10.0], [30.0, 250.0]], flux_ref=[1.0, 3.0, 2.0], spindex=[0.0, -0.7, -1.0], ref_freq=150e6)
+    ia = RI.InterferometerArray(['a', 'b', 'c', 'd'], bl, ch, telescope={'shape': 'delta'}, skycoords='altaz', pointing_coords='altaz')
+    ia.reserve(2)
+    for j in range(2):
+        ia.observe((2457000.5 + j, 20.0 * j), {'Tnet': 100.0}, NP.ones(32), [90.0, 270.0], skymod, 60.0)
+    with pytest.raises(RuntimeError):
+        ia.allgather_lags(1)                                           # needs the communicator of allgather()
+    gathered = ia.allgather(_abi.Context.comm_unique_id(), 1, 0)
+    assert all(isinstance(s, RI._DeviceSlot) for s in ia._cube)        # the shard itself never went to the host
+    w = NP.hanning(32) + 0.1
+    ia.delay_transform(pad=1.0, freq_wts=w, verbose=False)
+    lags = ia.allgather_lags(1)
+    assert lags.shape == (4, 32, 2) and NP.array_equal(lags, ia.skyvis_lag)
+    assert NP.array_equal(gathered, ia.skyvis_freq)
+    ref_lag, _ = DO.delay_transform(ia.skyvis_freq, ia.bp, ia.bp_wts, ia.freq_resolution, pad=1.0)
+    assert NP.max(NP.abs(lags - ref_lag)) <= 1e-10 * NP.max(NP.abs(ref_lag))
+    for t in range(2):                                                 # the visibilities are back in their slots afterwards
+        assert NP.array_equal(ia._ctx.get_vis(slot=t), ia.skyvis_freq[:, :, t])
