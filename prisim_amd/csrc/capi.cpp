@@ -257,6 +257,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
       ct /= 2;
     }
   }
+  if (ct > max_ct) ct = max_ct;          // a tuning request never overrides the accuracy cap (or the register budget) above
   pl.ct = ct;
   pl.pk = pl.f32 && (ct == 32 || ct == 64) && pl.kernel == PRISIM_KERNEL_RECURRENCE;
   pl.ntiles = (int)((nchan + ct - 1) / ct);

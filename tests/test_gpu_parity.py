@@ -148,7 +148,7 @@ def test_fp32_taper_grouped_and_exact_recurrences(ctx, monkeypatch):
     ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
     ctx.set_tuning(64, 0, 1)
     ctx.compute(precision=_abi.PRISIM_FP32, kernel=_abi.PRISIM_KERNEL_RECURRENCE)
-    assert ctx.timing()['last_taper_group'] == 0
+    assert ctx.timing()['last_taper_group'] == 0 and ctx.timing()['last_chan_tile'] == 32     # and onto 32-channel tiles, whatever was asked
     assert relerr(ctx.get_vis(), ref2, pb) <= TOL[_abi.PRISIM_FP32]
     ctx.set_tuning(0, 0, 0)
 
