@@ -105,7 +105,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--precision', choices=('fp32', 'fp64'), default='fp32')
     ap.add_argument('--nsrc', type=int, default=10000)
+    ap.add_argument('--workload', choices=('cfg3', 'cfg3d', 'cfg5'), default='cfg3',
+                    help='cfg3: the headline workload (BASELINE config 3, 1e4 point sources); cfg3d: config 3 with its nside=128 diffuse half '
+                         '(source-shape taper on); cfg5: one LST of config 5 (nside=256 diffuse sky, taper on)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--chan-tile', type=int, default=0, help='A/B hook: force the channel tile of the recurrence kernels (0 = planned)')
     args = ap.parse_args()
 
     # Libraries loaded later (RCCL prints a version banner on its first communicator) write to fd 1: keep the real stdout for
@@ -132,7 +136,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    cfg = W.config3(nsrc=args.nsrc)
+    if args.workload == 'cfg5':
+        cfg = W.config5(n_acc=1)
+    else:
+        cfg = W.config3(nsrc=args.nsrc, with_diffuse=(args.workload == 'cfg3d'))
     bl_all, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
     nbl_total, nchan, nsrc = bl_all.shape[0], ch.size, sky['dircos'].shape[0]
     bl_mine, n_real = shard_baselines(bl_all, world, rank)
@@ -144,6 +151,8 @@ def main():
     # PRISIM_BENCH_DEVICE: rehearsal hook (several ranks on one GPU to exercise the multi-process flow on a 1-GPU box)
     ctx = _abi.Context(int(os.environ.get('PRISIM_BENCH_DEVICE', local_rank)))
     ctx.set_array(bl_mine, ch, nt_max=K)
+    if args.chan_tile:
+        ctx.set_tuning(args.chan_tile, 0, 0)
     # inputs resident in HBM before the timed region: directions, reference fluxes, spectral indices;
     # beam x flux (nsrc x nchan) is built on the device (fused Airy beam x power law)
     ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY,
@@ -229,7 +238,7 @@ def main():
         alg_bytes = nsrc * nchan * wp + 24 * nsrc + 24 * bl_mine.shape[0] + 8 * nchan + 2 * 8 * bl_mine.shape[0] * nchan
         ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = traffic_src = None
-        if world == 1 and nsrc == 10000:
+        if world == 1 and nsrc == 10000 and args.workload == 'cfg3':
             tr = profiled_traffic('f32pk<64, false>' if dtype == 'f32' else 'k_skyvis_rec<double, 32, false>')
             if tr is not None:
                 traffic, traffic_src = tr

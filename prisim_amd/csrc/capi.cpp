@@ -237,7 +237,10 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   if (kernel == PRISIM_KERNEL_AUTO) pl.kernel = ctx->uniform ? PRISIM_KERNEL_RECURRENCE : PRISIM_KERNEL_DIRECT;
   const int64_t nbl = ctx->nbl, nchan = ctx->nchan, nsrc = ctx->nsrc;
   pl.nbgroups = (int)((nbl + kBlockThreads - 1) / kBlockThreads);
-  // channel tile: largest tile that still yields enough blocks to fill 256 CUs x 4 blocks
+  // channel tile: the cheapest tile (seed + 5 instructions per term, tiles past nchan are wasted work) that still yields enough
+  // blocks to fill 256 CUs x 4 blocks
+  // (fp64 48-channel tiles were tried: 5.98 instead of 6.47 instructions per term, but 22 tiles x 239 groups = 10.3 rounds of resident
+  // blocks end in a 7 % tail against 14.9 rounds at 32 channels -- measured 128 ms against 125 ms on the same box)
   int max_ct = pl.f32 ? 64 : 32;
   {
     // coarse channel grids with the taper run the exact per-step amplitude recurrence (the grouped form needs df/f_min <= 3.4e-3,
@@ -248,13 +251,18 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   }
   int ct = ctx->tune_ct;
   if (ct == 0) {
-    ct = max_ct;
     const int64_t want_blocks = 1024;
-    while (ct > 8) {
-      const int64_t tiles = (nchan + ct - 1) / ct;
-      const int64_t max_split = std::max<int64_t>(1, nsrc / 64);
-      if (tiles * pl.nbgroups * max_split >= want_blocks) break;
-      ct /= 2;
+    const int64_t max_split = std::max<int64_t>(1, nsrc / 64);
+    const double seed = pl.f32 ? 30.0 : 48.0;             // instructions per (source, baseline, tile) outside the pair loop (ISA census)
+    const double per_term = pl.f32 ? 2.5 : 5.0;
+    double best = 0.0;
+    ct = 8;
+    for (int cand : {64, 32, 16, 8}) {
+      if (cand > max_ct) continue;
+      const int64_t tiles = (nchan + cand - 1) / cand;
+      if (cand > 8 && tiles * pl.nbgroups * max_split < want_blocks) continue;
+      const double cost = (double)tiles * (seed + per_term * cand);
+      if (best == 0.0 || cost < best * (1.0 - 1e-9)) { best = cost; ct = cand; }
     }
   }
   if (ct > max_ct) ct = max_ct;          // a tuning request never overrides the accuracy cap (or the register budget) above
@@ -276,7 +284,8 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   if (nsplit == 0) {
     const int64_t base = (int64_t)pl.ntiles * pl.nbgroups;
     // resident blocks per CU = waves per SIMD the kernels are built for (PK_WAVES / WavesPerEU in skyvis_kernels.hip)
-    const int per_cu = pl.pk ? 2 : (pl.f32 ? 4 : (ct <= 8 ? 4 : (ct <= 16 ? 3 : 2)));
+    // (fp64: the 16 KiB phasor table + 36 KiB flush buffer + prefetch area = 56 KiB of LDS per block allow 2 blocks per CU)
+    const int per_cu = pl.pk ? 2 : (pl.f32 ? 4 : 2);
     const int64_t slots = (int64_t)std::max(ctx->cu_count, 1) * per_cu;
     // The grid runs in rounds of `slots` resident blocks.  Measured on 1/2, 1/4 and 1/8 baseline shards of config 3
     // (tools/shard_nsplit_sweep.py, candidates alternating): the step time is lowest when the sources are split so that the grid

@@ -166,6 +166,49 @@ __device__ __forceinline__ void sincos_qcycles(double a4, double& c, double& s) 
 }
 
 
+// fp64 (cos, sin) of 2 pi a from a table of kTabN unit phasors in LDS: the caller passes aN = a * kTabN (any magnitude below 2^31);
+// k = rint(aN) picks the table entry (k mod kTabN), the residual angle |t| <= pi / kTabN = 3.1e-3 rad needs only
+// sin t = t - t^3/6 (next term 2.3e-15) and cos t = 1 - t^2/2 + t^4/24 (next term 1.2e-18).  16 VALU instructions and one
+// ds_read_b128 instead of ~30 for the two minimax polynomials with quadrant logic: the fp64 kernels issue v_fma_f64 back to back
+// (SQ busy ~ 100 % of the fp64 rate, profiles/r02a_fp64), so every seed instruction saved is throughput.
+constexpr int kTabN = 1024;
+struct TabPhase { double r; double2 e; };      // residual in table steps (|r| <= 1/2) and the table phasor of one lookup
+__device__ __forceinline__ TabPhase sincos_tab_front(double aN, const double2* tab) {
+  // k = rint(aN) through the 1.5 * 2^52 shift: the low mantissa word of the sum is k modulo 2^32, so no conversion is needed
+  const double shifted = aN + 6755399441055744.0;
+  const double k = shifted - 6755399441055744.0;
+  TabPhase r;
+  r.r = aN - k;
+  r.e = tab[__double2loint(shifted) & (kTabN - 1)];
+  return r;
+}
+__device__ __forceinline__ void sincos_tab_back(const TabPhase& q, double& c, double& s) {
+  // t = w r with w = 2 pi / kTabN folded into the coefficients: sin t = r (w - w^3/6 r^2), cos t = 1 - w^2/2 r^2 + w^4/24 r^4
+  constexpr double w = 6.283185307179586476925 / kTabN;
+  const double z = q.r * q.r;
+  const double sl = q.r * __builtin_fma(z, -(w * w * w) / 6.0, w);
+  const double cl = __builtin_fma(z, __builtin_fma(z, (w * w * w * w) / 24.0, -0.5 * w * w), 1.0);
+  c = __builtin_fma(q.e.x, cl, -(q.e.y * sl));
+  s = __builtin_fma(q.e.y, cl, q.e.x * sl);
+}
+
+// each thread of the block fills kTabN / kBlockThreads entries (ocml sincospi: exact at the octant points); the caller barriers
+__device__ __forceinline__ void fill_phasor_table(double2* tab) {
+  for (int i = threadIdx.x; i < kTabN; i += kBlockThreads) {
+    double sn, cs;
+    sincospi((double)(2 * i) / (double)kTabN, &sn, &cs);
+    tab[i] = make_double2(cs, sn);
+  }
+}
+
+// a / c for c in [0.7, 1] to ~1e-15 relative: v_rcp_f64 seed (~2^-26) and one Newton step; the quotient is not corrected further
+// (the fp64 tolerance is 1e-11 of sum|pbflux|, and an error of tan(alpha/2) only shifts the step angle by ~alpha * 1e-15)
+__device__ __forceinline__ double div_unit_range_fast_f64(double a, double c) {
+  double r = __builtin_amdgcn_rcp(c);
+  r = __builtin_fma(r, __builtin_fma(-c, r, 1.0), r);
+  return a * r;
+}
+
 // ------------------------------------------------------------------------------------------
 // Recurrence kernel
 // ------------------------------------------------------------------------------------------
@@ -173,7 +216,8 @@ __device__ __forceinline__ void sincos_qcycles(double a4, double& c, double& s) 
 // up to 256 VGPRs on scheduling freedom and drops to 1-2 waves/SIMD, too few to keep the
 // 2-cycle fp32 VALU issue slots filled -- see tools/microbench_valu.hip results).
 template <typename T, int CT, bool TAPER> struct WavesPerEU {
-  static constexpr int value = (sizeof(T) == 4) ? (CT <= 32 ? 4 : 2) : (CT <= 8 ? 4 : (CT <= 16 ? 3 : 2));
+  // fp64: 56 KiB of LDS per block (phasor table, flush buffer, prefetch area) admit 2 blocks per CU whatever the tile
+  static constexpr int value = (sizeof(T) == 4) ? (CT <= 32 ? 4 : 2) : 2;
 };
 
 // Wave-local ordering point between LDS writes and LDS reads of other lanes of the same wave (DS operations of one wave
@@ -204,25 +248,38 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 
+// XCD-aware, load-balanced block -> (slab, baseline group) map.  Blocks are dealt round-robin to the 8 XCDs (blockIdx % 8 shares an
+// XCD).  The work items (slab, baseline group), slab-major, are cut into 8 equal contiguous ranges, one per XCD: the blocks resident
+// on one XCD walk the baseline groups of one slab before the next, so that slab's pbflux rows stay in the XCD's 4 MiB L2, and every
+// XCD gets the same number of blocks whatever the slab count (pinning whole slabs to XCDs left 2 of 8 XCDs with 2 instead of 3
+// tiles at 22 tiles: 9 % of the launch).  Returns false for the padding blocks past the last item.
+__device__ __forceinline__ bool block_item(const SkyvisParams& p, int& slab, int& bg) {
+  const int total = p.ntiles * p.nsplit * p.nbgroups;
+  const int per_xcd = (total + 7) >> 3;
+  const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  slab = item / p.nbgroups;
+  bg = item - slab * p.nbgroups;
+  return (int)(blockIdx.x >> 3) < per_xcd && item < total;
+}
+
 // LIFT: lifting (three-shear) form of the step rotation, see skyvis_rec_f32pk_body below; chosen per baseline group by the host.
 template <typename T, int CT, bool TAPER, bool LIFT>
-__device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned char* flush_lds) {
+__device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned char* flush_lds, unsigned char* pf_area, const double2* tab) {
   static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
   constexpr int HC = CT / 2;                       // channels per chain (here the taper multiplies pbflux, so z stays a pure rotation
                                                    // and the lifting form applies with or without it)
-  constexpr int NH = CT / 2;                       // elements per half row
+  // The row is fetched in NPART pieces of at most 64 bytes (16 SGPRs) through two SGPR buffers: with half rows (2 x 32 SGPRs at
+  // CT = 32 fp64) the buffers did not fit beside the kernel's other wave-uniform state and the compiler moved 103-134 SGPRs
+  // through v_readlane / v_writelane around the source loop.
+  constexpr int NPART = (CT * (int)sizeof(T) / 64) > 2 ? (CT * (int)sizeof(T) / 64) : 2;
+  constexpr int NH = CT / NPART;                   // elements per piece
+  static_assert(NPART % 2 == 0 && NH % 2 == 0, "pieces hold whole (up, down) pairs and alternate between two buffers");
   typedef const __attribute__((address_space(4))) T* crow_p;
   typedef const volatile __attribute__((address_space(4))) double* cdir_p;    // volatile: see the packed kernel (keeps the load where it is written)
   typedef const __attribute__((address_space(4))) float* cfsq_p;
 
-  // ---- XCD-aware block -> (slab, baseline group) map ------------------------------------
-  // Blocks are dealt round-robin to the 8 XCDs (blockIdx % 8 shares an XCD), so slab ids that
-  // are equal mod 8 live on one XCD and its L2 keeps that slab's pbflux rows hot.
-  const int xcd = blockIdx.x & 7;
-  const int j = blockIdx.x >> 3;
-  const int slab = xcd + 8 * (j / p.nbgroups);
-  const int bg = j % p.nbgroups;
-  if (slab >= p.ntiles * p.nsplit) return;
+  int slab, bg;
+  if (!block_item(p, slab, bg)) return;
   const int tile = slab % p.ntiles;
   const int split = slab / p.ntiles;
 
@@ -242,6 +299,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   const double fc = p.f0 + (double)(k0 + HC) * p.df;   // frequency of the seed (centre) channel
   const double df = p.df;
   const double fc4 = 4.0 * fc, df4 = 4.0 * df;         // quarter-cycle scaling for sincos_qcycles
+  const double fcN = fc * kTabN, dfN = df * kTabN, dfN_half = df * (0.5 * kTabN);   // table scaling for sincos_tab (fp64)
 
   // taper per-lane constants
   double bl2_c2 = 0.0, bpc = 0.0;
@@ -317,7 +375,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   const float* const pf_rows = reinterpret_cast<const float*>(reinterpret_cast<const T*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT +
                                                               (size_t)s_begin * CT);
   const float* const pf_dirs = reinterpret_cast<const float*>(p.dirs_prep) + (size_t)s_begin * 8;
-  const lptr_t pf_lds = (lptr_t)(flush_lds + flush_lds_bytes<T>() + (tid >> 6) * kPrefetchWaveBytes);
+  const lptr_t pf_lds = (lptr_t)(pf_area + (tid >> 6) * kPrefetchWaveBytes);
   const bool pf_on = n_loc >= 64;                    // 1 KiB = 4 ... 32 rows per request, clamped 32 rows before the end
   int seg0 = 0;
   do {
@@ -325,61 +383,97 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   if (wave_active && seg1 > seg0) {
     T ra[NH], rb[NH];                                  // [2j] = channel HC+j (up), [2j+1] = channel HC-1-j (down)
     double sv[4] = {0.0, 0.0, 0.0, 0.0};
+    // The seed of source s+1 is started one piece early (software pipeline): its delay d, the taper's kappa and -- fp64 -- the two
+    // phasor-table reads are formed right after the wait of phase 1 of source s, so the LDS latency hides behind a piece of pair
+    // arithmetic and no s_waitcnt ever has a table read and a fresh scalar request outstanding together (LDS and SMEM share
+    // lgkmcnt and SMEM returns out of order: the only usable wait is lgkmcnt(0), which would otherwise expose a scalar-cache round
+    // trip at the top of every source).  The directions are therefore requested TWO sources ahead.
+    struct Pre { double d, kap; TabPhase pc, ps; };
+    auto front = [&](Pre& q) {
+      q.d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));   // seconds
+      q.kap = sv[3];
+      if constexpr (sizeof(T) == 8) {
+        q.pc = sincos_tab_front(q.d * fcN, tab);                                // phase at the centre channel
+        q.ps = sincos_tab_front(q.d * (LIFT ? dfN_half : dfN), tab);            // step (LIFT: its half angle)
+      }
+    };
+    Pre pre, pre_next;
     {
-      const crow_p r0 = gps + (size_t)seg0 * CT;
-#pragma unroll
-      for (int i = 0; i < NH; ++i) ra[i] = r0[i];
       const cdir_p d0 = gds + (size_t)seg0 * 4;
       sv[0] = d0[0]; sv[1] = d0[1]; sv[2] = d0[2];
       if (TAPER) sv[3] = d0[3];
+      front(pre);                                                      // waits for the direction
+      __builtin_amdgcn_sched_barrier(0);
+      const crow_p r0 = gps + (size_t)seg0 * CT;
+#pragma unroll
+      for (int i = 0; i < NH; ++i) ra[i] = r0[i];
+      const cdir_p d1 = gds + (size_t)((seg0 + 1 < seg1) ? seg0 + 1 : seg0) * 4;
+      sv[0] = d1[0]; sv[1] = d1[1]; sv[2] = d1[2];
+      if (TAPER) sv[3] = d1[3];
+      __builtin_amdgcn_sched_barrier(0);
     }
     for (int s = seg0; s < seg1; ++s) {
       const crow_p row = gps + (size_t)s * CT;
       const int sn = (s + 1 < seg1) ? s + 1 : s;                    // the last source is simply fetched again
+      const int sn2 = (s + 2 < seg1) ? s + 2 : seg1 - 1;
       if (pf_on && ((s - seg0) & 3) == 0) {
         // L2 warm-up, every 4th source: 1 KiB of rows and 8 directions kPrefetchAhead sources ahead (see k_skyvis_rec_f32pk)
-        constexpr int kRowDwords = CT * (int)sizeof(T) / 4;          // <= 64
+        constexpr int kRowDwords = CT * (int)sizeof(T) / 4;          // <= 96
         const int spf = (s + kPrefetchAhead < n_loc - 32) ? s + kPrefetchAhead : n_loc - 32;
         int lane_pf = lane;
         asm volatile("" : "+v"(lane_pf));                            // formed here from the lane id: no per-lane pointers kept live across the loop
         __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * kRowDwords + lane_pf * 4), pf_lds, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(pf_dirs + (size_t)spf * 8 + lane_pf), pf_lds, 4, 0, 0);
       }
-      // the first use of sv waits for everything in flight (first half row + direction); only then ask for the second half
-      const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));   // seconds
+      // top of source s: the first piece of its row, the direction of s+1 and the table reads of its own seed are in flight
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NH; ++i) rb[i] = row[NH + i];
       __builtin_amdgcn_sched_barrier(0);
+      const double d = pre.d;
 
-      T zc, zs, rc, rs;
-      sincos_qcycles(d * fc4, zc, zs);                           // phase at the centre channel
+      T zc, zs, rc = (T)1, rs;
       const double th4 = d * df4;
       T tl = (T)0;                         // tan(alpha/2), alpha = -2 pi theta the step angle (LIFT groups only)
-      if constexpr (LIFT && sizeof(T) == 8) {
-        // |theta| <= 1/4 cycle is guaranteed for this baseline group: half angle beta = pi theta in [-pi/4, pi/4] straight into the
-        // polynomial kernels (no reduction, no quadrant logic), tan(beta) by a short reciprocal; sin/cos of the step by doubling
-        double sb, cb;
-        sincos_kernel_f64(th4 * 0.78539816339744830962, sb, cb);                  // beta = (th4 / 4) * pi
-        rc = __builtin_fma(-2.0 * sb, sb, 1.0);                                   // cos 2 beta
-        rs = 2.0 * sb * cb;                                                       // sin 2 beta
-        tl = -div_unit_range_f64(sb, cb);                                         // alpha = -2 beta
+      if constexpr (sizeof(T) == 8) {
+        sincos_tab_back(pre.pc, zc, zs);
+        if constexpr (LIFT) {
+          // |theta| <= 1/4 cycle is guaranteed for this baseline group: half angle beta = pi theta in [-pi/4, pi/4] from the table,
+          // tan(beta) by a short reciprocal (cos beta >= 0.7), sin of the step by doubling; the lifting form never needs cos alpha
+          double sb, cb;
+          sincos_tab_back(pre.ps, cb, sb);
+          rs = 2.0 * sb * cb;                                                       // sin 2 beta
+          tl = -div_unit_range_fast_f64(sb, cb);                                    // alpha = -2 beta
+        } else {
+          sincos_tab_back(pre.ps, rc, rs);                       // phase step per channel
+        }
       } else {
-        sincos_qcycles(th4, rc, rs);                             // phase step per channel
+        sincos_qcycles(d * fc4, zc, zs);
+        sincos_qcycles(th4, rc, rs);
       }
       // exp(-2 pi i phi): z = (cos, -sin)
       T ur = zc, ui = -zs;            // up chain: channel HC + j
       const T rr = rc, ri = -rs;      // step forward; step backward is conj(r)
-      T dr = fma_(ur, rr, ui * ri);        // z * conj(r): channel HC-1
-      T di = fma_(ui, rr, -(ur * ri));
       if constexpr (LIFT && sizeof(T) == 4) tl = -tan_pi_y((float)(0.25 * th4));      // |theta| <= 1/8 cycle guaranteed
+      T dr, di;                            // z * conj(r): channel HC-1
+      if constexpr (LIFT) {
+        // one inverse lifting step (t -> -t, s -> -s)
+        const T xd = fma_(tl, ui, ur);
+        di = fma_(-ri, xd, ui);
+        dr = fma_(tl, di, xd);
+      } else {
+        dr = fma_(ur, rr, ui * ri);
+        di = fma_(ui, rr, -(ur * ri));
+      }
       // source-shape taper  w = exp(-g f^2),  g = kappa_s * (|b|^2/c^2 - tau^2),  tau = d + b.s_pc/c
       double gq = 0.0;
       float g2 = 0.f;
       double wu = 1.0, wd = 1.0, qu = 1.0, qd = 1.0, h = 1.0;
       if constexpr (TAPER) {
         const double tau = d + bpc;
-        gq = sv[3] * (bl2_c2 - tau * tau);
+        gq = pre.kap * (bl2_c2 - tau * tau);
         gq = gq > 0.0 ? gq : 0.0;      // |b|^2 >= (b.s)^2 up to rounding
         if constexpr (sizeof(T) == 4) {
           g2 = -(float)(gq * p.fsq_scale);   // fp32: direct exp2 per term (no error accumulation)
@@ -460,19 +554,36 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
         }
       };
       pairs(ra, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the second half row has landed before the next requests go out
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const crow_p rn = gps + (size_t)sn * CT;
 #pragma unroll
-        for (int i = 0; i < NH; ++i) ra[i] = rn[i];
-        const cdir_p dn = gds + (size_t)sn * 4;
-        sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
-        if (TAPER) sv[3] = dn[3];
+      for (int ph = 1; ph < NPART; ++ph) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): piece ph has landed before the next request goes out
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 1) {
+          front(pre_next);                           // direction of s+1 (requested one source ago): d, kappa, table reads
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ph + 1 < NPART) {
+          // piece ph + 1 of this source into the buffer piece ph - 1 has just left
+#pragma unroll
+          for (int i = 0; i < NH; ++i) {
+            if (ph & 1) ra[i] = row[(ph + 1) * NH + i];
+            else rb[i] = row[(ph + 1) * NH + i];
+          }
+        } else {
+          // first piece of the next source (NPART is even: it goes to ra) + the direction of the one after it
+          const crow_p rn = gps + (size_t)sn * CT;
+#pragma unroll
+          for (int i = 0; i < NH; ++i) ra[i] = rn[i];
+          const cdir_p dn = gds + (size_t)sn2 * 4;
+          sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
+          if (TAPER) sv[3] = dn[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph & 1) pairs(rb, ph * (NH / 2));
+        else pairs(ra, ph * (NH / 2));
       }
-      __builtin_amdgcn_sched_barrier(0);
-      pairs(rb, NH / 2);
+      pre = pre_next;
     }
   }
   flush();
@@ -483,13 +594,25 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
 template <typename T, int CT, bool TAPER>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(WavesPerEU<T, CT, TAPER>::value)))
 void k_skyvis_rec(const SkyvisParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<T>() + kPrefetchLdsBytes];
-  const int bg = (blockIdx.x >> 3) % p.nbgroups;
-  if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {        // block-uniform; the two bodies share no live state
-    skyvis_rec_body<T, CT, TAPER, true>(p, flush_lds);
+  // three separate LDS objects: the LDS-DMA prefetch writes (global_load_lds) are tracked by vmcnt, and the compiler makes every
+  // LDS read that may alias their target wait for vmcnt(0) -- with one shared array the phasor-table reads of the fp64 seed
+  // waited out an HBM round trip every 4th source
+  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<T>()];
+  __shared__ __attribute__((aligned(16))) unsigned char pf_area[kPrefetchLdsBytes];
+  __shared__ double2 tab_lds[sizeof(T) == 8 ? kTabN : 1];
+  const double2* tab = nullptr;
+  if constexpr (sizeof(T) == 8) {
+    fill_phasor_table(tab_lds);
+    __syncthreads();                                             // the only block barrier of the kernel: before any early exit
+    tab = tab_lds;
+  }
+  int slab_, bg;
+  const bool in_range = block_item(p, slab_, bg);                  // padding blocks read flag 0 and leave inside the body
+  if (in_range && p.lift_flags != nullptr && p.lift_flags[bg] != 0) {   // block-uniform; the two bodies share no live state
+    skyvis_rec_body<T, CT, TAPER, true>(p, flush_lds, pf_area, tab);
     return;
   }
-  skyvis_rec_body<T, CT, TAPER, false>(p, flush_lds);
+  skyvis_rec_body<T, CT, TAPER, false>(p, flush_lds, pf_area, tab);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -561,11 +684,8 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   constexpr int NPART = (TAPER && CT >= 64) ? 4 : 2;
   constexpr int NP = CT / NPART;                     // floats per piece
 
-  const int xcd = blockIdx.x & 7;
-  const int jblk = blockIdx.x >> 3;
-  const int slab = xcd + 8 * (jblk / p.nbgroups);
-  const int bg = jblk % p.nbgroups;
-  if (slab >= p.ntiles * p.nsplit) return;
+  int slab, bg;
+  if (!block_item(p, slab, bg)) return;
   const int tile = slab % p.ntiles;
   const int split = slab / p.ntiles;
 
@@ -877,16 +997,16 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>() + kPrefetchLdsBytes];
   if constexpr (!TAPER) {
     // block-uniform choice made by the host per baseline group; the two bodies share no live state
-    const int jblk = blockIdx.x >> 3;
-    const int bg = jblk % p.nbgroups;
+    int slab_, bg;
+    if (!block_item(p, slab_, bg)) return;
     if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {
       skyvis_rec_f32pk_body<CT, false, true>(p, flush_lds);
       return;
     }
   } else {
     // lift_flags[bg] = 1: |step angle| <= pi/4 for every source of this baseline group; 0: re-anchor the chains at their midpoint
-    const int jblk = blockIdx.x >> 3;
-    const int bg = jblk % p.nbgroups;
+    int slab_, bg;
+    if (!block_item(p, slab_, bg)) return;
     const bool small_step = p.lift_flags != nullptr && p.lift_flags[bg] != 0;
     if (p.taper_group) {                      // launch-uniform, chosen by the host from df / f_min
       if (small_step) skyvis_rec_f32pk_body<CT, true, false, true, 0>(p, flush_lds);
@@ -1043,9 +1163,9 @@ __global__ void k_fsq(const double* __restrict__ freqs, float* __restrict__ fsq,
 // ------------------------------------------------------------------------------------------
 template <typename T, int CT>
 static hipError_t launch_rec_ct(const SkyvisParams& p, hipStream_t stream) {
-  const int nslabs = p.ntiles * p.nsplit;
-  const int slabs_per_xcd = (nslabs + 7) / 8;
-  const unsigned grid = 8u * (unsigned)slabs_per_xcd * (unsigned)p.nbgroups;
+  const int64_t items = (int64_t)p.ntiles * p.nsplit * p.nbgroups;          // see block_item()
+  if (items <= 0 || items > 0x3fffffffLL) return hipErrorInvalidValue;
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
   if (p.taper)
     hipLaunchKernelGGL((k_skyvis_rec<T, CT, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   else
@@ -1055,9 +1175,9 @@ static hipError_t launch_rec_ct(const SkyvisParams& p, hipStream_t stream) {
 
 template <int CT>
 static hipError_t launch_rec_pk_ct(const SkyvisParams& p, hipStream_t stream) {
-  const int nslabs = p.ntiles * p.nsplit;
-  const int slabs_per_xcd = (nslabs + 7) / 8;
-  const unsigned grid = 8u * (unsigned)slabs_per_xcd * (unsigned)p.nbgroups;
+  const int64_t items = (int64_t)p.ntiles * p.nsplit * p.nbgroups;          // see block_item()
+  if (items <= 0 || items > 0x3fffffffLL) return hipErrorInvalidValue;
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
   if (p.taper)
     hipLaunchKernelGGL((k_skyvis_rec_f32pk<CT, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   else

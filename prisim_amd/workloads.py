@@ -97,7 +97,7 @@ def config3(nsrc=10000, with_diffuse=False):
         sky = concat_skies(sky, diffuse_sky(128, 33))
     return {'name': 'cfg3: HERA-350 (61075 bl) x 1024 ch x %d src, Airy 14 m' % sky['dircos'].shape[0], 'baselines': bl,
             'channels': channel_grid(150e6, 97656.25, 1024), 'sky': sky,
-            'beam': 'airy', 'diameter': 14.0, 'taper': False, 'precision': 'fp32'}
+            'beam': 'airy', 'diameter': 14.0, 'taper': bool(with_diffuse), 'precision': 'fp32'}
 
 
 def subsample(cfg, bl_stride=1, ch_count=None, src_stride=1):

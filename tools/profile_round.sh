@@ -1,14 +1,18 @@
 #!/bin/bash
-# rocprofv3 recipe behind profiles/<round>/ (run on the MI355X box through gpurun, from the repo root):
-#   tools/profile_round.sh r02      -> gpurun_out/prof_r02/{kernel_stats.csv, pmc_summary.json, bench_under_rocprof.json}
+# rocprofv3 recipe behind profiles/<tag>/ (run on the MI355X box through gpurun, from the repo root):
+#   tools/profile_round.sh r02_taper_f32 --workload cfg5 --steps 2
+#     -> gpurun_out/prof_<tag>/{kernel_stats.csv, pmc_summary.json, bench_under_rocprof.json}
 # Kernel timing and every counter group are separate passes (gpurun refuses --pmc combined with API tracing).
 set -e
-ROUND=${1:-rXX}
+TAG=${1:-rXX}
+shift || true
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_$ROUND
+OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+STEPS="--steps 5"
+case " $* " in *" --steps "*) STEPS="";; esac
+BENCH="python3 $REPO/bench.py $STEPS --warmup 1 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 echo "trace done"
 i=0
@@ -19,4 +23,6 @@ for group in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_V
   echo "pmc $i done"
 done
 cd "$REPO"
+git rev-parse HEAD:prisim_amd/csrc > "$OUT/csrc_tree_hash.txt" 2>/dev/null || sha1sum prisim_amd/csrc/*.hip prisim_amd/csrc/*.cpp prisim_amd/csrc/*.h | sha1sum | cut -d' ' -f1 > "$OUT/csrc_tree_hash.txt"
 python3 tools/summarize_pmc.py "$OUT"
+rm -rf "$OUT"/trace "$OUT"/pmc[0-9]
