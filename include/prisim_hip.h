@@ -180,6 +180,13 @@ int prisim_hip_set_external_beam(prisim_ctx* ctx, const double* beam, int64_t np
  * (the reference stores supplied beams as float32, interferometry.py:4466), times fluxes (:6254). */
 int prisim_hip_set_sky_external(prisim_ctx* ctx, const prisim_sky* sky);
 
+/* The same with the flux spectra formed on the device: S = flux_ref * (f / ref_freq_hz)^spindex (the spectrum
+ * SkyModel.generate_spectrum returns for a power-law sky model, interferometry.py:6249), or sky->flux_spectrum when given.
+ * Only nsrc-sized vectors cross PCIe per snapshot (a drift scan's 32 accumulations re-send no nsrc x nchan table);
+ * beam_kind, diameter_m, beam_pc_dircos and ext are ignored.  Like every set_sky_* call it allocates nothing after the first
+ * snapshot of a given size and does not synchronise the stream: inputs are copied to pinned staging before it returns. */
+int prisim_hip_set_sky_external_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky);
+
 /* Read back the device pbflux (float64 [nsrc][nchan]) -- for parity tests of the fused beams. */
 int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out);
 
@@ -193,6 +200,20 @@ int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out);
  * (delay_spectrum.py:3992-3993) instead of / in addition to out (either may be NULL). */
 int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts, double pad,
                                double* out, double* lags_out, double* out_power, double power_scale);
+
+/* The same transform with the results left in HBM: lag spectra [nt][nbl][nchan_out] complex128 (want_lag) and/or delay power
+ * float64 (want_power) of all nt snapshots stay resident in the context until read back (whole, or selected baselines) or
+ * exchanged with prisim_hip_allgather_lags -- config 5's 120 x 61075 spectra never cross PCIe unless asked for.
+ * bpwts: host [nbl][nchan] or NULL.  lags_out [nchan] / nout_out may be NULL.  Asynchronous on the context stream.
+ * When 1 + pad is an integer and nchan is 256 ... 4096 (a power of two) the stage is ONE kernel (delay_kernels.hip): every
+ * visibility is read once and every lag written once -- the kept samples of the zero-padded transform are exactly the
+ * nchan-point transform; other shapes run window/pad -> rocFFT -> shift/decimate. */
+int prisim_hip_delay_transform_device(prisim_ctx* ctx, int64_t nt, const double* bpwts, double pad, int want_lag, int want_power,
+                                      double power_scale, double* lags_out, int64_t* nout_out);
+/* Read back snapshots [t0, t0 + nt) of the resident spectra: out [nt][nrows][nchan_out] (complex128 / float64) for the baselines
+ * listed in rows[nrows], or [nt][nbl][nchan_out] when rows is NULL.  Synchronises the stream. */
+int prisim_hip_get_lags(prisim_ctx* ctx, int64_t t0, int64_t nt, const int64_t* rows, int64_t nrows, double* out);
+int prisim_hip_get_delay_power(prisim_ctx* ctx, int64_t t0, int64_t nt, const int64_t* rows, int64_t nrows, double* out);
 
 /* ---- phase-centre rotation (interferometry.py:7871-7877) --------------------------- */
 
@@ -227,6 +248,10 @@ int prisim_hip_allgather_slot_async(prisim_ctx* ctx, int64_t slot, int as_c64);
 /* Copy the gathered cube to the host: out [nt][nranks][nbl_shard][nchan], complex128 or complex64
  * according to the as_c64 of the last allgather. */
 int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out);
+/* All-gather of the RESIDENT lag spectra (prisim_hip_delay_transform_device with want_lag) of nt snapshots, device to device:
+ * the FFT runs along frequency, so every rank transforms its own baseline shard and the spectra are exchanged like the
+ * visibilities; the gathered cube then holds [nt][nranks][nbl_shard][nchan_out] complex128. */
+int prisim_hip_allgather_lags(prisim_ctx* ctx, int64_t nt);
 /* Checksum (sum of all re,im accumulated in double, fixed reduction order) of the gathered cube,
  * computed on the device. */
 int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out);
@@ -244,7 +269,8 @@ typedef struct prisim_timing {
   int32_t last_nsplit;       /* source split factor */
   int32_t last_lift_groups;  /* baseline groups (of 256) that ran the lifting (three-shear) rotation; 0 for the packed fp32 taper kernel */
   int32_t last_taper_group;  /* 1: the packed fp32 taper kernel ran its grouped recurrence (df/f_min <= 3.4e-3), 0: exact per-step form */
-  int32_t reserved_;
+  int32_t last_delay_fused;  /* 1: the last delay_transform_device ran the fused LDS FFT kernel, 0: the rocFFT pipeline */
+  double last_delay_ms;      /* hipEvent duration of the last prisim_hip_delay_transform_device (all batches) */
 } prisim_timing;
 
 int prisim_hip_sync(prisim_ctx* ctx);

@@ -23,8 +23,9 @@ EXPORTS = (
     'prisim_hip_create', 'prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version',
     'prisim_hip_set_array', 'prisim_hip_set_sky', 'prisim_hip_compute', 'prisim_hip_get_vis',
     'prisim_hip_skyvis', 'prisim_hip_set_vis', 'prisim_hip_set_sky_analytic',
-    'prisim_hip_set_external_beam', 'prisim_hip_set_sky_external', 'prisim_hip_get_pbflux',
-    'prisim_hip_delay_transform', 'prisim_hip_phase_rotate', 'prisim_hip_noise', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
+    'prisim_hip_set_external_beam', 'prisim_hip_set_sky_external', 'prisim_hip_set_sky_external_analytic', 'prisim_hip_get_pbflux',
+    'prisim_hip_delay_transform', 'prisim_hip_delay_transform_device', 'prisim_hip_get_lags', 'prisim_hip_get_delay_power',
+    'prisim_hip_allgather_lags', 'prisim_hip_phase_rotate', 'prisim_hip_noise', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
     'prisim_hip_allgather', 'prisim_hip_allgather_slot_async', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
 )
@@ -111,7 +112,7 @@ class PrisimTiming(C.Structure):
     _fields_ = [('last_kernel_ms', C.c_double), ('last_compute_ms', C.c_double), ('sum_kernel_ms', C.c_double),
                 ('n_kernel', C.c_int64), ('last_terms', C.c_int64), ('last_kernel_id', C.c_int32),
                 ('last_chan_tile', C.c_int32), ('last_nsplit', C.c_int32), ('last_lift_groups', C.c_int32),
-                ('last_taper_group', C.c_int32), ('reserved_', C.c_int32)]
+                ('last_taper_group', C.c_int32), ('last_delay_fused', C.c_int32), ('last_delay_ms', C.c_double)]
 
 
 class PrisimHipError(RuntimeError):
@@ -150,8 +151,13 @@ def load_library():
     lib.prisim_hip_set_sky_analytic.argtypes = [vp, C.POINTER(PrisimBeamSky)]
     lib.prisim_hip_set_external_beam.argtypes = [vp, vp, i64, i64, vp]
     lib.prisim_hip_set_sky_external.argtypes = [vp, C.POINTER(PrisimSky)]
+    lib.prisim_hip_set_sky_external_analytic.argtypes = [vp, C.POINTER(PrisimBeamSky)]
     lib.prisim_hip_get_pbflux.argtypes = [vp, vp]
     lib.prisim_hip_delay_transform.argtypes = [vp, i64, vp, dbl, vp, vp, vp, dbl]
+    lib.prisim_hip_delay_transform_device.argtypes = [vp, i64, vp, dbl, i32, i32, dbl, vp, C.POINTER(i64)]
+    lib.prisim_hip_get_lags.argtypes = [vp, i64, i64, vp, i64, vp]
+    lib.prisim_hip_get_delay_power.argtypes = [vp, i64, i64, vp, i64, vp]
+    lib.prisim_hip_allgather_lags.argtypes = [vp, i64]
     lib.prisim_hip_phase_rotate.argtypes = [vp, i64, vp]
     lib.prisim_hip_noise.argtypes = [vp, i64, vp, C.c_uint64, i64, vp]
     lib.prisim_hip_comm_unique_id.argtypes = [C.c_char_p]
@@ -321,6 +327,35 @@ class Context(object):
         self._check(self._lib.prisim_hip_set_sky_external(self._h, C.byref(sky)), 'prisim_hip_set_sky_external')
         self.nsrc = nsrc
 
+    def set_sky_external_analytic(self, dircos, flux_ref, spindex, ref_freq_hz, pc_dircos, fwhm_deg=None, flux_spectrum=None):
+        """External-beam sky whose flux spectra are formed on the device from the power law flux_ref*(f/ref)^spindex (only nsrc-sized
+        vectors are uploaded per snapshot), or from flux_spectrum (nsrc, nchan) when given."""
+        dc = NP.ascontiguousarray(dircos, dtype=NP.float64).reshape(-1, 3)
+        nsrc = dc.shape[0]
+        fs = fr = sp = None
+        if flux_spectrum is not None:
+            fs = NP.ascontiguousarray(flux_spectrum, dtype=NP.float64)
+            if fs.size != nsrc * self.nchan:
+                raise ValueError('flux_spectrum must have shape (nsrc, nchan)')
+            ref_freq_hz = 1.0 if ref_freq_hz is None else ref_freq_hz
+        else:
+            fr = NP.ascontiguousarray(flux_ref, dtype=NP.float64).ravel()
+            sp = NP.ascontiguousarray(spindex, dtype=NP.float64).ravel()
+            if fr.size != nsrc or sp.size != nsrc:
+                raise ValueError('flux_ref and spindex must have nsrc elements')
+        pc = NP.ascontiguousarray(pc_dircos, dtype=NP.float64).ravel()
+        if pc.size != 3:
+            raise ValueError('pc_dircos must have 3 elements')
+        fw = None
+        if fwhm_deg is not None:
+            fw = NP.ascontiguousarray(fwhm_deg, dtype=NP.float64).ravel()
+            if fw.size != nsrc:
+                raise ValueError('fwhm_deg must have nsrc elements')
+        sky = PrisimBeamSky(nsrc, _ptr(dc), _ptr(fr), _ptr(sp), _ptr(fs), float(ref_freq_hz), PRISIM_BEAM_DELTA, 1.0,
+                            _ptr(pc), _ptr(pc), _ptr(fw), None)
+        self._check(self._lib.prisim_hip_set_sky_external_analytic(self._h, C.byref(sky)), 'prisim_hip_set_sky_external_analytic')
+        self.nsrc = nsrc
+
     def get_pbflux(self):
         out = NP.empty((self.nsrc, self.nchan), dtype=NP.float64)
         self._check(self._lib.prisim_hip_get_pbflux(self._h, _ptr(out)), 'prisim_hip_get_pbflux')
@@ -366,6 +401,43 @@ class Context(object):
         self._check(self._lib.prisim_hip_delay_transform(self._h, int(nt), _ptr(w), pad, _ptr(out), _ptr(lags), _ptr(pw),
                                                          float(power_scale)), 'prisim_hip_delay_transform')
         return out, lags, pw
+
+    def delay_transform_device(self, nt, bpwts=None, pad=1.0, want_lag=True, want_power=False, power_scale=1.0):
+        """Delay-transform slots [0, nt) and leave the spectra in HBM (prisim_hip_delay_transform_device).  Returns (lags, nout);
+        read the results with get_lags / get_delay_power or exchange them with allgather_lags."""
+        pad = max(float(pad), 0.0)
+        w = None
+        if bpwts is not None:
+            w = NP.ascontiguousarray(bpwts, dtype=NP.float64).reshape(self.nbl, self.nchan)
+        lags = NP.empty(self.nchan, dtype=NP.float64)
+        nout = C.c_int64()
+        self._check(self._lib.prisim_hip_delay_transform_device(self._h, int(nt), _ptr(w), pad, 1 if want_lag else 0, 1 if want_power else 0,
+                                                                float(power_scale), _ptr(lags), C.byref(nout)),
+                    'prisim_hip_delay_transform_device')
+        self._dt_nout = int(nout.value)
+        return lags, self._dt_nout
+
+    def _get_resident(self, fn, what, dtype, t0, nt, rows):
+        r = None
+        nrow = self.nbl
+        if rows is not None:
+            r = NP.ascontiguousarray(rows, dtype=NP.int64).ravel()
+            nrow = r.size
+        out = NP.empty((nt, nrow, self._dt_nout), dtype=dtype)
+        self._check(fn(self._h, int(t0), int(nt), _ptr(r), 0 if r is None else r.size, _ptr(out)), what)
+        return out
+
+    def get_lags(self, t0, nt, rows=None):
+        """(nt, nrows | nbl, nout) complex128 lag spectra of snapshots [t0, t0 + nt) from the device-resident result."""
+        return self._get_resident(self._lib.prisim_hip_get_lags, 'prisim_hip_get_lags', NP.complex128, t0, nt, rows)
+
+    def get_delay_power(self, t0, nt, rows=None):
+        return self._get_resident(self._lib.prisim_hip_get_delay_power, 'prisim_hip_get_delay_power', NP.float64, t0, nt, rows)
+
+    def allgather_lags(self, nt):
+        """RCCL all-gather of the resident lag spectra, device to device; read with get_gathered(nt, nranks, row=nout)."""
+        self._check(self._lib.prisim_hip_allgather_lags(self._h, int(nt)), 'prisim_hip_allgather_lags')
+        self._gathered_c64 = False
 
     def set_vis(self, vis, slot=0):
         v = NP.ascontiguousarray(vis, dtype=NP.complex128)
@@ -423,10 +495,11 @@ class Context(object):
                     'prisim_hip_allgather_slot_async')
         self._gathered_c64 = bool(complex64)
 
-    def get_gathered(self, nt, nranks=None):
-        """(nt, nranks, nbl_shard, nchan): snapshot-major, rank blocks in rank order."""
+    def get_gathered(self, nt, nranks=None, row=None):
+        """(nt, nranks, nbl_shard, row): snapshot-major, rank blocks in rank order; row = nchan (visibilities) or nout (delay spectra)."""
         nranks = getattr(self, 'nranks', 1) if nranks is None else nranks
-        out = NP.empty((nt, nranks, self.nbl, self.nchan), dtype=NP.complex64 if getattr(self, '_gathered_c64', False) else NP.complex128)
+        row = self.nchan if row is None else int(row)
+        out = NP.empty((nt, nranks, self.nbl, row), dtype=NP.complex64 if getattr(self, '_gathered_c64', False) else NP.complex128)
         self._check(self._lib.prisim_hip_get_gathered(self._h, int(nt), _ptr(out)), 'prisim_hip_get_gathered')
         return out
 

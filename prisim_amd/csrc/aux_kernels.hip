@@ -301,14 +301,23 @@ __global__ void k_colmax_final(const double* __restrict__ partial, double* __res
   }
 }
 
-// pb_out[s][c] = float32( 10 ** (work - colmax[c]) ) * fluxes[s][c]
+// pb_out[s][c] = float32( 10 ** (work - colmax[c]) ) * flux[s][c];  flux from the table `fluxes`, or, when that is NULL, the power law
+// flux_ref[s] * (f_c / ref_freq) ** spindex[s] formed here (SkyModel.generate_spectrum of a 'func' sky model)
 __global__ void k_extbeam_finish(const double* __restrict__ work, const double* __restrict__ colmax, const double* __restrict__ fluxes,
-                                 double* __restrict__ pb_out, int64_t nsrc, int64_t nchan) {
+                                 const double* __restrict__ flux_ref, const double* __restrict__ spindex, const double* __restrict__ freqs,
+                                 double inv_ref_freq, double* __restrict__ pb_out, int64_t nsrc, int64_t nchan) {
   const int64_t total = nsrc * nchan;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = i % nchan;
     const double pb = (double)(float)exp10(work[i] - colmax[c]);      // :2101-2102 ; interferometry.py:4466 (float32 storage)
-    pb_out[i] = pb * fluxes[i];                                        // interferometry.py:6254
+    double fl;
+    if (fluxes) {
+      fl = fluxes[i];
+    } else {
+      const int64_t sidx = i / nchan;
+      fl = flux_ref[sidx] * pow(freqs[c] * inv_ref_freq, spindex[sidx]);
+    }
+    pb_out[i] = pb * fl;                                               // interferometry.py:6254
   }
 }
 
@@ -325,7 +334,8 @@ hipError_t launch_extbeam_table(const double* beam, const double* interp, double
   return hipGetLastError();
 }
 
-hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs, const double* fluxes, double* work,
+hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs, const double* fluxes, const double* flux_ref,
+                              const double* spindex, const double* freqs, double ref_freq, double* work,
                               double* colmax_scratch, double* pb_out, int64_t nsrc, int64_t nchan, hipStream_t stream) {
   if (nsrc == 0) return hipSuccess;
   const unsigned gs = (unsigned)(nsrc < 16384 ? nsrc : 16384);
@@ -335,7 +345,8 @@ hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs
   double* colmax = colmax_scratch + (size_t)1024 * nchan;
   hipLaunchKernelGGL(k_colmax_partial, dim3(nblk), dim3(256), 0, stream, work, partial, nsrc, nchan);
   hipLaunchKernelGGL(k_colmax_final, dim3(grid_for_(nchan)), dim3(256), 0, stream, partial, colmax, nblk, nchan);
-  hipLaunchKernelGGL(k_extbeam_finish, dim3(grid_for_(nsrc * nchan)), dim3(256), 0, stream, work, colmax, fluxes, pb_out, nsrc, nchan);
+  hipLaunchKernelGGL(k_extbeam_finish, dim3(grid_for_(nsrc * nchan)), dim3(256), 0, stream, work, colmax, fluxes, flux_ref, spindex, freqs,
+                     1.0 / ref_freq, pb_out, nsrc, nchan);
   return hipGetLastError();
 }
 

@@ -124,6 +124,16 @@ struct prisim_ctx {
   bool taper = false;
   double pc[3] = {0, 0, 1};
   DevBuf dirs, dirs_prep, pb, packed, partial, scratch;
+  // per-snapshot sky inputs (flux_ref / spindex or a flux table, beamformer elements, validity flag): owned by the context so that
+  // a set_sky_* call allocates nothing after the first snapshot
+  DevBuf sky_flux, sky_sp, sky_bf, sky_flag;
+  // pinned host staging for the small per-snapshot uploads (directions, flux_ref, spindex ...): the caller's arrays are copied here
+  // and sent with hipMemcpyAsync, so set_sky_* returns without a stream synchronisation; ev_stage marks the last upload that
+  // reads the area
+  void* h_stage = nullptr;
+  size_t h_stage_bytes = 0, h_stage_used = 0;
+  hipEvent_t ev_stage = nullptr;
+  bool stage_pending = false;
   // external beam
   DevBuf ext_table, ext_work, ext_colmax;
   int ext_nside = 0;
@@ -158,6 +168,13 @@ struct prisim_ctx {
   rocfft_execution_info fft_info = nullptr;
   size_t fft_len = 0, fft_batch = 0;
   DevBuf fft_work, fft_buf, dt_out, dt_pow, dt_wts;
+  // device-resident delay spectra of all snapshots (prisim_hip_delay_transform_device): [nt][nbl][nout] complex128 / float64
+  DevBuf dt_lag_all, dt_pow_all, dt_tw;
+  int64_t dt_tw_n = 0;              // channel count the twiddle table was built for
+  int64_t dt_nt = 0, dt_nout = 0;   // shape of the resident spectra
+  bool dt_have_lag = false, dt_have_pow = false;
+  hipEvent_t ev_d0 = nullptr, ev_d1 = nullptr;
+  int64_t gathered_row = 0;         // row length of the gathered cube (nchan for visibilities, nout for delay spectra)
 };
 
 namespace {
@@ -197,12 +214,63 @@ void release(DevBuf& b) {
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-// Collect the hipEvent timings of finished compute() calls, oldest first.  wait = true: block until every recorded entry is done.
-void harvest_timing(prisim_ctx* ctx, bool wait = true) {
+// Uploads above this size go straight from the caller's (pageable) memory and are waited for; smaller ones are staged.
+constexpr size_t kStageMaxBytes = (size_t)64 << 20;
+
+// Start a group of staged uploads needing `bytes` of pinned memory in total: waits until the previous group has left the area.
+int stage_begin(prisim_ctx* ctx, size_t bytes) {
+  if (ctx->stage_pending) {
+    if (hipEventSynchronize(ctx->ev_stage) != hipSuccess) return fail(ctx, PRISIM_ENODEV, "hipEventSynchronize(staging) failed");
+    ctx->stage_pending = false;
+  }
+  if (!ctx->ev_stage && hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming) != hipSuccess)
+    return fail(ctx, PRISIM_ENODEV, "hipEventCreate(staging) failed");
+  bytes += 4096;
+  if (bytes > ctx->h_stage_bytes) {
+    if (ctx->h_stage) { (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
+    const size_t want = std::max(bytes, (size_t)1 << 20);
+    if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) != hipSuccess) {
+      ctx->h_stage = nullptr;
+      return fail(ctx, PRISIM_ENOMEM, "hipHostMalloc(" + std::to_string(want) + " B) for the upload staging area failed");
+    }
+    ctx->h_stage_bytes = want;
+  }
+  ctx->h_stage_used = 0;
+  return PRISIM_OK;
+}
+
+// Reserve `bytes` of the staging area (256-byte aligned); the caller fills it and then calls stage_send.
+void* stage_alloc(prisim_ctx* ctx, size_t bytes) {
+  const size_t off = (ctx->h_stage_used + 255) & ~(size_t)255;
+  if (off + bytes > ctx->h_stage_bytes) return nullptr;
+  ctx->h_stage_used = off + bytes;
+  return (char*)ctx->h_stage + off;
+}
+
+hipError_t stage_send(prisim_ctx* ctx, void* dst, const void* staged, size_t bytes) {
+  return hipMemcpyAsync(dst, staged, bytes, hipMemcpyHostToDevice, ctx->stream);
+}
+
+// Copy a caller array into the staging area and send it.
+hipError_t stage_upload(prisim_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  void* h = stage_alloc(ctx, bytes);
+  if (!h) return hipErrorOutOfMemory;
+  memcpy(h, src, bytes);
+  return stage_send(ctx, dst, h, bytes);
+}
+
+void stage_end(prisim_ctx* ctx) {
+  if (hipEventRecord(ctx->ev_stage, ctx->stream) == hipSuccess) ctx->stage_pending = true;
+}
+
+// Collect the hipEvent timings of finished compute() calls, oldest first.  max_wait: how many of the pending entries may be
+// waited for (hipEventSynchronize); the rest are taken only if already complete.  -1: wait for all of them.
+void harvest_timing(prisim_ctx* ctx, int max_wait = -1) {
   while (ctx->ring_pending > 0) {
     const int i = (ctx->ring_head - ctx->ring_pending + 2 * prisim_ctx::kTimingRing) % prisim_ctx::kTimingRing;
-    if (wait) {
+    if (max_wait != 0) {
       if (hipEventSynchronize(ctx->ev_c1[i]) != hipSuccess) { ctx->ring_pending = 0; return; }
+      if (max_wait > 0) --max_wait;
     } else if (hipEventQuery(ctx->ev_c1[i]) != hipSuccess) {
       return;
     }
@@ -361,12 +429,16 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->dirs_prep, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
-                    &ctx->ext_work, &ctx->ext_colmax,
-                    &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts})
+                    &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
+                    &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
   for (int i = 0; i < prisim_ctx::kTimingRing; ++i)
     for (hipEvent_t ev : {ctx->ev_c0[i], ctx->ev_c1[i], ctx->ev_k0[i], ctx->ev_k1[i]})
       if (ev) (void)hipEventDestroy(ev);
+  if (ctx->ev_stage) (void)hipEventDestroy(ctx->ev_stage);
+  if (ctx->ev_d0) (void)hipEventDestroy(ctx->ev_d0);
+  if (ctx->ev_d1) (void)hipEventDestroy(ctx->ev_d1);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -423,19 +495,30 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   release(ctx->grad);
   release(ctx->gathered);
   release(ctx->sendbuf);
+  release(ctx->dt_lag_all);
+  release(ctx->dt_pow_all);
+  ctx->dt_nt = ctx->dt_nout = 0;
+  ctx->dt_have_lag = ctx->dt_have_pow = false;
   ctx->array_set = true;
   return PRISIM_OK;
 }
 
+// Directions + source-shape constants of one snapshot -> ctx->dirs, through the pinned staging area (no synchronisation).
+// `extra_stage_bytes`: staging the caller will use for its own small uploads in the same group (it calls stage_end()).
 static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, const double* pc_dircos,
-                         const double* fwhm_deg) {
+                         const double* fwhm_deg, size_t extra_stage_bytes) {
   if (nsrc < 0) return fail(ctx, PRISIM_EINVAL, "nsrc must be non-negative");
   if (nsrc > (int64_t)0x7fff0000) return fail(ctx, PRISIM_EINVAL, "nsrc must be below 2^31 (the kernels index sources with 32 bits)");
   if (nsrc > 0 && !dircos) return fail(ctx, PRISIM_EINVAL, "dircos is NULL");
   if (!pc_dircos) return fail(ctx, PRISIM_EINVAL, "pc_dircos is NULL");
   for (int i = 0; i < 3; ++i)
     if (!std::isfinite(pc_dircos[i])) return fail(ctx, PRISIM_EINVAL, "non-finite pc_dircos");
-  std::vector<double> d4((size_t)std::max<int64_t>(nsrc, 1) * 4, 0.0);
+  const size_t d4_bytes = (size_t)std::max<int64_t>(nsrc, 1) * 4 * sizeof(double);
+  int rc;
+  if ((rc = stage_begin(ctx, d4_bytes + extra_stage_bytes + 4096))) return rc;
+  double* d4 = (double*)stage_alloc(ctx, d4_bytes);
+  if (!d4) return fail(ctx, PRISIM_EINTERNAL, "staging area too small");
+  d4[0] = d4[1] = d4[2] = d4[3] = 0.0;
   double dmax2 = 0.0;
   for (int64_t s = 0; s < nsrc; ++s) {
     {
@@ -458,14 +541,25 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
     }
     d4[4 * s + 3] = kappa;
   }
-  int rc;
-  if ((rc = ensure(ctx, ctx->dirs, d4.size() * sizeof(double)))) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->dirs.p, d4.data(), d4.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // d4 is a local
+  if ((rc = ensure(ctx, ctx->dirs, d4_bytes))) return rc;
+  HIPCHK(ctx, stage_send(ctx, ctx->dirs.p, d4, d4_bytes));
   ctx->nsrc = nsrc;
   ctx->dmax = std::sqrt(dmax2);
   ctx->taper = fwhm_deg != nullptr;
   for (int i = 0; i < 3; ++i) ctx->pc[i] = pc_dircos[i];
+  return PRISIM_OK;
+}
+
+// Upload a caller array of `bytes`: staged (asynchronous) when small, otherwise straight from the caller's memory followed by
+// a stream synchronisation (the caller may reuse the array as soon as the call returns).
+static int upload_any(prisim_ctx* ctx, void* dst, const void* src, size_t bytes, bool* synced) {
+  if (bytes <= kStageMaxBytes && ctx->h_stage_used + bytes + 256 <= ctx->h_stage_bytes) {
+    HIPCHK(ctx, stage_upload(ctx, dst, src, bytes));
+    return PRISIM_OK;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (synced) *synced = true;
   return PRISIM_OK;
 }
 
@@ -476,33 +570,28 @@ int prisim_hip_set_sky(prisim_ctx* ctx, const prisim_sky* sky) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->sky_set = false;
   if (sky->nsrc > 0 && !sky->pbflux) return fail(ctx, PRISIM_EINVAL, "pbflux is NULL");
-  int rc = upload_common(ctx, sky->nsrc, sky->dircos, sky->pc_dircos, sky->fwhm_deg);
-  if (rc) return rc;
   const int64_t n = sky->nsrc * ctx->nchan;
+  const size_t pb_bytes = (size_t)std::max<int64_t>(n, 0) * (sky->pbflux_is_f32 ? sizeof(float) : sizeof(double));
+  const size_t fl_bytes = sky->fluxes ? (size_t)std::max<int64_t>(n, 0) * sizeof(double) : 0;
+  const size_t stage_extra = (pb_bytes <= kStageMaxBytes ? pb_bytes : 0) + (fl_bytes <= kStageMaxBytes ? fl_bytes : 0) + 1024;
+  int rc = upload_common(ctx, sky->nsrc, sky->dircos, sky->pc_dircos, sky->fwhm_deg, stage_extra);
+  if (rc) return rc;
   if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (n > 0) {
     if (sky->pbflux_is_f32) {
-      DevBuf tmp;
-      if ((rc = ensure(ctx, tmp, (size_t)n * sizeof(float)))) return rc;
-      hipError_t e = hipMemcpyAsync(tmp.p, sky->pbflux, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) e = launch_f32_to_f64((const float*)tmp.p, (double*)ctx->pb.p, n, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      release(tmp);
-      HIPCHK(ctx, e);
+      if ((rc = ensure(ctx, ctx->sky_flux, (size_t)n * sizeof(float)))) return rc;
+      if ((rc = upload_any(ctx, ctx->sky_flux.p, sky->pbflux, (size_t)n * sizeof(float), nullptr))) return rc;
+      HIPCHK(ctx, launch_f32_to_f64((const float*)ctx->sky_flux.p, (double*)ctx->pb.p, n, ctx->stream));
     } else {
-      HIPCHK(ctx, hipMemcpyAsync(ctx->pb.p, sky->pbflux, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if ((rc = upload_any(ctx, ctx->pb.p, sky->pbflux, (size_t)n * sizeof(double), nullptr))) return rc;
     }
     if (sky->fluxes) {   // pbfluxes = pb * fluxes (:6254) on the device
-      DevBuf tmp;
-      if ((rc = ensure(ctx, tmp, (size_t)n * sizeof(double)))) return rc;
-      hipError_t e = hipMemcpyAsync(tmp.p, sky->fluxes, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) e = launch_mul_inplace((double*)ctx->pb.p, (const double*)tmp.p, n, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      release(tmp);
-      HIPCHK(ctx, e);
+      if ((rc = ensure(ctx, ctx->sky_sp, (size_t)n * sizeof(double)))) return rc;
+      if ((rc = upload_any(ctx, ctx->sky_sp.p, sky->fluxes, (size_t)n * sizeof(double), nullptr))) return rc;
+      HIPCHK(ctx, launch_mul_inplace((double*)ctx->pb.p, (const double*)ctx->sky_sp.p, n, ctx->stream));
     }
   }
+  stage_end(ctx);
   ctx->sky_set = true;
   return PRISIM_OK;
 }
@@ -548,74 +637,74 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
   if (!sky->beam_pc_dircos) return fail(ctx, PRISIM_EINVAL, "beam_pc_dircos is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->sky_set = false;
-  int rc = upload_common(ctx, sky->nsrc, sky->dircos, sky->pc_dircos, sky->fwhm_deg);
-  if (rc) return rc;
   const int64_t ns = sky->nsrc;
   const int64_t n = ns * ctx->nchan;
+  const size_t frb = have_spec ? (size_t)n * sizeof(double) : (size_t)ns * sizeof(double);
+  const int bf_n = sky->ext ? sky->ext->bf_nelem : 0, bf_r = bf_n > 0 ? sky->ext->bf_nrand : 0;
+  const size_t bf_doubles = (size_t)bf_n * 3 + 2 * (size_t)bf_n * bf_r;
+  const size_t stage_extra = (frb <= kStageMaxBytes ? frb : 0) + (size_t)ns * sizeof(double) + bf_doubles * sizeof(double) + 4096;
+  int rc = upload_common(ctx, ns, sky->dircos, sky->pc_dircos, sky->fwhm_deg, stage_extra);
+  if (rc) return rc;
   if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (ns > 0) {
-    DevBuf fr, sp, bf, flag;
-    const size_t frb = have_spec ? (size_t)n * sizeof(double) : (size_t)ns * sizeof(double);
-    const int bf_n = sky->ext ? sky->ext->bf_nelem : 0, bf_r = bf_n > 0 ? sky->ext->bf_nrand : 0;
-    const size_t bf_doubles = (size_t)bf_n * 3 + 2 * (size_t)bf_n * bf_r;
-    if ((rc = ensure(ctx, fr, frb)) || (rc = ensure(ctx, sp, (size_t)ns * sizeof(double))) ||
-        (bf_n > 0 && (rc = ensure(ctx, bf, bf_doubles * sizeof(double)))) || (rc = ensure(ctx, flag, sizeof(int32_t)))) {
-      release(fr); release(sp); release(bf); release(flag);
+    if ((rc = ensure(ctx, ctx->sky_flux, frb)) || (rc = ensure(ctx, ctx->sky_sp, (size_t)ns * sizeof(double))) ||
+        (bf_n > 0 && (rc = ensure(ctx, ctx->sky_bf, bf_doubles * sizeof(double)))) || (rc = ensure(ctx, ctx->sky_flag, sizeof(int32_t))))
       return rc;
+    if ((rc = upload_any(ctx, ctx->sky_flux.p, have_spec ? sky->flux_spectrum : sky->flux_ref, frb, nullptr))) return rc;
+    if (bf_n > 0) {
+      double* b = (double*)ctx->sky_bf.p;
+      if ((rc = upload_any(ctx, b, sky->ext->bf_pos, (size_t)bf_n * 3 * sizeof(double), nullptr)) ||
+          (rc = upload_any(ctx, b + (size_t)bf_n * 3, sky->ext->bf_delays, (size_t)bf_n * bf_r * sizeof(double), nullptr)) ||
+          (rc = upload_any(ctx, b + (size_t)bf_n * 3 + (size_t)bf_n * bf_r, sky->ext->bf_gains, (size_t)bf_n * bf_r * sizeof(double), nullptr)))
+        return rc;
     }
-    int32_t hflag = 0;
-    hipError_t e = hipMemcpyAsync(fr.p, have_spec ? sky->flux_spectrum : sky->flux_ref, frb, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && bf_n > 0) {
-      double* b = (double*)bf.p;
-      e = hipMemcpyAsync(b, sky->ext->bf_pos, (size_t)bf_n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(b + (size_t)bf_n * 3, sky->ext->bf_delays, (size_t)bf_n * bf_r * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(b + (size_t)bf_n * 3 + (size_t)bf_n * bf_r, sky->ext->bf_gains, (size_t)bf_n * bf_r * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    }
-    if (e == hipSuccess && !have_spec)
-      e = hipMemcpyAsync(sp.p, sky->spindex, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-      BeamParams bp{};
-      bp.dirs = (const double*)ctx->dirs.p;
-      bp.flux_ref = have_spec ? nullptr : (const double*)fr.p;
-      bp.spindex = have_spec ? nullptr : (const double*)sp.p;
-      bp.flux_spec = have_spec ? (const double*)fr.p : nullptr;
-      bp.freqs = (const double*)ctx->freqs.p;
-      bp.ref_freq = have_spec ? 1.0 : sky->ref_freq_hz;
-      bp.beam_kind = sky->beam_kind;
-      bp.diameter = sky->diameter_m;
-      bp.bpc_x = sky->beam_pc_dircos[0]; bp.bpc_y = sky->beam_pc_dircos[1]; bp.bpc_z = sky->beam_pc_dircos[2];
-      if (sky->ext) {
-        const prisim_beam_ext* x = sky->ext;
-        bp.dip_x = x->dipole_dircos[0]; bp.dip_y = x->dipole_dircos[1]; bp.dip_z = x->dipole_dircos[2];
-        bp.dipole_mode = x->dipole_mode;
-        bp.nax1 = x->array_nax1; bp.nax2 = x->array_nax2; bp.sep1 = x->array_sep1; bp.sep2 = x->array_sep2;
-        const double ang = x->array_east2ax1_deg * M_PI / 180.0;
-        bp.rot_c = std::cos(ang); bp.rot_s = std::sin(ang);
-        bp.apc_x = x->array_pc_dircos[0]; bp.apc_y = x->array_pc_dircos[1]; bp.apc_z = x->array_pc_dircos[2];
-        bp.gp_height = x->ground_height; bp.gp_modify = x->ground_modify; bp.gp_scale = x->ground_scale; bp.gp_max = x->ground_max;
-        if (bf_n > 0) {
-          bp.bf_nelem = bf_n; bp.bf_nrand = bf_r;
-          bp.bf_pos = (const double*)bf.p;
-          bp.bf_delays = bp.bf_pos + (size_t)bf_n * 3;
-          bp.bf_gains = bp.bf_delays + (size_t)bf_n * bf_r;
-        }
+    if (!have_spec && (rc = upload_any(ctx, ctx->sky_sp.p, sky->spindex, (size_t)ns * sizeof(double), nullptr))) return rc;
+    BeamParams bp{};
+    bp.dirs = (const double*)ctx->dirs.p;
+    bp.flux_ref = have_spec ? nullptr : (const double*)ctx->sky_flux.p;
+    bp.spindex = have_spec ? nullptr : (const double*)ctx->sky_sp.p;
+    bp.flux_spec = have_spec ? (const double*)ctx->sky_flux.p : nullptr;
+    bp.freqs = (const double*)ctx->freqs.p;
+    bp.ref_freq = have_spec ? 1.0 : sky->ref_freq_hz;
+    bp.beam_kind = sky->beam_kind;
+    bp.diameter = sky->diameter_m;
+    bp.bpc_x = sky->beam_pc_dircos[0]; bp.bpc_y = sky->beam_pc_dircos[1]; bp.bpc_z = sky->beam_pc_dircos[2];
+    if (sky->ext) {
+      const prisim_beam_ext* x = sky->ext;
+      bp.dip_x = x->dipole_dircos[0]; bp.dip_y = x->dipole_dircos[1]; bp.dip_z = x->dipole_dircos[2];
+      bp.dipole_mode = x->dipole_mode;
+      bp.nax1 = x->array_nax1; bp.nax2 = x->array_nax2; bp.sep1 = x->array_sep1; bp.sep2 = x->array_sep2;
+      const double ang = x->array_east2ax1_deg * M_PI / 180.0;
+      bp.rot_c = std::cos(ang); bp.rot_s = std::sin(ang);
+      bp.apc_x = x->array_pc_dircos[0]; bp.apc_y = x->array_pc_dircos[1]; bp.apc_z = x->array_pc_dircos[2];
+      bp.gp_height = x->ground_height; bp.gp_modify = x->ground_modify; bp.gp_scale = x->ground_scale; bp.gp_max = x->ground_max;
+      if (bf_n > 0) {
+        bp.bf_nelem = bf_n; bp.bf_nrand = bf_r;
+        bp.bf_pos = (const double*)ctx->sky_bf.p;
+        bp.bf_delays = bp.bf_pos + (size_t)bf_n * 3;
+        bp.bf_gains = bp.bf_delays + (size_t)bf_n * bf_r;
       }
-      if (sky->beam_kind == PRISIM_BEAM_POLY)
-        for (int i = 0; i < 4; ++i) bp.poly[i] = sky->ext->poly_coef[i];
-      bp.flag = (int32_t*)flag.p;
-      bp.nsrc = ns; bp.nchan = ctx->nchan;
-      bp.pb_out = (double*)ctx->pb.p;
-      e = hipMemsetAsync(flag.p, 0, sizeof(int32_t), ctx->stream);
-      if (e == hipSuccess) e = launch_beam_flux(bp, ctx->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(&hflag, flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    release(fr); release(sp); release(bf); release(flag);
-    HIPCHK(ctx, e);
-    if (hflag & 2)
-      return fail(ctx, PRISIM_EINVAL, "Primary beam values were found to be NaN in some case(s). Check if the polynomial equations are valid for the frequencies specified.");
-    if (hflag & 1)
-      return fail(ctx, PRISIM_EINVAL, "Primary beam exceeds unity by a significant amount. Check the validity of the Primary beam equation for the angles specified.");
+    if (sky->beam_kind == PRISIM_BEAM_POLY)
+      for (int i = 0; i < 4; ++i) bp.poly[i] = sky->ext->poly_coef[i];
+    bp.flag = (int32_t*)ctx->sky_flag.p;
+    bp.nsrc = ns; bp.nchan = ctx->nchan;
+    bp.pb_out = (double*)ctx->pb.p;
+    HIPCHK(ctx, hipMemsetAsync(ctx->sky_flag.p, 0, sizeof(int32_t), ctx->stream));
+    HIPCHK(ctx, launch_beam_flux(bp, ctx->stream));
+    stage_end(ctx);
+    if (sky->beam_kind == PRISIM_BEAM_POLY) {
+      // only the polynomial beams can trip the reference's validity checks (:510-512, :802-807): the one case that reads back
+      int32_t hflag = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&hflag, ctx->sky_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (hflag & 2)
+        return fail(ctx, PRISIM_EINVAL, "Primary beam values were found to be NaN in some case(s). Check if the polynomial equations are valid for the frequencies specified.");
+      if (hflag & 1)
+        return fail(ctx, PRISIM_EINVAL, "Primary beam exceeds unity by a significant amount. Check the validity of the Primary beam equation for the angles specified.");
+    }
+  } else {
+    stage_end(ctx);
   }
   ctx->sky_set = true;
   return PRISIM_OK;
@@ -652,6 +741,20 @@ int prisim_hip_set_external_beam(prisim_ctx* ctx, const double* beam, int64_t np
   return PRISIM_OK;
 }
 
+// beam table -> pbflux for the current directions; fluxes: device [nsrc][nchan] table, or NULL with flux_ref / spindex (device [nsrc])
+static int extbeam_sky(prisim_ctx* ctx, int64_t nsrc, const double* d_fluxes, const double* d_flux_ref, const double* d_spindex,
+                       double ref_freq) {
+  const int64_t n = nsrc * ctx->nchan;
+  int rc;
+  if ((rc = ensure(ctx, ctx->ext_work, (size_t)n * sizeof(double))) ||
+      (rc = ensure(ctx, ctx->ext_colmax, (size_t)1025 * ctx->nchan * sizeof(double))))
+    return rc;
+  HIPCHK(ctx, launch_extbeam_sky((const double*)ctx->ext_table.p, ctx->ext_nside, (const double*)ctx->dirs.p, d_fluxes, d_flux_ref, d_spindex,
+                                 (const double*)ctx->freqs.p, ref_freq, (double*)ctx->ext_work.p, (double*)ctx->ext_colmax.p,
+                                 (double*)ctx->pb.p, nsrc, ctx->nchan, ctx->stream));
+  return PRISIM_OK;
+}
+
 int prisim_hip_set_sky_external(prisim_ctx* ctx, const prisim_sky* sky) {
   if (!ctx) return PRISIM_EINVAL;
   if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
@@ -661,25 +764,48 @@ int prisim_hip_set_sky_external(prisim_ctx* ctx, const prisim_sky* sky) {
   if (sky->nsrc > 0 && !sky->fluxes) return fail(ctx, PRISIM_EINVAL, "fluxes is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->sky_set = false;
-  int rc = upload_common(ctx, sky->nsrc, sky->dircos, sky->pc_dircos, sky->fwhm_deg);
-  if (rc) return rc;
   const int64_t n = sky->nsrc * ctx->nchan;
+  const size_t fl_bytes = (size_t)std::max<int64_t>(n, 0) * sizeof(double);
+  int rc = upload_common(ctx, sky->nsrc, sky->dircos, sky->pc_dircos, sky->fwhm_deg, (fl_bytes <= kStageMaxBytes ? fl_bytes : 0) + 1024);
+  if (rc) return rc;
   if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (n > 0) {
-    DevBuf fl;
-    if ((rc = ensure(ctx, fl, (size_t)n * sizeof(double))) || (rc = ensure(ctx, ctx->ext_work, (size_t)n * sizeof(double))) ||
-        (rc = ensure(ctx, ctx->ext_colmax, (size_t)1025 * ctx->nchan * sizeof(double)))) {
-      release(fl);
-      return rc;
-    }
-    hipError_t e = hipMemcpyAsync(fl.p, sky->fluxes, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess)
-      e = launch_extbeam_sky((const double*)ctx->ext_table.p, ctx->ext_nside, (const double*)ctx->dirs.p, (const double*)fl.p,
-                             (double*)ctx->ext_work.p, (double*)ctx->ext_colmax.p, (double*)ctx->pb.p, sky->nsrc, ctx->nchan, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    release(fl);
-    HIPCHK(ctx, e);
+    if ((rc = ensure(ctx, ctx->sky_flux, fl_bytes))) return rc;
+    if ((rc = upload_any(ctx, ctx->sky_flux.p, sky->fluxes, fl_bytes, nullptr))) return rc;
+    if ((rc = extbeam_sky(ctx, sky->nsrc, (const double*)ctx->sky_flux.p, nullptr, nullptr, 1.0))) return rc;
   }
+  stage_end(ctx);
+  ctx->sky_set = true;
+  return PRISIM_OK;
+}
+
+int prisim_hip_set_sky_external_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_external_analytic");
+  if (ctx->ext_nside <= 0) return fail(ctx, PRISIM_ESTATE, "set_external_beam must be called before set_sky_external_analytic");
+  const bool have_spec = sky->flux_spectrum != nullptr;
+  if (sky->nsrc > 0 && !have_spec && (!sky->flux_ref || !sky->spindex))
+    return fail(ctx, PRISIM_EINVAL, "flux_ref / spindex is NULL and no flux_spectrum given");
+  if (!have_spec && !(sky->ref_freq_hz > 0.0)) return fail(ctx, PRISIM_EINVAL, "ref_freq_hz must be positive");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->sky_set = false;
+  const int64_t ns = sky->nsrc;
+  const int64_t n = ns * ctx->nchan;
+  const size_t frb = have_spec ? (size_t)std::max<int64_t>(n, 0) * sizeof(double) : (size_t)std::max<int64_t>(ns, 0) * sizeof(double);
+  int rc = upload_common(ctx, ns, sky->dircos, sky->pc_dircos, sky->fwhm_deg,
+                         (frb <= kStageMaxBytes ? frb : 0) + (size_t)std::max<int64_t>(ns, 0) * sizeof(double) + 2048);
+  if (rc) return rc;
+  if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+  if (ns > 0) {
+    if ((rc = ensure(ctx, ctx->sky_flux, frb)) || (rc = ensure(ctx, ctx->sky_sp, (size_t)ns * sizeof(double)))) return rc;
+    if ((rc = upload_any(ctx, ctx->sky_flux.p, have_spec ? sky->flux_spectrum : sky->flux_ref, frb, nullptr))) return rc;
+    if (!have_spec && (rc = upload_any(ctx, ctx->sky_sp.p, sky->spindex, (size_t)ns * sizeof(double), nullptr))) return rc;
+    if ((rc = extbeam_sky(ctx, ns, have_spec ? (const double*)ctx->sky_flux.p : nullptr, have_spec ? nullptr : (const double*)ctx->sky_flux.p,
+                          have_spec ? nullptr : (const double*)ctx->sky_sp.p, have_spec ? 1.0 : sky->ref_freq_hz)))
+      return rc;
+  }
+  stage_end(ctx);
   ctx->sky_set = true;
   return PRISIM_OK;
 }
@@ -690,6 +816,7 @@ int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out) {
   if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int64_t n = ctx->nsrc * ctx->nchan;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (n > 0) HIPCHK(ctx, hipMemcpy(out, ctx->pb.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   return PRISIM_OK;
 }
@@ -762,7 +889,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   if (kernel == PRISIM_KERNEL_RECURRENCE && !ctx->uniform)
     return fail(ctx, PRISIM_EINVAL, "recurrence kernel needs a uniform channel grid");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  harvest_timing(ctx, /*wait=*/ctx->ring_pending >= prisim_ctx::kTimingRing);     // frees the oldest entry only when the ring is full
+  harvest_timing(ctx, /*max_wait=*/ctx->ring_pending >= prisim_ctx::kTimingRing ? 1 : 0);   // a full ring waits for its oldest entry only
   const size_t slot_elems = (size_t)ctx->nbl * ctx->nchan * 2;
   double* dst = (double*)ctx->cube.p + (size_t)slot * slot_elems;
   int rc;
@@ -906,6 +1033,12 @@ int prisim_hip_get_timing(prisim_ctx* ctx, prisim_timing* out, int reset) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     harvest_timing(ctx);
   }
+  if (ctx->ev_d1 && ctx->timing.last_delay_ms < 0.0) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float ms = 0.f;
+    if (hipEventSynchronize(ctx->ev_d1) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev_d0, ctx->ev_d1) == hipSuccess)
+      ctx->timing.last_delay_ms = ms;
+  }
   *out = ctx->timing;
   if (reset) { ctx->timing.sum_kernel_ms = 0.0; ctx->timing.n_kernel = 0; }
   return PRISIM_OK;
@@ -931,80 +1064,159 @@ int prisim_hip_set_tuning(prisim_ctx* ctx, int chan_tile, int src_chunk, int nsp
 
 // ---- delay transform ------------------------------------------------------------------------
 
-int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts, double pad, double* out,
-                               double* lags_out, double* out_power, double power_scale) {
-  if (!ctx) return PRISIM_EINVAL;
-  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
-  if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
-  if (!(pad >= 0.0) || !std::isfinite(pad)) pad = 0.0;   // interferometry.py:8091-8092
-  if (!ctx->uniform || ctx->nchan < 2) return fail(ctx, PRISIM_EINVAL, "delay transform needs >= 2 uniformly spaced channels");
+namespace {
+
+struct DelayGeom {
+  int64_t npad, nfft, nout;
+  double factor;
+  bool fused;          // integer 1 + pad and a power-of-two channel count: one LDS kernel, no padding, no rocFFT
+};
+
+DelayGeom delay_geom(const prisim_ctx* ctx, double pad) {
+  DelayGeom g{};
+  const int64_t nchan = ctx->nchan;
+  g.npad = (int64_t)((double)nchan * pad);                                // :8123
+  g.nfft = nchan + g.npad;
+  g.factor = 1.0 + pad;                                                   // :8131
+  g.nout = (int64_t)std::ceil((double)g.nfft / g.factor - 1e-12);         // len(arange(0, nfft, factor))
+  const double fr = std::round(g.factor);
+  g.fused = delay_fft_supported(nchan) && std::fabs(g.factor - fr) == 0.0 && fr >= 1.0 && g.nfft == nchan * (int64_t)fr && g.nout == nchan;
+  if (const char* env = getenv("PRISIM_HIP_DT_FUSED")) g.fused = g.fused && atoi(env) != 0;      // A/B hook
+  return g;
+}
+
+// Upload the window [nbl][nchan] (or none) and make sure the fused kernel's twiddle table / the rocFFT plan exist.
+int delay_prepare(prisim_ctx* ctx, const DelayGeom& g, const double* bpwts, int64_t nrows_batch) {
+  int rc;
+  const int64_t nchan = ctx->nchan, nbl = ctx->nbl;
+  if (bpwts) {
+    if ((rc = ensure(ctx, ctx->dt_wts, (size_t)nbl * nchan * sizeof(double)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dt_wts.p, bpwts, (size_t)nbl * nchan * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // bpwts is caller-owned
+  }
+  if (g.fused) {
+    if (ctx->dt_tw_n != nchan) {
+      std::vector<double> tw((size_t)nchan);            // nchan / 2 complex values W_N^m = exp(+2 pi i m / N)
+      for (int64_t m = 0; m < nchan / 2; ++m) {
+        const double a = 2.0 * M_PI * (double)m / (double)nchan;
+        tw[(size_t)2 * m] = std::cos(a);
+        tw[(size_t)2 * m + 1] = std::sin(a);
+      }
+      if ((rc = ensure(ctx, ctx->dt_tw, tw.size() * sizeof(double)))) return rc;
+      HIPCHK(ctx, hipMemcpy(ctx->dt_tw.p, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+      ctx->dt_tw_n = nchan;
+    }
+    return PRISIM_OK;
+  }
   std::string lerr;
   if (!load_rocfft(lerr)) return fail(ctx, PRISIM_ELIB, lerr);
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   RocfftApi& F = g_rocfft;
   if (!F.setup_done) {
     if (F.setup() != rocfft_status_success) return fail(ctx, PRISIM_ELIB, "rocfft_setup failed");
     F.setup_done = true;
   }
+  if ((rc = ensure(ctx, ctx->fft_buf, (size_t)nrows_batch * g.nfft * 2 * sizeof(double)))) return rc;
+  return PRISIM_OK;
+}
+
+// Transform `nrows` = ntc * nbl rows starting at snapshot slot t0 into the device buffers d_out ([nrows][nout] complex128) and/or
+// d_pow ([nrows][nout] float64).  Asynchronous on the context stream.
+int delay_batch(prisim_ctx* ctx, const DelayGeom& g, int64_t t0, int64_t nrows, bool have_wts, double* d_out, double* d_pow,
+                double power_scale) {
   const int64_t nchan = ctx->nchan, nbl = ctx->nbl;
-  const int64_t npad = (int64_t)((double)nchan * pad);                  // :8123
-  const int64_t nfft = nchan + npad;
-  const double factor = 1.0 + pad;                                      // :8131
-  const int64_t nout = (int64_t)std::ceil((double)nfft / factor - 1e-12);   // len(arange(0, nfft, factor))
-  // Snapshots are transformed in batches so that the padded work buffer stays <= 4 GiB whatever nt is
-  // (config 5: 120 x 61075 rows of 2048 would be 240 GB at once).
-  const int64_t row_bytes = nfft * 2 * (int64_t)sizeof(double);
+  const size_t slot_elems = (size_t)nbl * nchan * 2;
+  const double* src = (const double*)ctx->cube.p + (size_t)t0 * slot_elems;
+  const double* wts = have_wts ? (const double*)ctx->dt_wts.p : nullptr;
+  // rocFFT's inverse is unnormalised: sum_n x[n] e^{+2 pi i k n / N'}.  The reference forms ifft(x) * N' * df (:8125) = that sum times df.
+  const double scale = ctx->df;
+  if (g.fused) {
+    HIPCHK(ctx, launch_delay_fft(src, wts, (const double*)ctx->dt_tw.p, d_out, d_pow, nrows, nbl, nchan, scale, power_scale, ctx->cu_count,
+                                 ctx->stream));
+    return PRISIM_OK;
+  }
+  RocfftApi& F = g_rocfft;
+  int rc;
+  if (!ctx->fft_plan || ctx->fft_len != (size_t)g.nfft || ctx->fft_batch != (size_t)nrows) {
+    if (ctx->fft_plan) { F.plan_destroy(ctx->fft_plan); ctx->fft_plan = nullptr; }
+    size_t len = (size_t)g.nfft;
+    if (F.plan_create(&ctx->fft_plan, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                      rocfft_precision_double, 1, &len, (size_t)nrows, nullptr) != rocfft_status_success) {
+      ctx->fft_plan = nullptr;
+      return fail(ctx, PRISIM_ELIB, "rocfft_plan_create failed");
+    }
+    ctx->fft_len = (size_t)g.nfft; ctx->fft_batch = (size_t)nrows;
+    if (!ctx->fft_info && F.execution_info_create(&ctx->fft_info) != rocfft_status_success)
+      return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_create failed");
+    if (F.execution_info_set_stream(ctx->fft_info, ctx->stream) != rocfft_status_success)
+      return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_stream failed");
+    size_t wbytes = 0;
+    F.plan_get_work_buffer_size(ctx->fft_plan, &wbytes);
+    if (wbytes) {
+      if ((rc = ensure(ctx, ctx->fft_work, wbytes))) return rc;
+      if (F.execution_info_set_work_buffer(ctx->fft_info, ctx->fft_work.p, wbytes) != rocfft_status_success)
+        return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_work_buffer failed");
+    }
+  }
+  HIPCHK(ctx, launch_dt_prepare(src, wts, (double*)ctx->fft_buf.p, nrows, nbl, nchan, g.nfft, ctx->stream));
+  void* bufs[1] = {ctx->fft_buf.p};
+  if (F.execute(ctx->fft_plan, bufs, nullptr, ctx->fft_info) != rocfft_status_success)
+    return fail(ctx, PRISIM_ELIB, "rocfft_execute failed");
+  HIPCHK(ctx, launch_dt_finish((const double*)ctx->fft_buf.p, d_out, d_pow, nrows, g.nfft, g.nout, g.factor, scale, power_scale, ctx->stream));
+  return PRISIM_OK;
+}
+
+// snapshots per batch of the rocFFT pipeline so that its padded work buffer stays <= 4 GiB whatever nt is
+// (config 5: 120 x 61075 rows of 2048 would be 240 GB at once); the fused kernel needs no work buffer
+int64_t delay_batch_snapshots(const prisim_ctx* ctx, const DelayGeom& g, int64_t nt) {
+  if (g.fused && !getenv("PRISIM_HIP_DT_BATCH_BYTES")) return nt;
+  const int64_t row_bytes = g.nfft * 2 * (int64_t)sizeof(double);
   int64_t budget = (int64_t)4 << 30;
   if (const char* env = getenv("PRISIM_HIP_DT_BATCH_BYTES")) {   // test hook: force several batches on small cubes
     const long long v = atoll(env);
     if (v > 0) budget = v;
   }
-  int64_t nt_b = std::max<int64_t>(1, budget / (nbl * row_bytes));
-  if (nt_b > nt) nt_b = nt;
-  int rc;
-  if ((rc = ensure(ctx, ctx->fft_buf, (size_t)(nt_b * nbl) * row_bytes))) return rc;
-  if (bpwts) {
-    if ((rc = ensure(ctx, ctx->dt_wts, (size_t)nbl * nchan * sizeof(double)))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->dt_wts.p, bpwts, (size_t)nbl * nchan * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int64_t nt_b = std::max<int64_t>(1, budget / (ctx->nbl * row_bytes));
+  return std::min(nt_b, nt);
+}
+
+void delay_lags(const prisim_ctx* ctx, double* lags_out) {
+  // DSP.spectral_axis(nchan, delx=df, shift=True) (:8114) == fftshift(fftfreq(nchan, df))
+  for (int64_t i = 0; i < ctx->nchan; ++i) {
+    const int64_t k = i - ctx->nchan / 2;
+    lags_out[i] = (double)k / ((double)ctx->nchan * ctx->df);
   }
+}
+
+int delay_check(prisim_ctx* ctx, int64_t nt, double& pad) {
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
+  if (!(pad >= 0.0) || !std::isfinite(pad)) pad = 0.0;   // interferometry.py:8091-8092
+  if (!ctx->uniform || ctx->nchan < 2) return fail(ctx, PRISIM_EINVAL, "delay transform needs >= 2 uniformly spaced channels");
+  return PRISIM_OK;
+}
+
+}  // namespace
+
+int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts, double pad, double* out,
+                               double* lags_out, double* out_power, double power_scale) {
+  if (!ctx) return PRISIM_EINVAL;
+  int rc;
+  if ((rc = delay_check(ctx, nt, pad))) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const DelayGeom g = delay_geom(ctx, pad);
+  const int64_t nbl = ctx->nbl, nout = g.nout;
+  // the host-output form always goes batch by batch through two staging buffers
+  int64_t nt_b = delay_batch_snapshots(ctx, g, nt);
+  if (g.fused) nt_b = std::min<int64_t>(nt, std::max<int64_t>(1, ((int64_t)2 << 30) / (nbl * nout * 16)));
+  if ((rc = delay_prepare(ctx, g, bpwts, nt_b * nbl))) return rc;
   if (out && (rc = ensure(ctx, ctx->dt_out, (size_t)(nt_b * nbl) * nout * 2 * sizeof(double)))) return rc;
   if (out_power && (rc = ensure(ctx, ctx->dt_pow, (size_t)(nt_b * nbl) * nout * sizeof(double)))) return rc;
-  // rocFFT's inverse is unnormalised: sum_n x[n] e^{+2 pi i k n / N'}.  The reference forms
-  // ifft(x) * N' * df (:8125) = that sum times df.
-  const double scale = ctx->df;
-  const size_t slot_elems = (size_t)nbl * nchan * 2;
   for (int64_t t0 = 0; t0 < nt; t0 += nt_b) {
     const int64_t ntc = std::min(nt_b, nt - t0);
     const int64_t nrows = ntc * nbl;
-    if (!ctx->fft_plan || ctx->fft_len != (size_t)nfft || ctx->fft_batch != (size_t)nrows) {
-      if (ctx->fft_plan) { F.plan_destroy(ctx->fft_plan); ctx->fft_plan = nullptr; }
-      size_t len = (size_t)nfft;
-      if (F.plan_create(&ctx->fft_plan, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
-                        rocfft_precision_double, 1, &len, (size_t)nrows, nullptr) != rocfft_status_success) {
-        ctx->fft_plan = nullptr;
-        return fail(ctx, PRISIM_ELIB, "rocfft_plan_create failed");
-      }
-      ctx->fft_len = (size_t)nfft; ctx->fft_batch = (size_t)nrows;
-      if (!ctx->fft_info && F.execution_info_create(&ctx->fft_info) != rocfft_status_success)
-        return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_create failed");
-      if (F.execution_info_set_stream(ctx->fft_info, ctx->stream) != rocfft_status_success)
-        return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_stream failed");
-      size_t wbytes = 0;
-      F.plan_get_work_buffer_size(ctx->fft_plan, &wbytes);
-      if (wbytes) {
-        if ((rc = ensure(ctx, ctx->fft_work, wbytes))) return rc;
-        if (F.execution_info_set_work_buffer(ctx->fft_info, ctx->fft_work.p, wbytes) != rocfft_status_success)
-          return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_work_buffer failed");
-      }
-    }
-    HIPCHK(ctx, launch_dt_prepare((const double*)ctx->cube.p + (size_t)t0 * slot_elems, bpwts ? (const double*)ctx->dt_wts.p : nullptr,
-                                  (double*)ctx->fft_buf.p, nrows, nbl, nchan, nfft, ctx->stream));
-    void* bufs[1] = {ctx->fft_buf.p};
-    if (F.execute(ctx->fft_plan, bufs, nullptr, ctx->fft_info) != rocfft_status_success)
-      return fail(ctx, PRISIM_ELIB, "rocfft_execute failed");
-    HIPCHK(ctx, launch_dt_finish((const double*)ctx->fft_buf.p, out ? (double*)ctx->dt_out.p : nullptr,
-                                 out_power ? (double*)ctx->dt_pow.p : nullptr, nrows, nfft, nout, factor, scale, power_scale,
-                                 ctx->stream));
+    if ((rc = delay_batch(ctx, g, t0, nrows, bpwts != nullptr, out ? (double*)ctx->dt_out.p : nullptr,
+                          out_power ? (double*)ctx->dt_pow.p : nullptr, power_scale)))
+      return rc;
     if (out)
       HIPCHK(ctx, hipMemcpyAsync(out + (size_t)t0 * nbl * nout * 2, ctx->dt_out.p, (size_t)nrows * nout * 2 * sizeof(double),
                                  hipMemcpyDeviceToHost, ctx->stream));
@@ -1013,14 +1225,79 @@ int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts,
                                  hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // the staging buffers are reused by the next batch
   }
-  if (lags_out) {
-    // DSP.spectral_axis(nchan, delx=df, shift=True) (:8114) == fftshift(fftfreq(nchan, df))
-    for (int64_t i = 0; i < nchan; ++i) {
-      const int64_t k = i - nchan / 2;
-      lags_out[i] = (double)k / ((double)nchan * ctx->df);
-    }
-  }
+  if (lags_out) delay_lags(ctx, lags_out);
   return PRISIM_OK;
+}
+
+int prisim_hip_delay_transform_device(prisim_ctx* ctx, int64_t nt, const double* bpwts, double pad, int want_lag, int want_power,
+                                      double power_scale, double* lags_out, int64_t* nout_out) {
+  if (!ctx) return PRISIM_EINVAL;
+  int rc;
+  if ((rc = delay_check(ctx, nt, pad))) return rc;
+  if (!want_lag && !want_power) return fail(ctx, PRISIM_EINVAL, "nothing to compute: want_lag and want_power are both 0");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const DelayGeom g = delay_geom(ctx, pad);
+  const int64_t nbl = ctx->nbl, nout = g.nout;
+  const int64_t nt_b = delay_batch_snapshots(ctx, g, nt);
+  if ((rc = delay_prepare(ctx, g, bpwts, nt_b * nbl))) return rc;
+  ctx->dt_have_lag = ctx->dt_have_pow = false;
+  if (want_lag && (rc = ensure(ctx, ctx->dt_lag_all, (size_t)nt * nbl * nout * 2 * sizeof(double)))) return rc;
+  if (want_power && (rc = ensure(ctx, ctx->dt_pow_all, (size_t)nt * nbl * nout * sizeof(double)))) return rc;
+  if (!ctx->ev_d0) {
+    HIPCHK(ctx, hipEventCreate(&ctx->ev_d0));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev_d1));
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev_d0, ctx->stream));
+  for (int64_t t0 = 0; t0 < nt; t0 += nt_b) {
+    const int64_t ntc = std::min(nt_b, nt - t0);
+    double* d_out = want_lag ? (double*)ctx->dt_lag_all.p + (size_t)t0 * nbl * nout * 2 : nullptr;
+    double* d_pow = want_power ? (double*)ctx->dt_pow_all.p + (size_t)t0 * nbl * nout : nullptr;
+    if ((rc = delay_batch(ctx, g, t0, ntc * nbl, bpwts != nullptr, d_out, d_pow, power_scale))) return rc;
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev_d1, ctx->stream));
+  ctx->dt_nt = nt; ctx->dt_nout = nout;
+  ctx->dt_have_lag = want_lag != 0; ctx->dt_have_pow = want_power != 0;
+  ctx->timing.last_delay_fused = g.fused ? 1 : 0;
+  ctx->timing.last_delay_ms = -1.0;         // filled in by get_timing once the events have completed
+  if (lags_out) delay_lags(ctx, lags_out);
+  if (nout_out) *nout_out = nout;
+  return PRISIM_OK;
+}
+
+// Copy rows of the resident spectra to the host.  rows == NULL: all nbl baselines.
+static int get_resident(prisim_ctx* ctx, const DevBuf& buf, bool have, int reals, int64_t t0, int64_t nt, const int64_t* rows, int64_t nrows,
+                        double* out) {
+  if (!have || !buf.p) return fail(ctx, PRISIM_ESTATE, "delay_transform_device has not produced this quantity");
+  if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
+  if (t0 < 0 || nt <= 0 || t0 + nt > ctx->dt_nt) return fail(ctx, PRISIM_EINVAL, "snapshot range outside the resident spectra");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t nbl = ctx->nbl, nout = ctx->dt_nout;
+  const size_t row_bytes = (size_t)nout * reals * sizeof(double);
+  const char* base = (const char*)buf.p;
+  if (!rows) {
+    HIPCHK(ctx, hipMemcpy(out, base + (size_t)t0 * nbl * row_bytes, (size_t)nt * nbl * row_bytes, hipMemcpyDeviceToHost));
+    return PRISIM_OK;
+  }
+  if (nrows <= 0) return fail(ctx, PRISIM_EINVAL, "nrows must be positive when rows is given");
+  for (int64_t i = 0; i < nrows; ++i)
+    if (rows[i] < 0 || rows[i] >= nbl) return fail(ctx, PRISIM_EINVAL, "row index out of range");
+  for (int64_t t = 0; t < nt; ++t)
+    for (int64_t i = 0; i < nrows; ++i)
+      HIPCHK(ctx, hipMemcpyAsync((char*)out + ((size_t)t * nrows + i) * row_bytes, base + ((size_t)(t0 + t) * nbl + rows[i]) * row_bytes, row_bytes,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PRISIM_OK;
+}
+
+int prisim_hip_get_lags(prisim_ctx* ctx, int64_t t0, int64_t nt, const int64_t* rows, int64_t nrows, double* out) {
+  if (!ctx) return PRISIM_EINVAL;
+  return get_resident(ctx, ctx->dt_lag_all, ctx->dt_have_lag, 2, t0, nt, rows, nrows, out);
+}
+
+int prisim_hip_get_delay_power(prisim_ctx* ctx, int64_t t0, int64_t nt, const int64_t* rows, int64_t nrows, double* out) {
+  if (!ctx) return PRISIM_EINVAL;
+  return get_resident(ctx, ctx->dt_pow_all, ctx->dt_have_pow, 1, t0, nt, rows, nrows, out);
 }
 
 int prisim_hip_phase_rotate(prisim_ctx* ctx, int64_t nt, const double* diff_dircos) {
@@ -1098,11 +1375,12 @@ int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int ra
   return PRISIM_OK;
 }
 
-// Gather cube slot `slot` of every rank into gathered[slot][rank][b][f] on stream `st`.
-static int gather_one_slot(prisim_ctx* ctx, int64_t slot, int as_c64, hipStream_t st) {
-  const size_t shard = (size_t)ctx->nbl * ctx->nchan * 2;   // reals per snapshot shard
+// Gather snapshot `slot` of every rank into gathered[slot][rank][b][row] on stream `st`.  src_all: this rank's [nt][nbl][row] complex128
+// (the visibility cube or the resident lag spectra), row = reals / 2 per baseline.
+static int gather_one_slot(prisim_ctx* ctx, const double* src_all, int64_t row, int64_t slot, int as_c64, hipStream_t st) {
+  const size_t shard = (size_t)ctx->nbl * row * 2;   // reals per snapshot shard
   const size_t esz = as_c64 ? sizeof(float) : sizeof(double);
-  const double* src = (const double*)ctx->cube.p + (size_t)slot * shard;
+  const double* src = src_all + (size_t)slot * shard;
   const void* send = src;
   if (as_c64) {
     float* sb = (float*)ctx->sendbuf.p + (size_t)slot * shard;
@@ -1120,14 +1398,15 @@ static int gather_one_slot(prisim_ctx* ctx, int64_t slot, int as_c64, hipStream_
   return PRISIM_OK;
 }
 
-static int ensure_gather_buffers(prisim_ctx* ctx, int as_c64) {
-  const size_t shard = (size_t)ctx->nbl * ctx->nchan * 2;
+static int ensure_gather_buffers(prisim_ctx* ctx, int64_t row, int as_c64) {
+  const size_t shard = (size_t)ctx->nbl * row * 2;
   const size_t esz = as_c64 ? sizeof(float) : sizeof(double);
   int rc;
-  if (ctx->gathered.p && ctx->gathered_c64 != (as_c64 != 0)) release(ctx->gathered);
+  if (ctx->gathered.p && (ctx->gathered_c64 != (as_c64 != 0) || ctx->gathered_row != row)) release(ctx->gathered);
   if ((rc = ensure(ctx, ctx->gathered, shard * (size_t)ctx->nt_max * (size_t)ctx->nranks * esz))) return rc;
   if (as_c64 && (rc = ensure(ctx, ctx->sendbuf, shard * (size_t)ctx->nt_max * sizeof(float)))) return rc;
   ctx->gathered_c64 = as_c64 != 0;
+  ctx->gathered_row = row;
   return PRISIM_OK;
 }
 
@@ -1137,9 +1416,24 @@ int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt, int as_c64) {
   if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
-  if ((rc = ensure_gather_buffers(ctx, as_c64))) return rc;
+  if (ctx->comm_stream && ctx->comm_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
+  if ((rc = ensure_gather_buffers(ctx, ctx->nchan, as_c64))) return rc;
   for (int64_t t = 0; t < nt; ++t)
-    if ((rc = gather_one_slot(ctx, t, as_c64, ctx->stream))) return rc;
+    if ((rc = gather_one_slot(ctx, (const double*)ctx->cube.p, ctx->nchan, t, as_c64, ctx->stream))) return rc;
+  return PRISIM_OK;
+}
+
+int prisim_hip_allgather_lags(prisim_ctx* ctx, int64_t nt) {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (!ctx->dt_have_lag || !ctx->dt_lag_all.p) return fail(ctx, PRISIM_ESTATE, "delay_transform_device(want_lag) must be called first");
+  if (nt <= 0 || nt > ctx->dt_nt || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt does not match the resident lag spectra");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if (ctx->comm_stream && ctx->comm_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
+  if ((rc = ensure_gather_buffers(ctx, ctx->dt_nout, 0))) return rc;
+  for (int64_t t = 0; t < nt; ++t)
+    if ((rc = gather_one_slot(ctx, (const double*)ctx->dt_lag_all.p, ctx->dt_nout, t, 0, ctx->stream))) return rc;
   return PRISIM_OK;
 }
 
@@ -1153,16 +1447,16 @@ int prisim_hip_allgather_slot_async(prisim_ctx* ctx, int64_t slot, int as_c64) {
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_slot_done, hipEventDisableTiming));
   }
-  if (!ctx->gathered.p || ctx->gathered_c64 != (as_c64 != 0)) {
+  if (!ctx->gathered.p || ctx->gathered_c64 != (as_c64 != 0) || ctx->gathered_row != ctx->nchan) {
     // (re)allocation must not race with gathers in flight
     HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream));
-    if ((rc = ensure_gather_buffers(ctx, as_c64))) return rc;
+    if ((rc = ensure_gather_buffers(ctx, ctx->nchan, as_c64))) return rc;
   }
   // the gather of slot t waits for everything enqueued so far on the compute stream (i.e. compute(slot t)) ...
   HIPCHK(ctx, hipEventRecord(ctx->ev_slot_done, ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_slot_done, 0));
   // ... and runs on the communication stream, overlapping the next snapshot's compute
-  if ((rc = gather_one_slot(ctx, slot, as_c64, ctx->comm_stream))) return rc;
+  if ((rc = gather_one_slot(ctx, (const double*)ctx->cube.p, ctx->nchan, slot, as_c64, ctx->comm_stream))) return rc;
   ctx->comm_pending = true;
   return PRISIM_OK;
 }
@@ -1173,7 +1467,7 @@ int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out) {
   if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t esz = ctx->gathered_c64 ? sizeof(float) : sizeof(double);
-  const size_t bytes = (size_t)nt * ctx->nbl * ctx->nchan * 2 * (size_t)ctx->nranks * esz;
+  const size_t bytes = (size_t)nt * ctx->nbl * ctx->gathered_row * 2 * (size_t)ctx->nranks * esz;
   if (nt <= 0 || bytes > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt does not match the gathered cube");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->comm_stream) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
@@ -1187,7 +1481,7 @@ int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out) {
   if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t esz = ctx->gathered_c64 ? sizeof(float) : sizeof(double);
-  const int64_t n = nt * ctx->nbl * ctx->nchan * 2 * (int64_t)ctx->nranks;
+  const int64_t n = nt * ctx->nbl * ctx->gathered_row * 2 * (int64_t)ctx->nranks;
   if (nt <= 0 || (size_t)n * esz > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt does not match the gathered cube");
   int rc;
   if ((rc = ensure(ctx, ctx->scratch, 1025 * sizeof(double)))) return rc;

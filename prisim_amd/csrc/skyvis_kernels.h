@@ -83,15 +83,20 @@ hipError_t launch_mul_inplace(double* a, const double* b, int64_t n, hipStream_t
 // external HEALPix beam (aux_kernels.hip)
 hipError_t launch_extbeam_table(const double* beam, const double* interp, double* table, int64_t npix, int64_t nfreq,
                                 int64_t nchan, hipStream_t stream);
-hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs, const double* fluxes, double* work /*[nsrc][nchan]*/,
-                              double* colmax_scratch /*[1024*nchan + nchan]*/, double* pb_out, int64_t nsrc, int64_t nchan,
-                              hipStream_t stream);
+hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs, const double* fluxes /*[nsrc][nchan] or NULL*/,
+                              const double* flux_ref /*[nsrc]*/, const double* spindex /*[nsrc]*/, const double* freqs, double ref_freq,
+                              double* work /*[nsrc][nchan]*/, double* colmax_scratch /*[1024*nchan + nchan]*/, double* pb_out,
+                              int64_t nsrc, int64_t nchan, hipStream_t stream);
 
 // delay transform helpers (delay_kernels.hip)
 hipError_t launch_dt_prepare(const double* cube, const double* bpwts, double* work, int64_t nrows, int64_t nbl,
                              int64_t nchan, int64_t nfft, hipStream_t stream);
 hipError_t launch_dt_finish(const double* work, double* out, double* out_power, int64_t nrows, int64_t nfft,
                             int64_t nout, double factor, double scale, double power_scale, hipStream_t stream);
+// fused delay transform for power-of-two channel counts and integer 1 + pad (delay_kernels.hip)
+bool delay_fft_supported(int64_t nchan);
+hipError_t launch_delay_fft(const double* cube, const double* bpwts, const double* tw /*[nchan/2] complex*/, double* out, double* out_pow,
+                            int64_t nrows, int64_t nbl, int64_t nchan, double scale, double power_scale, int cu_count, hipStream_t stream);
 hipError_t launch_phase_rotate(double* cube, const double* blx, const double* bly, const double* blz, const double* freqs,
                                const double* diff /*[nt][3] device*/, int64_t nt, int64_t nbl, int64_t nchan, hipStream_t stream);
 hipError_t launch_noise(const double* rms, double* out, int64_t nbl, int64_t nchan, int64_t t, int64_t bl_offset, uint64_t seed,

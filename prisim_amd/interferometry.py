@@ -364,14 +364,20 @@ class InterferometerArray(object):
 
     def allgather_lags(self, nranks):
         """All-gather of the delay spectra of the baseline shards (the FFT is along frequency, so every rank transforms
-        its own shard and the spectra are exchanged like the visibilities).  Call after allgather() and delay_transform(); the lag
-        spectra take the place of the visibilities in the device cube slots for the exchange.  Returns (nranks*nbl, nlag, n_acc)."""
+        its own shard and the spectra are exchanged like the visibilities).  Call after allgather() and delay_transform().  Spectra
+        that delay_transform() left resident on the device go GPU -> GPU (prisim_hip_allgather_lags); host-side spectra take the
+        place of the visibilities in the device cube slots for the exchange.  Returns (nranks*nbl, nlag, n_acc)."""
         if not getattr(self, '_comm_ready', False):
             raise RuntimeError('allgather() must be called first (it sets up the communicator)')
+        if getattr(self, '_lag_resident', None) is not None:
+            nt, nout = self._lag_resident
+            self._ctx.allgather_lags(nt)
+            g = self._ctx.get_gathered(nt, nranks, row=nout)            # [t][rank][b][lag]
+            return NP.transpose(g.reshape(nt, nranks * self.baselines.shape[0], nout), (1, 2, 0))
         if self.skyvis_lag is None:
             raise RuntimeError('delay_transform() must be called first')
         if self.skyvis_lag.shape != (self.baselines.shape[0], self.channels.size, self.n_acc):
-            raise NotImplementedError('the delay spectra are exchanged through the visibility slots: this needs nlag == nchan (pad = 0, 1, 2, ...)')
+            raise NotImplementedError('host-side delay spectra are exchanged through the visibility slots: this needs nlag == nchan (pad = 0, 1, 2, ...)')
         _ = self.skyvis_freq                                           # make sure the host owns the visibilities before their slots are reused
         for t in range(self.n_acc):
             self._ctx.set_vis(NP.ascontiguousarray(self.skyvis_lag[:, :, t], dtype=NP.complex128), slot=t)
@@ -569,8 +575,20 @@ class InterferometerArray(object):
         if len(m2) > 0:
             skypos_altaz_roi = skypos_altaz[m2, :]                                    # :6219
             dircos_roi = GEOM.altaz2dircos(skypos_altaz_roi, 'degrees')               # :6263 (unconditional, Q4)
-            fluxes = NP.asarray(skymodel.generate_spectrum(ind=m2, frequency=self.channels, interp_method='pchip'),
-                                dtype=NP.float64).reshape(-1, nchan)                  # :6249
+            # flux spectra (:6249).  A power-law sky model (spec_type 'func') is described to the device by its nsrc-sized
+            # flux_ref / spindex vectors and S = flux_ref (f / ref_freq)^spindex is formed there; anything else goes through
+            # generate_spectrum on the host, as in the reference.
+            powerlaw = (getattr(skymodel, 'spec_type', None) == 'func' and pb is None
+                        and all(hasattr(skymodel, a) for a in ('flux_ref', 'spindex', 'ref_freq')))
+            if powerlaw:
+                fluxes = None
+                flux_ref = NP.asarray(skymodel.flux_ref, dtype=NP.float64)[m2]
+                spindex = NP.asarray(skymodel.spindex, dtype=NP.float64)[m2]
+                ref_freq = float(skymodel.ref_freq)
+            else:
+                fluxes = NP.asarray(skymodel.generate_spectrum(ind=m2, frequency=self.channels, interp_method='pchip'),
+                                    dtype=NP.float64).reshape(-1, nchan)
+                flux_ref = spindex = ref_freq = None
             fwhm = None
             src_shape = getattr(skymodel, 'src_shape', None)
             if src_shape is not None:                                                 # :6258, 6267
@@ -581,11 +599,11 @@ class InterferometerArray(object):
                 # supplied beam (ROI_parameters path): pbfluxes = pb * fluxes on the device (:6254)
                 self._ctx.set_sky(dircos_roi, pb, pc_dircos, fwhm_deg=fwhm, fluxes=fluxes)
             elif getattr(self, '_extbeam', None) is not None:
-                self._ctx.set_sky_external(dircos_roi, fluxes, pc_dircos, fwhm_deg=fwhm)
+                self._ctx.set_sky_external_analytic(dircos_roi, flux_ref, spindex, ref_freq, pc_dircos, fwhm_deg=fwhm, flux_spectrum=fluxes)
             else:
                 kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz,
                                                           first_frequency_hz=float(self.channels[0]))                   # :6252
-                self._ctx.set_sky_analytic(dircos_roi, None, None, None, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,
+                self._ctx.set_sky_analytic(dircos_roi, flux_ref, spindex, ref_freq, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,
                                            flux_spectrum=fluxes, ext=ext)
             slot = self.n_acc if self.n_acc < self._reserved else 0
             for i, snap in enumerate(self._cube):                       # a snapshot still parked in the slot about to be overwritten
@@ -637,6 +655,41 @@ class InterferometerArray(object):
             value = NP.asarray(value)
             self._cube = [value[:, :, i] for i in range(value.shape[2])]
             self._skyvis_cache = value
+
+    # skyvis_lag / lag_kernel: computed on the GPU by delay_transform(); when the visibility cube is resident on the device the
+    # spectra stay there too and are fetched on first read (config 5: 120 GB that a sharded run exchanges GPU -> GPU instead)
+    @property
+    def skyvis_lag(self):
+        if getattr(self, '_lag_resident', None) is not None and getattr(self, '_skyvis_lag', None) is None:
+            nt, nout = self._lag_resident
+            self._skyvis_lag = NP.transpose(self._ctx.get_lags(0, nt), (1, 2, 0))
+        return getattr(self, '_skyvis_lag', None)
+
+    @skyvis_lag.setter
+    def skyvis_lag(self, value):
+        self._skyvis_lag = value
+        self._lag_resident = None
+
+    def skyvis_lag_rows(self, rows):
+        """Delay spectra (len(rows), nlag, n_acc) of selected baselines without fetching the whole cube from the device."""
+        if getattr(self, '_lag_resident', None) is not None and getattr(self, '_skyvis_lag', None) is None:
+            nt, nout = self._lag_resident
+            return NP.transpose(self._ctx.get_lags(0, nt, rows=rows), (1, 2, 0))
+        if self.skyvis_lag is None:
+            raise RuntimeError('delay_transform() must be called first')
+        return self.skyvis_lag[NP.asarray(rows), :, :]
+
+    @property
+    def lag_kernel(self):
+        if getattr(self, '_lag_kernel', None) is None and getattr(self, '_lag_kernel_maker', None) is not None:
+            self._lag_kernel = self._lag_kernel_maker()
+            self._lag_kernel_maker = None
+        return getattr(self, '_lag_kernel', None)
+
+    @lag_kernel.setter
+    def lag_kernel(self, value):
+        self._lag_kernel = value
+        self._lag_kernel_maker = None
 
     # ------------------------------------------------------------------------------------------
     def observing_run(self, pointing_init, skymodel, t_acc, duration, channels,
@@ -1133,30 +1186,41 @@ class InterferometerArray(object):
                 outs.append(out)
             return NP.stack(outs, axis=2), lags
 
-        # number and type of the snapshots without forcing device-resident ones onto the host (_DeviceSlot placeholders)
+        # number of snapshots without forcing device-resident ones onto the host (_DeviceSlot placeholders)
         nt_all = len(self._cube) if self._cube else self._skyvis_override.shape[2]
-        dtype0 = self._cube[0].dtype if self._cube else self._skyvis_override.dtype
         wall = (self.bp * self.bp_wts).reshape(nbl, nchan, -1)
         same_wts = wall.shape[2] == 1 or bool(NP.all(wall == wall[:, :, [0]]))
         resident = self._reserved >= self.n_acc and bool(self._cube)     # device slots hold the snapshots: slot 0 must survive
-        if resident and self._reserved >= nt_all and self.n_acc == nt_all and same_wts and dtype0 == NP.complex128:
-            # the cube is resident on the GPU (reserve()): transform all snapshots in place, no re-upload
-            out, self.lags, _ = self._ctx.delay_transform(nt_all, bpwts=wall[:, :, 0], pad=pad)
-            self.skyvis_lag = NP.transpose(out, (1, 2, 0))
-            saved0 = self._ctx.get_vis(slot=0)
+        self._skyvis_lag, self._lag_resident = None, None
+        if resident and self._reserved >= nt_all and self.n_acc == nt_all and same_wts:
+            # the cube is resident on the GPU (reserve()): all snapshots are transformed where they are and the spectra stay in HBM
+            # until skyvis_lag is read (the device cube is complex128 for memsave runs too: nothing is rounded on the way)
+            self.lags, nout = self._ctx.delay_transform_device(nt_all, bpwts=wall[:, :, 0], pad=pad, want_lag=True)
+            self._lag_resident = (nt_all, nout)
         else:
             host_cube = NP.asarray(self.skyvis_freq, dtype=NP.complex128)
             saved0 = self._ctx.get_vis(slot=0) if resident else None       # the host-side transforms run through slot 0
-            self.skyvis_lag, self.lags = transform(host_cube)
+            self._skyvis_lag, self.lags = transform(host_cube)
+            if saved0 is not None:
+                self._ctx.set_vis(saved0, slot=0)
+
+        def through_slot0(fn):
+            saved = self._ctx.get_vis(slot=0) if resident else None
+            try:
+                return fn()
+            finally:
+                if saved is not None:
+                    self._ctx.set_vis(saved, slot=0)                   # put the resident snapshot back
+
         if self.vis_freq is not None:
-            self.vis_lag, _ = transform(NP.asarray(self.vis_freq, dtype=NP.complex128))
+            self.vis_lag = through_slot0(lambda: transform(NP.asarray(self.vis_freq, dtype=NP.complex128))[0])
         if self.vis_noise_freq is not None:
-            self.vis_noise_lag, _ = transform(NP.asarray(self.vis_noise_freq, dtype=NP.complex128))
-        if same_wts:
-            # the transform of bp * bp_wts (:8119 / :8127) is the same for every snapshot then: one FFT batch, repeated
-            kern, _ = transform(NP.ones((nbl, nchan, 1), dtype=NP.complex128))
-            self.lag_kernel = NP.repeat(kern, nt_all, axis=2)
-        else:
-            self.lag_kernel, _ = transform(NP.ones((nbl, nchan, nt_all), dtype=NP.complex128))
-        if saved0 is not None:
-            self._ctx.set_vis(saved0, slot=0)                              # put the resident snapshot back
+            self.vis_noise_lag = through_slot0(lambda: transform(NP.asarray(self.vis_noise_freq, dtype=NP.complex128))[0])
+
+        def make_kernel():
+            if same_wts:
+                # the transform of bp * bp_wts (:8119 / :8127) is the same for every snapshot then: one FFT batch, repeated
+                kern = through_slot0(lambda: transform(NP.ones((nbl, nchan, 1), dtype=NP.complex128))[0])
+                return NP.repeat(kern, nt_all, axis=2)
+            return through_slot0(lambda: transform(NP.ones((nbl, nchan, nt_all), dtype=NP.complex128))[0])
+        self._lag_kernel, self._lag_kernel_maker = None, make_kernel      # formed on first read of lag_kernel

@@ -69,6 +69,46 @@ def test_delay_transform_matches_numpy_restatement(ctx, pad):
     assert NP.max(NP.abs(pw - DO.delay_power(ref, 2.5))) <= 1e-9 * NP.max(NP.abs(ref)) ** 2 * 2.5
 
 
+@pytest.mark.parametrize('nchan', [256, 512, 1024, 2048, 4096])
+def test_fused_lds_delay_fft_matches_numpy_and_rocfft_pipeline(ctx, monkeypatch, nchan):
+    """Power-of-two channel counts with an integer 1 + pad run ONE kernel (delay_kernels.hip: three register stages, two LDS
+    exchanges): against the numpy restatement (zero padding, fftshift and decimation included), against the rocFFT pipeline on the
+    same device cube, host-output and device-resident forms, with and without a window, rows not a multiple of the rows per block."""
+    rng = NP.random.default_rng(nchan)
+    nbl, nt, df = 37, 2, 97656.25
+    ch = 150e6 + NP.arange(nchan) * df
+    ctx.set_array(rng.uniform(-100, 100, (nbl, 3)), ch, nt_max=nt)
+    cube = rng.normal(size=(nt, nbl, nchan)) + 1j * rng.normal(size=(nt, nbl, nchan))
+    for t in range(nt):
+        ctx.set_vis(cube[t], slot=t)
+    wts = rng.uniform(0.2, 1.0, (nbl, nchan))
+    vis_bft = NP.transpose(cube, (1, 2, 0))
+    for pad, w in ((1.0, wts), (0.0, None), (2.0, wts)):
+        wr = NP.ones((nbl, nchan, 1)) if w is None else w[:, :, None]
+        ref, ref_lags = DO.delay_transform(vis_bft, wr, NP.ones((nbl, nchan, 1)), df, pad=pad)
+        ref = NP.transpose(ref, (2, 0, 1))
+        out, lags, pw = ctx.delay_transform(nt, bpwts=w, pad=pad, want_power=True, power_scale=0.5)
+        assert out.shape == ref.shape == (nt, nbl, nchan)
+        assert NP.max(NP.abs(out - ref)) <= 1e-12 * NP.max(NP.abs(ref))
+        assert NP.max(NP.abs(pw - DO.delay_power(ref, 0.5))) <= 1e-11 * NP.max(NP.abs(ref)) ** 2
+        assert NP.allclose(lags, ref_lags, rtol=0, atol=1e-18)
+        lags2, nout = ctx.delay_transform_device(nt, bpwts=w, pad=pad, want_lag=True, want_power=True, power_scale=0.5)
+        assert nout == nchan and ctx.timing()['last_delay_fused'] == 1 and ctx.timing()['last_delay_ms'] > 0.0
+        assert NP.array_equal(ctx.get_lags(0, nt), out) and NP.array_equal(ctx.get_delay_power(0, nt), pw)
+        rows = NP.array([nbl - 1, 0, 5])
+        assert NP.array_equal(ctx.get_lags(1, 1, rows=rows), out[1:2][:, rows])
+        monkeypatch.setenv('PRISIM_HIP_DT_FUSED', '0')
+        out_r, _, pw_r = ctx.delay_transform(nt, bpwts=w, pad=pad, want_power=True, power_scale=0.5)
+        ctx.delay_transform_device(nt, bpwts=w, pad=pad)
+        assert ctx.timing()['last_delay_fused'] == 0
+        monkeypatch.delenv('PRISIM_HIP_DT_FUSED')
+        assert NP.max(NP.abs(out - out_r)) <= 1e-12 * NP.max(NP.abs(ref))
+    with pytest.raises(RuntimeError):
+        ctx.get_delay_power(0, nt)                                    # the last device transform produced lags only
+    with pytest.raises(ValueError):
+        ctx.get_lags(0, nt + 1)
+
+
 def test_delay_transform_in_snapshot_batches(ctx, monkeypatch):
     """Large cubes are transformed a few snapshots at a time (4 GiB work buffer); force 1-snapshot batches here."""
     rng = NP.random.default_rng(13)
