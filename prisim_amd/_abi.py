@@ -154,7 +154,7 @@ def load_library():
     lib.prisim_hip_set_sky_external_analytic.argtypes = [vp, C.POINTER(PrisimBeamSky)]
     lib.prisim_hip_get_pbflux.argtypes = [vp, vp]
     lib.prisim_hip_delay_transform.argtypes = [vp, i64, vp, dbl, vp, vp, vp, dbl]
-    lib.prisim_hip_delay_transform_device.argtypes = [vp, i64, vp, dbl, i32, i32, dbl, vp, C.POINTER(i64)]
+    lib.prisim_hip_delay_transform_device.argtypes = [vp, i64, vp, i64, dbl, i32, i32, dbl, vp, C.POINTER(i64)]
     lib.prisim_hip_get_lags.argtypes = [vp, i64, i64, vp, i64, vp]
     lib.prisim_hip_get_delay_power.argtypes = [vp, i64, i64, vp, i64, vp]
     lib.prisim_hip_allgather_lags.argtypes = [vp, i64]
@@ -406,12 +406,18 @@ class Context(object):
         """Delay-transform slots [0, nt) and leave the spectra in HBM (prisim_hip_delay_transform_device).  Returns (lags, nout);
         read the results with get_lags / get_delay_power or exchange them with allgather_lags."""
         pad = max(float(pad), 0.0)
-        w = None
+        w, wrows = None, 0
         if bpwts is not None:
-            w = NP.ascontiguousarray(bpwts, dtype=NP.float64).reshape(self.nbl, self.nchan)
+            w = NP.ascontiguousarray(bpwts, dtype=NP.float64)
+            if w.size == self.nchan:
+                w, wrows = w.reshape(1, self.nchan), 1                   # one window for every baseline
+            else:
+                w, wrows = w.reshape(self.nbl, self.nchan), self.nbl
+                if self.nbl > 1 and NP.array_equal(w, NP.broadcast_to(w[:1], w.shape)):
+                    w, wrows = NP.ascontiguousarray(w[:1]), 1
         lags = NP.empty(self.nchan, dtype=NP.float64)
         nout = C.c_int64()
-        self._check(self._lib.prisim_hip_delay_transform_device(self._h, int(nt), _ptr(w), pad, 1 if want_lag else 0, 1 if want_power else 0,
+        self._check(self._lib.prisim_hip_delay_transform_device(self._h, int(nt), _ptr(w), wrows, pad, 1 if want_lag else 0, 1 if want_power else 0,
                                                                 float(power_scale), _ptr(lags), C.byref(nout)),
                     'prisim_hip_delay_transform_device')
         self._dt_nout = int(nout.value)

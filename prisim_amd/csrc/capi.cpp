@@ -1086,12 +1086,17 @@ DelayGeom delay_geom(const prisim_ctx* ctx, double pad) {
 }
 
 // Upload the window [nbl][nchan] (or none) and make sure the fused kernel's twiddle table / the rocFFT plan exist.
-int delay_prepare(prisim_ctx* ctx, const DelayGeom& g, const double* bpwts, int64_t nrows_batch) {
+int delay_prepare(prisim_ctx* ctx, const DelayGeom& g, const double* bpwts, int64_t wts_rows, int64_t nrows_batch) {
   int rc;
   const int64_t nchan = ctx->nchan, nbl = ctx->nbl;
   if (bpwts) {
-    if ((rc = ensure(ctx, ctx->dt_wts, (size_t)nbl * nchan * sizeof(double)))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->dt_wts.p, bpwts, (size_t)nbl * nchan * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // one window row for every baseline (wts_rows == 1) is replicated on the device only for the rocFFT pipeline's k_dt_prepare
+    if (wts_rows != 1 && wts_rows != nbl) return fail(ctx, PRISIM_EINVAL, "wts_rows must be 1 or nbl");
+    const int64_t dev_rows = (g.fused || wts_rows == nbl) ? wts_rows : nbl;
+    if ((rc = ensure(ctx, ctx->dt_wts, (size_t)dev_rows * nchan * sizeof(double)))) return rc;
+    for (int64_t r = 0; r < (wts_rows == 1 ? dev_rows : 1); ++r)
+      HIPCHK(ctx, hipMemcpyAsync((double*)ctx->dt_wts.p + (size_t)r * nchan, bpwts, (size_t)(wts_rows == 1 ? 1 : nbl) * nchan * sizeof(double),
+                                 hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // bpwts is caller-owned
   }
   if (g.fused) {
@@ -1121,7 +1126,7 @@ int delay_prepare(prisim_ctx* ctx, const DelayGeom& g, const double* bpwts, int6
 
 // Transform `nrows` = ntc * nbl rows starting at snapshot slot t0 into the device buffers d_out ([nrows][nout] complex128) and/or
 // d_pow ([nrows][nout] float64).  Asynchronous on the context stream.
-int delay_batch(prisim_ctx* ctx, const DelayGeom& g, int64_t t0, int64_t nrows, bool have_wts, double* d_out, double* d_pow,
+int delay_batch(prisim_ctx* ctx, const DelayGeom& g, int64_t t0, int64_t nrows, bool have_wts, int64_t wts_rows, double* d_out, double* d_pow,
                 double power_scale) {
   const int64_t nchan = ctx->nchan, nbl = ctx->nbl;
   const size_t slot_elems = (size_t)nbl * nchan * 2;
@@ -1130,8 +1135,8 @@ int delay_batch(prisim_ctx* ctx, const DelayGeom& g, int64_t t0, int64_t nrows, 
   // rocFFT's inverse is unnormalised: sum_n x[n] e^{+2 pi i k n / N'}.  The reference forms ifft(x) * N' * df (:8125) = that sum times df.
   const double scale = ctx->df;
   if (g.fused) {
-    HIPCHK(ctx, launch_delay_fft(src, wts, (const double*)ctx->dt_tw.p, d_out, d_pow, nrows, nbl, nchan, scale, power_scale, ctx->cu_count,
-                                 ctx->stream));
+    HIPCHK(ctx, launch_delay_fft(src, wts, wts_rows, (const double*)ctx->dt_tw.p, d_out, d_pow, nrows, nbl, nchan, scale, power_scale,
+                                 ctx->cu_count, ctx->stream));
     return PRISIM_OK;
   }
   RocfftApi& F = g_rocfft;
@@ -1208,13 +1213,13 @@ int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts,
   // the host-output form always goes batch by batch through two staging buffers
   int64_t nt_b = delay_batch_snapshots(ctx, g, nt);
   if (g.fused) nt_b = std::min<int64_t>(nt, std::max<int64_t>(1, ((int64_t)2 << 30) / (nbl * nout * 16)));
-  if ((rc = delay_prepare(ctx, g, bpwts, nt_b * nbl))) return rc;
+  if ((rc = delay_prepare(ctx, g, bpwts, nbl, nt_b * nbl))) return rc;
   if (out && (rc = ensure(ctx, ctx->dt_out, (size_t)(nt_b * nbl) * nout * 2 * sizeof(double)))) return rc;
   if (out_power && (rc = ensure(ctx, ctx->dt_pow, (size_t)(nt_b * nbl) * nout * sizeof(double)))) return rc;
   for (int64_t t0 = 0; t0 < nt; t0 += nt_b) {
     const int64_t ntc = std::min(nt_b, nt - t0);
     const int64_t nrows = ntc * nbl;
-    if ((rc = delay_batch(ctx, g, t0, nrows, bpwts != nullptr, out ? (double*)ctx->dt_out.p : nullptr,
+    if ((rc = delay_batch(ctx, g, t0, nrows, bpwts != nullptr, nbl, out ? (double*)ctx->dt_out.p : nullptr,
                           out_power ? (double*)ctx->dt_pow.p : nullptr, power_scale)))
       return rc;
     if (out)
@@ -1229,7 +1234,7 @@ int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts,
   return PRISIM_OK;
 }
 
-int prisim_hip_delay_transform_device(prisim_ctx* ctx, int64_t nt, const double* bpwts, double pad, int want_lag, int want_power,
+int prisim_hip_delay_transform_device(prisim_ctx* ctx, int64_t nt, const double* bpwts, int64_t wts_rows, double pad, int want_lag, int want_power,
                                       double power_scale, double* lags_out, int64_t* nout_out) {
   if (!ctx) return PRISIM_EINVAL;
   int rc;
@@ -1239,7 +1244,7 @@ int prisim_hip_delay_transform_device(prisim_ctx* ctx, int64_t nt, const double*
   const DelayGeom g = delay_geom(ctx, pad);
   const int64_t nbl = ctx->nbl, nout = g.nout;
   const int64_t nt_b = delay_batch_snapshots(ctx, g, nt);
-  if ((rc = delay_prepare(ctx, g, bpwts, nt_b * nbl))) return rc;
+  if ((rc = delay_prepare(ctx, g, bpwts, wts_rows, nt_b * nbl))) return rc;
   ctx->dt_have_lag = ctx->dt_have_pow = false;
   if (want_lag && (rc = ensure(ctx, ctx->dt_lag_all, (size_t)nt * nbl * nout * 2 * sizeof(double)))) return rc;
   if (want_power && (rc = ensure(ctx, ctx->dt_pow_all, (size_t)nt * nbl * nout * sizeof(double)))) return rc;
@@ -1252,7 +1257,7 @@ int prisim_hip_delay_transform_device(prisim_ctx* ctx, int64_t nt, const double*
     const int64_t ntc = std::min(nt_b, nt - t0);
     double* d_out = want_lag ? (double*)ctx->dt_lag_all.p + (size_t)t0 * nbl * nout * 2 : nullptr;
     double* d_pow = want_power ? (double*)ctx->dt_pow_all.p + (size_t)t0 * nbl * nout : nullptr;
-    if ((rc = delay_batch(ctx, g, t0, ntc * nbl, bpwts != nullptr, d_out, d_pow, power_scale))) return rc;
+    if ((rc = delay_batch(ctx, g, t0, ntc * nbl, bpwts != nullptr, wts_rows, d_out, d_pow, power_scale))) return rc;
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev_d1, ctx->stream));
   ctx->dt_nt = nt; ctx->dt_nout = nout;

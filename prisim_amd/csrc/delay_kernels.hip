@@ -103,8 +103,12 @@ template <> __device__ __forceinline__ void dft_small<16>(double2 (&v)[16]) {
 }  // namespace
 
 // tw: [N / 2] W_N^m = exp(+2 pi i m / N), m < N / 2 (W_N^(m + N/2) = -W_N^m)
-template <int N>
-__global__ __launch_bounds__(256) void k_delay_fft(const double2* __restrict__ cube, const double* __restrict__ bpwts,
+// WMODE 0: no window; 1: one window [N] for every row (each thread keeps its 16 weights in registers for the whole launch);
+//       2: a window per baseline, bpwts [nbl][N], fetched with the row.
+// The 16 loads of a row are issued back to back, and the rows of the NEXT pass are requested before the current pass is
+// transformed (register double buffer): the kernel is HBM-bound only if enough bytes are in flight per CU.
+template <int N, int WMODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ? 2 : 1, 2))) void k_delay_fft(const double2* __restrict__ cube, const double* __restrict__ bpwts,
                                                     const double2* __restrict__ tw_g, double2* __restrict__ out,
                                                     double* __restrict__ out_pow, int64_t nrows, int64_t nbl, double scale,
                                                     double power_scale) {
@@ -125,24 +129,41 @@ __global__ __launch_bounds__(256) void k_delay_fft(const double2* __restrict__ c
     const double2 w = tw[m & (N / 2 - 1)];
     return (m & (N / 2)) ? make_double2(-w.x, -w.y) : w;
   };
+  double wfix[16];
+  if constexpr (WMODE == 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) wfix[q] = bpwts[j + M * q];
+  }
   __syncthreads();
 
   const int64_t npass = (nrows + RPB - 1) / RPB;
+  double2 vn[16];
+  double wn[16];
+  auto fetch = [&](int64_t pass) {      // x[j + M q], q = 0 ... 15: consecutive j are consecutive addresses
+    const int64_t row = pass * RPB + rl;
+    const int64_t rr = row < nrows ? row : nrows - 1;            // rows past the end re-read the last one and are never stored
+    const double2* src = cube + rr * N;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) vn[q] = src[j + M * q];
+    if constexpr (WMODE == 2) {
+      const double* wsrc = bpwts + (rr % nbl) * N;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) wn[q] = wsrc[j + M * q];
+    }
+  };
+  if ((int64_t)blockIdx.x < npass) fetch(blockIdx.x);
   for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
     const int64_t row = pass * RPB + rl;
     const bool live = row < nrows;
     double2 v[16];
-    // ---- stage A: x[j + M q], q = 0 ... 15 (coalesced: consecutive j), weights, 16-point DFT over q, twiddle W_N^(j p)
-    {
-      const double2* src = cube + (live ? row : 0) * N;
-      const double* wsrc = bpwts ? bpwts + ((live ? row : 0) % nbl) * N : nullptr;
+    // ---- stage A: window, 16-point DFT over q, twiddle W_N^(j p)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        double2 x = live ? src[j + M * q] : make_double2(0.0, 0.0);
-        if (wsrc) { const double w = wsrc[j + M * q]; x.x *= w; x.y *= w; }
-        v[q] = x;
-      }
+    for (int q = 0; q < 16; ++q) {
+      v[q] = vn[q];
+      if constexpr (WMODE == 1) { v[q].x *= wfix[q]; v[q].y *= wfix[q]; }
+      if constexpr (WMODE == 2) { v[q].x *= wn[q]; v[q].y *= wn[q]; }
     }
+    if (pass + gridDim.x < npass) fetch(pass + gridDim.x);       // in flight while this pass is transformed
     dft_small<16>(v);
 #pragma unroll
     for (int p = 0; p < 16; ++p) xb[p * (M + 1) + j] = (p == 0) ? v[0] : cmul(v[p], twid(j * p));
@@ -168,7 +189,7 @@ __global__ __launch_bounds__(256) void k_delay_fft(const double2* __restrict__ c
     } else {
       __syncthreads();                  // every thread of the row has read its stage-A values
 #pragma unroll
-      for (int pp = 0; pp < 16; ++pp) xb[a * 257 + p + 16 * pp] = (pp == 0 || a == 0) ? v[pp] : cmul(v[pp], twid(16 * a * pp));
+      for (int pp = 0; pp < 16; ++pp) xb[a * 257 + p + 16 * pp] = (pp == 0) ? v[0] : cmul(v[pp], twid(16 * a * pp));
       __syncthreads();
       // ---- stage C: thread L = j: R-point DFTs over a for c = L + M m, m < 16 / R; k = c + 256 r
 #pragma unroll
@@ -199,27 +220,37 @@ bool delay_fft_supported(int64_t nchan) {
 }
 
 template <int N>
-static hipError_t launch_delay_fft_n(const double* cube, const double* bpwts, const double* tw, double* out, double* out_pow,
+static hipError_t launch_delay_fft_n(const double* cube, const double* bpwts, int wts_rows, const double* tw, double* out, double* out_pow,
                                      int64_t nrows, int64_t nbl, double scale, double power_scale, int cu_count, hipStream_t stream) {
   constexpr int RPB = 256 / (N / 16);
   const int64_t npass = (nrows + RPB - 1) / RPB;
-  int64_t grid = (int64_t)(cu_count > 0 ? cu_count : 256) * 8;          // persistent blocks, a few per CU
+  int64_t grid = (int64_t)(cu_count > 0 ? cu_count : 256) * 2;          // persistent blocks: what is resident (2 per CU: 75 KB of LDS each)
   if (grid > npass) grid = npass;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_delay_fft<N>), dim3((unsigned)grid), dim3(256), 0, stream, reinterpret_cast<const double2*>(cube), bpwts,
-                     reinterpret_cast<const double2*>(tw), reinterpret_cast<double2*>(out), out_pow, nrows, nbl, scale, power_scale);
+  const dim3 g((unsigned)grid), b(256);
+  const double2* c2 = reinterpret_cast<const double2*>(cube);
+  const double2* t2 = reinterpret_cast<const double2*>(tw);
+  double2* o2 = reinterpret_cast<double2*>(out);
+  if (!bpwts)
+    hipLaunchKernelGGL((k_delay_fft<N, 0>), g, b, 0, stream, c2, bpwts, t2, o2, out_pow, nrows, nbl, scale, power_scale);
+  else if (wts_rows == 1)
+    hipLaunchKernelGGL((k_delay_fft<N, 1>), g, b, 0, stream, c2, bpwts, t2, o2, out_pow, nrows, nbl, scale, power_scale);
+  else
+    hipLaunchKernelGGL((k_delay_fft<N, 2>), g, b, 0, stream, c2, bpwts, t2, o2, out_pow, nrows, nbl, scale, power_scale);
   return hipGetLastError();
 }
 
-hipError_t launch_delay_fft(const double* cube, const double* bpwts, const double* tw, double* out, double* out_pow, int64_t nrows,
-                            int64_t nbl, int64_t nchan, double scale, double power_scale, int cu_count, hipStream_t stream) {
+// bpwts: device window, [N] (wts_rows == 1) or [nbl][N] (wts_rows == nbl), or NULL
+hipError_t launch_delay_fft(const double* cube, const double* bpwts, int64_t wts_rows, const double* tw, double* out, double* out_pow,
+                            int64_t nrows, int64_t nbl, int64_t nchan, double scale, double power_scale, int cu_count, hipStream_t stream) {
   if (nrows == 0) return hipSuccess;
+  const int wr = wts_rows == 1 ? 1 : 2;
   switch (nchan) {
-    case 256: return launch_delay_fft_n<256>(cube, bpwts, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
-    case 512: return launch_delay_fft_n<512>(cube, bpwts, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
-    case 1024: return launch_delay_fft_n<1024>(cube, bpwts, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
-    case 2048: return launch_delay_fft_n<2048>(cube, bpwts, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
-    case 4096: return launch_delay_fft_n<4096>(cube, bpwts, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
+    case 256: return launch_delay_fft_n<256>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
+    case 512: return launch_delay_fft_n<512>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
+    case 1024: return launch_delay_fft_n<1024>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
+    case 2048: return launch_delay_fft_n<2048>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
+    case 4096: return launch_delay_fft_n<4096>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
   }
   return hipErrorInvalidValue;
 }

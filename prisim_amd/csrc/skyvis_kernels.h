@@ -95,8 +95,9 @@ hipError_t launch_dt_finish(const double* work, double* out, double* out_power, 
                             int64_t nout, double factor, double scale, double power_scale, hipStream_t stream);
 // fused delay transform for power-of-two channel counts and integer 1 + pad (delay_kernels.hip)
 bool delay_fft_supported(int64_t nchan);
-hipError_t launch_delay_fft(const double* cube, const double* bpwts, const double* tw /*[nchan/2] complex*/, double* out, double* out_pow,
-                            int64_t nrows, int64_t nbl, int64_t nchan, double scale, double power_scale, int cu_count, hipStream_t stream);
+hipError_t launch_delay_fft(const double* cube, const double* bpwts /*device [wts_rows][nchan] or NULL*/, int64_t wts_rows /*1 or nbl*/,
+                            const double* tw /*[nchan/2] complex*/, double* out, double* out_pow, int64_t nrows, int64_t nbl, int64_t nchan,
+                            double scale, double power_scale, int cu_count, hipStream_t stream);
 hipError_t launch_phase_rotate(double* cube, const double* blx, const double* bly, const double* blz, const double* freqs,
                                const double* diff /*[nt][3] device*/, int64_t nt, int64_t nbl, int64_t nchan, hipStream_t stream);
 hipError_t launch_noise(const double* rms, double* out, int64_t nbl, int64_t nchan, int64_t t, int64_t bl_offset, uint64_t seed,

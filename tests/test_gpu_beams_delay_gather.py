@@ -83,11 +83,12 @@ def test_fused_lds_delay_fft_matches_numpy_and_rocfft_pipeline(ctx, monkeypatch,
         ctx.set_vis(cube[t], slot=t)
     wts = rng.uniform(0.2, 1.0, (nbl, nchan))
     vis_bft = NP.transpose(cube, (1, 2, 0))
-    for pad, w in ((1.0, wts), (0.0, None), (2.0, wts)):
-        wr = NP.ones((nbl, nchan, 1)) if w is None else w[:, :, None]
+    for pad, w in ((1.0, wts), (0.0, None), (2.0, wts), (1.0, wts[3])):          # windows: per baseline, none, one for all baselines
+        wfull = None if w is None else NP.broadcast_to(w, (nbl, nchan))
+        wr = NP.ones((nbl, nchan, 1)) if w is None else wfull[:, :, None]
         ref, ref_lags = DO.delay_transform(vis_bft, wr, NP.ones((nbl, nchan, 1)), df, pad=pad)
         ref = NP.transpose(ref, (2, 0, 1))
-        out, lags, pw = ctx.delay_transform(nt, bpwts=w, pad=pad, want_power=True, power_scale=0.5)
+        out, lags, pw = ctx.delay_transform(nt, bpwts=wfull, pad=pad, want_power=True, power_scale=0.5)
         assert out.shape == ref.shape == (nt, nbl, nchan)
         assert NP.max(NP.abs(out - ref)) <= 1e-12 * NP.max(NP.abs(ref))
         assert NP.max(NP.abs(pw - DO.delay_power(ref, 0.5))) <= 1e-11 * NP.max(NP.abs(ref)) ** 2
@@ -98,7 +99,7 @@ def test_fused_lds_delay_fft_matches_numpy_and_rocfft_pipeline(ctx, monkeypatch,
         rows = NP.array([nbl - 1, 0, 5])
         assert NP.array_equal(ctx.get_lags(1, 1, rows=rows), out[1:2][:, rows])
         monkeypatch.setenv('PRISIM_HIP_DT_FUSED', '0')
-        out_r, _, pw_r = ctx.delay_transform(nt, bpwts=w, pad=pad, want_power=True, power_scale=0.5)
+        out_r, _, pw_r = ctx.delay_transform(nt, bpwts=wfull, pad=pad, want_power=True, power_scale=0.5)
         ctx.delay_transform_device(nt, bpwts=w, pad=pad)
         assert ctx.timing()['last_delay_fused'] == 0
         monkeypatch.delenv('PRISIM_HIP_DT_FUSED')

@@ -36,8 +36,7 @@ def run(cfg, ctx, n_acc, spot=6, delay=False):
             dc, fr, sp, fw = sky['dircos'], sky['flux_ref'], sky['spindex'], sky['fwhm_deg']
         fwhm = fw if cfg['taper'] else None
         if cfg['beam'] == 'external':
-            flux = fr[:, None] * (ch[None, :] / sky['ref_freq']) ** sp[:, None]
-            ctx.set_sky_external(dc, flux, zen, fwhm_deg=fwhm)
+            ctx.set_sky_external_analytic(dc, fr, sp, sky['ref_freq'], zen, fwhm_deg=fwhm)
         else:
             ctx.set_sky_analytic(dc, fr, sp, sky['ref_freq'], kinds[cfg['beam']], cfg['diameter'], zen, zen, fwhm_deg=fwhm)
         ctx.compute(precision=prec, slot=j)
@@ -51,19 +50,48 @@ def run(cfg, ctx, n_acc, spot=6, delay=False):
             worst = float(NP.max(NP.abs(vis - ref) / NP.sum(NP.abs(pb), axis=0)[None, :]))
     ctx.sync()
     wall = time.perf_counter() - t0
+    if spot:
+        # same loop again without the parity spot check (oracle + two downloads): what a production run pays per snapshot
+        t0 = time.perf_counter()
+        for j in range(n_acc):
+            if n_acc > 1:
+                dc, altaz, keep = W.drift_snapshot_directions(sky, cfg['latitude'], j * cfg['t_acc'] * 360.0 * 1.00273790935 / 86400.0)
+                fr, sp, fw = sky['flux_ref'][keep], sky['spindex'][keep], sky['fwhm_deg'][keep]
+            else:
+                dc, fr, sp, fw = sky['dircos'], sky['flux_ref'], sky['spindex'], sky['fwhm_deg']
+            fwhm = fw if cfg['taper'] else None
+            if cfg['beam'] == 'external':
+                ctx.set_sky_external_analytic(dc, fr, sp, sky['ref_freq'], zen, fwhm_deg=fwhm)
+            else:
+                ctx.set_sky_analytic(dc, fr, sp, sky['ref_freq'], kinds[cfg['beam']], cfg['diameter'], zen, zen, fwhm_deg=fwhm)
+            ctx.compute(precision=prec, slot=j)
+        ctx.sync()
+        wall_nospot = time.perf_counter() - t0
+        ctx.timing(reset=True)
+        for j in range(n_acc):
+            ctx.compute(precision=prec, slot=j)
+        ctx.sync()
     tm = ctx.timing()
     kern_ms = tm['sum_kernel_ms']
     out = {'config': cfg['name'], 'nbl': int(bl.shape[0]), 'nchan': int(ch.size), 'nsrc_catalog': int(sky['dircos'].shape[0]),
            'n_acc': n_acc, 'precision': cfg['precision'], 'taper': bool(cfg['taper']), 'terms': float(terms),
            'kernel_ms_total': kern_ms, 'terms_per_s_kernel': terms / (kern_ms * 1e-3) if kern_ms > 0 else None,
-           'wall_s_incl_sky_staging_and_spot_check': wall, 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
+           'wall_s_incl_sky_staging_and_spot_check': wall, 'wall_s_incl_host_geometry_and_sky_staging': wall_nospot if spot else wall, 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
            'parity_spot_max_err_rel_sumflux': worst, 'tolerance': 5e-6 if cfg['precision'] == 'fp32' else 1e-11}
     if delay:
-        t1 = time.perf_counter()
-        _, lags, pw = ctx.delay_transform(n_acc, pad=1.0, want_power=True, power_scale=1.0, want_lag=False)
-        out['delay_power_spectrum_s'] = time.perf_counter() - t1
+        w = NP.blackman(ch.size)
+        for rep in range(2):
+            t1 = time.perf_counter()
+            ctx.delay_transform_device(n_acc, bpwts=w, pad=1.0, want_lag=False, want_power=True, power_scale=1.0)
+            ctx.sync()
+            out['delay_power_spectrum_wall_s'] = time.perf_counter() - t1
+        tmd = ctx.timing()
+        out['delay_power_spectrum_device_ms'] = tmd['last_delay_ms']
+        out['delay_fused_kernel'] = bool(tmd['last_delay_fused'])
         out['delay_ffts'] = int(n_acc * bl.shape[0])
-        out['delay_fft_length'] = int(2 * ch.size)
+        out['delay_fft_length_kept'] = int(ch.size)
+        nbytes = n_acc * bl.shape[0] * ch.size * (16 + 8)             # read each visibility once, write each power sample once
+        out['delay_algorithmic_GBps'] = nbytes / (tmd['last_delay_ms'] * 1e-3) / 1e9
     return out
 
 
