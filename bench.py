@@ -13,13 +13,22 @@ sky with all inputs already resident in HBM.  With N > 1 the baselines are shard
 blocks (one process per GPU, the reference's pp.key='bl' model, scripts/run_prisim.py:1775-1791),
 each rank writes snapshot t into slot t of its shard of the visibility cube, and the RCCL all-gather
 of the cube (issued per snapshot on a second HIP stream so that it overlaps the next snapshot's compute) is
-INSIDE the timed region.  The total workload is
-fixed as N grows ("scaling": "strong").  torch is used only for the multi-process rendezvous
-(gloo barrier / max-reduce / unique-id broadcast); all GPU work goes through libprisim_hip.so.
+INSIDE the timed region.  The total workload is fixed as N grows ("scaling": "strong").
 
-Rank 0 prints ONE JSON line.
+No torch anywhere: the launcher only provides RANK / WORLD_SIZE / LOCAL_RANK; the out-of-band exchange of the 128-byte RCCL id,
+the barriers and the max-over-ranks of the timing go through prisim_amd.rendezvous (loopback sockets), all GPU work through
+libprisim_hip.so.  If the RCCL communicator cannot be built at N > 1 the run FAILS (non-zero exit): there is no host-side gather.
+
+Rank 0 prints ONE JSON line.  Beside the contract's keys it carries (N = 1 only, all outside the timed region):
+  roofline / roofline_hbm   the dominant kernel against the VALU issue roofline (the binding one) and the HBM figure BASELINE words
+  cpu_baseline              C/OpenMP port of interferometry.py:6332-6340 on this box's host cores (bounded sample) + parity check
+  cpu_baseline_ref          the reference FORMULATION itself: numpy restatement, one process, slabbed like :6348-6376 (bounded sample)
+  e2e                       the same snapshots through InterferometerArray.observe(), host geometry and sky staging included
+  delay_ps                  delay power spectra of the K resident snapshots (interferometry.py:8114-8134 + delay_spectrum.py:3992):
+                            device time, FFT count, achieved algorithmic GB/s against the 8 TB/s HBM roofline
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,7 +39,7 @@ import numpy as NP
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from prisim_amd import _abi, workloads as W   # noqa: E402
+from prisim_amd import _abi, rendezvous, workloads as W   # noqa: E402
 
 FLOPS_PER_TERM = 10.0       # rotate (4 mul + 2 add) + accumulate (2 mul + 2 add) = 6 VALU slots
 PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # MI355X_MICROARCH.md chip table: vector FP32 157.3 TF; FP64 = half
@@ -53,6 +62,19 @@ def shard_baselines(bl, world, rank):
         pad = NP.repeat(bl[-1:], per - mine.shape[0], axis=0)
         mine = NP.vstack((mine, pad))
     return mine, hi - lo
+
+
+def csrc_hash():
+    """Identity of the kernel sources a profile was taken with: sha1 over prisim_amd/csrc (names + contents).  tools/profile_round.sh
+    stores it beside the counters; a PMC summary of other sources is not quoted as this build's traffic."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, 'prisim_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.cpp', '.h')):
+            h.update(name.encode())
+            with open(os.path.join(d, name), 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()
 
 
 def cpu_baseline(cfg, pbflux_sample_fn, target_terms=1.0e10):
@@ -79,23 +101,79 @@ def cpu_baseline(cfg, pbflux_sample_fn, target_terms=1.0e10):
                       'interferometry.py:6332-6340, %s' % (bls.shape[0], bl.shape[0], stride, nchan, nsrc, terms, dt, CO.flavour)}, bls, ref, stride
 
 
+def cpu_baseline_reference_formulation(cfg, pb, target_seconds=8.0):
+    """The reference's own formulation -- oracle/skyvis_oracle.py, the line-by-line numpy restatement of interferometry.py:6320-6376
+    (nsrc x nbl x nchan phase matrix, exp, multiply, sum over sources; slabbed over sources when it does not fit, :6348-6376) --
+    in ONE process, which is what one PRISim MPI rank executes.  Bounded sample: a few baselines of the same workload."""
+    from oracle import skyvis_oracle as O
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    nsrc, nchan = sky['dircos'].shape[0], ch.size
+    zen = NP.array([0.0, 0.0, 1.0])
+    fw = sky['fwhm_deg'] if cfg['taper'] else None
+    sel = NP.linspace(0, bl.shape[0] - 1, 4).astype(int)
+    t0 = time.perf_counter()
+    O.skyvis(bl[sel[:1]], ch, sky['dircos'], pb, zen, fwhm_deg=fw)                  # one baseline: sizes the sample
+    t1 = time.perf_counter() - t0
+    nb = int(max(2, min(64, target_seconds / max(t1, 1e-3))))
+    sel = NP.linspace(0, bl.shape[0] - 1, nb).astype(int)
+    t0 = time.perf_counter()
+    ref = O.skyvis(bl[sel], ch, sky['dircos'], pb, zen, fwhm_deg=fw)
+    dt = time.perf_counter() - t0
+    terms = float(nb) * nchan * nsrc
+    return {'value': terms / dt, 'unit': 'terms/s', 'cores': 1, 'kind': 'reference-formulation (numpy restatement, oracle/skyvis_oracle.py)',
+            'sample': '%d of %d baselines x %d ch x %d src = %.3g terms in %.1f s, one process, the statements of '
+                      'interferometry.py:6320-6343 (source slabs as :6348-6376 when the phase matrix does not fit)' % (nb, bl.shape[0], nchan, nsrc, terms, dt)}, sel, ref
+
+
 def profiled_traffic(kernel_tag):
-    """HBM bytes per launch of the dominant kernel, from the newest committed rocprofv3 PMC summary
-    (profiles/*/pmc_summary.json: separate --pmc passes of this same command, 2*FETCH_SIZE + WRITE_SIZE in KiB with the
-    gfx950 FETCH correction of MI355X_MICROARCH.md).  Counters cannot be read inside an ordinary run, so this is the
-    committed measurement for the same kernel/workload, or None."""
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary (profiles/*/pmc_summary.json: separate
+    --pmc passes of this same command, 2*FETCH_SIZE + WRITE_SIZE in KiB with the gfx950 FETCH correction of MI355X_MICROARCH.md)
+    -- only if that summary was taken with THIS build's kernel sources (csrc_hash), else None: counters cannot be read inside
+    an ordinary run, and a stale figure is worse than none."""
     import glob
+    mine = csrc_hash()
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'pmc_summary.json'))):
         try:
             with open(path) as f:
                 d = json.load(f)
+            if d.get('_csrc_hash') != mine:
+                continue
             if kernel_tag in d.get('_kernel', {}).get('Kernel_Name', '') and 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
                 best = ((2.0 * d['FETCH_SIZE']['mean_per_launch'] + d['WRITE_SIZE']['mean_per_launch']) * 1024.0,
                         os.path.relpath(path, ROOT))
         except Exception:
             pass
     return best
+
+
+def e2e_observe(cfg, n_snap, device, memsave):
+    """The same workload through the reference's entry point for the path, InterferometerArray.observe() (interferometry.py:5874):
+    per snapshot the host geometry (hadec -> altaz -> direction cosines of every source), the sky staging (nsrc-sized vectors), the
+    fused beam x flux, prep, pack and the sky-sum.  Returns terms/s over n_snap snapshots, wall clock around the loop + final sync."""
+    from prisim_amd import interferometry as RI, skymodel as SM
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    n = sky['dircos'].shape[0]
+    skymod = SM.SkyModel(location=sky['altaz'], flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
+                         src_shape=(NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1) if cfg['taper'] else None))
+
+    def observe(ia, j):
+        ia.observe((2457000.5 + j * 1e-4, 0.1 * j), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, -30.7224], skymod, 10.7, memsave=memsave)
+
+    ia = RI.InterferometerArray(['b%d' % i for i in range(bl.shape[0])], bl, ch, telescope={'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'},
+                                latitude=-30.7224, skycoords='altaz', pointing_coords='hadec', device=device)
+    ia.reserve(n_snap + 1)
+    observe(ia, 0)                      # warm-up snapshot: allocations, first-launch costs
+    ia._ctx.sync()
+    t0 = time.perf_counter()
+    for j in range(1, n_snap + 1):
+        observe(ia, j)
+    ia._ctx.sync()
+    dt = time.perf_counter() - t0
+    terms = float(bl.shape[0]) * ch.size * n * n_snap
+    ia._ctx.close()
+    return {'value': terms / dt, 'unit': 'terms/s', 'snapshots': n_snap, 'ms_per_snapshot': dt / n_snap * 1e3,
+            'path': 'InterferometerArray.observe(): host geometry + sky staging + fused beam + sky-sum, cube left resident on the device'}
 
 
 def main():
@@ -108,7 +186,7 @@ def main():
     ap.add_argument('--workload', choices=('cfg3', 'cfg3d', 'cfg5'), default='cfg3',
                     help='cfg3: the headline workload (BASELINE config 3, 1e4 point sources); cfg3d: config 3 with its nside=128 diffuse half '
                          '(source-shape taper on); cfg5: one LST of config 5 (nside=256 diffuse sky, taper on)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU baselines, the e2e and the delay-stage extras (profiling runs)')
     ap.add_argument('--chan-tile', type=int, default=0, help='A/B hook: force the channel tile of the recurrence kernels (0 = planned)')
     args = ap.parse_args()
 
@@ -125,16 +203,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
         args.gpus = world
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')      # single node: RCCL bootstraps over loopback
-        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')          # single node: RCCL bootstraps over loopback
+    rdzv = rendezvous.Rendezvous(rank, world)                  # sockets only: before any GPU call
 
     if args.workload == 'cfg5':
         cfg = W.config5(n_acc=1)
@@ -149,7 +219,8 @@ def main():
     zen = NP.array([0.0, 0.0, 1.0])
 
     # PRISIM_BENCH_DEVICE: rehearsal hook (several ranks on one GPU to exercise the multi-process flow on a 1-GPU box)
-    ctx = _abi.Context(int(os.environ.get('PRISIM_BENCH_DEVICE', local_rank)))
+    device = int(os.environ.get('PRISIM_BENCH_DEVICE', local_rank))
+    ctx = _abi.Context(device)
     ctx.set_array(bl_mine, ch, nt_max=K)
     if args.chan_tile:
         ctx.set_tuning(args.chan_tile, 0, 0)
@@ -158,74 +229,61 @@ def main():
     ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY,
                          cfg['diameter'], zen, zen, fwhm_deg=(sky['fwhm_deg'] if cfg['taper'] else None))
     c64 = (prec == _abi.PRISIM_FP32)
-    rccl_ok = True
     if world > 1:
-        # RCCL communicator: rank 0 creates the 128-byte id, gloo carries it to the other ranks
-        try:
-            uid = [_abi.Context.comm_unique_id() if rank == 0 else None]
-        except Exception as exc:                      # keep the ranks in step even if librccl cannot be loaded
-            uid = [None]
-            sys.stderr.write('rank %d: RCCL unique id failed: %r\n' % (rank, exc))
-        dist.broadcast_object_list(uid, src=0)
-        ok = 0
-        if uid[0] is not None:
+        # RCCL communicator: rank 0 creates the 128-byte id, the rendezvous carries it to the other ranks.  Any failure is fatal.
+        err = None
+        uid = b''
+        if rank == 0:
             try:
-                ctx.comm_init(uid[0], world, rank)
-                ok = 1
+                uid = _abi.Context.comm_unique_id()
             except Exception as exc:
-                sys.stderr.write('rank %d: RCCL comm_init failed: %r\n' % (rank, exc))
-        import torch
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        rccl_ok = bool(flag.item())
-
-    def host_gather(nt):
-        """Fallback when RCCL cannot be initialised: device -> host, gloo all_gather, kept only so that the bench still
-        reports a (slow) whole-job number instead of crashing; flagged in the JSON line."""
-        import torch
-        shard = NP.stack([ctx.get_vis(slot=t, complex64=c64) for t in range(nt)])
-        tsr = torch.from_numpy(NP.ascontiguousarray(shard.view(NP.float32 if c64 else NP.float64)))
-        parts = [torch.empty_like(tsr) for _ in range(world)]
-        dist.all_gather(parts, tsr)
-        return parts
+                err = 'RCCL unique id failed: %r' % (exc,)
+        uid = rdzv.broadcast_bytes(uid)
+        if len(uid) == 128:
+            try:
+                ctx.comm_init(uid, world, rank)
+            except Exception as exc:
+                err = 'RCCL comm_init failed: %r' % (exc,)
+        elif err is None:
+            err = 'no RCCL unique id received'
+        errs = [e for e in rdzv.allgather(err) if e]
+        if errs:
+            sys.stderr.write('rank %d: %s\n' % (rank, '; '.join(errs)))
+            rdzv.close()
+            sys.exit(3)        # no host-side gather fallback: a value printed without RCCL would not be the metric
 
     for i in range(Wm):
         ctx.compute(precision=prec, slot=i % K)
-        if world > 1 and rccl_ok:
+        if world > 1:
             ctx.allgather_slot_async(i % K, complex64=c64)
     ctx.sync()
     ctx.timing(reset=True)
 
-    barrier()
+    rdzv.barrier()
     ctx.sync()
     t0 = time.perf_counter()
     for t in range(K):
         ctx.compute(precision=prec, slot=t)
-        if world > 1 and rccl_ok:
+        if world > 1:
             # RCCL all-gather of snapshot t on the communication stream, overlapped with the sky-sum of snapshot t+1;
             # only the last snapshot's exchange is exposed.  Still inside the timed region.
             ctx.allgather_slot_async(t, complex64=c64)
     ctx.sync()
-    if world > 1 and not rccl_ok:
-        host_gather(K)
-    barrier()
+    rdzv.barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = rdzv.allreduce_max(t1 - t0)
 
     tm = ctx.timing()
     gather_ok = None
-    if world > 1 and rccl_ok:
-        # every rank must hold the same gathered cube: compare device checksums
+    if world > 1:
+        # every rank must hold the same gathered cube (device checksums agree) AND rank r's block of it must be rank r's own
+        # shard, element for element (a plain checksum would not see swapped rank blocks)
         cs = ctx.gathered_checksum(K, complex64=c64)
-        import torch
-        allcs = [None] * world
-        dist.all_gather_object(allcs, cs)
+        allcs = rdzv.allgather(cs)
         gather_ok = bool(all(abs(c - allcs[0]) <= 1e-9 * max(1.0, abs(allcs[0])) for c in allcs))
+        g = ctx.get_gathered(1, world)[0]                                  # snapshot 0: [rank][b][f]
+        mine = ctx.get_vis(slot=0, complex64=c64)
+        gather_ok = gather_ok and bool(all(rdzv.allgather(bool(NP.array_equal(g[rank], mine)))))
 
     if rank == 0:
         terms_total = float(nbl_total) * nchan * nsrc * K
@@ -257,30 +315,57 @@ def main():
             'roofline_hbm': {'bound': 'hbm', 'achieved': ach_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': ach_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                              'algorithmic_bytes_per_launch': alg_bytes},
+            'csrc_hash': csrc_hash(),
         }
         if world > 1:
-            out['gather'] = 'rccl-allgather (per snapshot, overlapped)' if rccl_ok else 'host-gloo-fallback (RCCL init failed)'
-        if gather_ok is not None:
+            out['gather'] = 'rccl-allgather (per snapshot, overlapped)'
             out['gather_ok'] = gather_ok
         if world == 1 and not args.no_cpu_baseline:
+            pb_host = None
             try:
-                def pb_sample():
-                    return ctx.get_pbflux()
-                cb, bls, ref, stride = cpu_baseline(cfg, pb_sample)
+                pb_host = ctx.get_pbflux()
+                cb, bls, ref, stride = cpu_baseline(cfg, lambda: pb_host)
                 out['cpu_baseline'] = cb
                 # parity spot-check of the timed GPU result against the checker on the same sample
                 vis = ctx.get_vis(slot=K - 1)
                 gpu = vis[::stride][:bls.shape[0]]
-                scale = NP.sum(NP.abs(pb_sample()), axis=0)[None, :]
+                scale = NP.sum(NP.abs(pb_host), axis=0)[None, :]
                 out['parity_max_err_rel_sumflux'] = float(NP.max(NP.abs(gpu - ref) / scale))
             except Exception as exc:   # the baseline is a report, never a reason to lose the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'terms/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
+            try:
+                cbr, sel, ref2 = cpu_baseline_reference_formulation(cfg, pb_host)
+                cbr['parity_of_gpu_vs_this_max_err_rel_sumflux'] = float(NP.max(NP.abs(ctx.get_vis(slot=K - 1)[sel] - ref2)
+                                                                                / NP.sum(NP.abs(pb_host), axis=0)[None, :]))
+                out['cpu_baseline_ref'] = cbr
+            except Exception as exc:
+                out['cpu_baseline_ref'] = {'value': None, 'unit': 'terms/s', 'cores': 1, 'kind': 'reference-formulation', 'sample': 'failed: %r' % (exc,)}
+            try:
+                # delay power spectra of the K resident snapshots, one window for all baselines, pad = 1 (run_prisim.py:954, 2284)
+                win = NP.blackman(nchan) + 0.01
+                for rep in range(2):
+                    ctx.delay_transform_device(K, bpwts=win, pad=1.0, want_lag=False, want_power=True, power_scale=1.0)
+                    ctx.sync()
+                tmd = ctx.timing()
+                nrow = K * bl_mine.shape[0]
+                dbytes = float(nrow) * nchan * (16 + 8)            # each visibility read once, each power sample written once
+                gbs = dbytes / (tmd['last_delay_ms'] * 1e-3) / 1e9
+                out['delay_ps'] = {'device_ms': tmd['last_delay_ms'], 'ffts': nrow, 'fft_length_kept': nchan, 'pad': 1.0,
+                                   'fused_lds_kernel': bool(tmd['last_delay_fused']),
+                                   'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                                                'algorithmic_bytes': dbytes}}
+            except Exception as exc:
+                out['delay_ps'] = {'device_ms': None, 'error': repr(exc)}
+            ctx.close()
+            try:
+                out['e2e'] = e2e_observe(cfg, 3, device, memsave=(prec == _abi.PRISIM_FP32))
+            except Exception as exc:
+                out['e2e'] = {'value': None, 'error': repr(exc)}
         json_out.write(json.dumps(out) + '\n')
         json_out.flush()
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rdzv.barrier()
+    rdzv.close()
 
 
 if __name__ == '__main__':

@@ -61,9 +61,14 @@ bool load_sym(void* h, const char* name, F& out) {
 
 bool load_rccl(std::string& err) {
   if (g_rccl.handle) return true;
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  // The ROCm RCCL this library was compiled against (<rccl/rccl.h> of /opt/rocm) first, by absolute path: a bare soname would
+  // resolve to whatever librccl the process already carries (a python process that imported torch carries torch's bundled one).
+  void* h = nullptr;
+  if (const char* env = getenv("PRISIM_RCCL_LIB")) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
   if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!h) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
   bool ok = load_sym(h, "ncclGetUniqueId", g_rccl.GetUniqueId) && load_sym(h, "ncclCommInitRank", g_rccl.CommInitRank) &&
             load_sym(h, "ncclAllGather", g_rccl.AllGather) && load_sym(h, "ncclCommDestroy", g_rccl.CommDestroy) &&

@@ -391,7 +391,13 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
     struct Pre { double d, kap; TabPhase pc, ps; };
     auto front = [&](Pre& q) {
       q.d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));   // seconds
-      q.kap = sv[3];
+      if constexpr (TAPER) {
+        double kap = sv[3];
+        asm volatile("" : "+v"(kap));            // carried in a VGPR: two more live SGPR pairs tipped the taper bodies into lane spills
+        q.kap = kap;
+      } else {
+        q.kap = 0.0;
+      }
       if constexpr (sizeof(T) == 8) {
         q.pc = sincos_tab_front(q.d * fcN, tab);                                // phase at the centre channel
         q.ps = sincos_tab_front(q.d * (LIFT ? dfN_half : dfN), tab);            // step (LIFT: its half angle)

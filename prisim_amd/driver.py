@@ -12,7 +12,8 @@ Replaced: `mpirun` ranks + per-rank part files + rank-0 concatenate become one p
 (RANK / WORLD_SIZE / LOCAL_RANK from the launcher) and a single RCCL all-gather of the visibility cube;
 the rank-0 ROI/beam precompute through FITS files disappears (beams are fused on the device).
 Not offered (out of scope): survey catalogs (SUMSS/NVSS/GLEAM/GSM need prisim/data, absent),
-gains, noise, uvfits/uvh5/HDF5 writers, `pp.key: 'freq' | 'src'`, plots, resource monitor.  Two synthetic sky models
+gains, uvfits/uvh5 writers, `pp.key: 'freq' | 'src'`, plots, resource monitor.  PRISim's HDF5 layout is written for
+single-process runs (save_formats.hdf5); a sharded run writes the gathered npz.  Two synthetic sky models
 are added because the reference's catalogs are not available offline: skyparm.model 'ptsrc_random' and 'healpix_synthetic'.
 Time: without astropy the LST ramp is lst_init + t * 15.0410686 deg/h (mean sidereal rate), jd from jd_init or obs_date.
 """
@@ -169,10 +170,12 @@ def build_skymodel(parms, infile_dir):
         ra, dec, fint, spindex = cat['RA'], cat['DEC'], cat['F_INT'], cat['SPINDEX']
         majax, minax = cat['MAJAX'], cat['MINAX']
         ref = sp['custom_reffreq'] * 1e9                                                         # :1655
-        lo = sp['flux_min'] * (ref / fluxcut_freq) ** sp['spindex']                              # :1658-1661
-        sel = fint >= lo
+        # the thresholds are given at fluxcut_freq and moved to the catalog frequency with EACH SOURCE's own catalog spectral
+        # index: `spindex = catdata['SPINDEX'].data` is assigned (:1649) before the cut (:1657-1660)
+        scale = (ref / fluxcut_freq) ** spindex
+        sel = fint >= sp['flux_min'] * scale
         if sp['flux_max'] is not None:
-            sel &= fint <= sp['flux_max'] * (ref / fluxcut_freq) ** sp['spindex']
+            sel &= fint <= sp['flux_max'] * scale
         if NP.sum(sel) == 0:
             raise IndexError('No sources in the catalog found satisfying flux threshold criteria')
         return SM.SkyModel(location=NP.stack((ra[sel], dec[sel]), axis=1), flux_ref=fint[sel], spindex=spindex[sel], ref_freq=ref,
@@ -196,17 +199,31 @@ def build_skymodel(parms, infile_dir):
 
 def load_external_beam(parms, infile_dir):
     """External beam file -> (beam [npix, nfreq], freqs_hz).  The reference reads FITS / HDF5 / UVBeam files
-    (run_prisim.py:489-520; astropy / h5py / pyuvdata, none of which exist offline); the layout kept here is the HDF5
-    one (gain_info/<pol> = nfreq x npix, spectral_info/freqs in Hz, FEKO_beam_to_healpix.py:161-198) stored as .npz:
-    keys 'beam' (npix, nfreq) or 'gain_info' (nfreq, npix), and 'freqs' (Hz)."""
+    (run_prisim.py:489-520).  Read here: the HDF5 layout its own converter writes (scripts/FEKO_beam_to_healpix.py:161-198:
+    gain_info/<pol> = nfreq x npix, spectral_info/freqs in Hz; beam.pol picks the dataset, default the first one) through the
+    HDF5 C library, and the same content as .npz: keys 'beam' (npix, nfreq) or 'gain_info' (nfreq, npix), and 'freqs' (Hz).
+    FITS and UVBeam need astropy / pyuvdata: not offered."""
     bm = parms['beam']
-    if str(bm.get('filefmt', 'npz')).lower() != 'npz':
-        raise NotImplementedError('beam.filefmt {0!r}: only the npz container can be read without astropy/h5py/pyuvdata'.format(bm.get('filefmt')))
+    fmt = str(bm.get('filefmt', 'npz')).lower()
+    if fmt not in ('hdf5', 'h5', 'npz'):
+        raise NotImplementedError('beam.filefmt {0!r}: HDF5 (gain_info/<pol>) and npz can be read; FITS / UVBeam need astropy / pyuvdata'.format(bm.get('filefmt')))
     path = bm['file']
     if path is None:
         raise ValueError('beam.file must be given when beam.use_external is true')
     if not os.path.isabs(path):
         path = os.path.join(infile_dir, path)
+    if fmt in ('hdf5', 'h5'):
+        from . import hdf5io
+        with hdf5io.File(path, 'r') as f:
+            pols = f.list('gain_info')
+            if not pols:
+                raise KeyError('gain_info group of the external beam file holds no polarisation dataset')
+            pol = bm.get('pol') or pols[0]
+            if pol not in pols:
+                raise KeyError('polarisation {0!r} not in the external beam file (has {1})'.format(pol, pols))
+            beam = NP.asarray(f.read('gain_info/' + pol), dtype=NP.float64).T          # file: nfreq x npix (run_prisim.py:492-494)
+            freqs = NP.asarray(f.read('spectral_info/freqs'), dtype=NP.float64)
+        return NP.ascontiguousarray(beam), freqs
     with NP.load(path) as f:
         beam = f['beam'] if 'beam' in f.files else f['gain_info'].T
         freqs = f['freqs']
@@ -322,7 +339,7 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         cube, labels_all, bl_all = ia.skyvis_freq[:nbl_total], labels, bl
     out = {'skyvis_freq': cube, 'bl': bl_all, 'labels': labels_all, 'freq': chans, 'lst': NP.asarray(ia.lst),
            'timestamp': NP.asarray(ia.timestamp), 'bl_length': NP.sqrt(NP.sum(bl_all ** 2, axis=1)), 't_sim': t_sim,
-           'antpos': antpos, 'ia': ia, 'blgroups': blgroups}
+           'antpos': antpos, 'ia': ia, 'blgroups': blgroups, 'world': world}
     if proc.get('delay_transform'):
         # every rank transforms its own shard on its GPU (the FFT runs along frequency); sharded runs then exchange the spectra
         ia.delay_transform(pad=float(proc.get('f_pad', 1.0)), freq_wts=window(chans.size, proc.get('bpass_shape', 'bhw')), verbose=False)
@@ -332,6 +349,9 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
 
 
 def save(out, parms, infile=None):
+    if parms['save_formats'].get('hdf5', False) and out.get('world', 1) > 1:
+        # before anything is written: every rank of a baseline-sharded run holds its own InterferometerArray shard
+        raise NotImplementedError('HDF5 output of a baseline-sharded run is not supported; use the gathered npz')
     ds = parms['dirstruct']
     simid = ds['simid'] or time.strftime('%Y-%m-%d-%H-%M-%S')
     outdir = os.path.join(ds['rootdir'], ds['project'], simid, 'simdata')
@@ -357,8 +377,6 @@ def save(out, parms, infile=None):
         # PRISim's HDF5 layout (interferometry.py:8717-8846) of this process's InterferometerArray, redundant baselines re-created
         # first when asked for (run_prisim.py:2325-2326).  Single-process runs only: a sharded run gathers the cube, not the object.
         ia = out['ia']
-        if len(ia.labels) != len(out['labels']) and not parms.get('save_redundant', True):
-            raise NotImplementedError('HDF5 output of a baseline-sharded run is not supported; use the gathered npz')
         if parms.get('save_redundant', True) and ia.blgroups and len(ia.labels) < sum(len(v) for v in ia.blgroups.values()):
             ia.duplicate_measurements()
         ia.save(path, fmt='HDF5', npz=False, overwrite=True, verbose=False)
@@ -379,20 +397,16 @@ def main(argv=None):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     uid = None
-    dist = None
+    from . import rendezvous
+    rdzv = rendezvous.Rendezvous(rank, world)      # loopback sockets; no torch, nothing touches the GPU before this returns
     if world > 1:
-        import torch.distributed as dist          # rendezvous only (gloo); all GPU work goes through libprisim_hip.so
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-        box = [_abi.Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
+        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+        uid = rdzv.broadcast_bytes(_abi.Context.comm_unique_id() if rank == 0 else b'')
     out = run(parms, infile_dir=os.path.dirname(os.path.abspath(args.infile)), rank=rank, world=world, device=local_rank, comm_uid=uid)
     if rank == 0:
         path = save(out, parms, args.infile)
         print('simulated {0} baselines x {1} channels x {2} snapshots in {3:.3f} s -> {4}'.format(
             out['skyvis_freq'].shape[0], out['skyvis_freq'].shape[1], out['skyvis_freq'].shape[2], out['t_sim'], path))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rdzv.barrier()
+    rdzv.close()
     return 0

@@ -82,6 +82,8 @@ def _declare(lib):
         'H5Tget_nmembers': (i, [hid_t]), 'H5Tget_member_name': (p, [hid_t, C.c_uint]), 'H5Tget_member_type': (hid_t, [hid_t, C.c_uint]),
         'H5Tget_member_offset': (sz, [hid_t, C.c_uint]), 'H5Tget_sign': (i, [hid_t]), 'H5free_memory': (i, [p]),
         'H5Lexists': (i, [hid_t, cs, hid_t]), 'H5Eset_auto2': (i, [hid_t, p, p]),
+        'H5Gopen2': (hid_t, [hid_t, cs, hid_t]), 'H5Gget_info': (i, [hid_t, p]),
+        'H5Lget_name_by_idx': (C.c_ssize_t, [hid_t, cs, i, i, hsize_t, p, sz, hid_t]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -313,3 +315,25 @@ class File(object):
 
     def exists(self, path):
         return self._lib.H5Lexists(self._fid, path.encode(), H5P_DEFAULT) > 0
+
+    def list(self, group):
+        """Names of the links of a group, in name order (h5py: list(f[group]))."""
+        lib = self._lib
+        gid = lib.H5Gopen2(self._fid, group.encode(), H5P_DEFAULT)
+        if gid < 0:
+            raise KeyError(group)
+
+        class _GInfo(C.Structure):                 # H5G_info_t
+            _fields_ = [('storage_type', C.c_int), ('nlinks', hsize_t), ('max_corder', C.c_int64), ('mounted', C.c_int)]
+        try:
+            info = _GInfo()
+            _check(lib.H5Gget_info(gid, C.byref(info)), 'H5Gget_info ' + group)
+            names = []
+            for k in range(int(info.nlinks)):
+                n = lib.H5Lget_name_by_idx(gid, b'.', 0, 0, k, None, 0, H5P_DEFAULT)         # H5_INDEX_NAME, H5_ITER_INC
+                buf = C.create_string_buffer(int(n) + 1)
+                lib.H5Lget_name_by_idx(gid, b'.', 0, 0, k, buf, int(n) + 1, H5P_DEFAULT)
+                names.append(buf.value.decode('utf-8'))
+            return names
+        finally:
+            lib.H5Gclose(gid)

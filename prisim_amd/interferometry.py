@@ -44,6 +44,34 @@ class _DeviceSlot(object):
         self.slot, self.dtype = slot, NP.dtype(dtype)
 
 
+class _LayerStack(object):
+    """The per-snapshot layers of a (nbl, nchan, n_acc) attribute (bp, bp_wts, Tsys) in the broadcastable form they were given in
+    -- (1 | nbl, 1 | nchan) -- instead of the dense arrays the reference grows by NP.dstack at every observe()
+    (interferometry.py:6019-6024, 6082-6086: 0.5 GB per snapshot and attribute at HERA-350 x 1024 channels, O(n_acc^2) copies).
+    The dense array with the reference's shape is formed when the attribute is read."""
+
+    def __init__(self, nbl, nchan, initial):
+        self.nbl, self.nchan = nbl, nchan
+        self.initial = NP.asarray(initial, dtype=NP.float64)         # value before the first snapshot, broadcastable to (nbl, nchan)
+        self.layers = []
+
+    def append(self, layer):
+        layer = NP.asarray(layer, dtype=NP.float64)
+        if layer.ndim == 3:
+            layer = layer[:, :, 0]
+        self.layers.append(layer.reshape((layer.shape[0] if layer.ndim == 2 else 1), -1) if layer.ndim else layer.reshape(1, 1))
+
+    def dense(self):
+        if not self.layers:
+            return NP.array(NP.broadcast_to(self.initial, (self.nbl, self.nchan)))
+        return NP.stack([NP.broadcast_to(l, (self.nbl, self.nchan)) for l in self.layers], axis=2)
+
+    def ones_like(self):
+        out = _LayerStack(self.nbl, self.nchan, NP.ones((1, 1)))
+        out.layers = [NP.ones((1, 1)) for _ in self.layers]
+        return out
+
+
 class LazyGeometricDelays(object):
     """Stand-in for one entry of ``InterferometerArray.geometric_delays`` (the reference stores the full
     nsrc x nbl matrix per snapshot, interferometry.py:6287-6291 -- 4.9 GB at HERA-350 x 1e4 sources).
@@ -165,10 +193,10 @@ class InterferometerArray(object):
             raise ValueError('Frequency units must be "GHz", "MHz", "kHz" or "Hz". If not set, it defaults to "Hz"')
 
         nbl, nchan = self.baselines.shape[0], self.channels.size
-        self.bp = NP.ones((nbl, nchan))                                               # :5790-5791
-        self.bp_wts = NP.ones((nbl, nchan))
+        self._stacks = {'bp': _LayerStack(nbl, nchan, NP.ones((1, 1))), 'bp_wts': _LayerStack(nbl, nchan, NP.ones((1, 1))),
+                        'Tsys': _LayerStack(nbl, nchan, NP.zeros((1, 1)))}                # :5790-5793, read through the properties below
+        self._dense = {}
         self.lag_kernel = None
-        self.Tsys = NP.zeros((nbl, nchan))
         self.Tsysinfo = []
         self.flux_unit = 'JY'
         self.timestamp = []
@@ -416,13 +444,13 @@ class InterferometerArray(object):
         if bandpass.ndim == 1:
             if bandpass.size != nchan:
                 raise ValueError('Specified bandpass incompatible with the number of frequency channels')
-            layer = NP.repeat(bandpass.reshape(1, -1), nbl, axis=0)[:, :, NP.newaxis]
+            layer = bandpass.reshape(1, -1)                                # one row for every baseline (dense on read)
         elif bandpass.ndim == 2:
             if bandpass.shape[1] != nchan:
                 raise ValueError('Specified bandpass incompatible with the number of frequency channels')
             elif bandpass.shape[0] != nbl:
                 raise ValueError('Specified bandpass incompatible with the number of interferometers')
-            layer = bandpass[:, :, NP.newaxis]
+            layer = bandpass
         elif bandpass.ndim == 3:
             if bandpass.shape[1] != nchan:
                 raise ValueError('Specified bandpass incompatible with the number of frequency channels')
@@ -433,8 +461,12 @@ class InterferometerArray(object):
             layer = bandpass
         else:
             raise ValueError('Specified bandpass has too many dimensions')
-        self.bp = layer if self.bp.ndim == 2 else NP.dstack((self.bp, layer))
-        self.bp_wts = NP.ones_like(self.bp)
+        self._append_layer('bp', layer)                                      # :6019-6022
+        if self._stacks.get('bp') is not None:
+            self._stacks['bp_wts'] = self._stacks['bp'].ones_like()          # :6024
+            self._dense.pop('bp_wts', None)
+        else:
+            self.bp_wts = NP.ones_like(self.bp)
 
     def _stack_tsys(self, Tsysinfo, bpcorrect):
         """interferometry.py:6026-6086."""
@@ -449,7 +481,7 @@ class InterferometerArray(object):
                 Tsys = Tsysinfo['Trx'] + Tsysinfo['Tant']['T0'] * (self.channels / Tsysinfo['Tant']['f0']) ** Tsysinfo['Tant']['spindex']
             except KeyError:
                 raise KeyError('One or more keys not found in input Tsysinfo')
-            Tsys = Tsys.reshape(1, -1) + NP.zeros(nbl).reshape(-1, 1)
+            Tsys = Tsys.reshape(1, -1)                                     # one row for every baseline (:6046; dense on read)
         self.Tsysinfo += [Tsysinfo]
         if bpcorrect is not None:
             if not isinstance(bpcorrect, NP.ndarray):
@@ -466,24 +498,26 @@ class InterferometerArray(object):
         if isinstance(Tsys, (int, float)):
             if Tsys < 0.0:
                 raise ValueError('Tsys found to be negative.')
-            layer = Tsys + NP.zeros((nbl, nchan, 1))
+            layer = NP.full((1, 1), float(Tsys))
         elif isinstance(Tsys, (list, tuple, NP.ndarray)):
             Tsys = NP.asarray(Tsys)
             if NP.any(Tsys < 0.0):
                 raise ValueError('Tsys should be non-negative.')
             if Tsys.size == 1:
-                layer = float(Tsys.ravel()[0]) + NP.zeros((nbl, nchan, 1))
-            elif Tsys.size == nbl:
-                layer = NP.repeat(Tsys.reshape(-1, 1), nchan, axis=1)[:, :, NP.newaxis]
+                layer = NP.full((1, 1), float(Tsys.ravel()[0]))
+            elif Tsys.shape == (1, nchan) or (Tsys.size == nchan and Tsys.size != nbl):
+                layer = Tsys.reshape(1, -1)
+            elif Tsys.size == nbl:                                        # (as in the reference, nbl wins when nbl == nchan)
+                layer = Tsys.reshape(-1, 1)
             elif Tsys.size == nchan:
-                layer = NP.repeat(Tsys.reshape(1, -1), nbl, axis=0)[:, :, NP.newaxis]
+                layer = Tsys.reshape(1, -1)
             elif Tsys.size == nbl * nchan:
-                layer = Tsys.reshape(-1, nchan)[:, :, NP.newaxis]
+                layer = Tsys.reshape(-1, nchan)
             else:
                 raise ValueError('Specified Tsys has incompatible dimensions with the number of baselines and/or number of frequency channels.')
         else:
             raise TypeError('Tsys should be a scalar, list, tuple, or numpy array')
-        self.Tsys = layer if self.Tsys.ndim == 2 else NP.dstack((self.Tsys, layer))
+        self._append_layer('Tsys', layer)                                    # :6082-6086
 
     # ------------------------------------------------------------------------------------------
     def observe(self, timeobj, Tsysinfo, bandpass, pointing_center, skymodel,
@@ -655,6 +689,42 @@ class InterferometerArray(object):
             value = NP.asarray(value)
             self._cube = [value[:, :, i] for i in range(value.shape[2])]
             self._skyvis_cache = value
+
+    # bp, bp_wts, Tsys: (nbl, nchan) before the first snapshot, (nbl, nchan, n_acc) afterwards, like the reference's; kept as
+    # per-snapshot layers (_LayerStack) and materialised on read.  Assigning an array replaces the layers.
+    def _get_stacked(self, name):
+        if name not in getattr(self, '_dense', {}):
+            self.__dict__.setdefault('_dense', {})[name] = self._stacks[name].dense()
+        return self._dense[name]
+
+    def _set_stacked(self, name, value):
+        self.__dict__.setdefault('_dense', {})[name] = NP.asarray(value)
+        self.__dict__.setdefault('_stacks', {})[name] = None
+
+    bp = property(lambda self: self._get_stacked('bp'), lambda self, v: self._set_stacked('bp', v))
+    bp_wts = property(lambda self: self._get_stacked('bp_wts'), lambda self, v: self._set_stacked('bp_wts', v))
+    Tsys = property(lambda self: self._get_stacked('Tsys'), lambda self, v: self._set_stacked('Tsys', v))
+
+    def _append_layer(self, name, layer):
+        """One more snapshot layer ((nbl | 1, nchan | 1), or (nbl, nchan, 1)) of a stacked attribute."""
+        st = self._stacks.get(name)
+        if st is not None:
+            st.append(layer)
+            self._dense.pop(name, None)
+            return
+        cur = self._dense[name]                                          # the attribute was assigned a dense array: grow that
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        layer = NP.asarray(layer)
+        layer = NP.array(NP.broadcast_to(layer if layer.ndim == 3 else layer.reshape(layer.shape[0] if layer.ndim == 2 else 1, -1)[:, :, NP.newaxis],
+                                         (nbl, nchan, 1)))
+        self._dense[name] = layer if cur.ndim == 2 else NP.dstack((cur, layer))
+
+    def _window_layers(self):
+        """bp * bp_wts per snapshot in compact form: a list of (1 | nbl, nchan) arrays, or None when only dense arrays exist."""
+        a, b = self._stacks.get('bp'), self._stacks.get('bp_wts')
+        if a is None or b is None or len(a.layers) != len(b.layers) or not a.layers:
+            return None
+        return [x * y for x, y in zip(a.layers, b.layers)]
 
     # skyvis_lag / lag_kernel: computed on the GPU by delay_transform(); when the visibility cube is resident on the device the
     # spectra stay there too and are fetched on first read (config 5: 120 GB that a sharded run exchanges GPU -> GPU instead)
@@ -1161,41 +1231,58 @@ class InterferometerArray(object):
         nbl, nchan = self.baselines.shape[0], self.channels.size
         if freq_wts is not None:                                                       # :8096-8107
             freq_wts = NP.asarray(freq_wts)
-            if freq_wts.size == nchan:
-                freq_wts = NP.repeat(NP.expand_dims(NP.repeat(freq_wts.reshape(1, -1), nbl, axis=0), axis=2), self.n_acc, axis=2)
-            elif freq_wts.size == nchan * self.n_acc:
-                freq_wts = NP.repeat(NP.expand_dims(freq_wts.reshape(nchan, -1), axis=0), nbl, axis=0)
-            elif freq_wts.size == nchan * nbl:
-                freq_wts = NP.repeat(NP.expand_dims(freq_wts.reshape(-1, nchan), axis=2), self.n_acc, axis=2)
-            elif freq_wts.size == nchan * nbl * self.n_acc:
-                freq_wts = freq_wts.reshape(nbl, nchan, self.n_acc)
+            if freq_wts.size == nchan and self._stacks.get('bp') is not None and len(self._stacks['bp'].layers) == self.n_acc:
+                # one window for every baseline and snapshot: kept as n_acc (1, nchan) layers (dense (nbl, nchan, n_acc) on read)
+                st = _LayerStack(nbl, nchan, NP.ones((1, 1)))
+                st.layers = [NP.asarray(freq_wts, dtype=NP.float64).reshape(1, -1)] * self.n_acc
+                self._stacks['bp_wts'] = st
+                self._dense.pop('bp_wts', None)
             else:
-                raise ValueError('window shape dimensions incompatible with number of channels and/or number of tiemstamps.')
-            self.bp_wts = freq_wts
+                if freq_wts.size == nchan:
+                    freq_wts = NP.repeat(NP.expand_dims(NP.repeat(freq_wts.reshape(1, -1), nbl, axis=0), axis=2), self.n_acc, axis=2)
+                elif freq_wts.size == nchan * self.n_acc:
+                    freq_wts = NP.repeat(NP.expand_dims(freq_wts.reshape(nchan, -1), axis=0), nbl, axis=0)
+                elif freq_wts.size == nchan * nbl:
+                    freq_wts = NP.repeat(NP.expand_dims(freq_wts.reshape(-1, nchan), axis=2), self.n_acc, axis=2)
+                elif freq_wts.size == nchan * nbl * self.n_acc:
+                    freq_wts = freq_wts.reshape(nbl, nchan, self.n_acc)
+                else:
+                    raise ValueError('window shape dimensions incompatible with number of channels and/or number of tiemstamps.')
+                self.bp_wts = freq_wts
         if not self._cube and self._skyvis_override is None:
             raise ValueError('no visibilities to transform: call observe() first')
+
+        # bp * bp_wts (:8116): compact per-snapshot layers when the attributes still are layer stacks, else the dense product
+        wlayers = self._window_layers()
+        if wlayers is not None:
+            same_wts = all(l.shape == wlayers[0].shape and NP.array_equal(l, wlayers[0]) for l in wlayers[1:])
+            def window(t):
+                return NP.broadcast_to(wlayers[t if t < len(wlayers) else 0], (nbl, nchan))
+            w_first = wlayers[0][0] if wlayers[0].shape[0] == 1 else wlayers[0]      # (nchan,): one window for every baseline
+        else:
+            wall = (self.bp * self.bp_wts).reshape(nbl, nchan, -1)
+            same_wts = wall.shape[2] == 1 or bool(NP.all(wall == wall[:, :, [0]]))
+            def window(t):
+                return wall[:, :, t if t < wall.shape[2] else 0]
+            w_first = wall[:, :, 0]
 
         def transform(cube):
             # cube (nbl, nchan, nt) times bp*bp_wts, one snapshot at a time through the device cube slot 0
             nt = cube.shape[2]
-            w3 = (self.bp * self.bp_wts).reshape(nbl, nchan, -1)
-            wts = w3 if w3.shape[2] == nt else NP.broadcast_to(w3[:, :, :1], (nbl, nchan, nt))   # per-snapshot weights, or one set for all
             outs = []
             for t in range(nt):
-                out, lags, _ = self._ctx.delay_transform_host(cube[:, :, t], wts[:, :, t], pad)
+                out, lags, _ = self._ctx.delay_transform_host(cube[:, :, t], window(t if not same_wts else 0), pad)
                 outs.append(out)
             return NP.stack(outs, axis=2), lags
 
         # number of snapshots without forcing device-resident ones onto the host (_DeviceSlot placeholders)
         nt_all = len(self._cube) if self._cube else self._skyvis_override.shape[2]
-        wall = (self.bp * self.bp_wts).reshape(nbl, nchan, -1)
-        same_wts = wall.shape[2] == 1 or bool(NP.all(wall == wall[:, :, [0]]))
         resident = self._reserved >= self.n_acc and bool(self._cube)     # device slots hold the snapshots: slot 0 must survive
         self._skyvis_lag, self._lag_resident = None, None
         if resident and self._reserved >= nt_all and self.n_acc == nt_all and same_wts:
             # the cube is resident on the GPU (reserve()): all snapshots are transformed where they are and the spectra stay in HBM
             # until skyvis_lag is read (the device cube is complex128 for memsave runs too: nothing is rounded on the way)
-            self.lags, nout = self._ctx.delay_transform_device(nt_all, bpwts=wall[:, :, 0], pad=pad, want_lag=True)
+            self.lags, nout = self._ctx.delay_transform_device(nt_all, bpwts=w_first, pad=pad, want_lag=True)
             self._lag_resident = (nt_all, nout)
         else:
             host_cube = NP.asarray(self.skyvis_freq, dtype=NP.complex128)

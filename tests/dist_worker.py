@@ -1,53 +1,75 @@
-"""Worker for tests/test_distributed_cpu.py: one process per rank, gloo backend, no GPU.
+"""Worker for tests/test_distributed_cpu.py (and its GPU twin): one process per rank, launched by torch.distributed.run.
 
-Exercises the N>1 plumbing bench.py uses -- equal-size contiguous baseline shards, out-of-band broadcast
-of the 128-byte communicator id, gather of the shards, max-reduce of timings -- with the oracle standing in
-for the GPU kernel and a gloo all_gather standing in for the RCCL one (RCCL needs one GPU per rank)."""
+Runs the PRODUCT's multi-rank code -- prisim_amd.rendezvous for the out-of-band id exchange / barrier / max-reduce, and
+prisim_amd.driver.run(parms, rank=r, world=N) with its baseline sharding (padded last shard), InterferometerArray.observe into
+reserved slots, allgather(), per-shard delay_transform() and allgather_lags() -- and checks the gathered cube and the gathered
+delay spectra against a world-1 run of the same driver, element for element.  RCCL needs one GPU per rank, so the context is
+replaced at the `_abi.Context` seam by a stand-in from tests/fake_context.py whose exchange is a gloo all_gather:
+  dist_worker.py oracle   no GPU (CPU suite)
+  dist_worker.py gpu      real HIP context, both ranks on device 0, gloo exchange
+"""
 import os
 import sys
 
 import numpy as NP
-import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench                                      # noqa: E402
-from oracle import skyvis_oracle as O             # noqa: E402
-from prisim_amd import workloads as W             # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import bench                                                 # noqa: E402
+from prisim_amd import _abi, driver, rendezvous              # noqa: E402
+import fake_context                                          # noqa: E402
+
+
+def parms_for_test():
+    p = driver.deep_merge(driver.DEFAULTS, {
+        'array': {'layout': 'HERA-19', 'redundant': False},                       # 171 baselines: 86 per rank, the last shard is padded
+        'telescope': {'id': 'custom', 'latitude': -30.7224},
+        'antenna': {'shape': 'delta', 'size': 1.0},
+        'bandpass': {'freq': 150e6, 'freq_resolution': 1e6, 'nchan': 16},
+        'obsparm': {'n_acc': 3, 't_acc': 600.0, 'obs_mode': 'drift'},
+        'pointing': {'lst_init': 1.0, 'drift_init': {'ha': 0.0, 'dec': -30.7224}},
+        'skyparm': {'model': 'ptsrc_random', 'n_src': 40, 'seed': 7, 'custom_reffreq': 0.150, 'spindex': -0.8},
+        'processing': {'delay_transform': True, 'f_pad': 1.0, 'bpass_shape': 'bhw'},
+    })
+    return p
 
 
 def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else 'oracle'
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    # the product's own rendezvous (what bench.py and the driver's main() use): id broadcast, barrier, reductions
+    rdzv = rendezvous.Rendezvous(rank, world)
+    uid = rdzv.broadcast_bytes(bytes(range(128)) if rank == 0 else b'')
+    assert uid == bytes(range(128))
+    assert rdzv.allreduce_max(float(rank + 1)) == float(world) and rdzv.allreduce_min(float(rank + 1)) == 1.0
+    assert rdzv.allgather({'rank': rank}) == [{'rank': r} for r in range(world)]
+    rdzv.barrier()
+    # gloo carries the stand-in communicator's data (RCCL's place)
     dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-    cfg = W.subsample(W.config2(), bl_stride=3, ch_count=24, src_stride=9)     # 57 baselines: not divisible by 2
-    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
-    pb = sky['flux_ref'][:, None] * (ch[None, :] / sky['ref_freq']) ** sky['spindex'][:, None]
-    zen = NP.array([0.0, 0.0, 1.0])
+    _abi.Context = fake_context.OracleContext if mode == 'oracle' else fake_context.GlooCommContext
 
-    uid = [bytes(range(128)) if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    assert uid[0] == bytes(range(128))
-
-    mine, n_real = bench.shard_baselines(bl, world, rank)
-    per = mine.shape[0]
-    shard = O.skyvis(mine, ch, sky['dircos'], pb, zen, fwhm_deg=sky['fwhm_deg'])
-    t = torch.from_numpy(NP.ascontiguousarray(shard.view(NP.float64)))
-    parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t)
-    gathered = NP.stack([p.numpy().view(NP.complex128) for p in parts])           # [world][per][nchan]
-    full = O.skyvis(bl, ch, sky['dircos'], pb, zen, fwhm_deg=sky['fwhm_deg'])
-    flat = gathered.reshape(world * per, -1)[:bl.shape[0]]                         # drop the padding rows
-    err = NP.max(NP.abs(flat - full))
-    tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    assert tt.item() == float(world)
+    parms = parms_for_test()
+    out = driver.run(parms, rank=rank, world=world, device=0, comm_uid=uid, verbose=False)
+    per, lo, hi = bench.shard_range(171, world, rank)
+    assert out['ia'].baselines.shape[0] == per                                  # equal shards, the last one padded
+    assert out['skyvis_freq'].shape == (171, 16, 3) and out['skyvis_lag'].shape == (171, 16, 3)   # padding rows dropped
+    ref = driver.run(parms, rank=0, world=1, device=0, verbose=False)          # the same driver, unsharded, in this process
+    tol = 0.0 if mode == 'oracle' else 1e-11 * float(NP.max(NP.abs(ref['skyvis_freq'])))
+    err_v = float(NP.max(NP.abs(out['skyvis_freq'] - ref['skyvis_freq'])))
+    err_l = float(NP.max(NP.abs(out['skyvis_lag'] - ref['skyvis_lag'])))
+    lag_scale = float(NP.max(NP.abs(ref['skyvis_lag'])))
+    ok = err_v <= tol and err_l <= max(tol, 1e-12 * lag_scale) and out['labels'] == ref['labels'] and NP.array_equal(out['bl'], ref['bl'])
+    all_ok = all(rdzv.allgather(bool(ok)))
+    rdzv.barrier()
+    rdzv.close()
     dist.barrier()
-    if err > 1e-9:
-        print('RANK %d MISMATCH %g' % (rank, err))
-        sys.exit(1)
-    print('RANK %d OK per=%d n_real=%d err=%.2e' % (rank, per, n_real, err))
     dist.destroy_process_group()
+    if not all_ok:
+        print('RANK %d MISMATCH vis %g lag %g' % (rank, err_v, err_l))
+        sys.exit(1)
+    print('RANK %d OK per=%d err_vis=%.2e err_lag=%.2e' % (rank, per, err_v, err_l))
 
 
 if __name__ == '__main__':

@@ -1,0 +1,135 @@
+"""TEST INFRASTRUCTURE: stand-ins injected at the `_abi.Context` seam so that the PRODUCT's multi-rank code
+(prisim_amd.driver.run -> InterferometerArray.observe / allgather / delay_transform / allgather_lags) runs where RCCL cannot:
+
+  OracleContext     no GPU at all (CPU suite): compute() is the numpy oracle, the delay transform its numpy restatement, and the
+                    exchange a gloo all_gather of host arrays.
+  GlooCommContext   the real Context (HIP kernels, device cube, device-resident delay spectra) with only the communicator
+                    replaced by gloo -- two ranks can then share the one GPU of a test box, which RCCL refuses.
+
+Only tests/ imports this module."""
+import numpy as NP
+
+from oracle import skyvis_oracle as O, beams_oracle as BO, delay_oracle as DO
+from prisim_amd import _abi
+
+
+def _gloo_allgather(arr):
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(NP.ascontiguousarray(arr).view(NP.float64).copy())
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [p.numpy().view(NP.complex128).reshape(arr.shape) for p in parts]
+
+
+class OracleContext(object):
+    def __init__(self, device=0):
+        self.nbl = self.nchan = self.nt_max = self.nsrc = 0
+        self._timing = {'last_terms': 0, 'last_delay_ms': 0.0, 'last_delay_fused': 0, 'last_chan_tile': 0, 'last_nsplit': 1,
+                        'sum_kernel_ms': 0.0, 'n_kernel': 0, 'last_kernel_ms': 0.0, 'last_taper_group': 0}
+
+    def close(self):
+        pass
+
+    def set_array(self, baselines, freqs_hz, nt_max=1):
+        self.bl = NP.asarray(baselines, dtype=NP.float64).reshape(-1, 3)
+        self.ch = NP.asarray(freqs_hz, dtype=NP.float64).ravel()
+        self.nbl, self.nchan, self.nt_max = self.bl.shape[0], self.ch.size, int(nt_max)
+        self.cube = NP.zeros((self.nt_max, self.nbl, self.nchan), dtype=NP.complex128)
+
+    def set_sky_analytic(self, dircos, flux_ref, spindex, ref_freq_hz, beam_kind, diameter_m, beam_pc_dircos, pc_dircos, fwhm_deg=None,
+                         flux_spectrum=None, ext=None):
+        self.dircos = NP.asarray(dircos, dtype=NP.float64).reshape(-1, 3)
+        self.nsrc = self.dircos.shape[0]
+        flux = NP.asarray(flux_spectrum) if flux_spectrum is not None else \
+            NP.asarray(flux_ref)[:, None] * (self.ch[None, :] / ref_freq_hz) ** NP.asarray(spindex)[:, None]
+        if beam_kind == _abi.PRISIM_BEAM_DELTA:
+            pb = NP.ones_like(flux)
+        elif beam_kind == _abi.PRISIM_BEAM_AIRY:
+            pb = BO.airy_disk_pattern(diameter_m, _altaz(self.dircos), self.ch)
+        elif beam_kind == _abi.PRISIM_BEAM_GAUSSIAN:
+            pb = BO.gaussian_beam(diameter_m, _altaz(self.dircos), self.ch, power=True)
+        else:
+            raise NotImplementedError('OracleContext: beam kind %d' % beam_kind)
+        self.pb = pb * flux
+        self.pc = NP.asarray(pc_dircos, dtype=NP.float64).ravel()
+        self.fwhm = None if fwhm_deg is None else NP.asarray(fwhm_deg, dtype=NP.float64)
+
+    def compute(self, precision=0, kernel=0, want_grad=False, slot=0):
+        self.cube[slot] = O.skyvis(self.bl, self.ch, self.dircos, self.pb, self.pc, fwhm_deg=self.fwhm)
+        self._timing['last_terms'] = self.nbl * self.nchan * self.nsrc
+
+    def get_vis(self, slot=0, want_grad=False, complex64=False):
+        v = self.cube[slot].astype(NP.complex64 if complex64 else NP.complex128)
+        return v
+
+    def set_vis(self, vis, slot=0):
+        self.cube[slot] = vis
+
+    def sync(self):
+        pass
+
+    def timing(self, reset=False):
+        return dict(self._timing)
+
+    # ---- communicator: gloo stands in for RCCL ----
+    @staticmethod
+    def comm_unique_id():
+        return bytes(range(128))
+
+    def comm_init(self, uid, nranks, rank):
+        assert len(uid) == 128
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def allgather(self, nt, complex64=False):
+        parts = _gloo_allgather(self.cube[:nt])                               # [rank][t][b][f]
+        self._gathered = NP.stack(parts, axis=1)                              # [t][rank][b][f]
+
+    def get_gathered(self, nt, nranks=None, row=None):
+        return self._gathered[:nt]
+
+    # ---- delay transform ----
+    def delay_transform_device(self, nt, bpwts=None, pad=1.0, want_lag=True, want_power=False, power_scale=1.0):
+        w = NP.ones((self.nbl, self.nchan)) if bpwts is None else NP.broadcast_to(NP.asarray(bpwts, dtype=NP.float64).reshape(-1, self.nchan),
+                                                                                    (self.nbl, self.nchan))
+        vis = NP.transpose(self.cube[:nt], (1, 2, 0))
+        lag, lags = DO.delay_transform(vis, w[:, :, None], NP.ones((self.nbl, self.nchan, 1)), self.ch[1] - self.ch[0], pad=pad)
+        self._lag = NP.ascontiguousarray(NP.transpose(lag, (2, 0, 1)))        # [t][b][lag]
+        self._dt_nout = self._lag.shape[2]
+        return lags, self._dt_nout
+
+    def get_lags(self, t0, nt, rows=None):
+        out = self._lag[t0:t0 + nt]
+        return out if rows is None else out[:, NP.asarray(rows)]
+
+    def allgather_lags(self, nt):
+        self._gathered = NP.stack(_gloo_allgather(self._lag[:nt]), axis=1)
+
+    def delay_transform_host(self, vis, bpwts, pad):
+        w = NP.ones((self.nbl, self.nchan)) if bpwts is None else NP.asarray(bpwts)
+        lag, lags = DO.delay_transform(NP.asarray(vis)[:, :, None], w[:, :, None], NP.ones((self.nbl, self.nchan, 1)), self.ch[1] - self.ch[0], pad=pad)
+        return lag[:, :, 0], lags, None
+
+
+def _altaz(dircos):
+    alt = NP.degrees(NP.arcsin(NP.clip(dircos[:, 2], -1.0, 1.0)))
+    az = NP.degrees(NP.arctan2(dircos[:, 0], dircos[:, 1])) % 360.0
+    return NP.stack((alt, az), axis=1)
+
+
+class GlooCommContext(_abi.Context):
+    """The real GPU context; only the exchange goes over gloo (through the host), so that two ranks can share one GPU."""
+
+    def comm_init(self, uid, nranks, rank):
+        assert len(uid) == 128
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def allgather(self, nt, complex64=False):
+        mine = NP.stack([self.get_vis(slot=t) for t in range(nt)])
+        self._gathered_host = NP.stack(_gloo_allgather(mine), axis=1)
+
+    def allgather_lags(self, nt):
+        self._gathered_host = NP.stack(_gloo_allgather(self.get_lags(0, nt)), axis=1)
+
+    def get_gathered(self, nt, nranks=None, row=None):
+        return self._gathered_host[:nt]

@@ -2,6 +2,7 @@
 structures match the header; the product path fails loudly without a GPU (no CPU fallback)."""
 import ctypes as C
 import os
+import sys
 import re
 
 import pytest
@@ -86,13 +87,34 @@ def test_sky_sum_kernels_use_no_scratch(tmp_path):
                           '-o', str(out)], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr
     text = out.read_text()
-    meta = text[text.index('amdhsa.kernels:'):]
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import kernel_meta as KM
     found = 0
-    for block in meta.split('- .agpr_count:')[1:]:
-        name = re.search(r'\.name:\s+(\S+)', block).group(1)
+    for row in KM.kernel_meta(text):
+        name = row['name']
         if 'k_skyvis_rec' not in name:
             continue
         found += 1
-        assert int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', block).group(1)) == 0, name
-        assert int(re.search(r'\.vgpr_spill_count:\s+(\d+)', block).group(1)) == 0, name
+        assert row['scratch'] == 0, name
+        assert row['vgpr_spill'] == 0, name
+        # SGPR spills (v_readlane / v_writelane through a spare VGPR) are tolerated in the prologue and around the flush, never in
+        # the source loops: round 1's fp64 kernels moved 103-134 SGPRs per source through lanes because their half-row operand
+        # buffers (2 x 32 SGPRs) did not fit
+        body = KM.kernel_body(text, name)
+        lines, loops = KM.loops(body)
+        src_loops = [(a, b) for a, b in loops
+                     if (lambda c: c.get('lds', 0) <= 4 and c.get('s_load', 0) and (c.get('v_pk', 0) + c.get('v_f64', 0) + c.get('v_other', 0)) > 60)(
+                         KM.census('\n'.join(lines[a:b + 1])))]
+        assert src_loops, name
+        # the compiler lays the every-4th-source prefetch branch out as overlapping variants of one loop: judge each cluster of
+        # overlapping loops by its tightest member (the path 3 of 4 sources take); the widest may hold the branch's few lane moves
+        clusters = []
+        for a, b in sorted(src_loops):
+            if clusters and a <= clusters[-1][-1][1]:
+                clusters[-1].append((a, b))
+            else:
+                clusters.append([(a, b)])
+        for cl in clusters:
+            a, b = min(cl, key=lambda ab: ab[1] - ab[0])
+            assert KM.census('\n'.join(lines[a:b + 1])).get('v_lane', 0) <= 1, (name, a, b)
     assert found >= 14

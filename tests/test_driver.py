@@ -94,6 +94,50 @@ def test_custom_catalog_and_flux_cut():
         driver.build_skymodel(p, EX)
 
 
+def test_flux_cut_uses_each_sources_own_catalog_spectral_index(tmp_path):
+    """run_prisim.py:1649-1660: the thresholds given at fluxcut_reffreq are moved to the catalog frequency with the catalog's
+    SPINDEX column (assigned at :1649, before the cut), not with the global skyparm.spindex."""
+    cat = tmp_path / 'cat.txt'
+    rows = ['RA DEC F_INT SPINDEX MAJAX MINAX PA',
+            '10.0 -30.0 1.00 -2.0 0 0 0',        # steep: 1 Jy at 150 MHz is 0.32 Jy... at 200 MHz threshold scale (150/200)^-2 = 1.78
+            '20.0 -30.0 1.00  0.0 0 0 0',        # flat: threshold scale 1
+            '30.0 -30.0 1.50 -2.0 0 0 0',
+            '40.0 -30.0 2.50 -2.0 0 0 0']
+    cat.write_text('\n'.join(rows) + '\n')
+    p = driver.deep_merge(driver.DEFAULTS, {'catalog': {'custom_file': str(cat)}, 'bandpass': {'freq': 150e6},
+                                            'skyparm': {'model': 'custom', 'custom_reffreq': 0.150, 'flux_min': 1.0, 'flux_max': 2.0,
+                                                        'fluxcut_reffreq': 200e6, 'spindex': 0.0}})
+    sm = driver.build_skymodel(p, str(tmp_path))
+    # per-source thresholds at 150 MHz: steep sources [1.78, 3.56], flat source [1, 2] -> rows 2 (flat, 1.0) and 4 (steep, 2.5) pass
+    assert sorted(sm.location[:, 0].tolist()) == [20.0, 40.0]
+    # with the global spindex (0.0) rows 1, 2, 3 would have passed instead
+    assert sm.flux_ref.tolist() == [1.0, 2.5] and sm.spindex.tolist() == [0.0, -2.0]
+
+
+def test_external_beam_hdf5_gain_info_layout(tmp_path):
+    """scripts/FEKO_beam_to_healpix.py:161-198 writes gain_info/<pol> (nfreq x npix) + spectral_info/freqs; run_prisim.py:489-494 reads it."""
+    from prisim_amd import hdf5io
+    try:
+        f = hdf5io.File(str(tmp_path / 'beam.hdf5'), 'w')
+    except hdf5io.HDF5Unavailable:
+        pytest.skip('libhdf5 not available')
+    rng = NP.random.default_rng(5)
+    gains = {'P1': rng.uniform(0.1, 1.0, (3, 48)), 'P2': rng.uniform(0.1, 1.0, (3, 48))}
+    with f:
+        f.write('header/npol', 2)
+        f.write('spectral_info/freqs', NP.array([100e6, 150e6, 200e6]))
+        for pol, g in gains.items():
+            f.write('gain_info/' + pol, g)
+    p = driver.deep_merge(driver.DEFAULTS, {'beam': {'use_external': True, 'file': str(tmp_path / 'beam.hdf5'), 'filefmt': 'HDF5'}})
+    beam, freqs = driver.load_external_beam(p, '.')
+    assert beam.shape == (48, 3) and NP.array_equal(beam, gains['P1'].T) and NP.array_equal(freqs, [100e6, 150e6, 200e6])
+    p['beam']['pol'] = 'P2'
+    assert NP.array_equal(driver.load_external_beam(p, '.')[0], gains['P2'].T)
+    p['beam']['pol'] = 'P9'
+    with pytest.raises(KeyError):
+        driver.load_external_beam(p, '.')
+
+
 def test_window_shapes():
     for shape in ('rect', 'bhw', 'bnw'):
         w = driver.window(64, shape)

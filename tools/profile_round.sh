@@ -23,6 +23,6 @@ for group in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_V
   echo "pmc $i done"
 done
 cd "$REPO"
-git rev-parse HEAD:prisim_amd/csrc > "$OUT/csrc_tree_hash.txt" 2>/dev/null || sha1sum prisim_amd/csrc/*.hip prisim_amd/csrc/*.cpp prisim_amd/csrc/*.h | sha1sum | cut -d' ' -f1 > "$OUT/csrc_tree_hash.txt"
+python3 -c "import bench; print(bench.csrc_hash())" > "$OUT/csrc_hash.txt"
 python3 tools/summarize_pmc.py "$OUT"
 rm -rf "$OUT"/trace "$OUT"/pmc[0-9]

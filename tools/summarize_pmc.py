@@ -49,6 +49,11 @@ try:
 except Exception as e:      # noqa
     d['bench_line_error'] = repr(e)
 summary['_derived'] = d
+try:
+    with open(os.path.join(out, 'csrc_hash.txt')) as f:
+        summary['_csrc_hash'] = f.read().strip()      # bench.csrc_hash() of the sources this profile was taken with
+except Exception:
+    pass
 with open(os.path.join(out, 'pmc_summary.json'), 'w') as f:
     json.dump(summary, f, indent=1)
 print(json.dumps(d, indent=1))
