@@ -1090,7 +1090,7 @@ class InterferometerArray(object):
             f.write('antenna_element/shape', str(tel.get('shape', 'delta')))
             f.write('antenna_element/ocoords', ocoords)
             f.write('antenna_element/size', NP.asarray(tel.get('size', 1.0), dtype=NP.float64), attrs={'units': 'm'})
-            f.write('antenna_element/orientation', NP.asarray(tel.get('orientation', [90.0, 270.0]), dtype=NP.float64).ravel(),
+            f.write('antenna_element/orientation', NP.asarray(tel.get('orientation', [[90.0, 270.0]]), dtype=NP.float64),      # as held (:8766)
                     attrs=({'units': 'deg'} if ocoords != 'dircos' else None))
             if tel.get('groundplane') is not None:
                 f.write('antenna_element/groundplane', float(tel['groundplane']))

@@ -56,12 +56,23 @@ class OracleContext(object):
         self.fwhm = None if fwhm_deg is None else NP.asarray(fwhm_deg, dtype=NP.float64)
 
     def compute(self, precision=0, kernel=0, want_grad=False, slot=0):
-        self.cube[slot] = O.skyvis(self.bl, self.ch, self.dircos, self.pb, self.pc, fwhm_deg=self.fwhm)
+        if want_grad:
+            self.cube[slot], g = O.skyvis(self.bl, self.ch, self.dircos, self.pb, self.pc, fwhm_deg=self.fwhm, gradient=True)
+            self._grad = getattr(self, '_grad', {})
+            self._grad[slot] = g
+        else:
+            self.cube[slot] = O.skyvis(self.bl, self.ch, self.dircos, self.pb, self.pc, fwhm_deg=self.fwhm)
         self._timing['last_terms'] = self.nbl * self.nchan * self.nsrc
 
     def get_vis(self, slot=0, want_grad=False, complex64=False):
-        v = self.cube[slot].astype(NP.complex64 if complex64 else NP.complex128)
-        return v
+        ctype = NP.complex64 if complex64 else NP.complex128
+        v = self.cube[slot].astype(ctype)
+        return (v, self._grad[slot].astype(ctype)) if want_grad else v
+
+    def noise(self, rms, seed, bl_offset=0):
+        rng = NP.random.default_rng(int(seed) & 0xFFFFFFFF)
+        r = NP.asarray(rms, dtype=NP.float64)
+        return r / NP.sqrt(2.0) * (rng.standard_normal(r.shape) + 1j * rng.standard_normal(r.shape))
 
     def set_vis(self, vis, slot=0):
         self.cube[slot] = vis
