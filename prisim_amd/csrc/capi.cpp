@@ -885,6 +885,32 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   return PRISIM_OK;
 }
 
+// V + the three baseline-gradient sums of one snapshot in one pass (k_skyvis_grad_f64): dst [nbl][nchan], gdst [3][nbl][nchan] complex128
+static int run_grad_pass(prisim_ctx* ctx, const Plan& pl, double* dst, double* gdst) {
+  SkyvisParams p{};
+  p.bl_x = (const double*)ctx->blx.p; p.bl_y = (const double*)ctx->bly.p; p.bl_z = (const double*)ctx->blz.p;
+  p.nbl = ctx->nbl; p.nchan = ctx->nchan;
+  p.f0 = ctx->f0; p.df = ctx->df; p.inv_c = 1.0 / kC;
+  p.dirs = (const double*)ctx->dirs.p;
+  p.dirs_prep = (const double*)ctx->dirs_prep.p;
+  p.pb_packed = ctx->packed.p;
+  p.lift_flags = ctx->lift_flags.p ? (const int32_t*)ctx->lift_flags.p : nullptr;      // per 256 baselines; the kernel reads [group of 64 >> 2]
+  p.nsrc = ctx->nsrc; p.nsrc_pad = pl.nsrc_pad;
+  p.pc_x = ctx->pc[0]; p.pc_y = ctx->pc[1]; p.pc_z = ctx->pc[2];
+  p.taper = ctx->taper ? 1 : 0;
+  p.ntiles = pl.ntiles; p.nbgroups = (int)((ctx->nbl + 63) / 64); p.nsplit = 1; p.src_per_split = pl.nsrc_pad;
+  p.src_chunk = pl.chunk;
+  p.scale_comp = -1;
+  p.out = dst;
+  p.grad_out = gdst;
+  HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, false, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
+                          (const double*)ctx->dirs.p, -1, 1, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
+  HIPCHK(ctx, launch_skyvis_grad_f64(p, pl.ct, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
+  return PRISIM_OK;
+}
+
 int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad, int64_t slot) {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set || !ctx->sky_set) return fail(ctx, PRISIM_ESTATE, "set_array and set_sky must precede compute");
@@ -912,7 +938,21 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     ctx->timing.last_terms = 0;
     return PRISIM_OK;
   }
-  const Plan pl = make_plan(ctx, precision, kernel);
+  Plan pl = make_plan(ctx, precision, kernel);
+  // fp64 visibility + baseline gradient on a uniform channel grid: ONE pass of the fused MFMA kernel (k_skyvis_grad_f64, 2.4 x a
+  // plain fp64 pass instead of 4 x).  fp32 requests keep four packed-fp32 passes, which are faster than the fp64 kernel
+  // (PRISIM_HIP_FUSED_GRAD=0: the four-pass form for fp64 too -- the A/B baseline; non-uniform grids use the direct kernel).
+  bool fused_grad = want_grad && pl.kernel == PRISIM_KERNEL_RECURRENCE && !pl.f32;
+  if (const char* env = getenv("PRISIM_HIP_FUSED_GRAD")) fused_grad = fused_grad && atoi(env) != 0;
+  if (fused_grad) {
+    pl = make_plan(ctx, PRISIM_FP64, PRISIM_KERNEL_RECURRENCE);
+    pl.ct = ctx->taper ? 16 : 32;                 // the taper's per-lane recurrence state does not fit beside 128 accumulator VGPRs
+    pl.pk = false;
+    pl.ntiles = (int)((ctx->nchan + pl.ct - 1) / pl.ct);
+    pl.nsplit = 1;
+    pl.nsrc_pad = round_up(pl.nsrc_pad, 4);       // the kernel walks the sources four at a time (zero rows past nsrc)
+    pl.src_per_split = pl.nsrc_pad;
+  }
   ctx->timing.last_lift_groups = 0;
   ctx->timing.last_taper_group = 0;
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE) {
@@ -952,8 +992,12 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE)
     HIPCHK(ctx, launch_prep_dirs((const double*)ctx->dirs.p, (double*)ctx->dirs_prep.p, ctx->nsrc, pl.nsrc_pad, ctx->pc[0],
                                  ctx->pc[1], ctx->pc[2], 1.0 / kC, ctx->stream));
-  if ((rc = run_pass(ctx, pl, dst, -1, true))) return rc;
-  if (want_grad) {
+  if (fused_grad) {
+    if ((rc = run_grad_pass(ctx, pl, dst, (double*)ctx->grad.p + (size_t)slot * 3 * slot_elems))) return rc;
+  } else if ((rc = run_pass(ctx, pl, dst, -1, true))) {
+    return rc;
+  }
+  if (want_grad && !fused_grad) {
     for (int comp = 0; comp < 3; ++comp) {
       double* gdst = (double*)ctx->grad.p + ((size_t)slot * 3 + comp) * slot_elems;
       if ((rc = run_pass(ctx, pl, gdst, comp, false))) return rc;

@@ -42,10 +42,13 @@ struct SkyvisParams {
   double* out;               // [nsplit][nbl][nchan] complex128 (nsplit==1: the cube slot itself)
   int32_t out_f32;           // 1: out is [nsplit][nbl][nchan] complex64 partial sums (fp32 run, every split flushes exactly once)
   int32_t pad2_;
+  double* grad_out;          // fused gradient kernel: [3][nbl][nchan] complex128 of this slot
 };
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);
 hipError_t launch_skyvis_rec_f32pk(const SkyvisParams& p, int ct, hipStream_t stream);
+// V + baseline gradient in one pass (fp64, MFMA 4x4x4): p.nbgroups = groups of 64 baselines, p.nsplit = 1, ct = 16 or 32
+hipError_t launch_skyvis_grad_f64(const SkyvisParams& p, int ct, hipStream_t stream);
 hipError_t launch_fsq_pairs(const float* fsq, float* pairs, int ct, int ntiles, hipStream_t stream);
 hipError_t launch_skyvis_direct(const SkyvisParams& p, const double* freqs, const double* pb, const double* scale,
                                 hipStream_t stream);

@@ -209,6 +209,46 @@ __device__ __forceinline__ double div_unit_range_fast_f64(double a, double c) {
   return a * r;
 }
 
+// fp64 source-shape taper along frequency as a second-order multiplicative recurrence of the Gaussian w = exp(-g f^2):
+//   w_{k+1} = w_k q_k,  q_{k+1} = q_k h,   h = exp(-2 g df^2);   w_{k-1} = w_k q'_k, q'_{k-1} = q'_k h
+// Returns the weights of channels HC (wu) and HC-1 (wd) of the tile centred on fc and the ratios that advance them.
+__device__ __forceinline__ void taper_seed_f64(double gq, double fc, double df, double& wu, double& wd, double& qu, double& qd, double& h) {
+  const double x1 = -2.0 * gq * fc * df, x2 = -gq * df * df;
+  double e1, e1inv, e2;
+  if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(x1) < 0.1 && __builtin_fabs(x2) < 1e-3)) == 0) {
+    // the usual case (df << f): exp(+-x1) from the even and odd series to x^9 (next term 3e-17 at |x1| = 0.1) and
+    // exp(x2) from five terms, instead of two library exponentials and an fp64 division -- wave-uniform choice
+    const double z = x1 * x1;
+    double ce = 2.48015873015873015873e-05;                                    // 1/8!
+    ce = __builtin_fma(ce, z, 1.38888888888888888889e-03);
+    ce = __builtin_fma(ce, z, 4.16666666666666666667e-02);
+    ce = __builtin_fma(ce, z, 0.5);
+    ce = __builtin_fma(ce, z, 1.0);
+    double so = 2.75573192239858906526e-06;                                    // 1/9!
+    so = __builtin_fma(so, z, 1.98412698412698412698e-04);
+    so = __builtin_fma(so, z, 8.33333333333333333333e-03);
+    so = __builtin_fma(so, z, 1.66666666666666666667e-01);
+    so = __builtin_fma(so, z, 1.0) * x1;
+    e1 = ce + so;
+    e1inv = ce - so;
+    double p2 = 4.16666666666666666667e-02;
+    p2 = __builtin_fma(p2, x2, 1.66666666666666666667e-01);
+    p2 = __builtin_fma(p2, x2, 0.5);
+    p2 = __builtin_fma(p2, x2, 1.0);
+    e2 = __builtin_fma(p2, x2, 1.0);
+  } else {
+    e1 = exp(x1);
+    e1inv = 1.0 / e1;
+    e2 = exp(x2);
+  }
+  h = e2 * e2;
+  wu = exp(-gq * fc * fc);                  // channel HC
+  qu = e1 * e2;                             // w_{HC+1}/w_{HC}
+  qd = e2 * e1inv;                          // w_{HC-1}/w_{HC}
+  wd = wu * qd;                             // channel HC-1
+  qd *= h;                                  // w_{HC-2}/w_{HC-1}
+}
+
 // ------------------------------------------------------------------------------------------
 // Recurrence kernel
 // ------------------------------------------------------------------------------------------
@@ -484,42 +524,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
         if constexpr (sizeof(T) == 4) {
           g2 = -(float)(gq * p.fsq_scale);   // fp32: direct exp2 per term (no error accumulation)
         } else {
-          // fp64: second-order multiplicative recurrence of the Gaussian in frequency:
-          //   w_{k+1} = w_k q_k,  q_{k+1} = q_k h,   h = exp(-2 g df^2);   w_{k-1} = w_k q'_k, q'_{k-1} = q'_k h
-          const double x1 = -2.0 * gq * fc * df, x2 = -gq * df * df;
-          double e1, e1inv, e2;
-          if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(x1) < 0.1 && __builtin_fabs(x2) < 1e-3)) == 0) {
-            // the usual case (df << f): exp(+-x1) from the even and odd series to x^9 (next term 3e-17 at |x1| = 0.1) and
-            // exp(x2) from five terms, instead of two library exponentials and an fp64 division -- wave-uniform choice
-            const double z = x1 * x1;
-            double ce = 2.48015873015873015873e-05;                                    // 1/8!
-            ce = __builtin_fma(ce, z, 1.38888888888888888889e-03);
-            ce = __builtin_fma(ce, z, 4.16666666666666666667e-02);
-            ce = __builtin_fma(ce, z, 0.5);
-            ce = __builtin_fma(ce, z, 1.0);
-            double so = 2.75573192239858906526e-06;                                    // 1/9!
-            so = __builtin_fma(so, z, 1.98412698412698412698e-04);
-            so = __builtin_fma(so, z, 8.33333333333333333333e-03);
-            so = __builtin_fma(so, z, 1.66666666666666666667e-01);
-            so = __builtin_fma(so, z, 1.0) * x1;
-            e1 = ce + so;
-            e1inv = ce - so;
-            double p2 = 4.16666666666666666667e-02;
-            p2 = __builtin_fma(p2, x2, 1.66666666666666666667e-01);
-            p2 = __builtin_fma(p2, x2, 0.5);
-            p2 = __builtin_fma(p2, x2, 1.0);
-            e2 = __builtin_fma(p2, x2, 1.0);
-          } else {
-            e1 = exp(x1);
-            e1inv = 1.0 / e1;
-            e2 = exp(x2);
-          }
-          h = e2 * e2;
-          wu = exp(-gq * fc * fc);                  // channel HC
-          qu = e1 * e2;                             // w_{HC+1}/w_{HC}
-          qd = e2 * e1inv;                          // w_{HC-1}/w_{HC}
-          wd = wu * qd;                             // channel HC-1
-          qd *= h;                                  // w_{HC-2}/w_{HC-1}
+          taper_seed_f64(gq, fc, df, wu, wd, qu, qd, h);
         }
       }
 
@@ -619,6 +624,168 @@ void k_skyvis_rec(const SkyvisParams p) {
     return;
   }
   skyvis_rec_body<T, CT, TAPER, false>(p, flush_lds, pf_area, tab);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused visibility + baseline-gradient kernel (interferometry.py:6330, 6338, 6343):
+//   V[b,f] and G_k[b,f] = sum_s dircos[s,k] * (summand), k = 0..2, in ONE pass over the sources.
+//
+// The four sums share the phasor; they differ by a per-source coefficient c_i(s) = (1, l_s, m_s, n_s).  That IS a small matrix
+// product -- out[i][b] += sum_s c_i(s) p(s,f) * z(s,b,f) -- and it maps exactly onto v_mfma_f64_4x4x4_4b_f64
+// (layout probed by tools/mfma_layout_test.hip: A[i][k] <- lane 16 k + 4 blk + i, B[k][j] <- lane 16 k + 4 blk + j,
+// D[i][j] -> lane 16 i + 4 blk + j):
+//   * a wavefront owns 16 baselines (4 blocks x 4 columns j) and walks the sources FOUR at a time: lane 16 k + q follows baseline q
+//     of the wave and source 4 g + k, forms its phasor z by the same centre-seeded lifting recurrence as k_skyvis_rec (B operand),
+//     and supplies A = c_(lane % 4)(s_k) * p(s_k, f) for its own source;
+//   * one MFMA then adds, for all 16 baselines, the four sources into the four sums: 256 FMAs in ~17 cycles.  Lane 16 i + q ends with
+//     sum i of baseline q: 2 CT doubles per lane.
+// What it buys (profiles/r02_microbench_mfma.txt): on MI355X the fp64 MFMA runs on the SAME datapath as v_fma_f64 -- an MFMA loop and a
+// VALU loop of two waves on one SIMD take the sum of their times, and 256 FMAs / 17 cycles is the VALU's 64 FMAs / 4 cycles -- so the
+// matrix instruction adds no throughput; it removes instructions: per pair of channels 4 MFMAs (= 16 v_fma_f64 of work) + 8 VALU
+// operations, against 4 passes x 10 VALU operations.  Measured on config 3 (tools/grad_timing.py): 287 ms against 476 ms for the four
+// fp64 passes and 118 ms for a plain fp64 pass: V + gradient = 2.4 x a plain pass.  The accumulate FMAs alone (4 sums x re/im) are
+// 1.6 x a plain pass's whole inner loop, so nothing on this datapath gets the gradient under ~2.2 x.  (fp32 requests keep the four
+// packed-fp32 passes: 235 ms, faster than this fp64 kernel; an fp32 MFMA 4x4x1 form would share the fp32 datapath likewise.)
+// pbflux rows and directions are per lane group here (4 sources per wavefront), so they come through vector loads (4 distinct
+// 16-byte addresses per instruction).
+// ------------------------------------------------------------------------------------------
+template <int CT, bool TAPER, bool LIFT>
+__device__ __forceinline__ void skyvis_grad_f64_body(const SkyvisParams& p, const double2* tab) {
+  constexpr int HC = CT / 2;
+  int slab, bg;
+  if (!block_item(p, slab, bg)) return;          // p.nbgroups counts groups of 64 baselines for this kernel
+  const int tile = slab % p.ntiles;              // the host plans nsplit = 1: every block walks all sources
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int k = lane >> 4;                        // source phase (B / A role), sum index i (D role)
+  const int x = lane & 3;                         // A role: which coefficient this lane supplies
+  const int64_t bw0 = (int64_t)bg * 64 + (tid >> 6) * 16;     // first baseline of this wave
+  const int64_t b_raw = bw0 + (lane & 15);
+  const bool b_valid = b_raw < p.nbl;
+  const int64_t b = b_valid ? b_raw : (p.nbl - 1);
+  if (bw0 >= p.nbl) return;                       // wave-uniform: whole wave out of range
+
+  const double bx = p.bl_x[b], by = p.bl_y[b], bz = p.bl_z[b];
+  const int k0 = tile * CT;
+  const double fc = p.f0 + (double)(k0 + HC) * p.df;
+  const double df = p.df;
+  const double fcN = fc * kTabN, dfN = df * kTabN, dfN_half = df * (0.5 * kTabN);
+  double bl2_c2 = 0.0, bpc = 0.0;
+  if (TAPER) {
+    bl2_c2 = (bx * bx + by * by + bz * bz) * (p.inv_c * p.inv_c);
+    bpc = (bx * p.pc_x + by * p.pc_y + bz * p.pc_z) * p.inv_c;
+  }
+
+  double a_ur[HC], a_ui[HC], a_dr[HC], a_di[HC];    // sum (lane >> 4) of baseline (lane & 15): channels HC + j (up), HC - 1 - j (down)
+#pragma unroll
+  for (int j = 0; j < HC; ++j) { a_ur[j] = 0.0; a_ui[j] = 0.0; a_dr[j] = 0.0; a_di[j] = 0.0; }
+
+  const double* const rows = reinterpret_cast<const double*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT;
+  const double4* const prep = reinterpret_cast<const double4*>(p.dirs_prep);
+  const double4* const raw = reinterpret_cast<const double4*>(p.dirs);
+  const int64_t ns_pad = p.nsrc_pad;             // a multiple of 4 (the source chunk); rows and prepared directions past nsrc are zero
+
+  for (int64_t s0 = 0; s0 < ns_pad; s0 += 4) {
+    const int64_t s = s0 + k;
+    const double4 sv = prep[s];
+    const double4 rw = raw[s < p.nsrc ? s : p.nsrc - 1];
+    const double2* const row = reinterpret_cast<const double2*>(rows + (size_t)s * CT);     // (up, down) pairs
+    double2 pr[HC];
+#pragma unroll
+    for (int j = 0; j < HC; ++j) pr[j] = row[j];
+    const double cx = (x == 0) ? 1.0 : (x == 1 ? rw.x : (x == 2 ? rw.y : rw.z));
+    const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));
+
+    double zc, zs, rc = 1.0, rs, tl = 0.0;
+    {
+      const TabPhase pc = sincos_tab_front(d * fcN, tab);
+      const TabPhase ps = sincos_tab_front(d * (LIFT ? dfN_half : dfN), tab);
+      sincos_tab_back(pc, zc, zs);
+      if constexpr (LIFT) {
+        double sb, cb;
+        sincos_tab_back(ps, cb, sb);
+        rs = 2.0 * sb * cb;
+        tl = -div_unit_range_fast_f64(sb, cb);
+      } else {
+        sincos_tab_back(ps, rc, rs);
+      }
+    }
+    double ur = zc, ui = -zs;
+    const double rr = rc, ri = -rs;
+    double dr, di;
+    if constexpr (LIFT) {
+      const double xd = __builtin_fma(tl, ui, ur);
+      di = __builtin_fma(-ri, xd, ui);
+      dr = __builtin_fma(tl, di, xd);
+    } else {
+      dr = __builtin_fma(ur, rr, ui * ri);
+      di = __builtin_fma(ui, rr, -(ur * ri));
+    }
+    // The taper weight w(s, b, f) belongs to the (source, baseline) pair, i.e. to the B operand (the A operand of a lane serves all
+    // four baselines of its block): B = w z, advanced with the weight's own recurrence.
+    double wu = 1.0, wd = 1.0, qu = 1.0, qd = 1.0, h = 1.0;
+    if constexpr (TAPER) {
+      const double tau = d + bpc;
+      double gq = sv.w * (bl2_c2 - tau * tau);
+      gq = gq > 0.0 ? gq : 0.0;
+      taper_seed_f64(gq, fc, df, wu, wd, qu, qd, h);
+    }
+#pragma unroll
+    for (int j = 0; j < HC; ++j) {
+      const double au = cx * pr[j].x, ad = cx * pr[j].y;
+      double bur = ur, bui = ui, bdr = dr, bdi = di;
+      if constexpr (TAPER) {
+        bur *= wu; bui *= wu; bdr *= wd; bdi *= wd;
+        wu *= qu; qu *= h; wd *= qd; qd *= h;
+      }
+      a_ur[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(au, bur, a_ur[j], 0, 0, 0);
+      a_ui[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(au, bui, a_ui[j], 0, 0, 0);
+      a_dr[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, bdr, a_dr[j], 0, 0, 0);
+      a_di[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, bdi, a_di[j], 0, 0, 0);
+      if constexpr (LIFT) {
+        const double xu = __builtin_fma(-tl, ui, ur);
+        const double yu = __builtin_fma(ri, xu, ui);
+        ur = __builtin_fma(-tl, yu, xu); ui = yu;
+        const double xd = __builtin_fma(tl, di, dr);
+        const double yd = __builtin_fma(-ri, xd, di);
+        dr = __builtin_fma(tl, yd, xd); di = yd;
+      } else {
+        const double nur = __builtin_fma(ur, rr, -(ui * ri));
+        const double nui = __builtin_fma(ur, ri, ui * rr);
+        const double ndr = __builtin_fma(dr, rr, di * ri);
+        const double ndi = __builtin_fma(di, rr, -(dr * ri));
+        ur = nur; ui = nui; dr = ndr; di = ndi;
+      }
+    }
+  }
+  // lane 16 i + q holds sum i (0: visibility, 1-3: gradient components) of baseline bw0 + q
+  if (b_valid) {
+    const int i = k;
+    double2* const dst = (i == 0) ? reinterpret_cast<double2*>(p.out) : reinterpret_cast<double2*>(p.grad_out) + (size_t)(i - 1) * p.nbl * p.nchan;
+    double2* const o = dst + (size_t)b * p.nchan;
+#pragma unroll
+    for (int j = 0; j < HC; ++j) {
+      const int ku = k0 + HC + j, kd = k0 + HC - 1 - j;
+      if (ku < p.nchan) o[ku] = make_double2(a_ur[j], a_ui[j]);
+      if (kd < p.nchan) o[kd] = make_double2(a_dr[j], a_di[j]);
+    }
+  }
+}
+
+template <int CT, bool TAPER>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_skyvis_grad_f64(const SkyvisParams p) {
+  __shared__ double2 tab_lds[kTabN];
+  fill_phasor_table(tab_lds);
+  __syncthreads();
+  int slab_, bg;
+  const bool in_range = block_item(p, slab_, bg);
+  if (in_range && p.lift_flags != nullptr && p.lift_flags[bg >> 2] != 0) {      // flags are kept per 256 baselines
+    skyvis_grad_f64_body<CT, TAPER, true>(p, tab_lds);
+    return;
+  }
+  skyvis_grad_f64_body<CT, TAPER, false>(p, tab_lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1214,6 +1381,23 @@ hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_
     }
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_skyvis_grad_f64(const SkyvisParams& p, int ct, hipStream_t stream) {
+  // p.nbgroups = groups of 64 baselines, p.nsplit = 1
+  const int64_t items = (int64_t)p.ntiles * p.nbgroups;
+  if (items <= 0 || items > 0x3fffffffLL || p.nsplit != 1) return hipErrorInvalidValue;
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
+  if (ct == 32) {
+    if (p.taper) hipLaunchKernelGGL((k_skyvis_grad_f64<32, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
+    else hipLaunchKernelGGL((k_skyvis_grad_f64<32, false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
+  } else if (ct == 16) {
+    if (p.taper) hipLaunchKernelGGL((k_skyvis_grad_f64<16, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
+    else hipLaunchKernelGGL((k_skyvis_grad_f64<16, false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_skyvis_direct(const SkyvisParams& p, const double* freqs, const double* pb, const double* scale,

@@ -93,6 +93,35 @@ def test_oracle_parity_all_variants(ctx, shape, taper):
     assert relerr(ctx.get_vis(), ref, pb) <= TOL[_abi.PRISIM_FP64]
 
 
+@pytest.mark.parametrize('shape', [(3, 64, 100), (171, 256, 601), (70, 100, 33), (1, 1, 1), (257, 33, 66)])
+@pytest.mark.parametrize('taper', [False, True])
+def test_fused_mfma_gradient_matches_oracle_and_four_pass_form(ctx, monkeypatch, shape, taper):
+    """interferometry.py:6330, 6338, 6343.  V and the three gradient sums come out of ONE pass (k_skyvis_grad_f64: the four sums are
+    a 4 x 4 x 4 fp64 MFMA per channel with lanes = 16 baselines x 4 sources) -- against the numpy oracle, and against the four
+    separate passes it replaces; ragged sizes (baselines not a multiple of 16, sources not a multiple of 4, channels not a multiple
+    of the tile), long baselines (no lifting), source chunks that do not divide by four, both precisions' entry."""
+    nbl, nchan, nsrc = shape
+    bl, ch, dc, pb, pc, fw = _random_case(23, nbl, nchan, nsrc, taper)
+    bl[::3] *= 12.0                                                   # some baseline groups beyond the lifting guarantee
+    ref, gref = O.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw, gradient=True)
+    ctx.set_array(bl, ch)
+    ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
+    for chunk in (0, 7):
+        ctx.set_tuning(0, chunk, 0)
+        for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):               # fp32 requests keep the four packed-fp32 passes
+            ctx.compute(precision=prec, want_grad=True)
+            v, g = ctx.get_vis(want_grad=True)
+            assert relerr(v, ref, pb) <= TOL[prec] and max(relerr(g[k], gref[k], pb) for k in range(3)) <= TOL[prec], (shape, taper, prec, chunk)
+    ctx.compute(precision=_abi.PRISIM_FP64, want_grad=True)
+    v, g = ctx.get_vis(want_grad=True)
+    ctx.set_tuning(0, 0, 0)
+    monkeypatch.setenv('PRISIM_HIP_FUSED_GRAD', '0')
+    ctx.compute(precision=_abi.PRISIM_FP64, want_grad=True)
+    v4, g4 = ctx.get_vis(want_grad=True)
+    monkeypatch.delenv('PRISIM_HIP_FUSED_GRAD')
+    assert relerr(v4, v, pb) <= 1e-12 and max(relerr(g4[k], g[k], pb) for k in range(3)) <= 1e-12
+
+
 @pytest.mark.parametrize('taper', [False, True])
 def test_fp32_periodic_flush_read_modify_write(ctx, monkeypatch, taper):
     """fp32 partial sums are added into the fp64 cube every flush_src sources (16384 in production, config 5 crosses it 24

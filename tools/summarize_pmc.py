@@ -2,7 +2,7 @@
 import csv, glob, json, os, shutil, sys
 
 out = sys.argv[1]
-KERNEL = 'k_skyvis_rec'            # matches k_skyvis_rec<...> and k_skyvis_rec_f32pk<...>
+KERNEL = os.environ.get('PROFILE_KERNEL', 'k_skyvis_rec')            # matches k_skyvis_rec<...> and k_skyvis_rec_f32pk<...>
 
 stats = glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True)
 summary = {}
