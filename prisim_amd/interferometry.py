@@ -943,7 +943,7 @@ class InterferometerArray(object):
             phase_center = NP.repeat(phase_center, n_acc, axis=0)
         elif phase_center.shape[0] != n_acc:
             raise ValueError('One phase center must be provided for every timestamp.')
-        if self.skyvis_freq is None:
+        if not getattr(self, '_cube', None) and getattr(self, '_skyvis_override', None) is None:
             raise ValueError('no visibilities to rotate: call observe() first')
         cur = self._pc_dircos(self.phase_center, self.phase_center_coords)
         new = self._pc_dircos(phase_center, phase_center_coords)
@@ -958,15 +958,21 @@ class InterferometerArray(object):
                 out[:, :, t] = self._ctx.get_vis(slot=0)
             return out
 
-        dtype = self.skyvis_freq.dtype
-        self.skyvis_freq = rotate(self.skyvis_freq).astype(dtype)                      # :7877
-        if self.vis_freq is not None:
-            self.vis_freq = rotate(self.vis_freq)
-        if self.vis_noise_freq is not None:
-            self.vis_noise_freq = rotate(self.vis_noise_freq)
-        if self._reserved >= n_acc:                        # keep the device-resident cube in step
-            for t in range(n_acc):
-                self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
+        resident = self._reserved >= n_acc and len(self._cube) == n_acc and all(isinstance(sn, _DeviceSlot) for sn in self._cube)
+        if resident and self.vis_freq is None and self.vis_noise_freq is None:
+            # the whole cube lives on the device (reserve()) and was never read: rotate it where it is, one kernel over all snapshots
+            self._ctx.phase_rotate(n_acc, diff)                                         # :7877
+            self._skyvis_cache = None
+        else:
+            dtype = self.skyvis_freq.dtype
+            self.skyvis_freq = rotate(self.skyvis_freq).astype(dtype)                  # :7877
+            if self.vis_freq is not None:
+                self.vis_freq = rotate(self.vis_freq)
+            if self.vis_noise_freq is not None:
+                self.vis_noise_freq = rotate(self.vis_noise_freq)
+            if self._reserved >= n_acc:                        # keep the device-resident cube in step
+                for t in range(n_acc):
+                    self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
         self.phase_center = self._convert_pc(new, self.phase_center_coords)            # :7874-7875
         if do_delay_transform:
             self.delay_transform(verbose=verbose)

@@ -402,6 +402,15 @@ def test_interferometer_array_phase_centering_project_conjugate():
     assert NP.max(NP.abs(ia.skyvis_freq[:, :, 0] - ref)) <= 1e-10
     assert NP.allclose(ia.phase_center, [[80.0, 100.0]] * 2) and ia.phase_center_coords == 'altaz'
     assert NP.array_equal(ia._ctx.get_vis(slot=1), ia.skyvis_freq[:, :, 1])            # device cube follows
+    # a cube that never left the device is rotated where it is (one kernel over all snapshots), nothing is downloaded
+    ib = RI.InterferometerArray([('a', 'b'), ('a', 'c'), ('b', 'c')], bl, ch, telescope={'shape': 'delta'}, latitude=lat, skycoords='altaz',
+                                pointing_coords='altaz')
+    ib.reserve(2)
+    for j in range(2):
+        ib.observe((2457000.5 + j, 15.0 * j), {'Tnet': 100.0}, NP.ones(16), [90.0, 270.0], skymod, 10.0)
+    ib.phase_centering(phase_center=NP.array([[80.0, 100.0]]), phase_center_coords='altaz')
+    assert all(isinstance(sn, RI._DeviceSlot) for sn in ib._cube)
+    assert NP.max(NP.abs(ib.skyvis_freq - ia.skyvis_freq)) <= 1e-12
     # rotating back restores the original
     ia.phase_centering(phase_center=NP.array([[90.0, 270.0]]), phase_center_coords='altaz')
     assert NP.max(NP.abs(ia.skyvis_freq - before)) <= 1e-10

@@ -13,9 +13,9 @@ cd /tmp && export TMPDIR=/tmp
 STEPS="--steps 5"
 case " $* " in *" --steps "*) STEPS="";; esac
 BENCH="python3 $REPO/bench.py $STEPS --warmup 1 --no-cpu-baseline $*"
-# PROFILE_CMD: another program to profile instead of bench.py (e.g. "python3 tools/profile_delay.py 4"); PROFILE_KERNEL: the kernel
+# PROFILE_CMD: another program to profile instead of bench.py (e.g. "python3 @REPO@/tools/profile_delay.py 4"); PROFILE_KERNEL: the kernel
 # whose counters tools/summarize_pmc.py condenses (default k_skyvis_rec)
-if [ -n "$PROFILE_CMD" ]; then BENCH="$PROFILE_CMD"; fi
+if [ -n "$PROFILE_CMD" ]; then BENCH="${PROFILE_CMD//@REPO@/$REPO}"; fi     # the passes run from /tmp: write @REPO@ for the repo root
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 echo "trace done"
 i=0
