@@ -19,7 +19,7 @@ Differences kept on purpose:
   Q20 delay_transform transforms whichever of the three cubes exist.
   sky coordinates 'radec' are converted with HA = LST - RA (no precession / nutation / aberration;
   astropy's FK5->AltAz is outside the boundary, SURVEY.md 7 "Hard parts").
-Out of scope here: init_file (HDF5/FITS persistence), gains, noise, uvfits.
+Out of scope here: gain tables, FITS persistence, uvfits / uvh5.
 """
 import os
 import warnings
@@ -385,7 +385,9 @@ class InterferometerArray(object):
         if not getattr(self, '_comm_ready', False):
             self._ctx.comm_init(comm_uid, nranks, rank)
             self._comm_ready = True
-        c64 = bool(self._cube) and self._cube[0].dtype == NP.complex64           # works for host arrays and _DeviceSlot placeholders
+        # complex64 on the wire only when EVERY snapshot was observed with memsave (host arrays and _DeviceSlot placeholders both
+        # carry their dtype); a run that mixes precisions, or has no snapshot yet, gathers complex128
+        c64 = bool(self._cube) and all(NP.dtype(sn.dtype) == NP.complex64 for sn in self._cube)
         self._ctx.allgather(self.n_acc, complex64=c64)
         g = self._ctx.get_gathered(self.n_acc, nranks)                 # [t][rank][b][f]
         return NP.transpose(g.reshape(self.n_acc, nranks * self.baselines.shape[0], self.channels.size), (1, 2, 0))
