@@ -128,7 +128,7 @@ struct prisim_ctx {
   int64_t nsrc = 0;
   bool taper = false;
   double pc[3] = {0, 0, 1};
-  DevBuf dirs, dirs_prep, pb, packed, partial, scratch;
+  DevBuf dirs, dirs_prep, dirs_c32, pb, packed, partial, scratch;
   // per-snapshot sky inputs (flux_ref / spindex or a flux table, beamformer elements, validity flag): owned by the context so that
   // a set_sky_* call allocates nothing after the first snapshot
   DevBuf sky_flux, sky_sp, sky_bf, sky_flag;
@@ -433,7 +433,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->fft_plan && g_rocfft.plan_destroy) g_rocfft.plan_destroy(ctx->fft_plan);
   if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
-                    &ctx->dirs_prep, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
+                    &ctx->dirs_prep, &ctx->dirs_c32, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
                     &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
@@ -826,9 +826,8 @@ int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out) {
   return PRISIM_OK;
 }
 
-// one sky-sum pass into `dst` ([nbl][nchan] complex128); scale_comp >= 0 multiplies pbflux rows by dircos[:,comp]
-static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp, bool timed) {
-  SkyvisParams p{};
+// kernel parameters common to every sky-sum launch of the current array / sky / plan
+static void fill_params(prisim_ctx* ctx, const Plan& pl, SkyvisParams& p) {
   p.bl_x = (const double*)ctx->blx.p; p.bl_y = (const double*)ctx->bly.p; p.bl_z = (const double*)ctx->blz.p;
   p.nbl = ctx->nbl; p.nchan = ctx->nchan;
   p.f0 = ctx->f0; p.df = ctx->df; p.inv_c = 1.0 / kC;
@@ -852,7 +851,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     const long v = atol(env);
     if (v > 0 && v < (1L << 30)) p.flush_src = (int32_t)v;
   }
-  p.scale_comp = scale_comp;
+  p.scale_comp = -1;
   {
     // grouped taper recurrence (skyvis_kernels.hip): second-order residual (11.09 (df/f)^2)^2 * 0.565 <= 1e-8 of sum|pbflux|
     const double fmin = std::min(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
@@ -860,6 +859,13 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     if (const char* env = getenv("PRISIM_HIP_TAPER_GROUP")) p.taper_group = (atoi(env) != 0 && ctx->taper) ? 1 : 0;   // A/B hook
     ctx->timing.last_taper_group = (pl.pk && p.taper_group) ? 1 : 0;
   }
+}
+
+// one sky-sum pass into `dst` ([nbl][nchan] complex128); scale_comp >= 0 multiplies pbflux rows by dircos[:,comp]
+static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp, bool timed) {
+  SkyvisParams p{};
+  fill_params(ctx, pl, p);
+  p.scale_comp = scale_comp;
   if (pl.kernel == PRISIM_KERNEL_DIRECT) {
     p.out = dst;
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
@@ -885,28 +891,25 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   return PRISIM_OK;
 }
 
-// V + the three baseline-gradient sums of one snapshot in one pass (k_skyvis_grad_f64): dst [nbl][nchan], gdst [3][nbl][nchan] complex128
+// V + the three baseline-gradient sums of one snapshot in one pass: dst [nbl][nchan], gdst [3][nbl][nchan] complex128.
+// fp64: k_skyvis_grad_f64 (MFMA 4x4x4, groups of 64 baselines); fp32: the GRAD bodies of the packed kernel (16-channel tiles).
 static int run_grad_pass(prisim_ctx* ctx, const Plan& pl, double* dst, double* gdst) {
   SkyvisParams p{};
-  p.bl_x = (const double*)ctx->blx.p; p.bl_y = (const double*)ctx->bly.p; p.bl_z = (const double*)ctx->blz.p;
-  p.nbl = ctx->nbl; p.nchan = ctx->nchan;
-  p.f0 = ctx->f0; p.df = ctx->df; p.inv_c = 1.0 / kC;
-  p.dirs = (const double*)ctx->dirs.p;
-  p.dirs_prep = (const double*)ctx->dirs_prep.p;
-  p.pb_packed = ctx->packed.p;
-  p.lift_flags = ctx->lift_flags.p ? (const int32_t*)ctx->lift_flags.p : nullptr;      // per 256 baselines; the kernel reads [group of 64 >> 2]
-  p.nsrc = ctx->nsrc; p.nsrc_pad = pl.nsrc_pad;
-  p.pc_x = ctx->pc[0]; p.pc_y = ctx->pc[1]; p.pc_z = ctx->pc[2];
-  p.taper = ctx->taper ? 1 : 0;
-  p.ntiles = pl.ntiles; p.nbgroups = (int)((ctx->nbl + 63) / 64); p.nsplit = 1; p.src_per_split = pl.nsrc_pad;
-  p.src_chunk = pl.chunk;
-  p.scale_comp = -1;
+  fill_params(ctx, pl, p);
+  p.nsplit = 1; p.src_per_split = pl.nsrc_pad;
   p.out = dst;
   p.grad_out = gdst;
-  HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, false, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
+  p.out_f32 = 0;
+  HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
                           (const double*)ctx->dirs.p, -1, 1, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
-  HIPCHK(ctx, launch_skyvis_grad_f64(p, pl.ct, ctx->stream));
+  if (pl.f32) {
+    p.dirs_c32 = (const float*)ctx->dirs_c32.p;
+    HIPCHK(ctx, launch_skyvis_grad_f32(p, ctx->stream));
+  } else {
+    p.nbgroups = (int)((ctx->nbl + 63) / 64);      // the MFMA kernel's blocks own 64 baselines; lift flags stay per 256 (it reads [group >> 2])
+    HIPCHK(ctx, launch_skyvis_grad_f64(p, pl.ct, ctx->stream));
+  }
   HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
   return PRISIM_OK;
 }
@@ -939,18 +942,20 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     return PRISIM_OK;
   }
   Plan pl = make_plan(ctx, precision, kernel);
-  // fp64 visibility + baseline gradient on a uniform channel grid: ONE pass of the fused MFMA kernel (k_skyvis_grad_f64, 2.4 x a
-  // plain fp64 pass instead of 4 x).  fp32 requests keep four packed-fp32 passes, which are faster than the fp64 kernel
-  // (PRISIM_HIP_FUSED_GRAD=0: the four-pass form for fp64 too -- the A/B baseline; non-uniform grids use the direct kernel).
-  bool fused_grad = want_grad && pl.kernel == PRISIM_KERNEL_RECURRENCE && !pl.f32;
+  // Visibility + baseline gradient on a uniform channel grid: ONE fused pass -- fp64: the MFMA kernel k_skyvis_grad_f64 (2.4 x a plain
+  // fp64 pass instead of 4 x); fp32: the GRAD bodies of the packed kernel on 16-channel tiles (13 packed instructions per pair of terms
+  // against 4 passes x 5).  PRISIM_HIP_FUSED_GRAD=0: the four-pass form (the A/B baseline; non-uniform grids use the direct kernel).
+  bool fused_grad = want_grad && pl.kernel == PRISIM_KERNEL_RECURRENCE;
   if (const char* env = getenv("PRISIM_HIP_FUSED_GRAD")) fused_grad = fused_grad && atoi(env) != 0;
   if (fused_grad) {
-    pl = make_plan(ctx, PRISIM_FP64, PRISIM_KERNEL_RECURRENCE);
-    pl.ct = ctx->taper ? 16 : 32;                 // the taper's per-lane recurrence state does not fit beside 128 accumulator VGPRs
-    pl.pk = false;
+    const bool f32 = pl.f32;
+    pl = make_plan(ctx, f32 ? PRISIM_FP32 : PRISIM_FP64, PRISIM_KERNEL_RECURRENCE);
+    // fp32: 4 x 2 x 16 packed accumulators = 128 VGPRs; fp64: the taper's per-lane recurrence state does not fit beside 128 at 32
+    pl.ct = f32 ? 16 : (ctx->taper ? 16 : 32);
+    pl.pk = f32;
     pl.ntiles = (int)((ctx->nchan + pl.ct - 1) / pl.ct);
     pl.nsplit = 1;
-    pl.nsrc_pad = round_up(pl.nsrc_pad, 4);       // the kernel walks the sources four at a time (zero rows past nsrc)
+    pl.nsrc_pad = round_up(pl.nsrc_pad, 4);       // the fp64 kernel walks the sources four at a time (zero rows past nsrc)
     pl.src_per_split = pl.nsrc_pad;
   }
   ctx->timing.last_lift_groups = 0;
@@ -989,9 +994,15 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     }
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev_c0[ctx->ring_head], ctx->stream));
-  if (pl.kernel == PRISIM_KERNEL_RECURRENCE)
-    HIPCHK(ctx, launch_prep_dirs((const double*)ctx->dirs.p, (double*)ctx->dirs_prep.p, ctx->nsrc, pl.nsrc_pad, ctx->pc[0],
+  if (pl.kernel == PRISIM_KERNEL_RECURRENCE) {
+    float* c32 = nullptr;
+    if (fused_grad && pl.f32) {
+      if ((rc = ensure(ctx, ctx->dirs_c32, (size_t)pl.nsrc_pad * 8 * sizeof(float)))) return rc;
+      c32 = (float*)ctx->dirs_c32.p;
+    }
+    HIPCHK(ctx, launch_prep_dirs((const double*)ctx->dirs.p, (double*)ctx->dirs_prep.p, c32, ctx->nsrc, pl.nsrc_pad, ctx->pc[0],
                                  ctx->pc[1], ctx->pc[2], 1.0 / kC, ctx->stream));
+  }
   if (fused_grad) {
     if ((rc = run_grad_pass(ctx, pl, dst, (double*)ctx->grad.p + (size_t)slot * 3 * slot_elems))) return rc;
   } else if ((rc = run_pass(ctx, pl, dst, -1, true))) {

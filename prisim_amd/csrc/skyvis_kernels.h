@@ -42,20 +42,23 @@ struct SkyvisParams {
   double* out;               // [nsplit][nbl][nchan] complex128 (nsplit==1: the cube slot itself)
   int32_t out_f32;           // 1: out is [nsplit][nbl][nchan] complex64 partial sums (fp32 run, every split flushes exactly once)
   int32_t pad2_;
-  double* grad_out;          // fused gradient kernel: [3][nbl][nchan] complex128 of this slot
+  double* grad_out;          // fused gradient kernels: [3][nbl][nchan] complex128 of this slot
+  const float* dirs_c32;     // fused fp32 gradient kernel: [nsrc_pad][8] (l, l, m, m, n, n, 0, 0)
 };
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);
 hipError_t launch_skyvis_rec_f32pk(const SkyvisParams& p, int ct, hipStream_t stream);
 // V + baseline gradient in one pass (fp64, MFMA 4x4x4): p.nbgroups = groups of 64 baselines, p.nsplit = 1, ct = 16 or 32
 hipError_t launch_skyvis_grad_f64(const SkyvisParams& p, int ct, hipStream_t stream);
+// the same in packed fp32 (VALU; p.nbgroups = groups of 256 baselines, 16-channel tiles, p.nsplit = 1, p.dirs_c32)
+hipError_t launch_skyvis_grad_f32(const SkyvisParams& p, hipStream_t stream);
 hipError_t launch_fsq_pairs(const float* fsq, float* pairs, int ct, int ntiles, hipStream_t stream);
 hipError_t launch_skyvis_direct(const SkyvisParams& p, const double* freqs, const double* pb, const double* scale,
                                 hipStream_t stream);
 hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct,
                        int ntiles, const double* dirs, int scale_comp, int interleave, hipStream_t stream);
-hipError_t launch_prep_dirs(const double* dirs, double* prep, int64_t nsrc, int64_t nsrc_pad, double pcx, double pcy,
-                            double pcz, double inv_c, hipStream_t stream);
+hipError_t launch_prep_dirs(const double* dirs, double* prep, float* c32 /*[nsrc_pad][8] or NULL*/, int64_t nsrc, int64_t nsrc_pad, double pcx,
+                            double pcy, double pcz, double inv_c, hipStream_t stream);
 hipError_t launch_reduce_partials(const void* part, bool part_f32, double* out, int64_t n2, int nsplit, hipStream_t stream);
 hipError_t launch_f32_to_f64(const float* in, double* out, int64_t n, hipStream_t stream);
 hipError_t launch_fsq(const double* freqs, float* fsq, int64_t nchan, int64_t npad, double scale, hipStream_t stream);

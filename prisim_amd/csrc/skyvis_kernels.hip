@@ -644,8 +644,9 @@ void k_skyvis_rec(const SkyvisParams p) {
 // matrix instruction adds no throughput; it removes instructions: per pair of channels 4 MFMAs (= 16 v_fma_f64 of work) + 8 VALU
 // operations, against 4 passes x 10 VALU operations.  Measured on config 3 (tools/grad_timing.py): 287 ms against 476 ms for the four
 // fp64 passes and 118 ms for a plain fp64 pass: V + gradient = 2.4 x a plain pass.  The accumulate FMAs alone (4 sums x re/im) are
-// 1.6 x a plain pass's whole inner loop, so nothing on this datapath gets the gradient under ~2.2 x.  (fp32 requests keep the four
-// packed-fp32 passes: 235 ms, faster than this fp64 kernel; an fp32 MFMA 4x4x1 form would share the fp32 datapath likewise.)
+// 1.6 x a plain pass's whole inner loop, so nothing on this datapath gets the gradient under ~2.2 x.  (fp32 requests run the GRAD
+// bodies of the packed kernel, k_skyvis_grad_f32pk: plain packed FMAs -- an fp32 MFMA 4x4x1 form would share the fp32 datapath likewise
+// and deliver 256 FMAs per ~9 cycles against v_pk_fma_f32's 128 per 4.)
 // pbflux rows and directions are per lane group here (4 sources per wavefront), so they come through vector loads (4 distinct
 // 16-byte addresses per instruction).
 // ------------------------------------------------------------------------------------------
@@ -826,6 +827,7 @@ __device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __bui
 typedef const __attribute__((address_space(4))) float* cfloat_p;
 typedef const __attribute__((address_space(4))) double* cdouble_p;
 typedef const volatile __attribute__((address_space(4))) double* cvdouble_p;
+typedef const volatile __attribute__((address_space(4))) float* cvfloat_p;
 
 // exp2(D) - 1 to ~1e-8 absolute for the small per-step taper exponents of the grouped form: 5-term series in x = D ln2, clamped
 // to |x| <= 1.  The host selects the grouped form only for df/f_min <= 3.4e-3, where |x| >= 1/8 implies a taper weight below
@@ -846,8 +848,13 @@ __device__ __forceinline__ float exp2m1_small(float D) {
 // baselines).  5e-6 is the tolerance and a sky may be dominated by one source, so the chains are re-formed exactly at their
 // midpoint (hardware sin/cos of the fp64-reduced phase + one exp2): 1 = the down chain only (every taper run, ~4 % of its time),
 // 2 = both chains (baseline groups whose step angle is not guaranteed <= pi/4).
-template <int CT, bool TAPER, bool LIFT, bool TGROUP = false, int REANCHOR = 0>
+// GRAD: visibility AND the three baseline-gradient sums G_k = sum_s dircos[s,k] * (summand) (interferometry.py:6330) in one pass: the
+// term t = p * zeta is formed once (2 packed multiplies per pair) and added into four accumulator sets, the gradient ones through
+// packed FMAs whose coefficient (l, l), (m, m), (n, n) is an SGPR-pair operand -- 13 packed instructions per pair of terms against
+// 4 passes x 5.  CT = 16 (128 accumulator VGPRs); MFMA would not help: it shares the FMA datapath.
+template <int CT, bool TAPER, bool LIFT, bool TGROUP = false, int REANCHOR = 0, bool GRAD = false>
 __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, unsigned char* flush_lds) {
+  constexpr int NR = GRAD ? 4 : 1;                   // accumulator sets: V (+ G_l, G_m, G_n)
   static_assert(!(TAPER && LIFT), "the taper-folded recurrence is a scaled rotation: no lifting form");
   static_assert(TAPER || !TGROUP, "TGROUP is a taper variant");
   static_assert(TAPER || REANCHOR == 0, "REANCHOR is a taper variant");
@@ -886,9 +893,11 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   const float kBf = (float)(-2.0 * 1.4426950408889634 * fc_hz * p.df);
   const float kCf = (float)(-1.4426950408889634 * p.df * p.df);
 
-  f32x2 acc_re[HC], acc_im[HC];
+  f32x2 acc_re[NR][HC], acc_im[NR][HC];
 #pragma unroll
-  for (int j = 0; j < HC; ++j) { acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f); }
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int j = 0; j < HC; ++j) { acc_re[r][j] = (f32x2)(0.f); acc_im[r][j] = (f32x2)(0.f); }
 
   const cfloat_p gp = (cfloat_p)(uintptr_t)(reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT);
   const cdouble_p gd = (cdouble_p)(uintptr_t)p.dirs_prep;
@@ -906,13 +915,17 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));        // opaque: keeps the 64 store addresses from being hoisted out of the segment loop and spilled
 #pragma unroll
+      for (int rs = 0; rs < NR; ++rs) {
+      // destination of accumulator set rs: the visibility slot, or gradient component rs - 1 of this slot
+      double2* const outr = (rs == 0) ? out : reinterpret_cast<double2*>(p.grad_out) + (size_t)(rs - 1) * p.nbl * p.nchan;
+#pragma unroll
       for (int pz = 0; pz < HC / 8; ++pz) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
           const int j = 8 * pz + jj;
-          wbuf[lane * 17 + jj] = make_float2(acc_re[j].x, acc_im[j].x);
-          wbuf[lane * 17 + 8 + jj] = make_float2(acc_re[j].y, acc_im[j].y);
-          acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f);           // dead during the stores below
+          wbuf[lane * 17 + jj] = make_float2(acc_re[rs][j].x, acc_im[rs][j].x);
+          wbuf[lane * 17 + 8 + jj] = make_float2(acc_re[rs][j].y, acc_im[rs][j].y);
+          acc_re[rs][j] = (f32x2)(0.f); acc_im[rs][j] = (f32x2)(0.f);   // dead during the stores below
         }
         wave_lds_sync();
         const int c = lane_o & 15;
@@ -923,10 +936,10 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           const float2 a = wbuf[bi * 17 + c];
           const int64_t bb = bw0 + bi;
           if (bb < p.nbl && k < p.nchan) {
-            if (p.out_f32) {                                       // complex64 partial of a source split: written once, no read-modify-write
+            if (!GRAD && p.out_f32) {                              // complex64 partial of a source split: written once, no read-modify-write
               reinterpret_cast<float2*>(p.out)[((size_t)split * p.nbl + (size_t)bb) * p.nchan + k] = a;
             } else {
-              double2* o = out + (size_t)bb * p.nchan + k;
+              double2* o = outr + (size_t)bb * p.nchan + k;
               double2 v = make_double2((double)a.x, (double)a.y);
               if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
               *o = v;
@@ -936,9 +949,12 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
         }
         wave_lds_sync();
       }
+      }
     }
 #pragma unroll
-    for (int j = 0; j < HC; ++j) { acc_re[j] = (f32x2)(0.f); acc_im[j] = (f32x2)(0.f); }
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int j = 0; j < HC; ++j) { acc_re[r][j] = (f32x2)(0.f); acc_im[r][j] = (f32x2)(0.f); }
     first_flush = false;
   };
 
@@ -959,7 +975,14 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
     // the row is fetched in NPART pieces through two SGPR buffers (piece k in buffer k & 1), one piece ahead of its use
     float ra[NP], rb[NP];
     double sv[4] = {0.0, 0.0, 0.0, 0.0};
+    float cs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // GRAD: (l, l, m, m, n, n) of the source as SGPR pairs
+    const cvfloat_p gcs = (cvfloat_p)(uintptr_t)(GRAD ? p.dirs_c32 + (size_t)s_begin * 8 : nullptr);
     {
+      if constexpr (GRAD) {
+        const cvfloat_p c0 = gcs + (size_t)seg0 * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cs[i] = c0[i];
+      }
       const cfloat_p r0 = gps + (size_t)seg0 * CT;
 #pragma unroll
       for (int i = 0; i < NP; ++i) ra[i] = r0[i];
@@ -974,7 +997,8 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       const int sn = (s + 1 < seg1) ? s + 1 : s;                    // the last source is simply fetched again
       if (pf_on && ((s - seg0) & 3) == 0) {
         // every 4th source: the next 4 rows (64 lanes x 16 B) and 8 directions (64 lanes x 4 B), kPrefetchAhead sources ahead
-        const int spf = (s + kPrefetchAhead < n_loc - 8) ? s + kPrefetchAhead : n_loc - 8;
+        constexpr int kPfRows = (256 / CT) > 8 ? (256 / CT) : 8;          // rows one 1 KiB request covers (>= the 8 directions)
+        const int spf = (s + kPrefetchAhead < n_loc - kPfRows) ? s + kPrefetchAhead : n_loc - kPfRows;
         int lane_pf = lane;
         asm volatile("" : "+v"(lane_pf));                            // formed here from the lane id: no per-lane pointers kept live across the loop
         __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * CT + lane_pf * 4), pf_lds, 16, 0, 0);
@@ -982,6 +1006,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       }
       // the first use of sv waits for everything in flight (first piece + direction); only then ask for the second piece
       const double d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));
+      const f32x2 CL = {cs[0], cs[1]}, CM = {cs[2], cs[3]}, CN = {cs[4], cs[5]};     // this source's coefficients (GRAD)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NP; ++i) rb[i] = row[NP + i];
@@ -1083,8 +1108,16 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
             const int m = j % 8;
             if (m != 0) pp = pkfma(pp, EK[kmap[m]], pp);
           }
-          acc_re[j] = pkfma(pp, zre, acc_re[j]);
-          acc_im[j] = pkfma(pp, zim, acc_im[j]);
+          if constexpr (GRAD) {
+            const f32x2 tre = pp * zre, tim = pp * zim;
+            acc_re[0][j] += tre; acc_im[0][j] += tim;
+            acc_re[1][j] = pkfma(tre, CL, acc_re[1][j]); acc_im[1][j] = pkfma(tim, CL, acc_im[1][j]);
+            acc_re[2][j] = pkfma(tre, CM, acc_re[2][j]); acc_im[2][j] = pkfma(tim, CM, acc_im[2][j]);
+            acc_re[3][j] = pkfma(tre, CN, acc_re[3][j]); acc_im[3][j] = pkfma(tim, CN, acc_im[3][j]);
+          } else {
+            acc_re[0][j] = pkfma(pp, zre, acc_re[0][j]);
+            acc_im[0][j] = pkfma(pp, zim, acc_im[0][j]);
+          }
           if (LIFT) {
             // x1 = x - t y, y1 = y + s x1, x2 = x1 - t y1
             const f32x2 x1 = pkfma(NT, zim, zre);
@@ -1152,6 +1185,11 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           const cvdouble_p dn = gds + (size_t)sn * 4;
           sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
           if (TAPER) sv[3] = dn[3];
+          if constexpr (GRAD) {
+            const cvfloat_p cn = gcs + (size_t)sn * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) cs[i] = cn[i];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ph & 1) pairs(rb, ph * (NP / 2));
@@ -1191,6 +1229,30 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
     return;
   }
   skyvis_rec_f32pk_body<CT, TAPER, false>(p, flush_lds);
+}
+
+// fp32 visibility + baseline gradient in one pass (GRAD bodies of the packed kernel, 16-channel tiles, no source split)
+template <bool TAPER>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
+void k_skyvis_grad_f32pk(const SkyvisParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>() + kPrefetchLdsBytes];
+  int slab_, bg;
+  if (!block_item(p, slab_, bg)) return;
+  const bool small_step = p.lift_flags != nullptr && p.lift_flags[bg] != 0;
+  if constexpr (!TAPER) {
+    if (small_step) skyvis_rec_f32pk_body<16, false, true, false, 0, true>(p, flush_lds);
+    else skyvis_rec_f32pk_body<16, false, false, false, 0, true>(p, flush_lds);
+  } else {
+    // 8 steps per chain: one group of the grouped recurrence and no mid-chain re-anchoring (HC < 32); the REANCHOR = 2 bodies are the ones
+    // that seed the step phasor for any step angle (groups without the |theta| <= 1/8 cycle guarantee)
+    if (p.taper_group) {
+      if (small_step) skyvis_rec_f32pk_body<16, true, false, true, 0, true>(p, flush_lds);
+      else skyvis_rec_f32pk_body<16, true, false, true, 2, true>(p, flush_lds);
+    } else {
+      if (small_step) skyvis_rec_f32pk_body<16, true, false, false, 0, true>(p, flush_lds);
+      else skyvis_rec_f32pk_body<16, true, false, false, 2, true>(p, flush_lds);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1294,15 +1356,23 @@ __global__ void k_pack(const double* __restrict__ pb, T* __restrict__ packed, in
 }
 
 // dirs_prep[s] = ((l,m,n) - s_pc)/c, kappa   for s < nsrc;  zeros for nsrc <= s < nsrc_pad
-__global__ void k_prep_dirs(const double* __restrict__ dirs, double* __restrict__ prep, int64_t nsrc, int64_t nsrc_pad,
-                            double pcx, double pcy, double pcz, double inv_c) {
+// c32 (optional): [nsrc_pad][8] floats (l, l, m, m, n, n, 0, 0): the gradient coefficients as ready SGPR-pair operands
+__global__ void k_prep_dirs(const double* __restrict__ dirs, double* __restrict__ prep, float* __restrict__ c32, int64_t nsrc,
+                            int64_t nsrc_pad, double pcx, double pcy, double pcz, double inv_c) {
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nsrc_pad; s += (int64_t)gridDim.x * blockDim.x) {
     double4 v = make_double4(0, 0, 0, 0);
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (s < nsrc) {
       const double4 r = reinterpret_cast<const double4*>(dirs)[s];
       v = make_double4((r.x - pcx) * inv_c, (r.y - pcy) * inv_c, (r.z - pcz) * inv_c, r.w);
+      c0 = make_float4((float)r.x, (float)r.x, (float)r.y, (float)r.y);
+      c1 = make_float4((float)r.z, (float)r.z, 0.f, 0.f);
     }
     reinterpret_cast<double4*>(prep)[s] = v;
+    if (c32) {
+      reinterpret_cast<float4*>(c32)[2 * s] = c0;
+      reinterpret_cast<float4*>(c32)[2 * s + 1] = c1;
+    }
   }
 }
 
@@ -1383,14 +1453,23 @@ hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_
   return hipErrorInvalidValue;
 }
 
+hipError_t launch_skyvis_grad_f32(const SkyvisParams& p, hipStream_t stream) {
+  // p.nbgroups = groups of 256 baselines, p.nsplit = 1, 16-channel tiles, p.dirs_c32 and p.grad_out set
+  const int64_t items = (int64_t)p.ntiles * p.nbgroups;
+  if (items <= 0 || items > 0x3fffffffLL || p.nsplit != 1 || !p.dirs_c32 || !p.grad_out) return hipErrorInvalidValue;
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
+  if (p.taper) hipLaunchKernelGGL((k_skyvis_grad_f32pk<true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
+  else hipLaunchKernelGGL((k_skyvis_grad_f32pk<false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_skyvis_grad_f64(const SkyvisParams& p, int ct, hipStream_t stream) {
   // p.nbgroups = groups of 64 baselines, p.nsplit = 1
   const int64_t items = (int64_t)p.ntiles * p.nbgroups;
   if (items <= 0 || items > 0x3fffffffLL || p.nsplit != 1) return hipErrorInvalidValue;
   const unsigned grid = 8u * (unsigned)((items + 7) / 8);
-  if (ct == 32) {
-    if (p.taper) hipLaunchKernelGGL((k_skyvis_grad_f64<32, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
-    else hipLaunchKernelGGL((k_skyvis_grad_f64<32, false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
+  if (ct == 32 && !p.taper) {           // (the taper's per-lane recurrence state does not fit beside 128 accumulator VGPRs at 32 channels)
+    hipLaunchKernelGGL((k_skyvis_grad_f64<32, false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   } else if (ct == 16) {
     if (p.taper) hipLaunchKernelGGL((k_skyvis_grad_f64<16, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
     else hipLaunchKernelGGL((k_skyvis_grad_f64<16, false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
@@ -1459,10 +1538,10 @@ hipError_t launch_fsq_pairs(const float* fsq, float* pairs, int ct, int ntiles, 
   return hipGetLastError();
 }
 
-hipError_t launch_prep_dirs(const double* dirs, double* prep, int64_t nsrc, int64_t nsrc_pad, double pcx, double pcy,
+hipError_t launch_prep_dirs(const double* dirs, double* prep, float* c32, int64_t nsrc, int64_t nsrc_pad, double pcx, double pcy,
                             double pcz, double inv_c, hipStream_t stream) {
   if (nsrc_pad == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_prep_dirs, dim3(grid_for(nsrc_pad)), dim3(256), 0, stream, dirs, prep, nsrc, nsrc_pad, pcx, pcy,
+  hipLaunchKernelGGL(k_prep_dirs, dim3(grid_for(nsrc_pad)), dim3(256), 0, stream, dirs, prep, c32, nsrc, nsrc_pad, pcx, pcy,
                      pcz, inv_c);
   return hipGetLastError();
 }

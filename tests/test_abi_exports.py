@@ -92,11 +92,13 @@ def test_sky_sum_kernels_use_no_scratch(tmp_path):
     found = 0
     for row in KM.kernel_meta(text):
         name = row['name']
-        if 'k_skyvis_rec' not in name:
+        if 'k_skyvis_' not in name or 'direct' in name:
             continue
         found += 1
         assert row['scratch'] == 0, name
         assert row['vgpr_spill'] == 0, name
+        if 'grad_f64' in name:
+            continue                            # the MFMA kernel streams rows through vector loads: no scalar-row source loop to inspect
         # SGPR spills (v_readlane / v_writelane through a spare VGPR) are tolerated in the prologue and around the flush, never in
         # the source loops: round 1's fp64 kernels moved 103-134 SGPRs per source through lanes because their half-row operand
         # buffers (2 x 32 SGPRs) did not fit
@@ -117,4 +119,4 @@ def test_sky_sum_kernels_use_no_scratch(tmp_path):
         for cl in clusters:
             a, b = min(cl, key=lambda ab: ab[1] - ab[0])
             assert KM.census('\n'.join(lines[a:b + 1])).get('v_lane', 0) <= 1, (name, a, b)
-    assert found >= 14
+    assert found >= 19

@@ -96,9 +96,9 @@ def test_oracle_parity_all_variants(ctx, shape, taper):
 @pytest.mark.parametrize('shape', [(3, 64, 100), (171, 256, 601), (70, 100, 33), (1, 1, 1), (257, 33, 66)])
 @pytest.mark.parametrize('taper', [False, True])
 def test_fused_mfma_gradient_matches_oracle_and_four_pass_form(ctx, monkeypatch, shape, taper):
-    """interferometry.py:6330, 6338, 6343.  V and the three gradient sums come out of ONE pass (k_skyvis_grad_f64: the four sums are
-    a 4 x 4 x 4 fp64 MFMA per channel with lanes = 16 baselines x 4 sources) -- against the numpy oracle, and against the four
-    separate passes it replaces; ragged sizes (baselines not a multiple of 16, sources not a multiple of 4, channels not a multiple
+    """interferometry.py:6330, 6338, 6343.  V and the three gradient sums come out of ONE pass (fp64: k_skyvis_grad_f64, the four sums are
+    a 4 x 4 x 4 fp64 MFMA per channel with lanes = 16 baselines x 4 sources; fp32: k_skyvis_grad_f32pk, four accumulator sets fed by one
+    packed term) -- against the numpy oracle, and against the four separate passes they replace; ragged sizes (baselines not a multiple of 16, sources not a multiple of 4, channels not a multiple
     of the tile), long baselines (no lifting), source chunks that do not divide by four, both precisions' entry."""
     nbl, nchan, nsrc = shape
     bl, ch, dc, pb, pc, fw = _random_case(23, nbl, nchan, nsrc, taper)
@@ -108,7 +108,7 @@ def test_fused_mfma_gradient_matches_oracle_and_four_pass_form(ctx, monkeypatch,
     ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
     for chunk in (0, 7):
         ctx.set_tuning(0, chunk, 0)
-        for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):               # fp32 requests keep the four packed-fp32 passes
+        for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):               # fp64: MFMA kernel; fp32: GRAD bodies of the packed kernel
             ctx.compute(precision=prec, want_grad=True)
             v, g = ctx.get_vis(want_grad=True)
             assert relerr(v, ref, pb) <= TOL[prec] and max(relerr(g[k], gref[k], pb) for k in range(3)) <= TOL[prec], (shape, taper, prec, chunk)
@@ -118,8 +118,15 @@ def test_fused_mfma_gradient_matches_oracle_and_four_pass_form(ctx, monkeypatch,
     monkeypatch.setenv('PRISIM_HIP_FUSED_GRAD', '0')
     ctx.compute(precision=_abi.PRISIM_FP64, want_grad=True)
     v4, g4 = ctx.get_vis(want_grad=True)
+    ctx.compute(precision=_abi.PRISIM_FP32, want_grad=True)
+    v4s, g4s = ctx.get_vis(want_grad=True)
     monkeypatch.delenv('PRISIM_HIP_FUSED_GRAD')
     assert relerr(v4, v, pb) <= 1e-12 and max(relerr(g4[k], g[k], pb) for k in range(3)) <= 1e-12
+    monkeypatch.setenv('PRISIM_HIP_FLUSH_SRC', '16')                 # fp32: several read-modify-write flushes of all four cubes
+    ctx.compute(precision=_abi.PRISIM_FP32, want_grad=True)
+    vs, gs = ctx.get_vis(want_grad=True)
+    assert relerr(vs, ref, pb) <= TOL[_abi.PRISIM_FP32] and max(relerr(gs[k], gref[k], pb) for k in range(3)) <= TOL[_abi.PRISIM_FP32]
+    assert relerr(vs, v4s, pb) <= 2 * TOL[_abi.PRISIM_FP32]
 
 
 @pytest.mark.parametrize('taper', [False, True])

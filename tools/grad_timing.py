@@ -13,7 +13,8 @@ for taper in (False, True):
     ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, 14.0, zen, zen,
                          fwhm_deg=(NP.full(sky['dircos'].shape[0], 0.46) if taper else None))
     for name, prec, grad, env in (('plain_fp64', _abi.PRISIM_FP64, False, None), ('plain_fp32', _abi.PRISIM_FP32, False, None),
-                                  ('fused_grad', _abi.PRISIM_FP64, True, None), ('four_pass_fp64', _abi.PRISIM_FP64, True, '0'),
+                                  ('fused_grad_fp64', _abi.PRISIM_FP64, True, None), ('fused_grad_fp32', _abi.PRISIM_FP32, True, None),
+                                  ('four_pass_fp64', _abi.PRISIM_FP64, True, '0'),
                                   ('four_pass_fp32', _abi.PRISIM_FP32, True, '0')):
         if env is not None:
             os.environ['PRISIM_HIP_FUSED_GRAD'] = env

@@ -98,7 +98,7 @@ def main():
         keep = args[args.index('--keep') + 1]
     nloops = int(args[args.index('--loops') + 1]) if '--loops' in args else 0
     text = compile_asm(defs, keep)
-    rows = [r for r in kernel_meta(text) if 'k_skyvis_rec' in r['name']]
+    rows = [r for r in kernel_meta(text) if 'k_skyvis_' in r['name'] and 'direct' not in r['name']]
     dm = demangle([r['name'] for r in rows])
     for r in rows:
         pretty = dm[r['name']].replace('prisim::', '').replace('(prisim::SkyvisParams)', '')
