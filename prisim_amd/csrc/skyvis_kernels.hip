@@ -827,7 +827,8 @@ __device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __bui
 typedef const __attribute__((address_space(4))) float* cfloat_p;
 typedef const __attribute__((address_space(4))) double* cdouble_p;
 typedef const volatile __attribute__((address_space(4))) double* cvdouble_p;
-typedef const volatile __attribute__((address_space(4))) float* cvfloat_p;
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) f32x8* cf32x8_p;
 
 // exp2(D) - 1 to ~1e-8 absolute for the small per-step taper exponents of the grouped form: 5-term series in x = D ln2, clamped
 // to |x| <= 1.  The host selects the grouped form only for df/f_min <= 3.4e-3, where |x| >= 1/8 implies a taper weight below
@@ -975,14 +976,10 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
     // the row is fetched in NPART pieces through two SGPR buffers (piece k in buffer k & 1), one piece ahead of its use
     float ra[NP], rb[NP];
     double sv[4] = {0.0, 0.0, 0.0, 0.0};
-    float cs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // GRAD: (l, l, m, m, n, n) of the source as SGPR pairs
-    const cvfloat_p gcs = (cvfloat_p)(uintptr_t)(GRAD ? p.dirs_c32 + (size_t)s_begin * 8 : nullptr);
+    f32x8 cs = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // GRAD: (l, l, m, m, n, n, 0, 0) of the source: three SGPR pairs, one s_load_dwordx8
+    const cf32x8_p gcs = (cf32x8_p)(uintptr_t)(GRAD ? p.dirs_c32 + (size_t)s_begin * 8 : nullptr);
     {
-      if constexpr (GRAD) {
-        const cvfloat_p c0 = gcs + (size_t)seg0 * 8;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) cs[i] = c0[i];
-      }
+      if constexpr (GRAD) cs = gcs[seg0];
       const cfloat_p r0 = gps + (size_t)seg0 * CT;
 #pragma unroll
       for (int i = 0; i < NP; ++i) ra[i] = r0[i];
@@ -1185,11 +1182,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           const cvdouble_p dn = gds + (size_t)sn * 4;
           sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
           if (TAPER) sv[3] = dn[3];
-          if constexpr (GRAD) {
-            const cvfloat_p cn = gcs + (size_t)sn * 8;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) cs[i] = cn[i];
-          }
+          if constexpr (GRAD) cs = gcs[sn];
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ph & 1) pairs(rb, ph * (NP / 2));
