@@ -19,6 +19,8 @@ Pinning status (see DESIGN.md, section "Oracle"):
       - VLA / GMRT polynomial beams           primary_beams.py:445-513, 734-808
       - phased-array beamformer               primary_beams.py:1482-1754 (seeded jitter draws included)
       - phase-centre rotation                 interferometry.py:7871-7877
+      - HDF5 layout of save()                 interferometry.py:8723-8854 (tests/golden/make_hdf5_schema.py: the statements
+                                              executed against a recording h5py stand-in -> tests/golden/hdf5_schema.json)
   * PARITY UNPINNED (un-vendored, un-pinned third-party dependency
     ``astroutils``; the reference has no tests or golden vectors for them):
       - altaz<->dircos / hadec->altaz geometry (convention taken from in-tree

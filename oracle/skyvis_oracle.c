@@ -9,6 +9,11 @@
  * OpenMP over baselines = the reference's own parallel model (mpirun ranks over baseline chunks,
  * scripts/run_prisim.py:1775-1791), one thread standing in for one rank.
  *
+ * One knowing difference from the reference: |b|^2 - (c tau)^2 (:6265) is clamped at 0 here (and in the HIP kernels).  It is >= 0
+ * mathematically and can only go negative by rounding (a source exactly along a baseline); the reference takes its square root
+ * and yields NaN for that term.  The numpy restatement (skyvis_oracle.py, the one pinned to the golden vectors) keeps the
+ * reference's behaviour; this C port is pinned to the numpy restatement at 1e-12 on the golden inputs, where the case does not occur.
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
  * Build: make -C oracle   (gcc -O3 -march=native -fopenmp)
  */
