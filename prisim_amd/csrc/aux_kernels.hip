@@ -352,7 +352,7 @@ hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs
 
 // ---- delay transform -----------------------------------------------------------------------
 // work[row][n] (complex128, nfft per row) = cube[row][n] * w[b][n] for n < nchan, else 0.
-__global__ void k_dt_prepare(const double2* __restrict__ cube, const double* __restrict__ bpwts,
+__global__ void k_dt_prepare(const double2* __restrict__ cube, const double* __restrict__ bpwts, int64_t wts_rows,
                              double2* __restrict__ work, int64_t nrows, int64_t nbl, int64_t nchan, int64_t nfft) {
   const int64_t total = nrows * nfft;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -362,7 +362,7 @@ __global__ void k_dt_prepare(const double2* __restrict__ cube, const double* __r
     if (n < nchan) {
       v = cube[row * nchan + n];
       if (bpwts) {
-        const double w = bpwts[(row % nbl) * nchan + n];
+        const double w = bpwts[(wts_rows == 1 ? 0 : (row % nbl)) * nchan + n];      // one window for every baseline, or one per baseline
         v.x *= w; v.y *= w;
       }
     }
@@ -405,10 +405,10 @@ static unsigned grid_for(int64_t n) {
   return (unsigned)g;
 }
 
-hipError_t launch_dt_prepare(const double* cube, const double* bpwts, double* work, int64_t nrows, int64_t nbl,
+hipError_t launch_dt_prepare(const double* cube, const double* bpwts, int64_t wts_rows, double* work, int64_t nrows, int64_t nbl,
                              int64_t nchan, int64_t nfft, hipStream_t stream) {
   hipLaunchKernelGGL(k_dt_prepare, dim3(grid_for(nrows * nfft)), dim3(256), 0, stream,
-                     reinterpret_cast<const double2*>(cube), bpwts, reinterpret_cast<double2*>(work), nrows, nbl, nchan,
+                     reinterpret_cast<const double2*>(cube), bpwts, wts_rows, reinterpret_cast<double2*>(work), nrows, nbl, nchan,
                      nfft);
   return hipGetLastError();
 }

@@ -1150,13 +1150,9 @@ int delay_prepare(prisim_ctx* ctx, const DelayGeom& g, const double* bpwts, int6
   int rc;
   const int64_t nchan = ctx->nchan, nbl = ctx->nbl;
   if (bpwts) {
-    // one window row for every baseline (wts_rows == 1) is replicated on the device only for the rocFFT pipeline's k_dt_prepare
     if (wts_rows != 1 && wts_rows != nbl) return fail(ctx, PRISIM_EINVAL, "wts_rows must be 1 or nbl");
-    const int64_t dev_rows = (g.fused || wts_rows == nbl) ? wts_rows : nbl;
-    if ((rc = ensure(ctx, ctx->dt_wts, (size_t)dev_rows * nchan * sizeof(double)))) return rc;
-    for (int64_t r = 0; r < (wts_rows == 1 ? dev_rows : 1); ++r)
-      HIPCHK(ctx, hipMemcpyAsync((double*)ctx->dt_wts.p + (size_t)r * nchan, bpwts, (size_t)(wts_rows == 1 ? 1 : nbl) * nchan * sizeof(double),
-                                 hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ensure(ctx, ctx->dt_wts, (size_t)wts_rows * nchan * sizeof(double)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dt_wts.p, bpwts, (size_t)wts_rows * nchan * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // bpwts is caller-owned
   }
   if (g.fused) {
@@ -1222,7 +1218,7 @@ int delay_batch(prisim_ctx* ctx, const DelayGeom& g, int64_t t0, int64_t nrows, 
         return fail(ctx, PRISIM_ELIB, "rocfft_execution_info_set_work_buffer failed");
     }
   }
-  HIPCHK(ctx, launch_dt_prepare(src, wts, (double*)ctx->fft_buf.p, nrows, nbl, nchan, g.nfft, ctx->stream));
+  HIPCHK(ctx, launch_dt_prepare(src, wts, wts_rows, (double*)ctx->fft_buf.p, nrows, nbl, nchan, g.nfft, ctx->stream));
   void* bufs[1] = {ctx->fft_buf.p};
   if (F.execute(ctx->fft_plan, bufs, nullptr, ctx->fft_info) != rocfft_status_success)
     return fail(ctx, PRISIM_ELIB, "rocfft_execute failed");

@@ -63,7 +63,6 @@ __device__ __forceinline__ void dft4(double2& v0, double2& v1, double2& v2, doub
 }
 
 template <int R> __device__ __forceinline__ void dft_small(double2 (&v)[16]);
-template <> __device__ __forceinline__ void dft_small<1>(double2 (&)[16]) {}
 template <> __device__ __forceinline__ void dft_small<2>(double2 (&v)[16]) { dft2(v[0], v[1]); }
 template <> __device__ __forceinline__ void dft_small<4>(double2 (&v)[16]) { dft4(v[0], v[1], v[2], v[3]); }
 template <> __device__ __forceinline__ void dft_small<8>(double2 (&v)[16]) {

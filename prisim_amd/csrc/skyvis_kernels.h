@@ -95,8 +95,8 @@ hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs
                               int64_t nsrc, int64_t nchan, hipStream_t stream);
 
 // delay transform helpers (delay_kernels.hip)
-hipError_t launch_dt_prepare(const double* cube, const double* bpwts, double* work, int64_t nrows, int64_t nbl,
-                             int64_t nchan, int64_t nfft, hipStream_t stream);
+hipError_t launch_dt_prepare(const double* cube, const double* bpwts /*device [wts_rows][nchan] or NULL*/, int64_t wts_rows /*1 or nbl*/,
+                             double* work, int64_t nrows, int64_t nbl, int64_t nchan, int64_t nfft, hipStream_t stream);
 hipError_t launch_dt_finish(const double* work, double* out, double* out_power, int64_t nrows, int64_t nfft,
                             int64_t nout, double factor, double scale, double power_scale, hipStream_t stream);
 // fused delay transform for power-of-two channel counts and integer 1 + pad (delay_kernels.hip)

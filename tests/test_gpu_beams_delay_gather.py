@@ -102,6 +102,7 @@ def test_fused_lds_delay_fft_matches_numpy_and_rocfft_pipeline(ctx, monkeypatch,
         out_r, _, pw_r = ctx.delay_transform(nt, bpwts=wfull, pad=pad, want_power=True, power_scale=0.5)
         ctx.delay_transform_device(nt, bpwts=w, pad=pad)
         assert ctx.timing()['last_delay_fused'] == 0
+        assert NP.array_equal(ctx.get_lags(0, nt), out_r)             # (the one-row window goes to the rocFFT pipeline as one row too)
         monkeypatch.delenv('PRISIM_HIP_DT_FUSED')
         assert NP.max(NP.abs(out - out_r)) <= 1e-12 * NP.max(NP.abs(ref))
     with pytest.raises(RuntimeError):
