@@ -14,7 +14,7 @@
 //   A: thread j: 16-point DFT over n = j + (N/16) q, twiddle W_N^(j p), to LDS [p][j]
 //   B: thread (p, a): 16-point DFT over j = a + R q', twiddle W_N^(16 a p'), to LDS [a][p + 16 p']
 //   C: thread L: R-point DFTs over a for c = p + 16 p' = L + (N/16) m; output index k = c + 256 r
-// Both exchanges are laid out so that every 64-lane 16-byte access spreads evenly over the LDS banks (row pitches M + 1 and 257).
+// Both exchanges are laid out so that every group of 8 lanes of a 16-byte access hits 8 different bank slots (pitches M + R, 256 + 8/R).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "skyvis_kernels.h"
@@ -115,8 +115,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ?
   constexpr int M = N / 16;             // threads per row = points per first-stage column
   constexpr int R = N / 256;            // radix of the last stage
   constexpr int RPB = 256 / M;          // rows per block pass
-  constexpr int PITCH = N + 16;         // elements of LDS per row: max(16 (M + 1), 257 R) <= N + 16
-  static_assert(257 * R <= PITCH && 16 * (M + 1) <= PITCH, "exchange layouts fit the row buffer");
+  // LDS exchange pitches.  A 64-lane 16-byte access is served 8 lanes per clock (128 B/clk): it is conflict-free when every group of 8
+  // consecutive lanes touches 8 different 16-byte slots modulo 128 B.  Stage-B lanes are (p, a) = (lane / R, lane % R) and read
+  // [p * PA + a + R q]: PA = M + R puts consecutive p at slot offsets R apart; they write [a * PB + p + 16 p']: PB = 256 + 8 / R does the
+  // same for consecutive a (any odd pitch when R >= 8, where 8 lanes share one p).  Measured with the first layout (pitches M + 1 and 257):
+  // SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE.
+  constexpr int PA = M + R;
+  constexpr int PB = 256 + (R >= 8 ? 1 : (R >= 2 ? 8 / R : 1));
+  constexpr int PITCH = (16 * PA > R * PB) ? 16 * PA : R * PB;      // elements of LDS per row
+  static_assert(16 * PA <= PITCH && R * PB <= PITCH, "exchange layouts fit the row buffer");
   __shared__ double2 tw[N / 2];
   __shared__ double2 xbuf[RPB * PITCH];
 
@@ -165,12 +172,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ?
     if (pass + gridDim.x < npass) fetch(pass + gridDim.x);       // in flight while this pass is transformed
     dft_small<16>(v);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) xb[p * (M + 1) + j] = (p == 0) ? v[0] : cmul(v[p], twid(j * p));
+    for (int p = 0; p < 16; ++p) xb[p * PA + j] = (p == 0) ? v[0] : cmul(v[p], twid(j * p));
     __syncthreads();
     // ---- stage B: thread (p, a): 16-point DFT over j = a + R q'
     const int p = j / R, a = j % R;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = xb[p * (M + 1) + a + R * q];
+    for (int q = 0; q < 16; ++q) v[q] = xb[p * PA + a + R * q];
     dft_small<16>(v);
     if constexpr (R == 1) {
       // k = p + 16 p': done.  out[(k + N/2) mod N]
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ?
     } else {
       __syncthreads();                  // every thread of the row has read its stage-A values
 #pragma unroll
-      for (int pp = 0; pp < 16; ++pp) xb[a * 257 + p + 16 * pp] = (pp == 0) ? v[0] : cmul(v[pp], twid(16 * a * pp));
+      for (int pp = 0; pp < 16; ++pp) xb[a * PB + p + 16 * pp] = (pp == 0) ? v[0] : cmul(v[pp], twid(16 * a * pp));
       __syncthreads();
       // ---- stage C: thread L = j: R-point DFTs over a for c = L + M m, m < 16 / R; k = c + 256 r
 #pragma unroll
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ?
         const int c = j + M * m;
         double2 u[16];
 #pragma unroll
-        for (int aa = 0; aa < R; ++aa) u[aa] = xb[aa * 257 + c];
+        for (int aa = 0; aa < R; ++aa) u[aa] = xb[aa * PB + c];
         dft_small<R>(u);
         if (live) {
 #pragma unroll
