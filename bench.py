@@ -26,6 +26,8 @@ Rank 0 prints ONE JSON line.  Beside the contract's keys it carries (N = 1 only,
   e2e                       the same snapshots through InterferometerArray.observe(), host geometry and sky staging included
   delay_ps                  delay power spectra of the K resident snapshots (interferometry.py:8114-8134 + delay_spectrum.py:3992):
                             device time, FFT count, achieved algorithmic GB/s against the 8 TB/s HBM roofline
+  other_kernels             one timed launch each of the fp64 kernel (headline sky) and of the packed fp32 taper kernel (config 3 with its
+                            nside-128 diffuse half): the kernels the headline workload itself does not run
 """
 import argparse
 import hashlib
@@ -145,6 +147,38 @@ def profiled_traffic(kernel_tag):
         except Exception:
             pass
     return best
+
+
+def other_kernels(ctx, cfg, zen):
+    """Driver-run figures for the sky-sum kernels the headline workload does not exercise (same array, same context, one timed launch each
+    after one warm-up): the fp64 kernel on the headline sky, and the packed fp32 kernel with the source-shape taper on BASELINE config 3
+    as worded -- 1e4 point sources + nside=128 diffuse (108 048 sources above the horizon), the kernel every diffuse configuration runs."""
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    res = {}
+
+    def timed(prec):
+        best = None
+        for rep in range(2):
+            ctx.compute(precision=prec, slot=0)
+            ctx.sync()
+            best = ctx.timing()
+        return best
+
+    tm = timed(_abi.PRISIM_FP64)
+    terms = float(tm['last_terms'])
+    res['fp64'] = {'kernel': 'k_skyvis_rec<double,%d>' % tm['last_chan_tile'], 'kernel_ms': tm['last_kernel_ms'], 'terms_per_s': terms / (tm['last_kernel_ms'] * 1e-3),
+                   'roofline_frac': terms * FLOPS_PER_TERM / (tm['last_kernel_ms'] * 1e-3) / 1e12 / PEAK_TFLOPS['f64'], 'workload': cfg['name']}
+    cfg_d = W.config3(with_diffuse=True)
+    sky_d = cfg_d['sky']
+    ctx.set_sky_analytic(sky_d['dircos'], sky_d['flux_ref'], sky_d['spindex'], sky_d['ref_freq'], _abi.PRISIM_BEAM_AIRY, cfg_d['diameter'], zen, zen,
+                         fwhm_deg=sky_d['fwhm_deg'])
+    tm = timed(_abi.PRISIM_FP32)
+    terms = float(tm['last_terms'])
+    res['fp32_taper'] = {'kernel': 'k_skyvis_rec_f32pk<%d,taper>' % tm['last_chan_tile'], 'kernel_ms': tm['last_kernel_ms'],
+                         'terms_per_s': terms / (tm['last_kernel_ms'] * 1e-3), 'grouped_recurrence': bool(tm['last_taper_group']),
+                         'roofline_frac_vs_no_taper_contract': terms * FLOPS_PER_TERM / (tm['last_kernel_ms'] * 1e-3) / 1e12 / PEAK_TFLOPS['f32'],
+                         'workload': cfg_d['name'] + ' (taper on)'}
+    return res
 
 
 def e2e_observe(cfg, n_snap, device, memsave):
@@ -356,6 +390,10 @@ def main():
                                                 'algorithmic_bytes': dbytes}}
             except Exception as exc:
                 out['delay_ps'] = {'device_ms': None, 'error': repr(exc)}
+            try:
+                out['other_kernels'] = other_kernels(ctx, cfg, zen)
+            except Exception as exc:
+                out['other_kernels'] = {'error': repr(exc)}
             ctx.close()
             try:
                 out['e2e'] = e2e_observe(cfg, 3, device, memsave=(prec == _abi.PRISIM_FP32))

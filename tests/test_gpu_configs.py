@@ -67,7 +67,7 @@ def test_config4_drift_external_beam():
 
 
 def test_config3_with_diffuse_half_one_snapshot():
-    """BASELINE config 3 as worded: 1e4 point sources + nside=128 diffuse sky (108 304 sources above the horizon, taper on)
+    """BASELINE config 3 as worded: 1e4 point sources + nside=128 diffuse sky (108 048 sources above the horizon, taper on)
     on all 61 075 HERA-350 baselines x 1024 channels, fp32, spot-checked on 4 baselines."""
     cfg = W.config3(with_diffuse=True)
     bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
