@@ -206,7 +206,7 @@ int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts,
  * exchanged with prisim_hip_allgather_lags -- config 5's 120 x 61075 spectra never cross PCIe unless asked for.
  * bpwts: host window [wts_rows][nchan] with wts_rows = 1 (one window for every baseline: 8 KB instead of 500 MB at HERA-350)
  * or nbl, or NULL.  lags_out [nchan] / nout_out may be NULL.  Asynchronous on the context stream.
- * When 1 + pad is an integer and nchan is 256 ... 4096 (a power of two) the stage is ONE kernel (delay_kernels.hip): every
+ * When 1 + pad is an integer and nchan is 256 R with R in {1, 2, 3, 4, 8, 16} the stage is ONE kernel (delay_kernels.hip): every
  * visibility is read once and every lag written once -- the kept samples of the zero-padded transform are exactly the
  * nchan-point transform; other shapes run window/pad -> rocFFT -> shift/decimate. */
 int prisim_hip_delay_transform_device(prisim_ctx* ctx, int64_t nt, const double* bpwts, int64_t wts_rows, double pad, int want_lag, int want_power,

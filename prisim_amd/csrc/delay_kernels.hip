@@ -1,4 +1,4 @@
-// delay_kernels.hip -- fused delay transform for power-of-two channel counts (gfx950).
+// delay_kernels.hip -- fused delay transform for channel counts 256 R, R in {1, 2, 3, 4, 8, 16} (gfx950).
 //
 // Reference path replaced: prisim/interferometry.py:8114-8134 (InterferometerArray.delay_transform):
 //   x = V * bp * bp_wts  ->  zero-pad to N' = N (1 + pad)  ->  ifft * N' * df  ->  fftshift  ->  keep every (1 + pad)-th lag.
@@ -10,7 +10,7 @@
 // (5 N log2 N flops against 32 N bytes: 1.6 flop/byte at N = 1024).
 //
 // One row (baseline, snapshot) = N complex128 = N/16 threads x 16 points, three register stages with two LDS exchanges:
-//   N = 16 * 16 * R,  R = N / 256 in {1, 2, 4, 8, 16}
+//   N = 16 * 16 * R,  R = N / 256 in {1, 2, 3, 4, 8, 16}   (768 = the MWA's 24 x 32 fine channels)
 //   A: thread j: 16-point DFT over n = j + (N/16) q, twiddle W_N^(j p), to LDS [p][j]
 //   B: thread (p, a): 16-point DFT over j = a + R q', twiddle W_N^(16 a p'), to LDS [a][p + 16 p']
 //   C: thread L: R-point DFTs over a for c = p + 16 p' = L + (N/16) m; output index k = c + 256 r
@@ -64,6 +64,15 @@ __device__ __forceinline__ void dft4(double2& v0, double2& v1, double2& v2, doub
 
 template <int R> __device__ __forceinline__ void dft_small(double2 (&v)[16]);
 template <> __device__ __forceinline__ void dft_small<2>(double2 (&v)[16]) { dft2(v[0], v[1]); }
+template <> __device__ __forceinline__ void dft_small<3>(double2 (&v)[16]) {
+  // w = exp(+2 pi i / 3) = (-1/2, +sqrt(3)/2):  X1 = a + w b + w^2 c,  X2 = a + w^2 b + w c
+  const double2 a = v[0], sbc = cadd(v[1], v[2]), dbc = csub(v[1], v[2]);
+  const double2 m = make_double2(__builtin_fma(-0.5, sbc.x, a.x), __builtin_fma(-0.5, sbc.y, a.y));       // a - (b + c)/2
+  const double2 q = make_double2(-0.86602540378443864676 * dbc.y, 0.86602540378443864676 * dbc.x);          // i sqrt(3)/2 (b - c)
+  v[0] = cadd(a, sbc);
+  v[1] = cadd(m, q);
+  v[2] = csub(m, q);
+}
 template <> __device__ __forceinline__ void dft_small<4>(double2 (&v)[16]) { dft4(v[0], v[1], v[2], v[3]); }
 template <> __device__ __forceinline__ void dft_small<8>(double2 (&v)[16]) {
   // n = j + 2 q (j < 2, q < 4), k = p + 4 r:  X[p + 4 r] = sum_j W_8^(j p) W_2^(j r) [ sum_q v[j + 2 q] W_4^(q p) ]
@@ -111,29 +120,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ?
                                                     const double2* __restrict__ tw_g, double2* __restrict__ out,
                                                     double* __restrict__ out_pow, int64_t nrows, int64_t nbl, double scale,
                                                     double power_scale) {
-  static_assert(N >= 256 && N <= 4096 && (N & (N - 1)) == 0, "N = 256 ... 4096, a power of two");
+  static_assert(N % 256 == 0 && N >= 256 && N <= 4096, "N = 256 R");
   constexpr int M = N / 16;             // threads per row = points per first-stage column
-  constexpr int R = N / 256;            // radix of the last stage
-  constexpr int RPB = 256 / M;          // rows per block pass
+  constexpr int R = N / 256;            // radix of the last stage: 1, 2, 3 (768 channels), 4, 8, 16
+  static_assert(R == 1 || R == 2 || R == 3 || R == 4 || R == 8 || R == 16, "last-stage radix");
+  constexpr int RPB = 256 / M;          // rows per block pass (R = 3: 5 rows, 16 of the 256 threads only keep the barriers company)
+  constexpr int NC = (256 + M - 1) / M; // stage-C passes of a thread over the 256 (p, p') columns
   // LDS exchange pitches.  A 64-lane 16-byte access is served 8 lanes per clock (128 B/clk): it is conflict-free when every group of 8
   // consecutive lanes touches 8 different 16-byte slots modulo 128 B.  Stage-B lanes are (p, a) = (lane / R, lane % R) and read
   // [p * PA + a + R q]: PA = M + R puts consecutive p at slot offsets R apart; they write [a * PB + p + 16 p']: PB = 256 + 8 / R does the
-  // same for consecutive a (any odd pitch when R >= 8, where 8 lanes share one p).  Measured with the first layout (pitches M + 1 and 257):
-  // SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE.
+  // same for consecutive a (R = 3: 259; any odd pitch when R >= 8, where 8 lanes share one p).  Measured with the first layout
+  // (pitches M + 1 and 257): SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE.
   constexpr int PA = M + R;
-  constexpr int PB = 256 + (R >= 8 ? 1 : (R >= 2 ? 8 / R : 1));
+  constexpr int PB = 256 + (R >= 8 ? 1 : (R == 3 ? 3 : (R >= 2 ? 8 / R : 1)));
   constexpr int PITCH = (16 * PA > R * PB) ? 16 * PA : R * PB;      // elements of LDS per row
   static_assert(16 * PA <= PITCH && R * PB <= PITCH, "exchange layouts fit the row buffer");
   __shared__ double2 tw[N / 2];
   __shared__ double2 xbuf[RPB * PITCH];
 
   for (int i = threadIdx.x; i < N / 2; i += 256) tw[i] = tw_g[i];
-  const int rl = threadIdx.x / M;       // row of this pass the thread works on
+  constexpr bool ALLT = (RPB * M == 256);                          // every thread has a row (all but R = 3)
+  constexpr bool POW2 = (N & (N - 1)) == 0;
+  const bool tactive = ALLT || (int)threadIdx.x < RPB * M;         // R = 3: threads 240 ... 255 have no row
+  const int rl = (ALLT || tactive) ? threadIdx.x / M : 0;          // row of this pass the thread works on
   const int j = threadIdx.x % M;        // thread within the row
   double2* const xb = xbuf + rl * PITCH;
   auto twid = [&](int m) {              // W_N^m for 0 <= m < N
-    const double2 w = tw[m & (N / 2 - 1)];
-    return (m & (N / 2)) ? make_double2(-w.x, -w.y) : w;
+    if constexpr (POW2) {
+      const double2 w = tw[m & (N / 2 - 1)];
+      return (m & (N / 2)) ? make_double2(-w.x, -w.y) : w;
+    } else {
+      const double2 w = tw[m >= N / 2 ? m - N / 2 : m];
+      return (m >= N / 2) ? make_double2(-w.x, -w.y) : w;
+    }
+  };
+  auto shifted = [&](int k) {           // (k + N/2) mod N
+    if constexpr (POW2) return (k + N / 2) & (N - 1);
+    else return k >= N / 2 ? k - N / 2 : k + N / 2;
   };
   double wfix[16];
   if constexpr (WMODE == 1) {
@@ -160,7 +183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ?
   if ((int64_t)blockIdx.x < npass) fetch(blockIdx.x);
   for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
     const int64_t row = pass * RPB + rl;
-    const bool live = row < nrows;
+    const bool live = tactive && row < nrows;
     double2 v[16];
     // ---- stage A: window, 16-point DFT over q, twiddle W_N^(j p)
 #pragma unroll
@@ -171,8 +194,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ?
     }
     if (pass + gridDim.x < npass) fetch(pass + gridDim.x);       // in flight while this pass is transformed
     dft_small<16>(v);
+    if (tactive) {
 #pragma unroll
-    for (int p = 0; p < 16; ++p) xb[p * PA + j] = (p == 0) ? v[0] : cmul(v[p], twid(j * p));
+      for (int p = 0; p < 16; ++p) xb[p * PA + j] = (p == 0) ? v[0] : cmul(v[p], twid(j * p));
+    }
     __syncthreads();
     // ---- stage B: thread (p, a): 16-point DFT over j = a + R q'
     const int p = j / R, a = j % R;
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ?
 #pragma unroll
         for (int pp = 0; pp < 16; ++pp) {
           const int k = p + 16 * pp;
-          const int64_t o = row * N + ((k + N / 2) & (N - 1));
+          const int64_t o = row * N + shifted(k);
           const double2 r = make_double2(v[pp].x * scale, v[pp].y * scale);
           if (out) out[o] = r;
           if (out_pow) out_pow[o] = (r.x * r.x + r.y * r.y) * power_scale;
@@ -194,22 +219,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ?
       }
     } else {
       __syncthreads();                  // every thread of the row has read its stage-A values
+      if (tactive) {
 #pragma unroll
-      for (int pp = 0; pp < 16; ++pp) xb[a * PB + p + 16 * pp] = (pp == 0) ? v[0] : cmul(v[pp], twid(16 * a * pp));
+        for (int pp = 0; pp < 16; ++pp) xb[a * PB + p + 16 * pp] = (pp == 0) ? v[0] : cmul(v[pp], twid(16 * a * pp));
+      }
       __syncthreads();
-      // ---- stage C: thread L = j: R-point DFTs over a for c = L + M m, m < 16 / R; k = c + 256 r
+      // ---- stage C: thread L = j: R-point DFTs over a for the columns c = L + M m < 256; k = c + 256 r
 #pragma unroll
-      for (int m = 0; m < 16 / R; ++m) {
+      for (int m = 0; m < NC; ++m) {
         const int c = j + M * m;
+        const bool cok = (256 % M == 0) || c < 256;
         double2 u[16];
 #pragma unroll
-        for (int aa = 0; aa < R; ++aa) u[aa] = xb[aa * PB + c];
+        for (int aa = 0; aa < R; ++aa) u[aa] = xb[aa * PB + (cok ? c : 0)];
         dft_small<R>(u);
-        if (live) {
+        if (live && cok) {
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const int k = c + 256 * r;
-            const int64_t o = row * N + ((k + N / 2) & (N - 1));
+            const int64_t o = row * N + shifted(k);
             const double2 res = make_double2(u[r].x * scale, u[r].y * scale);
             if (out) out[o] = res;
             if (out_pow) out_pow[o] = (res.x * res.x + res.y * res.y) * power_scale;
@@ -222,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 1024 ?
 }
 
 bool delay_fft_supported(int64_t nchan) {
-  return nchan == 256 || nchan == 512 || nchan == 1024 || nchan == 2048 || nchan == 4096;
+  return nchan == 256 || nchan == 512 || nchan == 768 || nchan == 1024 || nchan == 2048 || nchan == 4096;
 }
 
 template <int N>
@@ -254,6 +282,7 @@ hipError_t launch_delay_fft(const double* cube, const double* bpwts, int64_t wts
   switch (nchan) {
     case 256: return launch_delay_fft_n<256>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
     case 512: return launch_delay_fft_n<512>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
+    case 768: return launch_delay_fft_n<768>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
     case 1024: return launch_delay_fft_n<1024>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
     case 2048: return launch_delay_fft_n<2048>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);
     case 4096: return launch_delay_fft_n<4096>(cube, bpwts, wr, tw, out, out_pow, nrows, nbl, scale, power_scale, cu_count, stream);

@@ -69,9 +69,9 @@ def test_delay_transform_matches_numpy_restatement(ctx, pad):
     assert NP.max(NP.abs(pw - DO.delay_power(ref, 2.5))) <= 1e-9 * NP.max(NP.abs(ref)) ** 2 * 2.5
 
 
-@pytest.mark.parametrize('nchan', [256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize('nchan', [256, 512, 768, 1024, 2048, 4096])
 def test_fused_lds_delay_fft_matches_numpy_and_rocfft_pipeline(ctx, monkeypatch, nchan):
-    """Power-of-two channel counts with an integer 1 + pad run ONE kernel (delay_kernels.hip: three register stages, two LDS
+    """Channel counts 256 R (R = 1, 2, 3, 4, 8, 16; 768 = the MWA grid) with an integer 1 + pad run ONE kernel (delay_kernels.hip: three register stages, two LDS
     exchanges): against the numpy restatement (zero padding, fftshift and decimation included), against the rocFFT pipeline on the
     same device cube, host-output and device-resident forms, with and without a window, rows not a multiple of the rows per block."""
     rng = NP.random.default_rng(nchan)

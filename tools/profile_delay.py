@@ -11,7 +11,7 @@ import numpy as NP
 from prisim_amd import _abi, workloads as W
 
 nt = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-cfg = W.config5(n_acc=nt)
+cfg = W.config4(n_acc=nt) if (len(sys.argv) > 2 and sys.argv[2] == 'cfg4') else W.config5(n_acc=nt)
 bl, ch = cfg['baselines'], cfg['channels']
 ctx = _abi.Context(0)
 ctx.set_array(bl, ch, nt_max=nt)
