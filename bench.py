@@ -164,7 +164,22 @@ def other_kernels(ctx, cfg, zen):
             best = ctx.timing()
         return best
 
+    def timed_grad(prec):
+        best = None
+        for rep in range(2):
+            ctx.compute(precision=prec, want_grad=True, slot=0)
+            ctx.sync()
+            t = ctx.timing()['last_compute_ms']
+            best = t if best is None else min(best, t)
+        return best
+
+    plain32 = timed(_abi.PRISIM_FP32)['last_compute_ms']
     tm = timed(_abi.PRISIM_FP64)
+    plain64 = tm['last_compute_ms']
+    g64, g32 = timed_grad(_abi.PRISIM_FP64), timed_grad(_abi.PRISIM_FP32)
+    res['gradient'] = {'what': 'visibility + baseline gradient (interferometry.py:6330-6343) in one fused pass; ms per snapshot incl. pack/prep',
+                       'fp64_ms': g64, 'fp64_over_plain_pass': g64 / plain64, 'fp32_ms': g32, 'fp32_over_plain_pass': g32 / plain32,
+                       'kernels': 'k_skyvis_grad_f64 (MFMA 4x4x4) / k_skyvis_grad_f32pk'}
     terms = float(tm['last_terms'])
     res['fp64'] = {'kernel': 'k_skyvis_rec<double,%d>' % tm['last_chan_tile'], 'kernel_ms': tm['last_kernel_ms'], 'terms_per_s': terms / (tm['last_kernel_ms'] * 1e-3),
                    'roofline_frac': terms * FLOPS_PER_TERM / (tm['last_kernel_ms'] * 1e-3) / 1e12 / PEAK_TFLOPS['f64'], 'workload': cfg['name']}
