@@ -1,5 +1,6 @@
 """CPU: host-side logic -- layouts, channel grid, HEALPix, geometry, workloads, sharding, sky model,
 beam dispatch, argument validation of the reference-mirroring interface."""
+import os
 import numpy as NP
 import pytest
 
@@ -223,3 +224,38 @@ def test_beamformer_settings_follow_the_reference_draw_order_and_checks():
     assert 'array' in ext and 'beamformer' not in ext
     kind, size, bpc, ext = PB.device_beam_spec({'shape': 'delta'}, pointing_info={'delays': NP.zeros(16)})     # no element_locs: factor 1 (:387-389)
     assert ext is None
+
+
+def test_bench_quotes_profiled_traffic_only_for_the_running_sources(tmp_path, monkeypatch):
+    """bench.roofline.traffic comes from profiles/*/pmc_summary.json only when that summary carries the hash of the kernel sources that
+    are running (bench.csrc_hash); a summary of other sources is ignored (null beats stale)."""
+    import json
+    import bench
+    h = bench.csrc_hash()
+    assert len(h) == 40 and h == bench.csrc_hash()
+    prof = tmp_path / 'profiles' / 'rXX'
+    prof.mkdir(parents=True)
+    (tmp_path / 'prisim_amd').mkdir()
+    os.symlink(os.path.join(bench.ROOT, 'prisim_amd', 'csrc'), str(tmp_path / 'prisim_amd' / 'csrc'))
+    summary = {'_kernel': {'Kernel_Name': 'void prisim::k_skyvis_rec_f32pk<64, false>(prisim::SkyvisParams)'},
+               'FETCH_SIZE': {'mean_per_launch': 1000.0}, 'WRITE_SIZE': {'mean_per_launch': 500.0}, '_csrc_hash': 'not-this-build'}
+    (prof / 'pmc_summary.json').write_text(json.dumps(summary))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    assert bench.profiled_traffic('f32pk<64, false>') is None
+    summary['_csrc_hash'] = h
+    (prof / 'pmc_summary.json').write_text(json.dumps(summary))
+    got = bench.profiled_traffic('f32pk<64, false>')
+    assert got is not None and got[0] == (2 * 1000.0 + 500.0) * 1024.0      # 2 x FETCH_SIZE + WRITE_SIZE, KiB -> B (gfx950 FETCH correction)
+    assert bench.profiled_traffic('k_skyvis_rec<double') is None
+
+
+def test_committed_round_profiles_match_the_committed_sources():
+    """The round's rocprofv3 summaries under profiles/ were taken with the kernel sources that are committed beside them."""
+    import glob
+    import json
+    import bench
+    paths = sorted(glob.glob(os.path.join(bench.ROOT, 'profiles', 'r02_*', 'pmc_summary.json')))
+    assert len(paths) >= 5
+    for path in paths:
+        with open(path) as f:
+            assert json.load(f).get('_csrc_hash') == bench.csrc_hash(), path
