@@ -14,6 +14,7 @@ Pinning status (see DESIGN.md, section "Oracle"):
       - fp32 ("memsave") DFT sum              interferometry.py:6323, 6327
       - source-shape taper                    interferometry.py:6259-6283
       - baseline gradient                     interferometry.py:6338, 6343
+      - apply_gradients (consumer of it)      interferometry.py:6726-6819 (the method itself, on a stand-in object)
       - Gaussian / Airy beams (zenith)        primary_beams.py:609-623, 716-728
       - dipole, 4x4 array factor, presets     primary_beams.py:975-1235, 1239-1478, 9-441
       - VLA / GMRT polynomial beams           primary_beams.py:445-513, 734-808

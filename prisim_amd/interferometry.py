@@ -1056,6 +1056,57 @@ class InterferometerArray(object):
             for t in range(self.n_acc):
                 self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
 
+    def apply_gradients(self, gradient_mode=None, perturbations=None):
+        """First-order change of the sky visibilities under small baseline displacements, from the gradient cube observe()
+        accumulated with gradient_mode='baseline' (interferometry.py:6726-6819; arithmetic :6810-6812):
+
+            delta V[..., b, f, t] = -2 pi i / lambda_f * sum_k db[..., k, b] * G[k, b, f, t]
+
+        perturbations   {'baseline': array of shape (3, nbl), (nseed, 3, nbl) or (n1, n2, ..., 3, nbl)} in the units of
+                        `baselines`.  Fewer than three coordinate rows are completed with zeros and more than three are cut
+                        to the first three, each with a warning, as in the reference.  The caller's dictionary is left as
+                        given (the reference reshapes the array inside it in place).
+        Returns an (n1, ..., nbl, nchan, n_acc) complex array; a plain (3, nbl) input gives a leading axis of 1.
+        """
+        if gradient_mode is None:
+            gradient_mode = self.gradient_mode
+        if perturbations is None:
+            perturbations = {gradient_mode: NP.zeros((1, 1, 1))}
+        if self.gradient_mode is None or not self.gradient:
+            raise AttributeError('No gradient attribute found')
+        if not isinstance(perturbations, dict):
+            raise TypeError('Input perturbations must be a dictionary')
+        if not isinstance(gradient_mode, str):
+            raise TypeError('Input gradient_mode must be a string')
+        if gradient_mode not in ['baseline']:
+            raise KeyError('Specified gradient mode {0} not currently supported'.format(gradient_mode))
+        if gradient_mode not in perturbations:
+            raise KeyError('{0} key not found in input perturbations'.format(gradient_mode))
+        if gradient_mode != self.gradient_mode:
+            raise ValueError('Specified gradient mode {0} not found in attribute'.format(gradient_mode))
+        pert = perturbations[gradient_mode]
+        if not isinstance(pert, NP.ndarray):
+            raise TypeError('Perturbations must be specified as a numpy array')
+        if pert.ndim < 2:
+            raise ValueError('Perturbations must be two--dimensions or higher')
+        if pert.ndim == 2:
+            pert = pert[NP.newaxis, ...]
+        lead = pert.shape[:-2]
+        pert = pert.reshape(-1, pert.shape[-2], pert.shape[-1])                      # nseed x ncoord x nbl
+        grad = self.gradient[gradient_mode]                                          # 3 x nbl x nchan x n_acc
+        if pert.shape[2] != grad.shape[1]:
+            raise ValueError('Number of {0} perturbations not equal to that in the gradient attribute'.format(gradient_mode))
+        ncoord = pert.shape[1]
+        if ncoord < 3:
+            warnings.warn('Only {0}-dimensional coordinates specified. Proceeding with zero perturbations in other coordinate axes.'.format(ncoord))
+        elif ncoord > 3:
+            warnings.warn('{0}-dimensional coordinates specified. Proceeding with only the first three dimensions of coordinate axes.'.format(3))
+        ncoord = min(ncoord, 3)                                                      # absent rows contribute nothing
+        wavenumber = 2.0 * NP.pi * self.channels / C_LIGHT                           # 2 pi / lambda
+        delta = NP.einsum('skb,kbft->sbft', pert[:, :ncoord, :], grad[:ncoord])
+        delta = -1j * wavenumber.reshape(1, 1, -1, 1) * delta
+        return delta.reshape(lead + grad.shape[1:])
+
     # ------------------------------------------------------------------------------------------
     def save(self, outfile, fmt='HDF5', tabtype='BinTableHDU', npz=True, overwrite=False, uvfits_parms=None, verbose=True):
         """Write the object to disk in PRISim's HDF5 layout (interferometry.py:8393-8863; groups and dataset names of

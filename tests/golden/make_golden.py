@@ -21,6 +21,8 @@ source text is stored in this repository.
   golden_polybeams.npz primary_beams.py:445-513 (VLA_primary_beam_PBCOR), 734-808 (GMRT_primary_beam), 9-441 (id 'vla' / 'gmrt' / 'ugmrt')
   golden_beamformer.npz primary_beams.py:1482-1754 (array_field_pattern: beamformer delays / gains / pointing centre / seeded
                        delay and gain jitter, complex64 arithmetic), 9-441 (id 'mwa' and shape 'dipole' with pointing_info)
+  golden_apply_gradients.npz  interferometry.py:6726-6819 (method apply_gradients, called on a stand-in object that holds the
+                       attributes it reads: gradient, gradient_mode, channels, labels, lst)
 """
 import os
 import sys
@@ -276,6 +278,33 @@ def make_polybeams():
     print('golden_polybeams.npz:', {k: v.shape for k, v in out.items() if k.startswith('pbg')}, {k: (float(v.min()), float(v.max())) for k, v in out.items() if k.startswith('pbg')})
 
 
+def make_apply_gradients():
+    import warnings
+    rng = NP.random.default_rng(20261004)
+    nbl, nchan, nt = 7, 12, 3
+    channels = 150e6 + (NP.arange(nchan) - nchan // 2) * 390625.0
+    gradient = rng.normal(size=(3, nbl, nchan, nt)) + 1j * rng.normal(size=(3, nbl, nchan, nt))
+    ns = {'NP': NP, 'FCNST': FCNST, 'warnings': warnings}
+    exec(ref_block('interferometry.py', [(6726, 6819)]), ns)
+    self_ = types.SimpleNamespace(gradient_mode='baseline', gradient={'baseline': gradient}, channels=channels,
+                                  labels=NP.arange(nbl), lst=NP.arange(nt))
+    out = {'gradient': gradient, 'channels': channels}
+    cases = {'seeds3': rng.normal(scale=0.05, size=(4, 3, nbl)),         # nseed x 3 x nbl
+             'plain2d': rng.normal(scale=0.05, size=(3, nbl)),           # one realisation, no seed axis
+             'grid5d': rng.normal(scale=0.05, size=(2, 3, 3, nbl)),      # (n1, n2, 3, nbl)
+             'xy_only': rng.normal(scale=0.05, size=(2, 2, nbl)),        # z perturbation missing -> zero, with a warning
+             'x_only': rng.normal(scale=0.05, size=(2, 1, nbl)),
+             'four_axes': rng.normal(scale=0.05, size=(2, 4, nbl))}      # fourth axis dropped, with a warning
+    for name, pert in cases.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            res = ns['apply_gradients'](self_, gradient_mode='baseline', perturbations={'baseline': pert.copy()})
+        out['pert_' + name] = pert
+        out['delta_' + name] = res
+    NP.savez_compressed(os.path.join(HERE, 'golden_apply_gradients.npz'), **out)
+    print('golden_apply_gradients.npz:', {k: v.shape for k, v in out.items()})
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree not available: golden vectors can only be regenerated in the build container')
@@ -283,3 +312,4 @@ if __name__ == '__main__':
     make_beams()
     make_beamformer()
     make_polybeams()
+    make_apply_gradients()

@@ -218,6 +218,14 @@ def test_interferometer_array_observe_matches_oracle():
         assert ia2.skyvis_freq.dtype == (NP.complex64 if memsave else NP.complex128)
         assert NP.max(NP.abs(ia2.skyvis_freq[:, :, 0] - ref) / scale) <= tol
         assert NP.max(NP.abs(ia2.gradient['baseline'][:, :, :, 0] - gref) / scale[None]) <= tol
+        # apply_gradients (interferometry.py:6726-6819) on the cube the fused kernel produced: first-order prediction of mm-level
+        # baseline errors against the oracle at the displaced baselines (phase-centre delays held, as the gradient holds them)
+        db = NP.random.default_rng(5 + j).normal(scale=1e-3, size=(3, bl.shape[0]))
+        dv = ia2.apply_gradients(perturbations={'baseline': db})[0, :, :, 0]
+        assert NP.max(NP.abs(dv - (-2j * NP.pi * ch[None, :] / 299792458.0) * NP.einsum('kb,kbf->bf', db, gref)) / scale) <= 10 * tol
+        moved = O.skyvis(bl + db.T, ch, sky['dircos'], pb, zen, fwhm_deg=sky['fwhm_deg']) \
+            * NP.exp(-2j * NP.pi * ch[None, :] * db[2][:, None] / 299792458.0)
+        assert NP.max(NP.abs(moved - ref - dv) / scale) <= 0.05 * NP.max(NP.abs(moved - ref) / scale) + 10 * tol
         assert ia2.n_acc == 1 and ia2.t_obs == 10.0 and ia2.lst == [30.0] and ia2.timestamp == [2457000.5 + j]
         assert ia2.bp.shape == (bl.shape[0], ch.size, 1) and ia2.Tsys.shape == (bl.shape[0], ch.size, 1)
         assert NP.asarray(ia2.geometric_delays[0]).shape == (n, bl.shape[0])

@@ -259,3 +259,89 @@ def test_committed_round_profiles_match_the_committed_sources():
     for path in paths:
         with open(path) as f:
             assert json.load(f).get('_csrc_hash') == bench.csrc_hash(), path
+
+
+# ---- apply_gradients (interferometry.py:6726-6819): the consumer of the fused baseline gradient ----
+def _oracle_array(monkeypatch, bl, ch):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fake_context
+    from prisim_amd import interferometry as RI
+    monkeypatch.setattr(_abi, 'Context', fake_context.OracleContext)
+    return RI.InterferometerArray(['b%d' % i for i in range(bl.shape[0])], bl, ch, telescope={'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'},
+                                  latitude=-30.7, skycoords='altaz', pointing_coords='hadec')
+
+
+def test_apply_gradients_matches_the_reference_method(monkeypatch):
+    """tests/golden/golden_apply_gradients.npz holds what the reference's own method returned (make_golden.make_apply_gradients)."""
+    g = NP.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'golden_apply_gradients.npz'))
+    grad, ch = g['gradient'], g['channels']
+    ia = _oracle_array(monkeypatch, NP.ones((grad.shape[1], 3)), ch)
+    ia.gradient_mode, ia.gradient = 'baseline', {'baseline': grad}
+    for name in ('seeds3', 'plain2d', 'grid5d', 'xy_only', 'x_only', 'four_axes'):
+        pert = g['pert_' + name]
+        given = {'baseline': pert.copy()}
+        if name in ('xy_only', 'x_only', 'four_axes'):
+            with pytest.warns(UserWarning):
+                res = ia.apply_gradients(gradient_mode='baseline', perturbations=given)
+        else:
+            res = ia.apply_gradients(perturbations=given)
+        ref = g['delta_' + name]
+        assert res.shape == ref.shape and res.dtype == ref.dtype, name
+        assert NP.max(NP.abs(res - ref)) <= 1e-13 * NP.max(NP.abs(ref)), name
+        assert NP.array_equal(given['baseline'], pert)                      # the caller's array is left alone
+    with pytest.raises(ValueError):                                         # the default stand-in is (1, 1, 1): one baseline only,
+        ia.apply_gradients()                                                # as in the reference (:6762-6763, 6798-6799)
+
+
+def test_apply_gradients_predicts_perturbed_visibilities(monkeypatch):
+    """V(b + db) = V(b) + apply_gradients(db) + O(|db|^2): observe() with the gradient, then displace every baseline by a few mm.
+    The reference's gradient (:6338, 6343) differentiates the geometric delays only, so the phase-centre delays stay those of the
+    unperturbed baselines."""
+    from oracle import skyvis_oracle as O, beams_oracle as BO
+    rng = NP.random.default_rng(11)
+    ch = 150e6 + 2e5 * NP.arange(6)
+    bl = rng.uniform(-60.0, 60.0, size=(5, 3)) * NP.array([1.0, 1.0, 0.02])
+    alt, az = rng.uniform(25.0, 89.0, 40), rng.uniform(0.0, 360.0, 40)
+    skymod = SM.SkyModel(location=NP.stack((alt, az), axis=1), flux_ref=rng.uniform(0.5, 5.0, 40), spindex=rng.uniform(-1.0, 0.0, 40), ref_freq=150e6)
+    ia = _oracle_array(monkeypatch, bl, ch)
+    for j in range(2):
+        ia.observe((2457000.5 + j, 10.0), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, -30.7], skymod, 10.0, gradient_mode='baseline')
+    assert ia.gradient['baseline'].shape == (3, 5, 6, 2)
+    db = rng.normal(scale=2e-3, size=(3, 3, 5))                              # 3 realisations of mm-level position errors
+    delta = ia.apply_gradients(perturbations={'baseline': db})
+    assert delta.shape == (3, 5, 6, 2)
+    pb = BO.airy_disk_pattern(14.0, NP.stack((alt, az), axis=1), ch, pointing_altaz=[90.0, 270.0]) * skymod.generate_spectrum(frequency=ch)
+    dc = O.altaz2dircos(NP.stack((alt, az), axis=1))
+    zen = NP.array([0.0, 0.0, 1.0])
+    v0 = O.skyvis(bl, ch, dc, pb, zen)
+    assert NP.max(NP.abs(ia.skyvis_freq[:, :, 0] - v0)) <= 1e-12 * NP.max(NP.abs(v0))
+    scale = NP.sum(NP.abs(pb), axis=0)[None, :]
+    for s in range(3):
+        v1 = O.skyvis(bl + db[s].T, ch, dc, pb, zen) * NP.exp(-2j * NP.pi * ch[None, :] * (db[s].T @ zen)[:, None] / 299792458.0)
+        first_order = NP.max(NP.abs(v1 - v0) / scale)
+        resid = NP.max(NP.abs(v1 - v0 - delta[s, :, :, 0]) / scale)
+        assert first_order > 1e-4 and resid < 2e-2 * first_order            # second order: (2 pi |db| / lambda) / 2 ~ 3e-3 of the first
+        assert NP.array_equal(delta[s, :, :, 0], delta[s, :, :, 1])          # same altaz sky in both snapshots
+
+
+def test_apply_gradients_argument_checks(monkeypatch):
+    ch = 150e6 + 1e5 * NP.arange(3)
+    ia = _oracle_array(monkeypatch, NP.ones((4, 3)), ch)
+    with pytest.raises(AttributeError):
+        ia.apply_gradients(perturbations={'baseline': NP.zeros((3, 4))})     # nothing observed with a gradient yet
+    ia.gradient_mode, ia.gradient = 'baseline', {'baseline': NP.zeros((3, 4, 3, 1), dtype=NP.complex128)}
+    with pytest.raises(TypeError):
+        ia.apply_gradients(perturbations=NP.zeros((3, 4)))
+    with pytest.raises(TypeError):
+        ia.apply_gradients(gradient_mode=1, perturbations={'baseline': NP.zeros((3, 4))})
+    with pytest.raises(KeyError):
+        ia.apply_gradients(gradient_mode='skypos', perturbations={'skypos': NP.zeros((3, 4))})
+    with pytest.raises(KeyError):
+        ia.apply_gradients(gradient_mode='baseline', perturbations={'frequency': NP.zeros((3, 4))})
+    with pytest.raises(TypeError):
+        ia.apply_gradients(perturbations={'baseline': [[0.0] * 4] * 3})
+    with pytest.raises(ValueError):
+        ia.apply_gradients(perturbations={'baseline': NP.zeros(4)})
+    with pytest.raises(ValueError):
+        ia.apply_gradients(perturbations={'baseline': NP.zeros((3, 5))})      # five baselines against four
