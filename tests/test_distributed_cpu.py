@@ -52,3 +52,51 @@ def test_two_ranks_on_one_gpu_real_kernels_gloo_exchange():
     """Both ranks on device 0 with the real HIP context (sky-sum kernels, device-resident cube and delay spectra); only the
     communicator is the gloo stand-in (RCCL refuses two ranks on one GPU)."""
     _run_workers('gpu', 2)
+
+
+# ---- bench.py itself at world size > 1 (the driver's scaling runs are the first time it meets more than one GPU) ----
+def _bench_ranks(tmp_path, nproc, mode='ok', extra=()):
+    import json
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), WORLD_SIZE=str(nproc), OMP_NUM_THREADS='1',
+               BENCH_REHEARSAL_DIR=str(tmp_path), BENCH_REHEARSAL_MODE=mode, PRISIM_RDZV_FILE=str(tmp_path / 'rdzv'))
+    procs = []
+    for r in range(nproc):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'bench_worker.py'), '--gpus', str(nproc), '--steps', '2',
+                                       '--warmup', '1', '--nsrc', '16', '--no-cpu-baseline'] + list(extra),
+                                      env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    codes = [p.returncode for p in procs]
+    lines = [[ln for ln in o[0].splitlines() if ln.strip()] for o in outs]
+    return codes, lines, [o[1] for o in outs], json
+
+
+def test_bench_main_at_world_size_three_prints_one_contract_line(tmp_path):
+    codes, lines, errs, json = _bench_ranks(tmp_path, 3)
+    assert codes == [0, 0, 0], errs
+    assert len(lines[0]) == 1 and lines[1] == [] and lines[2] == []            # rank 0 prints ONE line, the others nothing
+    d = json.loads(lines[0][0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline'):
+        assert key in d, key
+    assert d['n_gpus'] == 3 and d['steps'] == 2 and d['warmup'] == 1 and d['gather_ok'] is True
+    assert d['metric'] == 'visibility-terms/sec' and d['scaling'] == 'strong' and d['vs_baseline'] is None
+    assert d['config']['nbl'] == 61075 and d['config']['nsrc'] == 16 and d['config']['sharding'].startswith('baselines/3')
+    # whole-job value: all 61 075 baselines (not the padded 3 x 20 359), both steps, over the slowest rank's time
+    assert abs(d['value'] * d['ms_per_step'] * 1e-3 * 2 - 61075.0 * 1024 * 16 * 2) <= 1e-6 * 61075.0 * 1024 * 16 * 2
+    assert d['roofline']['terms_per_launch'] == 20359.0 * 1024 * 16            # per launch: this rank's padded shard
+
+
+def test_bench_main_fails_loudly_when_the_communicator_cannot_be_made(tmp_path):
+    for mode in ('init_fails_on_1', 'no_uid'):
+        sub = tmp_path / mode
+        sub.mkdir()
+        codes, lines, errs, _ = _bench_ranks(sub, 2, mode=mode)
+        assert codes == [3, 3], (mode, codes, errs)                             # every rank stops; no rank hangs in a collective
+        assert lines == [[], []]                                                # and no value is printed
+
+
+def test_bench_main_reports_a_gather_that_differs_between_ranks(tmp_path):
+    codes, lines, errs, json = _bench_ranks(tmp_path, 2, mode='rank1_differs')
+    assert codes == [0, 0], errs
+    assert json.loads(lines[0][0])['gather_ok'] is False
