@@ -196,6 +196,51 @@ def other_kernels(ctx, cfg, zen):
     return res
 
 
+def _smi_sample():
+    """(sclk MHz, package W) from one rocm-smi call, None where it cannot be read."""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '-d', '0'], capture_output=True, text=True, timeout=20).stdout
+    except Exception:
+        return None, None
+    m = re.search(r'sclk clock level:\s*\d+:\s*\((\d+)Mhz\)', out)
+    w = re.search(r'Package Power \(W\):\s*([0-9.]+)', out)
+    return (int(m.group(1)) if m else None), (float(w.group(1)) if w else None)
+
+
+def power_clock(ctx, cfg, zen, prec):
+    """What the chip does under the dominant kernel: ~2 s of back-to-back launches on the workload's sky with rocm-smi sampled in the middle,
+    then the same launch on a sky whose sources all sit at the phase centre (same kernel, grid and instruction stream; every phasor 1, every
+    rotation the identity).  The second holds the spec clock at less power and finishes sooner: the kernel is limited by data-dependent
+    switching power (profiles/r02_power_data_probe.txt).  The caller restores the workload's sky afterwards."""
+    import threading
+    sky = cfg['sky']
+    res = {}
+    for name, dc in (('workload_sky', sky['dircos']), ('constant_operands', NP.repeat(zen[None, :], sky['dircos'].shape[0], axis=0))):
+        ctx.set_sky_analytic(dc, sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, cfg['diameter'], zen, zen,
+                             fwhm_deg=(sky['fwhm_deg'] if cfg['taper'] else None))
+        for i in range(10):
+            ctx.compute(precision=prec, slot=0)
+        ctx.sync()
+        ctx.timing(reset=True)
+        sample = []
+        th = threading.Thread(target=lambda: sample.append(_smi_sample()))
+        n = 40
+        for i in range(n):
+            ctx.compute(precision=prec, slot=0)
+            if i == 4:
+                th.start()                  # the queue is ~2 s deep by now: the sample falls inside the run
+        ctx.sync()
+        th.join()
+        tm = ctx.timing()
+        res[name] = {'kernel_ms': tm['sum_kernel_ms'] / max(1, tm['n_kernel']), 'launches': n,
+                     'sclk_mhz': sample[0][0] if sample else None, 'package_w': sample[0][1] if sample else None}
+    res['what'] = ('dominant kernel back to back; constant_operands = every source at the phase centre (same instruction stream, operands that '
+                   'never change)')
+    return res
+
+
 def e2e_observe(cfg, n_snap, device, memsave):
     """The same workload through the reference's entry point for the path, InterferometerArray.observe() (interferometry.py:5874):
     per snapshot the host geometry (hadec -> altaz -> direction cosines of every source), the sky staging (nsrc-sized vectors), the
@@ -406,6 +451,12 @@ def main():
             except Exception as exc:
                 out['delay_ps'] = {'device_ms': None, 'error': repr(exc)}
             try:
+                out['power_clock'] = power_clock(ctx, cfg, zen, prec)
+            except Exception as exc:
+                out['power_clock'] = {'error': repr(exc)}
+            try:
+                ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY,
+                                     cfg['diameter'], zen, zen, fwhm_deg=(sky['fwhm_deg'] if cfg['taper'] else None))
                 out['other_kernels'] = other_kernels(ctx, cfg, zen)
             except Exception as exc:
                 out['other_kernels'] = {'error': repr(exc)}
