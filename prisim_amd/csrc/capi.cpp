@@ -139,6 +139,7 @@ struct prisim_ctx {
   size_t h_stage_bytes = 0, h_stage_used = 0;
   hipEvent_t ev_stage = nullptr;
   bool stage_pending = false;
+  bool stage_open = false;        // copies of the current group have been queued and stage_end() has not run yet
   // external beam
   DevBuf ext_table, ext_work, ext_colmax;
   int ext_nside = 0;
@@ -228,6 +229,11 @@ int stage_begin(prisim_ctx* ctx, size_t bytes) {
     if (hipEventSynchronize(ctx->ev_stage) != hipSuccess) return fail(ctx, PRISIM_ENODEV, "hipEventSynchronize(staging) failed");
     ctx->stage_pending = false;
   }
+  if (ctx->stage_open) {
+    // the previous group was abandoned on an error path after some of its copies had been queued: let them leave the area first
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, PRISIM_ENODEV, "hipStreamSynchronize(staging) failed");
+    ctx->stage_open = false;
+  }
   if (!ctx->ev_stage && hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming) != hipSuccess)
     return fail(ctx, PRISIM_ENODEV, "hipEventCreate(staging) failed");
   bytes += 4096;
@@ -253,6 +259,7 @@ void* stage_alloc(prisim_ctx* ctx, size_t bytes) {
 }
 
 hipError_t stage_send(prisim_ctx* ctx, void* dst, const void* staged, size_t bytes) {
+  ctx->stage_open = true;
   return hipMemcpyAsync(dst, staged, bytes, hipMemcpyHostToDevice, ctx->stream);
 }
 
@@ -265,7 +272,10 @@ hipError_t stage_upload(prisim_ctx* ctx, void* dst, const void* src, size_t byte
 }
 
 void stage_end(prisim_ctx* ctx) {
-  if (hipEventRecord(ctx->ev_stage, ctx->stream) == hipSuccess) ctx->stage_pending = true;
+  if (hipEventRecord(ctx->ev_stage, ctx->stream) == hipSuccess) {
+    ctx->stage_pending = true;
+    ctx->stage_open = false;         // otherwise stays set: the next group then waits for the whole stream
+  }
 }
 
 // Collect the hipEvent timings of finished compute() calls, oldest first.  max_wait: how many of the pending entries may be
