@@ -233,6 +233,10 @@ def load_external_beam(parms, infile_dir):
 def window(nchan, shape):
     """Frequency window for the delay transform (DSP.windowing, astroutils: unpinned).  area-normalised to mean 1."""
     n = NP.arange(nchan)
+    if nchan < 2:
+        if shape not in ('rect', 'RECT', None, 'bhw', 'BHW', 'bnw', 'BNW'):
+            raise ValueError('bpass_shape must be "rect", "bhw" or "bnw"')
+        return NP.ones(nchan)                     # a one-channel band has nothing to taper (and the cosine terms would divide by zero)
     if shape in ('rect', 'RECT', None):
         w = NP.ones(nchan)
     elif shape in ('bhw', 'BHW'):
@@ -283,9 +287,14 @@ def schedule(parms):
     return jd, lst, hadec, t_acc, n_acc
 
 
-def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose=True):
+def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose=True, host_copy='all'):
     """Simulate the observation described by `parms` on this rank's GPU.  Returns a dict with the (gathered) visibility
-    cube (nbl, nchan, n_acc), baselines, labels, channels, lst, timestamps and timing."""
+    cube (nbl, nchan, n_acc), baselines, labels, channels, lst, timestamps and timing.  host_copy (sharded runs): 'all' = every
+    rank downloads the gathered cube and spectra, 'root' = rank 0 only (the others return None for them; every GPU still holds
+    the gathered data)."""
+    if host_copy not in ('all', 'root'):
+        raise ValueError("host_copy must be 'all' or 'root'")
+    download = host_copy == 'all' or rank == 0
     extbeam = None
     if parms['beam'].get('use_external'):
         extbeam = load_external_beam(parms, infile_dir)
@@ -333,7 +342,8 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     if world > 1:
         if comm_uid is None:
             raise ValueError('comm_uid is needed when world > 1')
-        cube = ia.allgather(comm_uid, world, rank)[:nbl_total]          # shards go GPU -> GPU; the host never sees this rank's own cube
+        cube = ia.allgather(comm_uid, world, rank, download=download)   # shards go GPU -> GPU; the host never sees this rank's own cube
+        cube = cube[:nbl_total] if cube is not None else None
         labels_all, bl_all = labels, bl
     else:
         cube, labels_all, bl_all = ia.skyvis_freq[:nbl_total], labels, bl
@@ -343,7 +353,11 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     if proc.get('delay_transform'):
         # every rank transforms its own shard on its GPU (the FFT runs along frequency); sharded runs then exchange the spectra
         ia.delay_transform(pad=float(proc.get('f_pad', 1.0)), freq_wts=window(chans.size, proc.get('bpass_shape', 'bhw')), verbose=False)
-        out['skyvis_lag'] = ia.allgather_lags(world)[:nbl_total] if world > 1 else ia.skyvis_lag
+        if world > 1:
+            lag = ia.allgather_lags(world, download=download)
+            out['skyvis_lag'] = lag[:nbl_total] if lag is not None else None
+        else:
+            out['skyvis_lag'] = ia.skyvis_lag
         out['lags'] = ia.lags
     return out
 
@@ -402,7 +416,8 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
         uid = rdzv.broadcast_bytes(_abi.Context.comm_unique_id() if rank == 0 else b'')
-    out = run(parms, infile_dir=os.path.dirname(os.path.abspath(args.infile)), rank=rank, world=world, device=local_rank, comm_uid=uid)
+    out = run(parms, infile_dir=os.path.dirname(os.path.abspath(args.infile)), rank=rank, world=world, device=local_rank, comm_uid=uid,
+              host_copy='root')                    # only rank 0 writes: the other ranks leave the gathered cube in HBM
     if rank == 0:
         path = save(out, parms, args.infile)
         print('simulated {0} baselines x {1} channels x {2} snapshots in {3:.3f} s -> {4}'.format(

@@ -377,9 +377,10 @@ class InterferometerArray(object):
         if getattr(self, '_extbeam', None) is not None:
             self._ctx.set_external_beam(*self._extbeam)
 
-    def allgather(self, comm_uid, nranks, rank):
+    def allgather(self, comm_uid, nranks, rank, download=True):
         """One RCCL all-gather of the baseline shards of all ranks (equal shard sizes; replaces the reference's per-rank
-        part files + rank-0 concatenate, scripts/run_prisim.py:2207, 2233-2242).  Returns (nranks*nbl, nchan, n_acc)."""
+        part files + rank-0 concatenate, scripts/run_prisim.py:2207, 2233-2242).  Returns (nranks*nbl, nchan, n_acc), or None with
+        download=False (the gathered cube then stays in HBM only: a rank that writes nothing need not pull it over PCIe)."""
         if self._reserved < self.n_acc:
             raise RuntimeError('reserve(n_acc) must be called before observing to keep the cube on the device')
         if not getattr(self, '_comm_ready', False):
@@ -389,10 +390,12 @@ class InterferometerArray(object):
         # carry their dtype); a run that mixes precisions, or has no snapshot yet, gathers complex128
         c64 = bool(self._cube) and all(NP.dtype(sn.dtype) == NP.complex64 for sn in self._cube)
         self._ctx.allgather(self.n_acc, complex64=c64)
+        if not download:
+            return None
         g = self._ctx.get_gathered(self.n_acc, nranks)                 # [t][rank][b][f]
         return NP.transpose(g.reshape(self.n_acc, nranks * self.baselines.shape[0], self.channels.size), (1, 2, 0))
 
-    def allgather_lags(self, nranks):
+    def allgather_lags(self, nranks, download=True):
         """All-gather of the delay spectra of the baseline shards (the FFT is along frequency, so every rank transforms
         its own shard and the spectra are exchanged like the visibilities).  Call after allgather() and delay_transform().  Spectra
         that delay_transform() left resident on the device go GPU -> GPU (prisim_hip_allgather_lags); host-side spectra take the
@@ -402,6 +405,8 @@ class InterferometerArray(object):
         if getattr(self, '_lag_resident', None) is not None:
             nt, nout = self._lag_resident
             self._ctx.allgather_lags(nt)
+            if not download:
+                return None
             g = self._ctx.get_gathered(nt, nranks, row=nout)            # [t][rank][b][lag]
             return NP.transpose(g.reshape(nt, nranks * self.baselines.shape[0], nout), (1, 2, 0))
         if self.skyvis_lag is None:
@@ -412,9 +417,11 @@ class InterferometerArray(object):
         for t in range(self.n_acc):
             self._ctx.set_vis(NP.ascontiguousarray(self.skyvis_lag[:, :, t], dtype=NP.complex128), slot=t)
         self._ctx.allgather(self.n_acc, complex64=False)
-        g = self._ctx.get_gathered(self.n_acc, nranks)
+        g = self._ctx.get_gathered(self.n_acc, nranks) if download else None
         for t in range(self.n_acc):                                    # and the visibilities go back into their slots
             self._ctx.set_vis(NP.asarray(self.skyvis_freq[:, :, t], dtype=NP.complex128), slot=t)
+        if g is None:
+            return None
         return NP.transpose(g.reshape(self.n_acc, nranks * self.baselines.shape[0], self.channels.size), (1, 2, 0))
 
     # ------------------------------------------------------------------------------------------

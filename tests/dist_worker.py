@@ -61,6 +61,12 @@ def main():
     err_l = float(NP.max(NP.abs(out['skyvis_lag'] - ref['skyvis_lag'])))
     lag_scale = float(NP.max(NP.abs(ref['skyvis_lag'])))
     ok = err_v <= tol and err_l <= max(tol, 1e-12 * lag_scale) and out['labels'] == ref['labels'] and NP.array_equal(out['bl'], ref['bl'])
+    # what the YAML entry point does (driver.main): only rank 0 pulls the gathered cube and spectra to the host
+    out_root = driver.run(parms, rank=rank, world=world, device=0, comm_uid=uid, verbose=False, host_copy='root')
+    if rank == 0:
+        ok = ok and NP.array_equal(out_root['skyvis_freq'], out['skyvis_freq']) and NP.array_equal(out_root['skyvis_lag'], out['skyvis_lag'])
+    else:
+        ok = ok and out_root['skyvis_freq'] is None and out_root['skyvis_lag'] is None
     all_ok = all(rdzv.allgather(bool(ok)))
     rdzv.barrier()
     rdzv.close()
