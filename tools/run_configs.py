@@ -14,7 +14,7 @@ from prisim_amd import _abi, workloads as W, primary_beams as PB
 from oracle import c_oracle as CO
 
 
-def run(cfg, ctx, n_acc, spot=6, delay=False):
+def run(cfg, ctx, n_acc, spot=6, delay=False, cpu=False):
     bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
     prec = _abi.PRISIM_FP32 if cfg['precision'] == 'fp32' else _abi.PRISIM_FP64
     zen = NP.array([0.0, 0.0, 1.0])
@@ -78,6 +78,24 @@ def run(cfg, ctx, n_acc, spot=6, delay=False):
            'kernel_ms_total': kern_ms, 'terms_per_s_kernel': terms / (kern_ms * 1e-3) if kern_ms > 0 else None,
            'wall_s_incl_sky_staging_and_spot_check': wall, 'wall_s_incl_host_geometry_and_sky_staging': wall_nospot if spot else wall, 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
            'parity_spot_max_err_rel_sumflux': worst, 'tolerance': 5e-6 if cfg['precision'] == 'fp32' else 1e-11}
+    if cpu and n_acc == 1 and terms <= 3e8:
+        # the CPU beside it on the same box: the numpy restatement of the reference's statements, one process, and the
+        # C/OpenMP port on every host core -- whole configuration, and the GPU result checked against both
+        from oracle import skyvis_oracle as O
+        pb = ctx.get_pbflux()
+        fwhm = sky['fwhm_deg'] if cfg['taper'] else None
+        gpu = ctx.get_vis(slot=0)
+        scale = NP.sum(NP.abs(pb), axis=0)[None, :]
+        t1 = time.perf_counter(); ref_np = O.skyvis(bl, ch, sky['dircos'], pb, zen, fwhm_deg=fwhm); t_np = time.perf_counter() - t1
+        CO.use_native_build()
+        threads = max(1, min(16, os.cpu_count() or 1, CO.max_threads()))                # the box's CPU share for one GPU is 16 cores
+        CO.skyvis(bl[:threads], ch, sky['dircos'], pb, zen, fwhm_deg=fwhm, nthreads=threads)   # load + thread pool warm-up
+        t1 = time.perf_counter(); ref_c = CO.skyvis(bl, ch, sky['dircos'], pb, zen, fwhm_deg=fwhm, nthreads=threads); t_c = time.perf_counter() - t1
+        out['cpu'] = {'numpy_reference_formulation_terms_per_s': terms / t_np, 'numpy_seconds': t_np, 'c_openmp_terms_per_s': terms / t_c,
+                      'c_openmp_seconds': t_c, 'c_openmp_threads': threads,
+                      'gpu_vs_numpy_max_err_rel_sumflux': float(NP.max(NP.abs(gpu - ref_np) / scale)),
+                      'gpu_vs_c_max_err_rel_sumflux': float(NP.max(NP.abs(gpu - ref_c) / scale)),
+                      'gpu_kernel_over_numpy': t_np / (kern_ms * 1e-3), 'gpu_kernel_over_c_openmp': t_c / (kern_ms * 1e-3)}
     if delay:
         w = NP.blackman(ch.size)
         for rep in range(2):
@@ -100,13 +118,14 @@ def main():
     ap.add_argument('--lst5', type=int, default=2)
     ap.add_argument('--nside5', type=int, default=256)
     ap.add_argument('--configs', default='1,2,3,4,5')
+    ap.add_argument('--cpu', action='store_true', help='configs 1 and 2: also time the numpy restatement and the C/OpenMP port on the host cores')
     args = ap.parse_args()
     ctx = _abi.Context(0)
     which = [int(x) for x in args.configs.split(',')]
     if 1 in which:
-        print(json.dumps(run(W.config1(), ctx, 1)), flush=True)
+        print(json.dumps(run(W.config1(), ctx, 1, cpu=args.cpu)), flush=True)
     if 2 in which:
-        print(json.dumps(run(W.config2(), ctx, 1)), flush=True)
+        print(json.dumps(run(W.config2(), ctx, 1, cpu=args.cpu)), flush=True)
     if 3 in which:
         print(json.dumps(run(W.config3(), ctx, 1)), flush=True)
     if 4 in which:
