@@ -8,7 +8,8 @@ never as the thing measured or shipped.  ``prisim_amd`` never imports it.
 Pinning status (see DESIGN.md, section "Oracle"):
   * PINNED against the reference's own statements executed under Python 3 on
     seeded inputs (tests/golden/make_golden.py reads the cited line ranges of
-    /root/reference at generation time, in this container only):
+    /root/reference at generation time, in this container only; the sky-sum statements on
+    two cases: baselines <= 150 m and an MWA-scale one, <= 2.5 km / ~1600 cycles of phase):
       - geometric delay (dircos path)        baseline_delay_horizon.py:236-240
       - fp64 DFT sum                          interferometry.py:6332, 6340
       - fp32 ("memsave") DFT sum              interferometry.py:6323, 6327

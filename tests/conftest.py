@@ -14,10 +14,12 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
-@pytest.fixture(scope='session')
-def golden_skyvis():
+@pytest.fixture(scope='session', params=['golden_skyvis.npz', 'golden_skyvis_long.npz'], ids=['hera_scale', 'mwa_scale'])
+def golden_skyvis(request):
+    """The reference's own statements executed on seeded inputs (tests/golden/make_golden.py): 37 sources x 9 baselines (<= 150 m) x 24
+    channels of 390 kHz at 150 MHz, and 101 sources x 21 baselines (<= 2.5 km, ~1600 cycles of phase) x 32 channels of 40 kHz at 185 MHz."""
     import numpy as NP
-    return dict(NP.load(os.path.join(GOLDEN, 'golden_skyvis.npz')))
+    return dict(NP.load(os.path.join(GOLDEN, request.param)))
 
 
 @pytest.fixture(scope='session')

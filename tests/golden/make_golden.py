@@ -10,7 +10,8 @@ run unchanged under Python 3.  This script reads the cited line ranges from the 
 source AT GENERATION TIME, dedents them and exec()s them on seeded inputs.  No reference
 source text is stored in this repository.
 
-  golden_skyvis.npz    interferometry.py:6332,6340 (fp64), 6335 (+taper), 6338/6343 (gradient),
+  golden_skyvis.npz, golden_skyvis_long.npz (the same statements on 2.5 km baselines)
+                       interferometry.py:6332,6340 (fp64), 6335 (+taper), 6338/6343 (gradient),
                        6323,6326,6327,6330 (fp32 "memsave"), taper 6259-6262,6265-6270,6281-6283,
                        baseline_delay_horizon.py:133-241 (function geometric_delay, dircos path),
                        phase_centering :7871-7872, 7877
@@ -63,12 +64,11 @@ def altaz2dircos(altaz):
     return NP.stack((NP.cos(alt) * NP.sin(az), NP.cos(alt) * NP.cos(az), NP.sin(alt)), axis=1)
 
 
-def make_skyvis():
-    rng = NP.random.default_rng(20261003)
-    nsrc, nbl, nchan = 37, 9, 24
-    baselines = rng.uniform(-150.0, 150.0, size=(nbl, 3))
+def make_skyvis(fname='golden_skyvis.npz', seed=20261003, nsrc=37, nbl=9, nchan=24, maxbl=150.0, f0=150e6, df=390625.0):
+    rng = NP.random.default_rng(seed)
+    baselines = rng.uniform(-maxbl, maxbl, size=(nbl, 3))
     baselines[:, 2] *= 0.02
-    channels = 150e6 + (NP.arange(nchan) - nchan // 2) * 390625.0
+    channels = f0 + (NP.arange(nchan) - nchan // 2) * df
     alt = NP.degrees(NP.arcsin(rng.uniform(0.1, 1.0, nsrc)))
     az = rng.uniform(0.0, 360.0, nsrc)
     skypos_dircos_roi = altaz2dircos(NP.stack((alt, az), axis=1))
@@ -139,11 +139,11 @@ def make_skyvis():
     out['phase_pc_new'] = pc_new
     out['phase_cube_out'] = e['self'].skyvis_freq
 
-    NP.savez_compressed(os.path.join(HERE, 'golden_skyvis.npz'),
+    NP.savez_compressed(os.path.join(HERE, fname),
                         baselines=baselines, channels=channels, dircos=skypos_dircos_roi, pbfluxes=pbfluxes,
                         pc_dircos=pc_dircos.ravel(), src_shape=src_shape, geometric_delays=geometric_delays,
                         pc_delay_offsets=pc_delay_offsets, **out)
-    print('golden_skyvis.npz:', {k: v.shape for k, v in out.items()})
+    print(fname + ':', {k: v.shape for k, v in out.items()})
 
 
 def make_beams():
@@ -309,6 +309,8 @@ if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree not available: golden vectors can only be regenerated in the build container')
     make_skyvis()
+    # the same statements on an MWA-like case: baselines to 2.5 km (delays to ~8 us, ~1600 cycles of phase), 40 kHz channels at 185 MHz
+    make_skyvis('golden_skyvis_long.npz', seed=20261005, nsrc=101, nbl=21, nchan=32, maxbl=2500.0, f0=185e6, df=40e3)
     make_beams()
     make_beamformer()
     make_polybeams()
