@@ -480,3 +480,29 @@ def test_full_size_config5_snapshot_properties(ctx):
     odd = NP.arange(n) % 3 == 1
     parts = run(odd) + run(~odd)
     assert relerr(parts, full, pb) <= 1e-5
+
+
+# ---------------------------------------------------------------- the binding INTEGRATION.md shows to a PRISim maintainer
+def test_integration_md_stub_runs_as_written(golden_skyvis):
+    """The ctypes stub of INTEGRATION.md section 1 is executed as written (only the library path is made absolute) and must reproduce the
+    reference's own fp64 and memsave results on the golden inputs, gradient included."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'INTEGRATION.md')) as f:
+        text = f.read()
+    code = re.search(r'```python\n(.*?)```', text, re.S).group(1)
+    assert "C.CDLL('libprisim_hip.so')" in code
+    code = code.replace("C.CDLL('libprisim_hip.so')", 'C.CDLL(%r)' % _abi.LIB_PATH)
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md#1', 'exec'), ns)
+    g = golden_skyvis
+    hip = ns['HipSkySum'](g['baselines'], g['channels'])
+    v, gr = hip.skyvis(g['dircos'], g['pbfluxes'], g['pc_dircos'], src_fwhm_deg=_fwhm(g), gradient=True)
+    assert v.dtype == NP.complex128
+    assert relerr(v, g['skyvis_f64_taper'], g['pbfluxes']) <= 1e-11
+    assert max(relerr(gr[k], g['grad_f64_taper'][k], g['pbfluxes']) for k in range(3)) <= 1e-11
+    v32 = hip.skyvis(g['dircos'], g['pbfluxes'], g['pc_dircos'], memsave=True)
+    assert v32.dtype == NP.complex64 and relerr(v32, g['skyvis_f64'], g['pbfluxes']) <= 5e-6
+    with pytest.raises(ValueError):
+        hip.skyvis(g['dircos'][:5] * NP.nan, g['pbfluxes'][:5], g['pc_dircos'])           # PRISIM_EINVAL -> ValueError, as the stub maps it
