@@ -53,7 +53,9 @@ DEFAULTS = {
     'skyparm': {'model': 'custom', 'epoch': '2000', 'nside': 16, 'flux_unit': 'Jy', 'custom_reffreq': 0.150, 'flux_min': 0.0,
                 'flux_max': None, 'fluxcut_reffreq': None, 'spindex': -0.83, 'roi_radius': None, 'n_src': 100, 'seed': 1},
     'catalog': {'custom_file': 'custom_catalog.txt'},
-    'processing': {'gradient_mode': None, 'f_pad': 1.0, 'bpass_shape': 'bhw', 'delay_transform': False, 'memsave': False},
+    'processing': {'gradient_mode': None, 'f_pad': 1.0, 'bpass_shape': 'bhw', 'delay_transform': False, 'memsave': False,
+                   'add_noise': None, 'noise_seed': None},
+    'phasing': {'center': [90.0, 270.0], 'coords': 'altaz'},
     'pp': {'key': 'bl', 'eqvol': True},
     'save_redundant': True,
     'save_formats': {'npz': True, 'hdf5': False},
@@ -339,6 +341,27 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
             print('snapshot {0}/{1}: lst = {2:.4f} deg, {3} sources'.format(j + 1, n_acc, lst[j], ia.obs_catalog_indices[-1].size
                                                                               if len(ia.obs_catalog_indices) > j else 0))
     t_sim = time.time() - t0
+    # After the snapshots the reference adds thermal noise and re-centres the phases on phasing.center (run_prisim.py:2278-2282); the same
+    # here through the class methods.  The noise stage makes host-side cubes of the size of the visibility cube (vis_noise_freq, vis_freq,
+    # as in the reference): processing.add_noise = null (default) runs it up to 4 GiB per cube and says so when it skips, true / false
+    # force it; baseline-sharded runs gather the sky visibilities only and leave the noise out.  The re-centring is per baseline: every rank
+    # rotates its own shard where it lies, before the exchange.
+    noise_done = False
+    if world == 1:
+        want_noise = proc.get('add_noise')
+        cube_bytes = 16.0 * nbl_total * chans.size * n_acc
+        if want_noise is None:
+            want_noise = cube_bytes <= 4.0 * 2 ** 30
+            if not want_noise and verbose:
+                print('thermal noise left out: the cube is {0:.1f} GiB (processing.add_noise: true forces it)'.format(cube_bytes / 2 ** 30))
+        if want_noise:
+            ia.generate_noise(seed=proc.get('noise_seed'))
+            ia.add_noise()
+            noise_done = True
+    ph = parms.get('phasing') or {}
+    if ph.get('center') is not None:
+        ref_point = {'coords': ph.get('coords', 'altaz'), 'location': NP.asarray(ph['center'], dtype=float).reshape(1, -1)}
+        ia.rotate_visibilities(ref_point, do_delay_transform=False, verbose=False)
     if world > 1:
         if comm_uid is None:
             raise ValueError('comm_uid is needed when world > 1')
@@ -350,6 +373,8 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     out = {'skyvis_freq': cube, 'bl': bl_all, 'labels': labels_all, 'freq': chans, 'lst': NP.asarray(ia.lst),
            'timestamp': NP.asarray(ia.timestamp), 'bl_length': NP.sqrt(NP.sum(bl_all ** 2, axis=1)), 't_sim': t_sim,
            'antpos': antpos, 'ia': ia, 'blgroups': blgroups, 'world': world}
+    if noise_done:
+        out['vis_freq'], out['vis_noise_freq'] = ia.vis_freq[:nbl_total], ia.vis_noise_freq[:nbl_total]
     if proc.get('delay_transform'):
         # every rank transforms its own shard on its GPU (the FFT runs along frequency); sharded runs then exchange the spectra
         ia.delay_transform(pad=float(proc.get('f_pad', 1.0)), freq_wts=window(chans.size, proc.get('bpass_shape', 'bhw')), verbose=False)
@@ -377,13 +402,13 @@ def save(out, parms, infile=None):
         if any(c > 1 for c in counts):
             out = dict(out)
             out['labels'] = [m for lbl in out['labels'] for m in out['blgroups'].get(lbl, [lbl])]
-            for key, axis in (('skyvis_freq', 0), ('bl', 0), ('bl_length', 0), ('skyvis_lag', 0)):
+            for key, axis in (('skyvis_freq', 0), ('vis_freq', 0), ('vis_noise_freq', 0), ('bl', 0), ('bl_length', 0), ('skyvis_lag', 0)):
                 if key in out:
                     out[key] = NP.repeat(out[key], counts, axis=axis)
     if parms['save_formats'].get('npz', True):
         keys = {k: out[k] for k in ('skyvis_freq', 'lst', 'freq', 'timestamp', 'bl', 'bl_length')}          # interferometry.py:8862
         keys['labels'] = NP.asarray(out['labels'])
-        for extra in ('skyvis_lag', 'lags'):
+        for extra in ('vis_freq', 'vis_noise_freq', 'skyvis_lag', 'lags'):                                   # :8860-8861 when noise was added
             if extra in out:
                 keys[extra] = out[extra]
         NP.savez_compressed(path + '.npz', **keys)

@@ -32,6 +32,7 @@ def parms_for_test():
         'pointing': {'lst_init': 1.0, 'drift_init': {'ha': 0.0, 'dec': -30.7224}},
         'skyparm': {'model': 'ptsrc_random', 'n_src': 40, 'seed': 7, 'custom_reffreq': 0.150, 'spindex': -0.8},
         'processing': {'delay_transform': True, 'f_pad': 1.0, 'bpass_shape': 'bhw'},
+        'phasing': {'center': [75.0, 40.0], 'coords': 'altaz'},                   # away from the pointing: every rank re-centres its own shard
     })
     return p
 

@@ -80,6 +80,11 @@ class OracleContext(object):
     def sync(self):
         pass
 
+    def phase_rotate(self, nt, diff_dircos):
+        d = NP.asarray(diff_dircos, dtype=NP.float64).reshape(-1, 3)
+        for t in range(nt):
+            self.cube[t] = self.cube[t] * NP.exp(-2j * NP.pi * self.ch[None, :] * (self.bl @ d[t])[:, None] / 299792458.0)
+
     def timing(self, reset=False):
         return dict(self._timing)
 

@@ -173,7 +173,10 @@ def test_config1_yaml_end_to_end_matches_oracle(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     out = NP.load(os.path.join(str(tmp_path), 'prisim_amd_cfg1', 'cfg1', 'simdata', 'simvis.npz'))
-    assert sorted(out.files) == sorted(['skyvis_freq', 'lst', 'freq', 'timestamp', 'bl', 'bl_length', 'labels', 'skyvis_lag', 'lags'])
+    # the reference's npz keys (interferometry.py:8860-8861, noise added as in run_prisim.py:2278-2279) + labels and the delay spectra
+    assert sorted(out.files) == sorted(['skyvis_freq', 'vis_freq', 'vis_noise_freq', 'lst', 'freq', 'timestamp', 'bl', 'bl_length', 'labels',
+                                        'skyvis_lag', 'lags'])
+    assert NP.allclose(out['vis_freq'], out['skyvis_freq'] + out['vis_noise_freq'], rtol=1e-12, atol=0) and NP.std(out['vis_noise_freq'].real) > 0
     vis = out['skyvis_freq']
     assert vis.shape == (6, 64, 1)
     # oracle: same catalog in the local frame at lst = 0
@@ -189,6 +192,30 @@ def test_config1_yaml_end_to_end_matches_oracle(tmp_path):
     w = driver.window(64, 'bhw')
     lag, lags = DO.delay_transform(ref[:, :, None], NP.ones((6, 64, 1)), NP.broadcast_to(w[None, :, None], (6, 64, 1)), ch[1] - ch[0], pad=1.0)
     assert NP.max(NP.abs(out['skyvis_lag'] - lag)) <= 1e-10 * NP.max(NP.abs(lag))
+
+
+@pytest.mark.gpu
+def test_phasing_center_of_the_yaml_is_where_the_visibilities_end_up():
+    """run_prisim.py:2281-2282: after the snapshots the visibilities are re-centred on phasing.center.  A run with the phase centre 10 degrees
+    off zenith must equal the oracle's sky-sum phased there directly."""
+    from oracle import skyvis_oracle as O, beams_oracle as BO
+    p = driver.load_parms(os.path.join(EX, 'config1.yaml'))
+    p['array']['file'] = os.path.join(EX, 'config1_layout.txt')
+    p['catalog']['custom_file'] = os.path.join(EX, 'config1_catalog.txt')
+    p['phasing'] = {'center': [80.0, 30.0], 'coords': 'altaz'}
+    p['processing']['add_noise'] = False
+    p['processing']['delay_transform'] = False
+    out = driver.run(p, infile_dir=EX, verbose=False)
+    assert 'vis_freq' not in out
+    sm = driver.build_skymodel(p, EX)
+    lat = p['telescope']['latitude']
+    altaz = O.hadec2altaz(NP.stack((0.0 - sm.location[:, 0], sm.location[:, 1]), 1), lat)
+    ch = out['freq']
+    pb = BO.gaussian_beam(14.0, altaz, ch, pointing_altaz=O.hadec2altaz([[0.0, lat]], lat)[0]) * sm.generate_spectrum(frequency=ch)
+    pc_new = O.altaz2dircos(NP.array([[80.0, 30.0]]))[0]
+    ref = O.skyvis(out['bl'], ch, O.altaz2dircos(altaz), pb, pc_new, fwhm_deg=NP.zeros(altaz.shape[0]))
+    assert NP.max(NP.abs(out['skyvis_freq'][:, :, 0] - ref) / O.abs_flux_sum(pb)[None, :]) <= 1e-11
+    assert NP.allclose(out['ia'].phase_center, [[80.0, 30.0]] if out['ia'].phase_center_coords == 'altaz' else out['ia'].phase_center)
 
 
 @pytest.mark.gpu
