@@ -18,6 +18,7 @@ are added because the reference's catalogs are not available offline: skyparm.mo
 Time: without astropy the LST ramp is lst_init + t * 15.0410686 deg/h (mean sidereal rate), jd from jd_init or obs_date.
 """
 import copy
+import hashlib
 import datetime
 import os
 import time
@@ -344,20 +345,23 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     # After the snapshots the reference adds thermal noise and re-centres the phases on phasing.center (run_prisim.py:2278-2282); the same
     # here through the class methods.  The noise stage makes host-side cubes of the size of the visibility cube (vis_noise_freq, vis_freq,
     # as in the reference): processing.add_noise = null (default) runs it up to 4 GiB per cube and says so when it skips, true / false
-    # force it; baseline-sharded runs gather the sky visibilities only and leave the noise out.  The re-centring is per baseline: every rank
-    # rotates its own shard where it lies, before the exchange.
+    # force it.  Both steps are per baseline: every rank does them on its own shard, before the exchange (the noise cube is gathered too).
     noise_done = False
-    if world == 1:
-        want_noise = proc.get('add_noise')
-        cube_bytes = 16.0 * nbl_total * chans.size * n_acc
-        if want_noise is None:
-            want_noise = cube_bytes <= 4.0 * 2 ** 30
-            if not want_noise and verbose:
-                print('thermal noise left out: the cube is {0:.1f} GiB (processing.add_noise: true forces it)'.format(cube_bytes / 2 ** 30))
-        if want_noise:
-            ia.generate_noise(seed=proc.get('noise_seed'))
-            ia.add_noise()
-            noise_done = True
+    want_noise = proc.get('add_noise')
+    cube_bytes = 16.0 * nbl_total * chans.size * n_acc
+    if want_noise is None:
+        want_noise = cube_bytes <= 4.0 * 2 ** 30
+        if not want_noise and verbose and rank == 0:
+            print('thermal noise left out: the cube is {0:.1f} GiB (processing.add_noise: true forces it)'.format(cube_bytes / 2 ** 30))
+    if want_noise:
+        # counter-based draws keyed on the GLOBAL baseline index: a shard draws exactly what the unsharded run draws for its baselines, given
+        # the same seed -- processing.noise_seed, else one derived from the communicator id every rank holds (single process: a fresh one)
+        seed = proc.get('noise_seed')
+        if seed is None and world > 1:
+            seed = int.from_bytes(hashlib.sha1(bytes(comm_uid or b'')).digest()[:8], 'little')
+        ia.generate_noise(seed=seed, bl_offset=lo)
+        ia.add_noise()
+        noise_done = True
     ph = parms.get('phasing') or {}
     if ph.get('center') is not None:
         ref_point = {'coords': ph.get('coords', 'altaz'), 'location': NP.asarray(ph['center'], dtype=float).reshape(1, -1)}
@@ -368,13 +372,20 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         cube = ia.allgather(comm_uid, world, rank, download=download)   # shards go GPU -> GPU; the host never sees this rank's own cube
         cube = cube[:nbl_total] if cube is not None else None
         labels_all, bl_all = labels, bl
+        noise_all = None
+        if noise_done:
+            noise_all = ia.allgather_cube(ia.vis_noise_freq, world, download=download)
+            noise_all = noise_all[:nbl_total] if noise_all is not None else None
     else:
         cube, labels_all, bl_all = ia.skyvis_freq[:nbl_total], labels, bl
     out = {'skyvis_freq': cube, 'bl': bl_all, 'labels': labels_all, 'freq': chans, 'lst': NP.asarray(ia.lst),
            'timestamp': NP.asarray(ia.timestamp), 'bl_length': NP.sqrt(NP.sum(bl_all ** 2, axis=1)), 't_sim': t_sim,
            'antpos': antpos, 'ia': ia, 'blgroups': blgroups, 'world': world}
-    if noise_done:
+    if noise_done and world == 1:
         out['vis_freq'], out['vis_noise_freq'] = ia.vis_freq[:nbl_total], ia.vis_noise_freq[:nbl_total]
+    elif noise_done:
+        out['vis_noise_freq'] = noise_all
+        out['vis_freq'] = (cube + noise_all) if (cube is not None and noise_all is not None) else None
     if proc.get('delay_transform'):
         # every rank transforms its own shard on its GPU (the FFT runs along frequency); sharded runs then exchange the spectra
         ia.delay_transform(pad=float(proc.get('f_pad', 1.0)), freq_wts=window(chans.size, proc.get('bpass_shape', 'bhw')), verbose=False)
@@ -403,13 +414,13 @@ def save(out, parms, infile=None):
             out = dict(out)
             out['labels'] = [m for lbl in out['labels'] for m in out['blgroups'].get(lbl, [lbl])]
             for key, axis in (('skyvis_freq', 0), ('vis_freq', 0), ('vis_noise_freq', 0), ('bl', 0), ('bl_length', 0), ('skyvis_lag', 0)):
-                if key in out:
+                if out.get(key) is not None:
                     out[key] = NP.repeat(out[key], counts, axis=axis)
     if parms['save_formats'].get('npz', True):
         keys = {k: out[k] for k in ('skyvis_freq', 'lst', 'freq', 'timestamp', 'bl', 'bl_length')}          # interferometry.py:8862
         keys['labels'] = NP.asarray(out['labels'])
         for extra in ('vis_freq', 'vis_noise_freq', 'skyvis_lag', 'lags'):                                   # :8860-8861 when noise was added
-            if extra in out:
+            if out.get(extra) is not None:
                 keys[extra] = out[extra]
         NP.savez_compressed(path + '.npz', **keys)
     if parms['save_formats'].get('hdf5', False) and out.get('ia') is not None:

@@ -413,9 +413,20 @@ class InterferometerArray(object):
             raise RuntimeError('delay_transform() must be called first')
         if self.skyvis_lag.shape != (self.baselines.shape[0], self.channels.size, self.n_acc):
             raise NotImplementedError('host-side delay spectra are exchanged through the visibility slots: this needs nlag == nchan (pad = 0, 1, 2, ...)')
+        return self.allgather_cube(self.skyvis_lag, nranks, download=download)
+
+    def allgather_cube(self, cube, nranks, download=True):
+        """All-gather of a host-side (nbl, nchan, n_acc) cube of this shard that has no device copy (the thermal noise, host-side delay
+        spectra): it takes the place of the visibilities in the device cube slots for the exchange, and the visibilities go back afterwards.
+        Call after allgather().  Returns (nranks*nbl, nchan, n_acc), or None with download=False."""
+        if not getattr(self, '_comm_ready', False):
+            raise RuntimeError('allgather() must be called first (it sets up the communicator)')
+        cube = NP.asarray(cube)
+        if cube.shape != (self.baselines.shape[0], self.channels.size, self.n_acc):
+            raise ValueError('cube must have the shape of the visibility cube (nbl, nchan, n_acc)')
         _ = self.skyvis_freq                                           # make sure the host owns the visibilities before their slots are reused
         for t in range(self.n_acc):
-            self._ctx.set_vis(NP.ascontiguousarray(self.skyvis_lag[:, :, t], dtype=NP.complex128), slot=t)
+            self._ctx.set_vis(NP.ascontiguousarray(cube[:, :, t], dtype=NP.complex128), slot=t)
         self._ctx.allgather(self.n_acc, complex64=False)
         g = self._ctx.get_gathered(self.n_acc, nranks) if download else None
         for t in range(self.n_acc):                                    # and the visibilities go back into their slots

@@ -31,7 +31,7 @@ def parms_for_test():
         'obsparm': {'n_acc': 3, 't_acc': 600.0, 'obs_mode': 'drift'},
         'pointing': {'lst_init': 1.0, 'drift_init': {'ha': 0.0, 'dec': -30.7224}},
         'skyparm': {'model': 'ptsrc_random', 'n_src': 40, 'seed': 7, 'custom_reffreq': 0.150, 'spindex': -0.8},
-        'processing': {'delay_transform': True, 'f_pad': 1.0, 'bpass_shape': 'bhw'},
+        'processing': {'delay_transform': True, 'f_pad': 1.0, 'bpass_shape': 'bhw', 'noise_seed': 20261004},
         'phasing': {'center': [75.0, 40.0], 'coords': 'altaz'},                   # away from the pointing: every rank re-centres its own shard
     })
     return p
@@ -62,12 +62,18 @@ def main():
     err_l = float(NP.max(NP.abs(out['skyvis_lag'] - ref['skyvis_lag'])))
     lag_scale = float(NP.max(NP.abs(ref['skyvis_lag'])))
     ok = err_v <= tol and err_l <= max(tol, 1e-12 * lag_scale) and out['labels'] == ref['labels'] and NP.array_equal(out['bl'], ref['bl'])
+    # thermal noise: every shard draws what the unsharded run draws for its baselines; re-centred like the visibilities, gathered with them
+    noise_scale = float(NP.max(NP.abs(ref['vis_noise_freq'])))
+    err_n = float(NP.max(NP.abs(out['vis_noise_freq'] - ref['vis_noise_freq'])))
+    err_s = float(NP.max(NP.abs(out['vis_freq'] - ref['vis_freq'])))
+    ok = ok and noise_scale > 0 and err_n <= 1e-12 * noise_scale and err_s <= 1e-12 * noise_scale + tol
     # what the YAML entry point does (driver.main): only rank 0 pulls the gathered cube and spectra to the host
     out_root = driver.run(parms, rank=rank, world=world, device=0, comm_uid=uid, verbose=False, host_copy='root')
     if rank == 0:
-        ok = ok and NP.array_equal(out_root['skyvis_freq'], out['skyvis_freq']) and NP.array_equal(out_root['skyvis_lag'], out['skyvis_lag'])
+        ok = ok and NP.array_equal(out_root['skyvis_freq'], out['skyvis_freq']) and NP.array_equal(out_root['skyvis_lag'], out['skyvis_lag']) \
+            and NP.array_equal(out_root['vis_noise_freq'], out['vis_noise_freq'])
     else:
-        ok = ok and out_root['skyvis_freq'] is None and out_root['skyvis_lag'] is None
+        ok = ok and out_root['skyvis_freq'] is None and out_root['skyvis_lag'] is None and out_root['vis_freq'] is None
     all_ok = all(rdzv.allgather(bool(ok)))
     rdzv.barrier()
     rdzv.close()

@@ -70,9 +70,14 @@ class OracleContext(object):
         return (v, self._grad[slot].astype(ctype)) if want_grad else v
 
     def noise(self, rms, seed, bl_offset=0):
-        rng = NP.random.default_rng(int(seed) & 0xFFFFFFFF)
-        r = NP.asarray(rms, dtype=NP.float64)
-        return r / NP.sqrt(2.0) * (rng.standard_normal(r.shape) + 1j * rng.standard_normal(r.shape))
+        # like the device generator, keyed on the GLOBAL baseline index: a shard draws what the unsharded run draws for its baselines
+        r = NP.asarray(rms, dtype=NP.float64)                                  # (nt, nbl, nchan)
+        out = NP.empty(r.shape, dtype=NP.complex128)
+        for b in range(r.shape[1]):
+            rng = NP.random.default_rng([int(seed) & 0xFFFFFFFF, int(bl_offset) + b])
+            z = rng.standard_normal((r.shape[0], r.shape[2], 2))
+            out[:, b, :] = r[:, b, :] / NP.sqrt(2.0) * (z[..., 0] + 1j * z[..., 1])
+        return out
 
     def set_vis(self, vis, slot=0):
         self.cube[slot] = vis
