@@ -57,7 +57,8 @@ int prisim_hip_create(int device, prisim_ctx** out);
 void prisim_hip_destroy(prisim_ctx* ctx);
 /* Message of the last error on ctx (ctx may be NULL: last error of a failed create). */
 const char* prisim_hip_last_error(const prisim_ctx* ctx);
-/* Library version string "prisim_hip <major>.<minor> gfx950". */
+/* Library version string "prisim_hip <major>.<minor> gfx950"; the minor number changes with every change of a struct or a signature
+   in this header (0.2: prisim_timing carries the delay-stage fields).  A binding should refuse a library that reports another one. */
 const char* prisim_hip_version(void);
 
 /* ---- array: baselines + channels, resident across snapshots ---------------------------- */

@@ -10,6 +10,7 @@ import numpy as NP
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libprisim_hip.so')
+ABI_VERSION = 'prisim_hip 0.2 gfx950'       # prisim_hip_version(): bumped whenever a struct or a signature of include/prisim_hip.h changes
 
 PRISIM_OK = 0
 PRISIM_EINVAL, PRISIM_ENODEV, PRISIM_ENOMEM, PRISIM_ESTATE, PRISIM_ELIB, PRISIM_EINTERNAL = -1, -2, -3, -4, -5, -6
@@ -142,6 +143,11 @@ def load_library():
     lib.prisim_hip_last_error.restype = C.c_char_p
     lib.prisim_hip_version.argtypes = []
     lib.prisim_hip_version.restype = C.c_char_p
+    have = (lib.prisim_hip_version() or b'').decode()
+    if have != ABI_VERSION:
+        # a library of another round next to this binding: the structs below (prisim_timing, prisim_beam_sky ...) would be read wrongly
+        raise PrisimHipError('{0} reports {1!r}, this binding is written for {2!r}: rebuild it (python -c "import __graft_entry__ as g; '
+                             'g.build()")'.format(LIB_PATH, have, ABI_VERSION))
     lib.prisim_hip_set_array.argtypes = [vp, vp, i64, vp, i64, i64]
     lib.prisim_hip_set_sky.argtypes = [vp, C.POINTER(PrisimSky)]
     lib.prisim_hip_compute.argtypes = [vp, i32, i32, i32, i64]

@@ -394,7 +394,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
 
 extern "C" {
 
-const char* prisim_hip_version(void) { return "prisim_hip 0.1 gfx950"; }
+const char* prisim_hip_version(void) { return "prisim_hip 0.2 gfx950"; }     // 0.2: prisim_timing grew (delay fields), device-resident delay spectra
 
 const char* prisim_hip_last_error(const prisim_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 

@@ -31,6 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_string_without_context():
     lib = _abi.load_library()
     assert lib.prisim_hip_version().decode().startswith('prisim_hip ')
+    assert lib.prisim_hip_version().decode() == _abi.ABI_VERSION            # the binding refuses any other library (stale build)
     assert isinstance(lib.prisim_hip_last_error(None), bytes)
 
 
@@ -120,3 +121,13 @@ def test_sky_sum_kernels_use_no_scratch(tmp_path):
             a, b = min(cl, key=lambda ab: ab[1] - ab[0])
             assert KM.census('\n'.join(lines[a:b + 1])).get('v_lane', 0) <= 1, (name, a, b)
     assert found >= 19
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    """A stale libprisim_hip.so beside a newer binding (or the reverse) would have its structs misread: loading must fail loudly."""
+    monkeypatch.setattr(_abi, '_lib', None)
+    monkeypatch.setattr(_abi, 'ABI_VERSION', 'prisim_hip 9.9 gfx950')
+    with pytest.raises(_abi.PrisimHipError, match='rebuild'):
+        _abi.load_library()
+    monkeypatch.undo()
+    assert _abi.load_library() is not None
