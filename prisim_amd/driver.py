@@ -12,8 +12,9 @@ Replaced: `mpirun` ranks + per-rank part files + rank-0 concatenate become one p
 (RANK / WORLD_SIZE / LOCAL_RANK from the launcher) and a single RCCL all-gather of the visibility cube;
 the rank-0 ROI/beam precompute through FITS files disappears (beams are fused on the device).
 Not offered (out of scope): survey catalogs (SUMSS/NVSS/GLEAM/GSM need prisim/data, absent),
-gains, uvfits/uvh5 writers, `pp.key: 'freq' | 'src'`, plots, resource monitor.  PRISim's HDF5 layout is written for
-single-process runs (save_formats.hdf5); a sharded run writes the gathered npz.  Two synthetic sky models
+gains, uvfits/uvh5 writers, `pp.key: 'freq' | 'src'`, plots, resource monitor.  After the snapshots: thermal noise, re-centring on
+phasing.center, delay transform and the npz / HDF5 files, in the reference's order (:2278-2286); in a sharded run every rank does the
+per-baseline steps on its own shard and rank 0 puts the whole array together from the gathered cubes (assemble_full_array).  Two synthetic sky models
 are added because the reference's catalogs are not available offline: skyparm.model 'ptsrc_random' and 'healpix_synthetic'.
 Time: without astropy the LST ramp is lst_init + t * 15.0410686 deg/h (mean sidereal rate), jd from jd_init or obs_date.
 """
@@ -318,10 +319,10 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     skymod = build_skymodel(parms, infile_dir)
     jd, lst, hadec, t_acc, n_acc = schedule(parms)
     proc = parms['processing']
-    ia = RI.InterferometerArray(labels_mine, bl_mine, chans, telescope=tel, eff_Q=parms['telescope']['eff_Q'],
-                                latitude=tel['latitude'], longitude=tel['longitude'], altitude=tel['altitude'],
-                                skycoords='radec', A_eff=parms['telescope']['A_eff'], pointing_coords='hadec', device=device,
-                                blgroupinfo={'groups': blgroups, 'reversemap': {m: k for k, v in blgroups.items() for m in v}})
+    ia_kwargs = dict(telescope=tel, eff_Q=parms['telescope']['eff_Q'], latitude=tel['latitude'], longitude=tel['longitude'],
+                     altitude=tel['altitude'], skycoords='radec', A_eff=parms['telescope']['A_eff'], pointing_coords='hadec', device=device,
+                     blgroupinfo={'groups': blgroups, 'reversemap': {m: k for k, v in blgroups.items() for m in v}})
+    ia = RI.InterferometerArray(labels_mine, bl_mine, chans, **ia_kwargs)
     ia.reserve(n_acc)
     if extbeam is not None:
         bm = parms['beam']
@@ -380,7 +381,7 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         cube, labels_all, bl_all = ia.skyvis_freq[:nbl_total], labels, bl
     out = {'skyvis_freq': cube, 'bl': bl_all, 'labels': labels_all, 'freq': chans, 'lst': NP.asarray(ia.lst),
            'timestamp': NP.asarray(ia.timestamp), 'bl_length': NP.sqrt(NP.sum(bl_all ** 2, axis=1)), 't_sim': t_sim,
-           'antpos': antpos, 'ia': ia, 'blgroups': blgroups, 'world': world}
+           'antpos': antpos, 'ia': ia, 'blgroups': blgroups, 'world': world, 'ia_kwargs': ia_kwargs}
     if noise_done and world == 1:
         out['vis_freq'], out['vis_noise_freq'] = ia.vis_freq[:nbl_total], ia.vis_noise_freq[:nbl_total]
     elif noise_done:
@@ -392,21 +393,48 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         if world > 1:
             lag = ia.allgather_lags(world, download=download)
             out['skyvis_lag'] = lag[:nbl_total] if lag is not None else None
+            if noise_done and ia.vis_lag is not None and ia.vis_lag.shape == (bl_mine.shape[0], chans.size, n_acc):
+                # the spectra of the noisy and of the noise cube (host-side on every shard) travel like the noise cube did
+                for key, arr in (('vis_lag', ia.vis_lag), ('vis_noise_lag', ia.vis_noise_lag)):
+                    g = ia.allgather_cube(arr, world, download=download)
+                    out[key] = g[:nbl_total] if g is not None else None
         else:
             out['skyvis_lag'] = ia.skyvis_lag
         out['lags'] = ia.lags
     return out
 
 
+def assemble_full_array(out, parms):
+    """The InterferometerArray of the WHOLE array from what rank 0 of a baseline-sharded run holds: its own shard object (everything that
+    does not depend on the baseline) and the gathered cubes.  Stands where the reference concatenates the per-rank part files
+    (run_prisim.py:2233-2242)."""
+    if out.get('skyvis_freq') is None:
+        raise ValueError('this rank did not download the gathered cube (host_copy)')
+    shard = out['ia']
+    if shard.gradient_mode is not None:
+        raise NotImplementedError('the baseline gradients of a sharded run are not gathered')
+    full = RI.InterferometerArray(out['labels'], out['bl'], out['freq'], **out['ia_kwargs'])
+    full.adopt_observation(shard)
+    full.skyvis_freq = out['skyvis_freq']
+    if out.get('vis_freq') is not None:
+        full.vis_freq, full.vis_noise_freq = out['vis_freq'], out['vis_noise_freq']
+    if out.get('skyvis_lag') is not None:
+        full.skyvis_lag = out['skyvis_lag']
+    if out.get('vis_lag') is not None:
+        full.vis_lag, full.vis_noise_lag = out['vis_lag'], out['vis_noise_lag']
+    ph = parms.get('phasing') or {}
+    if ph.get('center') is not None:                  # the shards were re-centred there before the exchange: projected baselines to match
+        full.project_baselines({'coords': ph.get('coords', 'altaz'), 'location': NP.asarray(ph['center'], dtype=float).reshape(1, -1)})
+    return full
+
+
 def save(out, parms, infile=None):
-    if parms['save_formats'].get('hdf5', False) and out.get('world', 1) > 1:
-        # before anything is written: every rank of a baseline-sharded run holds its own InterferometerArray shard
-        raise NotImplementedError('HDF5 output of a baseline-sharded run is not supported; use the gathered npz')
     ds = parms['dirstruct']
     simid = ds['simid'] or time.strftime('%Y-%m-%d-%H-%M-%S')
     outdir = os.path.join(ds['rootdir'], ds['project'], simid, 'simdata')
     os.makedirs(outdir, exist_ok=True)
     path = os.path.join(outdir, 'simvis')
+    out_hdf5 = out                                    # the HDF5 path re-creates the redundant baselines itself (duplicate_measurements)
     if parms.get('save_redundant', True) and out.get('blgroups'):
         # re-create the redundant baselines from the simulated unique ones (run_prisim.py:2325-2326, interferometry.py:6889-6895)
         counts = [len(out['blgroups'].get(lbl, [lbl])) for lbl in out['labels']]
@@ -424,9 +452,10 @@ def save(out, parms, infile=None):
                 keys[extra] = out[extra]
         NP.savez_compressed(path + '.npz', **keys)
     if parms['save_formats'].get('hdf5', False) and out.get('ia') is not None:
-        # PRISim's HDF5 layout (interferometry.py:8717-8846) of this process's InterferometerArray, redundant baselines re-created
-        # first when asked for (run_prisim.py:2325-2326).  Single-process runs only: a sharded run gathers the cube, not the object.
-        ia = out['ia']
+        # PRISim's HDF5 layout (interferometry.py:8717-8846) of the InterferometerArray, redundant baselines re-created first when asked
+        # for (run_prisim.py:2325-2326).
+        # a baseline-sharded run first puts the whole array together from rank 0's shard object and the gathered cubes
+        ia = assemble_full_array(out_hdf5, parms) if out.get('world', 1) > 1 else out['ia']
         if parms.get('save_redundant', True) and ia.blgroups and len(ia.labels) < sum(len(v) for v in ia.blgroups.values()):
             ia.duplicate_measurements()
         ia.save(path, fmt='HDF5', npz=False, overwrite=True, verbose=False)

@@ -1074,6 +1074,48 @@ class InterferometerArray(object):
             for t in range(self.n_acc):
                 self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
 
+    def adopt_observation(self, shard):
+        """Make this (so far unobserved) array stand for the WHOLE array of an observation of which `shard` -- another InterferometerArray, one
+        rank's baseline shard -- was a part: take over everything that does not depend on the baseline (snapshots, pointings, phase centres,
+        system-temperature records, the bandpass / weights / Tsys layers).  What the reference gets by concatenating the per-rank part files
+        along the baseline axis (scripts/run_prisim.py:2233-2242, interferometry.py `concatenate`); here the visibility cubes arrive through
+        the all-gather and are assigned by the caller (skyvis_freq, vis_freq, vis_noise_freq, skyvis_lag ...).  Per-baseline layers of a
+        shard cannot stand for the other shards' baselines and are refused."""
+        if self.timestamp:
+            raise ValueError('adopt_observation() is for an array that has not observed anything itself')
+        if not NP.array_equal(self.channels, shard.channels):
+            raise ValueError('the shard was observed on another channel grid')
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        for name in ('bp', 'bp_wts', 'Tsys'):
+            st = shard._stacks.get(name)
+            if st is not None:
+                if any(l.shape[0] != 1 for l in st.layers) or (NP.ndim(st.initial) == 2 and st.initial.shape[0] not in (1,)):
+                    raise ValueError('{0} of the shard varies with the baseline: not enough to describe the whole array'.format(name))
+                new = _LayerStack(nbl, nchan, st.initial)
+                new.layers = list(st.layers)
+                self._stacks[name] = new
+                self.__dict__.setdefault('_dense', {}).pop(name, None)
+            else:
+                dense = NP.asarray(shard._dense[name])
+                if dense.shape[0] > 1 and not NP.array_equal(dense, NP.broadcast_to(dense[:1], dense.shape)):
+                    raise ValueError('{0} of the shard varies with the baseline: not enough to describe the whole array'.format(name))
+                self._set_stacked(name, NP.array(NP.broadcast_to(dense[:1], (nbl,) + dense.shape[1:])))
+        if shard.vis_rms_freq is not None:
+            rms = NP.asarray(shard.vis_rms_freq)
+            if rms.shape[0] > 1 and not NP.array_equal(rms, NP.broadcast_to(rms[:1], rms.shape)):
+                raise ValueError('vis_rms_freq of the shard varies with the baseline: not enough to describe the whole array')
+            self.vis_rms_freq = NP.array(NP.broadcast_to(rms[:1], (nbl,) + rms.shape[1:]))
+        self.timestamp, self.t_acc, self.lst = list(shard.timestamp), list(shard.t_acc), list(shard.lst)
+        self.t_obs, self.n_acc = shard.t_obs, shard.n_acc
+        self.Tsysinfo = list(shard.Tsysinfo)
+        self.pointing_center = NP.array(shard.pointing_center)
+        self.phase_center = NP.array(shard.phase_center)
+        self.phase_center_coords = shard.phase_center_coords
+        self.obs_catalog_indices = list(shard.obs_catalog_indices)
+        self.flux_unit = shard.flux_unit
+        self.lags = None if shard.lags is None else NP.array(shard.lags)
+        self.noise_seed = getattr(shard, 'noise_seed', None)
+
     def apply_gradients(self, gradient_mode=None, perturbations=None):
         """First-order change of the sky visibilities under small baseline displacements, from the gradient cube observe()
         accumulated with gradient_mode='baseline' (interferometry.py:6726-6819; arithmetic :6810-6812):

@@ -37,6 +37,58 @@ def parms_for_test():
     return p
 
 
+def _hdf5_of_sharded_run_equals_unsharded(parms, out_sharded, out_single):
+    """Rank 0 of the sharded run writes PRISim's HDF5 file of the WHOLE array (driver.assemble_full_array: its own shard object + the
+    gathered cubes, where the reference concatenates part files); it must hold what the unsharded run's file holds, dataset by dataset."""
+    import tempfile
+    from prisim_amd import hdf5io
+    try:
+        hdf5io._load()
+    except hdf5io.HDF5Unavailable:
+        return True
+    files = []
+    for tag, out in (('sharded', out_sharded), ('single', out_single)):
+        p = driver.deep_merge(parms, {'dirstruct': {'rootdir': tempfile.mkdtemp() + '/', 'project': 'p', 'simid': tag},
+                                      'save_formats': {'npz': True, 'hdf5': True}})
+        driver.save(out, p)
+        files.append(os.path.join(p['dirstruct']['rootdir'], 'p', tag, 'simdata', 'simvis.hdf5'))
+
+    def content(fname):
+        found = {}
+        with hdf5io.File(fname, 'r') as f:
+            def walk(group):
+                for name in f.list(group or '/'):
+                    path = (group + '/' + name) if group else name
+                    try:
+                        f.list(path)
+                        walk(path)
+                    except KeyError:
+                        found[path] = f.read(path)
+            walk('')
+        return found
+    a, b = content(files[0]), content(files[1])
+    if sorted(a) != sorted(b):
+        print('HDF5 objects differ:', sorted(set(a) ^ set(b)))
+        return False
+    for key in a:
+        va, vb = a[key], b[key]
+        if isinstance(va, str) or isinstance(vb, str):
+            same = va == vb
+        else:
+            va, vb = NP.asarray(va), NP.asarray(vb)
+            if va.shape != vb.shape:
+                same = False
+            elif va.dtype.kind in 'fc':
+                scale = float(NP.max(NP.abs(vb))) if vb.size else 0.0
+                same = bool(NP.all(NP.isnan(va) == NP.isnan(vb))) and float(NP.max(NP.abs(NP.nan_to_num(va - vb)), initial=0.0)) <= 1e-11 * max(scale, 1e-300)
+            else:
+                same = bool(NP.array_equal(va, vb))
+        if not same:
+            print('HDF5 dataset differs:', key)
+            return False
+    return len(a) > 30
+
+
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else 'oracle'
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
@@ -74,6 +126,8 @@ def main():
             and NP.array_equal(out_root['vis_noise_freq'], out['vis_noise_freq'])
     else:
         ok = ok and out_root['skyvis_freq'] is None and out_root['skyvis_lag'] is None and out_root['vis_freq'] is None
+    if rank == 0:
+        ok = ok and _hdf5_of_sharded_run_equals_unsharded(parms, out_root, ref)
     all_ok = all(rdzv.allgather(bool(ok)))
     rdzv.barrier()
     rdzv.close()
