@@ -4,9 +4,9 @@
 Metric (BASELINE.json): visibility-terms/s = nbl * nchan * nsrc * nt / wall, on the synthetic
 HERA-350 x 1024-channel x 1e4-source workload (SURVEY.md 8(d) config 3, fp32 with tolerance check).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1 launched bare: starts its own N ranks, prisim_amd.launch -- no torch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W        (the driver's launcher: only its RANK / WORLD_SIZE are used)
 
 A "step" is one snapshot: one pass of the hot path (prep + pack + sky-sum kernel) over the whole
 sky with all inputs already resident in HBM.  With N > 1 the baselines are sharded in contiguous
@@ -17,13 +17,18 @@ INSIDE the timed region.  The total workload is fixed as N grows ("scaling": "st
 
 No torch anywhere: the launcher only provides RANK / WORLD_SIZE / LOCAL_RANK; the out-of-band exchange of the 128-byte RCCL id,
 the barriers and the max-over-ranks of the timing go through prisim_amd.rendezvous (loopback sockets), all GPU work through
-libprisim_hip.so.  If the RCCL communicator cannot be built at N > 1 the run FAILS (non-zero exit): there is no host-side gather.
+libprisim_hip.so.  If the RCCL communicator cannot be built at N > 1, or its 1 MiB self-test all-gather does not deliver every
+rank's pattern, the run FAILS before the timed region (exit 3, RCCL's own warnings on stderr): there is no host-side gather.
+At N > 1 the line also carries `gather` (bytes per peer, per-snapshot ms on the communication stream, the exposed tail after the last
+sky-sum, GB/s per xGMI link against 153), the slowest / fastest rank's kernel ms and `value_n1_equiv` = value / N.
 
 Rank 0 prints ONE JSON line.  Beside the contract's keys it carries (N = 1 only, all outside the timed region):
   roofline / roofline_hbm   the dominant kernel against the VALU issue roofline (the binding one) and the HBM figure BASELINE words
   cpu_baseline              C/OpenMP port of interferometry.py:6332-6340 on this box's host cores (bounded sample) + parity check
   cpu_baseline_ref          the reference FORMULATION itself: numpy restatement, one process, slabbed like :6348-6376 (bounded sample)
+  cpu_baseline_ref_xN       the reference's parallel model: N such processes side by side over baseline chunks (mpirun, run_prisim.py:1749-1791)
   e2e                       the same snapshots through InterferometerArray.observe(), host geometry and sky staging included
+  e2e_host                  the same with every snapshot landing in (pinned) HOST memory: downloads overlapped with the next sky-sum
   delay_ps                  delay power spectra of the K resident snapshots (interferometry.py:8114-8134 + delay_spectrum.py:3992):
                             device time, FFT count, achieved algorithmic GB/s against the 8 TB/s HBM roofline
   other_kernels             one timed launch each of the fp64 kernel (headline sky) and of the packed fp32 taper kernel (config 3 with its
@@ -41,11 +46,12 @@ import numpy as NP
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from prisim_amd import _abi, rendezvous, workloads as W   # noqa: E402
+from prisim_amd import _abi, launch, rendezvous, workloads as W   # noqa: E402
 
 FLOPS_PER_TERM = 10.0       # rotate (4 mul + 2 add) + accumulate (2 mul + 2 add) = 6 VALU slots
 PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # MI355X_MICROARCH.md chip table: vector FP32 157.3 TF; FP64 = half
 HBM_PEAK_GBS = 8000.0
+XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md: 7 point-to-point links of ~153 GB/s per GPU
 
 
 def shard_range(nbl, world, rank):
@@ -79,28 +85,149 @@ def csrc_hash():
     return h.hexdigest()
 
 
-def cpu_baseline(cfg, pbflux_sample_fn, target_terms=1.0e10):
+def host_cpu_info():
+    """The host this process may run on: CPU model, logical CPUs, the affinity set, the physical cores inside it, any cgroup quota."""
+    info = {'cpu_model': None, 'nproc': os.cpu_count()}
+    cores = {}
+    try:
+        cur = {}
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if ':' in line:
+                    k, v = [x.strip() for x in line.split(':', 1)]
+                    cur[k] = v
+                elif cur:
+                    if info['cpu_model'] is None:
+                        info['cpu_model'] = cur.get('model name')
+                    cores[int(cur.get('processor', -1))] = (cur.get('physical id', '0'), cur.get('core id', cur.get('processor')))
+                    cur = {}
+            if cur:
+                cores[int(cur.get('processor', -1))] = (cur.get('physical id', '0'), cur.get('core id', cur.get('processor')))
+                if info['cpu_model'] is None:
+                    info['cpu_model'] = cur.get('model name')
+    except Exception:
+        pass
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except Exception:
+        aff = list(range(os.cpu_count() or 1))
+    info['affinity_cpus'] = len(aff)
+    phys = {cores[c] for c in aff if c in cores}
+    info['physical_cores'] = len(phys) if phys else len(aff)
+    info['sockets'] = len({p[0] for p in phys}) if phys else None
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, per = f.read().split()
+            if q != 'max':
+                quota = float(q) / float(per)
+    except Exception:
+        pass
+    info['cgroup_cpu_quota'] = quota
+    usable = info['physical_cores']
+    if quota:
+        usable = max(1, min(usable, int(quota)))
+    info['usable_cores'] = usable
+    return info
+
+
+def cpu_baseline(cfg, pbflux_sample_fn, target_seconds=8.0):
     """Time the C oracle (oracle/skyvis_oracle.c, the checker) on a bounded baseline sample of the same
-    workload, on this box's host cores.  Reported baseline only -- never the thing measured above."""
+    workload, on ALL the physical cores this process may use on this box (one OpenMP thread per core).  The sample is sized from a
+    calibration pass so that the leg takes about target_seconds.  Reported baseline only -- never the thing measured above."""
     from oracle import c_oracle as CO
     CO.use_native_build()          # -march=native for THIS host's cores (falls back to the shipped portable build)
-    threads = max(1, min(16, os.cpu_count() or 1, CO.max_threads()))
+    cpu = host_cpu_info()
+    threads = max(1, cpu['usable_cores'])
     bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
     nsrc, nchan = sky['dircos'].shape[0], ch.size
-    nbl_s = int(max(threads, min(bl.shape[0], target_terms // (nsrc * nchan))))
-    stride = max(1, bl.shape[0] // nbl_s)
-    bls = NP.ascontiguousarray(bl[::stride][:nbl_s])
     pb = pbflux_sample_fn()
     zen = NP.array([0.0, 0.0, 1.0])
     fw = sky['fwhm_deg'] if cfg['taper'] else None
-    CO.skyvis(bls[:threads], ch, sky['dircos'], pb, zen, fwhm_deg=fw, nthreads=threads)     # warm-up
+    ncal = min(bl.shape[0], threads)
+    cal_sel = NP.linspace(0, bl.shape[0] - 1, ncal).astype(int)
+    CO.skyvis(bl[cal_sel], ch, sky['dircos'], pb, zen, fwhm_deg=fw, nthreads=threads)     # warm-up: threads, page faults
+    t0 = time.perf_counter()
+    CO.skyvis(bl[cal_sel], ch, sky['dircos'], pb, zen, fwhm_deg=fw, nthreads=threads)     # calibration: one baseline per thread
+    t_cal = max(time.perf_counter() - t0, 1e-4)
+    rounds = int(max(1, min(target_seconds / t_cal, bl.shape[0] // max(ncal, 1))))
+    nbl_s = min(bl.shape[0], ncal * rounds)
+    stride = max(1, bl.shape[0] // nbl_s)
+    bls = NP.ascontiguousarray(bl[::stride][:nbl_s])
     t0 = time.perf_counter()
     ref = CO.skyvis(bls, ch, sky['dircos'], pb, zen, fwhm_deg=fw, nthreads=threads)
     dt = time.perf_counter() - t0
     terms = float(bls.shape[0]) * nchan * nsrc
-    return {'value': terms / dt, 'unit': 'terms/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d of %d baselines (every %d-th) x %d ch x %d src = %.3g terms in %.1f s, C/OpenMP libm-sincos port of '
-                      'interferometry.py:6332-6340, %s' % (bls.shape[0], bl.shape[0], stride, nchan, nsrc, terms, dt, CO.flavour)}, bls, ref, stride
+    return {'value': terms / dt, 'unit': 'terms/s', 'cores': threads, 'threads': threads, 'kind': 'port',
+            'cpu_model': cpu['cpu_model'], 'nproc': cpu['nproc'], 'physical_cores': cpu['physical_cores'], 'sockets': cpu['sockets'],
+            'affinity_cpus': cpu['affinity_cpus'], 'cgroup_cpu_quota': cpu['cgroup_cpu_quota'],
+            'sample': '%d of %d baselines (every %d-th) x %d ch x %d src = %.3g terms in %.1f s on %d threads (one per physical core this '
+                      'process may use), C/OpenMP libm-sincos port of interferometry.py:6332-6340, %s'
+                      % (bls.shape[0], bl.shape[0], stride, nchan, nsrc, terms, dt, threads, CO.flavour)}, bls, ref, stride
+
+
+def cpu_baseline_ref_xn(cfg, pb, t_one_baseline, max_ranks=32, target_seconds=8.0, slab_bytes=128 << 20):
+    """The reference's own parallel model on this box: N independent single-threaded numpy processes, each simulating a contiguous chunk
+    of baselines with the statements of interferometry.py:6320-6376 (oracle/ref_rank.py; `mpirun -n N run_prisim.py`,
+    scripts/run_prisim.py:1749-1791, README.rst:93-99).  N = the physical cores this process may use, capped at max_ranks (each rank
+    holds a slab_bytes phase-matrix slab plus three temporaries of that size); the ranks start together on a go-file and the rate is
+    all their terms over the SLOWEST rank's time, as a job's wall clock would be."""
+    import subprocess
+    import tempfile
+    import shutil
+    cpu = host_cpu_info()
+    n = int(max(1, min(max_ranks, cpu['usable_cores'])))
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    nsrc, nchan = sky['dircos'].shape[0], ch.size
+    per = int(max(1, min(16, target_seconds / max(t_one_baseline, 1e-3))))       # baselines per rank
+    sel = NP.linspace(0, bl.shape[0] - 1, n * per).astype(int)
+    tmp = tempfile.mkdtemp(prefix='prisim_refxn_')
+    try:
+        inputs = os.path.join(tmp, 'inputs.npz')
+        arrs = dict(bl=bl[sel], ch=ch, dircos=sky['dircos'], pb=pb, pc=NP.array([0.0, 0.0, 1.0]))
+        if cfg['taper']:
+            arrs['fwhm'] = sky['fwhm_deg']
+        NP.savez(inputs, **arrs)
+        prefix = os.path.join(tmp, 'run')
+        env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'oracle', 'ref_rank.py'), inputs, str(r), str(n), prefix, str(slab_bytes)],
+                                  env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for r in range(n)]
+        t_wait = time.time()
+        while not all(os.path.exists('%s.ready%d' % (prefix, r)) for r in range(n)):
+            if time.time() - t_wait > 120.0 or any(p.poll() not in (None, 0) for p in procs):
+                for p_ in procs:
+                    if p_.poll() is None:
+                        p_.kill()
+                raise RuntimeError('reference ranks did not start')
+            time.sleep(0.01)
+        t0 = time.perf_counter()
+        open(prefix + '.go', 'w').close()
+        for p_ in procs:
+            try:
+                p_.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    if q.poll() is None:
+                        q.kill()
+                raise RuntimeError('a reference rank did not finish within 300 s')
+        wall = time.perf_counter() - t0
+        if any(p_.returncode != 0 for p_ in procs):
+            raise RuntimeError('a reference rank failed: ' + (procs[0].stderr.read().decode()[-300:] if procs[0].stderr else ''))
+        vis = NP.zeros((sel.size, nchan), dtype=NP.complex128)
+        secs = []
+        for r in range(n):
+            with NP.load('%s.rank%d.npz' % (prefix, r)) as f:
+                vis[int(f['lo']):int(f['hi'])] = f['vis']
+                secs.append(float(f['seconds']))
+        terms = float(sel.size) * nchan * nsrc
+        return {'value': terms / max(secs), 'unit': 'terms/s', 'cores': n, 'ranks': n, 'kind': 'reference-formulation x N ranks (oracle/ref_rank.py)',
+                'cpu_model': cpu['cpu_model'], 'nproc': cpu['nproc'], 'physical_cores': cpu['physical_cores'],
+                'slowest_rank_s': max(secs), 'fastest_rank_s': min(secs), 'wall_incl_startup_s': wall,
+                'sample': '%d ranks x %d baselines x %d ch x %d src = %.3g terms; rate = all terms / slowest rank (%.1f s); one numpy process '
+                          'per rank, %d MiB source slabs (interferometry.py:6348-6376), the reference\'s mpirun model (run_prisim.py:1749-1791)'
+                          % (n, per, nchan, nsrc, terms, max(secs), slab_bytes >> 20)}, sel, vis
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline_reference_formulation(cfg, pb, target_seconds=8.0):
@@ -124,7 +251,8 @@ def cpu_baseline_reference_formulation(cfg, pb, target_seconds=8.0):
     terms = float(nb) * nchan * nsrc
     return {'value': terms / dt, 'unit': 'terms/s', 'cores': 1, 'kind': 'reference-formulation (numpy restatement, oracle/skyvis_oracle.py)',
             'sample': '%d of %d baselines x %d ch x %d src = %.3g terms in %.1f s, one process, the statements of '
-                      'interferometry.py:6320-6343 (source slabs as :6348-6376 when the phase matrix does not fit)' % (nb, bl.shape[0], nchan, nsrc, terms, dt)}, sel, ref
+                      'interferometry.py:6320-6343 (source slabs as :6348-6376 when the phase matrix does not fit)' % (nb, bl.shape[0], nchan, nsrc, terms, dt),
+            'seconds_per_baseline': dt / nb}, sel, ref
 
 
 def profiled_traffic(kernel_tag):
@@ -241,7 +369,7 @@ def power_clock(ctx, cfg, zen, prec):
     return res
 
 
-def e2e_observe(cfg, n_snap, device, memsave):
+def e2e_observe(cfg, n_snap, device, memsave, to_host=False):
     """The same workload through the reference's entry point for the path, InterferometerArray.observe() (interferometry.py:5874):
     per snapshot the host geometry (hadec -> altaz -> direction cosines of every source), the sky staging (nsrc-sized vectors), the
     fused beam x flux, prep, pack and the sky-sum.  Returns terms/s over n_snap snapshots, wall clock around the loop + final sync."""
@@ -256,18 +384,28 @@ def e2e_observe(cfg, n_snap, device, memsave):
 
     ia = RI.InterferometerArray(['b%d' % i for i in range(bl.shape[0])], bl, ch, telescope={'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'},
                                 latitude=-30.7224, skycoords='altaz', pointing_coords='hadec', device=device)
-    ia.reserve(n_snap + 1)
-    observe(ia, 0)                      # warm-up snapshot: allocations, first-launch costs
+    ia.reserve(n_snap + 1, host_staging=to_host)
+    observe(ia, 0)                      # warm-up snapshot: allocations (incl. the pinned host cube), first-launch costs
     ia._ctx.sync()
     t0 = time.perf_counter()
     for j in range(1, n_snap + 1):
         observe(ia, j)
+    if to_host:
+        cube = ia.skyvis_freq           # (nbl, nchan, n_acc) on the host: waits for the last snapshot's copy only
+        assert cube.shape == (bl.shape[0], ch.size, n_snap + 1)
     ia._ctx.sync()
     dt = time.perf_counter() - t0
     terms = float(bl.shape[0]) * ch.size * n * n_snap
+    res = {'value': terms / dt, 'unit': 'terms/s', 'snapshots': n_snap, 'ms_per_snapshot': dt / n_snap * 1e3}
+    if to_host:
+        res['staged'] = bool(ia._stage and ia._host_cube is not None)
+        res['host_bytes_per_snapshot'] = int(bl.shape[0]) * int(ch.size) * (8 if memsave else 16)
+        res['path'] = ('InterferometerArray.observe() with reserve(host_staging=True): as e2e, plus every snapshot copied into a page-locked host '
+                       'cube on a copy stream under the next snapshot\'s sky-sum; the clock stops when skyvis_freq is readable on the host')
+    else:
+        res['path'] = 'InterferometerArray.observe(): host geometry + sky staging + fused beam + sky-sum, cube left resident on the device'
     ia._ctx.close()
-    return {'value': terms / dt, 'unit': 'terms/s', 'snapshots': n_snap, 'ms_per_snapshot': dt / n_snap * 1e3,
-            'path': 'InterferometerArray.observe(): host geometry + sky staging + fused beam + sky-sum, cube left resident on the device'}
+    return res
 
 
 def main():
@@ -282,7 +420,14 @@ def main():
                          '(source-shape taper on); cfg5: one LST of config 5 (nside=256 diffuse sky, taper on)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU baselines, the e2e and the delay-stage extras (profiling runs)')
     ap.add_argument('--chan-tile', type=int, default=0, help='A/B hook: force the channel tile of the recurrence kernels (0 = planned)')
+    ap.add_argument('--want-grad', action='store_true', help='profiling hook: every step also computes the baseline gradient (fused kernel)')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # launched bare: become the launcher.  N rank processes are started BEFORE anything here touches the GPU (this process never
+        # does), with RANK / LOCAL_RANK / WORLD_SIZE set; rank 0's JSON line goes to the inherited stdout; the exit code is the job's.
+        script = os.environ.get('PRISIM_BENCH_SELF', os.path.abspath(__file__))
+        sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, script] + sys.argv[1:]))
 
     # Libraries loaded later (RCCL prints a version banner on its first communicator) write to fd 1: keep the real stdout for
     # the ONE JSON line of the contract and send everything else to stderr.
@@ -294,10 +439,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
-        args.gpus = world
-    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')          # single node: RCCL bootstraps over loopback
+        args.gpus = world                                      # the launcher's world size is the truth
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')          # single node: RCCL bootstraps over loopback (one node is all this bench does)
+    if world > 1:
+        os.environ.setdefault('NCCL_DEBUG', 'WARN')            # a communicator that cannot be built says why, on stderr
     rdzv = rendezvous.Rendezvous(rank, world)                  # sockets only: before any GPU call
 
     if args.workload == 'cfg5':
@@ -340,24 +485,32 @@ def main():
                 err = 'RCCL comm_init failed: %r' % (exc,)
         elif err is None:
             err = 'no RCCL unique id received'
+        if err is None:
+            try:
+                ctx.comm_selftest(1 << 20)     # 1 MiB per rank through ncclAllGather, every rank's pattern verified on the host
+            except Exception as exc:
+                err = 'RCCL self-test failed: %r' % (exc,)
         errs = [e for e in rdzv.allgather(err) if e]
         if errs:
             sys.stderr.write('rank %d: %s\n' % (rank, '; '.join(errs)))
             rdzv.close()
             sys.exit(3)        # no host-side gather fallback: a value printed without RCCL would not be the metric
 
+    wg = bool(args.want_grad)
     for i in range(Wm):
-        ctx.compute(precision=prec, slot=i % K)
+        ctx.compute(precision=prec, slot=i % K, want_grad=wg)
         if world > 1:
             ctx.allgather_slot_async(i % K, complex64=c64)
     ctx.sync()
     ctx.timing(reset=True)
+    if world > 1:
+        ctx.comm_stats(reset=True)
 
     rdzv.barrier()
     ctx.sync()
     t0 = time.perf_counter()
     for t in range(K):
-        ctx.compute(precision=prec, slot=t)
+        ctx.compute(precision=prec, slot=t, want_grad=wg)
         if world > 1:
             # RCCL all-gather of snapshot t on the communication stream, overlapped with the sky-sum of snapshot t+1;
             # only the last snapshot's exchange is exposed.  Still inside the timed region.
@@ -369,6 +522,26 @@ def main():
 
     tm = ctx.timing()
     gather_ok = None
+    my_kern_ms = tm['sum_kernel_ms'] / max(1, tm['n_kernel'])
+    rank_kern_ms = rdzv.allgather(my_kern_ms)
+    gstats = None
+    if world > 1:
+        cs_ = ctx.comm_stats()
+        per_snap = cs_['sum_gather_ms'] / max(1, cs_['n_gathers'])
+        mine_g = {'per_snapshot_ms': per_snap, 'max_ms': cs_['max_gather_ms'], 'exposed_ms': cs_['last_gather_after_compute_ms'],
+                  'bytes_per_peer': cs_['bytes_per_peer'], 'n': cs_['n_gathers'], 'prio': [cs_['stream_priority'], cs_['stream_priority_lowest']]}
+        allg = rdzv.allgather(mine_g)
+        worst = max(allg, key=lambda g: g['per_snapshot_ms'])
+        gbps = (worst['bytes_per_peer'] / (worst['per_snapshot_ms'] * 1e-3) / 1e9) if worst['per_snapshot_ms'] > 0 else None
+        gstats = {'what': 'ncclAllGather of one snapshot per step on the highest-priority communication stream, overlapped with the next sky-sum',
+                  'bytes_per_peer': worst['bytes_per_peer'], 'wire_dtype': 'complex64' if c64 else 'complex128',
+                  'per_snapshot_ms': worst['per_snapshot_ms'], 'per_snapshot_ms_all_ranks': [g['per_snapshot_ms'] for g in allg],
+                  'max_ms': max(g['max_ms'] for g in allg),
+                  'exposed_ms': max(g['exposed_ms'] for g in allg),
+                  'exposed_ms_what': 'end of the LAST snapshot\'s gather minus end of its sky-sum, slowest rank: the part no compute hides',
+                  'GBps_per_link': gbps, 'link_peak_GBps': XGMI_LINK_GBS, 'link_frac': (gbps / XGMI_LINK_GBS) if gbps else None,
+                  'GBps_per_link_what': 'one shard to each of N-1 peers over its own xGMI link, while the sky-sum grid occupies the CUs (slowest rank)',
+                  'gathers_measured': worst['n'], 'comm_stream_priority': worst['prio'][0], 'lowest_priority': worst['prio'][1]}
     if world > 1:
         # every rank must hold the same gathered cube (device checksums agree) AND rank r's block of it must be rank r's own
         # shard, element for element (a plain checksum would not see swapped rank blocks)
@@ -385,12 +558,13 @@ def main():
         kern_ms = tm['sum_kernel_ms'] / max(1, tm['n_kernel'])
         # terms one launch of the dominant kernel processes on this rank (padded shard)
         terms_launch = float(bl_mine.shape[0]) * nchan * nsrc
-        ach_tflops = terms_launch * FLOPS_PER_TERM / (kern_ms * 1e-3) / 1e12
+        flops_term = FLOPS_PER_TERM + (6.0 if wg else 0.0)      # the gradient adds 6 flops per term (three more real x complex FMAs)
+        ach_tflops = terms_launch * flops_term / (kern_ms * 1e-3) / 1e12
         wp = 4 if prec == _abi.PRISIM_FP32 else 8
         alg_bytes = nsrc * nchan * wp + 24 * nsrc + 24 * bl_mine.shape[0] + 8 * nchan + 2 * 8 * bl_mine.shape[0] * nchan
         ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = traffic_src = None
-        if world == 1 and nsrc == 10000 and args.workload == 'cfg3':
+        if world == 1 and nsrc == 10000 and args.workload == 'cfg3' and not wg:
             tr = profiled_traffic('f32pk<64, false>' if dtype == 'f32' else 'k_skyvis_rec<double, 32, false>')
             if tr is not None:
                 traffic, traffic_src = tr
@@ -404,16 +578,19 @@ def main():
             'roofline': {'bound': 'valu', 'achieved': ach_tflops, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
                          'frac': ach_tflops / PEAK_TFLOPS[dtype], 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                          'traffic_source': traffic_src,
-                         'kernel': 'k_skyvis_rec', 'avg_kernel_ms': kern_ms, 'flops_per_term': FLOPS_PER_TERM,
+                         'kernel': 'k_skyvis_grad' if wg else 'k_skyvis_rec', 'avg_kernel_ms': kern_ms, 'flops_per_term': flops_term,
                          'terms_per_launch': terms_launch},
             'roofline_hbm': {'bound': 'hbm', 'achieved': ach_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': ach_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                              'algorithmic_bytes_per_launch': alg_bytes},
             'csrc_hash': csrc_hash(),
         }
+        out['kernel_ms_per_rank'] = {'min': min(rank_kern_ms), 'max': max(rank_kern_ms), 'all': rank_kern_ms}
+        out['value_n1_equiv'] = value / world           # whole-job rate per GPU: what to hold against the N = 1 line
         if world > 1:
-            out['gather'] = 'rccl-allgather (per snapshot, overlapped)'
+            out['gather'] = gstats
             out['gather_ok'] = gather_ok
+            out['launcher'] = 'torch.distributed.run env' if 'TORCHELASTIC_RUN_ID' in os.environ else 'prisim_amd.launch'
         if world == 1 and not args.no_cpu_baseline:
             pb_host = None
             try:
@@ -427,13 +604,24 @@ def main():
                 out['parity_max_err_rel_sumflux'] = float(NP.max(NP.abs(gpu - ref) / scale))
             except Exception as exc:   # the baseline is a report, never a reason to lose the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'terms/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (exc,)}
+            t_one = None
             try:
                 cbr, sel, ref2 = cpu_baseline_reference_formulation(cfg, pb_host)
                 cbr['parity_of_gpu_vs_this_max_err_rel_sumflux'] = float(NP.max(NP.abs(ctx.get_vis(slot=K - 1)[sel] - ref2)
                                                                                 / NP.sum(NP.abs(pb_host), axis=0)[None, :]))
+                t_one = cbr.pop('seconds_per_baseline')
                 out['cpu_baseline_ref'] = cbr
             except Exception as exc:
                 out['cpu_baseline_ref'] = {'value': None, 'unit': 'terms/s', 'cores': 1, 'kind': 'reference-formulation', 'sample': 'failed: %r' % (exc,)}
+            try:
+                if t_one is None:
+                    raise RuntimeError('the one-process leg failed')
+                cbx, selx, refx = cpu_baseline_ref_xn(cfg, pb_host, t_one)
+                cbx['parity_of_gpu_vs_this_max_err_rel_sumflux'] = float(NP.max(NP.abs(ctx.get_vis(slot=K - 1)[selx] - refx)
+                                                                                / NP.sum(NP.abs(pb_host), axis=0)[None, :]))
+                out['cpu_baseline_ref_xN'] = cbx
+            except Exception as exc:
+                out['cpu_baseline_ref_xN'] = {'value': None, 'unit': 'terms/s', 'cores': 0, 'kind': 'reference-formulation x N', 'sample': 'failed: %r' % (exc,)}
             try:
                 # delay power spectra of the K resident snapshots, one window for all baselines, pad = 1 (run_prisim.py:954, 2284)
                 win = NP.blackman(nchan) + 0.01
@@ -465,6 +653,12 @@ def main():
                 out['e2e'] = e2e_observe(cfg, 3, device, memsave=(prec == _abi.PRISIM_FP32))
             except Exception as exc:
                 out['e2e'] = {'value': None, 'error': repr(exc)}
+            try:
+                out['e2e_host'] = e2e_observe(cfg, 3, device, memsave=(prec == _abi.PRISIM_FP32), to_host=True)
+                if out['e2e'].get('ms_per_snapshot'):
+                    out['e2e_host']['over_e2e'] = out['e2e_host']['ms_per_snapshot'] / out['e2e']['ms_per_snapshot']
+            except Exception as exc:
+                out['e2e_host'] = {'value': None, 'error': repr(exc)}
         json_out.write(json.dumps(out) + '\n')
         json_out.flush()
     ctx.close()

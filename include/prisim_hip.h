@@ -58,7 +58,7 @@ void prisim_hip_destroy(prisim_ctx* ctx);
 /* Message of the last error on ctx (ctx may be NULL: last error of a failed create). */
 const char* prisim_hip_last_error(const prisim_ctx* ctx);
 /* Library version string "prisim_hip <major>.<minor> gfx950"; the minor number changes with every change of a struct or a signature
-   in this header (0.2: prisim_timing carries the delay-stage fields).  A binding should refuse a library that reports another one. */
+   in this header (0.2: prisim_timing carries the delay-stage fields; 0.3: prisim_comm_stats, self-test, gradient gather, asynchronous downloads).  A binding should refuse a library that reports another one. */
 const char* prisim_hip_version(void);
 
 /* ---- array: baselines + channels, resident across snapshots ---------------------------- */
@@ -257,6 +257,41 @@ int prisim_hip_allgather_lags(prisim_ctx* ctx, int64_t nt);
 /* Checksum (sum of all re,im accumulated in double, fixed reduction order) of the gathered cube,
  * computed on the device. */
 int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out);
+/* The baseline-gradient cubes of a sharded run (gradient_mode='baseline'; the reference concatenates them over baseline chunks,
+ * interferometry.py:8349-8350): gathers [nt][3][nbl_shard][nchan] into [nt][nranks][3][nbl_shard][nchan]; read with
+ * prisim_hip_get_gathered (its rows are then 3 nchan long). */
+int prisim_hip_allgather_grad(prisim_ctx* ctx, int64_t nt, int as_c64);
+/* All-gather of `bytes` per rank filled with a rank-dependent pattern, read back and verified on the host: run once before any
+ * timed or production exchange so that a communicator that cannot move data fails HERE (PRISIM_ELIB + message), not as a wrong cube.
+ * Also valid on a 1-rank context without a communicator (device copy). */
+int prisim_hip_comm_selftest(prisim_ctx* ctx, int64_t bytes);
+
+/* What the overlapped per-snapshot gathers (prisim_hip_allgather_slot_async) cost, from hipEvent pairs on the communication stream. */
+typedef struct prisim_comm_stats {
+  int64_t n_gathers;                     /* gathers measured since the last reset */
+  int64_t bytes_per_peer;                /* bytes of this rank's shard that every peer receives per gather (= bytes it receives from each) */
+  double sum_gather_ms;                  /* start -> end on the communication stream (complex64 rounding kernel included), summed */
+  double last_gather_ms, max_gather_ms;
+  double last_gather_after_compute_ms;   /* end of the LAST gather minus end of the sky-sum it followed: the part no later compute hid */
+  int32_t stream_priority;               /* priority the communication stream was created with (numerically lower = higher) ... */
+  int32_t stream_priority_lowest;        /* ... and the lowest the device offers (the compute stream runs at default priority 0) */
+  int32_t nranks;
+  int32_t reserved_;
+} prisim_comm_stats;
+int prisim_hip_get_comm_stats(prisim_ctx* ctx, prisim_comm_stats* out, int reset);
+
+/* ---- host-visible results without a serial PCIe tail (interferometry.py:6384-6393: skyvis_freq lives on the host) ---------------- */
+
+/* Page-locked host memory for asynchronous downloads (hipHostMalloc / hipHostFree). */
+int prisim_hip_host_alloc(int64_t bytes, void** out);
+int prisim_hip_host_free(void* p);
+/* Enqueue the download of cube slot `slot` (and of its gradient block when grad != NULL) into caller memory that must stay valid
+ * until prisim_hip_wait_downloads / prisim_hip_sync returns: the copy waits for everything issued so far on the compute stream and
+ * runs on a copy stream, i.e. the PCIe transfer of snapshot t overlaps the sky-sum of snapshot t+1.  out_is_c64: rounded to
+ * complex64 on the device first (half the bytes).  Memory from prisim_hip_host_alloc gives a true overlap; pageable memory works
+ * but is staged by the runtime. */
+int prisim_hip_get_vis_async(prisim_ctx* ctx, int64_t slot, void* vis, void* grad, int out_is_c64);
+int prisim_hip_wait_downloads(prisim_ctx* ctx);
 
 /* ---- timing / introspection -------------------------------------------------------------- */
 

@@ -10,7 +10,7 @@ import numpy as NP
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libprisim_hip.so')
-ABI_VERSION = 'prisim_hip 0.2 gfx950'       # prisim_hip_version(): bumped whenever a struct or a signature of include/prisim_hip.h changes
+ABI_VERSION = 'prisim_hip 0.3 gfx950'       # prisim_hip_version(): bumped whenever a struct or a signature of include/prisim_hip.h changes
 
 PRISIM_OK = 0
 PRISIM_EINVAL, PRISIM_ENODEV, PRISIM_ENOMEM, PRISIM_ESTATE, PRISIM_ELIB, PRISIM_EINTERNAL = -1, -2, -3, -4, -5, -6
@@ -29,6 +29,8 @@ EXPORTS = (
     'prisim_hip_allgather_lags', 'prisim_hip_phase_rotate', 'prisim_hip_noise', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
     'prisim_hip_allgather', 'prisim_hip_allgather_slot_async', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
+    'prisim_hip_allgather_grad', 'prisim_hip_comm_selftest', 'prisim_hip_get_comm_stats',
+    'prisim_hip_host_alloc', 'prisim_hip_host_free', 'prisim_hip_get_vis_async', 'prisim_hip_wait_downloads',
 )
 
 
@@ -116,6 +118,12 @@ class PrisimTiming(C.Structure):
                 ('last_taper_group', C.c_int32), ('last_delay_fused', C.c_int32), ('last_delay_ms', C.c_double)]
 
 
+class PrisimCommStats(C.Structure):
+    _fields_ = [('n_gathers', C.c_int64), ('bytes_per_peer', C.c_int64), ('sum_gather_ms', C.c_double), ('last_gather_ms', C.c_double),
+                ('max_gather_ms', C.c_double), ('last_gather_after_compute_ms', C.c_double), ('stream_priority', C.c_int32),
+                ('stream_priority_lowest', C.c_int32), ('nranks', C.c_int32), ('reserved_', C.c_int32)]
+
+
 class PrisimHipError(RuntimeError):
     """Raised when libprisim_hip.so is missing/unloadable or no GPU is usable."""
 
@@ -176,6 +184,13 @@ def load_library():
     lib.prisim_hip_get_timing.argtypes = [vp, C.POINTER(PrisimTiming), i32]
     lib.prisim_hip_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p]
     lib.prisim_hip_set_tuning.argtypes = [vp, i32, i32, i32]
+    lib.prisim_hip_allgather_grad.argtypes = [vp, i64, i32]
+    lib.prisim_hip_comm_selftest.argtypes = [vp, i64]
+    lib.prisim_hip_get_comm_stats.argtypes = [vp, C.POINTER(PrisimCommStats), i32]
+    lib.prisim_hip_host_alloc.argtypes = [i64, C.POINTER(vp)]
+    lib.prisim_hip_host_free.argtypes = [vp]
+    lib.prisim_hip_get_vis_async.argtypes = [vp, i64, vp, vp, i32]
+    lib.prisim_hip_wait_downloads.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ('prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version'):
@@ -197,6 +212,22 @@ def _raise(code, msg):
     if code == PRISIM_ESTATE:
         raise RuntimeError(msg)
     raise PrisimHipError(msg)
+
+
+def host_empty(shape, dtype):
+    """numpy array over page-locked host memory (prisim_hip_host_alloc): the destination of asynchronous downloads.  Freed when the
+    last view of it is garbage-collected."""
+    import weakref
+    lib = load_library()
+    dtype = NP.dtype(dtype)
+    nbytes = int(NP.prod(shape, dtype=NP.int64)) * dtype.itemsize
+    p = C.c_void_p()
+    rc = lib.prisim_hip_host_alloc(max(nbytes, 1), C.byref(p))
+    if rc != PRISIM_OK:
+        _raise(rc, 'prisim_hip_host_alloc({0} B) failed: {1}'.format(nbytes, lib.prisim_hip_last_error(None).decode()))
+    buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+    weakref.finalize(buf, lib.prisim_hip_host_free, C.c_void_p(p.value))
+    return NP.frombuffer(buf, dtype=dtype, count=int(NP.prod(shape, dtype=NP.int64))).reshape(shape)
 
 
 class Context(object):
@@ -514,6 +545,40 @@ class Context(object):
         out = NP.empty((nt, nranks, self.nbl, row), dtype=NP.complex64 if getattr(self, '_gathered_c64', False) else NP.complex128)
         self._check(self._lib.prisim_hip_get_gathered(self._h, int(nt), _ptr(out)), 'prisim_hip_get_gathered')
         return out
+
+    def allgather_grad(self, nt, complex64=False):
+        """Gather the baseline-gradient cube of nt snapshots; read with get_gathered_grad(nt, nranks)."""
+        self._check(self._lib.prisim_hip_allgather_grad(self._h, int(nt), 1 if complex64 else 0), 'prisim_hip_allgather_grad')
+        self._gathered_c64 = bool(complex64)
+
+    def get_gathered_grad(self, nt, nranks=None):
+        """(nt, nranks, 3, nbl_shard, nchan) after allgather_grad."""
+        nranks = getattr(self, 'nranks', 1) if nranks is None else nranks
+        g = self.get_gathered(nt, nranks, row=3 * self.nchan)                  # rows of 3*nchan: the block is [3][nbl][nchan] per rank
+        return g.reshape(nt, nranks, 3, self.nbl, self.nchan)
+
+    def comm_selftest(self, nbytes=1 << 20):
+        """All-gather of a rank-dependent pattern, verified on the host; raises PrisimHipError when the communicator cannot move data."""
+        self._check(self._lib.prisim_hip_comm_selftest(self._h, int(nbytes)), 'prisim_hip_comm_selftest')
+
+    def comm_stats(self, reset=False):
+        st = PrisimCommStats()
+        self._check(self._lib.prisim_hip_get_comm_stats(self._h, C.byref(st), 1 if reset else 0), 'prisim_hip_get_comm_stats')
+        return {k: getattr(st, k) for k, _ in PrisimCommStats._fields_ if k != 'reserved_'}
+
+    # ---- asynchronous downloads ----
+    def get_vis_async(self, slot, out, grad_out=None):
+        """Enqueue the download of slot `slot` into `out` (nbl, nchan) complex128 / complex64 -- ideally an array from host_empty() --
+        on the copy stream, behind the compute issued so far.  The arrays must stay alive until wait_downloads() / sync()."""
+        if out.shape != (self.nbl, self.nchan) or out.dtype not in (NP.complex128, NP.complex64) or not out.flags['C_CONTIGUOUS']:
+            raise ValueError('out must be a C-contiguous (nbl, nchan) complex128 / complex64 array')
+        c64 = out.dtype == NP.complex64
+        if grad_out is not None and (grad_out.shape != (3, self.nbl, self.nchan) or grad_out.dtype != out.dtype or not grad_out.flags['C_CONTIGUOUS']):
+            raise ValueError('grad_out must be a C-contiguous (3, nbl, nchan) array of the dtype of out')
+        self._check(self._lib.prisim_hip_get_vis_async(self._h, int(slot), _ptr(out), _ptr(grad_out), 1 if c64 else 0), 'prisim_hip_get_vis_async')
+
+    def wait_downloads(self):
+        self._check(self._lib.prisim_hip_wait_downloads(self._h), 'prisim_hip_wait_downloads')
 
     def gathered_checksum(self, nt, complex64=None):
         v = C.c_double()

@@ -168,6 +168,16 @@ struct prisim_ctx {
   int nranks = 1, rank = 0;
   DevBuf gathered, sendbuf;
   bool gathered_c64 = false;
+  // gather timing: a ring of (compute-stream marker, gather start, gather end) events per overlapped gather, harvested in order
+  static constexpr int kCommRing = 32;
+  hipEvent_t ev_gc[kCommRing] = {}, ev_g0[kCommRing] = {}, ev_g1[kCommRing] = {};
+  int cring_head = 0, cring_pending = 0;
+  prisim_comm_stats cstats{};
+  // asynchronous downloads (prisim_hip_get_vis_async): copy stream behind an event on the compute stream
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copy_ready = nullptr;
+  bool copy_pending = false;
+  DevBuf dl_stage;                       // complex64 staging of one slot (+ its three gradient slots)
 
   // fft
   rocfft_plan fft_plan = nullptr;
@@ -186,8 +196,27 @@ struct prisim_ctx {
 namespace {
 
 int fail(prisim_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->err = msg; else g_create_error = msg;
+  try {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+  } catch (...) {      // the message itself could not be stored: the code still says what happened
+  }
   return code;
+}
+
+// Every extern "C" entry runs its body through this: no C++ exception crosses the ABI; a failed host allocation
+// becomes PRISIM_ENOMEM, anything else PRISIM_EINTERNAL with the exception's text.
+template <typename F>
+int guarded(prisim_ctx* ctx, F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return fail(ctx, PRISIM_ENOMEM, "out of host memory");
+  } catch (const std::exception& e) {
+    const char* w = e.what();
+    try { return fail(ctx, PRISIM_EINTERNAL, std::string("C++ exception: ") + (w ? w : "?")); } catch (...) { return PRISIM_EINTERNAL; }
+  } catch (...) {
+    return fail(ctx, PRISIM_EINTERNAL, "unknown C++ exception");
+  }
 }
 
 #define HIPCHK(ctx, call)                                                                      \
@@ -300,6 +329,59 @@ void harvest_timing(prisim_ctx* ctx, int max_wait = -1) {
   }
 }
 
+// Collect finished gather timings (oldest first).  wait_all: hipEventSynchronize every pending entry; otherwise only take what is complete.
+void harvest_comm(prisim_ctx* ctx, bool wait_all) {
+  while (ctx->cring_pending > 0) {
+    const int i = (ctx->cring_head - ctx->cring_pending + 2 * prisim_ctx::kCommRing) % prisim_ctx::kCommRing;
+    if (wait_all) {
+      if (hipEventSynchronize(ctx->ev_g1[i]) != hipSuccess) { ctx->cring_pending = 0; return; }
+    } else if (hipEventQuery(ctx->ev_g1[i]) != hipSuccess) {
+      return;
+    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_g0[i], ctx->ev_g1[i]) == hipSuccess) {
+      ctx->cstats.last_gather_ms = ms;
+      ctx->cstats.sum_gather_ms += ms;
+      if (ms > ctx->cstats.max_gather_ms) ctx->cstats.max_gather_ms = ms;
+      ctx->cstats.n_gathers += 1;
+    }
+    // what the overlap did not hide of THIS gather: its end against the compute-stream marker recorded when it was enqueued
+    // (= the end of the snapshot's own sky-sum); only the last harvested entry is kept -- the gathers before it ran under later compute
+    if (hipEventElapsedTime(&ms, ctx->ev_gc[i], ctx->ev_g1[i]) == hipSuccess) ctx->cstats.last_gather_after_compute_ms = ms;
+    ctx->cring_pending -= 1;
+  }
+}
+
+// The communication stream gets the HIGHEST priority the device offers: its RCCL kernels are few blocks that must be scheduled
+// beside a sky-sum grid occupying every CU; with equal priority they would only start as sky-sum blocks drain.
+int ensure_comm_stream(prisim_ctx* ctx) {
+  if (ctx->comm_stream) return PRISIM_OK;
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+  if (hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->comm_stream = nullptr;
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    greatest = 0; least = 0;
+  }
+  ctx->cstats.stream_priority = greatest;
+  ctx->cstats.stream_priority_lowest = least;
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_slot_done, hipEventDisableTiming));
+  for (int i = 0; i < prisim_ctx::kCommRing; ++i) {
+    HIPCHK(ctx, hipEventCreate(&ctx->ev_gc[i]));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev_g0[i]));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev_g1[i]));
+  }
+  return PRISIM_OK;
+}
+
+int ensure_copy_stream(prisim_ctx* ctx) {
+  if (ctx->copy_stream) return PRISIM_OK;
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copy_ready, hipEventDisableTiming));
+  return PRISIM_OK;
+}
+
 struct Plan {
   int kernel;      // PRISIM_KERNEL_*
   bool f32;
@@ -394,11 +476,12 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
 
 extern "C" {
 
-const char* prisim_hip_version(void) { return "prisim_hip 0.2 gfx950"; }     // 0.2: prisim_timing grew (delay fields), device-resident delay spectra
+const char* prisim_hip_version(void) { return "prisim_hip 0.3 gfx950"; }     // 0.3: comm stats / self-test / gradient gather, asynchronous downloads
 
 const char* prisim_hip_last_error(const prisim_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int prisim_hip_create(int device, prisim_ctx** out) {
+  return guarded(nullptr, [&]() -> int {
   if (!out) return fail(nullptr, PRISIM_EINVAL, "out is NULL");
   *out = nullptr;
   int ndev = 0;
@@ -430,6 +513,7 @@ int prisim_hip_create(int device, prisim_ctx** out) {
   }
   *out = ctx;
   return PRISIM_OK;
+  });
 }
 
 void prisim_hip_destroy(prisim_ctx* ctx) {
@@ -438,14 +522,20 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   if (ctx->ev_slot_done) (void)hipEventDestroy(ctx->ev_slot_done);
+  for (int i = 0; i < prisim_ctx::kCommRing; ++i)
+    for (hipEvent_t ev : {ctx->ev_gc[i], ctx->ev_g0[i], ctx->ev_g1[i]})
+      if (ev) (void)hipEventDestroy(ev);
   if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+  if (ctx->ev_copy_ready) (void)hipEventDestroy(ctx->ev_copy_ready);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->fft_plan && g_rocfft.plan_destroy) g_rocfft.plan_destroy(ctx->fft_plan);
   if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->dirs_prep, &ctx->dirs_c32, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
-                    &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
+                    &ctx->dl_stage, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
   for (int i = 0; i < prisim_ctx::kTimingRing; ++i)
     for (hipEvent_t ev : {ctx->ev_c0[i], ctx->ev_c1[i], ctx->ev_k0[i], ctx->ev_k1[i]})
@@ -460,6 +550,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
 
 int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, const double* freqs_hz, int64_t nchan,
                          int64_t nt_max) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!bl_enu || !freqs_hz) return fail(ctx, PRISIM_EINVAL, "bl_enu / freqs_hz is NULL");
   if (nbl <= 0 || nchan <= 0 || nt_max <= 0) return fail(ctx, PRISIM_EINVAL, "nbl, nchan and nt_max must be positive");
@@ -516,6 +607,7 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   ctx->dt_have_lag = ctx->dt_have_pow = false;
   ctx->array_set = true;
   return PRISIM_OK;
+  });
 }
 
 // Directions + source-shape constants of one snapshot -> ctx->dirs, through the pinned staging area (no synchronisation).
@@ -579,6 +671,7 @@ static int upload_any(prisim_ctx* ctx, void* dst, const void* src, size_t bytes,
 }
 
 int prisim_hip_set_sky(prisim_ctx* ctx, const prisim_sky* sky) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky");
@@ -609,9 +702,11 @@ int prisim_hip_set_sky(prisim_ctx* ctx, const prisim_sky* sky) {
   stage_end(ctx);
   ctx->sky_set = true;
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_analytic");
@@ -723,9 +818,11 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
   }
   ctx->sky_set = true;
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_set_external_beam(prisim_ctx* ctx, const double* beam, int64_t npix, int64_t nfreq, const double* interp_matrix) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_external_beam");
   if (!beam || !interp_matrix) return fail(ctx, PRISIM_EINVAL, "beam / interp_matrix is NULL");
@@ -754,6 +851,7 @@ int prisim_hip_set_external_beam(prisim_ctx* ctx, const double* beam, int64_t np
   HIPCHK(ctx, e);
   ctx->ext_nside = (int)nside;
   return PRISIM_OK;
+  });
 }
 
 // beam table -> pbflux for the current directions; fluxes: device [nsrc][nchan] table, or NULL with flux_ref / spindex (device [nsrc])
@@ -771,6 +869,7 @@ static int extbeam_sky(prisim_ctx* ctx, int64_t nsrc, const double* d_fluxes, co
 }
 
 int prisim_hip_set_sky_external(prisim_ctx* ctx, const prisim_sky* sky) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_external");
@@ -792,9 +891,11 @@ int prisim_hip_set_sky_external(prisim_ctx* ctx, const prisim_sky* sky) {
   stage_end(ctx);
   ctx->sky_set = true;
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_set_sky_external_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_external_analytic");
@@ -823,9 +924,11 @@ int prisim_hip_set_sky_external_analytic(prisim_ctx* ctx, const prisim_beam_sky*
   stage_end(ctx);
   ctx->sky_set = true;
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->sky_set) return fail(ctx, PRISIM_ESTATE, "no sky set");
   if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
@@ -834,6 +937,7 @@ int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (n > 0) HIPCHK(ctx, hipMemcpy(out, ctx->pb.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   return PRISIM_OK;
+  });
 }
 
 // kernel parameters common to every sky-sum launch of the current array / sky / plan
@@ -925,6 +1029,7 @@ static int run_grad_pass(prisim_ctx* ctx, const Plan& pl, double* dst, double* g
 }
 
 int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad, int64_t slot) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set || !ctx->sky_set) return fail(ctx, PRISIM_ESTATE, "set_array and set_sky must precede compute");
   if (precision != PRISIM_FP64 && precision != PRISIM_FP32) return fail(ctx, PRISIM_EINVAL, "unknown precision");
@@ -1032,6 +1137,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   ctx->timing.last_chan_tile = pl.kernel == PRISIM_KERNEL_RECURRENCE ? pl.ct : 1;
   ctx->timing.last_nsplit = pl.kernel == PRISIM_KERNEL_RECURRENCE ? pl.nsplit : 1;
   return PRISIM_OK;
+  });
 }
 
 static void to_c64(const double* in, float* out, size_t n2) {
@@ -1039,6 +1145,7 @@ static void to_c64(const double* in, float* out, size_t n2) {
 }
 
 int prisim_hip_get_vis(prisim_ctx* ctx, int64_t slot, void* vis, void* grad, int out_is_c64) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
   if (slot < 0 || slot >= ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "slot out of range");
@@ -1064,9 +1171,11 @@ int prisim_hip_get_vis(prisim_ctx* ctx, int64_t slot, void* vis, void* grad, int
     }
   }
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_set_vis(prisim_ctx* ctx, int64_t slot, const double* vis) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
   if (slot < 0 || slot >= ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "slot out of range");
@@ -1077,26 +1186,34 @@ int prisim_hip_set_vis(prisim_ctx* ctx, int64_t slot, const double* vis) {
                              hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_skyvis(prisim_ctx* ctx, const prisim_sky* sky, int precision, int kernel, void* vis, void* grad,
                       int out_is_c64) {
+  return guarded(ctx, [&]() -> int {
   int rc = prisim_hip_set_sky(ctx, sky);
   if (rc) return rc;
   if ((rc = prisim_hip_compute(ctx, precision, kernel, grad != nullptr, 0))) return rc;
   return prisim_hip_get_vis(ctx, 0, vis, grad, out_is_c64);
+  });
 }
 
 int prisim_hip_sync(prisim_ctx* ctx) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->comm_stream && ctx->comm_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
+  if (ctx->copy_stream && ctx->copy_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream)); ctx->copy_pending = false; }
   harvest_timing(ctx);
+  harvest_comm(ctx, true);
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_get_timing(prisim_ctx* ctx, prisim_timing* out, int reset) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
   if (ctx->ring_pending > 0) {
@@ -1112,17 +1229,21 @@ int prisim_hip_get_timing(prisim_ctx* ctx, prisim_timing* out, int reset) {
   *out = ctx->timing;
   if (reset) { ctx->timing.sum_kernel_ms = 0.0; ctx->timing.n_kernel = 0; }
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_device_info(prisim_ctx* ctx, int* cu_count, int* clock_khz, char name[64]) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (cu_count) *cu_count = ctx->cu_count;
   if (clock_khz) *clock_khz = ctx->clock_khz;
   if (name) { memcpy(name, ctx->devname, 64); name[63] = 0; }
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_set_tuning(prisim_ctx* ctx, int chan_tile, int src_chunk, int nsplit) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (chan_tile != 0 && chan_tile != 8 && chan_tile != 16 && chan_tile != 32 && chan_tile != 64)
     return fail(ctx, PRISIM_EINVAL, "chan_tile must be 0, 8, 16, 32 or 64");
@@ -1130,6 +1251,7 @@ int prisim_hip_set_tuning(prisim_ctx* ctx, int chan_tile, int src_chunk, int nsp
     return fail(ctx, PRISIM_EINVAL, "src_chunk must be in [0,256], nsplit in [0,4096]");
   ctx->tune_ct = chan_tile; ctx->tune_chunk = src_chunk; ctx->tune_nsplit = nsplit;
   return PRISIM_OK;
+  });
 }
 
 // ---- delay transform ------------------------------------------------------------------------
@@ -1270,6 +1392,7 @@ int delay_check(prisim_ctx* ctx, int64_t nt, double& pad) {
 
 int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts, double pad, double* out,
                                double* lags_out, double* out_power, double power_scale) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   int rc;
   if ((rc = delay_check(ctx, nt, pad))) return rc;
@@ -1298,10 +1421,12 @@ int prisim_hip_delay_transform(prisim_ctx* ctx, int64_t nt, const double* bpwts,
   }
   if (lags_out) delay_lags(ctx, lags_out);
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_delay_transform_device(prisim_ctx* ctx, int64_t nt, const double* bpwts, int64_t wts_rows, double pad, int want_lag, int want_power,
                                       double power_scale, double* lags_out, int64_t* nout_out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   int rc;
   if ((rc = delay_check(ctx, nt, pad))) return rc;
@@ -1333,6 +1458,7 @@ int prisim_hip_delay_transform_device(prisim_ctx* ctx, int64_t nt, const double*
   if (lags_out) delay_lags(ctx, lags_out);
   if (nout_out) *nout_out = nout;
   return PRISIM_OK;
+  });
 }
 
 // Copy rows of the resident spectra to the host.  rows == NULL: all nbl baselines.
@@ -1362,16 +1488,21 @@ static int get_resident(prisim_ctx* ctx, const DevBuf& buf, bool have, int reals
 }
 
 int prisim_hip_get_lags(prisim_ctx* ctx, int64_t t0, int64_t nt, const int64_t* rows, int64_t nrows, double* out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   return get_resident(ctx, ctx->dt_lag_all, ctx->dt_have_lag, 2, t0, nt, rows, nrows, out);
+  });
 }
 
 int prisim_hip_get_delay_power(prisim_ctx* ctx, int64_t t0, int64_t nt, const int64_t* rows, int64_t nrows, double* out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   return get_resident(ctx, ctx->dt_pow_all, ctx->dt_have_pow, 1, t0, nt, rows, nrows, out);
+  });
 }
 
 int prisim_hip_phase_rotate(prisim_ctx* ctx, int64_t nt, const double* diff_dircos) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
   if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
@@ -1386,9 +1517,11 @@ int prisim_hip_phase_rotate(prisim_ctx* ctx, int64_t nt, const double* diff_dirc
                                   (const double*)ctx->freqs.p, (const double*)ctx->scratch.p, nt, ctx->nbl, ctx->nchan, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // diff_dircos is caller-owned
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_noise(prisim_ctx* ctx, int64_t nt, const double* rms, uint64_t seed, int64_t bl_offset, double* out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
   if (nt <= 0 || !rms || !out || bl_offset < 0) return fail(ctx, PRISIM_EINVAL, "bad noise arguments");
@@ -1412,11 +1545,13 @@ int prisim_hip_noise(prisim_ctx* ctx, int64_t nt, const double* rms, uint64_t se
   release(drms); release(dout);
   HIPCHK(ctx, e);
   return PRISIM_OK;
+  });
 }
 
 // ---- multi-GPU ------------------------------------------------------------------------------
 
 int prisim_hip_comm_unique_id(char id[128]) {
+  return guarded(nullptr, [&]() -> int {
   if (!id) return PRISIM_EINVAL;
   std::string lerr;
   if (!load_rccl(lerr)) return fail(nullptr, PRISIM_ELIB, lerr);
@@ -1426,9 +1561,11 @@ int prisim_hip_comm_unique_id(char id[128]) {
   if (r != ncclSuccess) return fail(nullptr, PRISIM_ELIB, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
   memcpy(id, &uid, 128);
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int rank) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!id || nranks <= 0 || rank < 0 || rank >= nranks) return fail(ctx, PRISIM_EINVAL, "bad communicator arguments");
   std::string lerr;
@@ -1444,6 +1581,7 @@ int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int ra
   }
   ctx->nranks = nranks; ctx->rank = rank;
   return PRISIM_OK;
+  });
 }
 
 // Gather snapshot `slot` of every rank into gathered[slot][rank][b][row] on stream `st`.  src_all: this rank's [nt][nbl][row] complex128
@@ -1482,6 +1620,7 @@ static int ensure_gather_buffers(prisim_ctx* ctx, int64_t row, int as_c64) {
 }
 
 int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt, int as_c64) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
   if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
@@ -1492,9 +1631,11 @@ int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt, int as_c64) {
   for (int64_t t = 0; t < nt; ++t)
     if ((rc = gather_one_slot(ctx, (const double*)ctx->cube.p, ctx->nchan, t, as_c64, ctx->stream))) return rc;
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_allgather_lags(prisim_ctx* ctx, int64_t nt) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
   if (!ctx->dt_have_lag || !ctx->dt_lag_all.p) return fail(ctx, PRISIM_ESTATE, "delay_transform_device(want_lag) must be called first");
@@ -1506,33 +1647,46 @@ int prisim_hip_allgather_lags(prisim_ctx* ctx, int64_t nt) {
   for (int64_t t = 0; t < nt; ++t)
     if ((rc = gather_one_slot(ctx, (const double*)ctx->dt_lag_all.p, ctx->dt_nout, t, 0, ctx->stream))) return rc;
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_allgather_slot_async(prisim_ctx* ctx, int64_t slot, int as_c64) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
   if (slot < 0 || slot >= ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "slot out of range");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
-  if (!ctx->comm_stream) {
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_slot_done, hipEventDisableTiming));
-  }
+  if ((rc = ensure_comm_stream(ctx))) return rc;
   if (!ctx->gathered.p || ctx->gathered_c64 != (as_c64 != 0) || ctx->gathered_row != ctx->nchan) {
     // (re)allocation must not race with gathers in flight
     HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream));
     if ((rc = ensure_gather_buffers(ctx, ctx->nchan, as_c64))) return rc;
   }
+  if (ctx->cring_pending >= prisim_ctx::kCommRing) {          // a full ring waits for its oldest entry only
+    const int o = (ctx->cring_head - ctx->cring_pending + 2 * prisim_ctx::kCommRing) % prisim_ctx::kCommRing;
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_g1[o]));
+  }
+  harvest_comm(ctx, false);
+  const int ri = ctx->cring_head;
   // the gather of slot t waits for everything enqueued so far on the compute stream (i.e. compute(slot t)) ...
-  HIPCHK(ctx, hipEventRecord(ctx->ev_slot_done, ctx->stream));
-  HIPCHK(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_slot_done, 0));
-  // ... and runs on the communication stream, overlapping the next snapshot's compute
+  HIPCHK(ctx, hipEventRecord(ctx->ev_gc[ri], ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_gc[ri], 0));
+  // ... and runs on the (highest-priority) communication stream, overlapping the next snapshot's compute
+  HIPCHK(ctx, hipEventRecord(ctx->ev_g0[ri], ctx->comm_stream));
   if ((rc = gather_one_slot(ctx, (const double*)ctx->cube.p, ctx->nchan, slot, as_c64, ctx->comm_stream))) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_g1[ri], ctx->comm_stream));
+  ctx->cring_head = (ctx->cring_head + 1) % prisim_ctx::kCommRing;
+  ctx->cring_pending += 1;
+  ctx->cstats.bytes_per_peer = (int64_t)((size_t)ctx->nbl * ctx->nchan * 2 * (as_c64 ? sizeof(float) : sizeof(double)));
+  ctx->cstats.nranks = ctx->nranks;
   ctx->comm_pending = true;
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
   if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
@@ -1544,9 +1698,11 @@ int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out) {
   if (ctx->comm_stream) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
   HIPCHK(ctx, hipMemcpy(out, ctx->gathered.p, bytes, hipMemcpyDeviceToHost));
   return PRISIM_OK;
+  });
 }
 
 int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
   if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
@@ -1561,6 +1717,156 @@ int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out) {
   HIPCHK(ctx, hipMemcpyAsync(out, ctx->scratch.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return PRISIM_OK;
+  });
+}
+
+int prisim_hip_allgather_grad(prisim_ctx* ctx, int64_t nt, int as_c64) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (!ctx->grad.p) return fail(ctx, PRISIM_ESTATE, "no gradient has been computed");
+  if (nt <= 0 || nt > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "nt out of range");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if (ctx->comm_stream && ctx->comm_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
+  // a snapshot's gradient block is [3][nbl][nchan]: the same exchange with rows of 3 nchan -> gathered [nt][nranks][3][nbl][nchan]
+  if ((rc = ensure_gather_buffers(ctx, 3 * ctx->nchan, as_c64))) return rc;
+  for (int64_t t = 0; t < nt; ++t)
+    if ((rc = gather_one_slot(ctx, (const double*)ctx->grad.p, 3 * ctx->nchan, t, as_c64, ctx->stream))) return rc;
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_comm_selftest(prisim_ctx* ctx, int64_t bytes) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (bytes < 4 || bytes > ((int64_t)1 << 30)) return fail(ctx, PRISIM_EINVAL, "selftest size must be in [4 B, 1 GiB]");
+  if (ctx->nranks > 1 && !ctx->comm) return fail(ctx, PRISIM_ESTATE, "comm_init has not been called");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)bytes / 4;
+  const int nr = ctx->nranks;
+  std::vector<uint32_t> h(n * (size_t)nr);
+  auto pattern = [](int r, size_t i) { return (uint32_t)(r + 1) * 0x9E3779B1u ^ (uint32_t)(i * 0x85EBCA6Bu + 0x1234567u); };
+  for (size_t i = 0; i < n; ++i) h[i] = pattern(ctx->rank, i);
+  DevBuf dsend, drecv;
+  int rc;
+  if ((rc = ensure(ctx, dsend, n * 4)) || (rc = ensure(ctx, drecv, n * 4 * (size_t)nr))) { release(dsend); release(drecv); return rc; }
+  hipError_t e = hipMemcpyAsync(dsend.p, h.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(drecv.p, 0, n * 4 * (size_t)nr, ctx->stream);
+  std::string nerr;
+  if (e == hipSuccess) {
+    if (ctx->comm) {
+      ncclResult_t r = g_rccl.AllGather(dsend.p, drecv.p, n, ncclUint32, ctx->comm, ctx->stream);
+      if (r != ncclSuccess) nerr = std::string("ncclAllGather (self-test): ") + g_rccl.GetErrorString(r);
+    } else {
+      e = hipMemcpyAsync(drecv.p, dsend.p, n * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+  }
+  if (e == hipSuccess && nerr.empty()) e = hipMemcpyAsync(h.data(), drecv.p, n * 4 * (size_t)nr, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && nerr.empty()) e = hipStreamSynchronize(ctx->stream);
+  release(dsend); release(drecv);
+  if (!nerr.empty()) return fail(ctx, PRISIM_ELIB, nerr);
+  HIPCHK(ctx, e);
+  for (int r = 0; r < nr; ++r)
+    for (size_t i = 0; i < n; ++i)
+      if (h[(size_t)r * n + i] != pattern(r, i))
+        return fail(ctx, PRISIM_ELIB, "RCCL self-test: block of rank " + std::to_string(r) + " arrived corrupted at word " + std::to_string(i) +
+                                          " on rank " + std::to_string(ctx->rank));
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_get_comm_stats(prisim_ctx* ctx, prisim_comm_stats* out, int reset) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
+  if (ctx->cring_pending > 0) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    harvest_comm(ctx, true);
+  }
+  ctx->cstats.nranks = ctx->nranks;
+  *out = ctx->cstats;
+  if (reset) {
+    ctx->cstats.n_gathers = 0;
+    ctx->cstats.sum_gather_ms = ctx->cstats.max_gather_ms = ctx->cstats.last_gather_ms = ctx->cstats.last_gather_after_compute_ms = 0.0;
+  }
+  return PRISIM_OK;
+  });
+}
+
+// ---- host-visible results without a serial PCIe tail --------------------------------------------
+
+int prisim_hip_host_alloc(int64_t bytes, void** out) {
+  return guarded(nullptr, [&]() -> int {
+  if (!out) return fail(nullptr, PRISIM_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (bytes <= 0) return fail(nullptr, PRISIM_EINVAL, "bytes must be positive");
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(nullptr, e == hipErrorOutOfMemory ? PRISIM_ENOMEM : PRISIM_ENODEV,
+                                   std::string("hipHostMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+  *out = p;
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_host_free(void* p) {
+  return guarded(nullptr, [&]() -> int {
+  if (p && hipHostFree(p) != hipSuccess) return fail(nullptr, PRISIM_EINVAL, "hipHostFree: not a prisim_hip_host_alloc pointer");
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_get_vis_async(prisim_ctx* ctx, int64_t slot, void* vis, void* grad, int out_is_c64) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (slot < 0 || slot >= ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "slot out of range");
+  if (!vis) return fail(ctx, PRISIM_EINVAL, "vis is NULL");
+  if (grad && !ctx->grad.p) return fail(ctx, PRISIM_ESTATE, "no gradient has been computed");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure_copy_stream(ctx))) return rc;
+  const size_t slot_elems = (size_t)ctx->nbl * ctx->nchan * 2;
+  const double* src = (const double*)ctx->cube.p + (size_t)slot * slot_elems;
+  const double* gsrc = grad ? (const double*)ctx->grad.p + (size_t)slot * 3 * slot_elems : nullptr;
+  // the download waits for everything enqueued so far on the compute stream (the snapshot's sky-sum) and then runs on the copy stream,
+  // under the next snapshot's compute
+  HIPCHK(ctx, hipEventRecord(ctx->ev_copy_ready, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_copy_ready, 0));
+  if (!out_is_c64) {
+    HIPCHK(ctx, hipMemcpyAsync(vis, src, slot_elems * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
+    if (grad) HIPCHK(ctx, hipMemcpyAsync(grad, gsrc, 3 * slot_elems * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
+  } else {
+    // rounded to complex64 on the device (the reference's memsave dtype, :6183): half the PCIe bytes.  One staging buffer is enough --
+    // conversion and copy of slot t+1 follow the copy of slot t in stream order.
+    if (ctx->dl_stage.bytes < 4 * slot_elems * sizeof(float)) {
+      HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));      // a copy in flight may still read the old buffer
+      if ((rc = ensure(ctx, ctx->dl_stage, 4 * slot_elems * sizeof(float)))) return rc;
+    }
+    float* st = (float*)ctx->dl_stage.p;
+    HIPCHK(ctx, launch_f64_to_f32(src, st, (int64_t)slot_elems, ctx->copy_stream));
+    HIPCHK(ctx, hipMemcpyAsync(vis, st, slot_elems * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
+    if (grad) {
+      HIPCHK(ctx, launch_f64_to_f32(gsrc, st + slot_elems, (int64_t)(3 * slot_elems), ctx->copy_stream));
+      HIPCHK(ctx, hipMemcpyAsync(grad, st + slot_elems, 3 * slot_elems * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+  }
+  ctx->copy_pending = true;
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_wait_downloads(prisim_ctx* ctx) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (ctx->copy_stream && ctx->copy_pending) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    ctx->copy_pending = false;
+  }
+  return PRISIM_OK;
+  });
 }
 
 }  // extern "C"

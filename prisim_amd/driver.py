@@ -8,8 +8,9 @@ pointing schedules (:709-733), the custom catalog columns RA DEC F_INT SPINDEX M
 (:1645-1684), baseline sharding across processes (`pp.key: 'bl'`, :1775-1791) and the NPZ output keys
 (interferometry.py:8859-8863).
 
-Replaced: `mpirun` ranks + per-rank part files + rank-0 concatenate become one process per GPU
-(RANK / WORLD_SIZE / LOCAL_RANK from the launcher) and a single RCCL all-gather of the visibility cube;
+Replaced: `mpirun` ranks + per-rank part files + rank-0 concatenate become one process per GPU (`run_prisim.py -n N` starts them
+itself through prisim_amd.launch; any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK works too) and a single RCCL all-gather of the
+visibility cube;
 the rank-0 ROI/beam precompute through FITS files disappears (beams are fused on the device).
 Not offered (out of scope): survey catalogs (SUMSS/NVSS/GLEAM/GSM need prisim/data, absent),
 gains, uvfits/uvh5 writers, `pp.key: 'freq' | 'src'`, plots, resource monitor.  After the snapshots: thermal noise, re-centring on
@@ -323,7 +324,9 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
                      altitude=tel['altitude'], skycoords='radec', A_eff=parms['telescope']['A_eff'], pointing_coords='hadec', device=device,
                      blgroupinfo={'groups': blgroups, 'reversemap': {m: k for k, v in blgroups.items() for m in v}})
     ia = RI.InterferometerArray(labels_mine, bl_mine, chans, **ia_kwargs)
-    ia.reserve(n_acc)
+    # unsharded runs hand the cube to the host (files, the caller): each snapshot's download is queued under the next one's sky-sum;
+    # sharded runs gather on the device and never copy their own shard
+    ia.reserve(n_acc, host_staging=(world == 1))
     if extbeam is not None:
         bm = parms['beam']
         ia.set_external_beam(extbeam[0], extbeam[1], spec_interp=bm.get('spec_interp', 'cubic'), chromatic=bool(bm.get('chromatic', True)),
@@ -377,11 +380,19 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         if noise_done:
             noise_all = ia.allgather_cube(ia.vis_noise_freq, world, download=download)
             noise_all = noise_all[:nbl_total] if noise_all is not None else None
+        grad_all = None
+        if ia.gradient_mode is not None:
+            # the gradient cubes are per baseline too: gathered like the visibilities (interferometry.py:8349-8350 concatenates them)
+            g = ia.allgather_gradient(world, download=download)
+            grad_all = {ia.gradient_mode: g[:, :nbl_total]} if g is not None else None
     else:
         cube, labels_all, bl_all = ia.skyvis_freq[:nbl_total], labels, bl
+        grad_all = {k: v[:, :nbl_total] for k, v in ia.gradient.items()} if ia.gradient_mode is not None else None
     out = {'skyvis_freq': cube, 'bl': bl_all, 'labels': labels_all, 'freq': chans, 'lst': NP.asarray(ia.lst),
            'timestamp': NP.asarray(ia.timestamp), 'bl_length': NP.sqrt(NP.sum(bl_all ** 2, axis=1)), 't_sim': t_sim,
            'antpos': antpos, 'ia': ia, 'blgroups': blgroups, 'world': world, 'ia_kwargs': ia_kwargs}
+    if ia.gradient_mode is not None:
+        out['gradient_mode'], out['gradient'] = ia.gradient_mode, grad_all
     if noise_done and world == 1:
         out['vis_freq'], out['vis_noise_freq'] = ia.vis_freq[:nbl_total], ia.vis_noise_freq[:nbl_total]
     elif noise_done:
@@ -393,11 +404,20 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         if world > 1:
             lag = ia.allgather_lags(world, download=download)
             out['skyvis_lag'] = lag[:nbl_total] if lag is not None else None
-            if noise_done and ia.vis_lag is not None and ia.vis_lag.shape == (bl_mine.shape[0], chans.size, n_acc):
-                # the spectra of the noisy and of the noise cube (host-side on every shard) travel like the noise cube did
-                for key, arr in (('vis_lag', ia.vis_lag), ('vis_noise_lag', ia.vis_noise_lag)):
-                    g = ia.allgather_cube(arr, world, download=download)
-                    out[key] = g[:nbl_total] if g is not None else None
+            if noise_done and ia.vis_lag is not None:
+                if ia.vis_lag.shape == (bl_mine.shape[0], chans.size, n_acc):
+                    # the spectra of the noisy and of the noise cube (host-side on every shard) travel like the noise cube did
+                    for key, arr in (('vis_lag', ia.vis_lag), ('vis_noise_lag', ia.vis_noise_lag)):
+                        g = ia.allgather_cube(arr, world, download=download)
+                        out[key] = g[:nbl_total] if g is not None else None
+                else:
+                    # nlag != nchan (a fractional f_pad): these host-side spectra cannot ride in the visibility slots.  Nothing is
+                    # dropped: whoever assembles the whole array (assemble_full_array, rank 0) transforms the gathered vis_freq /
+                    # vis_noise_freq cubes there.
+                    out['noisy_lags_deferred'] = True
+                    if verbose and rank == 0:
+                        print('vis_lag / vis_noise_lag (nlag = {0} != nchan = {1}) are formed from the gathered cubes on rank 0'.format(
+                            ia.vis_lag.shape[1], chans.size))
         else:
             out['skyvis_lag'] = ia.skyvis_lag
         out['lags'] = ia.lags
@@ -411,17 +431,31 @@ def assemble_full_array(out, parms):
     if out.get('skyvis_freq') is None:
         raise ValueError('this rank did not download the gathered cube (host_copy)')
     shard = out['ia']
-    if shard.gradient_mode is not None:
-        raise NotImplementedError('the baseline gradients of a sharded run are not gathered')
     full = RI.InterferometerArray(out['labels'], out['bl'], out['freq'], **out['ia_kwargs'])
     full.adopt_observation(shard)
     full.skyvis_freq = out['skyvis_freq']
+    if shard.gradient_mode is not None:
+        if out.get('gradient') is None:
+            raise ValueError('this rank did not download the gathered gradient cube (host_copy)')
+        full.gradient_mode, full.gradient = shard.gradient_mode, dict(out['gradient'])
     if out.get('vis_freq') is not None:
         full.vis_freq, full.vis_noise_freq = out['vis_freq'], out['vis_noise_freq']
     if out.get('skyvis_lag') is not None:
         full.skyvis_lag = out['skyvis_lag']
     if out.get('vis_lag') is not None:
         full.vis_lag, full.vis_noise_lag = out['vis_lag'], out['vis_noise_lag']
+    proc = parms.get('processing') or {}
+    if out.get('skyvis_lag') is not None:
+        if out.get('noisy_lags_deferred') and out.get('vis_freq') is not None:
+            # the noisy cubes' spectra could not be exchanged (nlag != nchan): transform the gathered cubes here, on this rank's GPU
+            lag_gathered = full.skyvis_lag
+            full.delay_transform(pad=float(proc.get('f_pad', 1.0)), freq_wts=window(len(out['freq']), proc.get('bpass_shape', 'bhw')), verbose=False)
+            full.skyvis_lag = lag_gathered
+        elif shard.lag_kernel is not None:
+            # lag_kernel = transform of bp * bp_wts (:8119): with one window for every baseline a shard's rows all equal the whole array's
+            kern = NP.asarray(shard.lag_kernel)
+            if kern.shape[0] >= 1 and NP.array_equal(kern, NP.broadcast_to(kern[:1], kern.shape)):
+                full.lag_kernel = NP.array(NP.broadcast_to(kern[:1], (full.baselines.shape[0],) + kern.shape[1:]))
     ph = parms.get('phasing') or {}
     if ph.get('center') is not None:                  # the shards were re-centred there before the exchange: projected baselines to match
         full.project_baselines({'coords': ph.get('coords', 'altaz'), 'location': NP.asarray(ph['center'], dtype=float).reshape(1, -1)})
@@ -470,7 +504,15 @@ def main(argv=None):
     import argparse
     parser = argparse.ArgumentParser(description='Program to simulate interferometer array data (MI355X path)')
     parser.add_argument('-i', '--infile', dest='infile', required=True, type=str, help='File specifying input parameters')
+    parser.add_argument('-n', '--nranks', dest='nranks', type=int, default=1,
+                        help='number of GPUs: starts that many rank processes itself (the `mpirun -n N` of README.rst:93-99; no torch, no MPI)')
     args = parser.parse_args(argv)
+    if 'WORLD_SIZE' not in os.environ and args.nranks > 1:
+        # become the launcher before anything touches the GPU: N children run this same entry with RANK / WORLD_SIZE set
+        import sys
+        from . import launch
+        script = os.path.abspath(sys.argv[0])
+        return launch.spawn_ranks(args.nranks, [sys.executable, script] + list(sys.argv[1:] if argv is None else argv))
     parms = load_parms(args.infile)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

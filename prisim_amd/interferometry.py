@@ -38,10 +38,11 @@ SIDEREAL_RATE = 1.00273790935    # sidereal seconds per solar second
 class _DeviceSlot(object):
     """Placeholder in InterferometerArray._cube for a snapshot that so far lives only in slot `slot` of the device cube (after
     reserve()); the host copy is fetched the first time skyvis_freq is read.  Runs that gather on the device never fetch it."""
-    __slots__ = ('slot', 'dtype')
+    __slots__ = ('slot', 'dtype', 'staged')
 
-    def __init__(self, slot, dtype):
+    def __init__(self, slot, dtype, staged=False):
         self.slot, self.dtype = slot, NP.dtype(dtype)
+        self.staged = staged           # an asynchronous download into the pinned host cube is in flight or done (reserve(host_staging=True))
 
 
 class _LayerStack(object):
@@ -241,6 +242,8 @@ class InterferometerArray(object):
         self._cube = []        # per-snapshot (nbl, nchan) visibilities, stacked lazily into skyvis_freq
         self._grad = []
         self._reserved = 1     # snapshot slots of the device cube (reserve())
+        self._stage, self._host_cube = False, None      # reserve(host_staging=True): snapshots are copied to a pinned host cube as they finish
+        self._device_in_step = False                    # device slots [0, n_acc) hold the current skyvis_freq
 
     def _init_from_hdf5(self, init_file, device):
         """Attributes from a file written by save() / by PRISim (interferometry.py:5186-5657; same group and dataset names,
@@ -348,14 +351,19 @@ class InterferometerArray(object):
         self._reserved = max(int(self.n_acc), 1)
         self._ctx = _abi.Context(device)
         self._ctx.set_array(self.baselines, self.channels, nt_max=self._reserved)
+        self._stage, self._host_cube = False, None
         self.skyvis_freq = skyvis
-        for t in range(skyvis.shape[2]):
-            self._ctx.set_vis(NP.ascontiguousarray(skyvis[:, :, t], dtype=NP.complex128), slot=t)
+        self._upload_cube()
 
-    def reserve(self, n_acc):
+    def reserve(self, n_acc, host_staging=False):
         """Allocate `n_acc` snapshot slots in the device visibility cube so that every observe() also leaves its result
         resident on the GPU (slot = snapshot index) for a later allgather() / device-side delay transform.  Not in the
-        reference (its cube is a host array grown by dstack, interferometry.py:6384-6393)."""
+        reference (its cube is a host array grown by dstack, interferometry.py:6384-6393).
+
+        host_staging=True: the reference's product is skyvis_freq ON THE HOST (:6384-6393).  Every observe() then also enqueues the
+        download of its snapshot into a page-locked host cube on a copy stream, behind its own sky-sum and beside the next one's
+        (prisim_hip_get_vis_async): reading skyvis_freq afterwards only waits for the last copy instead of pulling the whole cube
+        over PCIe in one serial tail.  Falls back to the lazy download when the pinned cube cannot be allocated."""
         n_acc = int(n_acc)
         if n_acc < 1:
             raise ValueError('n_acc must be positive')
@@ -363,7 +371,24 @@ class InterferometerArray(object):
             raise RuntimeError('reserve() must be called before the first observe()')
         self._ctx.set_array(self.baselines, self.channels, nt_max=n_acc)
         self._reserved = n_acc
+        self._stage, self._host_cube = bool(host_staging), None
         self._restore_external_beam()
+
+    def _stage_download(self, slot, dtype):
+        """Enqueue the asynchronous download of device slot `slot` into the pinned host cube; False when staging is off / unavailable."""
+        if not getattr(self, '_stage', False):
+            return False
+        if self._host_cube is None:
+            try:
+                self._host_cube = _abi.host_empty((self._reserved, self.baselines.shape[0], self.channels.size), dtype)
+            except (MemoryError, _abi.PrisimHipError, OSError) as exc:
+                warnings.warn('host staging switched off: the pinned host cube could not be allocated ({0})'.format(exc))
+                self._stage = False
+                return False
+        if self._host_cube.dtype != NP.dtype(dtype):
+            return False                     # a run that mixes memsave and full precision: this snapshot takes the lazy path
+        self._ctx.get_vis_async(slot, self._host_cube[slot])
+        return True
 
     def set_external_beam(self, beam, beam_freqs_hz, spec_interp='cubic', chromatic=True, select_freq=None):
         """Use a tabulated HEALPix (RING, local zenith-angle/azimuth frame) power beam [npix, nfreq] for all following
@@ -414,6 +439,24 @@ class InterferometerArray(object):
         if self.skyvis_lag.shape != (self.baselines.shape[0], self.channels.size, self.n_acc):
             raise NotImplementedError('host-side delay spectra are exchanged through the visibility slots: this needs nlag == nchan (pad = 0, 1, 2, ...)')
         return self.allgather_cube(self.skyvis_lag, nranks, download=download)
+
+    def allgather_gradient(self, nranks, download=True):
+        """All-gather of the baseline-gradient cubes of the shards (gradient_mode='baseline'): the reference concatenates them over the
+        baseline chunks (interferometry.py:8349-8350).  The gradient blocks observe() left in the device gradient cube go GPU -> GPU
+        (prisim_hip_allgather_grad).  Call after allgather().  Returns (3, nranks*nbl, nchan, n_acc), or None with download=False."""
+        if not getattr(self, '_comm_ready', False):
+            raise RuntimeError('allgather() must be called first (it sets up the communicator)')
+        if self.gradient_mode is None or len(self._grad) != self.n_acc:
+            raise RuntimeError('every snapshot must have been observed with gradient_mode set')
+        if self._reserved < self.n_acc:
+            raise RuntimeError('reserve(n_acc) must be called before observing to keep the gradient cube on the device')
+        c64 = all(NP.dtype(g.dtype) == NP.complex64 for g in self._grad)
+        self._ctx.allgather_grad(self.n_acc, complex64=c64)
+        if not download:
+            return None
+        g = self._ctx.get_gathered_grad(self.n_acc, nranks)             # [t][rank][k][b][f]
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        return NP.transpose(g, (2, 1, 3, 4, 0)).reshape(3, nranks * nbl, nchan, self.n_acc)
 
     def allgather_cube(self, cube, nranks, download=True):
         """All-gather of a host-side (nbl, nchan, n_acc) cube of this shard that has no device copy (the thermal noise, host-side delay
@@ -664,9 +707,12 @@ class InterferometerArray(object):
                 if isinstance(snap, _DeviceSlot) and snap.slot == slot:
                     self._cube[i] = self._ctx.get_vis(slot=slot, complex64=(snap.dtype == NP.complex64))
             self._ctx.compute(precision=prec, want_grad=want_grad, slot=slot)
+            self._device_in_step = slot == self.n_acc and (self.n_acc == 0 or getattr(self, '_device_in_step', False))
             if slot == self.n_acc and not want_grad:
-                # the snapshot stays in its own slot of the device cube: no download now (1 GB and 20 ms per HERA-350 snapshot)
+                # the snapshot stays in its own slot of the device cube: no synchronous download (1 GB and 20 ms per HERA-350
+                # snapshot); with host staging its copy to the pinned host cube is queued behind the sky-sum, on the copy stream
                 skyvis, skyvis_gradient = _DeviceSlot(slot, datatype), None
+                skyvis.staged = self._stage_download(slot, datatype)
             else:
                 res = self._ctx.get_vis(slot=slot, want_grad=want_grad, complex64=memsave)
                 skyvis, skyvis_gradient = res if want_grad else (res, None)
@@ -677,6 +723,11 @@ class InterferometerArray(object):
             warnings.warn('No sources found in the catalog within matching radius. Simply populating the observed visibilities and/or gradients with noise.')
             skyvis = NP.zeros((nbl, nchan), dtype=datatype)
             skyvis_gradient = NP.zeros((3, nbl, nchan), dtype=datatype) if want_grad else None
+            if self.n_acc < self._reserved:                                            # the snapshot's device slot says the same
+                self._ctx.set_vis(NP.zeros((nbl, nchan), dtype=NP.complex128), slot=self.n_acc)
+                self._device_in_step = self.n_acc == 0 or getattr(self, '_device_in_step', False)
+            else:
+                self._device_in_step = False
 
         self._cube.append(skyvis)                                                     # :6384-6393
         self._skyvis_cache = None
@@ -696,19 +747,39 @@ class InterferometerArray(object):
         if not getattr(self, '_cube', None):
             return self._skyvis_override
         if getattr(self, '_skyvis_cache', None) is None:
+            staged = [isinstance(sn, _DeviceSlot) and sn.staged for sn in self._cube]
+            if any(staged):
+                self._ctx.wait_downloads()                              # the copies ran under the later snapshots' sky-sums
             for i, snap in enumerate(self._cube):
                 if isinstance(snap, _DeviceSlot):                       # first read: fetch the device-resident snapshots
-                    self._cube[i] = self._ctx.get_vis(slot=snap.slot, complex64=(snap.dtype == NP.complex64))
-            self._skyvis_cache = NP.stack(self._cube, axis=2)
+                    if snap.staged:
+                        self._cube[i] = self._host_cube[snap.slot]
+                    else:
+                        self._cube[i] = self._ctx.get_vis(slot=snap.slot, complex64=(snap.dtype == NP.complex64))
+            hc = getattr(self, '_host_cube', None)
+            if hc is not None and all(staged) and all(self._cube[i].base is not None and NP.shares_memory(self._cube[i], hc[i])
+                                                      for i in range(len(self._cube))):
+                # every snapshot already sits in the pinned host cube [t][b][f]: the reference's (nbl, nchan, n_acc) is a view of it
+                self._skyvis_cache = NP.moveaxis(hc[:len(self._cube)], 0, 2)
+            else:
+                self._skyvis_cache = NP.stack(self._cube, axis=2)
         return self._skyvis_cache
 
     @skyvis_freq.setter
     def skyvis_freq(self, value):
         self._skyvis_override = value
+        self._device_in_step = False      # the device slots no longer hold this cube (callers that re-upload set the flag again)
         if value is not None:
             value = NP.asarray(value)
             self._cube = [value[:, :, i] for i in range(value.shape[2])]
             self._skyvis_cache = value
+
+    def _upload_cube(self):
+        """Put the host visibility cube into the device slots (needs reserve(n_acc) slots) and mark the two as in step."""
+        cube = self.skyvis_freq
+        for t in range(cube.shape[2]):
+            self._ctx.set_vis(NP.ascontiguousarray(cube[:, :, t], dtype=NP.complex128), slot=t)
+        self._device_in_step = True
 
     # bp, bp_wts, Tsys: (nbl, nchan) before the first snapshot, (nbl, nchan, n_acc) afterwards, like the reference's; kept as
     # per-snapshot layers (_LayerStack) and materialised on read.  Assigning an array replaces the layers.
@@ -983,6 +1054,9 @@ class InterferometerArray(object):
             # the whole cube lives on the device (reserve()) and was never read: rotate it where it is, one kernel over all snapshots
             self._ctx.phase_rotate(n_acc, diff)                                         # :7877
             self._skyvis_cache = None
+            for sn in self._cube:                              # host copies staged before the rotation are stale: queue them again
+                if sn.staged:
+                    sn.staged = self._stage_download(sn.slot, sn.dtype)
         else:
             dtype = self.skyvis_freq.dtype
             self.skyvis_freq = rotate(self.skyvis_freq).astype(dtype)                  # :7877
@@ -991,8 +1065,7 @@ class InterferometerArray(object):
             if self.vis_noise_freq is not None:
                 self.vis_noise_freq = rotate(self.vis_noise_freq)
             if self._reserved >= n_acc:                        # keep the device-resident cube in step
-                for t in range(n_acc):
-                    self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
+                self._upload_cube()
         self.phase_center = self._convert_pc(new, self.phase_center_coords)            # :7874-7875
         if do_delay_transform:
             self.delay_transform(verbose=verbose)
@@ -1071,8 +1144,7 @@ class InterferometerArray(object):
         self._ctx.set_array(self.baselines, self.channels, nt_max=self._reserved)      # the resident array follows the flip
         self._restore_external_beam()
         if self._reserved >= self.n_acc and self.skyvis_freq is not None:
-            for t in range(self.n_acc):
-                self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
+            self._upload_cube()
 
     def adopt_observation(self, shard):
         """Make this (so far unobserved) array stand for the WHOLE array of an observation of which `shard` -- another InterferometerArray, one
@@ -1331,8 +1403,7 @@ class InterferometerArray(object):
         self._ctx.set_array(self.baselines, self.channels, nt_max=self._reserved)
         self._restore_external_beam()
         if self._reserved >= self.n_acc and self.skyvis_freq is not None:
-            for t in range(self.n_acc):
-                self._ctx.set_vis(self.skyvis_freq[:, :, t], slot=t)
+            self._upload_cube()
         self.generate_noise()                                                          # :6905-6906
         self.add_noise()
 
@@ -1396,7 +1467,13 @@ class InterferometerArray(object):
 
         # number of snapshots without forcing device-resident ones onto the host (_DeviceSlot placeholders)
         nt_all = len(self._cube) if self._cube else self._skyvis_override.shape[2]
-        resident = self._reserved >= self.n_acc and bool(self._cube)     # device slots hold the snapshots: slot 0 must survive
+        # Are the device slots holding THIS cube?  observe() into reserved slots leaves them in step; assigning skyvis_freq (the setter,
+        # adopt_observation + assignment, assemble_full_array) does not -- then the cube is uploaded first when the slots exist,
+        # otherwise the transform goes snapshot by snapshot through slot 0.
+        if bool(self._cube) and self._reserved >= nt_all and self.n_acc == nt_all and not getattr(self, '_device_in_step', False) \
+                and not any(isinstance(sn, _DeviceSlot) for sn in self._cube):
+            self._upload_cube()
+        resident = self._reserved >= self.n_acc and bool(self._cube) and getattr(self, '_device_in_step', False)   # slot 0 must survive
         self._skyvis_lag, self._lag_resident = None, None
         if resident and self._reserved >= nt_all and self.n_acc == nt_all and same_wts:
             # the cube is resident on the GPU (reserve()): all snapshots are transformed where they are and the spectra stay in HBM

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Entry point with the reference's name and flag: run_prisim.py -i parms.yaml (README.rst:93-99).
-Multi-GPU: python -m torch.distributed.run --nproc-per-node N scripts/run_prisim.py -i parms.yaml"""
+Multi-GPU: scripts/run_prisim.py -n N -i parms.yaml (starts its own N ranks, one per GPU -- no torch, no MPI;
+`python -m prisim_amd.launch -n N scripts/run_prisim.py -i parms.yaml` is the same thing)."""
 import os
 import sys
 

@@ -75,6 +75,15 @@ class PatternContext(object):
             parts.append(NP.load(p))
         self._gathered[slot] = NP.stack(parts)                                   # [rank][b][f]
 
+    def comm_selftest(self, nbytes=1 << 20):
+        if self.mode == 'selftest_fails_on_0' and self.rank == 0:
+            raise RuntimeError('stand-in: the self-test all-gather delivered a corrupted block')
+
+    def comm_stats(self, reset=False):
+        return {'n_gathers': self._n, 'bytes_per_peer': int(self.cube[0].nbytes), 'sum_gather_ms': 0.25 * self._n, 'last_gather_ms': 0.25,
+                'max_gather_ms': 0.3, 'last_gather_after_compute_ms': 0.2, 'stream_priority': -1, 'stream_priority_lowest': 1,
+                'nranks': self.nranks}
+
     def sync(self):
         pass
 
@@ -96,6 +105,7 @@ class PatternContext(object):
 
 
 _abi.Context = PatternContext
+os.environ['PRISIM_BENCH_SELF'] = os.path.abspath(__file__)        # a bare `--gpus N` launch spawns THIS file as its ranks
 import bench  # noqa: E402
 
 if __name__ == '__main__':

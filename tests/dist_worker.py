@@ -1,18 +1,20 @@
-"""Worker for tests/test_distributed_cpu.py (and its GPU twin): one process per rank, launched by torch.distributed.run.
+"""Worker for tests/test_distributed_cpu.py (and its GPU twin): one process per rank, started by prisim_amd.launch (no torch).
 
 Runs the PRODUCT's multi-rank code -- prisim_amd.rendezvous for the out-of-band id exchange / barrier / max-reduce, and
 prisim_amd.driver.run(parms, rank=r, world=N) with its baseline sharding (padded last shard), InterferometerArray.observe into
 reserved slots, allgather(), per-shard delay_transform() and allgather_lags() -- and checks the gathered cube and the gathered
 delay spectra against a world-1 run of the same driver, element for element.  RCCL needs one GPU per rank, so the context is
-replaced at the `_abi.Context` seam by a stand-in from tests/fake_context.py whose exchange is a gloo all_gather:
+replaced at the `_abi.Context` seam by a stand-in from tests/fake_context.py whose exchange goes through the product's own socket
+rendezvous (host arrays):
   dist_worker.py oracle   no GPU (CPU suite)
-  dist_worker.py gpu      real HIP context, both ranks on device 0, gloo exchange
+  dist_worker.py gpu      real HIP context, both ranks on device 0, host exchange
+A second, shorter run with processing.gradient_mode = 'baseline' checks the gathered gradient cube (interferometry.py:8349-8350) and the
+HDF5 file rank 0 writes from it against the unsharded run.
 """
 import os
 import sys
 
 import numpy as NP
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -99,9 +101,8 @@ def main():
     assert rdzv.allreduce_max(float(rank + 1)) == float(world) and rdzv.allreduce_min(float(rank + 1)) == 1.0
     assert rdzv.allgather({'rank': rank}) == [{'rank': r} for r in range(world)]
     rdzv.barrier()
-    # gloo carries the stand-in communicator's data (RCCL's place)
-    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-    _abi.Context = fake_context.OracleContext if mode == 'oracle' else fake_context.GlooCommContext
+    fake_context.RDZV = rdzv                                   # carries the stand-in communicator's data (RCCL's place)
+    _abi.Context = fake_context.OracleContext if mode == 'oracle' else fake_context.HostCommContext
 
     parms = parms_for_test()
     out = driver.run(parms, rank=rank, world=world, device=0, comm_uid=uid, verbose=False)
@@ -128,11 +129,22 @@ def main():
         ok = ok and out_root['skyvis_freq'] is None and out_root['skyvis_lag'] is None and out_root['vis_freq'] is None
     if rank == 0:
         ok = ok and _hdf5_of_sharded_run_equals_unsharded(parms, out_root, ref)
+    # baseline gradients of a sharded run: gathered like the visibilities, equal to the unsharded run's, and in rank 0's HDF5 file
+    gparms = driver.deep_merge(parms, {'processing': {'gradient_mode': 'baseline', 'delay_transform': False, 'add_noise': False},
+                                       'obsparm': {'n_acc': 2}})
+    gout = driver.run(gparms, rank=rank, world=world, device=0, comm_uid=uid, verbose=False, host_copy='root')
+    if rank == 0:
+        gref = driver.run(gparms, rank=0, world=1, device=0, verbose=False)
+        g, gr = gout['gradient']['baseline'], gref['gradient']['baseline']
+        gscale = float(NP.max(NP.abs(gr)))
+        err_g = float(NP.max(NP.abs(g - gr))) if g.shape == gr.shape else float('inf')
+        ok = ok and g.shape == (3, 171, 16, 2) and gscale > 0 and err_g <= (0.0 if mode == 'oracle' else 1e-11 * gscale)
+        ok = ok and _hdf5_of_sharded_run_equals_unsharded(gparms, gout, gref)
+    else:
+        ok = ok and gout['gradient'] is None
     all_ok = all(rdzv.allgather(bool(ok)))
     rdzv.barrier()
     rdzv.close()
-    dist.barrier()
-    dist.destroy_process_group()
     if not all_ok:
         print('RANK %d MISMATCH vis %g lag %g' % (rank, err_v, err_l))
         sys.exit(1)

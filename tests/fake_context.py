@@ -2,9 +2,11 @@
 (prisim_amd.driver.run -> InterferometerArray.observe / allgather / delay_transform / allgather_lags) runs where RCCL cannot:
 
   OracleContext     no GPU at all (CPU suite): compute() is the numpy oracle, the delay transform its numpy restatement, and the
-                    exchange a gloo all_gather of host arrays.
-  GlooCommContext   the real Context (HIP kernels, device cube, device-resident delay spectra) with only the communicator
-                    replaced by gloo -- two ranks can then share the one GPU of a test box, which RCCL refuses.
+                    exchange an all-gather of host arrays over the product's own socket rendezvous (prisim_amd.rendezvous).
+  HostCommContext   the real Context (HIP kernels, device cube, device-resident delay spectra) with only the communicator
+                    replaced by that host exchange -- two ranks can then share the one GPU of a test box, which RCCL refuses.
+
+No torch: the workers are started by prisim_amd.launch and set `fake_context.RDZV` to their Rendezvous before the first exchange.
 
 Only tests/ imports this module."""
 import numpy as NP
@@ -13,13 +15,14 @@ from oracle import skyvis_oracle as O, beams_oracle as BO, delay_oracle as DO
 from prisim_amd import _abi
 
 
-def _gloo_allgather(arr):
-    import torch
-    import torch.distributed as dist
-    t = torch.from_numpy(NP.ascontiguousarray(arr).view(NP.float64).copy())
-    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(parts, t)
-    return [p.numpy().view(NP.complex128).reshape(arr.shape) for p in parts]
+RDZV = None          # the worker's prisim_amd.rendezvous.Rendezvous: carries the stand-in communicator's data (RCCL's place)
+
+
+def _host_allgather(arr):
+    """Every rank's array (same shape and dtype on all ranks), in rank order."""
+    a = NP.ascontiguousarray(arr)
+    parts = RDZV.allgather_bytes(a.tobytes())
+    return [NP.frombuffer(p, dtype=a.dtype).reshape(a.shape).copy() for p in parts]
 
 
 class OracleContext(object):
@@ -93,7 +96,7 @@ class OracleContext(object):
     def timing(self, reset=False):
         return dict(self._timing)
 
-    # ---- communicator: gloo stands in for RCCL ----
+    # ---- communicator: the socket rendezvous stands in for RCCL ----
     @staticmethod
     def comm_unique_id():
         return bytes(range(128))
@@ -103,11 +106,35 @@ class OracleContext(object):
         self.nranks, self.rank = int(nranks), int(rank)
 
     def allgather(self, nt, complex64=False):
-        parts = _gloo_allgather(self.cube[:nt])                               # [rank][t][b][f]
+        parts = _host_allgather(self.cube[:nt])                               # [rank][t][b][f]
         self._gathered = NP.stack(parts, axis=1)                              # [t][rank][b][f]
 
     def get_gathered(self, nt, nranks=None, row=None):
         return self._gathered[:nt]
+
+    def allgather_grad(self, nt, complex64=False):
+        mine = NP.stack([self._grad[t] for t in range(nt)])                   # [t][k][b][f]
+        self._gathered_grad = NP.stack(_host_allgather(mine), axis=1)         # [t][rank][k][b][f]
+
+    def get_gathered_grad(self, nt, nranks=None):
+        return self._gathered_grad[:nt]
+
+    def comm_selftest(self, nbytes=1 << 20):
+        got = _host_allgather(NP.full(4, self.rank, dtype=NP.int32))
+        assert [int(g[0]) for g in got] == list(range(self.nranks))
+
+    def comm_stats(self, reset=False):
+        return {'n_gathers': 0, 'bytes_per_peer': 0, 'sum_gather_ms': 0.0, 'last_gather_ms': 0.0, 'max_gather_ms': 0.0,
+                'last_gather_after_compute_ms': 0.0, 'stream_priority': 0, 'stream_priority_lowest': 0, 'nranks': getattr(self, 'nranks', 1)}
+
+    # ---- downloads ----
+    def get_vis_async(self, slot, out, grad_out=None):
+        out[...] = self.cube[slot].astype(out.dtype)
+        if grad_out is not None:
+            grad_out[...] = self._grad[slot].astype(out.dtype)
+
+    def wait_downloads(self):
+        pass
 
     # ---- delay transform ----
     def delay_transform_device(self, nt, bpwts=None, pad=1.0, want_lag=True, want_power=False, power_scale=1.0):
@@ -124,7 +151,7 @@ class OracleContext(object):
         return out if rows is None else out[:, NP.asarray(rows)]
 
     def allgather_lags(self, nt):
-        self._gathered = NP.stack(_gloo_allgather(self._lag[:nt]), axis=1)
+        self._gathered = NP.stack(_host_allgather(self._lag[:nt]), axis=1)
 
     def delay_transform_host(self, vis, bpwts, pad):
         w = NP.ones((self.nbl, self.nchan)) if bpwts is None else NP.asarray(bpwts)
@@ -138,8 +165,8 @@ def _altaz(dircos):
     return NP.stack((alt, az), axis=1)
 
 
-class GlooCommContext(_abi.Context):
-    """The real GPU context; only the exchange goes over gloo (through the host), so that two ranks can share one GPU."""
+class HostCommContext(_abi.Context):
+    """The real GPU context; only the exchange goes through the host (socket rendezvous), so that two ranks can share one GPU."""
 
     def comm_init(self, uid, nranks, rank):
         assert len(uid) == 128
@@ -147,10 +174,21 @@ class GlooCommContext(_abi.Context):
 
     def allgather(self, nt, complex64=False):
         mine = NP.stack([self.get_vis(slot=t) for t in range(nt)])
-        self._gathered_host = NP.stack(_gloo_allgather(mine), axis=1)
+        self._gathered_host = NP.stack(_host_allgather(mine), axis=1)
 
     def allgather_lags(self, nt):
-        self._gathered_host = NP.stack(_gloo_allgather(self.get_lags(0, nt)), axis=1)
+        self._gathered_host = NP.stack(_host_allgather(self.get_lags(0, nt)), axis=1)
+
+    def allgather_grad(self, nt, complex64=False):
+        mine = NP.stack([self.get_vis(slot=t, want_grad=True)[1] for t in range(nt)])
+        self._gathered_grad_host = NP.stack(_host_allgather(mine), axis=1)
+
+    def get_gathered_grad(self, nt, nranks=None):
+        return self._gathered_grad_host[:nt]
+
+    def comm_selftest(self, nbytes=1 << 20):
+        got = _host_allgather(NP.full(4, self.rank, dtype=NP.int32))
+        assert [int(g[0]) for g in got] == list(range(self.nranks))
 
     def get_gathered(self, nt, nranks=None, row=None):
         return self._gathered_host[:nt]

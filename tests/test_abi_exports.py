@@ -46,6 +46,24 @@ def test_struct_layouts_match_header():
     assert _abi.PrisimBeamSky.beam_kind.offset == 48 and _abi.PrisimBeamSky.diameter_m.offset == 56
     # prisim_timing: 3 double, 2 int64, 6 int32, 1 double -> 72 bytes
     assert C.sizeof(_abi.PrisimTiming) == 72 and _abi.PrisimTiming.last_delay_ms.offset == 64
+    # prisim_comm_stats: 2 int64, 4 double, 4 int32 -> 64 bytes
+    assert C.sizeof(_abi.PrisimCommStats) == 64 and _abi.PrisimCommStats.stream_priority.offset == 48
+
+
+def test_every_export_is_guarded_against_cpp_exceptions():
+    """no C++ exception crosses the ABI.  Every `int prisim_hip_*` entry of capi.cpp runs its body through guarded()
+    (bad_alloc -> PRISIM_ENOMEM, anything else -> PRISIM_EINTERNAL); the void / const char* entries cannot throw by construction."""
+    src = open(os.path.join(ROOT, 'prisim_amd', 'csrc', 'capi.cpp')).read()
+    entries = re.findall(r'^int (prisim_hip_\w+)\(', src, flags=re.M)
+    assert sorted(entries) == sorted(n for n in _abi.EXPORTS if n not in ('prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version'))
+    for name in entries:
+        body = src[src.index('int %s(' % name):]
+        head = body[:body.index('{') + 200]
+        assert 'return guarded(' in head.split('\n', 3)[-1] or 'return guarded(' in head, name
+    # host allocations of caller-sized vectors run inside the guard: a failed one comes back as a code, e.g. from host_alloc
+    lib = _abi.load_library()
+    p = C.c_void_p()
+    assert lib.prisim_hip_host_alloc(-5, C.byref(p)) == _abi.PRISIM_EINVAL and not p.value
 
 
 def test_null_context_is_rejected_not_crashing():

@@ -1,5 +1,6 @@
-"""CPU: world_size-2 rehearsal of the PRODUCT's multi-rank path (prisim_amd.rendezvous + prisim_amd.driver.run with baseline
-shards, padded last shard, all-gather of the cube and of the delay spectra), gloo standing in for RCCL at the Context seam."""
+"""CPU: world_size-2 / -3 rehearsal of the PRODUCT's multi-rank path (prisim_amd.launch + prisim_amd.rendezvous + prisim_amd.driver.run
+with baseline shards, padded last shard, all-gather of the cube, of the delay spectra and of the gradient cube), a host exchange over the
+rendezvous sockets standing in for RCCL at the Context seam.  No torch anywhere."""
 import os
 import socket
 import subprocess
@@ -17,10 +18,11 @@ def _free_port():
 
 
 def _run_workers(mode, nproc=2):
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dist_worker.py'), mode]
-    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, OMP_NUM_THREADS='2')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PRISIM_RDZV_FILE'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'prisim_amd.launch', '-n', str(nproc), os.path.join(ROOT, 'tests', 'dist_worker.py'), mode]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     out = res.stdout + res.stderr
     assert res.returncode == 0, out[-3000:]
     for r in range(nproc):
@@ -48,9 +50,9 @@ import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_gpu_real_kernels_gloo_exchange():
-    """Both ranks on device 0 with the real HIP context (sky-sum kernels, device-resident cube and delay spectra); only the
-    communicator is the gloo stand-in (RCCL refuses two ranks on one GPU)."""
+def test_two_ranks_on_one_gpu_real_kernels_host_exchange():
+    """Both ranks on device 0 with the real HIP context (sky-sum kernels, device-resident cube, gradient cube and delay spectra); only the
+    communicator is the host stand-in (RCCL refuses two ranks on one GPU)."""
     _run_workers('gpu', 2)
 
 
@@ -85,6 +87,40 @@ def test_bench_main_at_world_size_three_prints_one_contract_line(tmp_path):
     # whole-job value: all 61 075 baselines (not the padded 3 x 20 359), both steps, over the slowest rank's time
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 * 2 - 61075.0 * 1024 * 16 * 2) <= 1e-6 * 61075.0 * 1024 * 16 * 2
     assert d['roofline']['terms_per_launch'] == 20359.0 * 1024 * 16            # per launch: this rank's padded shard
+
+
+def test_bench_launched_bare_spawns_its_own_ranks_and_reports_the_gather(tmp_path):
+    """`python bench.py --gpus 3` with no launcher: bench.main() becomes the launcher (prisim_amd.launch.spawn_ranks), its three children
+    run the rank code, rank 0's ONE line comes through, and the N > 1 keys of the contract are there."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS='1', BENCH_REHEARSAL_DIR=str(tmp_path), BENCH_REHEARSAL_MODE='ok')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PRISIM_RDZV_FILE', 'MASTER_PORT'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'bench_worker.py'), '--gpus', '3', '--steps', '2', '--warmup', '1', '--nsrc', '16',
+                          '--no-cpu-baseline'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 3 and d['gather_ok'] is True and d['launcher'] == 'prisim_amd.launch'
+    g = d['gather']
+    for key in ('bytes_per_peer', 'per_snapshot_ms', 'exposed_ms', 'GBps_per_link', 'link_peak_GBps', 'comm_stream_priority'):
+        assert key in g, key
+    assert g['link_peak_GBps'] == 153.0 and g['bytes_per_peer'] > 0 and g['per_snapshot_ms'] > 0
+    assert abs(g['GBps_per_link'] - g['bytes_per_peer'] / (g['per_snapshot_ms'] * 1e-3) / 1e9) < 1e-9 * g['GBps_per_link'] + 1e-12
+    assert len(d['kernel_ms_per_rank']['all']) == 3 and d['kernel_ms_per_rank']['max'] >= d['kernel_ms_per_rank']['min']
+    assert abs(d['value_n1_equiv'] * 3 - d['value']) <= 1e-9 * d['value']
+
+
+def test_bench_launched_bare_exits_nonzero_when_a_rank_fails(tmp_path):
+    env = dict(os.environ, OMP_NUM_THREADS='1', BENCH_REHEARSAL_DIR=str(tmp_path), BENCH_REHEARSAL_MODE='selftest_fails_on_0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PRISIM_RDZV_FILE', 'MASTER_PORT'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'bench_worker.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--nsrc', '16',
+                          '--no-cpu-baseline'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 3, (res.returncode, res.stderr[-2000:])        # the RCCL self-test failed: exit 3, before any timed step
+    assert [ln for ln in res.stdout.splitlines() if ln.strip()] == []       # and no value was printed
+    assert 'self-test' in res.stderr
 
 
 def test_bench_main_fails_loudly_when_the_communicator_cannot_be_made(tmp_path):

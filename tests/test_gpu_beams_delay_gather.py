@@ -179,6 +179,110 @@ def test_rccl_communicator_of_one_rank(ctx):
         c.close()
 
 
+def test_rccl_selftest_gather_stats_and_gradient_gather_on_one_rank(ctx):
+    """What bench.py and the driver do around RCCL at N > 1, on the one GPU a test box has: the pattern self-test through
+    ncclAllGather, the overlapped per-snapshot gather on the high-priority stream with its event timing, and the gradient-cube gather."""
+    rng = NP.random.default_rng(41)
+    ch = 150e6 + NP.arange(32) * 1.0e5
+    bl = rng.uniform(-100, 100, (70, 3))
+    s = O.altaz2dircos(NP.stack((rng.uniform(20, 90, 50), rng.uniform(0, 360, 50)), 1))
+    p = rng.uniform(0, 3, (50, ch.size))
+    zen = NP.array([0.0, 0.0, 1.0])
+    c = _abi.Context(0)
+    try:
+        c.set_array(bl, ch, nt_max=3)
+        c.comm_selftest(1 << 16)                                  # no communicator yet: device-copy form of the same check
+        c.comm_init(_abi.Context.comm_unique_id(), 1, 0)
+        c.comm_selftest(1 << 20)
+        c.set_sky(s, p, zen)
+        c.comm_stats(reset=True)
+        for t in range(3):
+            c.compute(want_grad=True, slot=t)
+            c.allgather_slot_async(t)
+        c.sync()
+        st = c.comm_stats()
+        assert st['n_gathers'] == 3 and st['bytes_per_peer'] == 70 * 32 * 16 and st['nranks'] == 1
+        assert 0.0 < st['last_gather_ms'] <= st['max_gather_ms'] and st['sum_gather_ms'] >= st['max_gather_ms']
+        assert st['last_gather_after_compute_ms'] > 0.0
+        assert st['stream_priority'] <= 0 <= st['stream_priority_lowest']     # created with the highest priority the device offers
+        g = c.get_gathered(3, 1)
+        for t in range(3):
+            v, grad = c.get_vis(slot=t, want_grad=True)
+            assert NP.array_equal(g[t, 0], v)
+        c.allgather_grad(3)
+        gg = c.get_gathered_grad(3, 1)
+        assert gg.shape == (3, 1, 3, 70, 32)
+        ref_v, ref_g = O.skyvis(bl, ch, s, p, zen, gradient=True)
+        for t in range(3):
+            assert NP.array_equal(gg[t, 0], c.get_vis(slot=t, want_grad=True)[1])
+            assert NP.max(NP.abs(gg[t, 0] - ref_g)) <= 1e-11 * NP.sum(NP.abs(p), axis=0).max()
+    finally:
+        c.close()
+
+
+def test_asynchronous_downloads_into_pinned_host_memory(ctx):
+    """prisim_hip_get_vis_async: the copy-stream download of every slot (complex128 and device-rounded complex64, with and without the
+    gradient block) equals the synchronous get_vis."""
+    rng = NP.random.default_rng(43)
+    ch = 150e6 + NP.arange(48) * 1.0e5
+    bl = rng.uniform(-200, 200, (300, 3))
+    s = O.altaz2dircos(NP.stack((rng.uniform(20, 90, 64), rng.uniform(0, 360, 64)), 1))
+    zen = NP.array([0.0, 0.0, 1.0])
+    c = _abi.Context(0)
+    try:
+        c.set_array(bl, ch, nt_max=4)
+        host128 = _abi.host_empty((4, 300, 48), NP.complex128)
+        host64 = _abi.host_empty((4, 300, 48), NP.complex64)
+        hostg = _abi.host_empty((4, 3, 300, 48), NP.complex64)
+        pageable = NP.empty((300, 48), dtype=NP.complex128)
+        for t in range(4):
+            c.set_sky(s, rng.uniform(0, 3, (64, ch.size)), zen)
+            c.compute(want_grad=True, slot=t)
+            c.get_vis_async(t, host128[t])                        # queued behind slot t's sky-sum, runs beside slot t+1's
+            c.get_vis_async(t, host64[t], grad_out=hostg[t])
+        c.get_vis_async(2, pageable)                              # pageable destination: staged by the runtime, same result
+        c.wait_downloads()
+        for t in range(4):
+            v, g = c.get_vis(slot=t, want_grad=True)
+            assert NP.array_equal(host128[t], v)
+            assert NP.array_equal(host64[t], v.astype(NP.complex64)) and NP.array_equal(hostg[t], g.astype(NP.complex64))
+        assert NP.array_equal(pageable, c.get_vis(slot=2))
+        with pytest.raises(ValueError):
+            c.get_vis_async(0, NP.empty((3, 3), dtype=NP.complex128))
+        del host128, host64, hostg                                # pinned memory goes back (finalizers)
+    finally:
+        c.close()
+
+
+def test_host_staging_through_the_class_matches_the_lazy_download():
+    """reserve(host_staging=True): every observe() queues its snapshot's download; skyvis_freq is then a view of the pinned cube, equal to
+    what the lazy path fetches -- also after a re-centring on the device, which re-queues the copies."""
+    cfg = W.config2()
+    bl, ch, sky = cfg['baselines'], cfg['channels'][:64], cfg['sky']
+    n = sky['dircos'].shape[0]
+    skymod = SM.SkyModel(location=sky['altaz'], flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
+                         src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1))
+    labels = ['b%d' % i for i in range(bl.shape[0])]
+    cubes = []
+    for staging in (True, False):
+        for memsave in (False, True):
+            ia = RI.InterferometerArray(labels, bl, ch, telescope={'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'},
+                                        latitude=-30.7224, skycoords='altaz', pointing_coords='hadec')
+            ia.reserve(3, host_staging=staging)
+            for j in range(3):
+                ia.observe((2457000.5 + j * 1e-3, 5.0 * j), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, -30.7224], skymod, 10.0, memsave=memsave)
+            assert all(isinstance(sn, RI._DeviceSlot) and sn.staged == staging for sn in ia._cube)
+            ia.phase_centering(phase_center=NP.array([[80.0, 120.0]]), phase_center_coords='altaz', verbose=False)
+            cube = ia.skyvis_freq
+            assert cube.dtype == (NP.complex64 if memsave else NP.complex128)
+            if staging:
+                assert NP.shares_memory(cube, ia._host_cube)
+            cubes.append(NP.array(cube))
+            ia._ctx.close()
+    assert NP.array_equal(cubes[0], cubes[2]) and NP.array_equal(cubes[1], cubes[3])
+    assert NP.max(NP.abs(cubes[0])) > 0
+
+
 # ---------------------------------------------------------------- InterferometerArray drop-in
 class FakeTime(object):
     """astropy.time.Time-like: observe() only needs .jd and .sidereal_time('apparent').deg (:6113, :6395)."""

@@ -57,11 +57,14 @@ def test_config4_drift_external_beam():
         dc, altaz, keep = W.drift_snapshot_directions(sky, lat, j * cfg['t_acc'] * SIDEREAL_DEG_PER_SEC)
         assert NP.array_equal(ia.obs_catalog_indices[j], NP.flatnonzero(keep))
         flux = sky['flux_ref'][keep, None] * (ch[None, :] / sky['ref_freq']) ** sky['spindex'][keep, None]
-        pb = H.external_beam(cfg['beam_table'], cfg['beam_freqs'], NP.pi / 2 - NP.radians(altaz[:, 0]), NP.radians(altaz[:, 1]), ch) * flux
+        # the reference stores a supplied beam as float32 (interferometry.py:4466) before pb * fluxes (:6254): so does the checker
+        beam = H.external_beam(cfg['beam_table'], cfg['beam_freqs'], NP.pi / 2 - NP.radians(altaz[:, 0]), NP.radians(altaz[:, 1]), ch)
+        pb = beam.astype(NP.float32).astype(NP.float64) * flux
         ref = CO.skyvis(bl[sel], ch, dc, pb, zen, fwhm_deg=sky['fwhm_deg'][keep])
         scale = NP.sum(NP.abs(pb), axis=0)[None, :]
-        # 5e-6: the fp32 tolerance of the path; the float32-rounded beam (interferometry.py:4466) adds <= 6e-8 per source
-        assert NP.max(NP.abs(cube[sel, :, j] - ref) / scale) <= 5.2e-6, j
+        err = float(NP.max(NP.abs(cube[sel, :, j] - ref) / scale))
+        print('config 4 snapshot %d: max err / sum|pbflux| = %.3e' % (j, err))
+        assert err <= 5e-6, j                      # the stated fp32 tolerance of the path
         assert NP.max(NP.abs(cube[nbl:, :, j] - NP.conj(cube[sel, :, j])) / scale) <= 1e-5          # V(-b) = conj V(b)
     assert NP.max(NP.abs(cube[:, :, 0] - cube[:, :, 2])) > 0                                      # the sky did drift
 

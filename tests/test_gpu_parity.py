@@ -333,6 +333,23 @@ def test_kat_hermitian_linearity_additivity(ctx, prec):
     assert NP.max(NP.abs(full[3] - p.sum(0)) / p.sum(0)) <= TOL[prec]
 
 
+@pytest.mark.parametrize('prec', [_abi.PRISIM_FP64, _abi.PRISIM_FP32])
+def test_kat3_two_equal_sources_envelope(ctx, prec):
+    """KAT-3: two equal sources of flux p give |V| = 2 p |cos(pi f b.(s1 - s2)/c)| -- the beat envelope, a closed form
+    no oracle is involved in."""
+    zen = NP.array([0.0, 0.0, 1.0])
+    s = O.altaz2dircos([[60.0, 10.0], [75.0, 200.0]])
+    p = NP.full((2, CH.size), 2.0)
+    ctx.set_array(BL, CH)
+    ctx.set_tuning(0, 0, 0)
+    v = ctx.skyvis(s, p, zen, precision=prec)
+    dphi = NP.pi * CH[None, :] * (BL @ (s[0] - s[1]))[:, None] / C
+    assert NP.max(NP.abs(NP.abs(v) - NP.abs(4.0 * NP.cos(dphi))) / 4.0) <= TOL[prec]
+    # and the phase is that of the mean direction: V = 2 p cos(dphi) exp(-2 pi i f b.((s1 + s2)/2 - zen)/c)
+    mean = 4.0 * NP.cos(dphi) * NP.exp(-2j * NP.pi * CH[None, :] * (BL @ (0.5 * (s[0] + s[1]) - zen))[:, None] / C)
+    assert relerr(v, mean, p) <= TOL[prec]
+
+
 def test_kat_taper_limits(ctx):
     zen = NP.array([0.0, 0.0, 1.0])
     s = O.altaz2dircos([[50.0, 90.0]])

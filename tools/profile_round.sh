@@ -25,6 +25,12 @@ for group in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_V
   rocprofv3 --pmc $group --output-format csv -d "$OUT/pmc$i" -- $BENCH > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err" || echo "pmc group $i failed: $group"
   echo "pmc $i done"
 done
+# PROFILE_EXTRA_PMC: one more counter group, e.g. "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" for the MFMA gradient kernel
+if [ -n "$PROFILE_EXTRA_PMC" ]; then
+  i=$((i+1))
+  rocprofv3 --pmc $PROFILE_EXTRA_PMC --output-format csv -d "$OUT/pmc$i" -- $BENCH > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err" || echo "pmc group $i failed: $PROFILE_EXTRA_PMC"
+  echo "pmc $i done"
+fi
 cd "$REPO"
 python3 -c "import bench; print(bench.csrc_hash())" > "$OUT/csrc_hash.txt"
 python3 tools/summarize_pmc.py "$OUT"
