@@ -391,8 +391,8 @@ def e2e_observe(cfg, n_snap, device, memsave, to_host=False):
     for j in range(1, n_snap + 1):
         observe(ia, j)
     if to_host:
-        cube = ia.skyvis_freq           # (nbl, nchan, n_acc) on the host: waits for the last snapshot's copy only
-        assert cube.shape == (bl.shape[0], ch.size, n_snap + 1)
+        cube = ia.skyvis_freq_snapshots()      # (n_acc, nbl, nchan) in page-locked host memory: waits for the last snapshot's copy only
+        assert cube.shape == (n_snap + 1, bl.shape[0], ch.size)
     ia._ctx.sync()
     dt = time.perf_counter() - t0
     terms = float(bl.shape[0]) * ch.size * n * n_snap
@@ -401,7 +401,8 @@ def e2e_observe(cfg, n_snap, device, memsave, to_host=False):
         res['staged'] = bool(ia._stage and ia._host_cube is not None)
         res['host_bytes_per_snapshot'] = int(bl.shape[0]) * int(ch.size) * (8 if memsave else 16)
         res['path'] = ('InterferometerArray.observe() with reserve(host_staging=True): as e2e, plus every snapshot copied into a page-locked host '
-                       'cube on a copy stream under the next snapshot\'s sky-sum; the clock stops when skyvis_freq is readable on the host')
+                       'cube on a copy stream under the next snapshot\'s sky-sum; the clock stops when the snapshot-major cube (skyvis_freq_snapshots) is '
+                       'readable on the host')
     else:
         res['path'] = 'InterferometerArray.observe(): host geometry + sky staging + fused beam + sky-sum, cube left resident on the device'
     ia._ctx.close()
@@ -574,7 +575,8 @@ def main():
             'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': cfg['name'], 'nbl': nbl_total, 'nchan': nchan, 'nsrc': nsrc, 'nt': K,
                        'beam': 'airy D=14 m fused on device', 'sharding': 'baselines/%d + 1 RCCL all-gather' % world,
-                       'kernel': 'recurrence ct=%d nsplit=%d' % (tm['last_chan_tile'], tm['last_nsplit'])},
+                       'kernel': 'recurrence ct=%d nsplit=%d' % (tm['last_chan_tile'], tm['last_nsplit']),
+                       'taper_split_runs': tm.get('last_taper_split', 0), 'taper_uncorrected_groups': tm.get('last_split_uncorrected_groups', 0)},
             'roofline': {'bound': 'valu', 'achieved': ach_tflops, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
                          'frac': ach_tflops / PEAK_TFLOPS[dtype], 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                          'traffic_source': traffic_src,

@@ -308,6 +308,8 @@ typedef struct prisim_timing {
   int32_t last_taper_group;  /* 1: the packed fp32 taper kernel ran its grouped recurrence (df/f_min <= 3.4e-3), 0: exact per-step form */
   int32_t last_delay_fused;  /* 1: the last delay_transform_device ran the fused LDS FFT kernel, 0: the rocFFT pipeline */
   double last_delay_ms;      /* hipEvent duration of the last prisim_hip_delay_transform_device (all batches) */
+  int32_t last_taper_split;  /* > 0: the packed fp32 taper ran its split form over this many source runs of one source size each */
+  int32_t last_split_uncorrected_groups;   /* (source run, baseline group) pairs whose parabola bound allowed the uncorrected body */
 } prisim_timing;
 
 int prisim_hip_sync(prisim_ctx* ctx);

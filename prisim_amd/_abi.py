@@ -115,7 +115,8 @@ class PrisimTiming(C.Structure):
     _fields_ = [('last_kernel_ms', C.c_double), ('last_compute_ms', C.c_double), ('sum_kernel_ms', C.c_double),
                 ('n_kernel', C.c_int64), ('last_terms', C.c_int64), ('last_kernel_id', C.c_int32),
                 ('last_chan_tile', C.c_int32), ('last_nsplit', C.c_int32), ('last_lift_groups', C.c_int32),
-                ('last_taper_group', C.c_int32), ('last_delay_fused', C.c_int32), ('last_delay_ms', C.c_double)]
+                ('last_taper_group', C.c_int32), ('last_delay_fused', C.c_int32), ('last_delay_ms', C.c_double),
+                ('last_taper_split', C.c_int32), ('last_split_uncorrected_groups', C.c_int32)]
 
 
 class PrisimCommStats(C.Structure):

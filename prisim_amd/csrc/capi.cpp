@@ -117,6 +117,13 @@ struct prisim_ctx {
   int64_t nbl = 0, nchan = 0, nt_max = 0;
   DevBuf blx, bly, blz, freqs, fsq, fsq_pairs, cube, grad, lift_flags;
   std::vector<double> grp_maxlen;     // max |b| per group of kBlockThreads baselines (lifting-rotation guarantee)
+  std::vector<double> grp_maxh, grp_maxz;   // max horizontal length / max |b_z| per group (bound of the split taper's parabola)
+  // runs of consecutive sources with one source size kappa (HEALPix skies: one run; point sources + diffuse: two): the packed fp32
+  // taper kernel walks such skies run by run in its split form.  Empty: sizes vary from source to source (or no taper).
+  struct KappaRun { int64_t lo, hi; double kappa; };
+  std::vector<KappaRun> kappa_runs;
+  DevBuf split_flags, moments;
+  std::vector<int32_t> split_host;
   double dmax = 2.0;                  // max_s |s - s_pc| of the current sky
   std::vector<double> h_freqs;
   bool uniform = false;
@@ -535,7 +542,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->dirs_prep, &ctx->dirs_c32, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
-                    &ctx->dl_stage, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
+                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
   for (int i = 0; i < prisim_ctx::kTimingRing; ++i)
     for (hipEvent_t ev : {ctx->ev_c0[i], ctx->ev_c1[i], ctx->ev_k0[i], ctx->ev_k1[i]})
@@ -585,11 +592,16 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->h_freqs.assign(freqs_hz, freqs_hz + nchan);
   ctx->grp_maxlen.assign((size_t)((nbl + kBlockThreads - 1) / kBlockThreads), 0.0);
+  ctx->grp_maxh.assign(ctx->grp_maxlen.size(), 0.0);
+  ctx->grp_maxz.assign(ctx->grp_maxlen.size(), 0.0);
   ctx->lift_key_k = -1.0;                                  // the cached lifting flags belong to the previous array
   for (int64_t b = 0; b < nbl; ++b) {
     const double len = std::sqrt(x[b] * x[b] + y[b] * y[b] + z[b] * z[b]);
-    double& m = ctx->grp_maxlen[(size_t)(b / kBlockThreads)];
-    if (len > m) m = len;
+    const size_t g = (size_t)(b / kBlockThreads);
+    if (len > ctx->grp_maxlen[g]) ctx->grp_maxlen[g] = len;
+    const double hl = std::sqrt(x[b] * x[b] + y[b] * y[b]);
+    if (hl > ctx->grp_maxh[g]) ctx->grp_maxh[g] = hl;
+    if (std::fabs(z[b]) > ctx->grp_maxz[g]) ctx->grp_maxz[g] = std::fabs(z[b]);
   }
   ctx->nbl = nbl; ctx->nchan = nchan; ctx->nt_max = nt_max;
   // uniform channel grid?  f_k = f0 + k*df to within 1e-7 Hz (phase error <= 1e-13 cycles at 1 us delay)
@@ -647,6 +659,18 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
       kappa = M_LN2 * fd * fd;
     }
     d4[4 * s + 3] = kappa;
+  }
+  ctx->kappa_runs.clear();
+  if (fwhm_deg && nsrc > 0) {
+    constexpr size_t kMaxRuns = 8;
+    int64_t lo = 0;
+    for (int64_t s = 1; s <= nsrc; ++s) {
+      if (s == nsrc || d4[4 * s + 3] != d4[4 * lo + 3]) {
+        if (ctx->kappa_runs.size() == kMaxRuns) { ctx->kappa_runs.clear(); break; }     // sizes vary source by source: no runs
+        ctx->kappa_runs.push_back({lo, s, d4[4 * lo + 3]});
+        lo = s;
+      }
+    }
   }
   if ((rc = ensure(ctx, ctx->dirs, d4_bytes))) return rc;
   HIPCHK(ctx, stage_send(ctx, ctx->dirs.p, d4, d4_bytes));
@@ -966,6 +990,7 @@ static void fill_params(prisim_ctx* ctx, const Plan& pl, SkyvisParams& p) {
     if (v > 0 && v < (1L << 30)) p.flush_src = (int32_t)v;
   }
   p.scale_comp = -1;
+  p.src_lo = 0; p.src_hi = ctx->nsrc; p.accumulate = 0; p.kappa0 = 0.0; p.split_flags = nullptr;
   {
     // grouped taper recurrence (skyvis_kernels.hip): second-order residual (11.09 (df/f)^2)^2 * 0.565 <= 1e-8 of sum|pbflux|
     const double fmin = std::min(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
@@ -973,6 +998,73 @@ static void fill_params(prisim_ctx* ctx, const Plan& pl, SkyvisParams& p) {
     if (const char* env = getenv("PRISIM_HIP_TAPER_GROUP")) p.taper_group = (atoi(env) != 0 && ctx->taper) ? 1 : 0;   // A/B hook
     ctx->timing.last_taper_group = (pl.pk && p.taper_group) ? 1 : 0;
   }
+}
+
+// Decide whether this packed fp32 taper pass runs in the split form and prepare its per-run, per-group flags.  Needs: the packed
+// 64-channel kernel without a source split, the grouped recurrence's channel-grid condition, sources in <= 8 runs of one size each,
+// in-loop exponents kappa (|b| f / c)^2 <= 30 with a per-step exponent <= 1/8 (fp32 range and the series of exp2m1_small), and --
+// per baseline group -- a bound on the parabola the uncorrected grouped form leaves: relative to a term it is at most
+// 16 kappa (b.s)^2 df^2 / c^2 with (b.s)^2 <= (H rho_s + Z |n_s|)^2 (H, Z: the group's largest horizontal length and |b_z|), so
+// relative to sum|pbflux| it is at most 16 kappa df^2/c^2 (H^2 M2 + 2 H Z M11 + Z^2 M02) with the beam-weighted moments
+// M = sum_s |p_s| (.) / sum_s |p_s| of the run's sources, maximised over the channels (k_taper_moments: one pass over pbflux and one
+// small device-to-host copy per snapshot).  Groups above 2e-7 keep the correction (flag bit 1).
+static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams& p, std::vector<double>& run_bound) {
+  ctx->timing.last_taper_split = 0;
+  ctx->timing.last_split_uncorrected_groups = 0;
+  if (!(pl.pk && ctx->taper && pl.ct == 64 && pl.nsplit == 1 && p.taper_group && !ctx->kappa_runs.empty())) return false;
+  if (const char* env = getenv("PRISIM_HIP_TAPER_SPLIT")) { if (atoi(env) == 0) return false; }      // A/B hook
+  const double fmax = std::max(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
+  const double fmin = std::min(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
+  double lmax = 0.0;
+  for (double v : ctx->grp_maxlen) lmax = std::max(lmax, v);
+  double kmax = 0.0;
+  bool any_taper = false;
+  for (const auto& r : ctx->kappa_runs) { kmax = std::max(kmax, r.kappa); any_taper = any_taper || r.kappa > 0.0; }
+  if (!any_taper) return false;
+  const double umax = kmax * (lmax * fmax / kC) * (lmax * fmax / kC);
+  if (!(umax <= 30.0) || !(2.0 * umax * std::fabs(ctx->df) <= 0.125 * fmin)) return false;
+  const int64_t nchan = ctx->nchan;
+  const size_t nruns = ctx->kappa_runs.size();
+  if (ensure(ctx, ctx->moments, (size_t)4 * nchan * sizeof(double) * nruns) != PRISIM_OK) return false;
+  if (ensure(ctx, ctx->split_flags, nruns * (size_t)pl.nbgroups * sizeof(int32_t)) != PRISIM_OK) return false;
+  std::vector<double> mom((size_t)4 * nchan * nruns, 0.0);
+  for (size_t r = 0; r < nruns; ++r) {
+    const auto& run = ctx->kappa_runs[r];
+    if (run.kappa <= 0.0) continue;
+    if (launch_taper_moments((const double*)ctx->pb.p, (const double*)ctx->dirs.p, run.lo, run.hi, nchan,
+                             (double*)ctx->moments.p + r * (size_t)4 * nchan, ctx->stream) != hipSuccess) return false;
+  }
+  // (also waits for an upload that may still read split_host)
+  if (hipMemcpyAsync(mom.data(), ctx->moments.p, mom.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+  ctx->split_host.assign(nruns * (size_t)pl.nbgroups, 0);
+  run_bound.assign(nruns, 0.0);
+  int uncorrected = 0;
+  for (size_t r = 0; r < nruns; ++r) {
+    const auto& run = ctx->kappa_runs[r];
+    if (run.kappa <= 0.0) continue;
+    const double* m = mom.data() + r * (size_t)4 * nchan;
+    double m2 = 0.0, m11 = 0.0, m02 = 0.0;
+    for (int64_t k = 0; k < nchan; ++k) {
+      const double s0 = m[k];
+      if (!(s0 > 0.0)) continue;
+      m2 = std::max(m2, m[nchan + k] / s0); m11 = std::max(m11, m[2 * nchan + k] / s0); m02 = std::max(m02, m[3 * nchan + k] / s0);
+    }
+    const double c16 = 16.0 * run.kappa * (ctx->df / kC) * (ctx->df / kC);
+    for (int g = 0; g < pl.nbgroups; ++g) {
+      const double H = ctx->grp_maxh[(size_t)g], Z = ctx->grp_maxz[(size_t)g];
+      const double bound = c16 * (H * H * m2 + 2.0 * H * Z * m11 + Z * Z * m02);
+      run_bound[r] = std::max(run_bound[r], bound);
+      int32_t fl = ctx->lift_host[(size_t)g] ? 1 : 0;          // bit 0: small step angle (same guarantee as the lifting flag)
+      if (!(bound <= 2.0e-7)) fl |= 2; else ++uncorrected;
+      ctx->split_host[r * (size_t)pl.nbgroups + (size_t)g] = fl;
+    }
+  }
+  if (hipMemcpyAsync(ctx->split_flags.p, ctx->split_host.data(), ctx->split_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) !=
+      hipSuccess)
+    return false;
+  ctx->timing.last_split_uncorrected_groups = uncorrected;
+  return true;
 }
 
 // one sky-sum pass into `dst` ([nbl][nchan] complex128); scale_comp >= 0 multiplies pbflux rows by dircos[:,comp]
@@ -994,11 +1086,35 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   // fp32 kernels whose splits each flush exactly once store their partial sums as complex64: half the partial traffic
   const bool part_f32 = pl.nsplit > 1 && pl.f32 && pl.kernel == PRISIM_KERNEL_RECURRENCE && pl.src_per_split <= (int64_t)p.flush_src;
   p.out_f32 = part_f32 ? 1 : 0;
+  // Packed fp32 taper on a sky whose sources come in a few runs of one size each (every HEALPix sky; point sources + diffuse): the
+  // split form, run by run (skyvis_kernels.hip: TGROUP 2 / 3) -- size-0 runs take the plain (no-taper) bodies.
+  std::vector<double> run_bound;
+  const bool split = scale_comp < 0 && taper_split_plan(ctx, pl, p, run_bound);
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
-  if (pl.pk)
+  if (split) {
+    int launches = 0;
+    for (size_t r = 0; r < ctx->kappa_runs.size(); ++r) {
+      const prisim_ctx::KappaRun& run = ctx->kappa_runs[r];
+      SkyvisParams q = p;
+      q.src_lo = run.lo; q.src_hi = run.hi;
+      q.src_per_split = round_up(run.hi - run.lo, pl.chunk);
+      q.accumulate = launches > 0 ? 1 : 0;
+      if (run.kappa > 0.0) {
+        q.kappa0 = run.kappa;
+        q.split_flags = (const int32_t*)ctx->split_flags.p + r * (size_t)pl.nbgroups;
+        HIPCHK(ctx, launch_skyvis_rec_f32pk_split(q, pl.ct, ctx->stream));
+      } else {
+        q.taper = 0;                                   // point sources: w = 1 (:6270 sigma = inf), the lifting / plain bodies
+        HIPCHK(ctx, launch_skyvis_rec_f32pk(q, pl.ct, ctx->stream));
+      }
+      ++launches;
+    }
+    ctx->timing.last_taper_split = launches;
+  } else if (pl.pk) {
     HIPCHK(ctx, launch_skyvis_rec_f32pk(p, pl.ct, ctx->stream));
-  else
+  } else {
     HIPCHK(ctx, launch_skyvis_rec(p, pl.f32, pl.ct, ctx->stream));
+  }
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
   if (pl.nsplit > 1)
     HIPCHK(ctx, launch_reduce_partials(ctx->partial.p, part_f32, dst, ctx->nbl * ctx->nchan * 2, pl.nsplit, ctx->stream));
@@ -1075,6 +1191,8 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   }
   ctx->timing.last_lift_groups = 0;
   ctx->timing.last_taper_group = 0;
+  ctx->timing.last_taper_split = 0;
+  ctx->timing.last_split_uncorrected_groups = 0;
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE) {
     const size_t pbytes = (size_t)pl.ntiles * pl.nsrc_pad * pl.ct * (pl.f32 ? 4 : 8);
     if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;

@@ -44,10 +44,21 @@ struct SkyvisParams {
   int32_t pad2_;
   double* grad_out;          // fused gradient kernels: [3][nbl][nchan] complex128 of this slot
   const float* dirs_c32;     // fused fp32 gradient kernel: [nsrc_pad][8] (l, l, m, m, n, n, 0, 0)
+  // packed fp32 kernels: the source range of this launch (the whole sky: 0, nsrc) and whether an earlier launch already wrote the slot
+  int64_t src_lo, src_hi;
+  int32_t accumulate;        // 1: the first flush adds to what the output slot holds (a later source range of the same snapshot)
+  int32_t pad3_;
+  // split taper form (k_skyvis_rec_f32pk_split): one source size for the whole range
+  double kappa0;             // ln2 (2 sin(fwhm/2))^2 of every source in [src_lo, src_hi)
+  const int32_t* split_flags;// [nbgroups] bit 0: small step angle, bit 1: keep the parabola correction
 };
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);
 hipError_t launch_skyvis_rec_f32pk(const SkyvisParams& p, int ct, hipStream_t stream);
+// split taper form for a source range of one source size (ct = 64; p.src_lo/src_hi, p.kappa0, p.split_flags, p.accumulate)
+hipError_t launch_skyvis_rec_f32pk_split(const SkyvisParams& p, int ct, hipStream_t stream);
+// beam-weighted sky moments of sources [s_lo, s_hi) per channel into out[4][nchan] (device), see k_taper_moments
+hipError_t launch_taper_moments(const double* pb, const double* dirs, int64_t s_lo, int64_t s_hi, int64_t nchan, double* out, hipStream_t stream);
 // V + baseline gradient in one pass (fp64, MFMA 4x4x4): p.nbgroups = groups of 64 baselines, p.nsplit = 1, ct = 16 or 32
 hipError_t launch_skyvis_grad_f64(const SkyvisParams& p, int ct, hipStream_t stream);
 // the same in packed fp32 (VALU; p.nbgroups = groups of 256 baselines, 16-channel tiles, p.nsplit = 1, p.dirs_c32)

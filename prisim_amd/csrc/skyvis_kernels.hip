@@ -853,11 +853,23 @@ __device__ __forceinline__ float exp2m1_small(float D) {
 // term t = p * zeta is formed once (2 packed multiplies per pair) and added into four accumulator sets, the gradient ones through
 // packed FMAs whose coefficient (l, l), (m, m), (n, n) is an SGPR-pair operand -- 13 packed instructions per pair of terms against
 // 4 passes x 5.  CT = 16 (128 accumulator VGPRs); MFMA would not help: it shares the FMA datapath.
-template <int CT, bool TAPER, bool LIFT, bool TGROUP = false, int REANCHOR = 0, bool GRAD = false>
+// TGROUP: 0 = exact per-step amplitude recurrence; 1 = grouped (8 steps at the group's geometric-mean ratio + parabola correction);
+//   2, 3 = SPLIT forms of the grouped recurrence for a source range with ONE source size (kappa0, the case of every HEALPix sky:
+//   FWHM = nside2resol for all pixels, run_prisim.py:1230-1246).  The taper exponent kappa (|b|^2 - (b.s)^2) f^2/c^2 splits into a
+//   source-independent part, exp(-kappa0 |b|^2 f^2/c^2), applied ONCE per flush to the fp32 partial sums (exactly, per baseline and
+//   channel), and exp(+kappa0 (b.s)^2 f^2/c^2), carried by the recurrence.  For a sky seen through a beam the second exponent is
+//   small wherever the flux is ((b.s)^2 <= |b|^2 sin^2 theta), so the parabola the grouped form leaves inside a group --
+//   16 kappa (b.s)^2 df^2/c^2 at most, relative to the term -- can be BOUNDED from beam-weighted moments of the sky (the host does,
+//   per baseline group, capi.cpp:taper_split_plan) and, where that bound is below 2e-7 of sum|pbflux|, not corrected at all:
+//   3 = no parabola correction (6.375 packed instructions per pair of terms instead of 7.25), 2 = corrected (groups that fail the bound).
+template <int CT, bool TAPER, bool LIFT, int TGROUP = 0, int REANCHOR = 0, bool GRAD = false>
 __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, unsigned char* flush_lds) {
   constexpr int NR = GRAD ? 4 : 1;                   // accumulator sets: V (+ G_l, G_m, G_n)
+  constexpr bool SPLIT = TGROUP >= 2;
+  constexpr bool PARABOLA = TGROUP == 1 || TGROUP == 2;
   static_assert(!(TAPER && LIFT), "the taper-folded recurrence is a scaled rotation: no lifting form");
   static_assert(TAPER || !TGROUP, "TGROUP is a taper variant");
+  static_assert(!(SPLIT && GRAD), "the split taper form is built for the plain sky-sum");
   static_assert(TAPER || REANCHOR == 0, "REANCHOR is a taper variant");
   constexpr int HC = CT / 2;
   // pieces per row: halves (2 x 32 SGPRs at CT = 64) without the taper; quarters with it, whose extra wave-uniform state would
@@ -870,9 +882,10 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   const int tile = slab % p.ntiles;
   const int split = slab / p.ntiles;
 
-  const int64_t s_begin = (int64_t)split * p.src_per_split;
+  // sources [src_lo, src_hi) of the sky (the whole sky unless the host walks it in ranges of one source size), cut into nsplit pieces
+  const int64_t s_begin = p.src_lo + (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
-  if (s_end > p.nsrc) s_end = p.nsrc;
+  if (s_end > p.src_hi) s_end = p.src_hi;
 
   const int tid = threadIdx.x;
   const int64_t b_raw = (int64_t)bg * kBlockThreads + tid;
@@ -903,10 +916,19 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   const cfloat_p gp = (cfloat_p)(uintptr_t)(reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT);
   const cdouble_p gd = (cdouble_p)(uintptr_t)p.dirs_prep;
   double2* const out = reinterpret_cast<double2*>(p.out) + (size_t)split * p.nbl * p.nchan;
-  bool first_flush = true;
+  bool first_flush = p.accumulate == 0;              // accumulate: an earlier launch (another source range) already wrote this slot
   float2* const wbuf = reinterpret_cast<float2*>(flush_lds) + (tid >> 6) * (64 * 17);
   const int lane = tid & 63;
   const int64_t bw0 = (int64_t)bg * kBlockThreads + (tid & ~63);      // first baseline of this wave
+  // SPLIT: log2 of the source-independent taper factor of a baseline at frequency f is kE f^2, kE = -log2(e) kappa0 |b|^2/c^2.  It is
+  // applied in the flush's STORE loop (few live registers there), so every lane parks its kE in LDS for the lanes that store its row.
+  double* const ke_lds = reinterpret_cast<double*>(flush_lds + flush_lds_bytes<float>() + kPrefetchLdsBytes) + (tid & ~63);
+  auto escale = [&](double ke, int kchan) -> double {
+    const double f = p.f0 + (double)kchan * p.df;
+    const double x = ke * f * f;                     // <= 0; integer part by ldexp, fraction by the hardware exp2: ~1e-7 relative
+    const double xi = __builtin_rint(x);
+    return (double)__builtin_ldexpf(__builtin_amdgcn_exp2f((float)(x - xi)), (int)__builtin_fmax(xi, -300.0));
+  };
 
   // fp32 partial sums -> fp64 cube (read-modify-write after the first flush), transposed through LDS 16 channels at a time:
   // piece pz holds the pairs j = 8 pz .. 8 pz + 7, i.e. channels HC+8pz .. HC+8pz+7 (columns 0-7) and HC-1-8pz .. HC-8-8pz
@@ -915,6 +937,10 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
     if (wave_active) {
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));        // opaque: keeps the 64 store addresses from being hoisted out of the segment loop and spilled
+      if constexpr (SPLIT) {
+        ke_lds[lane_o] = -1.4426950408889634 * p.kappa0 * bl2_c2;
+        wave_lds_sync();
+      }
 #pragma unroll
       for (int rs = 0; rs < NR; ++rs) {
       // destination of accumulator set rs: the visibility slot, or gradient component rs - 1 of this slot
@@ -937,11 +963,15 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           const float2 a = wbuf[bi * 17 + c];
           const int64_t bb = bw0 + bi;
           if (bb < p.nbl && k < p.nchan) {
-            if (!GRAD && p.out_f32) {                              // complex64 partial of a source split: written once, no read-modify-write
+            if (!GRAD && !SPLIT && p.out_f32) {                    // complex64 partial of a source split: written once, no read-modify-write
               reinterpret_cast<float2*>(p.out)[((size_t)split * p.nbl + (size_t)bb) * p.nchan + k] = a;
             } else {
               double2* o = outr + (size_t)bb * p.nchan + k;
               double2 v = make_double2((double)a.x, (double)a.y);
+              if constexpr (SPLIT) {
+                const double e = escale(ke_lds[bi], k);            // the source-independent half of the taper, exact per (baseline, channel)
+                v.x *= e; v.y *= e;
+              }
               if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
               *o = v;
             }
@@ -1056,22 +1086,38 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       float tB = 0.f, tC = 0.f, tA_keep = 0.f;
       if (TAPER) {
         const double tau = d + bpc;
-        double gq = sv[3] * (bl2_c2 - tau * tau);
-        gq = gq > 0.0 ? gq : 0.0;                       // |b|^2 >= (b.s)^2 up to rounding
+        double gq;
+        if constexpr (SPLIT) {
+          gq = -(sv[3] * tau * tau);                     // only the source-dependent part rides the recurrence (an amplitude that GROWS with f)
+        } else {
+          gq = sv[3] * (bl2_c2 - tau * tau);
+          gq = gq > 0.0 ? gq : 0.0;                      // |b|^2 >= (b.s)^2 up to rounding
+        }
         const float tA = (float)(gq * kA);               // |A| can reach tens of octaves: fp64 product; B and C are small
         const float gqf = (float)gq;
         tB = gqf * kBf;
         tC = gqf * kCf;
         tA_keep = tA;
-        const float w_u0 = __builtin_amdgcn_exp2f(tA);                 // channel HC
-        const float w_d0 = __builtin_amdgcn_exp2f(tA - tB + tC);       // channel HC-1
+        float w_u0, w_d0;
+        if constexpr (SPLIT) {
+          // the in-loop weight exp2(A) can be LARGE here (it is cancelled by the flush factor), so a float exponent of tens of octaves
+          // would cost 1e-6 of a term with w ~ 1: integer part by ldexp, fraction by the hardware exp2; the other channels hang on it
+          const double tAd = gq * kA;
+          const double ti = __builtin_rint(tAd);
+          w_u0 = __builtin_ldexpf(__builtin_amdgcn_exp2f((float)(tAd - ti)), (int)ti);
+          w_d0 = w_u0 * __builtin_amdgcn_exp2f(tC - tB);
+          tA_keep = w_u0;                                 // REANCHOR re-forms amplitudes as w_u0 * exp2(B j + C j^2)
+        } else {
+          w_u0 = __builtin_amdgcn_exp2f(tA);                           // channel HC
+          w_d0 = __builtin_amdgcn_exp2f(tA - tB + tC);                 // channel HC-1
+        }
         zre = zre * (f32x2){w_u0, w_d0};
         zim = zim * (f32x2){w_u0, w_d0};
         const float th = (TGROUP ? 16.0f : 2.0f) * tC * 0.6931471805599453f;   // exp2(2C) - 1 (exp2(16C) - 1) = th + th^2/2 + ...
         const float hm = __builtin_fmaf(0.5f * th, th, th);
         HM = (f32x2){hm, hm};
-        if (TGROUP) {
-          const float c = -0.6931471805599453f * tC;                     // >= 0
+        if (PARABOLA) {
+          const float c = -0.6931471805599453f * tC;                     // >= 0 (SPLIT: <= 0, the held ratio is then HIGH inside a group)
           EK[0] = (f32x2){7.f * c, 7.f * c};
           EK[1] = (f32x2){12.f * c, 12.f * c};
           EK[2] = (f32x2){15.f * c, 15.f * c};
@@ -1089,18 +1135,20 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
             // exact zeta at channel HC - 1 - j (down) and, REANCHOR == 2, HC + j (up): phase d f, amplitude exp2(L(-1-j)) / exp2(L(j))
             float cd, sd;
             sincos_cycles_hw(d * (fc_hz - (double)(j + 1) * p.df), cd, sd);
-            const float wd = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)((j + 1) * (j + 1)), __builtin_fmaf(tB, -(float)(j + 1), tA_keep)));
+            const float wd = SPLIT ? tA_keep * __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)((j + 1) * (j + 1)), tB * -(float)(j + 1)))
+                                   : __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)((j + 1) * (j + 1)), __builtin_fmaf(tB, -(float)(j + 1), tA_keep)));
             zre.y = cd * wd;
             zim.y = -(sd * wd);
             if (REANCHOR == 2) {
               float cu, su;
               sincos_cycles_hw(d * (fc_hz + (double)j * p.df), cu, su);
-              const float wu = __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(j * j), __builtin_fmaf(tB, (float)j, tA_keep)));
+              const float wu = SPLIT ? tA_keep * __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(j * j), tB * (float)j))
+                                     : __builtin_amdgcn_exp2f(__builtin_fmaf(tC, (float)(j * j), __builtin_fmaf(tB, (float)j, tA_keep)));
               zre.x = cu * wu;
               zim.x = -(su * wu);
             }
           }
-          if (TGROUP) {
+          if (PARABOLA) {
             constexpr int kmap[8] = {0, 0, 1, 2, 3, 2, 1, 0};          // m (8 - m) = 7, 12, 15, 16, 15, 12, 7 for m = 1..7
             const int m = j % 8;
             if (m != 0) pp = pkfma(pp, EK[kmap[m]], pp);
@@ -1213,15 +1261,65 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
     if (!block_item(p, slab_, bg)) return;
     const bool small_step = p.lift_flags != nullptr && p.lift_flags[bg] != 0;
     if (p.taper_group) {                      // launch-uniform, chosen by the host from df / f_min
-      if (small_step) skyvis_rec_f32pk_body<CT, true, false, true, 0>(p, flush_lds);
-      else skyvis_rec_f32pk_body<CT, true, false, true, 2>(p, flush_lds);
+      if (small_step) skyvis_rec_f32pk_body<CT, true, false, 1, 0>(p, flush_lds);
+      else skyvis_rec_f32pk_body<CT, true, false, 1, 2>(p, flush_lds);
     } else {
-      if (small_step) skyvis_rec_f32pk_body<CT, true, false, false, 1>(p, flush_lds);
-      else skyvis_rec_f32pk_body<CT, true, false, false, 2>(p, flush_lds);
+      if (small_step) skyvis_rec_f32pk_body<CT, true, false, 0, 1>(p, flush_lds);
+      else skyvis_rec_f32pk_body<CT, true, false, 0, 2>(p, flush_lds);
     }
     return;
   }
   skyvis_rec_f32pk_body<CT, TAPER, false>(p, flush_lds);
+}
+
+// Packed fp32 sky-sum of ONE source range whose sources share a size (kappa0): the split taper form (see skyvis_rec_f32pk_body).
+// split_flags[bg]: bit 0 = |step angle| <= pi/4 guaranteed for the group (no re-anchoring), bit 1 = the host could not bound the
+// uncorrected parabola below 2e-7 for this group: keep the correction.
+template <int CT>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
+void k_skyvis_rec_f32pk_split(const SkyvisParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>() + kPrefetchLdsBytes + kBlockThreads * sizeof(double)];
+  int slab_, bg;
+  if (!block_item(p, slab_, bg)) return;
+  const int fl = p.split_flags[bg];
+  if (fl & 2) {
+    if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 2, 0>(p, flush_lds);
+    else skyvis_rec_f32pk_body<CT, true, false, 2, 2>(p, flush_lds);
+  } else {
+    if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 3, 0>(p, flush_lds);
+    else skyvis_rec_f32pk_body<CT, true, false, 3, 2>(p, flush_lds);
+  }
+}
+
+// Beam-weighted moments of a source range per channel, for the host's bound on the split taper's uncorrected parabola:
+//   out[0][k] = sum_s p[s,k],  out[1][k] = sum_s p rho^2,  out[2][k] = sum_s p rho |n|,  out[3][k] = sum_s p n^2,   rho^2 = l^2 + m^2,
+// (l, m, n) the source direction: (b.s)^2 <= (|b_h| rho + |b_z| |n|)^2.  |p| is summed (the tolerance is relative to sum|pbflux|).
+__global__ void k_taper_moments(const double* __restrict__ pb, const double* __restrict__ dirs, int64_t s_lo, int64_t s_hi, int64_t nchan,
+                                double* __restrict__ out /*[4][nchan], zeroed*/) {
+  const int kc = threadIdx.x & 63, sl = threadIdx.x >> 6;                 // 64 channels x 4 source lanes
+  const int64_t k = (int64_t)blockIdx.x * 64 + kc;
+  const int64_t chunk = 1024;
+  const int64_t s0 = s_lo + (int64_t)blockIdx.y * chunk;
+  const int64_t s1 = (s0 + chunk < s_hi) ? s0 + chunk : s_hi;
+  double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+  if (k < nchan) {
+    for (int64_t s = s0 + sl; s < s1; s += 4) {
+      const double4 d = reinterpret_cast<const double4*>(dirs)[s];
+      const double v = __builtin_fabs(pb[(size_t)s * nchan + k]);
+      const double r2 = d.x * d.x + d.y * d.y, an = __builtin_fabs(d.z);
+      m0 += v; m1 += v * r2; m2 += v * __builtin_sqrt(r2) * an; m3 += v * an * an;
+    }
+  }
+  __shared__ double red[4][4][64];
+  red[0][sl][kc] = m0; red[1][sl][kc] = m1; red[2][sl][kc] = m2; red[3][sl][kc] = m3;
+  __syncthreads();
+  if (sl == 0 && k < nchan) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double v = red[q][0][kc] + red[q][1][kc] + red[q][2][kc] + red[q][3][kc];
+      atomicAdd(out + (size_t)q * nchan + k, v);
+    }
+  }
 }
 
 // fp32 visibility + baseline gradient in one pass (GRAD bodies of the packed kernel, 16-channel tiles, no source split)
@@ -1233,17 +1331,17 @@ void k_skyvis_grad_f32pk(const SkyvisParams p) {
   if (!block_item(p, slab_, bg)) return;
   const bool small_step = p.lift_flags != nullptr && p.lift_flags[bg] != 0;
   if constexpr (!TAPER) {
-    if (small_step) skyvis_rec_f32pk_body<16, false, true, false, 0, true>(p, flush_lds);
-    else skyvis_rec_f32pk_body<16, false, false, false, 0, true>(p, flush_lds);
+    if (small_step) skyvis_rec_f32pk_body<16, false, true, 0, 0, true>(p, flush_lds);
+    else skyvis_rec_f32pk_body<16, false, false, 0, 0, true>(p, flush_lds);
   } else {
     // 8 steps per chain: one group of the grouped recurrence and no mid-chain re-anchoring (HC < 32); the REANCHOR = 2 bodies are the ones
     // that seed the step phasor for any step angle (groups without the |theta| <= 1/8 cycle guarantee)
     if (p.taper_group) {
-      if (small_step) skyvis_rec_f32pk_body<16, true, false, true, 0, true>(p, flush_lds);
-      else skyvis_rec_f32pk_body<16, true, false, true, 2, true>(p, flush_lds);
+      if (small_step) skyvis_rec_f32pk_body<16, true, false, 1, 0, true>(p, flush_lds);
+      else skyvis_rec_f32pk_body<16, true, false, 1, 2, true>(p, flush_lds);
     } else {
-      if (small_step) skyvis_rec_f32pk_body<16, true, false, false, 0, true>(p, flush_lds);
-      else skyvis_rec_f32pk_body<16, true, false, false, 2, true>(p, flush_lds);
+      if (small_step) skyvis_rec_f32pk_body<16, true, false, 0, 0, true>(p, flush_lds);
+      else skyvis_rec_f32pk_body<16, true, false, 0, 2, true>(p, flush_lds);
     }
   }
 }
@@ -1427,6 +1525,24 @@ hipError_t launch_skyvis_rec_f32pk(const SkyvisParams& p, int ct, hipStream_t st
     case 64: return launch_rec_pk_ct<64>(p, stream);
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_skyvis_rec_f32pk_split(const SkyvisParams& p, int ct, hipStream_t stream) {
+  const int64_t items = (int64_t)p.ntiles * p.nsplit * p.nbgroups;
+  if (items <= 0 || items > 0x3fffffffLL || !p.split_flags || ct != 64) return hipErrorInvalidValue;
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
+  hipLaunchKernelGGL((k_skyvis_rec_f32pk_split<64>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_taper_moments(const double* pb, const double* dirs, int64_t s_lo, int64_t s_hi, int64_t nchan, double* out, hipStream_t stream) {
+  if (s_hi <= s_lo || nchan <= 0) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)4 * nchan * sizeof(double), stream);
+  if (e != hipSuccess) return e;
+  const int64_t gy = (s_hi - s_lo + 1023) / 1024;
+  if (gy > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_taper_moments, dim3((unsigned)((nchan + 63) / 64), (unsigned)gy), dim3(256), 0, stream, pb, dirs, s_lo, s_hi, nchan, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream) {

@@ -756,14 +756,22 @@ class InterferometerArray(object):
                         self._cube[i] = self._host_cube[snap.slot]
                     else:
                         self._cube[i] = self._ctx.get_vis(slot=snap.slot, complex64=(snap.dtype == NP.complex64))
-            hc = getattr(self, '_host_cube', None)
-            if hc is not None and all(staged) and all(self._cube[i].base is not None and NP.shares_memory(self._cube[i], hc[i])
-                                                      for i in range(len(self._cube))):
-                # every snapshot already sits in the pinned host cube [t][b][f]: the reference's (nbl, nchan, n_acc) is a view of it
-                self._skyvis_cache = NP.moveaxis(hc[:len(self._cube)], 0, 2)
-            else:
-                self._skyvis_cache = NP.stack(self._cube, axis=2)
+            # the reference's layout: (nbl, nchan, n_acc) C-contiguous, time fastest (:6385-6390) -- a host-side transpose of the
+            # per-snapshot arrays; skyvis_freq_snapshots() hands out the snapshot-major cube without it
+            self._skyvis_cache = NP.stack(self._cube, axis=2)
         return self._skyvis_cache
+
+    def skyvis_freq_snapshots(self):
+        """The visibilities snapshot-major, (n_acc, nbl, nchan) -- the layout they are computed and downloaded in.  With
+        reserve(host_staging=True) this is the page-locked host cube itself (no copy: the downloads already ran under the later
+        snapshots' sky-sums and only the last one is waited for); otherwise the snapshots are fetched and stacked."""
+        if not getattr(self, '_cube', None):
+            return None if self._skyvis_override is None else NP.moveaxis(NP.asarray(self._skyvis_override), 2, 0)
+        hc = getattr(self, '_host_cube', None)
+        if hc is not None and all(isinstance(sn, _DeviceSlot) and sn.staged and sn.slot == i for i, sn in enumerate(self._cube)):
+            self._ctx.wait_downloads()
+            return hc[:len(self._cube)]
+        return NP.moveaxis(self.skyvis_freq, 2, 0)
 
     @skyvis_freq.setter
     def skyvis_freq(self, value):

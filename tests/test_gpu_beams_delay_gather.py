@@ -273,10 +273,13 @@ def test_host_staging_through_the_class_matches_the_lazy_download():
                 ia.observe((2457000.5 + j * 1e-3, 5.0 * j), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, -30.7224], skymod, 10.0, memsave=memsave)
             assert all(isinstance(sn, RI._DeviceSlot) and sn.staged == staging for sn in ia._cube)
             ia.phase_centering(phase_center=NP.array([[80.0, 120.0]]), phase_center_coords='altaz', verbose=False)
-            cube = ia.skyvis_freq
-            assert cube.dtype == (NP.complex64 if memsave else NP.complex128)
             if staging:
-                assert NP.shares_memory(cube, ia._host_cube)
+                snaps = ia.skyvis_freq_snapshots()                # the pinned cube itself, snapshot-major, no copy
+                assert snaps.shape == (3, bl.shape[0], ch.size) and NP.shares_memory(snaps, ia._host_cube)
+            cube = ia.skyvis_freq
+            assert cube.dtype == (NP.complex64 if memsave else NP.complex128) and cube.flags['C_CONTIGUOUS']
+            if staging:
+                assert NP.array_equal(NP.moveaxis(snaps, 0, 2), cube)
             cubes.append(NP.array(cube))
             ia._ctx.close()
     assert NP.array_equal(cubes[0], cubes[2]) and NP.array_equal(cubes[1], cubes[3])

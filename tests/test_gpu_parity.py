@@ -189,6 +189,50 @@ def test_fp32_taper_grouped_and_exact_recurrences(ctx, monkeypatch):
     ctx.set_tuning(0, 0, 0)
 
 
+def test_fp32_split_taper_runs_of_one_source_size(ctx, monkeypatch):
+    """Skies whose sources come in runs of ONE size each (every HEALPix sky; point sources followed by a diffuse map) run the packed fp32
+    taper in its split form: exp(-kappa |b|^2 f^2/c^2) once per flush, exp(+kappa (b.s)^2 f^2/c^2) in the recurrence, and -- where the
+    host's beam-weighted bound allows -- no parabola correction inside a group.  Point-source runs (size 0) take the no-taper bodies.
+    Checked against the oracle and against the unsplit kernel, on a sky concentrated near the zenith (bound passes: uncorrected
+    bodies) and on one spread to the horizon with large sources (bound fails: corrected bodies); flushes every 97 sources so that
+    the per-flush factor and the read-modify-write across runs are exercised."""
+    rng = NP.random.default_rng(77)
+    nbl, nchan = 520, 128
+    bl = rng.uniform(-280.0, 280.0, size=(nbl, 3)); bl[:, 2] *= 0.005
+    bl[-40:] *= 3.0                                                       # a last group with longer baselines (re-anchored bodies)
+    ch = 150e6 + (NP.arange(nchan) - 64) * 97656.25
+    pc = NP.array([0.0, 0.0, 1.0])
+    monkeypatch.setenv('PRISIM_HIP_FLUSH_SRC', '97')
+    ctx.set_array(bl, ch)
+    ctx.set_tuning(64, 0, 1)
+    for name, alt_lo, fw_d, want_uncorrected in (('zenith', 82.0, 0.229, True), ('horizon', 5.0, 0.9, False)):
+        n_pt, n_df = 150, 450
+        alt = NP.degrees(NP.arcsin(rng.uniform(NP.sin(NP.radians(alt_lo)), 1.0, n_pt + n_df)))
+        dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, n_pt + n_df)), axis=1))
+        pb = rng.uniform(0.5, 10.0, size=(n_pt + n_df, 1)) * rng.uniform(0.5, 1.0, size=(n_pt + n_df, nchan))
+        fw = NP.concatenate((NP.zeros(n_pt), NP.full(n_df, fw_d)))
+        ref = CO.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw)
+        ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
+        ctx.compute(precision=_abi.PRISIM_FP32)
+        tm = ctx.timing()
+        assert tm['last_chan_tile'] == 64 and tm['last_taper_split'] == 2, (name, tm)
+        assert (tm['last_split_uncorrected_groups'] > 0) == want_uncorrected, (name, tm)
+        v_split = ctx.get_vis()
+        assert relerr(v_split, ref, pb) <= TOL[_abi.PRISIM_FP32], name
+        monkeypatch.setenv('PRISIM_HIP_TAPER_SPLIT', '0')
+        ctx.compute(precision=_abi.PRISIM_FP32)
+        assert ctx.timing()['last_taper_split'] == 0
+        assert relerr(ctx.get_vis(), v_split, pb) <= 1.5e-6, name
+        monkeypatch.delenv('PRISIM_HIP_TAPER_SPLIT')
+    # sizes that vary from source to source: no runs, the unsplit kernel
+    fw = rng.uniform(0.05, 0.4, n_pt + n_df)
+    ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
+    ctx.compute(precision=_abi.PRISIM_FP32)
+    assert ctx.timing()['last_taper_split'] == 0
+    assert relerr(ctx.get_vis(), CO.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw), pb) <= TOL[_abi.PRISIM_FP32]
+    ctx.set_tuning(0, 0, 0)
+
+
 @pytest.mark.parametrize('taper', [False, True])
 def test_fp32_single_source_worst_case_per_term(ctx, taper):
     """One source, so nothing averages: the error of every (baseline, channel) term against the fp64 oracle must stay inside the

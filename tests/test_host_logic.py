@@ -386,8 +386,11 @@ def test_host_staging_gives_the_same_cube_as_the_lazy_download(monkeypatch):
     assert all(isinstance(s, RI._DeviceSlot) and s.staged for s in staged._cube)
     assert all(isinstance(s, RI._DeviceSlot) and not s.staged for s in lazy._cube)
     a, b = staged.skyvis_freq, lazy.skyvis_freq
-    assert a.shape == b.shape == (5, 16, 3) and NP.array_equal(a, b)
-    assert NP.shares_memory(a, staged._host_cube)              # the (nbl, nchan, n_acc) cube IS the pinned cube, viewed time-last
+    staged3, _ = _observed_oracle_array(monkeypatch, 3, reserve=3, host_staging=True)
+    snaps = staged3.skyvis_freq_snapshots()                    # snapshot-major: the pinned cube itself, no copy
+    assert snaps.shape == (3, 5, 16) and NP.shares_memory(snaps, staged3._host_cube)
+    assert a.shape == b.shape == (5, 16, 3) and NP.array_equal(a, b) and a.flags['C_CONTIGUOUS']      # the reference's layout
+    assert NP.array_equal(NP.moveaxis(snaps, 0, 2), b) and NP.array_equal(lazy.skyvis_freq_snapshots(), snaps)
     # a re-centring on the device invalidates staged copies: they are queued again, and the host sees the rotated cube
     pc = NP.array([[80.0, 200.0]])
     staged2, _ = _observed_oracle_array(monkeypatch, 3, reserve=3, host_staging=True)
