@@ -205,7 +205,7 @@ def test_fp32_split_taper_runs_of_one_source_size(ctx, monkeypatch):
     monkeypatch.setenv('PRISIM_HIP_FLUSH_SRC', '97')
     ctx.set_array(bl, ch)
     ctx.set_tuning(64, 0, 1)
-    for name, alt_lo, fw_d, want_uncorrected in (('zenith', 82.0, 0.229, True), ('horizon', 5.0, 0.9, False)):
+    for name, alt_lo, fw_d, want_uncorrected in (('zenith', 82.0, 0.229, True), ('horizon', 5.0, 0.5, False)):
         n_pt, n_df = 150, 450
         alt = NP.degrees(NP.arcsin(rng.uniform(NP.sin(NP.radians(alt_lo)), 1.0, n_pt + n_df)))
         dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, n_pt + n_df)), axis=1))
