@@ -49,6 +49,9 @@ sys.path.insert(0, ROOT)
 from prisim_amd import _abi, launch, rendezvous, workloads as W   # noqa: E402
 
 FLOPS_PER_TERM = 10.0       # rotate (4 mul + 2 add) + accumulate (2 mul + 2 add) = 6 VALU slots
+# Taper contract: the amplitude rides on the step factor, rho = r * q, which is still ONE complex multiply (6 flop) + the
+# accumulate (4 flop); what the taper adds is advancing the ratio, rho_{k+1} = rho_k * h: 2 real multiplies per term = 12 flop, 8 VALU slots.
+FLOPS_PER_TERM_TAPER = 12.0
 PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # MI355X_MICROARCH.md chip table: vector FP32 157.3 TF; FP64 = half
 HBM_PEAK_GBS = 8000.0
 XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md: 7 point-to-point links of ~153 GB/s per GPU
@@ -320,6 +323,8 @@ def other_kernels(ctx, cfg, zen):
     res['fp32_taper'] = {'kernel': 'k_skyvis_rec_f32pk<%d,taper>' % tm['last_chan_tile'], 'kernel_ms': tm['last_kernel_ms'],
                          'terms_per_s': terms / (tm['last_kernel_ms'] * 1e-3), 'grouped_recurrence': bool(tm['last_taper_group']),
                          'roofline_frac_vs_no_taper_contract': terms * FLOPS_PER_TERM / (tm['last_kernel_ms'] * 1e-3) / 1e12 / PEAK_TFLOPS['f32'],
+                         'roofline_frac_vs_taper_contract': terms * FLOPS_PER_TERM_TAPER / (tm['last_kernel_ms'] * 1e-3) / 1e12 / PEAK_TFLOPS['f32'],
+                         'taper_split_runs': tm.get('last_taper_split', 0), 'taper_uncorrected_groups': tm.get('last_split_uncorrected_groups', 0),
                          'workload': cfg_d['name'] + ' (taper on)'}
     return res
 
@@ -587,6 +592,11 @@ def main():
                              'algorithmic_bytes_per_launch': alg_bytes},
             'csrc_hash': csrc_hash(),
         }
+        if cfg['taper'] and not wg:
+            out['roofline']['flops_per_term_taper_contract'] = FLOPS_PER_TERM_TAPER
+            out['roofline']['frac_vs_taper_contract'] = terms_launch * FLOPS_PER_TERM_TAPER / (kern_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype]
+            out['roofline']['frac_what'] = ('frac charges the no-taper 10 flop/term; frac_vs_taper_contract charges 12 (scaled rotation 6 + accumulate 4 + '
+                                            'ratio update 2)')
         out['kernel_ms_per_rank'] = {'min': min(rank_kern_ms), 'max': max(rank_kern_ms), 'all': rank_kern_ms}
         out['value_n1_equiv'] = value / world           # whole-job rate per GPU: what to hold against the N = 1 line
         if world > 1:

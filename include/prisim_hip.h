@@ -261,6 +261,11 @@ int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out);
  * interferometry.py:8349-8350): gathers [nt][3][nbl_shard][nchan] into [nt][nranks][3][nbl_shard][nchan]; read with
  * prisim_hip_get_gathered (its rows are then 3 nchan long). */
 int prisim_hip_allgather_grad(prisim_ctx* ctx, int64_t nt, int as_c64);
+/* Who receives the gathered cubes of every LATER gather call (allgather, allgather_slot_async, allgather_lags, allgather_grad):
+ * root = -1 (default) every rank (ncclAllGather: each GPU ends up with the whole cube, 60-120 GB at config 5); root = r only rank r
+ * (grouped ncclSend / ncclRecv: SURVEY 8(e) `gather_to_root`, the layout of the reference's rank-0 concatenate, run_prisim.py:2233-2242) --
+ * the other ranks then allocate no gathered cube, and prisim_hip_get_gathered / _gathered_checksum fail there with PRISIM_ESTATE. */
+int prisim_hip_set_gather_root(prisim_ctx* ctx, int root);
 /* All-gather of `bytes` per rank filled with a rank-dependent pattern, read back and verified on the host: run once before any
  * timed or production exchange so that a communicator that cannot move data fails HERE (PRISIM_ELIB + message), not as a wrong cube.
  * Also valid on a 1-rank context without a communicator (device copy). */

@@ -29,7 +29,7 @@ EXPORTS = (
     'prisim_hip_allgather_lags', 'prisim_hip_phase_rotate', 'prisim_hip_noise', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
     'prisim_hip_allgather', 'prisim_hip_allgather_slot_async', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
-    'prisim_hip_allgather_grad', 'prisim_hip_comm_selftest', 'prisim_hip_get_comm_stats',
+    'prisim_hip_allgather_grad', 'prisim_hip_comm_selftest', 'prisim_hip_get_comm_stats', 'prisim_hip_set_gather_root',
     'prisim_hip_host_alloc', 'prisim_hip_host_free', 'prisim_hip_get_vis_async', 'prisim_hip_wait_downloads',
 )
 
@@ -187,6 +187,7 @@ def load_library():
     lib.prisim_hip_set_tuning.argtypes = [vp, i32, i32, i32]
     lib.prisim_hip_allgather_grad.argtypes = [vp, i64, i32]
     lib.prisim_hip_comm_selftest.argtypes = [vp, i64]
+    lib.prisim_hip_set_gather_root.argtypes = [vp, i32]
     lib.prisim_hip_get_comm_stats.argtypes = [vp, C.POINTER(PrisimCommStats), i32]
     lib.prisim_hip_host_alloc.argtypes = [i64, C.POINTER(vp)]
     lib.prisim_hip_host_free.argtypes = [vp]
@@ -557,6 +558,10 @@ class Context(object):
         nranks = getattr(self, 'nranks', 1) if nranks is None else nranks
         g = self.get_gathered(nt, nranks, row=3 * self.nchan)                  # rows of 3*nchan: the block is [3][nbl][nchan] per rank
         return g.reshape(nt, nranks, 3, self.nbl, self.nchan)
+
+    def set_gather_root(self, root=None):
+        """Later gathers deliver to rank `root` only (None: to every rank); the other ranks then hold no gathered cube."""
+        self._check(self._lib.prisim_hip_set_gather_root(self._h, -1 if root is None else int(root)), 'prisim_hip_set_gather_root')
 
     def comm_selftest(self, nbytes=1 << 20):
         """All-gather of a rank-dependent pattern, verified on the host; raises PrisimHipError when the communicator cannot move data."""

@@ -33,6 +33,10 @@ struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;                   // optional (gather to one root): absent in very old RCCLs
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
@@ -74,6 +78,9 @@ bool load_rccl(std::string& err) {
             load_sym(h, "ncclAllGather", g_rccl.AllGather) && load_sym(h, "ncclCommDestroy", g_rccl.CommDestroy) &&
             load_sym(h, "ncclGetErrorString", g_rccl.GetErrorString);
   if (!ok) { err = "librccl lacks a required symbol"; dlclose(h); return false; }
+  if (!(load_sym(h, "ncclSend", g_rccl.Send) && load_sym(h, "ncclRecv", g_rccl.Recv) && load_sym(h, "ncclGroupStart", g_rccl.GroupStart) &&
+        load_sym(h, "ncclGroupEnd", g_rccl.GroupEnd)))
+    g_rccl.Send = nullptr;                              // gather-to-root then reports PRISIM_ELIB
   g_rccl.handle = h;
   return true;
 }
@@ -173,6 +180,7 @@ struct prisim_ctx {
   hipEvent_t ev_slot_done = nullptr;
   bool comm_pending = false;
   int nranks = 1, rank = 0;
+  int gather_root = -1;                  // -1: every rank receives the gathered cube (all-gather); r: only rank r does (ncclSend / ncclRecv)
   DevBuf gathered, sendbuf;
   bool gathered_c64 = false;
   // gather timing: a ring of (compute-stream marker, gather start, gather end) events per overlapped gather, harvested in order
@@ -429,10 +437,21 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
     const double per_term = pl.f32 ? 2.5 : 5.0;
     double best = 0.0;
     ct = 8;
+    // Small problems (config 2: 171 baselines = 3 wavefronts) cannot fill the chip whatever the tiling; what matters then is that
+    // every SIMD has work and that the seed is amortised over as many channels as the wave count allows.  Measured on config 2
+    // (tools/small_problem_census.py, profiles/r03_small_problem_census.jsonl): fp64 16-channel tiles 75.6 us against 85.8 at 8 and
+    // 81.0 at 32 (fp64 wants ~2 waves per SIMD to cover its dependent-issue latency), packed fp32 32-channel tiles 39.8 us against 54.2
+    // at 8 (a single wave issues v_pk_fma_f32 at near the full rate, the 2-cycle v_fma_f32 of the narrow tiles does not).  So a wider
+    // tile is admitted as soon as it still yields 1024 (fp64) / 512 (fp32) active wavefronts, even if that is fewer than 1024 blocks.
+    const int64_t waves_per_group = std::min<int64_t>(kBlockThreads / 64, (nbl + 63) / 64);
+    const int64_t active_waves_per_tile = (int64_t)(pl.nbgroups - 1) * (kBlockThreads / 64) +
+                                          std::min<int64_t>(kBlockThreads / 64, (nbl - (int64_t)(pl.nbgroups - 1) * kBlockThreads + 63) / 64);
+    (void)waves_per_group;
+    const int64_t want_waves = pl.f32 ? 512 : 1024;
     for (int cand : {64, 32, 16, 8}) {
       if (cand > max_ct) continue;
       const int64_t tiles = (nchan + cand - 1) / cand;
-      if (cand > 8 && tiles * pl.nbgroups * max_split < want_blocks) continue;
+      if (cand > 8 && tiles * pl.nbgroups * max_split < want_blocks && tiles * active_waves_per_tile * max_split < want_waves) continue;
       const double cost = (double)tiles * (seed + per_term * cand);
       if (best == 0.0 || cost < best * (1.0 - 1e-9)) { best = cost; ct = cand; }
     }
@@ -469,6 +488,16 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
     int64_t want = 1;
     if (base * 10 < slots * 60) want = (slots * 15 / 2 + base / 2) / base;       // round(7.5 * slots / base)
     want = std::min<int64_t>(want, std::max<int64_t>(1, nsrc / 32));             // keep >= 32 sources per split
+    {
+      // ... and every split writes a partial cube that k_reduce_partials reads again: keep that traffic (~3 TB/s effective) under
+      // ~3 % of the sky-sum's own time, but never below one round of resident blocks.  One rank's share of config 4 at N = 8
+      // (1016 bl x 768 ch x 24 576 sources): 2.86 ms at 16 splits against 3.13 ms at the 64 the round rule alone asks for.
+      const double rate = pl.f32 ? (ctx->taper ? 7.0e12 : 1.0e13) : (ctx->taper ? 2.8e12 : 5.0e12);       // terms/s of the big kernels
+      const double t_compute = (double)nbl * (double)nchan * (double)nsrc / rate;
+      const double t_split = 2.0 * (double)nbl * (double)nchan * (pl.f32 ? 8.0 : 16.0) / 3.0e12;
+      const int64_t cap = std::max<int64_t>((slots + base - 1) / std::max<int64_t>(base, 1), (int64_t)(0.03 * t_compute / t_split));
+      if (want > 16) want = std::max<int64_t>(16, std::min<int64_t>(want, cap));       // (splits up to 16 keep the measured round rule)
+    }
     nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, 64));
   }
   if (nsplit > nchunks) nsplit = (int)nchunks;
@@ -1714,14 +1743,35 @@ static int gather_one_slot(prisim_ctx* ctx, const double* src_all, int64_t row, 
     HIPCHK(ctx, launch_f64_to_f32(src, sb, (int64_t)shard, st));
     send = sb;
   }
-  char* dst = (char*)ctx->gathered.p + (size_t)slot * shard * (size_t)ctx->nranks * esz;
+  const bool receiver = ctx->gather_root < 0 || ctx->gather_root == ctx->rank;
+  char* dst = receiver ? (char*)ctx->gathered.p + (size_t)slot * shard * (size_t)ctx->nranks * esz : nullptr;
   if (ctx->nranks == 1 && !ctx->comm) {
     HIPCHK(ctx, hipMemcpyAsync(dst, send, shard * esz, hipMemcpyDeviceToDevice, st));
     return PRISIM_OK;
   }
   if (!ctx->comm) return fail(ctx, PRISIM_ESTATE, "comm_init has not been called");
-  ncclResult_t r = g_rccl.AllGather(send, dst, shard, as_c64 ? ncclFloat : ncclDouble, ctx->comm, st);
-  if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+  const ncclDataType_t ty = as_c64 ? ncclFloat : ncclDouble;
+  if (ctx->gather_root < 0) {
+    ncclResult_t r = g_rccl.AllGather(send, dst, shard, ty, ctx->comm, st);
+    if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+    return PRISIM_OK;
+  }
+  // gather to ONE rank (SURVEY 8(e) `gather_to_root`): the other GPUs keep no copy of the whole cube -- 120 GB at config 5.  One
+  // grouped call: the root posts a receive per peer into that peer's block, every other rank one send; the root's own block is a copy.
+  if (!g_rccl.Send) return fail(ctx, PRISIM_ELIB, "this librccl has no ncclSend / ncclRecv: gather to a root is unavailable");
+  ncclResult_t r = g_rccl.GroupStart();
+  if (r == ncclSuccess) {
+    if (receiver) {
+      for (int q = 0; q < ctx->nranks && r == ncclSuccess; ++q)
+        if (q != ctx->rank) r = g_rccl.Recv(dst + (size_t)q * shard * esz, shard, ty, q, ctx->comm, st);
+    } else {
+      r = g_rccl.Send(send, shard, ty, ctx->gather_root, ctx->comm, st);
+    }
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+  }
+  if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclSend/ncclRecv (gather to root): ") + g_rccl.GetErrorString(r));
+  if (receiver) HIPCHK(ctx, hipMemcpyAsync(dst + (size_t)ctx->rank * shard * esz, send, shard * esz, hipMemcpyDeviceToDevice, st));
   return PRISIM_OK;
 }
 
@@ -1730,7 +1780,8 @@ static int ensure_gather_buffers(prisim_ctx* ctx, int64_t row, int as_c64) {
   const size_t esz = as_c64 ? sizeof(float) : sizeof(double);
   int rc;
   if (ctx->gathered.p && (ctx->gathered_c64 != (as_c64 != 0) || ctx->gathered_row != row)) release(ctx->gathered);
-  if ((rc = ensure(ctx, ctx->gathered, shard * (size_t)ctx->nt_max * (size_t)ctx->nranks * esz))) return rc;
+  const bool receiver = ctx->gather_root < 0 || ctx->gather_root == ctx->rank;       // only receivers hold the whole cube
+  if ((rc = ensure(ctx, ctx->gathered, receiver ? shard * (size_t)ctx->nt_max * (size_t)ctx->nranks * esz : 16))) return rc;
   if (as_c64 && (rc = ensure(ctx, ctx->sendbuf, shard * (size_t)ctx->nt_max * sizeof(float)))) return rc;
   ctx->gathered_c64 = as_c64 != 0;
   ctx->gathered_row = row;
@@ -1808,6 +1859,7 @@ int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out) {
   if (!ctx) return PRISIM_EINVAL;
   if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
   if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
+  if (ctx->gather_root >= 0 && ctx->gather_root != ctx->rank) return fail(ctx, PRISIM_ESTATE, "the cube was gathered to another rank (set_gather_root)");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t esz = ctx->gathered_c64 ? sizeof(float) : sizeof(double);
   const size_t bytes = (size_t)nt * ctx->nbl * ctx->gathered_row * 2 * (size_t)ctx->nranks * esz;
@@ -1824,6 +1876,7 @@ int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out) {
   if (!ctx) return PRISIM_EINVAL;
   if (!out) return fail(ctx, PRISIM_EINVAL, "out is NULL");
   if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
+  if (ctx->gather_root >= 0 && ctx->gather_root != ctx->rank) return fail(ctx, PRISIM_ESTATE, "the cube was gathered to another rank (set_gather_root)");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t esz = ctx->gathered_c64 ? sizeof(float) : sizeof(double);
   const int64_t n = nt * ctx->nbl * ctx->gathered_row * 2 * (int64_t)ctx->nranks;
@@ -1851,6 +1904,19 @@ int prisim_hip_allgather_grad(prisim_ctx* ctx, int64_t nt, int as_c64) {
   if ((rc = ensure_gather_buffers(ctx, 3 * ctx->nchan, as_c64))) return rc;
   for (int64_t t = 0; t < nt; ++t)
     if ((rc = gather_one_slot(ctx, (const double*)ctx->grad.p, 3 * ctx->nchan, t, as_c64, ctx->stream))) return rc;
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_set_gather_root(prisim_ctx* ctx, int root) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (root < -1 || root >= ctx->nranks) return fail(ctx, PRISIM_EINVAL, "root must be -1 (all ranks) or a rank of the communicator");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->comm_stream && ctx->comm_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (root != ctx->gather_root) release(ctx->gathered);          // its size depends on who receives
+  ctx->gather_root = root;
   return PRISIM_OK;
   });
 }

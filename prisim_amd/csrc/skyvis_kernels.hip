@@ -830,45 +830,11 @@ typedef const volatile __attribute__((address_space(4))) double* cvdouble_p;
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) f32x8* cf32x8_p;
 
-// sin(2 pi y) and tan(pi y) for |y| <= 1/8 cycle in one go: the two polynomials of sin_2pi_y / tan_pi_y evaluated as the two halves of
-// packed FMAs (same operations in the same order per half, so the results are bit-identical to the scalar forms): 7 instructions
-// instead of 13 in the seed of every (source, baseline, tile) of the lifting bodies.
-__device__ __forceinline__ void sin2pi_tanpi_pk(float y, float& sn, float& tn) {
-  const float y2 = y * y;
-  const f32x2 Y2 = {y2, y2}, Y = {y, y};
-  f32x2 P = {-75.36964416503906f, __builtin_fmaf(769.7825317382812f, y2, 161.2586212158203f)};
-  P = pkfma(P, Y2, (f32x2){81.59197998046875f, 40.81293869018555f});
-  P = pkfma(P, Y2, (f32x2){-41.3416633605957f, 10.335405349731445f});
-  const f32x2 Q = pkfma(P, Y2, (f32x2){-1.7484555e-7f, -8.742278e-8f});
-  const f32x2 R = pkfma(Y, Q, Y * (f32x2){6.2831855f, 3.1415927410125732f});
-  sn = R.x; tn = R.y;
-}
-
-// cos(2 pi y) and sin(2 pi y) for |y| <= 1/8 cycle in one go (cos_2pi_y / sin_2pi_y as the halves of packed FMAs, bit-identical):
-// 8 instructions instead of 12 in the seed of the small-step taper bodies.
-__device__ __forceinline__ void cossin_2pi_y_pk(float y, float& cs, float& sn) {
-  const float y2 = y * y;
-  const f32x2 Y2 = {y2, y2};
-  f32x2 P = {__builtin_fmaf(-26.42625678337438f, y2, 60.24464137187666f), -75.36964416503906f};
-  P = pkfma(P, Y2, (f32x2){-85.45681720669373f, 81.59197998046875f});
-  P = pkfma(P, Y2, (f32x2){64.93939402266829f, -41.3416633605957f});
-  P = pkfma(P, Y2, (f32x2){-19.739208802178716f, -1.7484555e-7f});
-  const f32x2 R = pkfma(P, (f32x2){y2, y}, (f32x2){1.0f, y * 6.2831855f});
-  cs = R.x; sn = R.y;
-}
-
-// (exp2(D.x) - 1, exp2(D.y) - 1) by exp2m1_small's series on both halves at once
-__device__ __forceinline__ f32x2 exp2m1_small_pk(f32x2 D) {
-  f32x2 X = D * (f32x2){0.6931471805599453f, 0.6931471805599453f};
-  X.x = __builtin_amdgcn_fmed3f(X.x, -1.0f, 1.0f);
-  X.y = __builtin_amdgcn_fmed3f(X.y, -1.0f, 1.0f);
-  f32x2 E = pkfma(X, (f32x2){8.3333333e-3f, 8.3333333e-3f}, (f32x2){4.1666668e-2f, 4.1666668e-2f});
-  E = pkfma(E, X, (f32x2){0.16666667f, 0.16666667f});
-  E = pkfma(E, X, (f32x2){0.5f, 0.5f});
-  E = pkfma(E, X, (f32x2){1.0f, 1.0f});
-  return E * X;
-}
-
+// Tried and dropped (round 3, tools/ab_lib.py on one box): evaluating the seed's polynomial PAIRS -- (sin 2 pi y, tan pi y) of the lifting
+// bodies, (cos, sin) of the small-step taper bodies, the two exp2m1_small of the grouped recurrence -- as the halves of packed FMAs.
+// Bit-identical results and 6 + 4 + 8 fewer VALU instructions per (source, baseline, tile), but 61.5 instead of 60.9 ms on the headline
+// launch and 82.8 instead of 82.4 ms with the taper: the constant pairs cost SGPRs (48 -> 48 spills, 112 -> 120 lane moves around the
+// loops) and under the package power limit a packed FMA is not cheaper than the two scalar ones it replaces.
 // exp2(D) - 1 to ~1e-8 absolute for the small per-step taper exponents of the grouped form: 5-term series in x = D ln2, clamped
 // to |x| <= 1.  The host selects the grouped form only for df/f_min <= 3.4e-3, where |x| >= 1/8 implies a taper weight below
 // 1.5e-8 on every channel of the tile, so the loss of accuracy (and the clamp) out there is immaterial.
@@ -1083,9 +1049,8 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       float rr = 1.f, ri, tpy = 0.f, dr0, di0;
       if (LIFT) {
         const float yth = (float)(d * p.df);
-        float sn_;
-        sin2pi_tanpi_pk(yth, sn_, tpy);
-        ri = -sn_;
+        ri = -sin_2pi_y(yth);
+        tpy = tan_pi_y(yth);
         const float x1 = __builtin_fmaf(-tpy, ui0, ur0);
         di0 = __builtin_fmaf(-ri, x1, ui0);
         dr0 = __builtin_fmaf(-tpy, di0, x1);
@@ -1093,9 +1058,8 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
         if (TAPER && REANCHOR != 2) {
           // taper bodies of baseline groups whose |theta| <= 1/8 cycle is guaranteed (the host's lift flag): no quadrant logic
           const float yth = (float)(d * p.df);
-          float sn_;
-          cossin_2pi_y_pk(yth, rr, sn_);
-          ri = -sn_;
+          rr = cos_2pi_y(yth);
+          ri = -sin_2pi_y(yth);
         } else {
           float rc, rs;
           sincos_qcycles(d * df4, rc, rs);
@@ -1223,7 +1187,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
               // chains.  So q_g - 1 =: e_g is carried instead (accurate to ~1e-8: series at the first group, e_{g+1} = e_g + h + e_g h
               // after that) and rho_g = r + r e_g is one FMA: what is left is the rounding of r and of rho itself.
               if (j == 0) {
-                EQ = exp2m1_small_pk((f32x2){__builtin_fmaf(tC, 8.f, tB), __builtin_fmaf(tC, 10.f, -tB)});
+                EQ = (f32x2){exp2m1_small(__builtin_fmaf(tC, 8.f, tB)), exp2m1_small(__builtin_fmaf(tC, 10.f, -tB))};
               } else if ((j % 8) == 0) {
                 EQ = pkfma(EQ, HM, EQ + HM);                 // mean ratio of the next group: (1 + e)(1 + h) - 1, h = exp2(16 C) - 1
               }

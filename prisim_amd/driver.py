@@ -59,7 +59,7 @@ DEFAULTS = {
     'processing': {'gradient_mode': None, 'f_pad': 1.0, 'bpass_shape': 'bhw', 'delay_transform': False, 'memsave': False,
                    'add_noise': None, 'noise_seed': None},
     'phasing': {'center': [90.0, 270.0], 'coords': 'altaz'},
-    'pp': {'key': 'bl', 'eqvol': True},
+    'pp': {'key': 'bl', 'eqvol': True, 'gather': 'all'},
     'save_redundant': True,
     'save_formats': {'npz': True, 'hdf5': False},
     'diagnosis': {'wait_after_run': False},
@@ -373,7 +373,14 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     if world > 1:
         if comm_uid is None:
             raise ValueError('comm_uid is needed when world > 1')
-        cube = ia.allgather(comm_uid, world, rank, download=download)   # shards go GPU -> GPU; the host never sees this rank's own cube
+        # shards go GPU -> GPU; the host never sees this rank's own cube.  pp.gather: 'all' = every GPU ends up with the whole cube
+        # (ncclAllGather), 'root' = only rank 0 does (ncclSend / ncclRecv; the other GPUs keep nothing: 120 GB less at config 5)
+        gather = str(parms['pp'].get('gather', 'all')).lower()
+        if gather not in ('all', 'root'):
+            raise ValueError("pp.gather must be 'all' or 'root'")
+        if gather == 'root':
+            download = rank == 0
+        cube = ia.allgather(comm_uid, world, rank, download=download, root=(0 if gather == 'root' else None))
         cube = cube[:nbl_total] if cube is not None else None
         labels_all, bl_all = labels, bl
         noise_all = None

@@ -402,15 +402,20 @@ class InterferometerArray(object):
         if getattr(self, '_extbeam', None) is not None:
             self._ctx.set_external_beam(*self._extbeam)
 
-    def allgather(self, comm_uid, nranks, rank, download=True):
+    def allgather(self, comm_uid, nranks, rank, download=True, root=None):
         """One RCCL all-gather of the baseline shards of all ranks (equal shard sizes; replaces the reference's per-rank
         part files + rank-0 concatenate, scripts/run_prisim.py:2207, 2233-2242).  Returns (nranks*nbl, nchan, n_acc), or None with
-        download=False (the gathered cube then stays in HBM only: a rank that writes nothing need not pull it over PCIe)."""
+        download=False (the gathered cube then stays in HBM only: a rank that writes nothing need not pull it over PCIe).
+        root = r: this and every later gather of this array (lags, gradients, noise) deliver to rank r ONLY -- the other GPUs keep no
+        copy of the whole cube (SURVEY 8(e) gather_to_root); download must then be False everywhere else."""
         if self._reserved < self.n_acc:
             raise RuntimeError('reserve(n_acc) must be called before observing to keep the cube on the device')
+        if root is not None and download and rank != root:
+            raise ValueError('with root = {0} only that rank can download the gathered cube'.format(root))
         if not getattr(self, '_comm_ready', False):
             self._ctx.comm_init(comm_uid, nranks, rank)
             self._comm_ready = True
+        self._ctx.set_gather_root(root)
         # complex64 on the wire only when EVERY snapshot was observed with memsave (host arrays and _DeviceSlot placeholders both
         # carry their dtype); a run that mixes precisions, or has no snapshot yet, gathers complex128
         c64 = bool(self._cube) and all(NP.dtype(sn.dtype) == NP.complex64 for sn in self._cube)

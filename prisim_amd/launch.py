@@ -69,6 +69,27 @@ def spawn_ranks(nranks, argv, env=None, grace=10.0):
             rc = os.waitstatus_to_exitcode(status)
             procs[r].returncode = rc
             if rc != 0:
+                # A rank that dies takes its peers' sockets with it, and a peer can finish dying of the broken connection (exit 1, a
+                # traceback) BEFORE the culprit's interpreter has finished shutting down.  So look at who else has gone within a
+                # moment and report the rank with the most specific code: one that is not the generic 1, else the first reaped.
+                failed = [(r, rc)]
+                t_end = time.time() + 0.5
+                while alive and time.time() < t_end:
+                    try:
+                        pid2, status2 = os.waitpid(-1, os.WNOHANG)
+                    except ChildProcessError:
+                        break
+                    if pid2 == 0:
+                        time.sleep(0.01)
+                        continue
+                    r2 = alive.pop(pid2, None)
+                    if r2 is None:
+                        continue
+                    rc2 = os.waitstatus_to_exitcode(status2)
+                    procs[r2].returncode = rc2
+                    if rc2 != 0:
+                        failed.append((r2, rc2))
+                r, rc = next(((a, b) for a, b in failed if b != 1), failed[0])
                 code = rc if rc > 0 else 128 - rc          # killed by signal s: 128 + s, as a shell reports it
                 sys.stderr.write('prisim_amd.launch: rank %d exited with %d; stopping the other ranks\n' % (r, rc))
                 _stop(procs, set(alive.values()), grace)

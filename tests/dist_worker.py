@@ -131,7 +131,7 @@ def main():
         ok = ok and _hdf5_of_sharded_run_equals_unsharded(parms, out_root, ref)
     # baseline gradients of a sharded run: gathered like the visibilities, equal to the unsharded run's, and in rank 0's HDF5 file
     gparms = driver.deep_merge(parms, {'processing': {'gradient_mode': 'baseline', 'delay_transform': False, 'add_noise': False},
-                                       'obsparm': {'n_acc': 2}})
+                                       'obsparm': {'n_acc': 2}, 'pp': {'gather': 'root'}})       # and only rank 0 receives (gather to root)
     gout = driver.run(gparms, rank=rank, world=world, device=0, comm_uid=uid, verbose=False, host_copy='root')
     if rank == 0:
         gref = driver.run(gparms, rank=0, world=1, device=0, verbose=False)

@@ -105,6 +105,9 @@ class OracleContext(object):
         assert len(uid) == 128
         self.nranks, self.rank = int(nranks), int(rank)
 
+    def set_gather_root(self, root=None):
+        self._root = root           # the host stand-in delivers to every rank whatever the root: only who READS differs
+
     def allgather(self, nt, complex64=False):
         parts = _host_allgather(self.cube[:nt])                               # [rank][t][b][f]
         self._gathered = NP.stack(parts, axis=1)                              # [t][rank][b][f]
@@ -171,6 +174,9 @@ class HostCommContext(_abi.Context):
     def comm_init(self, uid, nranks, rank):
         assert len(uid) == 128
         self.nranks, self.rank = int(nranks), int(rank)
+
+    def set_gather_root(self, root=None):
+        self._root = root
 
     def allgather(self, nt, complex64=False):
         mine = NP.stack([self.get_vis(slot=t) for t in range(nt)])

@@ -209,6 +209,12 @@ def test_rccl_selftest_gather_stats_and_gradient_gather_on_one_rank(ctx):
         for t in range(3):
             v, grad = c.get_vis(slot=t, want_grad=True)
             assert NP.array_equal(g[t, 0], v)
+        c.set_gather_root(0)                                      # gather to one root (ncclSend / ncclRecv path; one rank: its own block)
+        c.allgather(3)
+        assert NP.array_equal(c.get_gathered(3, 1), g)
+        with pytest.raises(ValueError):
+            c.set_gather_root(1)                                  # not a rank of this communicator
+        c.set_gather_root(None)
         c.allgather_grad(3)
         gg = c.get_gathered_grad(3, 1)
         assert gg.shape == (3, 1, 3, 70, 32)
