@@ -662,11 +662,11 @@ def main():
                 out['other_kernels'] = {'error': repr(exc)}
             ctx.close()
             try:
-                out['e2e'] = e2e_observe(cfg, 3, device, memsave=(prec == _abi.PRISIM_FP32))
+                out['e2e'] = e2e_observe(cfg, 8, device, memsave=(prec == _abi.PRISIM_FP32))
             except Exception as exc:
                 out['e2e'] = {'value': None, 'error': repr(exc)}
             try:
-                out['e2e_host'] = e2e_observe(cfg, 3, device, memsave=(prec == _abi.PRISIM_FP32), to_host=True)
+                out['e2e_host'] = e2e_observe(cfg, 8, device, memsave=(prec == _abi.PRISIM_FP32), to_host=True)
                 if out['e2e'].get('ms_per_snapshot'):
                     out['e2e_host']['over_e2e'] = out['e2e_host']['ms_per_snapshot'] / out['e2e']['ms_per_snapshot']
             except Exception as exc:

@@ -9,7 +9,7 @@ import os
 import numpy as NP
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libprisim_hip.so')
+LIB_PATH = os.environ.get('PRISIM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libprisim_hip.so')      # PRISIM_HIP_LIB: A/B another build of the same ABI
 ABI_VERSION = 'prisim_hip 0.3 gfx950'       # prisim_hip_version(): bumped whenever a struct or a signature of include/prisim_hip.h changes
 
 PRISIM_OK = 0

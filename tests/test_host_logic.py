@@ -255,8 +255,7 @@ def test_committed_round_profiles_match_the_committed_sources():
     import json
     import bench
     paths = sorted(glob.glob(os.path.join(bench.ROOT, 'profiles', 'r03_*', 'pmc_summary.json')))
-    if not paths:
-        pytest.skip('round-3 profiles not taken yet')
+    assert len(paths) >= 8
     for path in paths:
         with open(path) as f:
             assert json.load(f).get('_csrc_hash') == bench.csrc_hash(), path
