@@ -1030,7 +1030,8 @@ static void fill_params(prisim_ctx* ctx, const Plan& pl, SkyvisParams& p) {
 }
 
 // Decide whether this packed fp32 taper pass runs in the split form and prepare its per-run, per-group flags.  Needs: the packed
-// 64-channel kernel without a source split, the grouped recurrence's channel-grid condition, sources in <= 8 runs of one size each,
+// 64-channel kernel, the grouped recurrence's channel-grid condition, sources in <= 8 runs of one size each (exactly one when the
+// sources are split into partial cubes),
 // in-loop exponents kappa (|b| f / c)^2 <= 30 with a per-step exponent <= 1/8 (fp32 range and the series of exp2m1_small), and --
 // per baseline group -- a bound on the parabola the uncorrected grouped form leaves: relative to a term it is at most
 // 16 kappa (b.s)^2 df^2 / c^2 with (b.s)^2 <= (H rho_s + Z |n_s|)^2 (H, Z: the group's largest horizontal length and |b_z|), so
@@ -1040,7 +1041,9 @@ static void fill_params(prisim_ctx* ctx, const Plan& pl, SkyvisParams& p) {
 static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams& p, std::vector<double>& run_bound) {
   ctx->timing.last_taper_split = 0;
   ctx->timing.last_split_uncorrected_groups = 0;
-  if (!(pl.pk && ctx->taper && pl.ct == 64 && pl.nsplit == 1 && p.taper_group && !ctx->kappa_runs.empty())) return false;
+  if (!(pl.pk && ctx->taper && pl.ct == 64 && p.taper_group && !ctx->kappa_runs.empty())) return false;
+  // with a source split (partial cubes, written once per split) only a sky that is ONE run: later runs could not add to the partials
+  if (pl.nsplit > 1 && !(ctx->kappa_runs.size() == 1 && ctx->kappa_runs[0].kappa > 0.0)) return false;
   if (const char* env = getenv("PRISIM_HIP_TAPER_SPLIT")) { if (atoi(env) == 0) return false; }      // A/B hook
   const double fmax = std::max(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
   const double fmin = std::min(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
@@ -1126,7 +1129,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
       const prisim_ctx::KappaRun& run = ctx->kappa_runs[r];
       SkyvisParams q = p;
       q.src_lo = run.lo; q.src_hi = run.hi;
-      q.src_per_split = round_up(run.hi - run.lo, pl.chunk);
+      if (pl.nsplit == 1) q.src_per_split = round_up(run.hi - run.lo, pl.chunk);       // (a split sky is one run: the plan's pieces stand)
       q.accumulate = launches > 0 ? 1 : 0;
       if (run.kappa > 0.0) {
         q.kappa0 = run.kappa;

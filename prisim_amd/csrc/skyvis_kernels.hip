@@ -968,8 +968,13 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           const float2 a = wbuf[bi * 17 + c];
           const int64_t bb = bw0 + bi;
           if (bb < p.nbl && k < p.nchan) {
-            if (!GRAD && !SPLIT && p.out_f32) {                    // complex64 partial of a source split: written once, no read-modify-write
-              reinterpret_cast<float2*>(p.out)[((size_t)split * p.nbl + (size_t)bb) * p.nchan + k] = a;
+            if (!GRAD && p.out_f32) {                              // complex64 partial of a source split: written once, no read-modify-write
+              float2 a2 = a;
+              if constexpr (SPLIT) {                               // every partial carries the flush factor (the sum of the partials is linear in it)
+                const float e = (float)escale(ke_lds[bi], k);
+                a2.x *= e; a2.y *= e;
+              }
+              reinterpret_cast<float2*>(p.out)[((size_t)split * p.nbl + (size_t)bb) * p.nchan + k] = a2;
             } else {
               double2* o = outr + (size_t)bb * p.nchan + k;
               double2 v = make_double2((double)a.x, (double)a.y);

@@ -224,6 +224,22 @@ def test_fp32_split_taper_runs_of_one_source_size(ctx, monkeypatch):
         assert ctx.timing()['last_taper_split'] == 0
         assert relerr(ctx.get_vis(), v_split, pb) <= 1.5e-6, name
         monkeypatch.delenv('PRISIM_HIP_TAPER_SPLIT')
+    # a sky that is ONE run also takes the split form when its sources are cut into partial cubes (baseline shards, config 4):
+    # every partial carries the flush factor
+    fw1 = NP.full(n_pt + n_df, 0.229)
+    ref1 = CO.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw1)
+    ctx.set_sky(dc, pb, pc, fwhm_deg=fw1)
+    for nsplit in (1, 2, 5):
+        ctx.set_tuning(64, 0, nsplit)
+        ctx.compute(precision=_abi.PRISIM_FP32)
+        tm = ctx.timing()
+        assert tm['last_taper_split'] == 1 and tm['last_nsplit'] == nsplit, tm
+        assert relerr(ctx.get_vis(), ref1, pb) <= TOL[_abi.PRISIM_FP32], nsplit
+    ctx.set_tuning(64, 0, 2)
+    ctx.set_sky(dc, pb, pc, fwhm_deg=fw)                                  # two runs + a source split: the unsplit kernel
+    ctx.compute(precision=_abi.PRISIM_FP32)
+    assert ctx.timing()['last_taper_split'] == 0
+    ctx.set_tuning(64, 0, 1)
     # sizes that vary from source to source: no runs, the unsplit kernel
     fw = rng.uniform(0.05, 0.4, n_pt + n_df)
     ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
