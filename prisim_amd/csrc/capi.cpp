@@ -129,8 +129,9 @@ struct prisim_ctx {
   // taper kernel walks such skies run by run in its split form.  Empty: sizes vary from source to source (or no taper).
   struct KappaRun { int64_t lo, hi; double kappa; };
   std::vector<KappaRun> kappa_runs;
-  DevBuf split_flags, moments;
-  std::vector<int32_t> split_host;
+  DevBuf split_flags, moments, grp_hz, split_count;      // grp_hz: [2][groups] (max horizontal length, max |b_z|) on the device
+  int32_t* h_split_count = nullptr;                      // pinned: uncorrected-group counts of the last split launch, per run (read after a sync)
+  int split_count_runs = 0;
   double dmax = 2.0;                  // max_s |s - s_pc| of the current sky
   std::vector<double> h_freqs;
   bool uniform = false;
@@ -496,7 +497,10 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
       const double t_compute = (double)nbl * (double)nchan * (double)nsrc / rate;
       const double t_split = 2.0 * (double)nbl * (double)nchan * (pl.f32 ? 8.0 : 16.0) / 3.0e12;
       const int64_t cap = std::max<int64_t>((slots + base - 1) / std::max<int64_t>(base, 1), (int64_t)(0.03 * t_compute / t_split));
-      if (want > 16) want = std::max<int64_t>(16, std::min<int64_t>(want, cap));       // (splits up to 16 keep the measured round rule)
+      // (splits up to 16 keep the measured round rule.)  Deeper ones: the sweep's optimum sits where the grid is ~1.5 rounds of
+      // resident blocks -- the second, half-empty round runs one block per CU, and a lone wave per SIMD issues packed FMAs at 3/4 of
+      // the full rate -- 2.53 ms at 16 splits against 3.28 at 19 and 2.75 at 10 or 24 on the config-4 share.
+      if (want > 16) want = std::max<int64_t>(16, std::min<int64_t>((3 * slots / 2 + base / 2) / std::max<int64_t>(base, 1), cap));
     }
     nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, 64));
   }
@@ -571,7 +575,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->dirs_prep, &ctx->dirs_c32, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
-                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
+                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->grp_hz, &ctx->split_count, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
   for (int i = 0; i < prisim_ctx::kTimingRing; ++i)
     for (hipEvent_t ev : {ctx->ev_c0[i], ctx->ev_c1[i], ctx->ev_k0[i], ctx->ev_k1[i]})
@@ -580,6 +584,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->ev_d0) (void)hipEventDestroy(ctx->ev_d0);
   if (ctx->ev_d1) (void)hipEventDestroy(ctx->ev_d1);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_split_count) (void)hipHostFree(ctx->h_split_count);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -631,6 +636,13 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
     const double hl = std::sqrt(x[b] * x[b] + y[b] * y[b]);
     if (hl > ctx->grp_maxh[g]) ctx->grp_maxh[g] = hl;
     if (std::fabs(z[b]) > ctx->grp_maxz[g]) ctx->grp_maxz[g] = std::fabs(z[b]);
+  }
+  {
+    const size_t ng = ctx->grp_maxh.size();
+    std::vector<double> hz(2 * ng);
+    for (size_t g = 0; g < ng; ++g) { hz[g] = ctx->grp_maxh[g]; hz[ng + g] = ctx->grp_maxz[g]; }
+    if ((rc = ensure(ctx, ctx->grp_hz, 2 * ng * sizeof(double)))) return rc;
+    HIPCHK(ctx, hipMemcpy(ctx->grp_hz.p, hz.data(), 2 * ng * sizeof(double), hipMemcpyHostToDevice));
   }
   ctx->nbl = nbl; ctx->nchan = nchan; ctx->nt_max = nt_max;
   // uniform channel grid?  f_k = f0 + k*df to within 1e-7 Hz (phase error <= 1e-13 cycles at 1 us delay)
@@ -1036,9 +1048,10 @@ static void fill_params(prisim_ctx* ctx, const Plan& pl, SkyvisParams& p) {
 // per baseline group -- a bound on the parabola the uncorrected grouped form leaves: relative to a term it is at most
 // 16 kappa (b.s)^2 df^2 / c^2 with (b.s)^2 <= (H rho_s + Z |n_s|)^2 (H, Z: the group's largest horizontal length and |b_z|), so
 // relative to sum|pbflux| it is at most 16 kappa df^2/c^2 (H^2 M2 + 2 H Z M11 + Z^2 M02) with the beam-weighted moments
-// M = sum_s |p_s| (.) / sum_s |p_s| of the run's sources, maximised over the channels (k_taper_moments: one pass over pbflux and one
-// small device-to-host copy per snapshot).  Groups above 2e-7 keep the correction (flag bit 1).
-static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams& p, std::vector<double>& run_bound) {
+// M = sum_s |p_s| (.) / sum_s |p_s| of the run's sources, maximised over the channels (k_taper_moments: one pass over pbflux;
+// k_split_flags turns them into the per-group flags ON THE DEVICE, so nothing is downloaded and a snapshot's launches never wait for
+// the previous snapshot's sky-sum).  Groups above 2e-7 keep the correction (flag bit 1).
+static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams& p) {
   ctx->timing.last_taper_split = 0;
   ctx->timing.last_split_uncorrected_groups = 0;
   if (!(pl.pk && ctx->taper && pl.ct == 64 && p.taper_group && !ctx->kappa_runs.empty())) return false;
@@ -1057,45 +1070,30 @@ static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams
   if (!(umax <= 30.0) || !(2.0 * umax * std::fabs(ctx->df) <= 0.125 * fmin)) return false;
   const int64_t nchan = ctx->nchan;
   const size_t nruns = ctx->kappa_runs.size();
+  const size_t ng = ctx->grp_maxh.size();
+  if ((size_t)pl.nbgroups != ng || !ctx->lift_flags.p) return false;
   if (ensure(ctx, ctx->moments, (size_t)4 * nchan * sizeof(double) * nruns) != PRISIM_OK) return false;
-  if (ensure(ctx, ctx->split_flags, nruns * (size_t)pl.nbgroups * sizeof(int32_t)) != PRISIM_OK) return false;
-  std::vector<double> mom((size_t)4 * nchan * nruns, 0.0);
-  for (size_t r = 0; r < nruns; ++r) {
-    const auto& run = ctx->kappa_runs[r];
-    if (run.kappa <= 0.0) continue;
-    if (launch_taper_moments((const double*)ctx->pb.p, (const double*)ctx->dirs.p, run.lo, run.hi, nchan,
-                             (double*)ctx->moments.p + r * (size_t)4 * nchan, ctx->stream) != hipSuccess) return false;
-  }
-  // (also waits for an upload that may still read split_host)
-  if (hipMemcpyAsync(mom.data(), ctx->moments.p, mom.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
-  ctx->split_host.assign(nruns * (size_t)pl.nbgroups, 0);
-  run_bound.assign(nruns, 0.0);
-  int uncorrected = 0;
-  for (size_t r = 0; r < nruns; ++r) {
-    const auto& run = ctx->kappa_runs[r];
-    if (run.kappa <= 0.0) continue;
-    const double* m = mom.data() + r * (size_t)4 * nchan;
-    double m2 = 0.0, m11 = 0.0, m02 = 0.0;
-    for (int64_t k = 0; k < nchan; ++k) {
-      const double s0 = m[k];
-      if (!(s0 > 0.0)) continue;
-      m2 = std::max(m2, m[nchan + k] / s0); m11 = std::max(m11, m[2 * nchan + k] / s0); m02 = std::max(m02, m[3 * nchan + k] / s0);
-    }
-    const double c16 = 16.0 * run.kappa * (ctx->df / kC) * (ctx->df / kC);
-    for (int g = 0; g < pl.nbgroups; ++g) {
-      const double H = ctx->grp_maxh[(size_t)g], Z = ctx->grp_maxz[(size_t)g];
-      const double bound = c16 * (H * H * m2 + 2.0 * H * Z * m11 + Z * Z * m02);
-      run_bound[r] = std::max(run_bound[r], bound);
-      int32_t fl = ctx->lift_host[(size_t)g] ? 1 : 0;          // bit 0: small step angle (same guarantee as the lifting flag)
-      if (!(bound <= 2.0e-7)) fl |= 2; else ++uncorrected;
-      ctx->split_host[r * (size_t)pl.nbgroups + (size_t)g] = fl;
-    }
-  }
-  if (hipMemcpyAsync(ctx->split_flags.p, ctx->split_host.data(), ctx->split_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) !=
-      hipSuccess)
+  if (ensure(ctx, ctx->split_flags, nruns * ng * sizeof(int32_t)) != PRISIM_OK) return false;
+  if (ensure(ctx, ctx->split_count, 8 * sizeof(int32_t)) != PRISIM_OK) return false;
+  if (!ctx->h_split_count && hipHostMalloc((void**)&ctx->h_split_count, 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+    ctx->h_split_count = nullptr;
     return false;
-  ctx->timing.last_split_uncorrected_groups = uncorrected;
+  }
+  // moments -> flags entirely on the stream: no download, so a snapshot's launches never wait for the previous snapshot's sky-sum
+  if (hipMemsetAsync(ctx->split_count.p, 0, 8 * sizeof(int32_t), ctx->stream) != hipSuccess) return false;
+  for (size_t r = 0; r < nruns; ++r) {
+    const auto& run = ctx->kappa_runs[r];
+    if (run.kappa <= 0.0) continue;
+    double* mom = (double*)ctx->moments.p + r * (size_t)4 * nchan;
+    if (launch_taper_moments((const double*)ctx->pb.p, (const double*)ctx->dirs.p, run.lo, run.hi, nchan, mom, ctx->stream) != hipSuccess) return false;
+    const double c16 = 16.0 * run.kappa * (ctx->df / kC) * (ctx->df / kC);
+    if (launch_split_flags(mom, nchan, (const double*)ctx->grp_hz.p, (const double*)ctx->grp_hz.p + ng, (const int32_t*)ctx->lift_flags.p, (int)ng, c16,
+                           2.0e-7, (int32_t*)ctx->split_flags.p + r * ng, (int32_t*)ctx->split_count.p + r, ctx->stream) != hipSuccess)
+      return false;
+  }
+  // the counts travel to pinned host memory behind the flags kernels; get_timing reads them after the compute's events have completed
+  if (hipMemcpyAsync(ctx->h_split_count, ctx->split_count.p, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+  ctx->split_count_runs = (int)nruns;
   return true;
 }
 
@@ -1120,8 +1118,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   p.out_f32 = part_f32 ? 1 : 0;
   // Packed fp32 taper on a sky whose sources come in a few runs of one size each (every HEALPix sky; point sources + diffuse): the
   // split form, run by run (skyvis_kernels.hip: TGROUP 2 / 3) -- size-0 runs take the plain (no-taper) bodies.
-  std::vector<double> run_bound;
-  const bool split = scale_comp < 0 && taper_split_plan(ctx, pl, p, run_bound);
+  const bool split = scale_comp < 0 && taper_split_plan(ctx, pl, p);
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
   if (split) {
     int launches = 0;
@@ -1375,6 +1372,12 @@ int prisim_hip_get_timing(prisim_ctx* ctx, prisim_timing* out, int reset) {
     float ms = 0.f;
     if (hipEventSynchronize(ctx->ev_d1) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev_d0, ctx->ev_d1) == hipSuccess)
       ctx->timing.last_delay_ms = ms;
+  }
+  if (ctx->timing.last_taper_split > 0 && ctx->h_split_count && ctx->ring_pending == 0) {
+    // (every compute's events have completed: the count copy queued before them has landed)
+    int n = 0;
+    for (int r = 0; r < ctx->split_count_runs && r < 8; ++r) n += ctx->h_split_count[r];
+    ctx->timing.last_split_uncorrected_groups = n;
   }
   *out = ctx->timing;
   if (reset) { ctx->timing.sum_kernel_ms = 0.0; ctx->timing.n_kernel = 0; }

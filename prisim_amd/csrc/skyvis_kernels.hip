@@ -866,12 +866,14 @@ __device__ __forceinline__ float exp2m1_small(float D) {
 //   small wherever the flux is ((b.s)^2 <= |b|^2 sin^2 theta), so the parabola the grouped form leaves inside a group --
 //   16 kappa (b.s)^2 df^2/c^2 at most, relative to the term -- can be BOUNDED from beam-weighted moments of the sky (the host does,
 //   per baseline group, capi.cpp:taper_split_plan) and, where that bound is below 2e-7 of sum|pbflux|, not corrected at all:
-//   3 = no parabola correction (6.375 packed instructions per pair of terms instead of 7.25), 2 = corrected (groups that fail the bound).
+//   3 = no parabola correction (6.375 packed instructions per pair of terms instead of 7.25), 2 = corrected (groups that fail the bound),
+//   4 = no correction and groups of 16 steps (the parabola is 4x larger: groups whose bound passes with that factor; 6.25 per pair).
 template <int CT, bool TAPER, bool LIFT, int TGROUP = 0, int REANCHOR = 0, bool GRAD = false>
 __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, unsigned char* flush_lds) {
   constexpr int NR = GRAD ? 4 : 1;                   // accumulator sets: V (+ G_l, G_m, G_n)
   constexpr bool SPLIT = TGROUP >= 2;
   constexpr bool PARABOLA = TGROUP == 1 || TGROUP == 2;
+  constexpr int GS = TGROUP == 4 ? 16 : 8;            // steps per group of the grouped forms
   static_assert(!(TAPER && LIFT), "the taper-folded recurrence is a scaled rotation: no lifting form");
   static_assert(TAPER || !TGROUP, "TGROUP is a taper variant");
   static_assert(!(SPLIT && GRAD), "the split taper form is built for the plain sky-sum");
@@ -1123,7 +1125,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
         }
         zre = zre * (f32x2){w_u0, w_d0};
         zim = zim * (f32x2){w_u0, w_d0};
-        const float th = (TGROUP ? 16.0f : 2.0f) * tC * 0.6931471805599453f;   // exp2(2C) - 1 (exp2(16C) - 1) = th + th^2/2 + ...
+        const float th = (TGROUP ? 2.0f * GS : 2.0f) * tC * 0.6931471805599453f;   // exp2(2C) - 1 (exp2(2 GS C) - 1) = th + th^2/2 + ...
         const float hm = __builtin_fmaf(0.5f * th, th, th);
         HM = (f32x2){hm, hm};
         if (PARABOLA) {
@@ -1192,11 +1194,11 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
               // chains.  So q_g - 1 =: e_g is carried instead (accurate to ~1e-8: series at the first group, e_{g+1} = e_g + h + e_g h
               // after that) and rho_g = r + r e_g is one FMA: what is left is the rounding of r and of rho itself.
               if (j == 0) {
-                EQ = (f32x2){exp2m1_small(__builtin_fmaf(tC, 8.f, tB)), exp2m1_small(__builtin_fmaf(tC, 10.f, -tB))};
-              } else if ((j % 8) == 0) {
-                EQ = pkfma(EQ, HM, EQ + HM);                 // mean ratio of the next group: (1 + e)(1 + h) - 1, h = exp2(16 C) - 1
+                EQ = (f32x2){exp2m1_small(__builtin_fmaf(tC, (float)GS, tB)), exp2m1_small(__builtin_fmaf(tC, (float)(GS + 2), -tB))};
+              } else if ((j % GS) == 0) {
+                EQ = pkfma(EQ, HM, EQ + HM);                 // mean ratio of the next group: (1 + e)(1 + h) - 1, h = exp2(2 GS C) - 1
               }
-              if ((j % 8) == 0) {
+              if ((j % GS) == 0) {
                 rho_re = pkfma(RR, EQ, RR);
                 rho_im = pkfma(RIC, EQ, RIC);
               }
@@ -1283,8 +1285,8 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
 }
 
 // Packed fp32 sky-sum of ONE source range whose sources share a size (kappa0): the split taper form (see skyvis_rec_f32pk_body).
-// split_flags[bg]: bit 0 = |step angle| <= pi/4 guaranteed for the group (no re-anchoring), bit 1 = the host could not bound the
-// uncorrected parabola below 2e-7 for this group: keep the correction.
+// split_flags[bg]: bit 0 = |step angle| <= pi/4 guaranteed for the group (no re-anchoring), bit 1 = the uncorrected parabola could not be
+// bounded below 2e-7 for this group: keep the correction, bit 2 = even four times the bound passes: groups of 16 steps.
 template <int CT>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void k_skyvis_rec_f32pk_split(const SkyvisParams p) {
@@ -1295,6 +1297,9 @@ void k_skyvis_rec_f32pk_split(const SkyvisParams p) {
   if (fl & 2) {
     if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 2, 0>(p, flush_lds);
     else skyvis_rec_f32pk_body<CT, true, false, 2, 2>(p, flush_lds);
+  } else if (fl & 4) {
+    if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 4, 0>(p, flush_lds);
+    else skyvis_rec_f32pk_body<CT, true, false, 4, 2>(p, flush_lds);
   } else {
     if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 3, 0>(p, flush_lds);
     else skyvis_rec_f32pk_body<CT, true, false, 3, 2>(p, flush_lds);
@@ -1330,6 +1335,48 @@ __global__ void k_taper_moments(const double* __restrict__ pb, const double* __r
       atomicAdd(out + (size_t)q * nchan + k, v);
     }
   }
+}
+
+// Per-group body choice of the split taper kernel from the moments, ON THE DEVICE (no host round trip: a download here would make every
+// snapshot's launch wait for the previous snapshot's sky-sum).  One block.  bound_g = c16 (H^2 M2 + 2 H Z M11 + Z^2 M02) with the
+// moments' per-channel ratios maximised over the channels; flags[g] = (small step angle ? 1 : 0) | (bound_g <= limit ? 0 : 2) |
+// (4 bound_g <= limit ? 4 : 0); *count += groups that run uncorrected.
+__global__ void k_split_flags(const double* __restrict__ mom /*[4][nchan]*/, int64_t nchan, const double* __restrict__ grp_h,
+                              const double* __restrict__ grp_z, const int32_t* __restrict__ lift_flags, int nbg, double c16, double limit,
+                              int32_t* __restrict__ flags, int32_t* __restrict__ count) {
+  __shared__ double sm[3][256];
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int64_t k = threadIdx.x; k < nchan; k += blockDim.x) {
+    const double s0 = mom[k];
+    if (s0 > 0.0) {
+      a = fmax(a, mom[nchan + k] / s0); b = fmax(b, mom[2 * nchan + k] / s0); c = fmax(c, mom[3 * nchan + k] / s0);
+    }
+  }
+  sm[0][threadIdx.x] = a; sm[1][threadIdx.x] = b; sm[2][threadIdx.x] = c;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      sm[0][threadIdx.x] = fmax(sm[0][threadIdx.x], sm[0][threadIdx.x + st]);
+      sm[1][threadIdx.x] = fmax(sm[1][threadIdx.x], sm[1][threadIdx.x + st]);
+      sm[2][threadIdx.x] = fmax(sm[2][threadIdx.x], sm[2][threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  const double m2 = sm[0][0], m11 = sm[1][0], m02 = sm[2][0];
+  int mine = 0;
+  for (int g = threadIdx.x; g < nbg; g += blockDim.x) {
+    const double H = grp_h[g], Z = grp_z[g];
+    const double bound = c16 * (H * H * m2 + 2.0 * H * Z * m11 + Z * Z * m02);
+    int32_t fl = lift_flags[g] ? 1 : 0;
+    if (!(bound <= limit)) {
+      fl |= 2;
+    } else {
+      ++mine;
+      if (4.0 * bound <= limit) fl |= 4;              // the parabola of a 16-step group is 4x that of an 8-step one
+    }
+    flags[g] = fl;
+  }
+  if (mine) atomicAdd(count, mine);
 }
 
 // fp32 visibility + baseline gradient in one pass (GRAD bodies of the packed kernel, 16-channel tiles, no source split)
@@ -1552,6 +1599,13 @@ hipError_t launch_taper_moments(const double* pb, const double* dirs, int64_t s_
   const int64_t gy = (s_hi - s_lo + 1023) / 1024;
   if (gy > 65535) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_taper_moments, dim3((unsigned)((nchan + 63) / 64), (unsigned)gy), dim3(256), 0, stream, pb, dirs, s_lo, s_hi, nchan, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_split_flags(const double* mom, int64_t nchan, const double* grp_h, const double* grp_z, const int32_t* lift_flags, int nbg,
+                              double c16, double limit, int32_t* flags, int32_t* count, hipStream_t stream) {
+  if (nbg <= 0 || nchan <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_split_flags, dim3(1), dim3(256), 0, stream, mom, nchan, grp_h, grp_z, lift_flags, nbg, c16, limit, flags, count);
   return hipGetLastError();
 }
 

@@ -41,6 +41,15 @@ def run_case(name, bl, ch, sky, beam_kind, precs, cands, reps=7):
             rows.append({'ct_asked': ct, 'nsplit_asked': ns, 'ct': t['last_chan_tile'], 'nsplit': t['last_nsplit'], 'kernel_us': k * 1e3, 'compute_us': c * 1e3,
                          'roofline_frac_kernel': terms * 10.0 / (k * 1e-3) / PEAK[prec], 'roofline_frac_compute': terms * 10.0 / (c * 1e-3) / PEAK[prec]})
         best = min(rows, key=lambda r: r['compute_us'])
+        if cands[0] == (0, 0) and len(rows) > 1:
+            # the planner's choice once more at the end: its first measurement also carries the clock ramp of a cold GPU
+            ctx.set_tuning(0, 0, 0)
+            km = []
+            for r in range(reps):
+                ctx.compute(precision=prec)
+                ctx.sync()
+                km.append(ctx.timing()['last_kernel_ms'])
+            rows[0]['kernel_us_remeasured_last'] = float(NP.median(km[2:])) * 1e3
         print(json.dumps({'case': name, 'precision': 'fp64' if prec == _abi.PRISIM_FP64 else 'fp32', 'terms': terms, 'planner': rows[0], 'best': best,
                           'all': rows}), flush=True)
     ctx.close()
