@@ -530,7 +530,8 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
         uid = rdzv.broadcast_bytes(_abi.Context.comm_unique_id() if rank == 0 else b'')
-    out = run(parms, infile_dir=os.path.dirname(os.path.abspath(args.infile)), rank=rank, world=world, device=local_rank, comm_uid=uid,
+    device = int(os.environ.get('PRISIM_DEVICE', local_rank))       # PRISIM_DEVICE: rehearsal hook (several ranks on the one GPU of a test box)
+    out = run(parms, infile_dir=os.path.dirname(os.path.abspath(args.infile)), rank=rank, world=world, device=device, comm_uid=uid,
               host_copy='root')                    # only rank 0 writes: the other ranks leave the gathered cube in HBM
     if rank == 0:
         path = save(out, parms, args.infile)
