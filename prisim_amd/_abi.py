@@ -116,7 +116,7 @@ class PrisimTiming(C.Structure):
                 ('n_kernel', C.c_int64), ('last_terms', C.c_int64), ('last_kernel_id', C.c_int32),
                 ('last_chan_tile', C.c_int32), ('last_nsplit', C.c_int32), ('last_lift_groups', C.c_int32),
                 ('last_taper_group', C.c_int32), ('last_delay_fused', C.c_int32), ('last_delay_ms', C.c_double),
-                ('last_taper_split', C.c_int32), ('last_split_uncorrected_groups', C.c_int32)]
+                ('last_taper_split', C.c_int32), ('last_split_uncorrected_groups', C.c_int32), ('last_culled_fraction', C.c_double)]
 
 
 class PrisimCommStats(C.Structure):

@@ -125,6 +125,14 @@ struct prisim_ctx {
   DevBuf blx, bly, blz, freqs, fsq, fsq_pairs, cube, grad, lift_flags;
   std::vector<double> grp_maxlen;     // max |b| per group of kBlockThreads baselines (lifting-rotation guarantee)
   std::vector<double> grp_maxh, grp_maxz;   // max horizontal length / max |b_z| per group (bound of the split taper's parabola)
+  std::vector<double> grp_minlen;           // min |b| per group (taper culling)
+  // Taper culling: cull_first[prec][run][group] = first source of the run that group still has to sum (device, int32); the sources before
+  // it contribute < exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux| to every baseline of the group.  cull_frac[prec]: culled share of
+  // the snapshot's terms; cull_any[prec]: anything culled at all.
+  DevBuf cull_first;
+  bool cull_any[2] = {false, false};
+  double cull_frac[2] = {0.0, 0.0};
+  int cull_nruns = 0;
   // runs of consecutive sources with one source size kappa (HEALPix skies: one run; point sources + diffuse: two): the packed fp32
   // taper kernel walks such skies run by run in its split form.  Empty: sizes vary from source to source (or no taper).
   struct KappaRun { int64_t lo, hi; double kappa; };
@@ -575,7 +583,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->dirs_prep, &ctx->dirs_c32, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
-                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->grp_hz, &ctx->split_count, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
+                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->grp_hz, &ctx->split_count, &ctx->cull_first, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
   for (int i = 0; i < prisim_ctx::kTimingRing; ++i)
     for (hipEvent_t ev : {ctx->ev_c0[i], ctx->ev_c1[i], ctx->ev_k0[i], ctx->ev_k1[i]})
@@ -628,11 +636,13 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   ctx->grp_maxlen.assign((size_t)((nbl + kBlockThreads - 1) / kBlockThreads), 0.0);
   ctx->grp_maxh.assign(ctx->grp_maxlen.size(), 0.0);
   ctx->grp_maxz.assign(ctx->grp_maxlen.size(), 0.0);
+  ctx->grp_minlen.assign(ctx->grp_maxlen.size(), 1e300);
   ctx->lift_key_k = -1.0;                                  // the cached lifting flags belong to the previous array
   for (int64_t b = 0; b < nbl; ++b) {
     const double len = std::sqrt(x[b] * x[b] + y[b] * y[b] + z[b] * z[b]);
     const size_t g = (size_t)(b / kBlockThreads);
     if (len > ctx->grp_maxlen[g]) ctx->grp_maxlen[g] = len;
+    if (len < ctx->grp_minlen[g]) ctx->grp_minlen[g] = len;
     const double hl = std::sqrt(x[b] * x[b] + y[b] * y[b]);
     if (hl > ctx->grp_maxh[g]) ctx->grp_maxh[g] = hl;
     if (std::fabs(z[b]) > ctx->grp_maxz[g]) ctx->grp_maxz[g] = std::fabs(z[b]);
@@ -674,8 +684,9 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
   for (int i = 0; i < 3; ++i)
     if (!std::isfinite(pc_dircos[i])) return fail(ctx, PRISIM_EINVAL, "non-finite pc_dircos");
   const size_t d4_bytes = (size_t)std::max<int64_t>(nsrc, 1) * 4 * sizeof(double);
+  const size_t cull_bytes = 2 * 8 * ctx->grp_maxlen.size() * sizeof(int32_t) + 512;      // [precision][<= 8 runs][groups]
   int rc;
-  if ((rc = stage_begin(ctx, d4_bytes + extra_stage_bytes + 4096))) return rc;
+  if ((rc = stage_begin(ctx, d4_bytes + extra_stage_bytes + cull_bytes + 4096))) return rc;
   double* d4 = (double*)stage_alloc(ctx, d4_bytes);
   if (!d4) return fail(ctx, PRISIM_EINTERNAL, "staging area too small");
   d4[0] = d4[1] = d4[2] = d4[3] = 0.0;
@@ -715,6 +726,58 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
   }
   if ((rc = ensure(ctx, ctx->dirs, d4_bytes))) return rc;
   HIPCHK(ctx, stage_send(ctx, ctx->dirs.p, d4, d4_bytes));
+  // Taper culling.  w = exp(-kappa (|b|^2 - (b.s)^2) f^2/c^2) and (b.s)^2 <= (H rho_s + Z |n_s|)^2, so for every baseline of a group
+  // (shortest length Lmin, largest horizontal length H, largest |b_z| Z) and every channel the exponent of source s is at least
+  //   x_s = kappa_s (Lmin^2 - (H rho_s + Z |n_s|)^2) fmin^2/c^2 .
+  // The leading sources of a run whose x_s >= T contribute together at most exp(-T) sum|pbflux|: T = 18 (1.5e-8) for fp32 requests,
+  // 28 (7e-13) for fp64 -- far inside the tolerances (5e-6 / 1e-11) -- and the kernels start the group's source loop behind them.
+  // Long baselines over coarse diffuse pixels (config 4: MWA to 2.5 km, nside 64) shed the sources nearest the zenith this way when
+  // the caller lists a run's sources by decreasing altitude (InterferometerArray.observe does); unordered skies just cull little.
+  ctx->cull_any[0] = ctx->cull_any[1] = false;
+  ctx->cull_frac[0] = ctx->cull_frac[1] = 0.0;
+  ctx->cull_nruns = 0;
+  {
+    const char* env = getenv("PRISIM_HIP_TAPER_CULL");
+    const size_t ng = ctx->grp_maxlen.size();
+    const size_t nruns = ctx->kappa_runs.size();
+    if (nruns > 0 && ng > 0 && !(env && atoi(env) == 0)) {
+      const double fmin = std::min(std::fabs(ctx->h_freqs.front()), std::fabs(ctx->h_freqs.back()));
+      const double fc2 = (fmin / kC) * (fmin / kC);
+      int32_t* tab = (int32_t*)stage_alloc(ctx, 2 * nruns * ng * sizeof(int32_t));
+      if (tab) {
+        const double thr[2] = {28.0, 18.0};                      // index = precision (PRISIM_FP64 = 0, PRISIM_FP32 = 1)
+        double culled[2] = {0.0, 0.0};
+        for (int pr = 0; pr < 2; ++pr)
+          for (size_t r = 0; r < nruns; ++r) {
+            const auto& run = ctx->kappa_runs[r];
+            for (size_t g = 0; g < ng; ++g) {
+              int64_t sfirst = run.lo;
+              if (run.kappa > 0.0 && run.kappa * ctx->grp_minlen[g] * ctx->grp_minlen[g] * fc2 >= thr[pr]) {
+                const double L2 = ctx->grp_minlen[g] * ctx->grp_minlen[g], H = ctx->grp_maxh[g], Z = ctx->grp_maxz[g];
+                while (sfirst < run.hi) {
+                  const double l = d4[4 * sfirst], m = d4[4 * sfirst + 1], n = d4[4 * sfirst + 2];
+                  const double proj = H * std::sqrt(l * l + m * m) + Z * std::fabs(n);
+                  if (!(run.kappa * (L2 - proj * proj) * fc2 >= thr[pr])) break;
+                  ++sfirst;
+                }
+              }
+              tab[(pr * nruns + r) * ng + g] = (int32_t)sfirst;
+              if (sfirst > run.lo) {
+                ctx->cull_any[pr] = true;
+                const int64_t nb = std::min<int64_t>(kBlockThreads, ctx->nbl - (int64_t)g * kBlockThreads);
+                culled[pr] += (double)(sfirst - run.lo) * (double)nb;
+              }
+            }
+          }
+        if (ctx->cull_any[0] || ctx->cull_any[1]) {
+          if ((rc = ensure(ctx, ctx->cull_first, 2 * nruns * ng * sizeof(int32_t)))) return rc;
+          HIPCHK(ctx, stage_send(ctx, ctx->cull_first.p, tab, 2 * nruns * ng * sizeof(int32_t)));
+          ctx->cull_nruns = (int)nruns;
+          for (int pr = 0; pr < 2; ++pr) ctx->cull_frac[pr] = culled[pr] / ((double)nsrc * (double)ctx->nbl);
+        }
+      }
+    }
+  }
   ctx->nsrc = nsrc;
   ctx->dmax = std::sqrt(dmax2);
   ctx->taper = fwhm_deg != nullptr;
@@ -1031,7 +1094,7 @@ static void fill_params(prisim_ctx* ctx, const Plan& pl, SkyvisParams& p) {
     if (v > 0 && v < (1L << 30)) p.flush_src = (int32_t)v;
   }
   p.scale_comp = -1;
-  p.src_lo = 0; p.src_hi = ctx->nsrc; p.accumulate = 0; p.kappa0 = 0.0; p.split_flags = nullptr;
+  p.src_lo = 0; p.src_hi = ctx->nsrc; p.accumulate = 0; p.kappa0 = 0.0; p.split_flags = nullptr; p.src_first = nullptr;
   {
     // grouped taper recurrence (skyvis_kernels.hip): second-order residual (11.09 (df/f)^2)^2 * 0.565 <= 1e-8 of sum|pbflux|
     const double fmin = std::min(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
@@ -1119,6 +1182,14 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   // Packed fp32 taper on a sky whose sources come in a few runs of one size each (every HEALPix sky; point sources + diffuse): the
   // split form, run by run (skyvis_kernels.hip: TGROUP 2 / 3) -- size-0 runs take the plain (no-taper) bodies.
   const bool split = scale_comp < 0 && taper_split_plan(ctx, pl, p);
+  // taper culling: per baseline group the first source it still has to sum (tables staged by set_sky_*); a launch over the whole sky
+  // can only skip the leading sources of the FIRST run
+  const int cpr = pl.f32 ? 1 : 0;
+  const bool cull = ctx->taper && ctx->cull_any[cpr] && ctx->cull_first.p && ctx->cull_nruns == (int)ctx->kappa_runs.size() &&
+                    (size_t)pl.nbgroups == ctx->grp_maxlen.size();
+  auto cull_table = [&](size_t r) { return (const int32_t*)ctx->cull_first.p + ((size_t)cpr * ctx->cull_nruns + r) * (size_t)pl.nbgroups; };
+  if (cull && !split) p.src_first = cull_table(0);
+  ctx->timing.last_culled_fraction = cull ? ctx->cull_frac[cpr] : 0.0;
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
   if (split) {
     int launches = 0;
@@ -1130,6 +1201,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
       q.accumulate = launches > 0 ? 1 : 0;
       if (run.kappa > 0.0) {
         q.kappa0 = run.kappa;
+        if (cull) q.src_first = cull_table(r);
         q.split_flags = (const int32_t*)ctx->split_flags.p + r * (size_t)pl.nbgroups;
         HIPCHK(ctx, launch_skyvis_rec_f32pk_split(q, pl.ct, ctx->stream));
       } else {
@@ -1222,6 +1294,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   ctx->timing.last_taper_group = 0;
   ctx->timing.last_taper_split = 0;
   ctx->timing.last_split_uncorrected_groups = 0;
+  ctx->timing.last_culled_fraction = 0.0;
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE) {
     const size_t pbytes = (size_t)pl.ntiles * pl.nsrc_pad * pl.ct * (pl.f32 ? 4 : 8);
     if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;

@@ -51,6 +51,9 @@ struct SkyvisParams {
   // split taper form (k_skyvis_rec_f32pk_split): one source size for the whole range
   double kappa0;             // ln2 (2 sin(fwhm/2))^2 of every source in [src_lo, src_hi)
   const int32_t* split_flags;// [nbgroups] bit 0: small step angle, bit 1: keep the parabola correction
+  // taper culling (recurrence kernels with the taper): the sources [range start, src_first[bg]) contribute less than the precision's
+  // cull threshold to every baseline of group bg and are skipped; nullptr = none
+  const int32_t* src_first;
 };
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);

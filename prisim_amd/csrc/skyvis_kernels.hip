@@ -323,9 +323,13 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   const int tile = slab % p.ntiles;
   const int split = slab / p.ntiles;
 
-  const int64_t s_begin = (int64_t)split * p.src_per_split;
+  int64_t s_begin = (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
   if (s_end > p.nsrc) s_end = p.nsrc;
+  if (TAPER && p.src_first != nullptr) {           // taper culling: the group's leading sources are provably below the tolerance (capi.cpp)
+    const int64_t f = p.src_first[bg];
+    if (f > s_begin) s_begin = f;
+  }
 
   const int tid = threadIdx.x;
   const int64_t b_raw = (int64_t)bg * kBlockThreads + tid;
@@ -890,9 +894,13 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   const int split = slab / p.ntiles;
 
   // sources [src_lo, src_hi) of the sky (the whole sky unless the host walks it in ranges of one source size), cut into nsplit pieces
-  const int64_t s_begin = p.src_lo + (int64_t)split * p.src_per_split;
+  int64_t s_begin = p.src_lo + (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
   if (s_end > p.src_hi) s_end = p.src_hi;
+  if (TAPER && p.src_first != nullptr) {           // taper culling: the group's leading sources are provably below the tolerance (capi.cpp)
+    const int64_t f = p.src_first[bg];
+    if (f > s_begin) s_begin = f;
+  }
 
   const int tid = threadIdx.x;
   const int64_t b_raw = (int64_t)bg * kBlockThreads + tid;

@@ -374,6 +374,25 @@ class InterferometerArray(object):
         self._stage, self._host_cube = bool(host_staging), None
         self._restore_external_beam()
 
+    def _cull_order(self, alt_deg, fwhm_deg):
+        """Permutation that lists every run of sources of one size by decreasing altitude, or None when nothing could be culled
+        (no source sizes, short baselines, more than 8 runs, or the sources already are in that order)."""
+        if fwhm_deg is None or fwhm_deg.size < 2:
+            return None
+        kmax = NP.log(2.0) * (2.0 * NP.sin(0.5 * NP.radians(float(NP.max(fwhm_deg))))) ** 2
+        lmax = float(NP.max(self.baseline_lengths)) if self.baseline_lengths.size else 0.0
+        fmin = float(NP.min(NP.abs(self.channels)))
+        if not kmax * (lmax * fmin / C_LIGHT) ** 2 >= 18.0:
+            return None
+        cuts = NP.flatnonzero(fwhm_deg[1:] != fwhm_deg[:-1]) + 1
+        if cuts.size >= 8:
+            return None
+        order = NP.arange(fwhm_deg.size)
+        bounds = NP.concatenate(([0], cuts, [fwhm_deg.size]))
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            order[lo:hi] = lo + NP.argsort(-alt_deg[lo:hi], kind='stable')
+        return None if NP.array_equal(order, NP.arange(order.size)) else order
+
     def _stage_download(self, slot, dtype):
         """Enqueue the asynchronous download of device slot `slot` into the pinned host cube; False when staging is off / unavailable."""
         if not getattr(self, '_stage', False):
@@ -697,15 +716,27 @@ class InterferometerArray(object):
                 src_shape = NP.asarray(src_shape, dtype=NP.float64)
                 fwhm = NP.sqrt(src_shape[m2, 0] * src_shape[m2, 1])
             prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
+            # Upload order.  The sum over sources does not care about their order, the taper culling of the library does: for every
+            # baseline group it skips the LEADING sources of a run of one source size whose weight is provably below the tolerance,
+            # and those are the sources nearest the zenith (long baselines resolve them out: b_perp ~ |b|).  So when anything can be
+            # culled at all -- kappa_max (|b|_max f_min / c)^2 >= 18 -- each run is listed by decreasing altitude.  Class state
+            # (obs_catalog_indices, geometric_delays) keeps the catalog order.
+            up = self._cull_order(skypos_altaz_roi[:, 0], fwhm)
+            dircos_up = dircos_roi
+            if up is not None:
+                dircos_up, fwhm = dircos_roi[up], fwhm[up]
+                flux_ref, spindex = (flux_ref[up], spindex[up]) if flux_ref is not None else (None, None)
+                fluxes = fluxes[up] if fluxes is not None else None
+                pb = pb[up] if pb is not None else None
             if pb is not None:
                 # supplied beam (ROI_parameters path): pbfluxes = pb * fluxes on the device (:6254)
-                self._ctx.set_sky(dircos_roi, pb, pc_dircos, fwhm_deg=fwhm, fluxes=fluxes)
+                self._ctx.set_sky(dircos_up, pb, pc_dircos, fwhm_deg=fwhm, fluxes=fluxes)
             elif getattr(self, '_extbeam', None) is not None:
-                self._ctx.set_sky_external_analytic(dircos_roi, flux_ref, spindex, ref_freq, pc_dircos, fwhm_deg=fwhm, flux_spectrum=fluxes)
+                self._ctx.set_sky_external_analytic(dircos_up, flux_ref, spindex, ref_freq, pc_dircos, fwhm_deg=fwhm, flux_spectrum=fluxes)
             else:
                 kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz,
                                                           first_frequency_hz=float(self.channels[0]))                   # :6252
-                self._ctx.set_sky_analytic(dircos_roi, flux_ref, spindex, ref_freq, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,
+                self._ctx.set_sky_analytic(dircos_up, flux_ref, spindex, ref_freq, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,
                                            flux_spectrum=fluxes, ext=ext)
             slot = self.n_acc if self.n_acc < self._reserved else 0
             for i, snap in enumerate(self._cube):                       # a snapshot still parked in the slot about to be overwritten

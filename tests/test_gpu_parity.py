@@ -249,6 +249,45 @@ def test_fp32_split_taper_runs_of_one_source_size(ctx, monkeypatch):
     ctx.set_tuning(0, 0, 0)
 
 
+def test_taper_culling_skips_only_what_is_below_the_tolerance(ctx, monkeypatch):
+    """Long baselines resolve out diffuse pixels: w = exp(-kappa |b_perp|^2 f^2/c^2) underflows for the sources nearest the zenith.  With
+    a run's sources listed by decreasing altitude the library starts every baseline group's source loop behind the leading sources whose
+    summed weight is below exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux|.  MWA-like baselines (to 2.5 km, sorted by length like the
+    driver's) over degree-size pixels: a good share of the (source, baseline) pairs goes, the result stays inside the tolerances against
+    the oracle that sums everything, and equals the unculled result to the cull bound."""
+    rng = NP.random.default_rng(91)
+    nbl, nchan, nsrc = 1024, 64, 1500
+    xy = rng.normal(0.0, 420.0, size=(nbl, 2))
+    bl = NP.hstack((xy, rng.normal(0.0, 0.5, size=(nbl, 1))))
+    bl = bl[NP.argsort(NP.sqrt(NP.sum(bl ** 2, axis=1)))]
+    ch = 170e6 + NP.arange(nchan) * 40e3
+    alt = NP.sort(NP.degrees(NP.arcsin(rng.uniform(NP.sin(NP.radians(3.0)), 1.0, nsrc))))[::-1]       # decreasing altitude
+    dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, nsrc)), axis=1))
+    pb = rng.uniform(0.5, 10.0, size=(nsrc, 1)) * rng.uniform(0.5, 1.0, size=(nsrc, nchan))
+    fw = NP.full(nsrc, 0.916)                                                                          # nside-64 pixels
+    pc = NP.array([0.0, 0.0, 1.0])
+    ref = CO.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw)
+    ctx.set_array(bl, ch)
+    ctx.set_tuning(0, 0, 0)
+    for prec, bound in ((_abi.PRISIM_FP32, 2e-8), (_abi.PRISIM_FP64, 1e-12)):
+        res = {}
+        for cull in ('1', '0'):
+            monkeypatch.setenv('PRISIM_HIP_TAPER_CULL', cull)
+            ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
+            ctx.compute(precision=prec)
+            res[cull] = ctx.get_vis()
+            frac = ctx.timing()['last_culled_fraction']
+            assert (frac > 0.10) if cull == '1' else (frac == 0.0), (prec, cull, frac)
+            assert relerr(res[cull], ref, pb) <= TOL[prec], (prec, cull)
+        assert relerr(res['1'], res['0'], pb) <= bound, prec
+    monkeypatch.delenv('PRISIM_HIP_TAPER_CULL')
+    # sources in no particular order: little or nothing to skip, same answer
+    perm = rng.permutation(nsrc)
+    ctx.set_sky(dc[perm], pb[perm], pc, fwhm_deg=fw)
+    ctx.compute(precision=_abi.PRISIM_FP32)
+    assert ctx.timing()['last_culled_fraction'] < 0.05 and relerr(ctx.get_vis(), ref, pb) <= TOL[_abi.PRISIM_FP32]
+
+
 @pytest.mark.parametrize('taper', [False, True])
 def test_fp32_single_source_worst_case_per_term(ctx, taper):
     """One source, so nothing averages: the error of every (baseline, channel) term against the fp64 oracle must stay inside the

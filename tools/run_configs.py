@@ -35,6 +35,11 @@ def run(cfg, ctx, n_acc, spot=6, delay=False, cpu=False):
         else:
             dc, fr, sp, fw = sky['dircos'], sky['flux_ref'], sky['spindex'], sky['fwhm_deg']
         fwhm = fw if cfg['taper'] else None
+        if cfg['taper']:
+            # what InterferometerArray.observe() does before it uploads a sky with source sizes: by decreasing altitude, so that the
+            # library's taper culling can skip the zenith-most sources of long-baseline groups (their weight underflows)
+            order = NP.argsort(-dc[:, 2], kind='stable')
+            dc, fr, sp, fwhm = dc[order], fr[order], sp[order], fwhm[order]
         if cfg['beam'] == 'external':
             ctx.set_sky_external_analytic(dc, fr, sp, sky['ref_freq'], zen, fwhm_deg=fwhm)
         else:
@@ -60,6 +65,9 @@ def run(cfg, ctx, n_acc, spot=6, delay=False, cpu=False):
             else:
                 dc, fr, sp, fw = sky['dircos'], sky['flux_ref'], sky['spindex'], sky['fwhm_deg']
             fwhm = fw if cfg['taper'] else None
+            if cfg['taper']:
+                order = NP.argsort(-dc[:, 2], kind='stable')
+                dc, fr, sp, fwhm = dc[order], fr[order], sp[order], fwhm[order]
             if cfg['beam'] == 'external':
                 ctx.set_sky_external_analytic(dc, fr, sp, sky['ref_freq'], zen, fwhm_deg=fwhm)
             else:
@@ -77,7 +85,8 @@ def run(cfg, ctx, n_acc, spot=6, delay=False, cpu=False):
            'n_acc': n_acc, 'precision': cfg['precision'], 'taper': bool(cfg['taper']), 'terms': float(terms),
            'kernel_ms_total': kern_ms, 'terms_per_s_kernel': terms / (kern_ms * 1e-3) if kern_ms > 0 else None,
            'wall_s_incl_sky_staging_and_spot_check': wall, 'wall_s_incl_host_geometry_and_sky_staging': wall_nospot if spot else wall, 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
-           'parity_spot_max_err_rel_sumflux': worst, 'tolerance': 5e-6 if cfg['precision'] == 'fp32' else 1e-11}
+           'parity_spot_max_err_rel_sumflux': worst, 'tolerance': 5e-6 if cfg['precision'] == 'fp32' else 1e-11,
+           'taper_split_runs': tm.get('last_taper_split', 0), 'taper_culled_fraction_last_snapshot': tm.get('last_culled_fraction', 0.0)}
     if cpu and n_acc == 1 and terms <= 3e8:
         # the CPU beside it on the same box: the numpy restatement of the reference's statements, one process, and the
         # C/OpenMP port on every host core -- whole configuration, and the GPU result checked against both
