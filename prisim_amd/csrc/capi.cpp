@@ -125,7 +125,7 @@ struct prisim_ctx {
   DevBuf blx, bly, blz, freqs, fsq, fsq_pairs, cube, grad, lift_flags;
   std::vector<double> grp_maxlen;     // max |b| per group of kBlockThreads baselines (lifting-rotation guarantee)
   std::vector<double> grp_maxh, grp_maxz;   // max horizontal length / max |b_z| per group (bound of the split taper's parabola)
-  std::vector<double> grp_minlen;           // min |b| per group (taper culling)
+  std::vector<double> grp_minh;             // min horizontal length per group (taper culling)
   // Taper culling: cull_first[prec][run][group] = first source of the run that group still has to sum (device, int32); the sources before
   // it contribute < exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux| to every baseline of the group.  cull_frac[prec]: culled share of
   // the snapshot's terms; cull_any[prec]: anything culled at all.
@@ -636,14 +636,14 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   ctx->grp_maxlen.assign((size_t)((nbl + kBlockThreads - 1) / kBlockThreads), 0.0);
   ctx->grp_maxh.assign(ctx->grp_maxlen.size(), 0.0);
   ctx->grp_maxz.assign(ctx->grp_maxlen.size(), 0.0);
-  ctx->grp_minlen.assign(ctx->grp_maxlen.size(), 1e300);
+  ctx->grp_minh.assign(ctx->grp_maxlen.size(), 1e300);
   ctx->lift_key_k = -1.0;                                  // the cached lifting flags belong to the previous array
   for (int64_t b = 0; b < nbl; ++b) {
     const double len = std::sqrt(x[b] * x[b] + y[b] * y[b] + z[b] * z[b]);
     const size_t g = (size_t)(b / kBlockThreads);
     if (len > ctx->grp_maxlen[g]) ctx->grp_maxlen[g] = len;
-    if (len < ctx->grp_minlen[g]) ctx->grp_minlen[g] = len;
     const double hl = std::sqrt(x[b] * x[b] + y[b] * y[b]);
+    if (hl < ctx->grp_minh[g]) ctx->grp_minh[g] = hl;
     if (hl > ctx->grp_maxh[g]) ctx->grp_maxh[g] = hl;
     if (std::fabs(z[b]) > ctx->grp_maxz[g]) ctx->grp_maxz[g] = std::fabs(z[b]);
   }
@@ -726,9 +726,11 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
   }
   if ((rc = ensure(ctx, ctx->dirs, d4_bytes))) return rc;
   HIPCHK(ctx, stage_send(ctx, ctx->dirs.p, d4, d4_bytes));
-  // Taper culling.  w = exp(-kappa (|b|^2 - (b.s)^2) f^2/c^2) and (b.s)^2 <= (H rho_s + Z |n_s|)^2, so for every baseline of a group
-  // (shortest length Lmin, largest horizontal length H, largest |b_z| Z) and every channel the exponent of source s is at least
-  //   x_s = kappa_s (Lmin^2 - (H rho_s + Z |n_s|)^2) fmin^2/c^2 .
+  // Taper culling.  w = exp(-kappa (|b|^2 - (b.s)^2) f^2/c^2), and for a baseline of horizontal length h and height z and a source at
+  // (rho, n) = (sin, cos) of the zenith angle, (b.s)^2 <= (h rho + |z| |n|)^2, i.e. |b|^2 - (b.s)^2 >= (h |n| - |z| rho)^2 when
+  // h |n| >= |z| rho (the identity h^2 + z^2 - (h rho + |z||n|)^2 = (h|n| - |z| rho)^2).  So for every baseline of a group (smallest
+  // horizontal length Hmin, largest |b_z| Z) and every channel the exponent of source s is at least
+  //   x_s = kappa_s max(Hmin |n_s| - Z rho_s, 0)^2 fmin^2/c^2 .
   // The leading sources of a run whose x_s >= T contribute together at most exp(-T) sum|pbflux|: T = 18 (1.5e-8) for fp32 requests,
   // 28 (7e-13) for fp64 -- far inside the tolerances (5e-6 / 1e-11) -- and the kernels start the group's source loop behind them.
   // Long baselines over coarse diffuse pixels (config 4: MWA to 2.5 km, nside 64) shed the sources nearest the zenith this way when
@@ -752,12 +754,12 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
             const auto& run = ctx->kappa_runs[r];
             for (size_t g = 0; g < ng; ++g) {
               int64_t sfirst = run.lo;
-              if (run.kappa > 0.0 && run.kappa * ctx->grp_minlen[g] * ctx->grp_minlen[g] * fc2 >= thr[pr]) {
-                const double L2 = ctx->grp_minlen[g] * ctx->grp_minlen[g], H = ctx->grp_maxh[g], Z = ctx->grp_maxz[g];
+              if (run.kappa > 0.0 && run.kappa * ctx->grp_minh[g] * ctx->grp_minh[g] * fc2 >= thr[pr]) {
+                const double H = ctx->grp_minh[g], Z = ctx->grp_maxz[g];
                 while (sfirst < run.hi) {
                   const double l = d4[4 * sfirst], m = d4[4 * sfirst + 1], n = d4[4 * sfirst + 2];
-                  const double proj = H * std::sqrt(l * l + m * m) + Z * std::fabs(n);
-                  if (!(run.kappa * (L2 - proj * proj) * fc2 >= thr[pr])) break;
+                  const double perp = H * std::fabs(n) - Z * std::sqrt(l * l + m * m);
+                  if (!(perp > 0.0 && run.kappa * perp * perp * fc2 >= thr[pr])) break;
                   ++sfirst;
                 }
               }

@@ -326,9 +326,16 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   int64_t s_begin = (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
   if (s_end > p.nsrc) s_end = p.nsrc;
-  if (TAPER && p.src_first != nullptr) {           // taper culling: the group's leading sources are provably below the tolerance (capi.cpp)
+  if (TAPER && p.src_first != nullptr) {
+    // taper culling: the group's leading sources are provably below the tolerance (capi.cpp).  What is left is cut into nsplit EQUAL
+    // pieces again, so that every split of the group shrinks alike (the XCD map deals whole slabs to XCDs: skipping only the first
+    // split's sources would idle one XCD and leave the launch as long as before)
     const int64_t f = p.src_first[bg];
-    if (f > s_begin) s_begin = f;
+    if (f > 0) {
+      const int64_t per = (p.nsrc - f + p.nsplit - 1) / p.nsplit;
+      s_begin = f + (int64_t)split * per;
+      s_end = s_begin + per < p.nsrc ? s_begin + per : p.nsrc;
+    }
   }
 
   const int tid = threadIdx.x;
@@ -897,9 +904,16 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   int64_t s_begin = p.src_lo + (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
   if (s_end > p.src_hi) s_end = p.src_hi;
-  if (TAPER && p.src_first != nullptr) {           // taper culling: the group's leading sources are provably below the tolerance (capi.cpp)
+  if (TAPER && p.src_first != nullptr) {
+    // taper culling: the group's leading sources are provably below the tolerance (capi.cpp).  What is left is cut into nsplit EQUAL
+    // pieces again, so that every split of the group shrinks alike (the XCD map deals whole slabs to XCDs: skipping only the first
+    // split's sources would idle one XCD and leave the launch as long as before)
     const int64_t f = p.src_first[bg];
-    if (f > s_begin) s_begin = f;
+    if (f > p.src_lo) {
+      const int64_t per = (p.src_hi - f + p.nsplit - 1) / p.nsplit;
+      s_begin = f + (int64_t)split * per;
+      s_end = s_begin + per < p.src_hi ? s_begin + per : p.src_hi;
+    }
   }
 
   const int tid = threadIdx.x;
