@@ -257,7 +257,7 @@ def test_taper_culling_skips_only_what_is_below_the_tolerance(ctx, monkeypatch):
     the oracle that sums everything, and equals the unculled result to the cull bound."""
     rng = NP.random.default_rng(91)
     nbl, nchan, nsrc = 1024, 64, 1500
-    xy = rng.normal(0.0, 420.0, size=(nbl, 2))
+    xy = rng.normal(0.0, 800.0, size=(nbl, 2))
     bl = NP.hstack((xy, rng.normal(0.0, 0.5, size=(nbl, 1))))
     bl = bl[NP.argsort(NP.sqrt(NP.sum(bl ** 2, axis=1)))]
     ch = 170e6 + NP.arange(nchan) * 40e3
@@ -277,7 +277,7 @@ def test_taper_culling_skips_only_what_is_below_the_tolerance(ctx, monkeypatch):
             ctx.compute(precision=prec)
             res[cull] = ctx.get_vis()
             frac = ctx.timing()['last_culled_fraction']
-            assert (frac > 0.10) if cull == '1' else (frac == 0.0), (prec, cull, frac)
+            assert (frac > (0.20 if prec == _abi.PRISIM_FP32 else 0.12)) if cull == '1' else (frac == 0.0), (prec, cull, frac)
             assert relerr(res[cull], ref, pb) <= TOL[prec], (prec, cull)
         assert relerr(res['1'], res['0'], pb) <= bound, prec
     monkeypatch.delenv('PRISIM_HIP_TAPER_CULL')
