@@ -9,8 +9,8 @@ HERA-350 x 1024-channel x 1e4-source workload (SURVEY.md 8(d) config 3, fp32 wit
          --master-port P bench.py --gpus N --steps K --warmup W        (the driver's launcher: only its RANK / WORLD_SIZE are used)
 
 A "step" is one snapshot: one pass of the hot path (prep + pack + sky-sum kernel) over the whole
-sky with all inputs already resident in HBM.  With N > 1 the baselines are sharded in contiguous
-blocks (one process per GPU, the reference's pp.key='bl' model, scripts/run_prisim.py:1775-1791),
+sky with all inputs already resident in HBM.  With N > 1 the baselines are sharded (one process per GPU, the reference's pp.key='bl'
+model, scripts/run_prisim.py:1775-1791; groups of 256 baselines dealt round-robin so that every rank gets its share of the long ones),
 each rank writes snapshot t into slot t of its shard of the visibility cube, and the RCCL all-gather
 of the cube (issued per snapshot on a second HIP stream so that it overlaps the next snapshot's compute) is
 INSIDE the timed region.  The total workload is fixed as N grows ("scaling": "strong").
@@ -46,7 +46,7 @@ import numpy as NP
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from prisim_amd import _abi, launch, rendezvous, workloads as W   # noqa: E402
+from prisim_amd import _abi, launch, rendezvous, sharding, workloads as W   # noqa: E402
 
 FLOPS_PER_TERM = 10.0       # rotate (4 mul + 2 add) + accumulate (2 mul + 2 add) = 6 VALU slots
 # Taper contract: the amplitude rides on the step factor, rho = r * q, which is still ONE complex multiply (6 flop) + the
@@ -58,21 +58,28 @@ XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md: 7 point-to-point links of 
 
 
 def shard_range(nbl, world, rank):
-    """Contiguous equal-size baseline blocks, ceil(nbl/world) each (last ones padded by repeating
-    the final baseline so that every rank -- and the all-gather -- has the same shard size)."""
+    """CONTIGUOUS equal-size baseline blocks (the reference's chunks) -- kept for tools/shard_balance.py, which measures what they cost:
+    the product shards through prisim_amd.sharding (groups of baselines dealt round-robin)."""
     per = (nbl + world - 1) // world
     lo = min(rank * per, nbl)
     hi = min(lo + per, nbl)
     return per, lo, hi
 
 
-def shard_baselines(bl, world, rank):
+def shard_baselines_contiguous(bl, world, rank):
     per, lo, hi = shard_range(bl.shape[0], world, rank)
     mine = bl[lo:hi]
     if mine.shape[0] < per:
         pad = NP.repeat(bl[-1:], per - mine.shape[0], axis=0)
         mine = NP.vstack((mine, pad))
     return mine, hi - lo
+
+
+def shard_baselines(bl, world, rank):
+    """This rank's baselines, padded to the common shard size, and how many of them are real (prisim_amd.sharding: groups of 256
+    baselines dealt round-robin, so that every rank gets its share of the long -- more expensive -- baselines)."""
+    mine, idx, n_real = sharding.shard_rows(bl, world, rank)
+    return mine, n_real
 
 
 def csrc_hash():
@@ -579,7 +586,8 @@ def main():
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': cfg['name'], 'nbl': nbl_total, 'nchan': nchan, 'nsrc': nsrc, 'nt': K,
-                       'beam': 'airy D=14 m fused on device', 'sharding': 'baselines/%d + 1 RCCL all-gather' % world,
+                       'beam': 'airy D=14 m fused on device',
+                       'sharding': 'baselines/%d (groups of %d dealt round-robin) + 1 RCCL all-gather' % (world, sharding.group_size(nbl_total, world)),
                        'kernel': 'recurrence ct=%d nsplit=%d' % (tm['last_chan_tile'], tm['last_nsplit']),
                        'taper_split_runs': tm.get('last_taper_split', 0), 'taper_uncorrected_groups': tm.get('last_split_uncorrected_groups', 0)},
             'roofline': {'bound': 'valu', 'achieved': ach_tflops, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',

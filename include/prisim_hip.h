@@ -230,6 +230,9 @@ int prisim_hip_phase_rotate(prisim_ctx* ctx, int64_t nt, const double* diff_dirc
  * draws exactly the numbers of the unsharded run.  rms: host [nt][nbl][nchan] float64 (vis_rms_freq, :6685-6689);
  * out: host complex128 [nt][nbl][nchan]. */
 int prisim_hip_noise(prisim_ctx* ctx, int64_t nt, const double* rms, uint64_t seed, int64_t bl_offset, double* out);
+/* The same for a shard whose baselines are not one contiguous range of the whole array (shards dealt round-robin in groups,
+ * prisim_amd/sharding.py): bl_index[nbl] = global index of every local baseline. */
+int prisim_hip_noise_indexed(prisim_ctx* ctx, int64_t nt, const double* rms, uint64_t seed, const int64_t* bl_index, double* out);
 
 /* ---- multi-GPU: baseline shards + one RCCL all-gather ---------------------- */
 
@@ -315,8 +318,8 @@ typedef struct prisim_timing {
   double last_delay_ms;      /* hipEvent duration of the last prisim_hip_delay_transform_device (all batches) */
   int32_t last_taper_split;  /* > 0: the packed fp32 taper ran its split form over this many source runs of one source size each */
   int32_t last_split_uncorrected_groups;   /* (source run, baseline group) pairs whose parabola bound allowed the uncorrected body */
-  double last_culled_fraction;             /* share of the snapshot's (source, baseline) pairs the taper culling skipped: their summed
-                                              contribution is below exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux| (0: none) */
+  double last_culled_fraction;             /* share of the snapshot's (source, baseline) pairs the taper culling skipped (packed fp32
+                                              kernels): their summed contribution is below exp(-18) of sum|pbflux| (0: none) */
 } prisim_timing;
 
 int prisim_hip_sync(prisim_ctx* ctx);

@@ -26,7 +26,8 @@ EXPORTS = (
     'prisim_hip_skyvis', 'prisim_hip_set_vis', 'prisim_hip_set_sky_analytic',
     'prisim_hip_set_external_beam', 'prisim_hip_set_sky_external', 'prisim_hip_set_sky_external_analytic', 'prisim_hip_get_pbflux',
     'prisim_hip_delay_transform', 'prisim_hip_delay_transform_device', 'prisim_hip_get_lags', 'prisim_hip_get_delay_power',
-    'prisim_hip_allgather_lags', 'prisim_hip_phase_rotate', 'prisim_hip_noise', 'prisim_hip_comm_unique_id', 'prisim_hip_comm_init',
+    'prisim_hip_allgather_lags', 'prisim_hip_phase_rotate', 'prisim_hip_noise', 'prisim_hip_noise_indexed', 'prisim_hip_comm_unique_id',
+    'prisim_hip_comm_init',
     'prisim_hip_allgather', 'prisim_hip_allgather_slot_async', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
     'prisim_hip_allgather_grad', 'prisim_hip_comm_selftest', 'prisim_hip_get_comm_stats', 'prisim_hip_set_gather_root',
@@ -175,6 +176,7 @@ def load_library():
     lib.prisim_hip_allgather_lags.argtypes = [vp, i64]
     lib.prisim_hip_phase_rotate.argtypes = [vp, i64, vp]
     lib.prisim_hip_noise.argtypes = [vp, i64, vp, C.c_uint64, i64, vp]
+    lib.prisim_hip_noise_indexed.argtypes = [vp, i64, vp, C.c_uint64, vp, vp]
     lib.prisim_hip_comm_unique_id.argtypes = [C.c_char_p]
     lib.prisim_hip_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
     lib.prisim_hip_allgather.argtypes = [vp, i64, i32]
@@ -503,13 +505,21 @@ class Context(object):
             raise ValueError('diff_dircos must have one row per snapshot')
         self._check(self._lib.prisim_hip_phase_rotate(self._h, int(nt), _ptr(d)), 'prisim_hip_phase_rotate')
 
-    def noise(self, rms, seed, bl_offset=0):
+    def noise(self, rms, seed, bl_offset=0, bl_index=None):
         """Complex Gaussian noise (nt, nbl, nchan) with per-element rms (interferometry.py:6692), Philox counter-based draws
-        on the device: identical for sharded and unsharded runs when bl_offset is the shard's first global baseline."""
+        on the device: identical for sharded and unsharded runs when bl_offset is the shard's first global baseline -- or, for
+        shards that are not one contiguous range, bl_index holds the global index of every local baseline."""
         r = NP.ascontiguousarray(rms, dtype=NP.float64)
         if r.ndim != 3 or r.shape[1:] != (self.nbl, self.nchan):
             raise ValueError('rms must have shape (nt, nbl, nchan)')
         out = NP.empty(r.shape, dtype=NP.complex128)
+        if bl_index is not None:
+            ix = NP.ascontiguousarray(bl_index, dtype=NP.int64).ravel()
+            if ix.size != self.nbl:
+                raise ValueError('bl_index must have one entry per baseline')
+            self._check(self._lib.prisim_hip_noise_indexed(self._h, r.shape[0], _ptr(r), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(ix), _ptr(out)),
+                        'prisim_hip_noise_indexed')
+            return out
         self._check(self._lib.prisim_hip_noise(self._h, r.shape[0], _ptr(r), int(seed) & 0xFFFFFFFFFFFFFFFF, int(bl_offset), _ptr(out)),
                     'prisim_hip_noise')
         return out

@@ -731,8 +731,9 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
   // h |n| >= |z| rho (the identity h^2 + z^2 - (h rho + |z||n|)^2 = (h|n| - |z| rho)^2).  So for every baseline of a group (smallest
   // horizontal length Hmin, largest |b_z| Z) and every channel the exponent of source s is at least
   //   x_s = kappa_s max(Hmin |n_s| - Z rho_s, 0)^2 fmin^2/c^2 .
-  // The leading sources of a run whose x_s >= T contribute together at most exp(-T) sum|pbflux|: T = 18 (1.5e-8) for fp32 requests,
-  // 28 (7e-13) for fp64 -- far inside the tolerances (5e-6 / 1e-11) -- and the kernels start the group's source loop behind them.
+  // The leading sources of a run whose x_s >= T contribute together at most exp(-T) sum|pbflux|: T = 18 (1.5e-8) for fp32 requests --
+  // far inside the 5e-6 tolerance -- and the packed fp32 kernels start the group's source loop behind them (the table for T = 28,
+  // 7e-13 against fp64's 1e-11, is formed too, but the fp64 kernels do not use it: run_pass).
   // Long baselines over coarse diffuse pixels (config 4: MWA to 2.5 km, nside 64) shed the sources nearest the zenith this way when
   // the caller lists a run's sources by decreasing altitude (InterferometerArray.observe does); unordered skies just cull little.
   ctx->cull_any[0] = ctx->cull_any[1] = false;
@@ -1187,8 +1188,8 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   // taper culling: per baseline group the first source it still has to sum (tables staged by set_sky_*); a launch over the whole sky
   // can only skip the leading sources of the FIRST run
   const int cpr = pl.f32 ? 1 : 0;
-  const bool cull = ctx->taper && ctx->cull_any[cpr] && ctx->cull_first.p && ctx->cull_nruns == (int)ctx->kappa_runs.size() &&
-                    (size_t)pl.nbgroups == ctx->grp_maxlen.size();
+  const bool cull = pl.pk && ctx->taper && ctx->cull_any[cpr] && ctx->cull_first.p && ctx->cull_nruns == (int)ctx->kappa_runs.size() &&
+                    (size_t)pl.nbgroups == ctx->grp_maxlen.size();             // (the packed fp32 kernels: see skyvis_rec_body)
   auto cull_table = [&](size_t r) { return (const int32_t*)ctx->cull_first.p + ((size_t)cpr * ctx->cull_nruns + r) * (size_t)pl.nbgroups; };
   if (cull && !split) p.src_first = cull_table(0);
   ctx->timing.last_culled_fraction = cull ? ctx->cull_frac[cpr] : 0.0;
@@ -1767,6 +1768,43 @@ int prisim_hip_noise(prisim_ctx* ctx, int64_t nt, const double* rms, uint64_t se
   for (int64_t t = 0; t < nt && e == hipSuccess; ++t) {
     e = hipMemcpyAsync(drms.p, rms + (size_t)t * n, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = launch_noise((const double*)drms.p, (double*)dout.p, ctx->nbl, ctx->nchan, t, bl_offset, seed, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out + (size_t)t * n * 2, dout.p, n * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  release(drms); release(dout);
+  HIPCHK(ctx, e);
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_noise_indexed(prisim_ctx* ctx, int64_t nt, const double* rms, uint64_t seed, const int64_t* bl_index, double* out) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array has not been called");
+  if (nt <= 0 || !rms || !out || !bl_index) return fail(ctx, PRISIM_EINVAL, "bad noise arguments");
+  for (int64_t b = 0; b < ctx->nbl; ++b)
+    if (bl_index[b] < 0) return fail(ctx, PRISIM_EINVAL, "negative global baseline index");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->nbl * ctx->nchan;
+  for (size_t i = 0; i < n * (size_t)nt; ++i)
+    if (!(rms[i] >= 0.0) || !std::isfinite(rms[i])) return fail(ctx, PRISIM_EINVAL, "noise rms must be finite and non-negative");
+  DevBuf drms, dout;
+  int rc;
+  if ((rc = ensure(ctx, drms, n * sizeof(double))) || (rc = ensure(ctx, dout, n * 2 * sizeof(double)))) {
+    release(drms); release(dout);
+    return rc;
+  }
+  hipError_t e = hipSuccess;
+  for (int64_t t = 0; t < nt && e == hipSuccess; ++t) {
+    e = hipMemcpyAsync(drms.p, rms + (size_t)t * n, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    // one launch per run of consecutive global indices: the generator's counter is (channel, global baseline, snapshot)
+    for (int64_t b0 = 0; b0 < ctx->nbl && e == hipSuccess;) {
+      int64_t b1 = b0 + 1;
+      while (b1 < ctx->nbl && bl_index[b1] == bl_index[b1 - 1] + 1) ++b1;
+      e = launch_noise((const double*)drms.p + (size_t)b0 * ctx->nchan, (double*)dout.p + (size_t)b0 * ctx->nchan * 2, b1 - b0, ctx->nchan, t,
+                       bl_index[b0], seed, ctx->stream);
+      b0 = b1;
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(out + (size_t)t * n * 2, dout.p, n * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }

@@ -323,20 +323,11 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   const int tile = slab % p.ntiles;
   const int split = slab / p.ntiles;
 
-  int64_t s_begin = (int64_t)split * p.src_per_split;
+  const int64_t s_begin = (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
   if (s_end > p.nsrc) s_end = p.nsrc;
-  if (TAPER && p.src_first != nullptr) {
-    // taper culling: the group's leading sources are provably below the tolerance (capi.cpp).  What is left is cut into nsplit EQUAL
-    // pieces again, so that every split of the group shrinks alike (the XCD map deals whole slabs to XCDs: skipping only the first
-    // split's sources would idle one XCD and leave the launch as long as before)
-    const int64_t f = p.src_first[bg];
-    if (f > 0) {
-      const int64_t per = (p.nsrc - f + p.nsplit - 1) / p.nsplit;
-      s_begin = f + (int64_t)split * per;
-      s_end = s_begin + per < p.nsrc ? s_begin + per : p.nsrc;
-    }
-  }
+  // (no taper culling here: it is built into the packed fp32 kernels only -- a variable source range cost k_skyvis_rec<double,32,true>
+  // 47 more SGPR spills, 33 of them as lane moves inside its source loop)
 
   const int tid = threadIdx.x;
   const int64_t b_raw = (int64_t)bg * kBlockThreads + tid;

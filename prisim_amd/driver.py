@@ -32,6 +32,7 @@ from . import _abi
 from . import geometry as GEOM
 from . import interferometry as RI
 from . import layouts as LAY
+from . import sharding as SH
 from . import skymodel as SM
 from . import workloads as W
 
@@ -309,13 +310,16 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     chans = W.channel_grid(float(bp['freq']), float(bp['freq_resolution']), int(bp['nchan']))      # run_prisim.py:900
     bl, labels, antpos, blgroups = baseline_info(parms)
     nbl_total = bl.shape[0]
-    per = (nbl_total + world - 1) // world                                                           # :1775-1791, equal shards
-    lo, hi = min(rank * per, nbl_total), min((rank + 1) * per, nbl_total)
-    bl_mine, labels_mine = bl[lo:hi], labels[lo:hi]
-    if bl_mine.shape[0] < per:                       # pad so that every rank gathers equal shards
-        npad = per - bl_mine.shape[0]
-        bl_mine = NP.vstack((bl_mine, NP.repeat(bl[-1:], npad, axis=0)))
-        labels_mine = labels_mine + ['pad'] * npad
+    # :1775-1791 cuts contiguous chunks; here groups of baselines are dealt round-robin (prisim_amd/sharding.py): the list is sorted by
+    # length and long baselines cost more (and are what the taper culling shortens), so every rank gets its share of them; shards are
+    # padded to equal size for the all-gather and the gathered cubes are put back into the global order (SH.unshard_rows)
+    bl_mine, idx_mine, n_real = SH.shard_rows(bl, world, rank)
+    per = bl_mine.shape[0]
+    labels_mine = [labels[i] for i in idx_mine] + ['pad'] * (per - n_real)
+    idx_padded = NP.concatenate((idx_mine, NP.full(per - n_real, nbl_total - 1, dtype=NP.int64)))     # padding rows repeat the last baseline
+
+    def unshard(gathered):
+        return None if gathered is None else SH.unshard_rows(gathered, nbl_total, world)
     tel = telescope_dict(parms)
     skymod = build_skymodel(parms, infile_dir)
     jd, lst, hadec, t_acc, n_acc = schedule(parms)
@@ -363,7 +367,7 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         seed = proc.get('noise_seed')
         if seed is None and world > 1:
             seed = int.from_bytes(hashlib.sha1(bytes(comm_uid or b'')).digest()[:8], 'little')
-        ia.generate_noise(seed=seed, bl_offset=lo)
+        ia.generate_noise(seed=seed, bl_index=idx_padded)
         ia.add_noise()
         noise_done = True
     ph = parms.get('phasing') or {}
@@ -380,18 +384,16 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
             raise ValueError("pp.gather must be 'all' or 'root'")
         if gather == 'root':
             download = rank == 0
-        cube = ia.allgather(comm_uid, world, rank, download=download, root=(0 if gather == 'root' else None))
-        cube = cube[:nbl_total] if cube is not None else None
+        cube = unshard(ia.allgather(comm_uid, world, rank, download=download, root=(0 if gather == 'root' else None)))
         labels_all, bl_all = labels, bl
         noise_all = None
         if noise_done:
-            noise_all = ia.allgather_cube(ia.vis_noise_freq, world, download=download)
-            noise_all = noise_all[:nbl_total] if noise_all is not None else None
+            noise_all = unshard(ia.allgather_cube(ia.vis_noise_freq, world, download=download))
         grad_all = None
         if ia.gradient_mode is not None:
             # the gradient cubes are per baseline too: gathered like the visibilities (interferometry.py:8349-8350 concatenates them)
             g = ia.allgather_gradient(world, download=download)
-            grad_all = {ia.gradient_mode: g[:, :nbl_total]} if g is not None else None
+            grad_all = {ia.gradient_mode: NP.moveaxis(unshard(NP.moveaxis(g, 1, 0)), 0, 1)} if g is not None else None
     else:
         cube, labels_all, bl_all = ia.skyvis_freq[:nbl_total], labels, bl
         grad_all = {k: v[:, :nbl_total] for k, v in ia.gradient.items()} if ia.gradient_mode is not None else None
@@ -409,14 +411,12 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         # every rank transforms its own shard on its GPU (the FFT runs along frequency); sharded runs then exchange the spectra
         ia.delay_transform(pad=float(proc.get('f_pad', 1.0)), freq_wts=window(chans.size, proc.get('bpass_shape', 'bhw')), verbose=False)
         if world > 1:
-            lag = ia.allgather_lags(world, download=download)
-            out['skyvis_lag'] = lag[:nbl_total] if lag is not None else None
+            out['skyvis_lag'] = unshard(ia.allgather_lags(world, download=download))
             if noise_done and ia.vis_lag is not None:
                 if ia.vis_lag.shape == (bl_mine.shape[0], chans.size, n_acc):
                     # the spectra of the noisy and of the noise cube (host-side on every shard) travel like the noise cube did
                     for key, arr in (('vis_lag', ia.vis_lag), ('vis_noise_lag', ia.vis_noise_lag)):
-                        g = ia.allgather_cube(arr, world, download=download)
-                        out[key] = g[:nbl_total] if g is not None else None
+                        out[key] = unshard(ia.allgather_cube(arr, world, download=download))
                 else:
                     # nlag != nchan (a fractional f_pad): these host-side spectra cannot ride in the visibility slots.  Nothing is
                     # dropped: whoever assembles the whole array (assemble_full_array, rank 0) transforms the gathered vis_freq /

@@ -990,7 +990,7 @@ class InterferometerArray(object):
         self.n_acc = n_acc
 
     # ------------------------------------------------------------------------------------------
-    def generate_noise(self, seed=None, bl_offset=0):
+    def generate_noise(self, seed=None, bl_offset=0, bl_index=None):
         """Thermal noise for every (baseline, channel, snapshot) from the system parameters (interferometry.py:6661-6693):
         vis_rms_freq = 2 k / sqrt(t_acc df) * Tsys / (A_eff eff_Q) / Jy (flux_unit 'JY') or Tsys / eff_Q / sqrt(t_acc df) ('K');
         vis_noise_freq = vis_rms_freq / sqrt(2) * (randn + 1j randn).  The normals are drawn on the GPU (counter-based Philox),
@@ -1011,7 +1011,8 @@ class InterferometerArray(object):
             seed = int(NP.random.SeedSequence().generate_state(2, dtype=NP.uint32).astype(NP.uint64) @ NP.array([1, 1 << 32], dtype=NP.uint64))
         rms_tbf = NP.ascontiguousarray(NP.transpose(NP.broadcast_to(self.vis_rms_freq, (self.baselines.shape[0], self.channels.size,
                                                                                           len(self.timestamp))), (2, 0, 1)))
-        noise = self._ctx.noise(rms_tbf, seed, bl_offset=bl_offset)                     # (nt, nbl, nchan)
+        # bl_offset / bl_index: this array's baselines inside the WHOLE array of a sharded run (the draws are keyed on the global index)
+        noise = self._ctx.noise(rms_tbf, seed, bl_offset=bl_offset, bl_index=bl_index)   # (nt, nbl, nchan)
         self.vis_noise_freq = NP.transpose(noise, (1, 2, 0))                             # :6692
         self.noise_seed = seed
 

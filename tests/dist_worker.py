@@ -91,6 +91,13 @@ def _hdf5_of_sharded_run_equals_unsharded(parms, out_sharded, out_single):
     return len(a) > 30
 
 
+def ref_bl_for_shard(nbl, world, rank):
+    """The baselines rank `rank` must hold: its round-robin groups of the whole (length-sorted) list."""
+    from prisim_amd import sharding
+    bl_all = driver.baseline_info(parms_for_test())[0]
+    return bl_all[sharding.shard_index(nbl, world, rank)]
+
+
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else 'oracle'
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
@@ -106,8 +113,10 @@ def main():
 
     parms = parms_for_test()
     out = driver.run(parms, rank=rank, world=world, device=0, comm_uid=uid, verbose=False)
-    per, lo, hi = bench.shard_range(171, world, rank)
-    assert out['ia'].baselines.shape[0] == per                                  # equal shards, the last one padded
+    from prisim_amd import sharding
+    per = sharding.shard_size(171, world)
+    assert out['ia'].baselines.shape[0] == per                                  # equal shards (groups dealt round-robin), padded
+    assert NP.array_equal(out['ia'].baselines[:sharding.shard_index(171, world, rank).size], ref_bl_for_shard(171, world, rank))
     assert out['skyvis_freq'].shape == (171, 16, 3) and out['skyvis_lag'].shape == (171, 16, 3)   # padding rows dropped
     ref = driver.run(parms, rank=0, world=1, device=0, verbose=False)          # the same driver, unsharded, in this process
     tol = 0.0 if mode == 'oracle' else 1e-11 * float(NP.max(NP.abs(ref['skyvis_freq'])))

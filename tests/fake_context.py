@@ -72,12 +72,12 @@ class OracleContext(object):
         v = self.cube[slot].astype(ctype)
         return (v, self._grad[slot].astype(ctype)) if want_grad else v
 
-    def noise(self, rms, seed, bl_offset=0):
+    def noise(self, rms, seed, bl_offset=0, bl_index=None):
         # like the device generator, keyed on the GLOBAL baseline index: a shard draws what the unsharded run draws for its baselines
         r = NP.asarray(rms, dtype=NP.float64)                                  # (nt, nbl, nchan)
         out = NP.empty(r.shape, dtype=NP.complex128)
         for b in range(r.shape[1]):
-            rng = NP.random.default_rng([int(seed) & 0xFFFFFFFF, int(bl_offset) + b])
+            rng = NP.random.default_rng([int(seed) & 0xFFFFFFFF, (int(bl_offset) + b) if bl_index is None else int(bl_index[b])])
             z = rng.standard_normal((r.shape[0], r.shape[2], 2))
             out[:, b, :] = r[:, b, :] / NP.sqrt(2.0) * (z[..., 0] + 1j * z[..., 1])
         return out

@@ -84,9 +84,12 @@ def test_bench_main_at_world_size_three_prints_one_contract_line(tmp_path):
     assert d['n_gpus'] == 3 and d['steps'] == 2 and d['warmup'] == 1 and d['gather_ok'] is True
     assert d['metric'] == 'visibility-terms/sec' and d['scaling'] == 'strong' and d['vs_baseline'] is None
     assert d['config']['nbl'] == 61075 and d['config']['nsrc'] == 16 and d['config']['sharding'].startswith('baselines/3')
-    # whole-job value: all 61 075 baselines (not the padded 3 x 20 359), both steps, over the slowest rank's time
+    # whole-job value: all 61 075 baselines (not the padded 3 x 20 480), both steps, over the slowest rank's time
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 * 2 - 61075.0 * 1024 * 16 * 2) <= 1e-6 * 61075.0 * 1024 * 16 * 2
-    assert d['roofline']['terms_per_launch'] == 20359.0 * 1024 * 16            # per launch: this rank's padded shard
+    sys.path.insert(0, ROOT)
+    from prisim_amd import sharding
+    assert sharding.shard_size(61075, 3) == 20480                              # 239 groups of 256 dealt round-robin: 80, 80, 79
+    assert d['roofline']['terms_per_launch'] == 20480.0 * 1024 * 16            # per launch: this rank's padded shard
 
 
 def test_bench_launched_bare_spawns_its_own_ranks_and_reports_the_gather(tmp_path):

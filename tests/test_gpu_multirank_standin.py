@@ -48,7 +48,9 @@ def test_bench_gpus_n_runs_end_to_end_on_one_gpu(fake_rccl, nranks, precision):
     d = json.loads(lines[0])
     assert d['n_gpus'] == nranks and d['steps'] == 2 and d['gather_ok'] is True and d['launcher'] == 'prisim_amd.launch'
     assert d['config']['nbl'] == 61075 and d['config']['nsrc'] == 1500 and d['dtype'] == ('f32' if precision == 'fp32' else 'f64')
-    per = (61075 + nranks - 1) // nranks
+    sys.path.insert(0, ROOT)
+    from prisim_amd import sharding
+    per = sharding.shard_size(61075, nranks)                       # groups of 256 baselines dealt round-robin, padded to the largest share
     assert d['roofline']['terms_per_launch'] == float(per) * 1024 * 1500
     g = d['gather']
     assert g['wire_dtype'] == ('complex64' if precision == 'fp32' else 'complex128')

@@ -252,7 +252,7 @@ def test_fp32_split_taper_runs_of_one_source_size(ctx, monkeypatch):
 def test_taper_culling_skips_only_what_is_below_the_tolerance(ctx, monkeypatch):
     """Long baselines resolve out diffuse pixels: w = exp(-kappa |b_perp|^2 f^2/c^2) underflows for the sources nearest the zenith.  With
     a run's sources listed by decreasing altitude the library starts every baseline group's source loop behind the leading sources whose
-    summed weight is below exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux|.  MWA-like baselines (to 2.5 km, sorted by length like the
+    summed weight is below exp(-18) of sum|pbflux| (packed fp32 kernels; fp64 requests sum everything).  MWA-like baselines (to 2.5 km, sorted by length like the
     driver's) over degree-size pixels: a good share of the (source, baseline) pairs goes, the result stays inside the tolerances against
     the oracle that sums everything, and equals the unculled result to the cull bound."""
     rng = NP.random.default_rng(91)
@@ -277,7 +277,8 @@ def test_taper_culling_skips_only_what_is_below_the_tolerance(ctx, monkeypatch):
             ctx.compute(precision=prec)
             res[cull] = ctx.get_vis()
             frac = ctx.timing()['last_culled_fraction']
-            assert (frac > (0.20 if prec == _abi.PRISIM_FP32 else 0.12)) if cull == '1' else (frac == 0.0), (prec, cull, frac)
+            # (the packed fp32 kernels cull; fp64 requests sum everything)
+            assert (frac > 0.20) if (cull == '1' and prec == _abi.PRISIM_FP32) else (frac == 0.0), (prec, cull, frac)
             assert relerr(res[cull], ref, pb) <= TOL[prec], (prec, cull)
         assert relerr(res['1'], res['0'], pb) <= bound, prec
     monkeypatch.delenv('PRISIM_HIP_TAPER_CULL')

@@ -106,19 +106,47 @@ def test_workload_shapes():
     assert sub['baselines'].shape[0] == 18 and sub['channels'].size == 16 and sub['sky']['flux_ref'].size == 215
 
 
-@pytest.mark.parametrize('nbl,world', [(61075, 1), (61075, 2), (61075, 8), (171, 4), (3, 8)])
+@pytest.mark.parametrize('nbl,world', [(61075, 1), (61075, 2), (61075, 3), (61075, 8), (8128, 8), (171, 2), (171, 4), (3, 8), (1, 2)])
 def test_baseline_sharding_covers_everything_once(nbl, world):
+    """prisim_amd.sharding: groups of baselines dealt round-robin, equal padded shard sizes, every baseline exactly once, and the
+    gathered rank-major cube goes back into the global order."""
+    from prisim_amd import sharding as SH
     bl = NP.arange(nbl * 3, dtype=float).reshape(nbl, 3)
-    seen = []
-    per0 = None
+    per = SH.shard_size(nbl, world)
+    group = SH.group_size(nbl, world)
+    assert 1 <= group <= 256 and (nbl < 1024 * world or group == 256)
+    seen, gathered = [], []
     for rank in range(world):
-        per, lo, hi = bench.shard_range(nbl, world, rank)
-        per0 = per if per0 is None else per0
-        assert per == per0
         mine, n_real = bench.shard_baselines(bl, world, rank)
-        assert mine.shape == (per, 3) and n_real == hi - lo
-        seen.append(mine[:n_real])
-    assert NP.array_equal(NP.vstack(seen), bl)
+        rows, idx, n2 = SH.shard_rows(bl, world, rank)
+        assert mine.shape == (per, 3) and n_real == n2 == idx.size and NP.array_equal(mine, rows)
+        assert NP.array_equal(mine[:n_real], bl[idx]) and NP.all(NP.diff(idx) > 0)
+        assert NP.all(mine[n_real:] == bl[-1])                                  # padding repeats the last baseline
+        assert per - n_real <= group                                            # shares differ by at most one group
+        seen.append(idx)
+        gathered.append(mine * 10.0 + rank)
+    assert NP.array_equal(NP.sort(NP.concatenate(seen)), NP.arange(nbl))
+    back = SH.unshard_rows(NP.concatenate(gathered), nbl, world)
+    owner = NP.empty(nbl)
+    for rank, idx in enumerate(seen):
+        owner[idx] = rank
+    assert NP.array_equal(back, bl * 10.0 + owner[:, None])
+    with pytest.raises(ValueError):
+        SH.unshard_rows(NP.zeros((world * per + 1, 3)), nbl, world)
+
+
+def test_round_robin_shards_spread_the_long_baselines():
+    """The headline array lists baselines by length; contiguous shards would give the last of 8 ranks every group that cannot use the
+    lifting rotation, the dealt-out ones give each rank 1 or 2 of them."""
+    from prisim_amd import sharding as SH
+    cfg = W.config3(nsrc=10)
+    length = NP.sqrt(NP.sum(cfg['baselines'] ** 2, axis=1))
+    assert NP.all(NP.diff(length) >= -1e-9)
+    long_ones = length > 298.5
+    per_rank = [int(NP.sum(long_ones[SH.shard_index(length.size, 8, r)])) for r in range(8)]
+    assert max(per_rank) - min(per_rank) <= 256 and min(per_rank) > 0
+    lo = 7 * ((length.size + 7) // 8)
+    assert int(NP.sum(long_ones[lo:])) == int(NP.sum(long_ones))               # contiguous: all of them on the last rank
 
 
 def test_skymodel_spectra():

@@ -1,0 +1,37 @@
+"""Load balance of baseline shards (one rank's work of an N-GPU run, measured on one GPU): the headline array's baselines are sorted by
+length, so CONTIGUOUS shards (the reference's chunks, scripts/run_prisim.py:1775-1791) give the last rank all the long baselines -- the
+groups that cannot use the lifting rotation (and, with the taper, the re-anchored bodies) -- and the job runs at the slowest rank's pace.
+Shards dealt round-robin in groups of 256 baselines give every rank its share.  Prints the step time (hipEvents, whole compute()) of
+every rank's shard for both schemes."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as NP
+
+import bench
+from prisim_amd import _abi, workloads as W
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+taper = len(sys.argv) > 2 and sys.argv[2] == 'taper'
+cfg = W.config3(with_diffuse=taper)
+bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+zen = NP.array([0.0, 0.0, 1.0])
+ctx = _abi.Context(0)
+out = {'n': N, 'workload': cfg['name'], 'taper': taper}
+for scheme in ('contiguous', 'interleaved'):
+    times = []
+    for r in range(N):
+        mine = bench.shard_baselines_contiguous(bl, N, r)[0] if scheme == 'contiguous' else bench.shard_baselines(bl, N, r)[0]
+        ctx.set_array(mine, ch, nt_max=1)
+        ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, 14.0, zen, zen,
+                             fwhm_deg=(sky['fwhm_deg'] if taper else None))
+        best = 1e9
+        for rep in range(4):
+            ctx.compute(precision=_abi.PRISIM_FP32)
+            ctx.sync()
+            best = min(best, ctx.timing()['last_compute_ms'])
+        times.append(best)
+    out[scheme] = {'ms_per_rank': times, 'slowest': max(times), 'mean': float(NP.mean(times)), 'slowest_over_mean': max(times) / float(NP.mean(times))}
+print(json.dumps(out))
