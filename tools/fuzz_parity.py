@@ -22,8 +22,12 @@ for case in range(ncase):
     df = float(rng.choice([24414.0625, 97656.25, 390625.0, 1.5e6]))
     f0 = float(rng.choice([50e6, 100e6, 180e6]))
     bl = rng.uniform(-maxbl, maxbl, size=(nbl, 3)); bl[:, 2] *= 0.02
+    if rng.integers(0, 2):
+        bl = bl[NP.argsort(NP.sqrt(NP.sum(bl ** 2, axis=1)))]      # by length, as the driver lists them
     ch = f0 + NP.arange(nchan) * df
     alt = NP.degrees(NP.arcsin(rng.uniform(0.05, 1.0, nsrc)))
+    if rng.integers(0, 2):
+        alt = NP.sort(alt)[::-1]          # by decreasing altitude, as observe() lists a run when the taper culling can skip sources
     dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, nsrc)), axis=1)) if nsrc else NP.zeros((0, 3))
     pb = rng.uniform(0.0, 10.0, size=(nsrc, 1)) * rng.uniform(0.2, 1.0, size=(nsrc, nchan))
     pc = O.altaz2dircos(NP.array([[rng.uniform(40, 90), rng.uniform(0, 360)]]))[0]
@@ -40,6 +44,15 @@ for case in range(ncase):
             hi = int(cuts[r]) if r < nrun - 1 else nsrc
             fw[lo:hi] = sizes[r]
             lo = hi
+    cull_case = nsrc > 64 and rng.integers(0, 6) == 0
+    if cull_case:
+        # a case built for the taper culling: long baselines listed by length, degree-size sources listed by decreasing altitude
+        taper = True
+        bl = rng.normal(0.0, 900.0, size=(nbl, 3)); bl[:, 2] *= 0.002
+        bl = bl[NP.argsort(NP.sqrt(NP.sum(bl ** 2, axis=1)))]
+        alt = NP.sort(alt)[::-1]
+        dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, nsrc)), axis=1))
+        fw = NP.full(nsrc, float(rng.choice([0.458, 0.916])))
     ref = CO.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw) if nsrc else NP.zeros((nbl, nchan), dtype=complex)
     scale = NP.maximum(NP.sum(NP.abs(pb), axis=0), 1e-300)[None, :]
     ctx.set_array(bl, ch)
@@ -47,6 +60,8 @@ for case in range(ncase):
     for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):
         cts = [0, 8, 16, 32] + ([64] if prec == _abi.PRISIM_FP32 else [])
         ct = int(rng.choice(cts)); nsplit = int(rng.choice([0, 1, 2, 5])); chunk = int(rng.choice([0, 1, 16, 64]))
+        if cull_case and prec == _abi.PRISIM_FP32:
+            ct = int(rng.choice([32, 64]))
         flush = int(rng.choice([0, 0, 0, 7, 64]))
         if flush: os.environ['PRISIM_HIP_FLUSH_SRC'] = str(flush)
         else: os.environ.pop('PRISIM_HIP_FLUSH_SRC', None)
@@ -64,6 +79,8 @@ for case in range(ncase):
                     print('FAIL-GRAD k=%d nbl=%d nchan=%d nsrc=%d taper=%d prec=%d ct=%d nsplit=%d flush=%d err=%.3e' % (k, nbl, nchan, nsrc, taper, prec, ct, nsplit, flush, gerr), flush=True)
         err = float(NP.max(NP.abs(v - ref) / scale)) if nsrc else float(NP.max(NP.abs(v)))
         ok = NP.all(NP.isfinite(v)) and err <= TOL[prec]
+        if ctx.timing().get('last_culled_fraction', 0.0) > 0:
+            globals()['nculled'] = globals().get('nculled', 0) + 1
         if ctx.timing().get('last_taper_split', 0) > 0:
             nsplitform = globals().get('nsplitform', 0) + 1
             globals()['nsplitform'] = nsplitform
@@ -73,4 +90,4 @@ for case in range(ncase):
                   (nbl, nchan, nsrc, taper, maxbl, df, f0, prec, ct, nsplit, chunk, flush, err, ctx.timing()), flush=True)
     if case % 25 == 0:
         print('case', case, 'fails', fails, '%.0fs' % (time.time() - t0), flush=True)
-print('DONE cases', ncase, 'fails', fails, 'cases that ran the split taper form', globals().get('nsplitform', 0))
+print('DONE cases', ncase, 'fails', fails, 'cases that ran the split taper form', globals().get('nsplitform', 0), 'cases with taper culling', globals().get('nculled', 0))
