@@ -51,6 +51,15 @@ def spawn_ranks(nranks, argv, env=None, grace=10.0):
     rdzv_file = os.path.join(tmpdir, 'rdzv')
     port = _free_port()
     procs = []
+
+    def _on_term(signum, frame):            # the launcher itself is being stopped: take the ranks along (no orphans on the GPUs)
+        raise KeyboardInterrupt
+
+    old_term = None
+    try:
+        old_term = signal.signal(signal.SIGTERM, _on_term)
+    except ValueError:                      # not the main thread: the caller's signal handling stands
+        pass
     try:
         for r in range(nranks):
             procs.append(subprocess.Popen(list(argv), env=rank_env(r, nranks, env, port, rdzv_file)))
@@ -99,6 +108,8 @@ def spawn_ranks(nranks, argv, env=None, grace=10.0):
         _stop(procs, set(range(len(procs))), grace)
         return 130
     finally:
+        if old_term is not None:
+            signal.signal(signal.SIGTERM, old_term)
         shutil.rmtree(tmpdir, ignore_errors=True)
 
 

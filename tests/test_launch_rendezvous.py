@@ -165,3 +165,28 @@ def test_collectives_do_not_time_out_while_a_rank_is_busy(tmp_path):
     finally:
         os.environ.pop('PRISIM_RDZV_FILE', None)
         th.join(1)
+
+
+def test_launcher_takes_its_ranks_along_when_it_is_terminated(tmp_path):
+    """SIGTERM to the launcher (a batch system's timeout) must not leave rank processes behind on the GPUs."""
+    import signal
+    marker = tmp_path / 'pids'
+    script = _script(tmp_path, '''
+        import time
+        with open(%r, 'a') as f:
+            f.write('%%d\\n' %% os.getpid())
+        time.sleep(120)
+    ''' % str(marker))
+    p = subprocess.Popen([sys.executable, '-m', 'prisim_amd.launch', '-n', '2', script], env=_clean_env(), cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while time.time() - t0 < 30 and (not marker.exists() or len(marker.read_text().split()) < 2):
+        time.sleep(0.05)
+    pids = [int(x) for x in marker.read_text().split()]
+    assert len(pids) == 2
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 130
+    time.sleep(0.2)
+    for pid in pids:
+        with pytest.raises(OSError):
+            os.kill(pid, 0)                                   # gone
