@@ -398,6 +398,17 @@ class InterferometerArray(object):
         if not getattr(self, '_stage', False):
             return False
         if self._host_cube is None:
+            need = self._reserved * self.baselines.shape[0] * self.channels.size * NP.dtype(dtype).itemsize
+            try:
+                avail = os.sysconf('SC_AVPHYS_PAGES') * os.sysconf('SC_PAGE_SIZE')
+            except (ValueError, OSError, AttributeError):
+                avail = None
+            if avail is not None and need > 0.5 * avail:
+                # page-locked memory cannot be swapped or reclaimed: a cube that would take most of the free RAM is not pinned
+                warnings.warn('host staging switched off: the pinned host cube would need {0:.1f} GiB of {1:.1f} GiB free'.format(
+                    need / 2.0 ** 30, avail / 2.0 ** 30))
+                self._stage = False
+                return False
             try:
                 self._host_cube = _abi.host_empty((self._reserved, self.baselines.shape[0], self.channels.size), dtype)
             except (MemoryError, _abi.PrisimHipError, OSError) as exc:
