@@ -439,7 +439,7 @@ def test_host_staging_falls_back_when_pinned_memory_is_unavailable(monkeypatch):
 def test_host_staging_is_refused_when_the_pinned_cube_would_take_most_of_the_free_memory(monkeypatch):
     import os as _os
     real = _os.sysconf
-    monkeypatch.setattr(_os, 'sysconf', lambda name: 16 if name == 'SC_AVPHYS_PAGES' else real(name))     # 16 free pages
+    monkeypatch.setattr(_os, 'sysconf', lambda name: 0 if name == 'SC_AVPHYS_PAGES' else real(name))      # no free pages
     monkeypatch.setattr(_abi, 'host_empty', lambda shape, dtype: (_ for _ in ()).throw(AssertionError('must not be reached')))
     with pytest.warns(UserWarning, match='host staging switched off: the pinned host cube would need'):
         ia, _ = _observed_oracle_array(monkeypatch, 2, reserve=2, host_staging=True)
