@@ -139,7 +139,6 @@ struct prisim_ctx {
   std::vector<KappaRun> kappa_runs;
   DevBuf split_flags, moments, grp_hz, split_count;      // grp_hz: [2][groups] (max horizontal length, max |b_z|) on the device
   int32_t* h_split_count = nullptr;                      // pinned: uncorrected-group counts of the last split launch, per run (read after a sync)
-  std::vector<int32_t> split_guard_host;                 // per group: 1 = too long for the split form's exponent guard (unsplit bodies)
   int split_count_runs = 0;
   double dmax = 2.0;                  // max_s |s - s_pc| of the current sky
   std::vector<double> h_freqs;
@@ -1111,9 +1110,8 @@ static void fill_params(prisim_ctx* ctx, const Plan& pl, SkyvisParams& p) {
 // Decide whether this packed fp32 taper pass runs in the split form and prepare its per-run, per-group flags.  Needs: the packed
 // 64-channel kernel, the grouped recurrence's channel-grid condition, sources in <= 8 runs of one size each (exactly one when the
 // sources are split into partial cubes),
-// in-loop exponents kappa (|b| f / c)^2 <= 30 with a per-step exponent <= 1/8 (fp32 range and the series of exp2m1_small) for at least
-// a quarter of the baseline groups (the others run the unsplit bodies inside the same launch), and -- per baseline group -- a bound on
-// the parabola the uncorrected grouped form leaves: relative to a term it is at most
+// in-loop exponents kappa (|b| f / c)^2 <= 30 with a per-step exponent <= 1/8 (fp32 range and the series of exp2m1_small), and --
+// per baseline group -- a bound on the parabola the uncorrected grouped form leaves: relative to a term it is at most
 // 16 kappa (b.s)^2 df^2 / c^2 with (b.s)^2 <= (H rho_s + Z |n_s|)^2 (H, Z: the group's largest horizontal length and |b_z|), so
 // relative to sum|pbflux| it is at most 16 kappa df^2/c^2 (H^2 M2 + 2 H Z M11 + Z^2 M02) with the beam-weighted moments
 // M = sum_s |p_s| (.) / sum_s |p_s| of the run's sources, maximised over the channels (k_taper_moments: one pass over pbflux;
@@ -1134,43 +1132,21 @@ static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams
   bool any_taper = false;
   for (const auto& r : ctx->kappa_runs) { kmax = std::max(kmax, r.kappa); any_taper = any_taper || r.kappa > 0.0; }
   if (!any_taper) return false;
-  // the exponent guard, per baseline group (groups that fail it run the unsplit bodies inside the same launch: flag bit 3); the
-  // launch takes the split kernel as soon as a quarter of the groups pass
-  (void)lmax;
-  const size_t ngr = ctx->grp_maxlen.size();
-  std::vector<int32_t> guard(ngr, 0);
-  size_t npass = 0;
-  for (size_t g = 0; g < ngr; ++g) {
-    const double L = ctx->grp_maxlen[g];
-    const double ug = kmax * (L * fmax / kC) * (L * fmax / kC);
-    const bool ok = ug <= 30.0 && 2.0 * ug * std::fabs(ctx->df) <= 0.125 * fmin;
-    guard[g] = ok ? 0 : 1;
-    npass += ok ? 1 : 0;
-  }
-  if (npass * 4 < ngr) return false;
+  const double umax = kmax * (lmax * fmax / kC) * (lmax * fmax / kC);
+  if (!(umax <= 30.0) || !(2.0 * umax * std::fabs(ctx->df) <= 0.125 * fmin)) return false;
   const int64_t nchan = ctx->nchan;
   const size_t nruns = ctx->kappa_runs.size();
   const size_t ng = ctx->grp_maxh.size();
   if ((size_t)pl.nbgroups != ng || !ctx->lift_flags.p) return false;
   if (ensure(ctx, ctx->moments, (size_t)4 * nchan * sizeof(double) * nruns) != PRISIM_OK) return false;
   if (ensure(ctx, ctx->split_flags, nruns * ng * sizeof(int32_t)) != PRISIM_OK) return false;
-  if (ensure(ctx, ctx->split_count, (8 + ng) * sizeof(int32_t)) != PRISIM_OK) return false;     // 8 counters + the per-group guard flags
+  if (ensure(ctx, ctx->split_count, 8 * sizeof(int32_t)) != PRISIM_OK) return false;
   if (!ctx->h_split_count && hipHostMalloc((void**)&ctx->h_split_count, 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
     ctx->h_split_count = nullptr;
     return false;
   }
   // moments -> flags entirely on the stream: no download, so a snapshot's launches never wait for the previous snapshot's sky-sum
   if (hipMemsetAsync(ctx->split_count.p, 0, 8 * sizeof(int32_t), ctx->stream) != hipSuccess) return false;
-  {
-    // guard flags: host vector -> device (kept alive in the context; rewritten only when they change, after the stream has drained)
-    if (ctx->split_guard_host != guard) {
-      if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
-      ctx->split_guard_host = guard;
-    }
-    if (hipMemcpyAsync((int32_t*)ctx->split_count.p + 8, ctx->split_guard_host.data(), ng * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) !=
-        hipSuccess)
-      return false;
-  }
   for (size_t r = 0; r < nruns; ++r) {
     const auto& run = ctx->kappa_runs[r];
     if (run.kappa <= 0.0) continue;
@@ -1178,8 +1154,7 @@ static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams
     if (launch_taper_moments((const double*)ctx->pb.p, (const double*)ctx->dirs.p, run.lo, run.hi, nchan, mom, ctx->stream) != hipSuccess) return false;
     const double c16 = 16.0 * run.kappa * (ctx->df / kC) * (ctx->df / kC);
     if (launch_split_flags(mom, nchan, (const double*)ctx->grp_hz.p, (const double*)ctx->grp_hz.p + ng, (const int32_t*)ctx->lift_flags.p, (int)ng, c16,
-                           2.0e-7, (const int32_t*)ctx->split_count.p + 8, (int32_t*)ctx->split_flags.p + r * ng, (int32_t*)ctx->split_count.p + r,
-                           ctx->stream) != hipSuccess)
+                           2.0e-7, (int32_t*)ctx->split_flags.p + r * ng, (int32_t*)ctx->split_count.p + r, ctx->stream) != hipSuccess)
       return false;
   }
   // the counts travel to pinned host memory behind the flags kernels; get_timing reads them after the compute's events have completed

@@ -1299,8 +1299,7 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
 
 // Packed fp32 sky-sum of ONE source range whose sources share a size (kappa0): the split taper form (see skyvis_rec_f32pk_body).
 // split_flags[bg]: bit 0 = |step angle| <= pi/4 guaranteed for the group (no re-anchoring), bit 1 = the uncorrected parabola could not be
-// bounded below 2e-7 for this group: keep the correction, bit 2 = even four times the bound passes: groups of 16 steps, bit 3 = the
-// group's longest baseline exceeds the split form's exponent guard: unsplit bodies.
+// bounded below 2e-7 for this group: keep the correction, bit 2 = even four times the bound passes: groups of 16 steps.
 template <int CT>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void k_skyvis_rec_f32pk_split(const SkyvisParams p) {
@@ -1308,12 +1307,7 @@ void k_skyvis_rec_f32pk_split(const SkyvisParams p) {
   int slab_, bg;
   if (!block_item(p, slab_, bg)) return;
   const int fl = p.split_flags[bg];
-  if (fl & 8) {
-    // this group's baselines are too long for the split form's fp32 range (in-loop exponent kappa0 (|b| f/c)^2 > 30): the unsplit
-    // grouped bodies, as k_skyvis_rec_f32pk<CT, true> runs them -- the other groups of the launch keep the split form
-    if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 1, 0>(p, flush_lds);
-    else skyvis_rec_f32pk_body<CT, true, false, 1, 2>(p, flush_lds);
-  } else if (fl & 2) {
+  if (fl & 2) {
     if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 2, 0>(p, flush_lds);
     else skyvis_rec_f32pk_body<CT, true, false, 2, 2>(p, flush_lds);
   } else if (fl & 4) {
@@ -1362,7 +1356,6 @@ __global__ void k_taper_moments(const double* __restrict__ pb, const double* __r
 // (4 bound_g <= limit ? 4 : 0); *count += groups that run uncorrected.
 __global__ void k_split_flags(const double* __restrict__ mom /*[4][nchan]*/, int64_t nchan, const double* __restrict__ grp_h,
                               const double* __restrict__ grp_z, const int32_t* __restrict__ lift_flags, int nbg, double c16, double limit,
-                              const int32_t* __restrict__ guard_fail /*[nbg] 1: exponent guard fails for the group*/,
                               int32_t* __restrict__ flags, int32_t* __restrict__ count) {
   __shared__ double sm[3][256];
   double a = 0.0, b = 0.0, c = 0.0;
@@ -1388,9 +1381,7 @@ __global__ void k_split_flags(const double* __restrict__ mom /*[4][nchan]*/, int
     const double H = grp_h[g], Z = grp_z[g];
     const double bound = c16 * (H * H * m2 + 2.0 * H * Z * m11 + Z * Z * m02);
     int32_t fl = lift_flags[g] ? 1 : 0;
-    if (guard_fail[g]) {
-      fl |= 8;                                        // unsplit bodies for this group
-    } else if (!(bound <= limit)) {
+    if (!(bound <= limit)) {
       fl |= 2;
     } else {
       ++mine;
@@ -1625,9 +1616,9 @@ hipError_t launch_taper_moments(const double* pb, const double* dirs, int64_t s_
 }
 
 hipError_t launch_split_flags(const double* mom, int64_t nchan, const double* grp_h, const double* grp_z, const int32_t* lift_flags, int nbg,
-                              double c16, double limit, const int32_t* guard_fail, int32_t* flags, int32_t* count, hipStream_t stream) {
+                              double c16, double limit, int32_t* flags, int32_t* count, hipStream_t stream) {
   if (nbg <= 0 || nchan <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_split_flags, dim3(1), dim3(256), 0, stream, mom, nchan, grp_h, grp_z, lift_flags, nbg, c16, limit, guard_fail, flags, count);
+  hipLaunchKernelGGL(k_split_flags, dim3(1), dim3(256), 0, stream, mom, nchan, grp_h, grp_z, lift_flags, nbg, c16, limit, flags, count);
   return hipGetLastError();
 }
 

@@ -205,9 +205,7 @@ def test_fp32_split_taper_runs_of_one_source_size(ctx, monkeypatch):
     monkeypatch.setenv('PRISIM_HIP_FLUSH_SRC', '97')
     ctx.set_array(bl, ch)
     ctx.set_tuning(64, 0, 1)
-    # 'long': degree-size sources -- the last baseline group (up to 1.2 km) exceeds the split form's exponent guard and runs the unsplit
-    # bodies inside the same launch, the others keep the split form
-    for name, alt_lo, fw_d, want_uncorrected in (('zenith', 82.0, 0.229, True), ('horizon', 5.0, 0.5, False), ('long', 60.0, 0.916, None)):
+    for name, alt_lo, fw_d, want_uncorrected in (('zenith', 82.0, 0.229, True), ('horizon', 5.0, 0.5, False)):
         n_pt, n_df = 150, 450
         alt = NP.degrees(NP.arcsin(rng.uniform(NP.sin(NP.radians(alt_lo)), 1.0, n_pt + n_df)))
         dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, n_pt + n_df)), axis=1))
@@ -218,8 +216,7 @@ def test_fp32_split_taper_runs_of_one_source_size(ctx, monkeypatch):
         ctx.compute(precision=_abi.PRISIM_FP32)
         tm = ctx.timing()
         assert tm['last_chan_tile'] == 64 and tm['last_taper_split'] == 2, (name, tm)
-        if want_uncorrected is not None:
-            assert (tm['last_split_uncorrected_groups'] > 0) == want_uncorrected, (name, tm)
+        assert (tm['last_split_uncorrected_groups'] > 0) == want_uncorrected, (name, tm)
         v_split = ctx.get_vis()
         assert relerr(v_split, ref, pb) <= TOL[_abi.PRISIM_FP32], name
         monkeypatch.setenv('PRISIM_HIP_TAPER_SPLIT', '0')
