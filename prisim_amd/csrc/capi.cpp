@@ -1176,8 +1176,13 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
     return PRISIM_OK;
   }
+  // fp64 with the source-shape taper (the reference's default precision on every run_prisim.py sky): the grouped kernel
+  // k_skyvis_taper_f64 on 16- / 32-channel tiles, rows in natural channel order (PRISIM_HIP_TAPER_F64_GROUP=0: the exact second-order
+  // form, k_skyvis_rec<double, CT, true> -- the A/B baseline and the 8-channel tiles' kernel)
+  bool g64 = !pl.f32 && ctx->taper && (pl.ct == 16 || pl.ct == 32);
+  if (const char* env = getenv("PRISIM_HIP_TAPER_F64_GROUP")) g64 = g64 && atoi(env) != 0;
   HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
-                          pl.ntiles, (const double*)ctx->dirs.p, scale_comp, 1, ctx->stream));
+                          pl.ntiles, (const double*)ctx->dirs.p, scale_comp, g64 ? 0 : 1, ctx->stream));
   p.out = pl.nsplit > 1 ? (double*)ctx->partial.p : dst;
   // fp32 kernels whose splits each flush exactly once store their partial sums as complex64: half the partial traffic
   const bool part_f32 = pl.nsplit > 1 && pl.f32 && pl.kernel == PRISIM_KERNEL_RECURRENCE && pl.src_per_split <= (int64_t)p.flush_src;
@@ -1188,8 +1193,8 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   // taper culling: per baseline group the first source it still has to sum (tables staged by set_sky_*); a launch over the whole sky
   // can only skip the leading sources of the FIRST run
   const int cpr = pl.f32 ? 1 : 0;
-  const bool cull = pl.pk && ctx->taper && ctx->cull_any[cpr] && ctx->cull_first.p && ctx->cull_nruns == (int)ctx->kappa_runs.size() &&
-                    (size_t)pl.nbgroups == ctx->grp_maxlen.size();             // (the packed fp32 kernels: see skyvis_rec_body)
+  const bool cull = (pl.pk || g64) && ctx->taper && ctx->cull_any[cpr] && ctx->cull_first.p && ctx->cull_nruns == (int)ctx->kappa_runs.size() &&
+                    (size_t)pl.nbgroups == ctx->grp_maxlen.size();             // (the packed fp32 kernels and the grouped fp64 kernel)
   auto cull_table = [&](size_t r) { return (const int32_t*)ctx->cull_first.p + ((size_t)cpr * ctx->cull_nruns + r) * (size_t)pl.nbgroups; };
   if (cull && !split) p.src_first = cull_table(0);
   ctx->timing.last_culled_fraction = cull ? ctx->cull_frac[cpr] : 0.0;
@@ -1216,6 +1221,23 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     ctx->timing.last_taper_split = launches;
   } else if (pl.pk) {
     HIPCHK(ctx, launch_skyvis_rec_f32pk(p, pl.ct, ctx->stream));
+  } else if (g64) {
+    // run by run when the sky comes in runs of one source size (so that every run's leading sources can be culled); with a source
+    // split (partial cubes, written once per split) only a sky that is one run -- otherwise one launch over the whole sky
+    const size_t nruns = ctx->kappa_runs.size();
+    if (nruns > 1 && pl.nsplit == 1) {
+      for (size_t r = 0; r < nruns; ++r) {
+        const prisim_ctx::KappaRun& run = ctx->kappa_runs[r];
+        SkyvisParams q = p;
+        q.src_lo = run.lo; q.src_hi = run.hi;
+        q.src_per_split = round_up(run.hi - run.lo, pl.chunk);
+        q.accumulate = r > 0 ? 1 : 0;
+        q.src_first = cull ? cull_table(r) : nullptr;
+        HIPCHK(ctx, launch_skyvis_taper_f64(q, pl.ct, ctx->stream));
+      }
+    } else {
+      HIPCHK(ctx, launch_skyvis_taper_f64(p, pl.ct, ctx->stream));
+    }
   } else {
     HIPCHK(ctx, launch_skyvis_rec(p, pl.f32, pl.ct, ctx->stream));
   }

@@ -60,6 +60,9 @@ hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_
 hipError_t launch_skyvis_rec_f32pk(const SkyvisParams& p, int ct, hipStream_t stream);
 // split taper form for a source range of one source size (ct = 64; p.src_lo/src_hi, p.kappa0, p.split_flags, p.accumulate)
 hipError_t launch_skyvis_rec_f32pk_split(const SkyvisParams& p, int ct, hipStream_t stream);
+// fp64 sky-sum with the taper in the grouped form (ct = 16 or 32; rows packed in NATURAL channel order: launch_pack interleave = 0;
+// p.src_lo/src_hi, p.src_first, p.accumulate as for the packed fp32 kernels)
+hipError_t launch_skyvis_taper_f64(const SkyvisParams& p, int ct, hipStream_t stream);
 // beam-weighted sky moments of sources [s_lo, s_hi) per channel into out[4][nchan] (device), see k_taper_moments
 // flags of the split taper kernel's baseline groups from those moments, on the device (k_split_flags); *count += uncorrected groups
 hipError_t launch_split_flags(const double* mom, int64_t nchan, const double* grp_h, const double* grp_z, const int32_t* lift_flags, int nbg,

@@ -209,6 +209,48 @@ __device__ __forceinline__ double div_unit_range_fast_f64(double a, double c) {
   return a * r;
 }
 
+// exp(x) for x <= 0 down to the underflow threshold from a table of 2^(i / kExpTabN) in LDS, split like sincos_tab so that the LDS read
+// can be issued a piece ahead of its use: k = rint(x kExpTabN / ln2) by the 1.5 * 2^52 shift (its low mantissa word is k in two's
+// complement), residual r = x - k ln2 / kExpTabN in two pieces (|k| < 2^21, the high piece carries 32 bits: the product is exact),
+// |r| <= 3.4e-4 so exp(r) = 1 + r + r^2/2 + r^3/6 + r^4/24 (next term 4e-20).  12 fp64 instructions against ~40 for the library call.
+constexpr int kExpTabN = 1024;
+struct ExpPhase { double r, t; int e; };
+__device__ __forceinline__ ExpPhase exp_tab_front(double x, const double* etab) {
+  x = __builtin_fmax(x, -800.0);
+  const double shifted = __builtin_fma(x, 1477.3197218702985, 6755399441055744.0);
+  const double k = shifted - 6755399441055744.0;
+  const int lo = __double2loint(shifted);
+  ExpPhase f;
+  f.r = __builtin_fma(k, 4.1024561256651217e-14, __builtin_fma(k, -0x1.62e42ff000000p-11, x));
+  f.t = etab[lo & (kExpTabN - 1)];
+  f.e = lo >> 10;
+  return f;
+}
+__device__ __forceinline__ double exp_tab_back(const ExpPhase& f) {
+  double q = __builtin_fma(f.r, 4.16666666666666666667e-02, 1.66666666666666666667e-01);
+  q = __builtin_fma(q, f.r, 0.5);
+  q = __builtin_fma(q, f.r, 1.0);
+  q = __builtin_fma(q, f.r, 1.0);
+  return __builtin_ldexp(f.t * q, f.e);
+}
+__device__ __forceinline__ void fill_exp_table(double* etab) {
+  for (int i = threadIdx.x; i < kExpTabN; i += kBlockThreads) etab[i] = exp2((double)i / (double)kExpTabN);
+}
+
+// exp(x) for |x| <= 0.1: Taylor series to x^9 (next term 2.8e-17)
+__device__ __forceinline__ double exp_series9(double x) {
+  double q = 2.75573192239858906526e-06;                                       // 1/9!
+  q = __builtin_fma(q, x, 2.48015873015873015873e-05);
+  q = __builtin_fma(q, x, 1.98412698412698412698e-04);
+  q = __builtin_fma(q, x, 1.38888888888888888889e-03);
+  q = __builtin_fma(q, x, 8.33333333333333333333e-03);
+  q = __builtin_fma(q, x, 4.16666666666666666667e-02);
+  q = __builtin_fma(q, x, 1.66666666666666666667e-01);
+  q = __builtin_fma(q, x, 0.5);
+  q = __builtin_fma(q, x, 1.0);
+  return __builtin_fma(q, x, 1.0);
+}
+
 // fp64 source-shape taper along frequency as a second-order multiplicative recurrence of the Gaussian w = exp(-g f^2):
 //   w_{k+1} = w_k q_k,  q_{k+1} = q_k h,   h = exp(-2 g df^2);   w_{k-1} = w_k q'_k, q'_{k-1} = q'_k h
 // Returns the weights of channels HC (wu) and HC-1 (wd) of the tile centred on fc and the ratios that advance them.
@@ -303,9 +345,20 @@ __device__ __forceinline__ bool block_item(const SkyvisParams& p, int& slab, int
 }
 
 // LIFT: lifting (three-shear) form of the step rotation, see skyvis_rec_f32pk_body below; chosen per baseline group by the host.
-template <typename T, int CT, bool TAPER, bool LIFT>
-__device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned char* flush_lds, unsigned char* pf_area, const double2* tab) {
+// TAPER: 0 = none; 1 = exact second-order amplitude recurrence on the pbflux operand (8 instructions per term);
+//   2 (fp64 only, k_skyvis_taper_f64) = the GROUPED form of the packed fp32 kernels carried over to fp64, made exact: ONE chain from the
+//   tile's first channel, zeta_j = w_j z_j advanced by a complex factor rho_t = r q_t that is held over a group of 8 steps at the group's
+//   geometric-mean amplitude ratio q_t = (w_{8t+8} / w_{8t})^(1/8) -- exact at the group ends, low by exp(nu m (8 - m)), nu = g df^2, at
+//   step m inside, and that factor (four per-lane values X^7, X^12, X^15, X^16 formed once per (source, baseline, tile)) is put back on
+//   the wave-uniform pbflux operand: 7 instructions per term (1 correction multiply, 2 accumulate FMAs, 4 for zeta * rho) and
+//   rho_{t+1} = rho_t exp(-16 nu) per group.  Nothing is truncated: every factor is formed to fp64 accuracy (short series, or the library
+//   exp on a wave-uniform slow path for steps that are not small).  Rows are packed in natural channel order, one group = one 64-byte piece.
+template <typename T, int CT, int TAPER, bool LIFT>
+__device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned char* flush_lds, unsigned char* pf_area, const double2* tab,
+                                                const double* etab = nullptr) {
   static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
+  static_assert(TAPER != 2 || (sizeof(T) == 8 && CT >= 16 && !LIFT), "the grouped fp64 taper: 16- or 32-channel tiles, folded (no lifting)");
+  constexpr bool GROUPED = TAPER == 2;
   constexpr int HC = CT / 2;                       // channels per chain (here the taper multiplies pbflux, so z stays a pure rotation
                                                    // and the lifting form applies with or without it)
   // The row is fetched in NPART pieces of at most 64 bytes (16 SGPRs) through two SGPR buffers: with half rows (2 x 32 SGPRs at
@@ -323,11 +376,27 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   const int tile = slab % p.ntiles;
   const int split = slab / p.ntiles;
 
-  const int64_t s_begin = (int64_t)split * p.src_per_split;
+  int64_t s_begin = (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
   if (s_end > p.nsrc) s_end = p.nsrc;
-  // (no taper culling here: it is built into the packed fp32 kernels only -- a variable source range cost k_skyvis_rec<double,32,true>
-  // 47 more SGPR spills, 33 of them as lane moves inside its source loop)
+  // (TAPER == 1 bodies: no source ranges, no taper culling -- a variable source range cost k_skyvis_rec<double,32,true> 47 more SGPR
+  // spills, 33 of them as lane moves inside its source loop; the grouped fp64 kernel has both)
+  if constexpr (GROUPED) {
+    // sources [src_lo, src_hi) of the sky (a run of one source size when the host walks the sky run by run), cut into nsplit pieces;
+    // taper culling as in the packed fp32 kernels: the group's leading sources are provably below the tolerance (capi.cpp) and what is
+    // left is cut into nsplit equal pieces again
+    s_begin = p.src_lo + (int64_t)split * p.src_per_split;
+    s_end = s_begin + p.src_per_split;
+    if (s_end > p.src_hi) s_end = p.src_hi;
+    if (p.src_first != nullptr) {
+      const int64_t f = p.src_first[bg];
+      if (f > p.src_lo) {
+        const int64_t per = (p.src_hi - f + p.nsplit - 1) / p.nsplit;
+        s_begin = f + (int64_t)split * per;
+        s_end = s_begin + per < p.src_hi ? s_begin + per : p.src_hi;
+      }
+    }
+  }
 
   const int tid = threadIdx.x;
   const int64_t b_raw = (int64_t)bg * kBlockThreads + tid;
@@ -338,7 +407,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
 
   const double bx = p.bl_x[b], by = p.bl_y[b], bz = p.bl_z[b];
   const int k0 = tile * CT;
-  const double fc = p.f0 + (double)(k0 + HC) * p.df;   // frequency of the seed (centre) channel
+  const double fc = p.f0 + (double)(k0 + (GROUPED ? 0 : HC)) * p.df;   // frequency of the seed channel (the tile's centre; GROUPED: its first)
   const double df = p.df;
   const double fc4 = 4.0 * fc, df4 = 4.0 * df;         // quarter-cycle scaling for sincos_qcycles
   const double fcN = fc * kTabN, dfN = df * kTabN, dfN_half = df * (0.5 * kTabN);   // table scaling for sincos_tab (fp64)
@@ -360,7 +429,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   const cfsq_p gfq = (cfsq_p)(uintptr_t)(p.fsq_pairs ? p.fsq_pairs + (size_t)tile * CT : nullptr);   // fp32 taper only
 
   double* const out = p.out + ((size_t)split * p.nbl * p.nchan) * 2;   // partial buffer of this split
-  bool first_flush = true;
+  bool first_flush = !GROUPED || p.accumulate == 0;    // accumulate: an earlier launch (another source run) already wrote this slot
 
   using FV = typename FlushCfg<T>::vec;
   constexpr int FCH = FlushCfg<T>::ch < CT ? FlushCfg<T>::ch : CT;
@@ -430,10 +499,17 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
     // arithmetic and no s_waitcnt ever has a table read and a fresh scalar request outstanding together (LDS and SMEM share
     // lgkmcnt and SMEM returns out of order: the only usable wait is lgkmcnt(0), which would otherwise expose a scalar-cache round
     // trip at the top of every source).  The directions are therefore requested TWO sources ahead.
-    struct Pre { double d, kap; TabPhase pc, ps; };
+    struct Pre { double d, kap; TabPhase pc, ps; ExpPhase ex; };
     auto front = [&](Pre& q) {
       q.d = __builtin_fma(bx, sv[0], __builtin_fma(by, sv[1], bz * sv[2]));   // seconds
-      if constexpr (TAPER) {
+      if constexpr (GROUPED) {
+        // g = kappa_s (|b|^2/c^2 - tau^2), tau = d + b.s_pc/c the un-offset delay; the table read of w_0 = exp(-g f_0^2) goes out here
+        const double tau = q.d + bpc;
+        double gq = sv[3] * __builtin_fma(-tau, tau, bl2_c2);
+        gq = __builtin_fmax(gq, 0.0);              // |b|^2 >= (b.s)^2 up to rounding
+        q.kap = gq;
+        q.ex = exp_tab_front(-gq * (fc * fc), etab);
+      } else if constexpr (TAPER != 0) {
         double kap = sv[3];
         asm volatile("" : "+v"(kap));            // carried in a VGPR: two more live SGPR pairs tipped the taper bodies into lane spills
         q.kap = kap;
@@ -506,7 +582,9 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
       const T rr = rc, ri = -rs;      // step forward; step backward is conj(r)
       if constexpr (LIFT && sizeof(T) == 4) tl = -tan_pi_y((float)(0.25 * th4));      // |theta| <= 1/8 cycle guaranteed
       T dr, di;                            // z * conj(r): channel HC-1
-      if constexpr (LIFT) {
+      if constexpr (GROUPED) {
+        dr = rr; di = ri;                  // (set below: the step factor rho)
+      } else if constexpr (LIFT) {
         // one inverse lifting step (t -> -t, s -> -s)
         const T xd = fma_(tl, ui, ur);
         di = fma_(-ri, xd, ui);
@@ -519,7 +597,38 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
       double gq = 0.0;
       float g2 = 0.f;
       double wu = 1.0, wd = 1.0, qu = 1.0, qd = 1.0, h = 1.0;
-      if constexpr (TAPER) {
+      double cm[4] = {1.0, 1.0, 1.0, 1.0}, hg = 1.0;      // GROUPED: X^7, X^12, X^15, X^16 (X = exp(g df^2)) and exp(-16 g df^2)
+      if constexpr (GROUPED) {
+        // ln w_j = -g (f_0 + j df)^2.  Group t (steps 8t .. 8t+8) holds the amplitude ratio q_t = exp(-a - nu (16 t + 8)), a = 2 g df f_0,
+        // nu = g df^2; zeta_0 = w_0 z_0, rho_0 = q_0 r, rho_{t+1} = rho_t exp(-16 nu); step m of a group is low by X^(m (8 - m)).
+        const double gq2 = pre.kap;
+        const double a = gq2 * (2.0 * df * fc);
+        const double u = gq2 * (df * df);
+        double E, y8;
+        if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(a) < 0.1 && u < 3.0e-5)) == 0) {
+          // the usual case (df << f): all by short series -- exp(-a) to a^9 (next term 2.8e-17), X = exp(u) to u^3 (next 3e-20), the
+          // powers by 7 multiplications, exp(-8 u) to (8u)^4 (next 2.7e-20)
+          E = exp_series9(-a);
+          const double X = __builtin_fma(u, __builtin_fma(u, __builtin_fma(u, 1.66666666666666666667e-01, 0.5), 1.0), 1.0);
+          const double X2 = X * X, X3 = X2 * X, X5 = X3 * X2;
+          cm[0] = X5 * X2;
+          cm[1] = cm[0] * X5;
+          cm[2] = cm[1] * X3;
+          cm[3] = cm[2] * X;
+          const double v = -8.0 * u;
+          y8 = __builtin_fma(v, __builtin_fma(v, __builtin_fma(v, __builtin_fma(v, 4.16666666666666666667e-02, 1.66666666666666666667e-01), 0.5), 1.0), 1.0);
+        } else {
+          // wave-uniform slow path: coarse channel grids or very long baselines over large sources
+          E = exp(-a);
+          cm[0] = exp(7.0 * u); cm[1] = exp(12.0 * u); cm[2] = exp(15.0 * u); cm[3] = exp(16.0 * u);
+          y8 = exp(-8.0 * u);
+        }
+        hg = y8 * y8;
+        const double w0 = exp_tab_back(pre.ex);
+        const double q0 = E * y8;
+        ur = w0 * zc; ui = -(w0 * zs);                 // zeta_0
+        dr = q0 * rr; di = q0 * ri;                    // rho_0 (the down-chain registers carry the step factor in this form)
+      } else if constexpr (TAPER != 0) {
         const double tau = d + bpc;
         gq = pre.kap * (bl2_c2 - tau * tau);
         gq = gq > 0.0 ? gq : 0.0;      // |b|^2 >= (b.s)^2 up to rounding
@@ -536,7 +645,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
           const int j = jbase + jj;
           const int ku = HC + j, kd = HC - 1 - j;
           T pu = r[2 * jj], pd = r[2 * jj + 1];
-          if constexpr (TAPER) {
+          if constexpr (TAPER != 0) {
             if constexpr (sizeof(T) == 4) {
               pu *= __builtin_amdgcn_exp2f(g2 * gfq[2 * j]);
               pd *= __builtin_amdgcn_exp2f(g2 * gfq[2 * j + 1]);
@@ -566,7 +675,29 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
           }
         }
       };
-      pairs(ra, 0);
+      // GROUPED: one piece = one group of 8 channels in natural order (7 instructions per term)
+      auto group = [&](const T (&r)[NH], int t) {
+        if constexpr (GROUPED) {
+          constexpr int kmap[8] = {0, 0, 1, 2, 3, 2, 1, 0};            // m (8 - m) = 7, 12, 15, 16, 15, 12, 7 for m = 1..7
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const int k = 8 * t + m;
+            T pc = r[m];
+            if (m != 0) pc *= (T)cm[kmap[m]];
+            acc_re[k] = fma_(pc, ur, acc_re[k]);
+            acc_im[k] = fma_(pc, ui, acc_im[k]);
+            if (!(t == NPART - 1 && m == 7)) {
+              const T t0 = ui * di, t1 = ur * di;
+              const T nr = fma_(ur, dr, -t0);
+              const T ni = fma_(ui, dr, t1);
+              ur = nr; ui = ni;
+            }
+          }
+          if (t + 1 < NPART) { dr *= (T)hg; di *= (T)hg; }
+        }
+      };
+      if constexpr (GROUPED) group(ra, 0);
+      else pairs(ra, 0);
 #pragma unroll
       for (int ph = 1; ph < NPART; ++ph) {
         __builtin_amdgcn_sched_barrier(0);
@@ -593,8 +724,13 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
           if (TAPER) sv[3] = dn[3];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ph & 1) pairs(rb, ph * (NH / 2));
-        else pairs(ra, ph * (NH / 2));
+        if constexpr (GROUPED) {
+          if (ph & 1) group(rb, ph);
+          else group(ra, ph);
+        } else {
+          if (ph & 1) pairs(rb, ph * (NH / 2));
+          else pairs(ra, ph * (NH / 2));
+        }
       }
       pre = pre_next;
     }
@@ -622,10 +758,25 @@ void k_skyvis_rec(const SkyvisParams p) {
   int slab_, bg;
   const bool in_range = block_item(p, slab_, bg);                  // padding blocks read flag 0 and leave inside the body
   if (in_range && p.lift_flags != nullptr && p.lift_flags[bg] != 0) {   // block-uniform; the two bodies share no live state
-    skyvis_rec_body<T, CT, TAPER, true>(p, flush_lds, pf_area, tab);
+    skyvis_rec_body<T, CT, TAPER ? 1 : 0, true>(p, flush_lds, pf_area, tab);
     return;
   }
-  skyvis_rec_body<T, CT, TAPER, false>(p, flush_lds, pf_area, tab);
+  skyvis_rec_body<T, CT, TAPER ? 1 : 0, false>(p, flush_lds, pf_area, tab);
+}
+
+// fp64 sky-sum with the source-shape taper in the grouped form (TAPER = 2 bodies above): interferometry.py:6257-6283, 6332-6335 at the
+// reference's default precision.  Sources [src_lo, src_hi), taper culling through src_first, accumulate for a later source run.
+template <int CT>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2)))
+void k_skyvis_taper_f64(const SkyvisParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<double>()];
+  __shared__ __attribute__((aligned(16))) unsigned char pf_area[kPrefetchLdsBytes];
+  __shared__ double2 tab_lds[kTabN];
+  __shared__ double etab_lds[kExpTabN];
+  fill_phasor_table(tab_lds);
+  fill_exp_table(etab_lds);
+  __syncthreads();                                               // the only block barrier of the kernel: before any early exit
+  skyvis_rec_body<double, CT, 2, false>(p, flush_lds, pf_area, tab_lds, etab_lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1637,6 +1788,18 @@ hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_
     }
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_skyvis_taper_f64(const SkyvisParams& p, int ct, hipStream_t stream) {
+  const int64_t items = (int64_t)p.ntiles * p.nsplit * p.nbgroups;          // see block_item()
+  if (items <= 0 || items > 0x3fffffffLL || !p.taper) return hipErrorInvalidValue;
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
+  switch (ct) {
+    case 16: hipLaunchKernelGGL((k_skyvis_taper_f64<16>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
+    case 32: hipLaunchKernelGGL((k_skyvis_taper_f64<32>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_skyvis_grad_f32(const SkyvisParams& p, hipStream_t stream) {

@@ -252,7 +252,7 @@ def test_fp32_split_taper_runs_of_one_source_size(ctx, monkeypatch):
 def test_taper_culling_skips_only_what_is_below_the_tolerance(ctx, monkeypatch):
     """Long baselines resolve out diffuse pixels: w = exp(-kappa |b_perp|^2 f^2/c^2) underflows for the sources nearest the zenith.  With
     a run's sources listed by decreasing altitude the library starts every baseline group's source loop behind the leading sources whose
-    summed weight is below exp(-18) of sum|pbflux| (packed fp32 kernels; fp64 requests sum everything).  MWA-like baselines (to 2.5 km, sorted by length like the
+    summed weight is below exp(-18) of sum|pbflux| (packed fp32 kernels; exp(-28) for the grouped fp64 kernel).  MWA-like baselines (to 2.5 km, sorted by length like the
     driver's) over degree-size pixels: a good share of the (source, baseline) pairs goes, the result stays inside the tolerances against
     the oracle that sums everything, and equals the unculled result to the cull bound."""
     rng = NP.random.default_rng(91)
@@ -277,8 +277,8 @@ def test_taper_culling_skips_only_what_is_below_the_tolerance(ctx, monkeypatch):
             ctx.compute(precision=prec)
             res[cull] = ctx.get_vis()
             frac = ctx.timing()['last_culled_fraction']
-            # (the packed fp32 kernels cull; fp64 requests sum everything)
-            assert (frac > 0.20) if (cull == '1' and prec == _abi.PRISIM_FP32) else (frac == 0.0), (prec, cull, frac)
+            # (the packed fp32 kernels cull below exp(-18), the grouped fp64 kernel below exp(-28) of sum|pbflux|)
+            assert (frac > (0.20 if prec == _abi.PRISIM_FP32 else 0.10)) if cull == '1' else (frac == 0.0), (prec, cull, frac)
             assert relerr(res[cull], ref, pb) <= TOL[prec], (prec, cull)
         assert relerr(res['1'], res['0'], pb) <= bound, prec
     monkeypatch.delenv('PRISIM_HIP_TAPER_CULL')
@@ -287,6 +287,67 @@ def test_taper_culling_skips_only_what_is_below_the_tolerance(ctx, monkeypatch):
     ctx.set_sky(dc[perm], pb[perm], pc, fwhm_deg=fw)
     ctx.compute(precision=_abi.PRISIM_FP32)
     assert ctx.timing()['last_culled_fraction'] < 0.05 and relerr(ctx.get_vis(), ref, pb) <= TOL[_abi.PRISIM_FP32]
+
+
+def test_fp64_grouped_taper_runs_culling_and_slow_path(ctx, monkeypatch):
+    """fp64 requests with the source-shape taper (the reference's default precision, interferometry.py:6332-6335) run the grouped kernel
+    k_skyvis_taper_f64 on 16- / 32-channel tiles: one chain per tile, the amplitude ratio held over groups of 8 channels and the known
+    in-group factor put back exactly on the pbflux operand.  Checked against the C oracle (1e-11 S_f) and against the exact second-order
+    kernel (PRISIM_HIP_TAPER_F64_GROUP=0) on: a sky of three source runs (point sources + two pixel sizes; run by run with accumulation
+    at nsplit = 1, one launch under a source split), sizes that vary source by source, a coarse descending channel grid with very
+    large sources (the wave-uniform library-exp path), and long baselines whose second run sheds its leading sources (culling)."""
+    rng = NP.random.default_rng(404)
+    nbl = 600
+    bl = rng.uniform(-290.0, 290.0, size=(nbl, 3)); bl[:, 2] *= 0.01
+    pc = O.altaz2dircos(NP.array([[84.0, 200.0]]))[0]
+    nsrc = 900
+    alt = NP.degrees(NP.arcsin(rng.uniform(NP.sin(NP.radians(4.0)), 1.0, nsrc)))
+    dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, nsrc)), axis=1))
+
+    def both(bl_, ch_, dc_, pb_, fw_, tunings, expect_group=True):
+        ref = CO.skyvis(bl_, ch_, dc_, pb_, pc, fwhm_deg=fw_)
+        ctx.set_array(bl_, ch_)
+        ctx.set_sky(dc_, pb_, pc, fwhm_deg=fw_)
+        for ct, nsplit in tunings:
+            ctx.set_tuning(ct, 0, nsplit)
+            monkeypatch.setenv('PRISIM_HIP_TAPER_F64_GROUP', '1')
+            ctx.compute(precision=_abi.PRISIM_FP64)
+            vg = ctx.get_vis()
+            assert relerr(vg, ref, pb_) <= TOL[_abi.PRISIM_FP64], (ct, nsplit)
+            monkeypatch.setenv('PRISIM_HIP_TAPER_F64_GROUP', '0')
+            ctx.compute(precision=_abi.PRISIM_FP64)
+            assert relerr(ctx.get_vis(), vg, pb_) <= 1e-12, (ct, nsplit)
+        monkeypatch.delenv('PRISIM_HIP_TAPER_F64_GROUP')
+        ctx.set_tuning(0, 0, 0)
+
+    ch = 150e6 + (NP.arange(100) - 50) * 97656.25                        # 100 channels: a ragged last tile at 16 and at 32
+    pb = rng.uniform(0.5, 10.0, size=(nsrc, 1)) * rng.uniform(0.5, 1.0, size=(nsrc, ch.size))
+    fw_runs = NP.concatenate((NP.zeros(200), NP.full(400, 0.458), NP.full(300, 0.916)))
+    both(bl, ch, dc, pb, fw_runs, [(32, 1), (16, 1), (32, 3), (16, 2), (0, 0)])
+    both(bl, ch, dc, pb, rng.uniform(0.0, 1.2, nsrc), [(32, 1), (16, 0)])
+    # coarse, descending grid + degree-scale sources on 2.5 km baselines: |2 g df f| and g df^2 leave the series' range
+    ch2 = 200e6 - NP.arange(40) * 3.0e6
+    bl2 = bl * 8.0
+    pb2 = rng.uniform(0.5, 10.0, size=(nsrc, 1)) * rng.uniform(0.5, 1.0, size=(nsrc, ch2.size))
+    both(bl2, ch2, dc, pb2, NP.full(nsrc, 2.0), [(32, 1), (16, 1)])
+    # culling in the SECOND run: point sources, then nside-64-size pixels by decreasing altitude under MWA-like baselines
+    xy = rng.normal(0.0, 800.0, size=(1024, 2))
+    bl3 = NP.hstack((xy, rng.normal(0.0, 0.5, size=(1024, 1))))
+    bl3 = bl3[NP.argsort(NP.sqrt(NP.sum(bl3 ** 2, axis=1)))]
+    ch3 = 170e6 + NP.arange(64) * 40e3
+    alt3 = NP.concatenate((alt[:100], NP.sort(alt[100:])[::-1]))
+    dc3 = O.altaz2dircos(NP.stack((alt3, rng.uniform(0, 360, nsrc)), axis=1))
+    pb3 = rng.uniform(0.5, 10.0, size=(nsrc, 1)) * rng.uniform(0.5, 1.0, size=(nsrc, ch3.size))
+    fw3 = NP.concatenate((NP.zeros(100), NP.full(nsrc - 100, 0.916)))
+    ref3 = CO.skyvis(bl3, ch3, dc3, pb3, pc, fwhm_deg=fw3)
+    ctx.set_array(bl3, ch3)
+    ctx.set_sky(dc3, pb3, pc, fwhm_deg=fw3)
+    for ct in (32, 16):
+        ctx.set_tuning(ct, 0, 1)
+        ctx.compute(precision=_abi.PRISIM_FP64)
+        assert ctx.timing()['last_culled_fraction'] > 0.05, ctx.timing()
+        assert relerr(ctx.get_vis(), ref3, pb3) <= TOL[_abi.PRISIM_FP64], ct
+    ctx.set_tuning(0, 0, 0)
 
 
 @pytest.mark.parametrize('taper', [False, True])
