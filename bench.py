@@ -31,8 +31,10 @@ Rank 0 prints ONE JSON line.  Beside the contract's keys it carries (N = 1 only,
   e2e_host                  the same with every snapshot landing in (pinned) HOST memory: downloads overlapped with the next sky-sum
   delay_ps                  delay power spectra of the K resident snapshots (interferometry.py:8114-8134 + delay_spectrum.py:3992):
                             device time, FFT count, achieved algorithmic GB/s against the 8 TB/s HBM roofline
-  other_kernels             one timed launch each of the fp64 kernel (headline sky) and of the packed fp32 taper kernel (config 3 with its
-                            nside-128 diffuse half): the kernels the headline workload itself does not run
+  other_kernels             min / median of 5 timed launches each of the fp64 kernel (headline sky), the fused gradient kernels, and -- on config 3
+                            with its nside-128 diffuse half -- the packed fp32 taper kernel and the grouped fp64 taper kernel: the kernels the
+                            headline workload itself does not run
+  config2                   BASELINE config 2 (HERA-19 x 256 ch x nside-16 diffuse, fp64): device time of one snapshot, min / median of 20
 """
 import argparse
 import hashlib
@@ -53,6 +55,10 @@ FLOPS_PER_TERM = 10.0       # rotate (4 mul + 2 add) + accumulat
 # accumulate (4 flop); what the taper adds is advancing the ratio, rho_{k+1} = rho_k * h: 2 real multiplies per term = 12 flop, 8 VALU slots.
 FLOPS_PER_TERM_TAPER = 12.0
 PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # MI355X_MICROARCH.md chip table: vector FP32 157.3 TF; FP64 = half
+# What the instruction the kernels are built from actually sustains on this chip: back-to-back v_pk_fma_f32 on every SIMD,
+# tools/microbench_valu.hip (profiles/r01_microbench_valu.txt): 126.6 TFLOP/s at 4 waves per SIMD (the chip does not hold the 2.4 GHz of the datasheet figure
+# under a full-width FMA stream); fp64 v_fma_f64 64.4.  Printed beside the datasheet fraction, never instead of it.
+MEASURED_PEAK_TFLOPS = {'f32': 126.6, 'f64': 64.4}
 HBM_PEAK_GBS = 8000.0
 XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md: 7 point-to-point links of ~153 GB/s per GPU
 
@@ -287,53 +293,96 @@ def profiled_traffic(kernel_tag):
     return best
 
 
-def other_kernels(ctx, cfg, zen):
-    """Driver-run figures for the sky-sum kernels the headline workload does not exercise (same array, same context, one timed launch each
-    after one warm-up): the fp64 kernel on the headline sky, and the packed fp32 kernel with the source-shape taper on BASELINE config 3
-    as worded -- 1e4 point sources + nside=128 diffuse (108 048 sources above the horizon), the kernel every diffuse configuration runs."""
+def other_kernels(ctx, cfg, zen, nlaunch=5):
+    """Driver-run figures for the sky-sum kernels the headline workload does not exercise (same array, same context; every figure is the
+    MINIMUM and the MEDIAN of `nlaunch` timed launches after one warm-up): the fp64 kernel on the headline sky, the fused gradient
+    kernels, and -- on BASELINE config 3 as worded, 1e4 point sources + nside=128 diffuse (108 048 sources above the horizon) -- the packed
+    fp32 taper kernel (every diffuse configuration's kernel) and the grouped fp64 taper kernel (the reference's default precision on such a
+    sky, interferometry.py:6332-6335), each against both contracts (10 flop per term, and the taper's 12)."""
     bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
-    res = {}
+    res = {'launches_per_figure': nlaunch}
 
-    def timed(prec):
-        best = None
-        for rep in range(2):
-            ctx.compute(precision=prec, slot=0)
+    def timed(prec, want_grad=False, n=nlaunch):
+        ctx.compute(precision=prec, want_grad=want_grad, slot=0)          # warm-up (first use of a kernel, table uploads)
+        ctx.sync()
+        ks, cs, tm = [], [], None
+        for rep in range(n):
+            ctx.compute(precision=prec, want_grad=want_grad, slot=0)
             ctx.sync()
-            best = ctx.timing()
-        return best
+            tm = ctx.timing()
+            ks.append(tm['last_kernel_ms'])
+            cs.append(tm['last_compute_ms'])
+        return {'kernel_ms_min': min(ks), 'kernel_ms_median': float(NP.median(ks)), 'compute_ms_min': min(cs),
+                'compute_ms_median': float(NP.median(cs))}, tm
 
-    def timed_grad(prec):
-        best = None
-        for rep in range(2):
-            ctx.compute(precision=prec, want_grad=True, slot=0)
-            ctx.sync()
-            t = ctx.timing()['last_compute_ms']
-            best = t if best is None else min(best, t)
-        return best
+    def frac(terms, ms, flops, key):
+        return terms * flops / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[key]
 
-    plain32 = timed(_abi.PRISIM_FP32)['last_compute_ms']
-    tm = timed(_abi.PRISIM_FP64)
-    plain64 = tm['last_compute_ms']
-    g64, g32 = timed_grad(_abi.PRISIM_FP64), timed_grad(_abi.PRISIM_FP32)
-    res['gradient'] = {'what': 'visibility + baseline gradient (interferometry.py:6330-6343) in one fused pass; ms per snapshot incl. pack/prep',
-                       'fp64_ms': g64, 'fp64_over_plain_pass': g64 / plain64, 'fp32_ms': g32, 'fp32_over_plain_pass': g32 / plain32,
-                       'kernels': 'k_skyvis_grad_f64 (MFMA 4x4x4) / k_skyvis_grad_f32pk'}
+    p32, _ = timed(_abi.PRISIM_FP32)
+    p64, tm = timed(_abi.PRISIM_FP64)
     terms = float(tm['last_terms'])
-    res['fp64'] = {'kernel': 'k_skyvis_rec<double,%d>' % tm['last_chan_tile'], 'kernel_ms': tm['last_kernel_ms'], 'terms_per_s': terms / (tm['last_kernel_ms'] * 1e-3),
-                   'roofline_frac': terms * FLOPS_PER_TERM / (tm['last_kernel_ms'] * 1e-3) / 1e12 / PEAK_TFLOPS['f64'], 'workload': cfg['name']}
+    res['fp64'] = dict(p64, kernel='k_skyvis_rec<double,%d>' % tm['last_chan_tile'], terms_per_s=terms / (p64['kernel_ms_min'] * 1e-3),
+                       roofline_frac=frac(terms, p64['kernel_ms_min'], FLOPS_PER_TERM, 'f64'),
+                       roofline_frac_median=frac(terms, p64['kernel_ms_median'], FLOPS_PER_TERM, 'f64'), workload=cfg['name'])
+    g64, _ = timed(_abi.PRISIM_FP64, want_grad=True)
+    g32, _ = timed(_abi.PRISIM_FP32, want_grad=True)
+    res['gradient'] = {'what': 'visibility + baseline gradient (interferometry.py:6330-6343) in one fused pass; ms per snapshot incl. pack/prep; '
+                               'roofline against 16 flop per term (10 + 6 for the three extra accumulations)',
+                       'fp64_ms': g64['compute_ms_min'], 'fp64_ms_median': g64['compute_ms_median'],
+                       'fp64_over_plain_pass': g64['compute_ms_min'] / p64['compute_ms_min'],
+                       'fp64_roofline_frac_16flop': frac(terms, g64['kernel_ms_min'], 16.0, 'f64'),
+                       'fp32_ms': g32['compute_ms_min'], 'fp32_ms_median': g32['compute_ms_median'],
+                       'fp32_over_plain_pass': g32['compute_ms_min'] / p32['compute_ms_min'],
+                       'fp32_roofline_frac_16flop': frac(terms, g32['kernel_ms_min'], 16.0, 'f32'),
+                       'kernels': 'k_skyvis_grad_f64 (MFMA 4x4x4) / k_skyvis_grad_f32pk'}
     cfg_d = W.config3(with_diffuse=True)
     sky_d = cfg_d['sky']
     ctx.set_sky_analytic(sky_d['dircos'], sky_d['flux_ref'], sky_d['spindex'], sky_d['ref_freq'], _abi.PRISIM_BEAM_AIRY, cfg_d['diameter'], zen, zen,
                          fwhm_deg=sky_d['fwhm_deg'])
-    tm = timed(_abi.PRISIM_FP32)
+    t32, tm = timed(_abi.PRISIM_FP32)
     terms = float(tm['last_terms'])
-    res['fp32_taper'] = {'kernel': 'k_skyvis_rec_f32pk<%d,taper>' % tm['last_chan_tile'], 'kernel_ms': tm['last_kernel_ms'],
-                         'terms_per_s': terms / (tm['last_kernel_ms'] * 1e-3), 'grouped_recurrence': bool(tm['last_taper_group']),
-                         'roofline_frac_vs_no_taper_contract': terms * FLOPS_PER_TERM / (tm['last_kernel_ms'] * 1e-3) / 1e12 / PEAK_TFLOPS['f32'],
-                         'roofline_frac_vs_taper_contract': terms * FLOPS_PER_TERM_TAPER / (tm['last_kernel_ms'] * 1e-3) / 1e12 / PEAK_TFLOPS['f32'],
-                         'taper_split_runs': tm.get('last_taper_split', 0), 'taper_uncorrected_groups': tm.get('last_split_uncorrected_groups', 0),
-                         'workload': cfg_d['name'] + ' (taper on)'}
+    res['fp32_taper'] = dict(t32, kernel='k_skyvis_rec_f32pk<%d,taper>' % tm['last_chan_tile'], terms_per_s=terms / (t32['kernel_ms_min'] * 1e-3),
+                             grouped_recurrence=bool(tm['last_taper_group']),
+                             roofline_frac_vs_no_taper_contract=frac(terms, t32['kernel_ms_min'], FLOPS_PER_TERM, 'f32'),
+                             roofline_frac_vs_taper_contract=frac(terms, t32['kernel_ms_min'], FLOPS_PER_TERM_TAPER, 'f32'),
+                             roofline_frac_vs_taper_contract_median=frac(terms, t32['kernel_ms_median'], FLOPS_PER_TERM_TAPER, 'f32'),
+                             taper_split_runs=tm.get('last_taper_split', 0), taper_uncorrected_groups=tm.get('last_split_uncorrected_groups', 0),
+                             workload=cfg_d['name'] + ' (taper on)')
+    t64, tm = timed(_abi.PRISIM_FP64)
+    res['fp64_taper'] = dict(t64, kernel='k_skyvis_taper_f64<%d> (grouped single-chain form)' % tm['last_chan_tile'],
+                             terms_per_s=terms / (t64['kernel_ms_min'] * 1e-3),
+                             roofline_frac_vs_no_taper_contract=frac(terms, t64['kernel_ms_min'], FLOPS_PER_TERM, 'f64'),
+                             roofline_frac_vs_taper_contract=frac(terms, t64['kernel_ms_min'], FLOPS_PER_TERM_TAPER, 'f64'),
+                             roofline_frac_vs_no_taper_contract_median=frac(terms, t64['kernel_ms_median'], FLOPS_PER_TERM, 'f64'),
+                             workload=cfg_d['name'] + ' (taper on), fp64')
     return res
+
+
+def config2_step(nlaunch=20):
+    """BASELINE config 2 as worded (HERA-19, 256 channels, nside-16 diffuse, fp64, taper): device time of one snapshot's compute
+    (prep + pack + kernel + partial reduce), minimum and median of `nlaunch` launches -- a 6.6e7-term problem: launch-bound."""
+    cfg = W.config2()
+    zen = NP.array([0.0, 0.0, 1.0])
+    sky = cfg['sky']
+    with _abi.Context(int(os.environ.get('PRISIM_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))) as c2:
+        c2.set_array(cfg['baselines'], cfg['channels'], nt_max=1)
+        c2.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, cfg['diameter'], zen, zen,
+                            fwhm_deg=sky['fwhm_deg'])
+        c2.compute(precision=_abi.PRISIM_FP64)
+        c2.sync()
+        ks, cs, tm = [], [], None
+        for rep in range(nlaunch):
+            c2.compute(precision=_abi.PRISIM_FP64)
+            c2.sync()
+            tm = c2.timing()
+            ks.append(tm['last_kernel_ms'])
+            cs.append(tm['last_compute_ms'])
+        terms = float(tm['last_terms'])
+        return {'workload': cfg['name'], 'terms': terms, 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
+                'kernel_us_min': 1e3 * min(ks), 'kernel_us_median': 1e3 * float(NP.median(ks)),
+                'compute_us_min': 1e3 * min(cs), 'compute_us_median': 1e3 * float(NP.median(cs)),
+                'roofline_frac_10flop': terms * FLOPS_PER_TERM / (min(ks) * 1e-3) / 1e12 / PEAK_TFLOPS['f64'],
+                'terms_per_s_whole_compute': terms / (min(cs) * 1e-3)}
 
 
 def _smi_sample():
@@ -593,6 +642,8 @@ def main():
             'roofline': {'bound': 'valu', 'achieved': ach_tflops, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
                          'frac': ach_tflops / PEAK_TFLOPS[dtype], 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                          'traffic_source': traffic_src,
+                         'frac_vs_measured_peak': ach_tflops / MEASURED_PEAK_TFLOPS[dtype], 'measured_peak': MEASURED_PEAK_TFLOPS[dtype],
+                         'measured_peak_what': 'back-to-back v_pk_fma_f32 (fp64: v_fma_f64) on every SIMD, profiles/r01_microbench_valu.txt',
                          'kernel': 'k_skyvis_grad' if wg else 'k_skyvis_rec', 'avg_kernel_ms': kern_ms, 'flops_per_term': flops_term,
                          'terms_per_launch': terms_launch},
             'roofline_hbm': {'bound': 'hbm', 'achieved': ach_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -644,15 +695,21 @@ def main():
                 out['cpu_baseline_ref_xN'] = {'value': None, 'unit': 'terms/s', 'cores': 0, 'kind': 'reference-formulation x N', 'sample': 'failed: %r' % (exc,)}
             try:
                 # delay power spectra of the K resident snapshots, one window for all baselines, pad = 1 (run_prisim.py:954, 2284)
+                # in K^2 (Mpc/h)^3: abs(.)^2 * jacobian1 * jacobian2 * Jy2K^2 (delay_spectrum.py:3659-3663, 3992) -- redshift, comoving
+                # distances, and the beam volume of the Airy pattern on a HEALPix nside-32 grid (evaluated on the device) on the host
+                from prisim_amd import delay_spectrum as DSM
                 win = NP.blackman(nchan) + 0.01
+                pconst = DSM.power_constants(ch, {'id': 'hera'}, freq_wts=win, device=device)
                 for rep in range(2):
-                    ctx.delay_transform_device(K, bpwts=win, pad=1.0, want_lag=False, want_power=True, power_scale=1.0)
+                    ctx.delay_transform_device(K, bpwts=win, pad=1.0, want_lag=False, want_power=True, power_scale=pconst['factor'])
                     ctx.sync()
                 tmd = ctx.timing()
                 nrow = K * bl_mine.shape[0]
                 dbytes = float(nrow) * nchan * (16 + 8)            # each visibility read once, each power sample written once
                 gbs = dbytes / (tmd['last_delay_ms'] * 1e-3) / 1e9
                 out['delay_ps'] = {'device_ms': tmd['last_delay_ms'], 'ffts': nrow, 'fft_length_kept': nchan, 'pad': 1.0,
+                                   'power_scale_K2_Mpc3_per_Jy2Hz2': pconst['factor'], 'z': pconst['z'], 'omega_bw_SrHz': float(pconst['omega_bw'][0]),
+                                   'rz_los_Mpc_h': pconst['rz_los'], 'drz_los_Mpc_h': pconst['drz_los'], 'cosmology': pconst['cosmology'],
                                    'fused_lds_kernel': bool(tmd['last_delay_fused']),
                                    'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                                                 'algorithmic_bytes': dbytes}}
@@ -669,6 +726,10 @@ def main():
             except Exception as exc:
                 out['other_kernels'] = {'error': repr(exc)}
             ctx.close()
+            try:
+                out['config2'] = config2_step()
+            except Exception as exc:
+                out['config2'] = {'error': repr(exc)}
             try:
                 out['e2e'] = e2e_observe(cfg, 8, device, memsave=(prec == _abi.PRISIM_FP32))
             except Exception as exc:

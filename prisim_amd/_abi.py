@@ -245,6 +245,7 @@ class Context(object):
             msg = self._lib.prisim_hip_last_error(None).decode()
             _raise(rc, 'prisim_hip_create(device={0}) failed: {1}'.format(device, msg))
         self._h = h
+        self.device = int(device)
         self.nbl = self.nchan = self.nt_max = 0
         self.nsrc = 0
 

@@ -146,8 +146,22 @@ class OracleContext(object):
         vis = NP.transpose(self.cube[:nt], (1, 2, 0))
         lag, lags = DO.delay_transform(vis, w[:, :, None], NP.ones((self.nbl, self.nchan, 1)), self.ch[1] - self.ch[0], pad=pad)
         self._lag = NP.ascontiguousarray(NP.transpose(lag, (2, 0, 1)))        # [t][b][lag]
+        self._pow = NP.abs(self._lag) ** 2 * power_scale if want_power else None
         self._dt_nout = self._lag.shape[2]
         return lags, self._dt_nout
+
+    def get_delay_power(self, t0, nt, rows=None):
+        out = self._pow[t0:t0 + nt]
+        return out if rows is None else out[:, NP.asarray(rows)]
+
+    def get_pbflux(self):
+        return NP.array(self.pb)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def get_lags(self, t0, nt, rows=None):
         out = self._lag[t0:t0 + nt]

@@ -56,8 +56,10 @@ err = float(NP.max(NP.abs(vis - ref) / NP.sum(NP.abs(pb), axis=0)[None, :]))
 
 # delay power spectra of every row, on the device
 w = NP.blackman(ch.size) + 0.01
+from prisim_amd import delay_spectrum as DSM
+pconst = DSM.power_constants(ch, {'id': 'hera'}, freq_wts=w)      # abs^2 -> K^2 (Mpc/h)^3 (delay_spectrum.py:3659-3663, 3992)
 t1 = time.perf_counter()
-ia._ctx.delay_transform_device(n_lst, bpwts=w, pad=1.0, want_lag=False, want_power=True, power_scale=1.0)
+ia._ctx.delay_transform_device(n_lst, bpwts=w, pad=1.0, want_lag=False, want_power=True, power_scale=pconst['factor'])
 ia._ctx.sync()
 dwall = time.perf_counter() - t1
 tmd = ia._ctx.timing()
@@ -69,4 +71,5 @@ print(json.dumps({
     'terms_per_s_wall': terms / wall, 'terms_per_s_kernel': terms / (tm['sum_kernel_ms'] * 1e-3), 'cube_GB_resident': rows * ch.size * 16 / 1e9,
     'parity_spot_max_err_rel_sumflux_last_lst': err, 'tolerance': 5e-6,
     'delay_ffts': rows, 'delay_device_ms': tmd['last_delay_ms'], 'delay_wall_s': dwall, 'delay_fused_kernel': bool(tmd['last_delay_fused']),
-    'delay_algorithmic_GBps': rows * ch.size * 24 / (tmd['last_delay_ms'] * 1e-3) / 1e9, 'delay_power_finite': bool(NP.all(NP.isfinite(pw)))}))
+    'delay_algorithmic_GBps': rows * ch.size * 24 / (tmd['last_delay_ms'] * 1e-3) / 1e9, 'delay_power_finite': bool(NP.all(NP.isfinite(pw))),
+    'delay_power_scale_K2_Mpc3_per_Jy2Hz2': pconst['factor'], 'delay_power_max_K2_Mpc3': float(NP.max(pw))}))

@@ -107,9 +107,12 @@ def run(cfg, ctx, n_acc, spot=6, delay=False, cpu=False):
                       'gpu_kernel_over_numpy': t_np / (kern_ms * 1e-3), 'gpu_kernel_over_c_openmp': t_c / (kern_ms * 1e-3)}
     if delay:
         w = NP.blackman(ch.size)
+        from prisim_amd import delay_spectrum as DSM
+        pconst = DSM.power_constants(ch, {'id': 'hera'}, freq_wts=w)      # abs^2 -> K^2 (Mpc/h)^3 (delay_spectrum.py:3659-3663, 3992)
+        out['delay_power_scale_K2_Mpc3_per_Jy2Hz2'] = pconst['factor']
         for rep in range(2):
             t1 = time.perf_counter()
-            ctx.delay_transform_device(n_acc, bpwts=w, pad=1.0, want_lag=False, want_power=True, power_scale=1.0)
+            ctx.delay_transform_device(n_acc, bpwts=w, pad=1.0, want_lag=False, want_power=True, power_scale=pconst['factor'])
             ctx.sync()
             out['delay_power_spectrum_wall_s'] = time.perf_counter() - t1
         tmd = ctx.timing()

@@ -13,7 +13,13 @@ if stats:
         for row in csv.DictReader(f):
             if KERNEL in row['Name'] and (avg_ms is None or float(row['AverageNs']) * 1e-6 > avg_ms):
                 avg_ms = float(row['AverageNs']) * 1e-6
-                summary['_kernel'] = {'Kernel_Name': row['Name']}
+                summary['_kernel'] = {'Kernel_Name': row['Name'], 'Calls': int(row['Calls']), 'TotalDurationNs': float(row['TotalDurationNs'])}
+    # PROFILE_LAUNCHES_PER_STEP = n: a step runs the kernel n times over source runs of different length (config 3 + diffuse: the point
+    # sources, then the pixels), so the figure to hold against the hipEvent time of a step is n x the average over all calls
+    lps = int(os.environ.get('PROFILE_LAUNCHES_PER_STEP', '1'))
+    if avg_ms is not None and lps > 1:
+        summary['_kernel']['launches_per_step'] = lps
+        avg_ms *= lps
 for path in sorted(glob.glob(os.path.join(out, 'pmc*', '**', '*counter_collection.csv'), recursive=True)):
     acc = {}
     with open(path) as f:
@@ -28,6 +34,9 @@ for path in sorted(glob.glob(os.path.join(out, 'pmc*', '**', '*counter_collectio
     for name, vals in per_counter.items():
         big = [v for v in vals if v >= 0.5 * max(vals)] or vals     # ignore tiny launches (parity spot check)
         summary[name] = {'launches': len(big), 'mean_per_launch': sum(big) / len(big)}
+        lps_ = int(os.environ.get('PROFILE_LAUNCHES_PER_STEP', '1'))
+        if lps_ > 1 and len(vals) % lps_ == 0:                      # several launches per step: the figure per STEP (all of them summed)
+            summary[name] = {'launches': len(vals), 'mean_per_launch': sum(vals) / (len(vals) // lps_), 'per': 'step of %d launches' % lps_}
 d = {}
 if avg_ms:
     d['avg_kernel_ms (rocprofv3 --kernel-trace --stats)'] = avg_ms
