@@ -60,9 +60,9 @@ DEFAULTS = {
     'processing': {'gradient_mode': None, 'f_pad': 1.0, 'bpass_shape': 'bhw', 'delay_transform': False, 'memsave': False,
                    'add_noise': None, 'noise_seed': None},
     'phasing': {'center': [90.0, 270.0], 'coords': 'altaz'},
-    'pp': {'key': 'bl', 'eqvol': True, 'gather': 'all'},
+    'pp': {'key': 'bl', 'eqvol': True, 'gather': None},      # gather: 'all' | 'root'; None = 'root' when only rank 0 keeps a host copy, else 'all'
     'save_redundant': True,
-    'save_formats': {'npz': True, 'hdf5': False},
+    'save_formats': {'npz': True, 'hdf5': False, 'npz_compress': True},
     'diagnosis': {'wait_after_run': False},
 }
 
@@ -189,13 +189,24 @@ def build_skymodel(parms, infile_dir):
                            epoch='J' + str(sp['epoch']))
     lst0 = (parms['pointing']['lst_init'] or 0.0) * 15.0
     lat = parms['telescope']['latitude']
-    if model == 'ptsrc_random':
-        sky = W.point_source_sky(int(sp['n_src']), int(sp['seed']), f_ref=sp['custom_reffreq'] * 1e9, spindex=sp['spindex'])
-    elif model == 'healpix_synthetic':
-        sky = W.diffuse_sky(int(sp['nside']), int(sp['seed']), f_ref=sp['custom_reffreq'] * 1e9, spindex=sp['spindex'])
+
+    def synthetic(spc):
+        if spc['model'] == 'ptsrc_random':
+            return W.point_source_sky(int(spc['n_src']), int(spc['seed']), f_ref=spc['custom_reffreq'] * 1e9, spindex=spc['spindex'])
+        if spc['model'] == 'healpix_synthetic':
+            return W.diffuse_sky(int(spc['nside']), int(spc['seed']), f_ref=spc['custom_reffreq'] * 1e9, spindex=spc['spindex'])
+        raise NotImplementedError('skyparm.model {0!r}: survey catalogs need prisim/data (absent); use custom, ptsrc_random, '
+                                  'healpix_synthetic or synthetic_mix'.format(spc['model']))
+    if model == 'synthetic_mix':
+        # several synthetic components in one sky, in the order given (the reference's combined models -- 'csm' = NVSS + SUMSS, 'asm' =
+        # diffuse + point sources, run_prisim.py:1020-1686 -- need its catalogs): skyparm.components = [{model: ..., <keys of that
+        # model>}, ...], every entry overlaid on skyparm.  Point sources first keeps the sky in runs of one source size each.
+        comps = sp.get('components') or []
+        if not comps:
+            raise ValueError("skyparm.model 'synthetic_mix' needs a non-empty skyparm.components list")
+        sky = W.concat_skies(*[synthetic(deep_merge({k: v for k, v in sp.items() if k != 'components'}, c)) for c in comps])
     else:
-        raise NotImplementedError('skyparm.model {0!r}: survey catalogs need prisim/data (absent); use custom, ptsrc_random or '
-                                  'healpix_synthetic'.format(model))
+        sky = synthetic(sp)
     hadec = GEOM.altaz2hadec(sky['altaz'], lat, units='degrees')         # local frame at lst_init -> (RA, Dec)
     radec = NP.stack(((lst0 - hadec[:, 0]) % 360.0, hadec[:, 1]), axis=1)
     n = radec.shape[0]
@@ -293,11 +304,12 @@ def schedule(parms):
     return jd, lst, hadec, t_acc, n_acc
 
 
-def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose=True, host_copy='all'):
+def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose=True, host_copy='all', rdzv=None):
     """Simulate the observation described by `parms` on this rank's GPU.  Returns a dict with the (gathered) visibility
     cube (nbl, nchan, n_acc), baselines, labels, channels, lst, timestamps and timing.  host_copy (sharded runs): 'all' = every
     rank downloads the gathered cube and spectra, 'root' = rank 0 only (the others return None for them; every GPU still holds
-    the gathered data)."""
+    the gathered data unless pp.gather is 'root').  rdzv (sharded runs): the ranks' rendezvous -- the outcome of the communicator
+    self-test is combined over it, so that every rank stops (SystemExit 3) when any rank's RCCL cannot move data."""
     if host_copy not in ('all', 'root'):
         raise ValueError("host_copy must be 'all' or 'root'")
     download = host_copy == 'all' or rank == 0
@@ -331,6 +343,26 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     # unsharded runs hand the cube to the host (files, the caller): each snapshot's download is queued under the next one's sky-sum;
     # sharded runs gather on the device and never copy their own shard
     ia.reserve(n_acc, host_staging=(world == 1))
+    if world > 1:
+        if comm_uid is None:
+            raise ValueError('comm_uid is needed when world > 1')
+        # communicator + self-test BEFORE the snapshots: a RCCL / xGMI setup that cannot move data must stop the job here, not write a
+        # wrong cube (prisim_hip_comm_selftest: 1 MiB all-gather of a rank-dependent pattern, verified on every rank's host)
+        ok, why = True, ''
+        try:
+            ia.comm_setup(comm_uid, world, rank)
+        except _abi.PrisimHipError as exc:
+            ok, why = False, str(exc)
+            if rdzv is None:
+                raise
+        if rdzv is not None:
+            outcomes = rdzv.allgather([bool(ok), why])
+            bad = [(r, o[1]) for r, o in enumerate(outcomes) if not o[0]]
+            if bad:
+                if rank == 0 or not ok:
+                    import sys
+                    sys.stderr.write('RCCL communicator self-test failed on rank(s) {0}: {1}\n'.format([r for r, _ in bad], bad[0][1]))
+                raise SystemExit(3)
     if extbeam is not None:
         bm = parms['beam']
         ia.set_external_beam(extbeam[0], extbeam[1], spec_interp=bm.get('spec_interp', 'cubic'), chromatic=bool(bm.get('chromatic', True)),
@@ -375,11 +407,10 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         ref_point = {'coords': ph.get('coords', 'altaz'), 'location': NP.asarray(ph['center'], dtype=float).reshape(1, -1)}
         ia.rotate_visibilities(ref_point, do_delay_transform=False, verbose=False)
     if world > 1:
-        if comm_uid is None:
-            raise ValueError('comm_uid is needed when world > 1')
         # shards go GPU -> GPU; the host never sees this rank's own cube.  pp.gather: 'all' = every GPU ends up with the whole cube
         # (ncclAllGather), 'root' = only rank 0 does (ncclSend / ncclRecv; the other GPUs keep nothing: 120 GB less at config 5)
-        gather = str(parms['pp'].get('gather', 'all')).lower()
+        gather = parms['pp'].get('gather')
+        gather = ('root' if host_copy == 'root' else 'all') if gather is None else str(gather).lower()
         if gather not in ('all', 'root'):
             raise ValueError("pp.gather must be 'all' or 'root'")
         if gather == 'root':
@@ -491,7 +522,9 @@ def save(out, parms, infile=None):
         for extra in ('vis_freq', 'vis_noise_freq', 'skyvis_lag', 'lags'):                                   # :8860-8861 when noise was added
             if out.get(extra) is not None:
                 keys[extra] = out[extra]
-        NP.savez_compressed(path + '.npz', **keys)
+        # (compressed like the reference's, interferometry.py:8859-8863; save_formats.npz_compress: false writes the arrays as they are --
+        # visibility cubes are noise-like and gigabytes of them deflate slowly)
+        (NP.savez_compressed if parms['save_formats'].get('npz_compress', True) else NP.savez)(path + '.npz', **keys)
     if parms['save_formats'].get('hdf5', False) and out.get('ia') is not None:
         # PRISim's HDF5 layout (interferometry.py:8717-8846) of the InterferometerArray, redundant baselines re-created first when asked
         # for (run_prisim.py:2325-2326).
@@ -518,8 +551,15 @@ def main(argv=None):
         # become the launcher before anything touches the GPU: N children run this same entry with RANK / WORLD_SIZE set
         import sys
         from . import launch
-        script = os.path.abspath(sys.argv[0])
-        return launch.spawn_ranks(args.nranks, [sys.executable, script] + list(sys.argv[1:] if argv is None else argv))
+        if argv is None:
+            cmd = [sys.executable, os.path.abspath(sys.argv[0])] + list(sys.argv[1:])
+        else:
+            # called programmatically (a host program, a test): the ranks run this module, not whatever sys.argv[0] happens to be
+            cmd = [sys.executable, '-m', 'prisim_amd.driver'] + list(argv)
+        pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ)
+        env['PYTHONPATH'] = pkg_parent + (os.pathsep + env['PYTHONPATH'] if env.get('PYTHONPATH') else '')
+        return launch.spawn_ranks(args.nranks, cmd, env=env)
     parms = load_parms(args.infile)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -532,7 +572,7 @@ def main(argv=None):
         uid = rdzv.broadcast_bytes(_abi.Context.comm_unique_id() if rank == 0 else b'')
     device = int(os.environ.get('PRISIM_DEVICE', local_rank))       # PRISIM_DEVICE: rehearsal hook (several ranks on the one GPU of a test box)
     out = run(parms, infile_dir=os.path.dirname(os.path.abspath(args.infile)), rank=rank, world=world, device=device, comm_uid=uid,
-              host_copy='root')                    # only rank 0 writes: the other ranks leave the gathered cube in HBM
+              host_copy='root', rdzv=rdzv)         # only rank 0 writes: by default (pp.gather: null) only its GPU receives the cube
     if rank == 0:
         path = save(out, parms, args.infile)
         print('simulated {0} baselines x {1} channels x {2} snapshots in {3:.3f} s -> {4}'.format(
@@ -540,3 +580,8 @@ def main(argv=None):
     rdzv.barrier()
     rdzv.close()
     return 0
+
+
+if __name__ == '__main__':
+    import sys
+    sys.exit(main())

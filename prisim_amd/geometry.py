@@ -140,3 +140,22 @@ def healpix_pix2ang_ring(nside, ipix=None):
         z[south] = -1.0 + iring.astype(float) ** 2 / (3.0 * nside ** 2)
         phi[south] = (iphi - 0.5) * NP.pi / (2.0 * iring)
     return NP.arccos(NP.clip(z, -1.0, 1.0)), phi
+
+
+def enu2xyz(enu, latitude, units='degrees'):
+    """Local East-North-Up vectors -> equatorial (X towards hour angle 0 on the celestial equator, Y towards hour angle -6 h (East),
+    Z towards the celestial pole) at the given latitude: x = -sin(lat) n + cos(lat) u, y = e, z = cos(lat) n + sin(lat) u.
+    (GEOM.enu2xyz of the reference's astroutils dependency, interferometry.py:7979; un-vendored, parity unpinned: the convention is the one
+    the reference's uvw rotation matrix at :7979-7985 is written for.)"""
+    enu = NP.asarray(enu, dtype=NP.float64).reshape(-1, 3)
+    lat = NP.radians(latitude) if units == 'degrees' else float(latitude)
+    e, n, u = enu[:, 0], enu[:, 1], enu[:, 2]
+    return NP.stack((-NP.sin(lat) * n + NP.cos(lat) * u, e, NP.cos(lat) * n + NP.sin(lat) * u), axis=1)
+
+
+def xyz2enu(xyz, latitude, units='degrees'):
+    """Inverse of enu2xyz (GEOM.xyz2enu, interferometry.py:6153): e = y, n = -sin(lat) x + cos(lat) z, u = cos(lat) x + sin(lat) z."""
+    xyz = NP.asarray(xyz, dtype=NP.float64).reshape(-1, 3)
+    lat = NP.radians(latitude) if units == 'degrees' else float(latitude)
+    x, y, z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    return NP.stack((y, -NP.sin(lat) * x + NP.cos(lat) * z, NP.cos(lat) * x + NP.sin(lat) * z), axis=1)

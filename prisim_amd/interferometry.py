@@ -233,12 +233,10 @@ class InterferometerArray(object):
             self.baseline_coords = baseline_coords
         else:
             raise ValueError('Baseline coordinates must be "equatorial" or "local". Check inputs.')
-        if baseline_coords == 'equatorial':
-            raise NotImplementedError('equatorial baselines (GEOM.xyz2enu, interferometry.py:6153) are not on the accelerated path')
 
         # GPU context: fails loudly when the HIP library or a device is missing
         self._ctx = _abi.Context(device)
-        self._ctx.set_array(self.baselines, self.channels, nt_max=1)
+        self._ctx.set_array(self._baselines_local(), self.channels, nt_max=1)
         self._cube = []        # per-snapshot (nbl, nchan) visibilities, stacked lazily into skyvis_freq
         self._grad = []
         self._reserved = 1     # snapshot slots of the device cube (reserve())
@@ -345,15 +343,20 @@ class InterferometerArray(object):
         self.lag_kernel = None
         self.obs_catalog_indices = []
         self.geometric_delays = []
-        if self.baseline_coords == 'equatorial':
-            raise NotImplementedError('equatorial baselines (GEOM.xyz2enu, interferometry.py:6153) are not on the accelerated path')
         self._cube, self._grad = [], []
         self._reserved = max(int(self.n_acc), 1)
         self._ctx = _abi.Context(device)
-        self._ctx.set_array(self.baselines, self.channels, nt_max=self._reserved)
+        self._ctx.set_array(self._baselines_local(), self.channels, nt_max=self._reserved)
         self._stage, self._host_cube = False, None
         self.skyvis_freq = skyvis
         self._upload_cube()
+
+    def _baselines_local(self):
+        """The baselines in the local East-North-Up frame the sky-sum works in: as given, or rotated from the equatorial frame at the
+        array's latitude (baseline_coords='equatorial'; interferometry.py:6151-6153 does this at every observe())."""
+        if getattr(self, 'baseline_coords', 'localenu') == 'equatorial':
+            return GEOM.xyz2enu(self.baselines, self.latitude, 'degrees')
+        return self.baselines
 
     def reserve(self, n_acc, host_staging=False):
         """Allocate `n_acc` snapshot slots in the device visibility cube so that every observe() also leaves its result
@@ -369,7 +372,7 @@ class InterferometerArray(object):
             raise ValueError('n_acc must be positive')
         if self.n_acc > 0:
             raise RuntimeError('reserve() must be called before the first observe()')
-        self._ctx.set_array(self.baselines, self.channels, nt_max=n_acc)
+        self._ctx.set_array(self._baselines_local(), self.channels, nt_max=n_acc)
         self._reserved = n_acc
         self._stage, self._host_cube = bool(host_staging), None
         self._restore_external_beam()
@@ -432,6 +435,17 @@ class InterferometerArray(object):
         if getattr(self, '_extbeam', None) is not None:
             self._ctx.set_external_beam(*self._extbeam)
 
+    def comm_setup(self, comm_uid, nranks, rank):
+        """Build the RCCL communicator of this array's context (once) and run its self-test: a 1 MiB all-gather of a rank-dependent
+        pattern verified on the host of every rank (prisim_hip_comm_selftest), so that a communicator that cannot move data raises HERE
+        (PrisimHipError) and not as a silently wrong cube on disk.  Returns True; callers that can talk to the other ranks combine the
+        outcomes (driver.run does, over the rendezvous) so that every rank stops when one fails."""
+        if not getattr(self, '_comm_ready', False):
+            self._ctx.comm_init(comm_uid, nranks, rank)
+            self._ctx.comm_selftest()
+            self._comm_ready = True
+        return True
+
     def allgather(self, comm_uid, nranks, rank, download=True, root=None):
         """One RCCL all-gather of the baseline shards of all ranks (equal shard sizes; replaces the reference's per-rank
         part files + rank-0 concatenate, scripts/run_prisim.py:2207, 2233-2242).  Returns (nranks*nbl, nchan, n_acc), or None with
@@ -442,9 +456,7 @@ class InterferometerArray(object):
             raise RuntimeError('reserve(n_acc) must be called before observing to keep the cube on the device')
         if root is not None and download and rank != root:
             raise ValueError('with root = {0} only that rank can download the gathered cube'.format(root))
-        if not getattr(self, '_comm_ready', False):
-            self._ctx.comm_init(comm_uid, nranks, rank)
-            self._comm_ready = True
+        self.comm_setup(comm_uid, nranks, rank)
         self._ctx.set_gather_root(root)
         # complex64 on the wire only when EVERY snapshot was observed with memsave (host arrays and _DeviceSlot placeholders both
         # carry their dtype); a run that mixes precisions, or has no snapshot yet, gathers complex128
@@ -763,7 +775,7 @@ class InterferometerArray(object):
             else:
                 res = self._ctx.get_vis(slot=slot, want_grad=want_grad, complex64=memsave)
                 skyvis, skyvis_gradient = res if want_grad else (res, None)
-            self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(self.baselines, dircos_roi,
+            self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(self._baselines_local(), dircos_roi,
                                                                                  NP.float32 if memsave else NP.float64)]   # :6287-6291
             self.obs_catalog_indices = self.obs_catalog_indices + [m2]                # :6377
         else:                                                                         # :6378-6382
@@ -1197,7 +1209,7 @@ class InterferometerArray(object):
                 arr[ind, :, :] = arr[ind, :, :].conj()
         if self.projected_baselines is not None:
             self.projected_baselines[ind, :, :] = -self.projected_baselines[ind, :, :]
-        self._ctx.set_array(self.baselines, self.channels, nt_max=self._reserved)      # the resident array follows the flip
+        self._ctx.set_array(self._baselines_local(), self.channels, nt_max=self._reserved)      # the resident array follows the flip
         self._restore_external_beam()
         if self._reserved >= self.n_acc and self.skyvis_freq is not None:
             self._upload_cube()
@@ -1456,7 +1468,7 @@ class InterferometerArray(object):
             if isinstance(arr, NP.ndarray) and arr.ndim >= 1 and arr.shape[0] > 1:
                 setattr(self, name, NP.repeat(arr, num_list, axis=0))
         # the resident device array follows the expanded baseline list (slots are re-uploaded on demand)
-        self._ctx.set_array(self.baselines, self.channels, nt_max=self._reserved)
+        self._ctx.set_array(self._baselines_local(), self.channels, nt_max=self._reserved)
         self._restore_external_beam()
         if self._reserved >= self.n_acc and self.skyvis_freq is not None:
             self._upload_cube()

@@ -65,16 +65,28 @@ def spawn_ranks(nranks, argv, env=None, grace=10.0):
             procs.append(subprocess.Popen(list(argv), env=rank_env(r, nranks, env, port, rdzv_file)))
         code = 0
         alive = {p.pid: r for r, p in enumerate(procs)}
+        def reap_one():
+            """(pid, status) of one of OUR ranks that has ended, or None: only the PIDs started here are polled (os.waitpid(pid, WNOHANG)),
+            so an exit status of any other child of the calling process -- another Popen, a pool, a test harness -- is never consumed."""
+            for pid in list(alive):
+                try:
+                    got, status = os.waitpid(pid, os.WNOHANG)
+                except ChildProcessError:
+                    alive.pop(pid, None)
+                    continue
+                if got == pid:
+                    return pid, status
+            return None
+
         while alive:
-            # children are reaped in the order they end (os.wait), so the rank reported -- and whose code the job returns -- is the one
-            # that failed FIRST, not a peer that died of the broken connection a moment later.  This process has no other children.
-            try:
-                pid, status = os.wait()
-            except ChildProcessError:
-                break
-            r = alive.pop(pid, None)
-            if r is None:
+            # ranks are reaped in the order they end (polled every few ms), so the rank reported -- and whose code the job returns -- is
+            # the one that failed FIRST, not a peer that died of the broken connection a moment later
+            got = reap_one()
+            if got is None:
+                time.sleep(0.005)
                 continue
+            pid, status = got
+            r = alive.pop(pid)
             rc = os.waitstatus_to_exitcode(status)
             procs[r].returncode = rc
             if rc != 0:
@@ -84,16 +96,12 @@ def spawn_ranks(nranks, argv, env=None, grace=10.0):
                 failed = [(r, rc)]
                 t_end = time.time() + 0.5
                 while alive and time.time() < t_end:
-                    try:
-                        pid2, status2 = os.waitpid(-1, os.WNOHANG)
-                    except ChildProcessError:
-                        break
-                    if pid2 == 0:
+                    got2 = reap_one()
+                    if got2 is None:
                         time.sleep(0.01)
                         continue
-                    r2 = alive.pop(pid2, None)
-                    if r2 is None:
-                        continue
+                    pid2, status2 = got2
+                    r2 = alive.pop(pid2)
                     rc2 = os.waitstatus_to_exitcode(status2)
                     procs[r2].returncode = rc2
                     if rc2 != 0:

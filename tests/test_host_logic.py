@@ -451,3 +451,32 @@ def test_host_staging_is_refused_when_the_pinned_cube_would_take_most_of_the_fre
     with pytest.warns(UserWarning, match='host staging switched off: the pinned host cube would need'):
         ia, _ = _observed_oracle_array(monkeypatch, 2, reserve=2, host_staging=True)
     assert ia.skyvis_freq.shape == (5, 16, 2) and not ia._stage
+
+
+def test_equatorial_baselines_are_rotated_to_the_local_frame(monkeypatch):
+    """baseline_coords='equatorial' (interferometry.py:6151-6153: GEOM.xyz2enu at the array's latitude): the same array given in the
+    equatorial frame observes what it observes given in ENU; the rotation itself against a hand calculation."""
+    import fake_context
+    from prisim_amd import interferometry as RI, skymodel as SM
+    lat = -30.7224
+    s, c = NP.sin(NP.radians(lat)), NP.cos(NP.radians(lat))
+    assert NP.allclose(GEOM.enu2xyz([[0.0, 1.0, 0.0]], lat), [[-s, 0.0, c]])              # North: towards the pole, tilted by the latitude
+    assert NP.allclose(GEOM.enu2xyz([[1.0, 0.0, 0.0]], lat), [[0.0, 1.0, 0.0]])           # East is Y
+    assert NP.allclose(GEOM.enu2xyz([[0.0, 0.0, 1.0]], lat), [[c, 0.0, s]])               # Up: hour angle 0, declination = latitude
+    rng = NP.random.default_rng(3)
+    bl = rng.uniform(-100.0, 100.0, size=(6, 3)) * NP.array([1.0, 1.0, 0.05])
+    assert NP.allclose(GEOM.xyz2enu(GEOM.enu2xyz(bl, lat), lat), bl, rtol=0, atol=1e-12)
+    monkeypatch.setattr(_abi, 'Context', fake_context.OracleContext)
+    ch = 150e6 + 1e5 * NP.arange(8)
+    skymod = SM.SkyModel(location=NP.stack((rng.uniform(20, 89, 30), rng.uniform(0, 360, 30)), axis=1), flux_ref=rng.uniform(1, 5, 30),
+                         spindex=NP.full(30, -0.7), ref_freq=150e6)
+    kw = dict(telescope={'id': 'hera'}, latitude=lat, skycoords='altaz', pointing_coords='hadec')
+    ia_enu = RI.InterferometerArray(['b%d' % i for i in range(6)], bl, ch, baseline_coords='localenu', **kw)
+    ia_eq = RI.InterferometerArray(['b%d' % i for i in range(6)], GEOM.enu2xyz(bl, lat), ch, baseline_coords='equatorial', **kw)
+    for ia in (ia_enu, ia_eq):
+        ia.observe((2457000.5, 10.0), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat], skymod, 10.0)
+    assert ia_eq.baseline_coords == 'equatorial' and NP.allclose(ia_eq.baselines, GEOM.enu2xyz(bl, lat))      # stored as given
+    assert NP.max(NP.abs(ia_eq.skyvis_freq - ia_enu.skyvis_freq)) <= 1e-10 * NP.max(NP.abs(ia_enu.skyvis_freq))
+    assert NP.allclose(NP.asarray(ia_eq.geometric_delays[0]), NP.asarray(ia_enu.geometric_delays[0]), rtol=0, atol=1e-18)
+    with pytest.raises(ValueError):
+        RI.InterferometerArray(['b0'], bl[:1], ch, baseline_coords='galactic', **kw)
