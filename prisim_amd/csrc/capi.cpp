@@ -130,6 +130,7 @@ struct prisim_ctx {
   // it contribute < exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux| to every baseline of the group.  cull_frac[prec]: culled share of
   // the snapshot's terms; cull_any[prec]: anything culled at all.
   DevBuf cull_first;
+  DevBuf step_tab;                        // round-4 experiment: step-phasor table of the packed fp32 kernel (PRISIM_HIP_STEP_TABLE=1)
   bool cull_any[2] = {false, false};
   double cull_frac[2] = {0.0, 0.0};
   int cull_nruns = 0;
@@ -583,7 +584,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->dirs_prep, &ctx->dirs_c32, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
-                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->grp_hz, &ctx->split_count, &ctx->cull_first, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
+                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->grp_hz, &ctx->split_count, &ctx->cull_first, &ctx->step_tab, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
   for (int i = 0; i < prisim_ctx::kTimingRing; ++i)
     for (hipEvent_t ev : {ctx->ev_c0[i], ctx->ev_c1[i], ctx->ev_k0[i], ctx->ev_k1[i]})
@@ -1220,7 +1221,18 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     }
     ctx->timing.last_taper_split = launches;
   } else if (pl.pk) {
-    HIPCHK(ctx, launch_skyvis_rec_f32pk(p, pl.ct, ctx->stream));
+    // A/B hook of the round-4 step-table experiment (profiles/r04_ab_step_table.txt): no taper, 64-channel tiles, no source split
+    const char* stab_env = getenv("PRISIM_HIP_STEP_TABLE");
+    if (stab_env && atoi(stab_env) != 0 && !ctx->taper && pl.ct == 64 && pl.nsplit == 1 && scale_comp < 0) {
+      const int64_t pitch = (int64_t)pl.nbgroups * kBlockThreads;
+      int rc2;
+      if ((rc2 = ensure(ctx, ctx->step_tab, (size_t)pl.nsrc_pad * (size_t)pitch * sizeof(float) * 2))) return rc2;
+      p.step_tab = (const float2*)ctx->step_tab.p;
+      p.step_tab_pitch = pitch;
+      HIPCHK(ctx, launch_skyvis_rec_f32pk_stab(p, ctx->stream));
+    } else {
+      HIPCHK(ctx, launch_skyvis_rec_f32pk(p, pl.ct, ctx->stream));
+    }
   } else if (g64) {
     // run by run when the sky comes in runs of one source size (so that every run's leading sources can be culled); with a source
     // split (partial cubes, written once per split) only a sky that is one run -- otherwise one launch over the whole sky
