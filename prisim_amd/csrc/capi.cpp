@@ -130,6 +130,8 @@ struct prisim_ctx {
   // it contribute < exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux| to every baseline of the group.  cull_frac[prec]: culled share of
   // the snapshot's terms; cull_any[prec]: anything culled at all.
   DevBuf cull_first;
+  std::vector<double> cull_rho, cull_an;    // scratch of the cull-table walk: sin / |cos| of the zenith angle of a run's leading sources
+  DevBuf moments_part;                    // per-chunk partial sums of k_taper_moments (reduced in fixed order)
   DevBuf step_tab;                        // round-4 experiment: step-phasor table of the packed fp32 kernel (PRISIM_HIP_STEP_TABLE=1)
   bool cull_any[2] = {false, false};
   double cull_frac[2] = {0.0, 0.0};
@@ -584,7 +586,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->dirs_prep, &ctx->dirs_c32, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
-                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->grp_hz, &ctx->split_count, &ctx->cull_first, &ctx->step_tab, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
+                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->grp_hz, &ctx->split_count, &ctx->cull_first, &ctx->step_tab, &ctx->moments_part, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
   for (int i = 0; i < prisim_ctx::kTimingRing; ++i)
     for (hipEvent_t ev : {ctx->ev_c0[i], ctx->ev_c1[i], ctx->ev_k0[i], ctx->ev_k1[i]})
@@ -751,20 +753,39 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
       if (tab) {
         const double thr[2] = {28.0, 18.0};                      // index = precision (PRISIM_FP64 = 0, PRISIM_FP32 = 1)
         double culled[2] = {0.0, 0.0};
-        for (int pr = 0; pr < 2; ++pr)
-          for (size_t r = 0; r < nruns; ++r) {
-            const auto& run = ctx->kappa_runs[r];
-            for (size_t g = 0; g < ng; ++g) {
+        // Serial host work per snapshot, so kept small: a run is only looked at when its longest-baseline group could cull anything at
+        // all, (rho, |n|) of its sources are formed once (not per group and precision), and the fp64 walk (the higher threshold) never
+        // goes past where the fp32 walk of the same group stopped.
+        double hmax = 0.0;
+        for (size_t g = 0; g < ng; ++g) hmax = std::max(hmax, ctx->grp_minh[g]);
+        std::vector<double>& rho = ctx->cull_rho;
+        std::vector<double>& an = ctx->cull_an;
+        for (size_t r = 0; r < nruns; ++r) {
+          const auto& run = ctx->kappa_runs[r];
+          const bool any_possible = run.kappa > 0.0 && run.kappa * hmax * hmax * fc2 >= thr[1];
+          int64_t nlead = 0;                                       // leading sources whose (rho, |n|) are formed so far
+          if (any_possible) { rho.clear(); an.clear(); }
+          for (size_t g = 0; g < ng; ++g) {
+            int64_t first32 = run.lo;
+            for (int pr = 1; pr >= 0; --pr) {                      // fp32 (threshold 18) first: the fp64 walk (28) stops no later
               int64_t sfirst = run.lo;
-              if (run.kappa > 0.0 && run.kappa * ctx->grp_minh[g] * ctx->grp_minh[g] * fc2 >= thr[pr]) {
+              const int64_t limit = pr == 1 ? run.hi : first32;
+              if (any_possible && run.kappa * ctx->grp_minh[g] * ctx->grp_minh[g] * fc2 >= thr[pr]) {
                 const double H = ctx->grp_minh[g], Z = ctx->grp_maxz[g];
-                while (sfirst < run.hi) {
-                  const double l = d4[4 * sfirst], m = d4[4 * sfirst + 1], n = d4[4 * sfirst + 2];
-                  const double perp = H * std::fabs(n) - Z * std::sqrt(l * l + m * m);
+                while (sfirst < limit) {
+                  const int64_t i = sfirst - run.lo;
+                  if (i >= nlead) {
+                    const double l = d4[4 * sfirst], m = d4[4 * sfirst + 1];
+                    rho.push_back(std::sqrt(l * l + m * m));
+                    an.push_back(std::fabs(d4[4 * sfirst + 2]));
+                    nlead = i + 1;
+                  }
+                  const double perp = H * an[(size_t)i] - Z * rho[(size_t)i];
                   if (!(perp > 0.0 && run.kappa * perp * perp * fc2 >= thr[pr])) break;
                   ++sfirst;
                 }
               }
+              if (pr == 1) first32 = sfirst;
               tab[(pr * nruns + r) * ng + g] = (int32_t)sfirst;
               if (sfirst > run.lo) {
                 ctx->cull_any[pr] = true;
@@ -773,6 +794,7 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
               }
             }
           }
+        }
         if (ctx->cull_any[0] || ctx->cull_any[1]) {
           if ((rc = ensure(ctx, ctx->cull_first, 2 * nruns * ng * sizeof(int32_t)))) return rc;
           HIPCHK(ctx, stage_send(ctx, ctx->cull_first.p, tab, 2 * nruns * ng * sizeof(int32_t)));
@@ -1152,7 +1174,10 @@ static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams
     const auto& run = ctx->kappa_runs[r];
     if (run.kappa <= 0.0) continue;
     double* mom = (double*)ctx->moments.p + r * (size_t)4 * nchan;
-    if (launch_taper_moments((const double*)ctx->pb.p, (const double*)ctx->dirs.p, run.lo, run.hi, nchan, mom, ctx->stream) != hipSuccess) return false;
+    if (ensure(ctx, ctx->moments_part, (size_t)taper_moments_chunks(run.lo, run.hi) * 4 * nchan * sizeof(double)) != PRISIM_OK) return false;
+    if (launch_taper_moments((const double*)ctx->pb.p, (const double*)ctx->dirs.p, run.lo, run.hi, nchan, (double*)ctx->moments_part.p, mom,
+                             ctx->stream) != hipSuccess)
+      return false;
     const double c16 = 16.0 * run.kappa * (ctx->df / kC) * (ctx->df / kC);
     if (launch_split_flags(mom, nchan, (const double*)ctx->grp_hz.p, (const double*)ctx->grp_hz.p + ng, (const int32_t*)ctx->lift_flags.p, (int)ng, c16,
                            2.0e-7, (int32_t*)ctx->split_flags.p + r * ng, (int32_t*)ctx->split_count.p + r, ctx->stream) != hipSuccess)

@@ -73,7 +73,10 @@ hipError_t launch_skyvis_taper_f64(const SkyvisParams& p, int ct, hipStream_t st
 // flags of the split taper kernel's baseline groups from those moments, on the device (k_split_flags); *count += uncorrected groups
 hipError_t launch_split_flags(const double* mom, int64_t nchan, const double* grp_h, const double* grp_z, const int32_t* lift_flags, int nbg,
                               double c16, double limit, int32_t* flags, int32_t* count, hipStream_t stream);
-hipError_t launch_taper_moments(const double* pb, const double* dirs, int64_t s_lo, int64_t s_hi, int64_t nchan, double* out, hipStream_t stream);
+// part: scratch [taper_moments_chunks(s_lo, s_hi)][4][nchan] doubles (per-chunk partial sums, added in chunk order: deterministic)
+int64_t taper_moments_chunks(int64_t s_lo, int64_t s_hi);
+hipError_t launch_taper_moments(const double* pb, const double* dirs, int64_t s_lo, int64_t s_hi, int64_t nchan, double* part, double* out,
+                                hipStream_t stream);
 // V + baseline gradient in one pass (fp64, MFMA 4x4x4): p.nbgroups = groups of 64 baselines, p.nsplit = 1, ct = 16 or 32
 hipError_t launch_skyvis_grad_f64(const SkyvisParams& p, int ct, hipStream_t stream);
 // the same in packed fp32 (VALU; p.nbgroups = groups of 256 baselines, 16-channel tiles, p.nsplit = 1, p.dirs_c32)

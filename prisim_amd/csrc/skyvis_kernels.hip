@@ -975,6 +975,16 @@ void k_skyvis_grad_f64(const SkyvisParams p) {
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Traffic experiment (tools/taper_traffic_ab.sh, profiles/r04_ab_taper_traffic.txt; never defined in the product build): with
+// -DPRISIM_EXPERIMENT_ROW_WRAP=N (a power of two) the packed kernels read row (s mod N) of their slab instead of row s, so the slab every
+// block streams is N x 256 bytes and stays in L2 whatever the blocks' drift -- the results are wrong, the arithmetic and the instruction
+// stream are the same: the launch then costs what it would cost if the row stream never missed L2.
+#ifdef PRISIM_EXPERIMENT_ROW_WRAP
+#define PRISIM_ROW_INDEX(s) ((s) & (PRISIM_EXPERIMENT_ROW_WRAP - 1))
+#else
+#define PRISIM_ROW_INDEX(s) (s)
+#endif
+
 __device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 typedef const __attribute__((address_space(4))) float* cfloat_p;
@@ -1194,7 +1204,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
     if constexpr (STAB) st_next = stab[(size_t)seg0 * (size_t)p.step_tab_pitch + lane];
     {
       if constexpr (GRAD) cs = gcs[seg0];
-      const cfloat_p r0 = gps + (size_t)seg0 * CT;
+      const cfloat_p r0 = gps + (size_t)PRISIM_ROW_INDEX(seg0) * CT;
 #pragma unroll
       for (int i = 0; i < NP; ++i) ra[i] = r0[i];
       // volatile: keeps instcombine from folding phi(load before the loop, load in the loop) into one load of a phi'd address at
@@ -1204,7 +1214,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       if (TAPER) sv[3] = d0[3];
     }
     for (int s = seg0; s < seg1; ++s) {
-      const cfloat_p row = gps + (size_t)s * CT;
+      const cfloat_p row = gps + (size_t)PRISIM_ROW_INDEX(s) * CT;
       const int sn = (s + 1 < seg1) ? s + 1 : s;                    // the last source is simply fetched again
       if (pf_on && ((s - seg0) & 3) == 0) {
         // every 4th source: the next 4 rows (64 lanes x 16 B) and 8 directions (64 lanes x 4 B), kPrefetchAhead sources ahead
@@ -1212,7 +1222,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
         const int spf = (s + kPrefetchAhead < n_loc - kPfRows) ? s + kPrefetchAhead : n_loc - kPfRows;
         int lane_pf = lane;
         asm volatile("" : "+v"(lane_pf));                            // formed here from the lane id: no per-lane pointers kept live across the loop
-        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * CT + lane_pf * 4), pf_lds, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)PRISIM_ROW_INDEX(spf) * CT + lane_pf * 4), pf_lds, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(pf_dirs + (size_t)spf * 8 + lane_pf), pf_lds, 4, 0, 0);
       }
       // the first use of sv waits for everything in flight (first piece + direction); only then ask for the second piece
@@ -1414,7 +1424,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           }
         } else {
           // first piece + direction of the next source (NPART is even: it goes to ra)
-          const cfloat_p rn = gps + (size_t)sn * CT;
+          const cfloat_p rn = gps + (size_t)PRISIM_ROW_INDEX(sn) * CT;
 #pragma unroll
           for (int i = 0; i < NP; ++i) ra[i] = rn[i];
           const cvdouble_p dn = gds + (size_t)sn * 4;
@@ -1517,8 +1527,11 @@ void k_skyvis_rec_f32pk_split(const SkyvisParams p) {
 // Beam-weighted moments of a source range per channel, for the host's bound on the split taper's uncorrected parabola:
 //   out[0][k] = sum_s p[s,k],  out[1][k] = sum_s p rho^2,  out[2][k] = sum_s p rho |n|,  out[3][k] = sum_s p n^2,   rho^2 = l^2 + m^2,
 // (l, m, n) the source direction: (b.s)^2 <= (|b_h| rho + |b_z| |n|)^2.  |p| is summed (the tolerance is relative to sum|pbflux|).
+// Deterministic: every block (a chunk of 1024 sources) writes its own partial sums, k_moments_reduce adds them in chunk order -- the
+// bound decides which body a baseline group runs, and a sum whose order changes from run to run (atomics) could flip a group that sits near
+// a limit, making fp32 results differ at 1e-7 of sum|pbflux| between runs of one input.
 __global__ void k_taper_moments(const double* __restrict__ pb, const double* __restrict__ dirs, int64_t s_lo, int64_t s_hi, int64_t nchan,
-                                double* __restrict__ out /*[4][nchan], zeroed*/) {
+                                double* __restrict__ part /*[gridDim.y][4][nchan]*/) {
   const int kc = threadIdx.x & 63, sl = threadIdx.x >> 6;                 // 64 channels x 4 source lanes
   const int64_t k = (int64_t)blockIdx.x * 64 + kc;
   const int64_t chunk = 1024;
@@ -1540,9 +1553,17 @@ __global__ void k_taper_moments(const double* __restrict__ pb, const double* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double v = red[q][0][kc] + red[q][1][kc] + red[q][2][kc] + red[q][3][kc];
-      atomicAdd(out + (size_t)q * nchan + k, v);
+      part[((size_t)blockIdx.y * 4 + q) * nchan + k] = v;
     }
   }
+}
+
+__global__ void k_moments_reduce(const double* __restrict__ part, int64_t nchunks, int64_t nchan, double* __restrict__ out /*[4][nchan]*/) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // (q, k)
+  if (i >= 4 * nchan) return;
+  double a = 0.0;
+  for (int64_t c = 0; c < nchunks; ++c) a += part[(size_t)c * 4 * nchan + i];
+  out[i] = a;
 }
 
 // Per-group body choice of the split taper kernel from the moments, ON THE DEVICE (no host round trip: a download here would make every
@@ -1810,13 +1831,15 @@ hipError_t launch_skyvis_rec_f32pk_split(const SkyvisParams& p, int ct, hipStrea
   return hipGetLastError();
 }
 
-hipError_t launch_taper_moments(const double* pb, const double* dirs, int64_t s_lo, int64_t s_hi, int64_t nchan, double* out, hipStream_t stream) {
-  if (s_hi <= s_lo || nchan <= 0) return hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)4 * nchan * sizeof(double), stream);
-  if (e != hipSuccess) return e;
-  const int64_t gy = (s_hi - s_lo + 1023) / 1024;
+int64_t taper_moments_chunks(int64_t s_lo, int64_t s_hi) { return (s_hi - s_lo + 1023) / 1024; }
+
+hipError_t launch_taper_moments(const double* pb, const double* dirs, int64_t s_lo, int64_t s_hi, int64_t nchan, double* part, double* out,
+                                hipStream_t stream) {
+  if (s_hi <= s_lo || nchan <= 0 || !part) return hipErrorInvalidValue;
+  const int64_t gy = taper_moments_chunks(s_lo, s_hi);
   if (gy > 65535) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_taper_moments, dim3((unsigned)((nchan + 63) / 64), (unsigned)gy), dim3(256), 0, stream, pb, dirs, s_lo, s_hi, nchan, out);
+  hipLaunchKernelGGL(k_taper_moments, dim3((unsigned)((nchan + 63) / 64), (unsigned)gy), dim3(256), 0, stream, pb, dirs, s_lo, s_hi, nchan, part);
+  hipLaunchKernelGGL(k_moments_reduce, dim3((unsigned)((4 * nchan + 255) / 256)), dim3(256), 0, stream, part, gy, nchan, out);
   return hipGetLastError();
 }
 

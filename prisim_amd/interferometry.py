@@ -87,6 +87,22 @@ class LazyGeometricDelays(object):
         return out if dtype is None else out.astype(dtype)
 
 
+def _available_host_bytes():
+    """Host memory that can be claimed without swapping: MemAvailable of /proc/meminfo (free pages + reclaimable cache), else the strictly
+    free pages (SC_AVPHYS_PAGES), else None."""
+    try:
+        with open('/proc/meminfo') as f:
+            for line in f:
+                if line.startswith('MemAvailable:'):
+                    return int(line.split()[1]) * 1024
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        return os.sysconf('SC_AVPHYS_PAGES') * os.sysconf('SC_PAGE_SIZE')
+    except (ValueError, OSError, AttributeError):
+        return None
+
+
 def _lst_and_jd(timeobj, lst):
     """Resolve (jd, lst_deg) from the accepted forms of ``timeobj`` (interferometry.py:6113, 6395)."""
     if hasattr(timeobj, 'sidereal_time'):
@@ -402,14 +418,13 @@ class InterferometerArray(object):
             return False
         if self._host_cube is None:
             need = self._reserved * self.baselines.shape[0] * self.channels.size * NP.dtype(dtype).itemsize
-            try:
-                avail = os.sysconf('SC_AVPHYS_PAGES') * os.sysconf('SC_PAGE_SIZE')
-            except (ValueError, OSError, AttributeError):
-                avail = None
-            if avail is not None and need > 0.5 * avail:
-                # page-locked memory cannot be swapped or reclaimed: a cube that would take most of the free RAM is not pinned
-                warnings.warn('host staging switched off: the pinned host cube would need {0:.1f} GiB of {1:.1f} GiB free'.format(
-                    need / 2.0 ** 30, avail / 2.0 ** 30))
+            avail = _available_host_bytes()
+            # Page-locked memory cannot be swapped or reclaimed, and reading skyvis_freq afterwards stacks the snapshots into a second
+            # (pageable) cube of the same size beside it: the budget is 2 x need, against what the kernel says can be made available
+            # (MemAvailable: free + reclaimable page cache -- a box that has just read a large catalog is not short of memory)
+            if avail is not None and 2 * need > avail:
+                warnings.warn('host staging switched off: the pinned host cube and its (nbl, nchan, n_acc) copy would need {0:.1f} GiB of '
+                              '{1:.1f} GiB available'.format(2 * need / 2.0 ** 30, avail / 2.0 ** 30))
                 self._stage = False
                 return False
             try:

@@ -130,3 +130,29 @@ def test_config5_two_lsts_and_delay_transform():
                                     ia.freq_resolution, pad=1.0)
     assert lag.shape == ref_lag.shape
     assert NP.max(NP.abs(lag - ref_lag)) <= 1e-10 * NP.max(NP.abs(ref_lag))
+
+
+@pytest.mark.parametrize('taper', [False, True])
+def test_fused_gradient_at_config3_array_size(taper):
+    """The fused V + baseline-gradient kernels (interferometry.py:6330, 6338, 6343) on the full HERA-350 array x 1024 channels -- every
+    baseline group, lifting and plain bodies, the MFMA lane layout on partly filled last groups -- with 2000 sources, both precisions,
+    checked on sampled baselines (first, last, around the lift / no-lift boundary) against the numpy oracle's gradient."""
+    from prisim_amd import _abi
+    cfg = W.config3(nsrc=2000)
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    zen = NP.array([0.0, 0.0, 1.0])
+    fw = NP.full(sky['dircos'].shape[0], 0.46) if taper else None
+    pb = BO.airy_disk_pattern(14.0, sky['altaz'], ch) * (sky['flux_ref'][:, None] * (ch[None, :] / sky['ref_freq']) ** sky['spindex'][:, None])
+    sel = NP.unique(NP.concatenate((_spot(bl, 5), [57599, 57600, 61074])))
+    ref, gref = O.skyvis(bl[sel], ch, sky['dircos'], pb, zen, fwhm_deg=fw, gradient=True)
+    scale = NP.sum(NP.abs(pb), axis=0)[None, :]
+    with _abi.Context(0) as ctx:
+        ctx.set_array(bl, ch, nt_max=1)
+        ctx.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, 14.0, zen, zen, fwhm_deg=fw)
+        for prec, tol in ((_abi.PRISIM_FP64, 1e-11), (_abi.PRISIM_FP32, 5e-6)):
+            ctx.compute(precision=prec, want_grad=True)
+            vis, grad = ctx.get_vis(want_grad=True)
+            assert NP.max(NP.abs(vis[sel] - ref) / scale) <= tol, (taper, prec)
+            for k in range(3):
+                assert NP.max(NP.abs(grad[k][sel] - gref[k]) / scale) <= tol, (taper, prec, k)
+            del vis, grad

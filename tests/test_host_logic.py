@@ -444,11 +444,11 @@ def test_host_staging_falls_back_when_pinned_memory_is_unavailable(monkeypatch):
 
 
 def test_host_staging_is_refused_when_the_pinned_cube_would_take_most_of_the_free_memory(monkeypatch):
-    import os as _os
-    real = _os.sysconf
-    monkeypatch.setattr(_os, 'sysconf', lambda name: 0 if name == 'SC_AVPHYS_PAGES' else real(name))      # no free pages
+    from prisim_amd import interferometry as RI_
+    assert RI_._available_host_bytes() > 0                                     # MemAvailable of /proc/meminfo on this box
+    monkeypatch.setattr(RI_, '_available_host_bytes', lambda: 1000)             # (the budget is 2 x the cube: pinned + its stacked copy)
     monkeypatch.setattr(_abi, 'host_empty', lambda shape, dtype: (_ for _ in ()).throw(AssertionError('must not be reached')))
-    with pytest.warns(UserWarning, match='host staging switched off: the pinned host cube would need'):
+    with pytest.warns(UserWarning, match='host staging switched off: the pinned host cube and its'):
         ia, _ = _observed_oracle_array(monkeypatch, 2, reserve=2, host_staging=True)
     assert ia.skyvis_freq.shape == (5, 16, 2) and not ia._stage
 
