@@ -58,8 +58,7 @@ void prisim_hip_destroy(prisim_ctx* ctx);
 /* Message of the last error on ctx (ctx may be NULL: last error of a failed create). */
 const char* prisim_hip_last_error(const prisim_ctx* ctx);
 /* Library version string "prisim_hip <major>.<minor> gfx950"; the minor number changes with every change of a struct or a signature
-   in this header (0.2: prisim_timing carries the delay-stage fields; 0.3: prisim_comm_stats, self-test, gradient gather, asynchronous downloads;
-   0.4: prisim_timing carries last_balanced_blocks).  A binding should refuse a library that reports another one. */
+   in this header (0.2: prisim_timing carries the delay-stage fields; 0.3: prisim_comm_stats, self-test, gradient gather, asynchronous downloads).  A binding should refuse a library that reports another one. */
 const char* prisim_hip_version(void);
 
 /* ---- array: baselines + channels, resident across snapshots ---------------------------- */
@@ -320,11 +319,7 @@ typedef struct prisim_timing {
   int32_t last_taper_split;  /* > 0: the packed fp32 taper ran its split form over this many source runs of one source size each */
   int32_t last_split_uncorrected_groups;   /* (source run, baseline group) pairs whose parabola bound allowed the uncorrected body */
   double last_culled_fraction;             /* share of the snapshot's (source, baseline) pairs the taper culling skipped (packed fp32
-                                              kernels; grouped fp64 kernel): their summed contribution is below exp(-18) / exp(-28)
-                                              of sum|pbflux| (0: none) */
-  int32_t last_balanced_blocks;            /* > 0: the sky-sum ran on the balanced grid with this many blocks (= resident blocks of the
-                                              chip), each walking an equal share of the work; 0: one (tile, split, group) per block */
-  int32_t reserved_;
+                                              kernels): their summed contribution is below exp(-18) of sum|pbflux| (0: none) */
 } prisim_timing;
 
 int prisim_hip_sync(prisim_ctx* ctx);

@@ -10,7 +10,7 @@ import numpy as NP
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PRISIM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libprisim_hip.so')      # PRISIM_HIP_LIB: A/B another build of the same ABI
-ABI_VERSION = 'prisim_hip 0.4 gfx950'       # prisim_hip_version(): bumped whenever a struct or a signature of include/prisim_hip.h changes
+ABI_VERSION = 'prisim_hip 0.3 gfx950'       # prisim_hip_version(): bumped whenever a struct or a signature of include/prisim_hip.h changes
 
 PRISIM_OK = 0
 PRISIM_EINVAL, PRISIM_ENODEV, PRISIM_ENOMEM, PRISIM_ESTATE, PRISIM_ELIB, PRISIM_EINTERNAL = -1, -2, -3, -4, -5, -6
@@ -117,8 +117,7 @@ class PrisimTiming(C.Structure):
                 ('n_kernel', C.c_int64), ('last_terms', C.c_int64), ('last_kernel_id', C.c_int32),
                 ('last_chan_tile', C.c_int32), ('last_nsplit', C.c_int32), ('last_lift_groups', C.c_int32),
                 ('last_taper_group', C.c_int32), ('last_delay_fused', C.c_int32), ('last_delay_ms', C.c_double),
-                ('last_taper_split', C.c_int32), ('last_split_uncorrected_groups', C.c_int32), ('last_culled_fraction', C.c_double),
-                ('last_balanced_blocks', C.c_int32), ('reserved_', C.c_int32)]
+                ('last_taper_split', C.c_int32), ('last_split_uncorrected_groups', C.c_int32), ('last_culled_fraction', C.c_double)]
 
 
 class PrisimCommStats(C.Structure):

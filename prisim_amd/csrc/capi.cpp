@@ -131,8 +131,6 @@ struct prisim_ctx {
   // the snapshot's terms; cull_any[prec]: anything culled at all.
   DevBuf cull_first;
   std::vector<double> cull_rho, cull_an;    // scratch of the cull-table walk: sin / |cos| of the zenith angle of a run's leading sources
-  DevBuf trace;                             // experiment hook PRISIM_HIP_BALANCED_TRACE
-  DevBuf piece_scratch, pieces, tail_item, piece_part;     // balanced grid: planner scratch, piece lists, tail owners, partial slots
   DevBuf moments_part;                    // per-chunk partial sums of k_taper_moments (reduced in fixed order)
   DevBuf step_tab;                        // round-4 experiment: step-phasor table of the packed fp32 kernel (PRISIM_HIP_STEP_TABLE=1)
   bool cull_any[2] = {false, false};
@@ -422,8 +420,6 @@ struct Plan {
   int ntiles;
   int nbgroups;
   bool pk;         // packed-fp32 kernel (k_skyvis_rec_f32pk) with interleaved pbflux pairs
-  bool g64;        // fp64 + taper on 16- / 32-channel tiles: the grouped kernel k_skyvis_taper_f64 (rows in natural channel order)
-  bool balanced;   // balanced grid: as many blocks as the chip holds, each walking an equal share of the work line (k_plan_pieces)
 };
 
 Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
@@ -438,16 +434,6 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   // (fp64 48-channel tiles were tried: 5.98 instead of 6.47 instructions per term, but 22 tiles x 239 groups = 10.3 rounds of resident
   // blocks end in a 7 % tail against 14.9 rounds at 32 channels -- measured 128 ms against 125 ms on the same box)
   int max_ct = pl.f32 ? 64 : 32;
-  // Balanced grid (skyvis_kernels.hip, k_plan_pieces): the launch has exactly the chip's resident blocks and every block an equal share of
-  // the work, so the tile no longer has to be narrow enough to make blocks, and sources are never split into whole partial cubes.  For the
-  // planner's own choices (no set_tuning request) on problems of >= 1e9 terms -- below that the launch is launch-bound and the two extra
-  // kernels (plan, tail reduction) cost more than the balance buys -- and for the kernels whose bodies take pieces: the packed fp32
-  // kernels, the fp64 kernel without the taper, the grouped fp64 taper kernel.  PRISIM_HIP_BALANCED=0: the legacy decomposition (A/B).
-  double min_terms = 1.0e9;
-  if (const char* env = getenv("PRISIM_HIP_BALANCED_MIN_TERMS")) min_terms = atof(env);      // test hook: exercise the piece lists on small skies
-  bool balanced = pl.kernel == PRISIM_KERNEL_RECURRENCE && ctx->tune_nsplit == 0 && ctx->tune_ct == 0 &&
-                  (double)nbl * (double)nchan * (double)nsrc >= min_terms && ctx->cu_count >= 8;
-  if (const char* env = getenv("PRISIM_HIP_BALANCED")) balanced = balanced && atoi(env) != 0;
   {
     // coarse channel grids with the taper run the exact per-step amplitude recurrence (the grouped form needs df/f_min <= 3.4e-3,
     // run_pass): its rounding grows with the chain length (5.8e-6 of one term at 32 steps and df/f = 3 %, tools/fuzz_parity.py),
@@ -456,10 +442,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
     if (pl.f32 && ctx->taper && !(fmin > 0.0 && std::fabs(ctx->df) <= 3.4e-3 * fmin)) max_ct = 32;
   }
   int ct = ctx->tune_ct;
-  if (ct == 0 && balanced) {
-    ct = max_ct;                         // the widest tile: the seed is amortised over the most channels, the grid is full whatever the tiling
-    while (ct > 8 && (int64_t)ct / 2 >= nchan) ct /= 2;          // (but not wider than the band)
-  } else if (ct == 0) {
+  if (ct == 0) {
     const int64_t want_blocks = 1024;
     const int64_t max_split = std::max<int64_t>(1, nsrc / 64);
     const double seed = pl.f32 ? 30.0 : 48.0;             // instructions per (source, baseline, tile) outside the pair loop (ISA census)
@@ -488,9 +471,6 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   if (ct > max_ct) ct = max_ct;          // a tuning request never overrides the accuracy cap (or the register budget) above
   pl.ct = ct;
   pl.pk = pl.f32 && (ct == 32 || ct == 64) && pl.kernel == PRISIM_KERNEL_RECURRENCE;
-  pl.g64 = !pl.f32 && ctx->taper && (ct == 16 || ct == 32) && pl.kernel == PRISIM_KERNEL_RECURRENCE;
-  if (const char* env = getenv("PRISIM_HIP_TAPER_F64_GROUP")) pl.g64 = pl.g64 && atoi(env) != 0;      // 0: the exact second-order form (A/B)
-  pl.balanced = balanced && (pl.pk || (!pl.f32 && (!ctx->taper || pl.g64)));
   pl.ntiles = (int)((nchan + ct - 1) / ct);
   // source chunk: granularity of the zero padding and of the source split (the kernels stream rows through scalar loads)
   const int esz = pl.f32 ? 4 : 8;
@@ -504,9 +484,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   // source split so that small problems still fill the GPU; each split is a multiple of the chunk
   int nsplit = ctx->tune_nsplit;
   const int64_t nchunks = pl.nsrc_pad / chunk;
-  if (pl.balanced) {
-    nsplit = 1;
-  } else if (nsplit == 0) {
+  if (nsplit == 0) {
     const int64_t base = (int64_t)pl.ntiles * pl.nbgroups;
     // resident blocks per CU = waves per SIMD the kernels are built for (PK_WAVES / WavesPerEU in skyvis_kernels.hip)
     // (fp64: the 16 KiB phasor table + 36 KiB flush buffer + prefetch area = 56 KiB of LDS per block allow 2 blocks per CU)
@@ -549,7 +527,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
 
 extern "C" {
 
-const char* prisim_hip_version(void) { return "prisim_hip 0.4 gfx950"; }     // 0.3: comm stats / self-test / gradient gather, asynchronous downloads
+const char* prisim_hip_version(void) { return "prisim_hip 0.3 gfx950"; }     // 0.3: comm stats / self-test / gradient gather, asynchronous downloads
 
 const char* prisim_hip_last_error(const prisim_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -608,7 +586,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->dirs_prep, &ctx->dirs_c32, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
-                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->grp_hz, &ctx->split_count, &ctx->cull_first, &ctx->step_tab, &ctx->moments_part, &ctx->piece_scratch, &ctx->pieces, &ctx->tail_item, &ctx->piece_part, &ctx->trace, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
+                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->grp_hz, &ctx->split_count, &ctx->cull_first, &ctx->step_tab, &ctx->moments_part, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
   for (int i = 0; i < prisim_ctx::kTimingRing; ++i)
     for (hipEvent_t ev : {ctx->ev_c0[i], ctx->ev_c1[i], ctx->ev_k0[i], ctx->ev_k1[i]})
@@ -1227,7 +1205,8 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   // fp64 with the source-shape taper (the reference's default precision on every run_prisim.py sky): the grouped kernel
   // k_skyvis_taper_f64 on 16- / 32-channel tiles, rows in natural channel order (PRISIM_HIP_TAPER_F64_GROUP=0: the exact second-order
   // form, k_skyvis_rec<double, CT, true> -- the A/B baseline and the 8-channel tiles' kernel)
-  const bool g64 = pl.g64;
+  bool g64 = !pl.f32 && ctx->taper && (pl.ct == 16 || pl.ct == 32);
+  if (const char* env = getenv("PRISIM_HIP_TAPER_F64_GROUP")) g64 = g64 && atoi(env) != 0;
   HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
                           pl.ntiles, (const double*)ctx->dirs.p, scale_comp, g64 ? 0 : 1, ctx->stream));
   p.out = pl.nsplit > 1 ? (double*)ctx->partial.p : dst;
@@ -1245,64 +1224,6 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   auto cull_table = [&](size_t r) { return (const int32_t*)ctx->cull_first.p + ((size_t)cpr * ctx->cull_nruns + r) * (size_t)pl.nbgroups; };
   if (cull && !split) p.src_first = cull_table(0);
   ctx->timing.last_culled_fraction = cull ? ctx->cull_frac[cpr] : 0.0;
-  // Balanced grid: every launch below is planned on the device first (k_plan_pieces: no host round trip, the culling table and the
-  // lift flags it weighs the groups by are device-resident) and followed by the tail reduction into dst.
-  int nblocks = pl.balanced ? ((std::max(ctx->cu_count, 8) * 2) & ~15) : 0;             // 2 resident blocks per CU (VGPRs / LDS of these kernels)
-  if (const char* env = getenv("PRISIM_HIP_BALANCED_BLOCKS")) { const int v = atoi(env) & ~15; if (pl.balanced && v >= 16 && v <= 65536) nblocks = v; }   // experiment hook
-  p.stagger = 0;
-  if (const char* env = getenv("PRISIM_HIP_BALANCED_STAGGER")) p.stagger = std::max(0, atoi(env));
-  if (pl.balanced) {
-    const int64_t nitems = (int64_t)pl.ntiles * pl.nbgroups;
-    const int maxp = plan_max_pieces(nitems, nblocks);
-    int rc2;
-    if ((rc2 = ensure(ctx, ctx->piece_scratch, (size_t)(nitems + 2) * sizeof(int64_t)))) return rc2;
-    if ((rc2 = ensure(ctx, ctx->pieces, (size_t)nblocks * maxp * sizeof(SkyPiece)))) return rc2;
-    if ((rc2 = ensure(ctx, ctx->tail_item, (size_t)nblocks * sizeof(int32_t)))) return rc2;
-    if ((rc2 = ensure(ctx, ctx->piece_part, (size_t)nblocks * kBlockThreads * pl.ct * 2 * sizeof(double)))) return rc2;
-    p.pieces = (const SkyPiece*)ctx->pieces.p;
-    p.max_pieces = maxp;
-    p.piece_blocks = nblocks;
-    p.piece_part = (double*)ctx->piece_part.p;
-  }
-  // relative cost per source of a group's body (x 64): the groups without the small-step guarantee run the plain rotation (no taper:
-  // 6 instead of 5 packed instructions per pair; fp64: 227 against 202 per source) or the re-anchored taper bodies
-  int old_share = 512;                                   // share (x 1024) of an XCD's work its first-dispatched half of the blocks gets
-  if (const char* env = getenv("PRISIM_HIP_BALANCED_OLD_SHARE")) old_share = std::min(1000, std::max(512, atoi(env)));
-  const int cost_lift = 64;
-  int cost_nolift = pl.f32 ? (ctx->taper ? 68 : 75) : (ctx->taper ? 64 : 72);
-  if (const char* env = getenv("PRISIM_HIP_BALANCED_COST_NOLIFT")) cost_nolift = std::max(1, atoi(env));        // experiment hook
-  // experiment hook: PRISIM_HIP_BALANCED_TRACE=<file> dumps, for the no-taper packed kernel, every block's piece list and the 100 MHz
-  // time stamps at its start and after each piece (synchronises: not for production runs)
-  const char* trace_path = pl.balanced ? getenv("PRISIM_HIP_BALANCED_TRACE") : nullptr;
-  if (trace_path) {
-    int rc3;
-    if ((rc3 = ensure(ctx, ctx->trace, (size_t)nblocks * (2 + p.max_pieces) * sizeof(unsigned long long)))) return rc3;
-    HIPCHK(ctx, hipMemsetAsync(ctx->trace.p, 0, (size_t)nblocks * (2 + p.max_pieces) * sizeof(unsigned long long), ctx->stream));
-    p.trace = (unsigned long long*)ctx->trace.p;
-  }
-  auto planned = [&](const SkyvisParams& q, auto&& launch) -> int {
-    if (pl.balanced)
-      HIPCHK(ctx, launch_plan_pieces(q, nblocks, q.max_pieces, cost_lift, cost_nolift, old_share, (int64_t*)ctx->piece_scratch.p,
-                                     (SkyPiece*)ctx->pieces.p, (int32_t*)ctx->tail_item.p, ctx->stream));
-    HIPCHK(ctx, launch(q));
-    if (trace_path) {
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      std::vector<unsigned long long> tr((size_t)nblocks * (2 + q.max_pieces));
-      std::vector<SkyPiece> pcs((size_t)nblocks * q.max_pieces);
-      HIPCHK(ctx, hipMemcpy(tr.data(), ctx->trace.p, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      HIPCHK(ctx, hipMemcpy(pcs.data(), ctx->pieces.p, pcs.size() * sizeof(SkyPiece), hipMemcpyDeviceToHost));
-      if (FILE* f = fopen(trace_path, "wb")) {
-        const int32_t hdr[4] = {nblocks, q.max_pieces, q.nbgroups, q.ntiles};
-        fwrite(hdr, sizeof(hdr), 1, f);
-        fwrite(tr.data(), sizeof(unsigned long long), tr.size(), f);
-        fwrite(pcs.data(), sizeof(SkyPiece), pcs.size(), f);
-        fclose(f);
-      }
-    }
-    if (pl.balanced) HIPCHK(ctx, launch_add_tails(q, nblocks, pl.ct, (const int32_t*)ctx->tail_item.p, dst, ctx->stream));
-    return PRISIM_OK;
-  };
-  int rcl;
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
   if (split) {
     int launches = 0;
@@ -1316,11 +1237,10 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
         q.kappa0 = run.kappa;
         if (cull) q.src_first = cull_table(r);
         q.split_flags = (const int32_t*)ctx->split_flags.p + r * (size_t)pl.nbgroups;
-        if ((rcl = planned(q, [&](const SkyvisParams& z) { return launch_skyvis_rec_f32pk_split(z, pl.ct, ctx->stream); }))) return rcl;
+        HIPCHK(ctx, launch_skyvis_rec_f32pk_split(q, pl.ct, ctx->stream));
       } else {
         q.taper = 0;                                   // point sources: w = 1 (:6270 sigma = inf), the lifting / plain bodies
-        q.src_first = nullptr;
-        if ((rcl = planned(q, [&](const SkyvisParams& z) { return launch_skyvis_rec_f32pk(z, pl.ct, ctx->stream); }))) return rcl;
+        HIPCHK(ctx, launch_skyvis_rec_f32pk(q, pl.ct, ctx->stream));
       }
       ++launches;
     }
@@ -1334,10 +1254,9 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
       if ((rc2 = ensure(ctx, ctx->step_tab, (size_t)pl.nsrc_pad * (size_t)pitch * sizeof(float) * 2))) return rc2;
       p.step_tab = (const float2*)ctx->step_tab.p;
       p.step_tab_pitch = pitch;
-      p.pieces = nullptr;                              // (the experiment runs the legacy decomposition)
       HIPCHK(ctx, launch_skyvis_rec_f32pk_stab(p, ctx->stream));
     } else {
-      if ((rcl = planned(p, [&](const SkyvisParams& z) { return launch_skyvis_rec_f32pk(z, pl.ct, ctx->stream); }))) return rcl;
+      HIPCHK(ctx, launch_skyvis_rec_f32pk(p, pl.ct, ctx->stream));
     }
   } else if (g64) {
     // run by run when the sky comes in runs of one source size (so that every run's leading sources can be culled); with a source
@@ -1351,13 +1270,13 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
         q.src_per_split = round_up(run.hi - run.lo, pl.chunk);
         q.accumulate = r > 0 ? 1 : 0;
         q.src_first = cull ? cull_table(r) : nullptr;
-        if ((rcl = planned(q, [&](const SkyvisParams& z) { return launch_skyvis_taper_f64(z, pl.ct, ctx->stream); }))) return rcl;
+        HIPCHK(ctx, launch_skyvis_taper_f64(q, pl.ct, ctx->stream));
       }
     } else {
-      if ((rcl = planned(p, [&](const SkyvisParams& z) { return launch_skyvis_taper_f64(z, pl.ct, ctx->stream); }))) return rcl;
+      HIPCHK(ctx, launch_skyvis_taper_f64(p, pl.ct, ctx->stream));
     }
   } else {
-    if ((rcl = planned(p, [&](const SkyvisParams& z) { return launch_skyvis_rec(z, pl.f32, pl.ct, ctx->stream); }))) return rcl;
+    HIPCHK(ctx, launch_skyvis_rec(p, pl.f32, pl.ct, ctx->stream));
   }
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
   if (pl.nsplit > 1)
@@ -1428,8 +1347,6 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     // fp32: 4 x 2 x 16 packed accumulators = 128 VGPRs; fp64: the taper's per-lane recurrence state does not fit beside 128 at 32
     pl.ct = f32 ? 16 : (ctx->taper ? 16 : 32);
     pl.pk = f32;
-    pl.g64 = false;
-    pl.balanced = false;                          // one unit per block: the gradient kernels keep the legacy decomposition
     pl.ntiles = (int)((ctx->nchan + pl.ct - 1) / pl.ct);
     pl.nsplit = 1;
     pl.nsrc_pad = round_up(pl.nsrc_pad, 4);       // the fp64 kernel walks the sources four at a time (zero rows past nsrc)
@@ -1501,7 +1418,6 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   ctx->timing.last_kernel_id = pl.kernel;
   ctx->timing.last_chan_tile = pl.kernel == PRISIM_KERNEL_RECURRENCE ? pl.ct : 1;
   ctx->timing.last_nsplit = pl.kernel == PRISIM_KERNEL_RECURRENCE ? pl.nsplit : 1;
-  ctx->timing.last_balanced_blocks = pl.balanced ? ((std::max(ctx->cu_count, 8) * 2) & ~15) : 0;
   return PRISIM_OK;
   });
 }

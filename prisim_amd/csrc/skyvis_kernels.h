@@ -8,11 +8,6 @@ namespace prisim {
 
 static constexpr int kBlockThreads = 256;   // 4 wavefronts; lanes = baselines
 
-// One unit of a block's work list in the balanced grid (k_plan_pieces): channel tile item / nbgroups of baseline group item % nbgroups,
-// sources [s_begin, s_end); dst = -1: the output slot itself (the piece holds the item's first source), dst >= 0: partial slot dst.
-// item < 0 ends a list.
-struct SkyPiece { int32_t item, s_begin, s_end, dst; };
-
 struct SkyvisParams {
   // array (resident)
   const double* bl_x;        // [nbl] metres, East
@@ -63,16 +58,6 @@ struct SkyvisParams {
   // rounded up to the block size
   const float2* step_tab;
   int64_t step_tab_pitch;
-  // balanced grid (nullptr: the legacy decomposition, one (tile, source split, baseline group) per block): the launch has piece_blocks
-  // blocks = resident slots of the chip, block b walks the list pieces[segment(b)][0 .. max_pieces)
-  const SkyPiece* pieces;
-  int32_t max_pieces;
-  int32_t piece_blocks;
-  int32_t stagger;           // balanced grid: blocks start after a block-dependent pause of up to `stagger` x 512 cycles (0: none)
-  int32_t pad5_;
-  unsigned long long* trace; // experiment hook (PRISIM_HIP_BALANCED_TRACE): [grid][2 + max_pieces] s_memrealtime stamps (100 MHz): block start,
-                             // end of every piece, 0-terminated
-  double* piece_part;        // [piece_blocks][kBlockThreads][CT] complex128: partial sums of the pieces that do not start their item
 };
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);
@@ -96,15 +81,6 @@ hipError_t launch_taper_moments(const double* pb, const double* dirs, int64_t s_
 hipError_t launch_skyvis_grad_f64(const SkyvisParams& p, int ct, hipStream_t stream);
 // the same in packed fp32 (VALU; p.nbgroups = groups of 256 baselines, 16-channel tiles, p.nsplit = 1, p.dirs_c32)
 hipError_t launch_skyvis_grad_f32(const SkyvisParams& p, hipStream_t stream);
-// Balanced grid.  k_plan_pieces (one block, on the stream: no host round trip) cuts the launch's work -- for every (tile, group) item the
-// sources [max(src_lo, src_first[bg]), src_hi) weighted by the group's body cost (cost_lift / cost_nolift per source, by lift_flags) --
-// into nblocks equal segments in item order and writes every segment's piece list, the slot its leading (non-initial) piece sums into,
-// and tail_item[segment] (the item that piece belongs to, -1: none).  scratch: (nitems + 2) int64.  max_pieces >= plan_max_pieces().
-int plan_max_pieces(int64_t nitems, int nblocks);
-hipError_t launch_plan_pieces(const SkyvisParams& p, int nblocks, int max_pieces, int cost_lift, int cost_nolift, int old_share_q10,
-                              int64_t* scratch, SkyPiece* pieces, int32_t* tail_item, hipStream_t stream);
-// out[item region] += partial slots of the item's non-initial pieces, in segment order (deterministic); ct = channel tile of the launch
-hipError_t launch_add_tails(const SkyvisParams& p, int nblocks, int ct, const int32_t* tail_item, double* out, hipStream_t stream);
 hipError_t launch_fsq_pairs(const float* fsq, float* pairs, int ct, int ntiles, hipStream_t stream);
 hipError_t launch_skyvis_direct(const SkyvisParams& p, const double* freqs, const double* pb, const double* scale,
                                 hipStream_t stream);

@@ -344,57 +344,6 @@ __device__ __forceinline__ bool block_item(const SkyvisParams& p, int& slab, int
   return (int)(blockIdx.x >> 3) < per_xcd && item < total;
 }
 
-// What one pass of a kernel body sums: channel tile `tile` of baseline group `bg` over sources [s_begin, s_end) into `dst`.
-//   legacy decomposition (p.pieces == nullptr): one unit per block from block_item(); split = which of the nsplit source ranges, the
-//     bodies derive the range themselves (src_per_split, culling) and write the split's partial cube -- dst = kDstLegacy;
-//   balanced grid (p.pieces, k_plan_pieces): a block walks its list of pieces; dst = -1: the output slot itself (the piece holds the
-//     item's first source: it initialises the region), dst >= 0: partial slot `dst` of p.piece_part ([slot][256 baselines][CT] complex128),
-//     added to the slot afterwards in a fixed order (k_add_tails).
-constexpr int kDstLegacy = -2;     // (-1: the output slot, what k_plan_pieces writes for the piece that starts an item)
-struct Work { int tile, bg, split, dst, s_begin, s_end; };
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }     // block-uniform by construction: keep it in an SGPR
-// The blocks of the balanced grid all start at t = 0 with the same instruction stream: two wavefronts that share a SIMD would then run
-// in lockstep for the whole launch (both in their seed, both at their waits, at the same moments).  A block-dependent pause at the start
-// puts them out of phase, as the staggered block starts of a multi-round grid do by themselves.
-__device__ __forceinline__ void stagger_start(const SkyvisParams& p) {
-  if (p.pieces != nullptr && p.stagger > 0) {
-    const unsigned h = ((unsigned)blockIdx.x * 2654435761u) >> 16;
-    const int n = (int)(h % (unsigned)p.stagger);
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);                  // 8 x 64 clocks
-  }
-}
-
-template <bool PIECES = true>
-__device__ __forceinline__ Work next_work(const SkyvisParams& p, int pi, bool& more) {
-  Work w;
-  w.tile = w.bg = w.split = w.s_begin = w.s_end = 0;
-  w.dst = kDstLegacy;
-  more = false;
-  if (PIECES && p.pieces != nullptr) {
-    if (pi >= p.max_pieces) return w;
-    const int nblk = (int)gridDim.x;                                           // a multiple of 8: block b runs segment (b & 7) nblk/8 + (b >> 3),
-    const int seg = (int)(blockIdx.x & 7) * (nblk >> 3) + (int)(blockIdx.x >> 3);   // so the blocks of one XCD walk neighbouring items
-    const SkyPiece* const pc = p.pieces + (size_t)seg * p.max_pieces + pi;
-    const int item = uni(pc->item);
-    if (item < 0) return w;
-    w.tile = item / p.nbgroups;
-    w.bg = item - w.tile * p.nbgroups;
-    w.dst = uni(pc->dst);
-    w.s_begin = uni(pc->s_begin);
-    w.s_end = uni(pc->s_end);
-    more = true;
-    return w;
-  }
-  if (pi > 0) return w;
-  int slab, bg;
-  if (!block_item(p, slab, bg)) return w;
-  w.tile = slab % p.ntiles;
-  w.split = slab / p.ntiles;
-  w.bg = bg;
-  more = true;
-  return w;
-}
-
 // LIFT: lifting (three-shear) form of the step rotation, see skyvis_rec_f32pk_body below; chosen per baseline group by the host.
 // TAPER: 0 = none; 1 = exact second-order amplitude recurrence on the pbflux operand (8 instructions per term);
 //   2 (fp64 only, k_skyvis_taper_f64) = the GROUPED form of the packed fp32 kernels carried over to fp64, made exact: ONE chain from the
@@ -405,8 +354,8 @@ __device__ __forceinline__ Work next_work(const SkyvisParams& p, int pi, bool& m
 //   rho_{t+1} = rho_t exp(-16 nu) per group.  Nothing is truncated: every factor is formed to fp64 accuracy (short series, or the library
 //   exp on a wave-uniform slow path for steps that are not small).  Rows are packed in natural channel order, one group = one 64-byte piece.
 template <typename T, int CT, int TAPER, bool LIFT>
-__device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, const Work w, unsigned char* flush_lds, unsigned char* pf_area,
-                                                const double2* tab, const double* etab = nullptr) {
+__device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned char* flush_lds, unsigned char* pf_area, const double2* tab,
+                                                const double* etab = nullptr) {
   static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
   static_assert(TAPER != 2 || (sizeof(T) == 8 && CT >= 16 && !LIFT), "the grouped fp64 taper: 16- or 32-channel tiles, folded (no lifting)");
   constexpr bool GROUPED = TAPER == 2;
@@ -422,19 +371,17 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, const Wor
   typedef const volatile __attribute__((address_space(4))) double* cdir_p;    // volatile: see the packed kernel (keeps the load where it is written)
   typedef const __attribute__((address_space(4))) float* cfsq_p;
 
-  const int tile = w.tile, split = w.split, bg = w.bg;
-  constexpr bool kTakesPieces = sizeof(T) == 8 && TAPER != 1;        // fp64 without the taper, and the grouped fp64 taper kernel
-  const bool legacy = !kTakesPieces || w.dst == kDstLegacy;
+  int slab, bg;
+  if (!block_item(p, slab, bg)) return;
+  const int tile = slab % p.ntiles;
+  const int split = slab / p.ntiles;
 
   int64_t s_begin = (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
   if (s_end > p.nsrc) s_end = p.nsrc;
-  // (TAPER == 1 bodies: no source ranges, no taper culling, no pieces -- a variable source range cost k_skyvis_rec<double,32,true> 47 more
-  // SGPR spills, 33 of them as lane moves inside its source loop; the grouped fp64 kernel has all three)
-  if (kTakesPieces && !legacy) {
-    s_begin = w.s_begin;
-    s_end = w.s_end;
-  } else if constexpr (GROUPED) {
+  // (TAPER == 1 bodies: no source ranges, no taper culling -- a variable source range cost k_skyvis_rec<double,32,true> 47 more SGPR
+  // spills, 33 of them as lane moves inside its source loop; the grouped fp64 kernel has both)
+  if constexpr (GROUPED) {
     // sources [src_lo, src_hi) of the sky (a run of one source size when the host walks the sky run by run), cut into nsplit pieces;
     // taper culling as in the packed fp32 kernels: the group's leading sources are provably below the tolerance (capi.cpp) and what is
     // left is cut into nsplit equal pieces again
@@ -482,11 +429,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, const Wor
   const cfsq_p gfq = (cfsq_p)(uintptr_t)(p.fsq_pairs ? p.fsq_pairs + (size_t)tile * CT : nullptr);   // fp32 taper only
 
   double* const out = p.out + ((size_t)split * p.nbl * p.nchan) * 2;   // partial buffer of this split
-  // accumulate: an earlier launch (another source run) already wrote this slot; partial slots of the balanced grid always start afresh
-  bool first_flush = !kTakesPieces ? true : (w.dst >= 0 || ((!GROUPED && legacy) || p.accumulate == 0));
-  // (a partial slot of the balanced grid is [256 baselines][CT channels]; its address is formed inside the flush from w.dst alone, so that
-  // nothing but that one SGPR stays live across the source loop)
-  const int dst_slot = kTakesPieces ? w.dst : kDstLegacy;
+  bool first_flush = !GROUPED || p.accumulate == 0;    // accumulate: an earlier launch (another source run) already wrote this slot
 
   using FV = typename FlushCfg<T>::vec;
   constexpr int FCH = FlushCfg<T>::ch < CT ? FlushCfg<T>::ch : CT;
@@ -518,9 +461,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, const Wor
             if (sizeof(T) == 4 && p.out_f32) {                     // complex64 partial of a source split: written once, no read-modify-write
               reinterpret_cast<float2*>(p.out)[((size_t)split * p.nbl + (size_t)bb) * p.nchan + k] = make_float2((float)a.x, (float)a.y);
             } else {
-              double2* o = (dst_slot >= 0)
-                  ? reinterpret_cast<double2*>(p.piece_part) + ((size_t)dst_slot * kBlockThreads + (size_t)(bb - (int64_t)bg * kBlockThreads)) * CT + (k - k0)
-                  : reinterpret_cast<double2*>(out) + (size_t)bb * p.nchan + k;
+              double2* o = reinterpret_cast<double2*>(out) + (size_t)bb * p.nchan + k;
               double2 v = make_double2((double)a.x, (double)a.y);
               if (!first_flush) { const double2 old = *o; v.x += old.x; v.y += old.y; }
               *o = v;
@@ -814,16 +755,13 @@ void k_skyvis_rec(const SkyvisParams p) {
     __syncthreads();                                             // the only block barrier of the kernel: before any early exit
     tab = tab_lds;
   }
-  constexpr bool PIECES = sizeof(T) == 8 && !TAPER;                   // the other instantiations always run one legacy unit per block
-  if (PIECES) stagger_start(p);
-  bool more;
-  for (int pi = 0; PIECES || pi == 0; ++pi) {
-    const Work w = next_work<PIECES>(p, pi, more);
-    if (!more) break;
-    // block-uniform choice per unit of work; the two bodies share no live state
-    if (p.lift_flags != nullptr && p.lift_flags[w.bg] != 0) skyvis_rec_body<T, CT, TAPER ? 1 : 0, true>(p, w, flush_lds, pf_area, tab);
-    else skyvis_rec_body<T, CT, TAPER ? 1 : 0, false>(p, w, flush_lds, pf_area, tab);
+  int slab_, bg;
+  const bool in_range = block_item(p, slab_, bg);                  // padding blocks read flag 0 and leave inside the body
+  if (in_range && p.lift_flags != nullptr && p.lift_flags[bg] != 0) {   // block-uniform; the two bodies share no live state
+    skyvis_rec_body<T, CT, TAPER ? 1 : 0, true>(p, flush_lds, pf_area, tab);
+    return;
   }
+  skyvis_rec_body<T, CT, TAPER ? 1 : 0, false>(p, flush_lds, pf_area, tab);
 }
 
 // fp64 sky-sum with the source-shape taper in the grouped form (TAPER = 2 bodies above): interferometry.py:6257-6283, 6332-6335 at the
@@ -838,13 +776,7 @@ void k_skyvis_taper_f64(const SkyvisParams p) {
   fill_phasor_table(tab_lds);
   fill_exp_table(etab_lds);
   __syncthreads();                                               // the only block barrier of the kernel: before any early exit
-  stagger_start(p);
-  bool more;
-  for (int pi = 0;; ++pi) {
-    const Work w = next_work(p, pi, more);
-    if (!more) break;
-    skyvis_rec_body<double, CT, 2, false>(p, w, flush_lds, pf_area, tab_lds, etab_lds);
-  }
+  skyvis_rec_body<double, CT, 2, false>(p, flush_lds, pf_area, tab_lds, etab_lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1103,7 +1035,7 @@ __device__ __forceinline__ float exp2m1_small(float D) {
 //   (source, baseline) pair from a table a pre-pass wrote (k_step_table: [nsrc_pad][pitch] float2, 512 contiguous bytes per wavefront and
 //   source) instead of evaluating the two polynomials in each of the 16 channel tiles.
 template <int CT, bool TAPER, bool LIFT, int TGROUP = 0, int REANCHOR = 0, bool GRAD = false, bool STAB = false>
-__device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, const Work w, unsigned char* flush_lds) {
+__device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, unsigned char* flush_lds) {
   static_assert(!STAB || (LIFT && !TAPER && !GRAD), "the step table serves the plain lifting bodies");
   constexpr int NR = GRAD ? 4 : 1;                   // accumulator sets: V (+ G_l, G_m, G_n)
   constexpr bool SPLIT = TGROUP >= 2;
@@ -1119,17 +1051,16 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, con
   constexpr int NPART = (TAPER && CT >= 64) ? 4 : 2;
   constexpr int NP = CT / NPART;                     // floats per piece
 
-  const int tile = w.tile, split = w.split, bg = w.bg;
-  const bool legacy = w.dst == kDstLegacy;
+  int slab, bg;
+  if (!block_item(p, slab, bg)) return;
+  const int tile = slab % p.ntiles;
+  const int split = slab / p.ntiles;
 
   // sources [src_lo, src_hi) of the sky (the whole sky unless the host walks it in ranges of one source size), cut into nsplit pieces
   int64_t s_begin = p.src_lo + (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
   if (s_end > p.src_hi) s_end = p.src_hi;
-  if (!legacy) {
-    s_begin = w.s_begin;                                 // balanced grid: the planner's piece (culling already applied)
-    s_end = w.s_end;
-  } else if (TAPER && p.src_first != nullptr) {
+  if (TAPER && p.src_first != nullptr) {
     // taper culling: the group's leading sources are provably below the tolerance (capi.cpp).  What is left is cut into nsplit EQUAL
     // pieces again, so that every split of the group shrinks alike (the XCD map deals whole slabs to XCDs: skipping only the first
     // split's sources would idle one XCD and leave the launch as long as before)
@@ -1170,10 +1101,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, con
   const cfloat_p gp = (cfloat_p)(uintptr_t)(reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT);
   const cdouble_p gd = (cdouble_p)(uintptr_t)p.dirs_prep;
   double2* const out = reinterpret_cast<double2*>(p.out) + (size_t)split * p.nbl * p.nchan;
-  bool first_flush = w.dst >= 0 || p.accumulate == 0;   // accumulate: an earlier launch (another source range) already wrote this slot
-  // (a partial slot of the balanced grid is [256 baselines][CT channels]; its address is formed inside the flush from w.dst alone, so that
-  // nothing but that one SGPR stays live across the source loop)
-  const int dst_slot = w.dst;
+  bool first_flush = p.accumulate == 0;              // accumulate: an earlier launch (another source range) already wrote this slot
   float2* const wbuf = reinterpret_cast<float2*>(flush_lds) + (tid >> 6) * (64 * 17);
   const int lane = tid & 63;
   const int64_t bw0 = (int64_t)bg * kBlockThreads + (tid & ~63);      // first baseline of this wave
@@ -1228,9 +1156,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, con
               }
               reinterpret_cast<float2*>(p.out)[((size_t)split * p.nbl + (size_t)bb) * p.nchan + k] = a2;
             } else {
-              double2* o = (dst_slot >= 0)
-                  ? reinterpret_cast<double2*>(p.piece_part) + ((size_t)dst_slot * kBlockThreads + (size_t)(bb - (int64_t)bg * kBlockThreads)) * CT + (k - k0)
-                  : outr + (size_t)bb * p.nchan + k;
+              double2* o = outr + (size_t)bb * p.nchan + k;
               double2 v = make_double2((double)a.x, (double)a.y);
               if constexpr (SPLIT) {
                 const double e = escale(ke_lds[bi], k);            // the source-independent half of the taper, exact per (baseline, channel)
@@ -1521,28 +1447,29 @@ template <int CT, bool TAPER>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void k_skyvis_rec_f32pk(const SkyvisParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>() + kPrefetchLdsBytes];
-  stagger_start(p);
-  unsigned long long* const tr = (p.pieces != nullptr && p.trace != nullptr && threadIdx.x == 0) ? p.trace + (size_t)blockIdx.x * (2 + p.max_pieces) : nullptr;
-  if (tr) tr[0] = __builtin_amdgcn_s_memrealtime();
-  bool more;
-  for (int pi = 0;; ++pi) {
-    const Work w = next_work(p, pi, more);
-    if (!more) { if (tr) tr[1 + pi] = 0ull; break; }
-    // lift_flags[bg] = 1: |step angle| <= pi/4 for every source of this baseline group (block-uniform per unit of work; the bodies share
-    // no live state).  No taper: the lifting rotation; taper: 0 = re-anchor the chains at their midpoint
-    const bool small_step = p.lift_flags != nullptr && p.lift_flags[w.bg] != 0;
-    if constexpr (!TAPER) {
-      if (small_step) skyvis_rec_f32pk_body<CT, false, true>(p, w, flush_lds);
-      else skyvis_rec_f32pk_body<CT, false, false>(p, w, flush_lds);
-    } else if (p.taper_group) {               // launch-uniform, chosen by the host from df / f_min
-      if (small_step) skyvis_rec_f32pk_body<CT, true, false, 1, 0>(p, w, flush_lds);
-      else skyvis_rec_f32pk_body<CT, true, false, 1, 2>(p, w, flush_lds);
-    } else {
-      if (small_step) skyvis_rec_f32pk_body<CT, true, false, 0, 1>(p, w, flush_lds);
-      else skyvis_rec_f32pk_body<CT, true, false, 0, 2>(p, w, flush_lds);
+  if constexpr (!TAPER) {
+    // block-uniform choice made by the host per baseline group; the two bodies share no live state
+    int slab_, bg;
+    if (!block_item(p, slab_, bg)) return;
+    if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {
+      skyvis_rec_f32pk_body<CT, false, true>(p, flush_lds);
+      return;
     }
-    if (tr) tr[1 + pi] = __builtin_amdgcn_s_memrealtime();
+  } else {
+    // lift_flags[bg] = 1: |step angle| <= pi/4 for every source of this baseline group; 0: re-anchor the chains at their midpoint
+    int slab_, bg;
+    if (!block_item(p, slab_, bg)) return;
+    const bool small_step = p.lift_flags != nullptr && p.lift_flags[bg] != 0;
+    if (p.taper_group) {                      // launch-uniform, chosen by the host from df / f_min
+      if (small_step) skyvis_rec_f32pk_body<CT, true, false, 1, 0>(p, flush_lds);
+      else skyvis_rec_f32pk_body<CT, true, false, 1, 2>(p, flush_lds);
+    } else {
+      if (small_step) skyvis_rec_f32pk_body<CT, true, false, 0, 1>(p, flush_lds);
+      else skyvis_rec_f32pk_body<CT, true, false, 0, 2>(p, flush_lds);
+    }
+    return;
   }
+  skyvis_rec_f32pk_body<CT, TAPER, false>(p, flush_lds);
 }
 
 // Round-4 experiment (PRISIM_HIP_STEP_TABLE=1, profiles/r04_ab_step_table.txt): the no-taper packed kernel with the lifting groups'
@@ -1551,14 +1478,13 @@ template <int CT>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void k_skyvis_rec_f32pk_stab(const SkyvisParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>() + kPrefetchLdsBytes];
-  stagger_start(p);
-  bool more;
-  for (int pi = 0;; ++pi) {
-    const Work w = next_work(p, pi, more);
-    if (!more) break;
-    if (p.lift_flags != nullptr && p.lift_flags[w.bg] != 0) skyvis_rec_f32pk_body<CT, false, true, 0, 0, false, true>(p, w, flush_lds);
-    else skyvis_rec_f32pk_body<CT, false, false>(p, w, flush_lds);
+  int slab_, bg;
+  if (!block_item(p, slab_, bg)) return;
+  if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {
+    skyvis_rec_f32pk_body<CT, false, true, 0, 0, false, true>(p, flush_lds);
+    return;
   }
+  skyvis_rec_f32pk_body<CT, false, false>(p, flush_lds);
 }
 
 // step_tab[s][b] = (-sin(2 pi y), tan(pi y)), y = (float)(d df), d = b . (s - s_pc)/c: exactly what the lifting bodies evaluate themselves
@@ -1583,22 +1509,18 @@ template <int CT>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void k_skyvis_rec_f32pk_split(const SkyvisParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>() + kPrefetchLdsBytes + kBlockThreads * sizeof(double)];
-  stagger_start(p);
-  bool more;
-  for (int pi = 0;; ++pi) {
-    const Work w = next_work(p, pi, more);
-    if (!more) break;
-    const int fl = p.split_flags[w.bg];
-    if (fl & 2) {
-      if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 2, 0>(p, w, flush_lds);
-      else skyvis_rec_f32pk_body<CT, true, false, 2, 2>(p, w, flush_lds);
-    } else if (fl & 4) {
-      if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 4, 0>(p, w, flush_lds);
-      else skyvis_rec_f32pk_body<CT, true, false, 4, 2>(p, w, flush_lds);
-    } else {
-      if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 3, 0>(p, w, flush_lds);
-      else skyvis_rec_f32pk_body<CT, true, false, 3, 2>(p, w, flush_lds);
-    }
+  int slab_, bg;
+  if (!block_item(p, slab_, bg)) return;
+  const int fl = p.split_flags[bg];
+  if (fl & 2) {
+    if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 2, 0>(p, flush_lds);
+    else skyvis_rec_f32pk_body<CT, true, false, 2, 2>(p, flush_lds);
+  } else if (fl & 4) {
+    if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 4, 0>(p, flush_lds);
+    else skyvis_rec_f32pk_body<CT, true, false, 4, 2>(p, flush_lds);
+  } else {
+    if (fl & 1) skyvis_rec_f32pk_body<CT, true, false, 3, 0>(p, flush_lds);
+    else skyvis_rec_f32pk_body<CT, true, false, 3, 2>(p, flush_lds);
   }
 }
 
@@ -1691,22 +1613,21 @@ template <bool TAPER>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void k_skyvis_grad_f32pk(const SkyvisParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>() + kPrefetchLdsBytes];
-  bool more;
-  const Work w = next_work<false>(p, 0, more);          // one unit per block: the gradient kernels run the legacy decomposition (nsplit = 1)
-  if (!more) return;
-  const bool small_step = p.lift_flags != nullptr && p.lift_flags[w.bg] != 0;
+  int slab_, bg;
+  if (!block_item(p, slab_, bg)) return;
+  const bool small_step = p.lift_flags != nullptr && p.lift_flags[bg] != 0;
   if constexpr (!TAPER) {
-    if (small_step) skyvis_rec_f32pk_body<16, false, true, 0, 0, true>(p, w, flush_lds);
-    else skyvis_rec_f32pk_body<16, false, false, 0, 0, true>(p, w, flush_lds);
+    if (small_step) skyvis_rec_f32pk_body<16, false, true, 0, 0, true>(p, flush_lds);
+    else skyvis_rec_f32pk_body<16, false, false, 0, 0, true>(p, flush_lds);
   } else {
     // 8 steps per chain: one group of the grouped recurrence and no mid-chain re-anchoring (HC < 32); the REANCHOR = 2 bodies are the ones
     // that seed the step phasor for any step angle (groups without the |theta| <= 1/8 cycle guarantee)
     if (p.taper_group) {
-      if (small_step) skyvis_rec_f32pk_body<16, true, false, 1, 0, true>(p, w, flush_lds);
-      else skyvis_rec_f32pk_body<16, true, false, 1, 2, true>(p, w, flush_lds);
+      if (small_step) skyvis_rec_f32pk_body<16, true, false, 1, 0, true>(p, flush_lds);
+      else skyvis_rec_f32pk_body<16, true, false, 1, 2, true>(p, flush_lds);
     } else {
-      if (small_step) skyvis_rec_f32pk_body<16, true, false, 0, 0, true>(p, w, flush_lds);
-      else skyvis_rec_f32pk_body<16, true, false, 0, 2, true>(p, w, flush_lds);
+      if (small_step) skyvis_rec_f32pk_body<16, true, false, 0, 0, true>(p, flush_lds);
+      else skyvis_rec_f32pk_body<16, true, false, 0, 2, true>(p, flush_lds);
     }
   }
 }
@@ -1858,169 +1779,13 @@ __global__ void k_fsq(const double* __restrict__ freqs, float* __restrict__ fsq,
 }
 
 // ------------------------------------------------------------------------------------------
-// Balanced grid: planner and tail reduction
-// ------------------------------------------------------------------------------------------
-// The legacy decomposition hands every block one (tile, source split, group) unit; the grid then runs in rounds of the chip's resident
-// blocks, the last round is partly empty, slower groups (no lifting rotation, re-anchored taper bodies) finish late, and small problems
-// need many source splits -- partial cubes the size of the output, written and read again.  Here the launch has exactly as many blocks as
-// the chip holds, and the work line (all items in slab-major order, each as long as its sources x its body cost) is cut into that many
-// EQUAL segments: every block starts at t = 0 and ends with the others; only the items a segment boundary falls into are summed in two
-// (rarely more) pieces, so the partial traffic is one 256 x CT block per cut instead of whole cubes.
-constexpr int kPlanThreads = 1024;
-constexpr int kPlanMinWidthDiv = 4;        // an item is at least 1/4 of the mean segment wide on the work line: bounds the pieces per segment
-
-__global__ __launch_bounds__(kPlanThreads)
-void k_plan_pieces(const SkyvisParams p, int nblocks, int max_pieces, int cost_lift, int cost_nolift, int old_share_q10,
-                   int64_t* __restrict__ prefix /*[nitems + 2]*/, SkyPiece* __restrict__ pieces, int32_t* __restrict__ tail_item) {
-  __shared__ int64_t red[kPlanThreads];
-  __shared__ int64_t carry_s, minw_s;
-  const int nitems = p.ntiles * p.nbgroups;
-  const int tid = threadIdx.x;
-  auto first_of = [&](int bg) -> int64_t {
-    int64_t f = p.src_lo;
-    if (p.src_first != nullptr) { const int64_t c = p.src_first[bg]; if (c > f) f = c; }
-    return f < p.src_hi ? f : p.src_hi;
-  };
-  auto cost_of = [&](int bg) -> int64_t { return (p.lift_flags != nullptr && p.lift_flags[bg] != 0) ? cost_lift : cost_nolift; };
-  // pass 1: total work -> minimum item width
-  int64_t acc = 0;
-  for (int i = tid; i < nitems; i += kPlanThreads) { const int bg = i % p.nbgroups; acc += (p.src_hi - first_of(bg)) * cost_of(bg); }
-  red[tid] = acc;
-  __syncthreads();
-  for (int st = kPlanThreads / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-  if (tid == 0) {
-    const int64_t l0 = (red[0] + nblocks - 1) / nblocks;
-    minw_s = l0 / kPlanMinWidthDiv > 1 ? l0 / kPlanMinWidthDiv : 1;
-    carry_s = 0;
-  }
-  __syncthreads();
-  const int64_t minw = minw_s;
-  // pass 2: exclusive prefix sums of the item widths, chunk by chunk
-  for (int base = 0; base < nitems; base += kPlanThreads) {
-    const int i = base + tid;
-    int64_t wdt = 0;
-    if (i < nitems) { const int bg = i % p.nbgroups; wdt = (p.src_hi - first_of(bg)) * cost_of(bg); if (wdt < minw) wdt = minw; }
-    red[tid] = wdt;
-    __syncthreads();
-    for (int st = 1; st < kPlanThreads; st <<= 1) {                     // inclusive scan
-      const int64_t add = tid >= st ? red[tid - st] : 0;
-      __syncthreads();
-      red[tid] += add;
-      __syncthreads();
-    }
-    if (i < nitems) prefix[i] = carry_s + red[tid] - wdt;
-    __syncthreads();
-    if (tid == kPlanThreads - 1) carry_s += red[tid];
-    __syncthreads();
-  }
-  if (tid == 0) prefix[nitems] = carry_s;
-  __syncthreads();
-  const int64_t W = carry_s;
-  // Segment boundaries.  The two blocks a CU holds are not served alike: the SIMD issues the OLDER wavefront first, the younger one gets the
-  // cycles the older leaves (measured, profiles/r04_balanced_grid.txt: 4.7 ms against 17-20 ms per item while both are resident).  Blocks
-  // are dispatched in index order, so the first half of an XCD's blocks are the older ones on their CUs: they are given old_share / 1024 of
-  // the XCD's work, the second half the rest, so that both finish together (512: equal segments).
-  const int B = nblocks >> 3, half = B >> 1;
-  const int64_t Wx = (W + 7) / 8;
-  const int64_t Lo = (Wx * old_share_q10 / 1024 + half - 1) / half, Ly = (Wx - Lo * half + (B - half) - 1) / (B - half);
-  auto bound = [&](int j) -> int64_t {                                   // start tick of segment j (j = nblocks: the end)
-    const int x = j / B, k = j - x * B;
-    int64_t v = (int64_t)x * Wx + (k < half ? (int64_t)k * Lo : (int64_t)half * Lo + (int64_t)(k - half) * (Ly > 0 ? Ly : 0));
-    const int64_t xend = (int64_t)(x + 1) * Wx;
-    if (v > xend) v = xend;
-    return v < W ? v : W;
-  };
-  // pass 3: one thread per segment
-  for (int j = tid; j < nblocks; j += kPlanThreads) {
-    SkyPiece* const list = pieces + (size_t)j * max_pieces;
-    int cnt = 0;
-    int32_t tail = -1;
-    const int64_t a = bound(j), b = (j + 1 < nblocks) ? bound(j + 1) : W;
-    if (a < b) {
-      int lo = 0, hi = nitems;                                          // largest i with prefix[i] <= a
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= a) lo = mid; else hi = mid; }
-      for (int i = lo; i < nitems && prefix[i] < b && cnt < max_pieces; ++i) {
-        const int bg = i % p.nbgroups;
-        const int64_t first = first_of(bg), n = p.src_hi - first, c = cost_of(bg);
-        const int64_t pi0 = prefix[i], pi1 = prefix[i + 1];
-        const bool head = a <= pi0;
-        int64_t olo = head ? 0 : ((a - pi0) / c) & ~(int64_t)7;
-        int64_t ohi = (b >= pi1) ? n : ((b - pi0) / c) & ~(int64_t)7;
-        if (olo > n) olo = n;
-        if (ohi > n) ohi = n;
-        // (a non-initial piece that the snapping left empty is still emitted -- its block writes zeros into its slot -- so that the slots of
-        // an item's later pieces form ONE unbroken run of segments: k_add_tails lets the first of the run add them all, in order)
-        SkyPiece pc;
-        pc.item = i;
-        pc.s_begin = (int32_t)(first + olo);
-        pc.s_end = (int32_t)(first + (ohi > olo ? ohi : olo));
-        pc.dst = head ? -1 : j;
-        if (!head) tail = i;
-        list[cnt++] = pc;
-      }
-    }
-    if (cnt < max_pieces) list[cnt].item = -1;
-    tail_item[j] = tail;
-  }
-}
-
-int plan_max_pieces(int64_t nitems, int nblocks) {
-  // every item is >= L0 / 4 wide and a segment at most 2 L0 (1 + nitems / (4 nblocks)) long (the older blocks' share): a segment holds at
-  // most 8 + 2 nitems / nblocks + 2 item starts, + its tail
-  return 2 * (int)(nitems / nblocks) + 2 * kPlanMinWidthDiv + 6;
-}
-
-template <int CT>
-__global__ void k_add_tails(const SkyvisParams p, const int32_t* __restrict__ tail_item, double2* __restrict__ out) {
-  const int j = blockIdx.x, nblk = gridDim.x;
-  const int item = tail_item[j];
-  if (item < 0 || (j > 0 && tail_item[j - 1] == item)) return;         // no tail here, or not the first tail of its item
-  const int tile = item / p.nbgroups, bg = item - tile * p.nbgroups;
-  const double2* const part = reinterpret_cast<const double2*>(p.piece_part);
-  for (int e = threadIdx.x; e < kBlockThreads * CT; e += blockDim.x) {
-    const int64_t bb = (int64_t)bg * kBlockThreads + e / CT;
-    const int64_t k = (int64_t)tile * CT + e % CT;
-    if (bb >= p.nbl || k >= p.nchan) continue;
-    double2* const o = out + (size_t)bb * p.nchan + k;
-    double2 v = *o;
-    for (int jj = j; jj < nblk && tail_item[jj] == item; ++jj) {        // segment order: deterministic
-      const double2 a = part[(size_t)jj * (kBlockThreads * CT) + e];
-      v.x += a.x; v.y += a.y;
-    }
-    *o = v;
-  }
-}
-
-hipError_t launch_plan_pieces(const SkyvisParams& p, int nblocks, int max_pieces, int cost_lift, int cost_nolift, int old_share_q10,
-                              int64_t* scratch, SkyPiece* pieces, int32_t* tail_item, hipStream_t stream) {
-  if (nblocks < 16 || (nblocks & 15) || max_pieces < 1 || p.src_hi >= (int64_t)0x7fffffff || p.nsplit != 1 || old_share_q10 < 512 ||
-      old_share_q10 > 1000)
-    return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_plan_pieces, dim3(1), dim3(kPlanThreads), 0, stream, p, nblocks, max_pieces, cost_lift, cost_nolift, old_share_q10, scratch,
-                     pieces, tail_item);
-  return hipGetLastError();
-}
-
-hipError_t launch_add_tails(const SkyvisParams& p, int nblocks, int ct, const int32_t* tail_item, double* out, hipStream_t stream) {
-  double2* o = reinterpret_cast<double2*>(out);
-  switch (ct) {
-    case 8: hipLaunchKernelGGL((k_add_tails<8>), dim3(nblocks), dim3(256), 0, stream, p, tail_item, o); break;
-    case 16: hipLaunchKernelGGL((k_add_tails<16>), dim3(nblocks), dim3(256), 0, stream, p, tail_item, o); break;
-    case 32: hipLaunchKernelGGL((k_add_tails<32>), dim3(nblocks), dim3(256), 0, stream, p, tail_item, o); break;
-    case 64: hipLaunchKernelGGL((k_add_tails<64>), dim3(nblocks), dim3(256), 0, stream, p, tail_item, o); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 template <typename T, int CT>
 static hipError_t launch_rec_ct(const SkyvisParams& p, hipStream_t stream) {
   const int64_t items = (int64_t)p.ntiles * p.nsplit * p.nbgroups;          // see block_item()
   if (items <= 0 || items > 0x3fffffffLL) return hipErrorInvalidValue;
-  const unsigned grid = p.pieces ? (unsigned)p.piece_blocks : 8u * (unsigned)((items + 7) / 8);
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
   if (p.taper)
     hipLaunchKernelGGL((k_skyvis_rec<T, CT, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   else
@@ -2032,7 +1797,7 @@ template <int CT>
 static hipError_t launch_rec_pk_ct(const SkyvisParams& p, hipStream_t stream) {
   const int64_t items = (int64_t)p.ntiles * p.nsplit * p.nbgroups;          // see block_item()
   if (items <= 0 || items > 0x3fffffffLL) return hipErrorInvalidValue;
-  const unsigned grid = p.pieces ? (unsigned)p.piece_blocks : 8u * (unsigned)((items + 7) / 8);
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
   if (p.taper)
     hipLaunchKernelGGL((k_skyvis_rec_f32pk<CT, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   else
@@ -2053,7 +1818,7 @@ hipError_t launch_skyvis_rec_f32pk_stab(const SkyvisParams& p, hipStream_t strea
   if (items <= 0 || items > 0x3fffffffLL || !p.step_tab || p.taper) return hipErrorInvalidValue;
   // the table first (inside the caller's timed region: it is part of what this form costs per snapshot)
   hipLaunchKernelGGL(k_step_table, dim3((unsigned)((p.step_tab_pitch + 255) / 256), 2048), dim3(256), 0, stream, p, const_cast<float2*>(p.step_tab));
-  const unsigned grid = p.pieces ? (unsigned)p.piece_blocks : 8u * (unsigned)((items + 7) / 8);
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
   hipLaunchKernelGGL((k_skyvis_rec_f32pk_stab<64>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   return hipGetLastError();
 }
@@ -2061,7 +1826,7 @@ hipError_t launch_skyvis_rec_f32pk_stab(const SkyvisParams& p, hipStream_t strea
 hipError_t launch_skyvis_rec_f32pk_split(const SkyvisParams& p, int ct, hipStream_t stream) {
   const int64_t items = (int64_t)p.ntiles * p.nsplit * p.nbgroups;
   if (items <= 0 || items > 0x3fffffffLL || !p.split_flags || ct != 64) return hipErrorInvalidValue;
-  const unsigned grid = p.pieces ? (unsigned)p.piece_blocks : 8u * (unsigned)((items + 7) / 8);
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
   hipLaunchKernelGGL((k_skyvis_rec_f32pk_split<64>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   return hipGetLastError();
 }
@@ -2105,7 +1870,7 @@ hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_
 hipError_t launch_skyvis_taper_f64(const SkyvisParams& p, int ct, hipStream_t stream) {
   const int64_t items = (int64_t)p.ntiles * p.nsplit * p.nbgroups;          // see block_item()
   if (items <= 0 || items > 0x3fffffffLL || !p.taper) return hipErrorInvalidValue;
-  const unsigned grid = p.pieces ? (unsigned)p.piece_blocks : 8u * (unsigned)((items + 7) / 8);
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
   switch (ct) {
     case 16: hipLaunchKernelGGL((k_skyvis_taper_f64<16>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
     case 32: hipLaunchKernelGGL((k_skyvis_taper_f64<32>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
@@ -2118,7 +1883,7 @@ hipError_t launch_skyvis_grad_f32(const SkyvisParams& p, hipStream_t stream) {
   // p.nbgroups = groups of 256 baselines, p.nsplit = 1, 16-channel tiles, p.dirs_c32 and p.grad_out set
   const int64_t items = (int64_t)p.ntiles * p.nbgroups;
   if (items <= 0 || items > 0x3fffffffLL || p.nsplit != 1 || !p.dirs_c32 || !p.grad_out) return hipErrorInvalidValue;
-  const unsigned grid = p.pieces ? (unsigned)p.piece_blocks : 8u * (unsigned)((items + 7) / 8);
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
   if (p.taper) hipLaunchKernelGGL((k_skyvis_grad_f32pk<true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   else hipLaunchKernelGGL((k_skyvis_grad_f32pk<false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   return hipGetLastError();
@@ -2128,7 +1893,7 @@ hipError_t launch_skyvis_grad_f64(const SkyvisParams& p, int ct, hipStream_t str
   // p.nbgroups = groups of 64 baselines, p.nsplit = 1
   const int64_t items = (int64_t)p.ntiles * p.nbgroups;
   if (items <= 0 || items > 0x3fffffffLL || p.nsplit != 1) return hipErrorInvalidValue;
-  const unsigned grid = p.pieces ? (unsigned)p.piece_blocks : 8u * (unsigned)((items + 7) / 8);
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
   if (ct == 32 && !p.taper) {           // (the taper's per-lane recurrence state does not fit beside 128 accumulator VGPRs at 32 channels)
     hipLaunchKernelGGL((k_skyvis_grad_f64<32, false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   } else if (ct == 16) {

@@ -350,75 +350,6 @@ def test_fp64_grouped_taper_runs_culling_and_slow_path(ctx, monkeypatch):
     ctx.set_tuning(0, 0, 0)
 
 
-def test_balanced_grid_equals_the_legacy_decomposition(ctx, monkeypatch):
-    """The balanced grid (k_plan_pieces: as many blocks as the chip holds, the work line cut into equal segments, an item a boundary falls
-    into summed in pieces, the non-initial pieces through partial slots and k_add_tails) against the oracle and against the legacy
-    decomposition (PRISIM_HIP_BALANCED=0), with the size threshold lowered so that a few items are cut into hundreds of pieces of 8-16
-    sources: both precisions, no taper (lifting and plain groups), fp32 split taper over three source runs with periodic flushes, fp64
-    grouped taper run by run, taper culling, sources fewer than blocks, and an explicit set_tuning request (legacy by contract)."""
-    rng = NP.random.default_rng(2026)
-    nbl, nchan, nsrc = 700, 200, 1300
-    bl = rng.uniform(-290.0, 290.0, size=(nbl, 3)); bl[:, 2] *= 0.01
-    bl[-150:] *= 9.0                                                      # a last group without the small-step guarantee
-    ch = 150e6 + (NP.arange(nchan) - 100) * 97656.25
-    pc = O.altaz2dircos(NP.array([[85.0, 120.0]]))[0]
-    alt = NP.degrees(NP.arcsin(rng.uniform(NP.sin(NP.radians(4.0)), 1.0, nsrc)))
-    dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, nsrc)), axis=1))
-    pb = rng.uniform(0.5, 10.0, size=(nsrc, 1)) * rng.uniform(0.5, 1.0, size=(nsrc, nchan))
-    monkeypatch.setenv('PRISIM_HIP_BALANCED_MIN_TERMS', '1')
-    ctx.set_array(bl, ch)
-    ctx.set_tuning(0, 0, 0)
-    cases = [('no taper', None), ('three runs', NP.concatenate((NP.zeros(300), NP.full(600, 0.229), NP.full(400, 0.458)))),
-             ('sizes vary', rng.uniform(0.0, 0.6, nsrc))]
-    for name, fw in cases:
-        ref = CO.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw)
-        ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
-        for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):
-            if prec == _abi.PRISIM_FP32:
-                monkeypatch.setenv('PRISIM_HIP_FLUSH_SRC', '40')            # pieces longer than a flush segment: read-modify-write of slots too
-            res = {}
-            for mode in ('1', '0'):
-                monkeypatch.setenv('PRISIM_HIP_BALANCED', mode)
-                ctx.compute(precision=prec)
-                tm = ctx.timing()
-                assert (tm['last_balanced_blocks'] > 0) == (mode == '1'), (name, prec, mode, tm)
-                res[mode] = ctx.get_vis()
-                assert relerr(res[mode], ref, pb) <= TOL[prec], (name, prec, mode)
-            assert relerr(res['1'], res['0'], pb) <= (1e-12 if prec == _abi.PRISIM_FP64 else 1.5e-6), (name, prec)
-            monkeypatch.delenv('PRISIM_HIP_FLUSH_SRC', raising=False)
-    monkeypatch.setenv('PRISIM_HIP_BALANCED', '1')
-    # fewer sources than blocks; one source; an explicit tuning request keeps the legacy decomposition
-    for n in (200, 1):
-        ref = CO.skyvis(bl, ch, dc[:n], pb[:n], pc)
-        ctx.set_sky(dc[:n], pb[:n], pc)
-        for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):
-            ctx.compute(precision=prec)
-            assert ctx.timing()['last_balanced_blocks'] > 0 and relerr(ctx.get_vis(), ref, pb[:n]) <= TOL[prec], (n, prec)
-    ctx.set_sky(dc, pb, pc)
-    ctx.set_tuning(0, 0, 2)
-    ctx.compute(precision=_abi.PRISIM_FP32)
-    assert ctx.timing()['last_balanced_blocks'] == 0 and ctx.timing()['last_nsplit'] == 2
-    assert relerr(ctx.get_vis(), CO.skyvis(bl, ch, dc, pb, pc), pb) <= TOL[_abi.PRISIM_FP32]
-    ctx.set_tuning(0, 0, 0)
-    # taper culling on the balanced grid: MWA-like baselines over nside-64-size pixels listed by decreasing altitude, second run
-    xy = rng.normal(0.0, 800.0, size=(1024, 2))
-    bl3 = NP.hstack((xy, rng.normal(0.0, 0.5, size=(1024, 1))))
-    bl3 = bl3[NP.argsort(NP.sqrt(NP.sum(bl3 ** 2, axis=1)))]
-    ch3 = 170e6 + NP.arange(64) * 40e3
-    alt3 = NP.concatenate((alt[:100], NP.sort(alt[100:])[::-1]))
-    dc3 = O.altaz2dircos(NP.stack((alt3, rng.uniform(0, 360, nsrc)), axis=1))
-    pb3 = rng.uniform(0.5, 10.0, size=(nsrc, 1)) * rng.uniform(0.5, 1.0, size=(nsrc, ch3.size))
-    fw3 = NP.concatenate((NP.zeros(100), NP.full(nsrc - 100, 0.916)))
-    ref3 = CO.skyvis(bl3, ch3, dc3, pb3, pc, fwhm_deg=fw3)
-    ctx.set_array(bl3, ch3)
-    ctx.set_sky(dc3, pb3, pc, fwhm_deg=fw3)
-    for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):
-        ctx.compute(precision=prec)
-        tm = ctx.timing()
-        assert tm['last_balanced_blocks'] > 0 and tm['last_culled_fraction'] > 0.05, tm
-        assert relerr(ctx.get_vis(), ref3, pb3) <= TOL[prec], prec
-
-
 @pytest.mark.parametrize('taper', [False, True])
 def test_fp32_single_source_worst_case_per_term(ctx, taper):
     """One source, so nothing averages: the error of every (baseline, channel) term against the fp64 oracle must stay inside the
