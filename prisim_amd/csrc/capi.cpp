@@ -1293,8 +1293,17 @@ static int run_grad_pass(prisim_ctx* ctx, const Plan& pl, double* dst, double* g
   p.out = dst;
   p.grad_out = gdst;
   p.out_f32 = 0;
-  HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
-                          (const double*)ctx->dirs.p, -1, 1, ctx->stream));
+  if (pl.f32 && !ctx->taper) {
+    // rows pre-multiplied by the gradient coefficients (1, l, m, n): 64 floats per (source, 16-channel tile)
+    int rc2;
+    if ((rc2 = ensure(ctx, ctx->packed, (size_t)pl.ntiles * pl.nsrc_pad * 64 * sizeof(float)))) return rc2;
+    p.pb_packed = ctx->packed.p;
+    HIPCHK(ctx, launch_pack_grad((const double*)ctx->pb.p, (float*)ctx->packed.p, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ntiles,
+                                 (const double*)ctx->dirs.p, ctx->stream));
+  } else {
+    HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
+                            (const double*)ctx->dirs.p, -1, 1, ctx->stream));
+  }
   HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
   if (pl.f32) {
     p.dirs_c32 = (const float*)ctx->dirs_c32.p;

@@ -79,13 +79,17 @@ hipError_t launch_taper_moments(const double* pb, const double* dirs, int64_t s_
                                 hipStream_t stream);
 // V + baseline gradient in one pass (fp64, MFMA 4x4x4): p.nbgroups = groups of 64 baselines, p.nsplit = 1, ct = 16 or 32
 hipError_t launch_skyvis_grad_f64(const SkyvisParams& p, int ct, hipStream_t stream);
-// the same in packed fp32 (VALU; p.nbgroups = groups of 256 baselines, 16-channel tiles, p.nsplit = 1, p.dirs_c32)
+// the same in packed fp32 (VALU; p.nbgroups = groups of 256 baselines, 16-channel tiles, p.nsplit = 1; with the taper: rows from
+// launch_pack + p.dirs_c32; without: rows from launch_pack_grad)
 hipError_t launch_skyvis_grad_f32(const SkyvisParams& p, hipStream_t stream);
 hipError_t launch_fsq_pairs(const float* fsq, float* pairs, int ct, int ntiles, hipStream_t stream);
 hipError_t launch_skyvis_direct(const SkyvisParams& p, const double* freqs, const double* pb, const double* scale,
                                 hipStream_t stream);
 hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct,
                        int ntiles, const double* dirs, int scale_comp, int interleave, hipStream_t stream);
+// rows of the fused fp32 gradient kernel without the taper: [ntiles(16 ch)][nsrc_pad][64] floats, pre-multiplied by (1, l, m, n)
+hipError_t launch_pack_grad(const double* pb, float* packed, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ntiles, const double* dirs,
+                            hipStream_t stream);
 hipError_t launch_prep_dirs(const double* dirs, double* prep, float* c32 /*[nsrc_pad][8] or NULL*/, int64_t nsrc, int64_t nsrc_pad, double pcx,
                             double pcy, double pcz, double inv_c, hipStream_t stream);
 hipError_t launch_reduce_partials(const void* part, bool part_f32, double* out, int64_t n2, int nsplit, hipStream_t stream);

@@ -1034,9 +1034,15 @@ __device__ __forceinline__ float exp2m1_small(float D) {
 //   STAB (round-4 experiment, PRISIM_HIP_STEP_TABLE=1): the lifting bodies read their step phasor (sin alpha, tan alpha/2) of a
 //   (source, baseline) pair from a table a pre-pass wrote (k_step_table: [nsrc_pad][pitch] float2, 512 contiguous bytes per wavefront and
 //   source) instead of evaluating the two polynomials in each of the 16 channel tiles.
-template <int CT, bool TAPER, bool LIFT, int TGROUP = 0, int REANCHOR = 0, bool GRAD = false, bool STAB = false>
+//   GPK (GRAD bodies without the taper): the rows arrive PRE-MULTIPLIED by the gradient coefficients -- k_pack_grad writes, per source and
+//   16-channel tile, the four operand rows p, p l, p m, p n interleaved per pair as (set, up / down), 64 floats = one 256-byte row like a
+//   64-channel tile's -- so every accumulator set takes its own SGPR-pair operand straight into v_pk_fma_f32: 8 accumulate FMAs + the
+//   3-instruction lifting rotation = 11 packed instructions per pair of terms instead of 13 (term = p zeta first, then four adds / FMAs), and
+//   the per-source coefficient load disappears.
+template <int CT, bool TAPER, bool LIFT, int TGROUP = 0, int REANCHOR = 0, bool GRAD = false, bool STAB = false, bool GPK = false>
 __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, unsigned char* flush_lds) {
   static_assert(!STAB || (LIFT && !TAPER && !GRAD), "the step table serves the plain lifting bodies");
+  static_assert(!GPK || (GRAD && !TAPER), "pre-multiplied rows: the gradient bodies without the taper");
   constexpr int NR = GRAD ? 4 : 1;                   // accumulator sets: V (+ G_l, G_m, G_n)
   constexpr bool SPLIT = TGROUP >= 2;
   constexpr bool PARABOLA = TGROUP == 1 || TGROUP == 2;
@@ -1049,7 +1055,8 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   // pieces per row: halves (2 x 32 SGPRs at CT = 64) without the taper; quarters with it, whose extra wave-uniform state would
   // otherwise push the row buffers out of the ~100 SGPRs (48 v_readlane/v_writelane per source in the loop)
   constexpr int NPART = (TAPER && CT >= 64) ? 4 : 2;
-  constexpr int NP = CT / NPART;                     // floats per piece
+  constexpr int ROWF = GPK ? 4 * CT : CT;            // floats per (source, tile) row
+  constexpr int NP = ROWF / NPART;                   // floats per piece
 
   int slab, bg;
   if (!block_item(p, slab, bg)) return;
@@ -1098,7 +1105,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
 #pragma unroll
     for (int j = 0; j < HC; ++j) { acc_re[r][j] = (f32x2)(0.f); acc_im[r][j] = (f32x2)(0.f); }
 
-  const cfloat_p gp = (cfloat_p)(uintptr_t)(reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT);
+  const cfloat_p gp = (cfloat_p)(uintptr_t)(reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * ROWF);
   const cdouble_p gd = (cdouble_p)(uintptr_t)p.dirs_prep;
   double2* const out = reinterpret_cast<double2*>(p.out) + (size_t)split * p.nbl * p.nchan;
   bool first_flush = p.accumulate == 0;              // accumulate: an earlier launch (another source range) already wrote this slot
@@ -1183,9 +1190,9 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   // One flush site, 32-bit source indices (the host keeps nsrc below 2^31).
   const int n_loc = s_end > s_begin ? (int)(s_end - s_begin) : 0;
   const int seg_len = p.flush_src > 0 ? p.flush_src : 0x7fffffff;
-  const cfloat_p gps = gp + (size_t)s_begin * CT;
+  const cfloat_p gps = gp + (size_t)s_begin * ROWF;
   const cdouble_p gds = gd + (size_t)s_begin * 4;
-  const float* const pf_rows = reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT + (size_t)s_begin * CT;
+  const float* const pf_rows = reinterpret_cast<const float*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * ROWF + (size_t)s_begin * ROWF;
   const float* const pf_dirs = reinterpret_cast<const float*>(p.dirs_prep) + (size_t)s_begin * 8;
   const lptr_t pf_lds = (lptr_t)(flush_lds + flush_lds_bytes<float>() + (tid >> 6) * kPrefetchWaveBytes);
   const bool pf_on = n_loc >= 64;                    // 4 (CT = 64) or 8 rows per request, clamped 8 rows before the end
@@ -1197,14 +1204,14 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
     float ra[NP], rb[NP];
     double sv[4] = {0.0, 0.0, 0.0, 0.0};
     f32x8 cs = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // GRAD: (l, l, m, m, n, n, 0, 0) of the source: three SGPR pairs, one s_load_dwordx8
-    const cf32x8_p gcs = (cf32x8_p)(uintptr_t)(GRAD ? p.dirs_c32 + (size_t)s_begin * 8 : nullptr);
+    const cf32x8_p gcs = (cf32x8_p)(uintptr_t)((GRAD && !GPK) ? p.dirs_c32 + (size_t)s_begin * 8 : nullptr);
     // STAB: this lane's column of the step table, one source ahead in a register pair
     const float2* const stab = STAB ? p.step_tab + (size_t)s_begin * (size_t)p.step_tab_pitch + (size_t)bw0 : nullptr;
     float2 st_next = make_float2(0.f, 0.f);
     if constexpr (STAB) st_next = stab[(size_t)seg0 * (size_t)p.step_tab_pitch + lane];
     {
-      if constexpr (GRAD) cs = gcs[seg0];
-      const cfloat_p r0 = gps + (size_t)PRISIM_ROW_INDEX(seg0) * CT;
+      if constexpr (GRAD && !GPK) cs = gcs[seg0];
+      const cfloat_p r0 = gps + (size_t)PRISIM_ROW_INDEX(seg0) * ROWF;
 #pragma unroll
       for (int i = 0; i < NP; ++i) ra[i] = r0[i];
       // volatile: keeps instcombine from folding phi(load before the loop, load in the loop) into one load of a phi'd address at
@@ -1214,15 +1221,15 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       if (TAPER) sv[3] = d0[3];
     }
     for (int s = seg0; s < seg1; ++s) {
-      const cfloat_p row = gps + (size_t)PRISIM_ROW_INDEX(s) * CT;
+      const cfloat_p row = gps + (size_t)PRISIM_ROW_INDEX(s) * ROWF;
       const int sn = (s + 1 < seg1) ? s + 1 : s;                    // the last source is simply fetched again
       if (pf_on && ((s - seg0) & 3) == 0) {
         // every 4th source: the next 4 rows (64 lanes x 16 B) and 8 directions (64 lanes x 4 B), kPrefetchAhead sources ahead
-        constexpr int kPfRows = (256 / CT) > 8 ? (256 / CT) : 8;          // rows one 1 KiB request covers (>= the 8 directions)
+        constexpr int kPfRows = (256 / ROWF) > 8 ? (256 / ROWF) : 8;      // rows one 1 KiB request covers (>= the 8 directions)
         const int spf = (s + kPrefetchAhead < n_loc - kPfRows) ? s + kPrefetchAhead : n_loc - kPfRows;
         int lane_pf = lane;
         asm volatile("" : "+v"(lane_pf));                            // formed here from the lane id: no per-lane pointers kept live across the loop
-        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)PRISIM_ROW_INDEX(spf) * CT + lane_pf * 4), pf_lds, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)PRISIM_ROW_INDEX(spf) * ROWF + lane_pf * 4), pf_lds, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(pf_dirs + (size_t)spf * 8 + lane_pf), pf_lds, 4, 0, 0);
       }
       // the first use of sv waits for everything in flight (first piece + direction); only then ask for the second piece
@@ -1327,6 +1334,32 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       constexpr int RESEED = 8;
 
       auto pairs = [&](const float (&r)[NP], int jbase) {
+        if constexpr (GPK) {
+          // 8 floats per pair: (set 0 .. 3) x (up, down) of p c_set; the piece holds NP / 8 pairs
+#pragma unroll
+          for (int jj = 0; jj < NP / 8; ++jj) {
+            const int j = jbase + jj;
+#pragma unroll
+            for (int rs = 0; rs < 4; ++rs) {
+              const f32x2 pr = {r[8 * jj + 2 * rs], r[8 * jj + 2 * rs + 1]};
+              acc_re[rs][j] = pkfma(pr, zre, acc_re[rs][j]);
+              acc_im[rs][j] = pkfma(pr, zim, acc_im[rs][j]);
+            }
+            if (LIFT) {
+              const f32x2 x1 = pkfma(NT, zim, zre);
+              const f32x2 y1 = pkfma(SS, x1, zim);
+              zre = pkfma(NT, y1, x1);
+              zim = y1;
+            } else {
+              const f32x2 t0 = zim * RI;
+              const f32x2 t1 = zre * RI;
+              const f32x2 nre = pkfma(zre, RR, t0);
+              const f32x2 nim = pkfma(zim, RR, -t1);
+              zre = nre; zim = nim;
+            }
+          }
+          return;
+        }
 #pragma unroll
         for (int jj = 0; jj < NP / 2; ++jj) {
           const int j = jbase + jj;
@@ -1424,17 +1457,17 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           }
         } else {
           // first piece + direction of the next source (NPART is even: it goes to ra)
-          const cfloat_p rn = gps + (size_t)PRISIM_ROW_INDEX(sn) * CT;
+          const cfloat_p rn = gps + (size_t)PRISIM_ROW_INDEX(sn) * ROWF;
 #pragma unroll
           for (int i = 0; i < NP; ++i) ra[i] = rn[i];
           const cvdouble_p dn = gds + (size_t)sn * 4;
           sv[0] = dn[0]; sv[1] = dn[1]; sv[2] = dn[2];
           if (TAPER) sv[3] = dn[3];
-          if constexpr (GRAD) cs = gcs[sn];
+          if constexpr (GRAD && !GPK) cs = gcs[sn];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ph & 1) pairs(rb, ph * (NP / 2));
-        else pairs(ra, ph * (NP / 2));
+        if (ph & 1) pairs(rb, ph * (GPK ? NP / 8 : NP / 2));
+        else pairs(ra, ph * (GPK ? NP / 8 : NP / 2));
       }
     }
   }
@@ -1617,8 +1650,9 @@ void k_skyvis_grad_f32pk(const SkyvisParams p) {
   if (!block_item(p, slab_, bg)) return;
   const bool small_step = p.lift_flags != nullptr && p.lift_flags[bg] != 0;
   if constexpr (!TAPER) {
-    if (small_step) skyvis_rec_f32pk_body<16, false, true, 0, 0, true>(p, flush_lds);
-    else skyvis_rec_f32pk_body<16, false, false, 0, 0, true>(p, flush_lds);
+    // rows pre-multiplied by (1, l, m, n) (k_pack_grad): the GPK bodies
+    if (small_step) skyvis_rec_f32pk_body<16, false, true, 0, 0, true, false, true>(p, flush_lds);
+    else skyvis_rec_f32pk_body<16, false, false, 0, 0, true, false, true>(p, flush_lds);
   } else {
     // 8 steps per chain: one group of the grouped recurrence and no mid-chain re-anchoring (HC < 32); the REANCHOR = 2 bodies are the ones
     // that seed the step phasor for any step angle (groups without the |theta| <= 1/8 cycle guarantee)
@@ -1729,6 +1763,26 @@ __global__ void k_pack(const double* __restrict__ pb, T* __restrict__ packed, in
       if (scale_comp >= 0) v *= dirs[(size_t)s * 4 + scale_comp];
     }
     packed[i] = (T)v;
+  }
+}
+
+// Rows of the fused fp32 gradient kernel without the taper (GPK bodies, 16-channel tiles): packed[tile][s][pair j][set r][up / down] =
+// pb[s][k] c_r(s), c = (1, l, m, n), k = tile 16 + 8 + j (up) / tile 16 + 7 - j (down); 64 floats per (source, tile); zero rows past nsrc.
+__global__ void k_pack_grad(const double* __restrict__ pb, float* __restrict__ packed, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ntiles,
+                            const double* __restrict__ dirs) {
+  const int64_t total = (int64_t)ntiles * nsrc_pad * 64;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 63);
+    const int j = e >> 3, rs = (e >> 1) & 3, ud = e & 1;
+    const int64_t s = (i >> 6) % nsrc_pad;
+    const int tile = (int)((i >> 6) / nsrc_pad);
+    const int64_t k = (int64_t)tile * 16 + (ud ? 7 - j : 8 + j);
+    double v = 0.0;
+    if (k < nchan && s < nsrc) {
+      v = pb[(size_t)s * nchan + k];
+      if (rs > 0) v *= dirs[(size_t)s * 4 + (rs - 1)];
+    }
+    packed[i] = (float)v;
   }
 }
 
@@ -1882,7 +1936,7 @@ hipError_t launch_skyvis_taper_f64(const SkyvisParams& p, int ct, hipStream_t st
 hipError_t launch_skyvis_grad_f32(const SkyvisParams& p, hipStream_t stream) {
   // p.nbgroups = groups of 256 baselines, p.nsplit = 1, 16-channel tiles, p.dirs_c32 and p.grad_out set
   const int64_t items = (int64_t)p.ntiles * p.nbgroups;
-  if (items <= 0 || items > 0x3fffffffLL || p.nsplit != 1 || !p.dirs_c32 || !p.grad_out) return hipErrorInvalidValue;
+  if (items <= 0 || items > 0x3fffffffLL || p.nsplit != 1 || (p.taper && !p.dirs_c32) || !p.grad_out) return hipErrorInvalidValue;
   const unsigned grid = 8u * (unsigned)((items + 7) / 8);
   if (p.taper) hipLaunchKernelGGL((k_skyvis_grad_f32pk<true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   else hipLaunchKernelGGL((k_skyvis_grad_f32pk<false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
@@ -1932,6 +1986,14 @@ hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, i
   else
     hipLaunchKernelGGL(k_pack<double>, dim3(grid_for(total)), dim3(256), 0, stream, pb, (double*)packed, nsrc, nsrc_pad,
                        nchan, ct, ntiles, dirs, scale_comp, interleave);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_grad(const double* pb, float* packed, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ntiles, const double* dirs,
+                            hipStream_t stream) {
+  const int64_t total = (int64_t)ntiles * nsrc_pad * 64;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_grad, dim3(grid_for(total)), dim3(256), 0, stream, pb, packed, nsrc, nsrc_pad, nchan, ntiles, dirs);
   return hipGetLastError();
 }
 

@@ -69,7 +69,7 @@ def _config4_inputs(tmp_path):
     return beam
 
 
-def _check_config4(npz, n_acc):
+def _check_config4(npz, n_acc, snapshots=None):
     from oracle import healpix_oracle as H
     out = NP.load(npz)
     cfg = W.config4(n_acc=n_acc)
@@ -77,7 +77,7 @@ def _check_config4(npz, n_acc):
     cube = out['skyvis_freq']
     assert cube.shape == (8128, 768, n_acc) and cube.dtype == NP.complex64 and NP.max(NP.abs(out['bl'] - bl)) == 0.0
     sel = _spot(bl.shape[0])
-    for j in range(n_acc):
+    for j in (range(n_acc) if snapshots is None else snapshots):
         dc, altaz, keep = W.drift_snapshot_directions(sky, lat, j * cfg['t_acc'] * SIDEREAL_DEG_PER_SEC)
         flux = sky['flux_ref'][keep, None] * (ch[None, :] / sky['ref_freq']) ** sky['spindex'][keep, None]
         beam = H.external_beam(cfg['beam_table'], cfg['beam_freqs'], NP.pi / 2 - NP.radians(altaz[:, 0]), NP.radians(altaz[:, 1]), ch)
@@ -96,6 +96,19 @@ def test_config4_yaml(tmp_path):
     path, npz, p = _yaml(tmp_path, 'config4', {'obsparm': {'n_acc': 3}, 'beam': {'file': beam}})
     assert driver.main(['-i', path]) == 0
     _check_config4(npz, 3)
+
+
+def test_config4_yaml_all_32_accumulations(tmp_path):
+    """examples/config4.yaml as shipped: the whole drift scan, 32 accumulations of 112 s (the sky moves by 15 degrees), every snapshot in
+    its own slot of the device cube with the downloads overlapped; first, middle and last snapshot against the oracle."""
+    beam = _config4_inputs(tmp_path)
+    path, npz, p = _yaml(tmp_path, 'config4', {'beam': {'file': beam}, 'dirstruct': {'simid': 'cfg4_full'}})
+    assert p['obsparm']['n_acc'] == 32
+    assert driver.main(['-i', path]) == 0
+    _check_config4(npz, 32, snapshots=(0, 15, 31))
+    out = NP.load(npz)
+    assert out['lst'].shape == (32,) and abs((out['lst'][31] - out['lst'][0]) - 31 * 112.0 * SIDEREAL_DEG_PER_SEC) <= 1e-9
+    assert NP.all(NP.isfinite(out['skyvis_freq'].view(NP.float32)))
 
 
 def test_config4_yaml_two_ranks_on_one_gpu(tmp_path):
