@@ -803,9 +803,15 @@ void k_skyvis_taper_f64(const SkyvisParams p) {
 // pbflux rows and directions are per lane group here (4 sources per wavefront), so they come through vector loads (4 distinct
 // 16-byte addresses per instruction).
 // ------------------------------------------------------------------------------------------
+// STAGE (32-channel tiles without the taper): the four sources' rows (4 x 256 B) and directions (4 x 64 B) of the NEXT group are brought
+// into a per-wave LDS area by two LDS-DMA loads (global_load_lds, no VGPRs) issued right after the current group's operands have been read
+// out of the other half of that area, so the MFMA loop of one group hides the memory latency of the next (round 3: the per-lane vector
+// loads at the loop top were waited for in place, SQ_WAIT_ANY 14 % of the wave cycles).
+constexpr int kGradStageWaveBytes = 2 * (1024 + 256);
 template <int CT, bool TAPER, bool LIFT>
-__device__ __forceinline__ void skyvis_grad_f64_body(const SkyvisParams& p, const double2* tab) {
+__device__ __forceinline__ void skyvis_grad_f64_body(const SkyvisParams& p, const double2* tab, unsigned char* stage) {
   constexpr int HC = CT / 2;
+  constexpr bool STAGE = CT == 32 && !TAPER;
   int slab, bg;
   if (!block_item(p, slab, bg)) return;          // p.nbgroups counts groups of 64 baselines for this kernel
   const int tile = slab % p.ntiles;              // the host plans nsplit = 1: every block walks all sources
@@ -840,14 +846,45 @@ __device__ __forceinline__ void skyvis_grad_f64_body(const SkyvisParams& p, cons
   const double4* const raw = reinterpret_cast<const double4*>(p.dirs);
   const int64_t ns_pad = p.nsrc_pad;             // a multiple of 4 (the source chunk); rows and prepared directions past nsrc are zero
 
+  // STAGE: this wave's two staging halves; lane L brings 16 bytes of row (L >> 4) and 4 bytes of the directions (lanes 0-31: prepared,
+  // 32-63: raw, clamped to the last real source like the direct loads)
+  unsigned char* const wst = stage + (tid >> 6) * kGradStageWaveBytes;
+  auto stage_issue = [&](int64_t s0n, int half) {
+    if constexpr (STAGE) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const char* const grow = reinterpret_cast<const char*>(rows + (size_t)(s0n + (ln >> 4)) * CT) + (ln & 15) * 16;
+      const int64_t sd = s0n + ((ln & 31) >> 3);
+      const char* const gdir = (ln < 32) ? reinterpret_cast<const char*>(prep + sd) + (ln & 7) * 4
+                                         : reinterpret_cast<const char*>(raw + (sd < p.nsrc ? sd : p.nsrc - 1)) + (ln & 7) * 4;
+      __builtin_amdgcn_global_load_lds((gptr_t)grow, (lptr_t)(wst + half * 1280), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gdir, (lptr_t)(wst + half * 1280 + 1024), 4, 0, 0);
+    }
+  };
+  if (STAGE && ns_pad > 0) stage_issue(0, 0);
   for (int64_t s0 = 0; s0 < ns_pad; s0 += 4) {
     const int64_t s = s0 + k;
-    const double4 sv = prep[s];
-    const double4 rw = raw[s < p.nsrc ? s : p.nsrc - 1];
-    const double2* const row = reinterpret_cast<const double2*>(rows + (size_t)s * CT);     // (up, down) pairs
+    double4 sv, rw;
     double2 pr[HC];
+    if constexpr (STAGE) {
+      const int half = (int)((s0 >> 2) & 1);
+      __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): this group's two DMA loads have landed
+      wave_lds_sync();
+      const unsigned char* const hb = wst + half * 1280;
+      sv = *reinterpret_cast<const double4*>(hb + 1024 + k * 32);
+      rw = *reinterpret_cast<const double4*>(hb + 1024 + 128 + k * 32);
+      const double2* const lrow = reinterpret_cast<const double2*>(hb + k * 256);
 #pragma unroll
-    for (int j = 0; j < HC; ++j) pr[j] = row[j];
+      for (int j = 0; j < HC; ++j) pr[j] = lrow[j];
+      wave_lds_sync();                                                      // operands are in registers: the other half may be overwritten
+      if (s0 + 4 < ns_pad) stage_issue(s0 + 4, half ^ 1);
+    } else {
+      sv = prep[s];
+      rw = raw[s < p.nsrc ? s : p.nsrc - 1];
+      const double2* const row = reinterpret_cast<const double2*>(rows + (size_t)s * CT);     // (up, down) pairs
+#pragma unroll
+      for (int j = 0; j < HC; ++j) pr[j] = row[j];
+    }
     const double cx = (x == 0) ? 1.0 : (x == 1 ? rw.x : (x == 2 ? rw.y : rw.z));
     const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));
 
@@ -931,15 +968,17 @@ template <int CT, bool TAPER>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_skyvis_grad_f64(const SkyvisParams p) {
   __shared__ double2 tab_lds[kTabN];
+  // (a separate LDS object: reads that might alias an LDS-DMA target are made to wait for vmcnt(0) -- the phasor-table reads must not)
+  __shared__ __attribute__((aligned(16))) unsigned char stage_lds[(CT == 32 && !TAPER) ? (kBlockThreads / 64) * kGradStageWaveBytes : 16];
   fill_phasor_table(tab_lds);
   __syncthreads();
   int slab_, bg;
   const bool in_range = block_item(p, slab_, bg);
   if (in_range && p.lift_flags != nullptr && p.lift_flags[bg >> 2] != 0) {      // flags are kept per 256 baselines
-    skyvis_grad_f64_body<CT, TAPER, true>(p, tab_lds);
+    skyvis_grad_f64_body<CT, TAPER, true>(p, tab_lds, stage_lds);
     return;
   }
-  skyvis_grad_f64_body<CT, TAPER, false>(p, tab_lds);
+  skyvis_grad_f64_body<CT, TAPER, false>(p, tab_lds, stage_lds);
 }
 
 // ------------------------------------------------------------------------------------------
