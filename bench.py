@@ -586,6 +586,10 @@ def main():
     gather_ok = None
     my_kern_ms = tm['sum_kernel_ms'] / max(1, tm['n_kernel'])
     rank_kern_ms = rdzv.allgather(my_kern_ms)
+    # what every rank's planner chose for its shard (a slow N > 1 line then says whether one rank ran another decomposition) and the whole
+    # compute() per step beside the kernel alone (prep + pack + kernel + partial-cube reduction)
+    rank_plan = rdzv.allgather({'chan_tile': int(tm['last_chan_tile']), 'nsplit': int(tm['last_nsplit']), 'lift_groups': int(tm['last_lift_groups']),
+                                'nbl_shard': int(bl_mine.shape[0]), 'last_compute_ms': float(tm['last_compute_ms'])})
     gstats = None
     if world > 1:
         cs_ = ctx.comm_stats()
@@ -657,6 +661,7 @@ def main():
             out['roofline']['frac_what'] = ('frac charges the no-taper 10 flop/term; frac_vs_taper_contract charges 12 (scaled rotation 6 + accumulate 4 + '
                                             'ratio update 2)')
         out['kernel_ms_per_rank'] = {'min': min(rank_kern_ms), 'max': max(rank_kern_ms), 'all': rank_kern_ms}
+        out['plan_per_rank'] = rank_plan
         out['value_n1_equiv'] = value / world           # whole-job rate per GPU: what to hold against the N = 1 line
         if world > 1:
             out['gather'] = gstats
