@@ -588,8 +588,8 @@ def main():
     rank_kern_ms = rdzv.allgather(my_kern_ms)
     # what every rank's planner chose for its shard (a slow N > 1 line then says whether one rank ran another decomposition) and the whole
     # compute() per step beside the kernel alone (prep + pack + kernel + partial-cube reduction)
-    rank_plan = rdzv.allgather({'chan_tile': int(tm['last_chan_tile']), 'nsplit': int(tm['last_nsplit']), 'lift_groups': int(tm['last_lift_groups']),
-                                'nbl_shard': int(bl_mine.shape[0]), 'last_compute_ms': float(tm['last_compute_ms'])})
+    rank_plan = rdzv.allgather({'chan_tile': int(tm['last_chan_tile']), 'nsplit': int(tm['last_nsplit']), 'lift_groups': int(tm.get('last_lift_groups', 0)),
+                                'nbl_shard': int(bl_mine.shape[0]), 'last_compute_ms': float(tm.get('last_compute_ms', 0.0))})
     gstats = None
     if world > 1:
         cs_ = ctx.comm_stats()
