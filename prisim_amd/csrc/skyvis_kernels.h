@@ -85,8 +85,9 @@ hipError_t launch_skyvis_grad_f32(const SkyvisParams& p, hipStream_t stream);
 hipError_t launch_fsq_pairs(const float* fsq, float* pairs, int ct, int ntiles, hipStream_t stream);
 hipError_t launch_skyvis_direct(const SkyvisParams& p, const double* freqs, const double* pb, const double* scale,
                                 hipStream_t stream);
+// (s_lo, s_hi): only the rows of these sources are written (default: all nsrc_pad rows)
 hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct,
-                       int ntiles, const double* dirs, int scale_comp, int interleave, hipStream_t stream);
+                       int ntiles, const double* dirs, int scale_comp, int interleave, hipStream_t stream, int64_t s_lo = 0, int64_t s_hi = -1);
 // rows of the fused fp32 gradient kernel without the taper: [ntiles(16 ch)][nsrc_pad][64] floats, pre-multiplied by (1, l, m, n)
 hipError_t launch_pack_grad(const double* pb, float* packed, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ntiles, const double* dirs,
                             hipStream_t stream);

@@ -380,7 +380,14 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   int64_t s_end = s_begin + p.src_per_split;
   if (s_end > p.nsrc) s_end = p.nsrc;
   // (TAPER == 1 bodies: no source ranges, no taper culling -- a variable source range cost k_skyvis_rec<double,32,true> 47 more SGPR
-  // spills, 33 of them as lane moves inside its source loop; the grouped fp64 kernel has both)
+  // spills, 33 of them as lane moves inside its source loop; the grouped fp64 kernel has both, the fp64 body without the taper takes a
+  // source range and accumulates: it sums the point-source runs of a mixed sky)
+  constexpr bool RANGED = GROUPED || (sizeof(T) == 8 && TAPER == 0);
+  if constexpr (RANGED && !GROUPED) {
+    s_begin = p.src_lo + (int64_t)split * p.src_per_split;
+    s_end = s_begin + p.src_per_split;
+    if (s_end > p.src_hi) s_end = p.src_hi;
+  }
   if constexpr (GROUPED) {
     // sources [src_lo, src_hi) of the sky (a run of one source size when the host walks the sky run by run), cut into nsplit pieces;
     // taper culling as in the packed fp32 kernels: the group's leading sources are provably below the tolerance (capi.cpp) and what is
@@ -429,7 +436,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   const cfsq_p gfq = (cfsq_p)(uintptr_t)(p.fsq_pairs ? p.fsq_pairs + (size_t)tile * CT : nullptr);   // fp32 taper only
 
   double* const out = p.out + ((size_t)split * p.nbl * p.nchan) * 2;   // partial buffer of this split
-  bool first_flush = !GROUPED || p.accumulate == 0;    // accumulate: an earlier launch (another source run) already wrote this slot
+  bool first_flush = !RANGED || p.accumulate == 0;     // accumulate: an earlier launch (another source run) already wrote this slot
 
   using FV = typename FlushCfg<T>::vec;
   constexpr int FCH = FlushCfg<T>::ch < CT ? FlushCfg<T>::ch : CT;
@@ -605,7 +612,23 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
         const double a = gq2 * (2.0 * df * fc);
         const double u = gq2 * (df * df);
         double E, y8;
-        if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(a) < 0.1 && u < 3.0e-5)) == 0) {
+        if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(a) < 4.0e-3 && u < 1.0e-6)) == 0) {
+          // HERA-size exponents (config 3 / 5: |a| <= 1.3e-3, u <= 4.2e-7): exp(-a) to a^5 (next term 5.7e-18), X to u^2 (1.7e-19),
+          // exp(-8u) to (8u)^3 with the factor folded into the coefficients (1.7e-22): 7 instructions fewer than the general short series
+          const double na = -a;
+          double q5 = __builtin_fma(na, 8.33333333333333333333e-03, 4.16666666666666666667e-02);
+          q5 = __builtin_fma(q5, na, 1.66666666666666666667e-01);
+          q5 = __builtin_fma(q5, na, 0.5);
+          q5 = __builtin_fma(q5, na, 1.0);
+          E = __builtin_fma(q5, na, 1.0);
+          const double X = __builtin_fma(u, __builtin_fma(u, 0.5, 1.0), 1.0);
+          const double X2 = X * X, X3 = X2 * X, X5 = X3 * X2;
+          cm[0] = X5 * X2;
+          cm[1] = cm[0] * X5;
+          cm[2] = cm[1] * X3;
+          cm[3] = cm[2] * X;
+          y8 = __builtin_fma(u, __builtin_fma(u, __builtin_fma(u, -8.53333333333333333333e+01, 32.0), -8.0), 1.0);
+        } else if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(a) < 0.1 && u < 3.0e-5)) == 0) {
           // the usual case (df << f): all by short series -- exp(-a) to a^9 (next term 2.8e-17), X = exp(u) to u^3 (next 3e-20), the
           // powers by 7 multiplications, exp(-8 u) to (8u)^4 (next 2.7e-20)
           E = exp_series9(-a);
@@ -1785,23 +1808,27 @@ void k_skyvis_direct(const SkyvisParams p, const double* __restrict__ freqs,
 // ------------------------------------------------------------------------------------------
 // interleave != 0: element 2j of a row holds channel HC+j, element 2j+1 channel HC-1-j (HC = ct/2),
 // the (up, down) operand pairs of k_skyvis_rec_f32pk.
+// Only the rows of sources [s_lo, s_hi) are written (the whole padded range: 0, nsrc_pad): a run of a mixed sky can be re-packed in the
+// layout its kernel wants.
 template <typename T>
 __global__ void k_pack(const double* __restrict__ pb, T* __restrict__ packed, int64_t nsrc, int64_t nsrc_pad,
                        int64_t nchan, int ct, int ntiles, const double* __restrict__ dirs, int scale_comp,
-                       int interleave) {
-  const int64_t total = (int64_t)ntiles * nsrc_pad * ct;
+                       int interleave, int64_t s_lo, int64_t s_hi) {
+  const int64_t nrow = s_hi - s_lo;
+  const int64_t total = (int64_t)ntiles * nrow * ct;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)(i % ct);
+    const int cpos = (int)(i % ct);
+    int c = cpos;
     if (interleave) c = (c & 1) ? (ct / 2 - 1 - (c >> 1)) : (ct / 2 + (c >> 1));
-    const int64_t s = (i / ct) % nsrc_pad;
-    const int tile = (int)(i / ((int64_t)ct * nsrc_pad));
+    const int64_t s = s_lo + (i / ct) % nrow;
+    const int tile = (int)(i / ((int64_t)ct * nrow));
     const int64_t k = (int64_t)tile * ct + c;
     double v = 0.0;
     if (k < nchan && s < nsrc) {
       v = pb[(size_t)s * nchan + k];
       if (scale_comp >= 0) v *= dirs[(size_t)s * 4 + scale_comp];
     }
-    packed[i] = (T)v;
+    packed[((size_t)tile * nsrc_pad + (size_t)s) * ct + cpos] = (T)v;
   }
 }
 
@@ -2016,15 +2043,17 @@ static unsigned grid_for(int64_t n) {
 }
 
 hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct,
-                       int ntiles, const double* dirs, int scale_comp, int interleave, hipStream_t stream) {
-  const int64_t total = (int64_t)ntiles * nsrc_pad * ct;
+                       int ntiles, const double* dirs, int scale_comp, int interleave, hipStream_t stream, int64_t s_lo, int64_t s_hi) {
+  if (s_hi < 0) { s_lo = 0; s_hi = nsrc_pad; }
+  if (s_lo < 0 || s_hi > nsrc_pad || s_hi < s_lo) return hipErrorInvalidValue;
+  const int64_t total = (int64_t)ntiles * (s_hi - s_lo) * ct;
   if (total == 0) return hipSuccess;
   if (f32)
     hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(total)), dim3(256), 0, stream, pb, (float*)packed, nsrc, nsrc_pad,
-                       nchan, ct, ntiles, dirs, scale_comp, interleave);
+                       nchan, ct, ntiles, dirs, scale_comp, interleave, s_lo, s_hi);
   else
     hipLaunchKernelGGL(k_pack<double>, dim3(grid_for(total)), dim3(256), 0, stream, pb, (double*)packed, nsrc, nsrc_pad,
-                       nchan, ct, ntiles, dirs, scale_comp, interleave);
+                       nchan, ct, ntiles, dirs, scale_comp, interleave, s_lo, s_hi);
   return hipGetLastError();
 }
 

@@ -73,6 +73,62 @@ class _LayerStack(object):
         return out
 
 
+class _LazyGradients(dict):
+    """InterferometerArray.gradient: {gradient_mode: (3, nbl, nchan, n_acc)} like the reference's, but the per-snapshot gradient blocks that
+    observe() left in the device gradient cube (reserve()) are only fetched -- and stacked, once, instead of the reference's per-snapshot
+    dstack (interferometry.py:6385-6393) -- when the entry is read.  Sharded runs that gather the gradients on the device never fetch them."""
+
+    def __init__(self, owner):
+        dict.__init__(self)
+        self._owner = owner
+
+    def _materialise(self, key):
+        ia = self._owner
+        if key == ia.gradient_mode and ia._grad and not dict.__contains__(self, key):
+            blocks = []
+            for i, g in enumerate(ia._grad):
+                if isinstance(g, _DeviceSlot):
+                    g = ia._ctx.get_vis(slot=g.slot, want_grad=True, complex64=(g.dtype == NP.complex64))[1]
+                    ia._grad[i] = g
+                blocks.append(g)
+            dict.__setitem__(self, key, NP.stack(blocks, axis=3))
+
+    def invalidate(self, key):
+        dict.pop(self, key, None)
+
+    def __getitem__(self, key):
+        self._materialise(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._materialise(key)
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (key == self._owner.gradient_mode and bool(self._owner._grad))
+
+    def __bool__(self):
+        return dict.__len__(self) > 0 or bool(self._owner._grad)
+
+    def keys(self):
+        ks = list(dict.keys(self))
+        if self._owner.gradient_mode is not None and self._owner._grad and self._owner.gradient_mode not in ks:
+            ks.append(self._owner.gradient_mode)
+        return ks
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+
 class LazyGeometricDelays(object):
     """Stand-in for one entry of ``InterferometerArray.geometric_delays`` (the reference stores the full
     nsrc x nbl matrix per snapshot, interferometry.py:6287-6291 -- 4.9 GB at HERA-350 x 1e4 sources).
@@ -780,12 +836,16 @@ class InterferometerArray(object):
             for i, snap in enumerate(self._cube):                       # a snapshot still parked in the slot about to be overwritten
                 if isinstance(snap, _DeviceSlot) and snap.slot == slot:
                     self._cube[i] = self._ctx.get_vis(slot=slot, complex64=(snap.dtype == NP.complex64))
+            for i, g in enumerate(self._grad):                          # ... and its gradient blocks
+                if isinstance(g, _DeviceSlot) and g.slot == slot:
+                    self._grad[i] = self._ctx.get_vis(slot=slot, want_grad=True, complex64=(g.dtype == NP.complex64))[1]
             self._ctx.compute(precision=prec, want_grad=want_grad, slot=slot)
             self._device_in_step = slot == self.n_acc and (self.n_acc == 0 or getattr(self, '_device_in_step', False))
-            if slot == self.n_acc and not want_grad:
+            if slot == self.n_acc:
                 # the snapshot stays in its own slot of the device cube: no synchronous download (1 GB and 20 ms per HERA-350
-                # snapshot); with host staging its copy to the pinned host cube is queued behind the sky-sum, on the copy stream
-                skyvis, skyvis_gradient = _DeviceSlot(slot, datatype), None
+                # snapshot; 4 GB with the gradient blocks); with host staging its copy to the pinned host cube is queued behind the
+                # sky-sum, on the copy stream.  The gradient blocks stay in the device gradient cube until `gradient` is read.
+                skyvis, skyvis_gradient = _DeviceSlot(slot, datatype), (_DeviceSlot(slot, datatype) if want_grad else None)
                 skyvis.staged = self._stage_download(slot, datatype)
             else:
                 res = self._ctx.get_vis(slot=slot, want_grad=want_grad, complex64=memsave)
@@ -807,7 +867,9 @@ class InterferometerArray(object):
         self._skyvis_cache = None
         if want_grad:
             self._grad.append(skyvis_gradient)
-            self.gradient[gradient_mode] = NP.stack(self._grad, axis=3)
+            if not isinstance(self.gradient, _LazyGradients):
+                self.gradient = _LazyGradients(self)
+            self.gradient.invalidate(gradient_mode)                                   # stacked again when it is next read
 
         self.timestamp = self.timestamp + [jd]                                        # :6395-6399
         self.t_acc = self.t_acc + [t_acc]
