@@ -480,3 +480,45 @@ def test_equatorial_baselines_are_rotated_to_the_local_frame(monkeypatch):
     assert NP.allclose(NP.asarray(ia_eq.geometric_delays[0]), NP.asarray(ia_enu.geometric_delays[0]), rtol=0, atol=1e-18)
     with pytest.raises(ValueError):
         RI.InterferometerArray(['b0'], bl[:1], ch, baseline_coords='galactic', **kw)
+
+
+def test_gradient_blocks_stay_on_the_device_until_read(monkeypatch):
+    """With reserve() the baseline-gradient blocks of every snapshot stay in the device gradient cube (observe() downloads nothing); the
+    `gradient` dictionary fetches and stacks them when it is first read, and equals what an unreserved run (synchronous downloads) holds."""
+    import fake_context
+    from prisim_amd import interferometry as RI, skymodel as SM
+    downloads = {'n': 0}
+
+    class Spy(fake_context.OracleContext):
+        def get_vis(self, slot=0, want_grad=False, complex64=False):
+            downloads['n'] += 1
+            return fake_context.OracleContext.get_vis(self, slot=slot, want_grad=want_grad, complex64=complex64)
+
+    monkeypatch.setattr(_abi, 'Context', Spy)
+    rng = NP.random.default_rng(8)
+    ch = 150e6 + 2e5 * NP.arange(6)
+    bl = rng.uniform(-60.0, 60.0, size=(5, 3)) * NP.array([1.0, 1.0, 0.02])
+    skymod = SM.SkyModel(location=NP.stack((rng.uniform(25, 89, 30), rng.uniform(0, 360, 30)), axis=1), flux_ref=rng.uniform(0.5, 5.0, 30),
+                         spindex=rng.uniform(-1.0, 0.0, 30), ref_freq=150e6)
+    kw = dict(telescope={'id': 'hera'}, latitude=-30.7, skycoords='altaz', pointing_coords='hadec')
+    res = {}
+    for reserve in (True, False):
+        ia = RI.InterferometerArray(['b%d' % i for i in range(5)], bl, ch, **kw)
+        if reserve:
+            ia.reserve(3)
+        downloads['n'] = 0
+        for j in range(3):
+            ia.observe((2457000.5 + j, 10.0 + 5 * j), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, -30.7], skymod, 10.0, gradient_mode='baseline')
+        if reserve:
+            assert downloads['n'] == 0 and all(isinstance(g, RI._DeviceSlot) for g in ia._grad)
+            assert 'baseline' in ia.gradient and bool(ia.gradient) and list(ia.gradient.keys()) == ['baseline']
+        res[reserve] = NP.array(ia.gradient['baseline'])
+        assert res[reserve].shape == (3, 5, 6, 3)
+        if reserve:
+            assert downloads['n'] == 3 and not any(isinstance(g, RI._DeviceSlot) for g in ia._grad)
+            n = downloads['n']
+            assert ia.gradient['baseline'] is ia.gradient['baseline'] and downloads['n'] == n      # stacked once
+            ia.observe((2457003.5, 25.0), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, -30.7], skymod, 10.0, gradient_mode='baseline')
+            assert ia.gradient['baseline'].shape == (3, 5, 6, 4)                                   # a fourth snapshot (slot 0 reused)
+            assert NP.array_equal(ia.gradient['baseline'][..., :3], res[True])
+    assert NP.max(NP.abs(res[True] - res[False])) <= 1e-12 * NP.max(NP.abs(res[False]))

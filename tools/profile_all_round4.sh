@@ -9,7 +9,7 @@ for t in $TAGS; do
   case $t in
     headline) tools/profile_round.sh r04_headline_f32; DONE="$DONE r04_headline_f32" ;;
     fp64) tools/profile_round.sh r04_fp64 --precision fp64; DONE="$DONE r04_fp64" ;;
-    taper64_3d) PROFILE_KERNEL=k_skyvis_taper PROFILE_LAUNCHES_PER_STEP=2 tools/profile_round.sh r04_taper_f64_cfg3d --workload cfg3d --precision fp64 --steps 2; DONE="$DONE r04_taper_f64_cfg3d" ;;
+    taper64_3d) PROFILE_KERNEL=k_skyvis_taper tools/profile_round.sh r04_taper_f64_cfg3d --workload cfg3d --precision fp64 --steps 2; DONE="$DONE r04_taper_f64_cfg3d" ;;
     taper64_5) PROFILE_KERNEL=k_skyvis_taper tools/profile_round.sh r04_taper_f64_cfg5 --workload cfg5 --precision fp64 --steps 2; DONE="$DONE r04_taper_f64_cfg5" ;;
     taper32_5) tools/profile_round.sh r04_taper_f32_cfg5 --workload cfg5 --steps 2; DONE="$DONE r04_taper_f32_cfg5" ;;
     taper32_3d) tools/profile_round.sh r04_taper_f32_cfg3d --workload cfg3d --steps 3; DONE="$DONE r04_taper_f32_cfg3d" ;;

@@ -3,7 +3,8 @@ nside=256 diffuse sky (392 704 pixels above the horizon, source-shape taper) x 1
 visibility cube resident in HBM, then the delay power spectra of all 7.3e6 rows (pad = 1) on the device.  One JSON line on stdout;
 progress on stderr.  ~7 minutes of kernels.
 
-    python tools/run_config5_full.py [n_lst]
+    python tools/run_config5_full.py [n_lst] [fp64]      fp64: the reference's default precision (memsave=False): complex128 snapshots, the grouped
+                                                         fp64 taper kernel, tolerance 1e-11 in the spot check, ~14 minutes of kernels
 """
 import json
 import os
@@ -18,6 +19,7 @@ from oracle import c_oracle as CO, beams_oracle as BO          # spot check of t
 
 SIDEREAL_DEG_PER_SEC = 360.0 * 1.00273790935 / 86400.0
 n_lst = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+fp64 = 'fp64' in sys.argv[2:]
 cfg = W.config5(n_acc=n_lst)
 bl, ch, sky, lat = cfg['baselines'], cfg['channels'], cfg['sky'], cfg['latitude']
 lst0 = 15.0
@@ -34,7 +36,7 @@ terms = 0
 t0 = time.perf_counter()
 for j in range(n_lst):
     ia.observe((2457000.5 + j * cfg['t_acc'] / 86400.0, lst0 + j * cfg['t_acc'] * SIDEREAL_DEG_PER_SEC), {'Tnet': 100.0}, NP.ones(ch.size),
-               [0.0, lat], skymod, cfg['t_acc'], memsave=True)
+               [0.0, lat], skymod, cfg['t_acc'], memsave=not fp64)
     terms += bl.shape[0] * ch.size * ia.obs_catalog_indices[j].size
     if j % 5 == 4 or j == n_lst - 1:
         ia._ctx.sync()
@@ -67,9 +69,9 @@ pw = ia._ctx.get_delay_power(n_lst - 1, 1, rows=sel)                            
 rows = n_lst * bl.shape[0]
 print(json.dumps({
     'config': cfg['name'], 'n_lst': n_lst, 'nbl': int(bl.shape[0]), 'nchan': int(ch.size), 'nsrc_catalog': int(n), 'terms': float(terms),
-    'precision': 'fp32', 'taper': True, 'wall_s_observe_loop': wall, 'kernel_s_total': tm['sum_kernel_ms'] * 1e-3, 'n_kernel': tm['n_kernel'],
+    'precision': 'fp64' if fp64 else 'fp32', 'taper': True, 'wall_s_observe_loop': wall, 'kernel_s_total': tm['sum_kernel_ms'] * 1e-3, 'n_kernel': tm['n_kernel'],
     'terms_per_s_wall': terms / wall, 'terms_per_s_kernel': terms / (tm['sum_kernel_ms'] * 1e-3), 'cube_GB_resident': rows * ch.size * 16 / 1e9,
-    'parity_spot_max_err_rel_sumflux_last_lst': err, 'tolerance': 5e-6,
+    'parity_spot_max_err_rel_sumflux_last_lst': err, 'tolerance': 1e-11 if fp64 else 5e-6,
     'delay_ffts': rows, 'delay_device_ms': tmd['last_delay_ms'], 'delay_wall_s': dwall, 'delay_fused_kernel': bool(tmd['last_delay_fused']),
     'delay_algorithmic_GBps': rows * ch.size * 24 / (tmd['last_delay_ms'] * 1e-3) / 1e9, 'delay_power_finite': bool(NP.all(NP.isfinite(pw))),
     'delay_power_scale_K2_Mpc3_per_Jy2Hz2': pconst['factor'], 'delay_power_max_K2_Mpc3': float(NP.max(pw))}))
