@@ -319,7 +319,8 @@ typedef struct prisim_timing {
   int32_t last_taper_split;  /* > 0: the packed fp32 taper ran its split form over this many source runs of one source size each */
   int32_t last_split_uncorrected_groups;   /* (source run, baseline group) pairs whose parabola bound allowed the uncorrected body */
   double last_culled_fraction;             /* share of the snapshot's (source, baseline) pairs the taper culling skipped (packed fp32
-                                              kernels): their summed contribution is below exp(-18) of sum|pbflux| (0: none) */
+                                              kernels, grouped fp64 taper kernel): their summed contribution is below exp(-18) (fp32) /
+                                              exp(-28) (fp64) of sum|pbflux| (0: none) */
 } prisim_timing;
 
 int prisim_hip_sync(prisim_ctx* ctx);
