@@ -159,6 +159,75 @@ def test_unsupported_modes_fail_loudly():
         driver.run(p)
 
 
+def test_shipped_yaml_files_describe_the_baseline_configs():
+    """examples/config3/4/5.yaml: the arrays, bands, skies and schedules of BASELINE.json's configs 3-5; config 4's committed
+    layout file is what its generator writes and gives the workload's 8128 baselines."""
+    p3 = driver.load_parms(os.path.join(EX, 'config3.yaml'))
+    assert driver.baseline_info(p3)[0].shape == (61075, 3) and p3['bandpass']['nchan'] == 1024 and p3['obsparm']['n_acc'] == 1
+    sm = driver.build_skymodel(p3, EX)
+    cfg = W.config3(with_diffuse=True)
+    assert sm.location.shape == (cfg['sky']['dircos'].shape[0], 2) and NP.array_equal(sm.flux_ref, cfg['sky']['flux_ref'])
+    assert NP.count_nonzero(sm.src_shape[:, 0] == 0.0) == 10000                      # the point sources come first: runs of one source size
+    p4 = driver.load_parms(os.path.join(EX, 'config4.yaml'))
+    p4['array']['file'] = os.path.join(ROOT, p4['array']['file'])
+    bl4 = driver.baseline_info(p4)[0]
+    c4 = W.config4()
+    assert bl4.shape == (8128, 3) and NP.max(NP.abs(bl4 - c4['baselines'])) == 0.0
+    assert p4['obsparm']['n_acc'] == 32 and p4['beam']['use_external'] and p4['beam']['filefmt'] == 'hdf5' and p4['pp']['gather'] == 'root'
+    assert NP.array_equal(W.channel_grid(p4['bandpass']['freq'], p4['bandpass']['freq_resolution'], p4['bandpass']['nchan']), c4['channels'])
+    p5 = driver.load_parms(os.path.join(EX, 'config5.yaml'))
+    assert p5['obsparm']['n_acc'] == 120 and p5['skyparm']['nside'] == 256 and p5['processing']['delay_transform'] is True
+    with pytest.raises(ValueError):
+        bad = driver.load_parms(os.path.join(EX, 'config3.yaml'))
+        bad['skyparm']['components'] = []
+        driver.build_skymodel(bad, EX)
+
+
+def test_sharded_run_stops_on_every_rank_when_any_self_test_fails(monkeypatch):
+    """driver.run builds the communicator and self-tests it before the first snapshot; the outcomes are combined over the rendezvous:
+    a rank whose own test passed still exits 3 when a peer's failed, and without a rendezvous the error itself propagates."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import fake_context
+    from prisim_amd import _abi
+    observed = {'n': 0}
+
+    class Ctx(fake_context.OracleContext):
+        fail = False
+
+        def comm_init(self, uid, nranks, rank):
+            self.nranks = nranks
+
+        def comm_selftest(self, nbytes=1 << 20):
+            if Ctx.fail:
+                raise _abi.PrisimHipError('self-test pattern mismatch')
+
+        def compute(self, *a, **k):
+            observed['n'] += 1
+            return fake_context.OracleContext.compute(self, *a, **k)
+
+    class Rdzv(object):
+        def __init__(self, peer):
+            self.peer = peer
+
+        def allgather(self, obj):
+            return [obj, self.peer]
+
+    monkeypatch.setattr(_abi, 'Context', Ctx)
+    p = driver.load_parms(os.path.join(EX, 'config2.yaml'))
+    uid = b'x' * 128
+    with pytest.raises(SystemExit) as e:                                      # my test passed, the peer's did not
+        driver.run(p, infile_dir=EX, rank=0, world=2, comm_uid=uid, verbose=False, host_copy='root', rdzv=Rdzv([False, 'peer: no data moved']))
+    assert e.value.code == 3 and observed['n'] == 0                           # before any snapshot
+    Ctx.fail = True
+    with pytest.raises(SystemExit) as e:                                      # mine failed: reported to the peers, exit 3
+        driver.run(p, infile_dir=EX, rank=1, world=2, comm_uid=uid, verbose=False, host_copy='root', rdzv=Rdzv([True, '']))
+    assert e.value.code == 3 and observed['n'] == 0
+    with pytest.raises(_abi.PrisimHipError):                                  # no rendezvous to report to: the error itself
+        driver.run(p, infile_dir=EX, rank=0, world=2, comm_uid=uid, verbose=False)
+    with pytest.raises(ValueError):
+        driver.run(p, infile_dir=EX, rank=0, world=2, comm_uid=None, verbose=False)
+
+
 @pytest.mark.gpu
 def test_config1_yaml_end_to_end_matches_oracle(tmp_path):
     """BASELINE config 1 through scripts/run_prisim.py -i examples/config1.yaml, checked against the oracle."""
