@@ -483,7 +483,6 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   pl.nsrc_pad = round_up(std::max<int64_t>(nsrc, 1), chunk);
   // source split so that small problems still fill the GPU; each split is a multiple of the chunk
   int nsplit = ctx->tune_nsplit;
-  const int64_t nchunks = pl.nsrc_pad / chunk;
   if (nsplit == 0) {
     const int64_t base = (int64_t)pl.ntiles * pl.nbgroups;
     // resident blocks per CU = waves per SIMD the kernels are built for (PK_WAVES / WavesPerEU in skyvis_kernels.hip)
@@ -514,7 +513,36 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
       if (want > 16) want = std::max<int64_t>(16, std::min<int64_t>((3 * slots / 2 + base / 2) / std::max<int64_t>(base, 1), cap));
     }
     nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, 64));
+    if (!pl.f32 && ctx->taper && (ct == 16 || ct == 32) && pl.kernel == PRISIM_KERNEL_RECURRENCE && nbl <= kBlockThreads && !ctx->tune_chunk) {
+      // One baseline group, fp64 with the taper: wave items (run_pass) -- two wavefronts on every SIMD, and at least 16 sources per
+      // item.  Config 2 (3 baseline waves x 16 tiles): 42 splits of 36 sources = 2016 wavefronts in 512 blocks.
+      const int64_t nbw = (nbl + 63) / 64;
+      const int64_t waves = 2LL * 4 * std::max(ctx->cu_count, 1);
+      int64_t s_want = std::max<int64_t>(1, waves / (pl.ntiles * nbw));
+      s_want = std::min<int64_t>(s_want, std::max<int64_t>(1, nsrc / 16));
+      if (s_want > 1) {
+        const int64_t per = round_up((nsrc + s_want - 1) / s_want, 4);
+        pl.chunk = 4;
+        pl.nsrc_pad = round_up(std::max<int64_t>(nsrc, 1), 16);
+        pl.src_per_split = per;
+        pl.nsplit = (int)((nsrc + per - 1) / per);
+        return pl;
+      }
+    }
   }
+  if (!ctx->tune_chunk) {
+    // A small sky cut into many pieces (config 2: 1504 sources, 32 splits fill the 512 block slots exactly): 64-source chunks would cap
+    // the split count at nsrc / 64 = 24 -- 62 us against 76 with 16-source chunks and 32 splits (tools/config2_fullwave_probe.py)
+    auto realised = [&](int c) {          // split count a chunk size allows: whole chunks per split
+      const int64_t nch = round_up(std::max<int64_t>(nsrc, 1), c) / c;
+      const int64_t per = (nch + nsplit - 1) / std::max(nsplit, 1);
+      return (nch + per - 1) / std::max<int64_t>(per, 1);
+    };
+    while (chunk > 16 && realised(chunk) < nsplit) chunk /= 2;
+    pl.chunk = chunk;
+    pl.nsrc_pad = round_up(std::max<int64_t>(nsrc, 1), chunk);
+  }
+  const int64_t nchunks = pl.nsrc_pad / chunk;
   if (nsplit > nchunks) nsplit = (int)nchunks;
   if (nsplit < 1) nsplit = 1;
   const int64_t chunks_per_split = (nchunks + nsplit - 1) / nsplit;
@@ -735,8 +763,8 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
   // horizontal length Hmin, largest |b_z| Z) and every channel the exponent of source s is at least
   //   x_s = kappa_s max(Hmin |n_s| - Z rho_s, 0)^2 fmin^2/c^2 .
   // The leading sources of a run whose x_s >= T contribute together at most exp(-T) sum|pbflux|: T = 18 (1.5e-8) for fp32 requests --
-  // far inside the 5e-6 tolerance -- and the packed fp32 kernels start the group's source loop behind them (the table for T = 28,
-  // 7e-13 against fp64's 1e-11, is formed too, but the fp64 kernels do not use it: run_pass).
+  // far inside the 5e-6 tolerance -- and the packed fp32 kernels start the group's source loop behind them; T = 28 (7e-13 against
+  // fp64's 1e-11) for fp64 requests, used by the grouped fp64 kernel k_skyvis_taper_f64 (run_pass).
   // Long baselines over coarse diffuse pixels (config 4: MWA to 2.5 km, nside 64) shed the sources nearest the zenith this way when
   // the caller lists a run's sources by decreasing altitude (InterferometerArray.observe does); unordered skies just cull little.
   ctx->cull_any[0] = ctx->cull_any[1] = false;
@@ -1190,6 +1218,15 @@ static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams
 }
 
 // one sky-sum pass into `dst` ([nbl][nchan] complex128); scale_comp >= 0 multiplies pbflux rows by dircos[:,comp]
+// Wave items (k_skyvis_taper_f64_wave): the grouped fp64 taper kernel on an array of one baseline group whose sources are split.
+// PRISIM_HIP_WAVE_ITEMS=0: block items (the A/B baseline).
+static bool wave_items(const prisim_ctx* ctx, const Plan& pl) {
+  bool on = !pl.f32 && ctx->taper && (pl.ct == 16 || pl.ct == 32) && pl.kernel == PRISIM_KERNEL_RECURRENCE && pl.nsplit > 1 &&
+            ctx->nbl <= kBlockThreads;
+  if (const char* env = getenv("PRISIM_HIP_WAVE_ITEMS")) on = on && atoi(env) != 0;
+  return on;
+}
+
 static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp, bool timed) {
   SkyvisParams p{};
   fill_params(ctx, pl, p);
@@ -1283,7 +1320,15 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
         }
       }
     } else {
-      HIPCHK(ctx, launch_skyvis_taper_f64(p, pl.ct, ctx->stream));
+      SkyvisParams q = p;
+      if (wave_items(ctx, pl)) {
+        // an array of at most 256 baselines with split sources: the unit of work is a wavefront (baseline wave, split), four per block
+        q.wave_nbw = (int32_t)((ctx->nbl + 63) / 64);
+        q.wave_nsplit = pl.nsplit;
+        q.nsplit = 1;
+        q.nbgroups = (q.wave_nbw * pl.nsplit + kBlockThreads / 64 - 1) / (kBlockThreads / 64);
+      }
+      HIPCHK(ctx, launch_skyvis_taper_f64(q, pl.ct, ctx->stream));
     }
   } else {
     HIPCHK(ctx, launch_skyvis_rec(p, pl.f32, pl.ct, ctx->stream));

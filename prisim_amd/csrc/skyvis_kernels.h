@@ -58,6 +58,10 @@ struct SkyvisParams {
   // rounded up to the block size
   const float2* step_tab;
   int64_t step_tab_pitch;
+  // wave items (k_skyvis_taper_f64_wave, nbl <= 256): wave_nbw = ceil(nbl / 64) baseline waves x wave_nsplit source splits, four items
+  // per block; 0 = block items
+  int32_t wave_nbw;
+  int32_t wave_nsplit;
 };
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);

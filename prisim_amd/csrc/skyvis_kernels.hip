@@ -353,10 +353,15 @@ __device__ __forceinline__ bool block_item(const SkyvisParams& p, int& slab, int
 //   the wave-uniform pbflux operand: 7 instructions per term (1 correction multiply, 2 accumulate FMAs, 4 for zeta * rho) and
 //   rho_{t+1} = rho_t exp(-16 nu) per group.  Nothing is truncated: every factor is formed to fp64 accuracy (short series, or the library
 //   exp on a wave-uniform slow path for steps that are not small).  Rows are packed in natural channel order, one group = one 64-byte piece.
-template <typename T, int CT, int TAPER, bool LIFT>
+// WITEM (k_skyvis_taper_f64_wave, arrays of at most 256 baselines): the unit of work is a WAVEFRONT, not a block -- item g = 4 bg + wave
+//   is (baseline wave g mod nbw, source split g / nbw), nbw = ceil(nbl / 64), p.wave_nsplit splits.  A 171-baseline array (config 2)
+//   fills 3 of a block's 4 wavefronts: with block items one SIMD of every CU idles and the 4th wave costs nothing when added (256
+//   baselines take the time of 171, tools/config2_fullwave_probe.py); with wave items all four SIMDs carry sources.
+template <typename T, int CT, int TAPER, bool LIFT, bool WITEM = false>
 __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned char* flush_lds, unsigned char* pf_area, const double2* tab,
                                                 const double* etab = nullptr) {
   static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
+  static_assert(!WITEM || TAPER == 2, "wave items: the grouped fp64 taper kernel only");
   static_assert(TAPER != 2 || (sizeof(T) == 8 && CT >= 16 && !LIFT), "the grouped fp64 taper: 16- or 32-channel tiles, folded (no lifting)");
   constexpr bool GROUPED = TAPER == 2;
   constexpr int HC = CT / 2;                       // channels per chain (here the taper multiplies pbflux, so z stays a pure rotation
@@ -374,7 +379,17 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   int slab, bg;
   if (!block_item(p, slab, bg)) return;
   const int tile = slab % p.ntiles;
-  const int split = slab / p.ntiles;
+  int split = slab / p.ntiles;
+  int bwave = 0;                                    // WITEM: this wave's 64 baselines start at 64 bwave
+  bool item_ok = true;
+  if constexpr (WITEM) {
+    const int g = bg * (kBlockThreads / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    split = g / p.wave_nbw;                         // (block_item sees p.nsplit = 1 and p.nbgroups = quads of items)
+    bwave = g - split * p.wave_nbw;
+    item_ok = split < p.wave_nsplit;
+  }
+  const int nsp = WITEM ? p.wave_nsplit : p.nsplit;
+  const int cg = WITEM ? 0 : bg;                    // baseline group of the culling table (WITEM: one group)
 
   int64_t s_begin = (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
@@ -396,9 +411,9 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
     s_end = s_begin + p.src_per_split;
     if (s_end > p.src_hi) s_end = p.src_hi;
     if (p.src_first != nullptr) {
-      const int64_t f = p.src_first[bg];
+      const int64_t f = p.src_first[cg];
       if (f > p.src_lo) {
-        const int64_t per = (p.src_hi - f + p.nsplit - 1) / p.nsplit;
+        const int64_t per = (p.src_hi - f + nsp - 1) / nsp;
         s_begin = f + (int64_t)split * per;
         s_end = s_begin + per < p.src_hi ? s_begin + per : p.src_hi;
       }
@@ -406,11 +421,11 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   }
 
   const int tid = threadIdx.x;
-  const int64_t b_raw = (int64_t)bg * kBlockThreads + tid;
+  const int64_t b_raw = WITEM ? (int64_t)bwave * 64 + (tid & 63) : (int64_t)bg * kBlockThreads + tid;
   const bool b_valid = b_raw < p.nbl;
   const int64_t b = b_valid ? b_raw : (p.nbl - 1);
   // a wavefront whose first baseline is out of range does no arithmetic (wave-uniform)
-  const bool wave_active = ((int64_t)bg * kBlockThreads + (tid & ~63)) < p.nbl;
+  const bool wave_active = WITEM ? item_ok : ((int64_t)bg * kBlockThreads + (tid & ~63)) < p.nbl;
 
   const double bx = p.bl_x[b], by = p.bl_y[b], bz = p.bl_z[b];
   const int k0 = tile * CT;
@@ -442,7 +457,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   constexpr int FCH = FlushCfg<T>::ch < CT ? FlushCfg<T>::ch : CT;
   FV* const wbuf = reinterpret_cast<FV*>(flush_lds) + (tid >> 6) * (64 * (FCH + 1));
   const int lane = tid & 63;
-  const int64_t bw0 = (int64_t)bg * kBlockThreads + (tid & ~63);      // first baseline of this wave
+  const int64_t bw0 = WITEM ? (int64_t)bwave * 64 : (int64_t)bg * kBlockThreads + (tid & ~63);      // first baseline of this wave
 
   auto flush = [&]() {
     if (wave_active) {
@@ -494,7 +509,9 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
                                                               (size_t)s_begin * CT);
   const float* const pf_dirs = reinterpret_cast<const float*>(p.dirs_prep) + (size_t)s_begin * 8;
   const lptr_t pf_lds = (lptr_t)(pf_area + (tid >> 6) * kPrefetchWaveBytes);
-  const bool pf_on = n_loc >= 64;                    // 1 KiB = 4 ... 32 rows per request, clamped 32 rows before the end
+  constexpr int kRowDwords = CT * (int)sizeof(T) / 4;                    // <= 96
+  constexpr int kReqRows = 256 / kRowDwords > 8 ? 256 / kRowDwords : 8;  // sources one warm-up request covers (1 KiB of rows, 8 directions)
+  const bool pf_on = n_loc >= 2 * kReqRows;          // requests are clamped kReqRows before the end of the wave's own range
   int seg0 = 0;
   do {
   const int seg1 = (n_loc - seg0 > seg_len) ? seg0 + seg_len : n_loc;
@@ -549,8 +566,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
       const int sn2 = (s + 2 < seg1) ? s + 2 : seg1 - 1;
       if (pf_on && ((s - seg0) & 3) == 0) {
         // L2 warm-up, every 4th source: 1 KiB of rows and 8 directions kPrefetchAhead sources ahead (see k_skyvis_rec_f32pk)
-        constexpr int kRowDwords = CT * (int)sizeof(T) / 4;          // <= 96
-        const int spf = (s + kPrefetchAhead < n_loc - 32) ? s + kPrefetchAhead : n_loc - 32;
+        const int spf = (s + kPrefetchAhead < n_loc - kReqRows) ? s + kPrefetchAhead : n_loc - kReqRows;
         int lane_pf = lane;
         asm volatile("" : "+v"(lane_pf));                            // formed here from the lane id: no per-lane pointers kept live across the loop
         __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * kRowDwords + lane_pf * 4), pf_lds, 16, 0, 0);
@@ -800,6 +816,21 @@ void k_skyvis_taper_f64(const SkyvisParams p) {
   fill_exp_table(etab_lds);
   __syncthreads();                                               // the only block barrier of the kernel: before any early exit
   skyvis_rec_body<double, CT, 2, false>(p, flush_lds, pf_area, tab_lds, etab_lds);
+}
+
+// The same for arrays of at most 256 baselines whose sources are split: wave items (WITEM above).  p.nbgroups = ceil(nbw wave_nsplit / 4)
+// quads of items, p.nsplit = 1, partial cube `split` of p.wave_nsplit.
+template <int CT>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2)))
+void k_skyvis_taper_f64_wave(const SkyvisParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<double>()];
+  __shared__ __attribute__((aligned(16))) unsigned char pf_area[kPrefetchLdsBytes];
+  __shared__ double2 tab_lds[kTabN];
+  __shared__ double etab_lds[kExpTabN];
+  fill_phasor_table(tab_lds);
+  fill_exp_table(etab_lds);
+  __syncthreads();
+  skyvis_rec_body<double, CT, 2, false, true>(p, flush_lds, pf_area, tab_lds, etab_lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1991,6 +2022,18 @@ hipError_t launch_skyvis_taper_f64(const SkyvisParams& p, int ct, hipStream_t st
   const int64_t items = (int64_t)p.ntiles * p.nsplit * p.nbgroups;          // see block_item()
   if (items <= 0 || items > 0x3fffffffLL || !p.taper) return hipErrorInvalidValue;
   const unsigned grid = 8u * (unsigned)((items + 7) / 8);
+  if (p.wave_nbw > 0) {
+    // wave items: one baseline group, p.nbgroups quads of (baseline wave, split) items
+    if (p.nsplit != 1 || p.wave_nsplit < 1 || p.nbl > kBlockThreads || (int64_t)p.wave_nbw * 64 < p.nbl ||
+        (int64_t)p.nbgroups * (kBlockThreads / 64) < (int64_t)p.wave_nbw * p.wave_nsplit)
+      return hipErrorInvalidValue;
+    switch (ct) {
+      case 16: hipLaunchKernelGGL((k_skyvis_taper_f64_wave<16>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
+      case 32: hipLaunchKernelGGL((k_skyvis_taper_f64_wave<32>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (ct) {
     case 16: hipLaunchKernelGGL((k_skyvis_taper_f64<16>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
     case 32: hipLaunchKernelGGL((k_skyvis_taper_f64<32>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;

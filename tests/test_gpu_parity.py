@@ -350,6 +350,55 @@ def test_fp64_grouped_taper_runs_culling_and_slow_path(ctx, monkeypatch):
     ctx.set_tuning(0, 0, 0)
 
 
+def test_fp64_taper_wave_items_on_small_arrays(ctx, monkeypatch):
+    """Arrays of at most 256 baselines whose sources are split run the grouped fp64 taper kernel with WAVE items
+    (k_skyvis_taper_f64_wave: item = (baseline wave, source split), four per block) so that every SIMD carries sources when the array
+    fills 1-3 wavefronts (config 1: 3 baselines, config 2: 171).  Against the C oracle and against block items
+    (PRISIM_HIP_WAVE_ITEMS=0) for 3 / 64 / 65 / 171 / 256 baselines, item counts that are and are not multiples of four, splits that do
+    not divide the sky, the planner's own choice, and a sky whose leading sources are culled."""
+    rng = NP.random.default_rng(271)
+    pc = O.altaz2dircos(NP.array([[86.0, 40.0]]))[0]
+    nsrc = 333
+    alt = NP.degrees(NP.arcsin(rng.uniform(NP.sin(NP.radians(5.0)), 1.0, nsrc)))
+    dc = O.altaz2dircos(NP.stack((alt, rng.uniform(0, 360, nsrc)), axis=1))
+    ch = 150e6 + (NP.arange(72) - 36) * 390625.0                        # ragged last tile at 16 and at 32
+    pb = rng.uniform(0.5, 10.0, size=(nsrc, 1)) * rng.uniform(0.5, 1.0, size=(nsrc, ch.size))
+    fw = NP.full(nsrc, 3.66)
+    for nbl in (3, 64, 65, 171, 256):
+        bl = rng.uniform(-60.0, 60.0, size=(nbl, 3)); bl[:, 2] *= 0.02
+        ref = CO.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw)
+        ctx.set_array(bl, ch)
+        ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
+        for ct, nsplit in ((16, 2), (16, 7), (32, 5), (16, 20), (0, 0)):
+            ctx.set_tuning(ct, 0, nsplit)
+            ctx.compute(precision=_abi.PRISIM_FP64)
+            vw = ctx.get_vis()
+            t = ctx.timing()
+            assert relerr(vw, ref, pb) <= TOL[_abi.PRISIM_FP64], (nbl, ct, nsplit, t)
+            if (ct, nsplit) == (0, 0):
+                assert t['last_nsplit'] > 1, t               # the planner splits a small array's sources (and so takes this path)
+            monkeypatch.setenv('PRISIM_HIP_WAVE_ITEMS', '0')
+            ctx.compute(precision=_abi.PRISIM_FP64)
+            assert relerr(ctx.get_vis(), vw, pb) <= 1e-13, (nbl, ct, nsplit)
+            monkeypatch.delenv('PRISIM_HIP_WAVE_ITEMS')
+    # culling: large pixels by decreasing altitude under 1.5 km baselines, sources split
+    ang, rad = rng.uniform(0, 2 * NP.pi, 200), rng.uniform(1200.0, 1500.0, 200)       # every baseline long: the one group sheds sources
+    bl = NP.stack((rad * NP.cos(ang), rad * NP.sin(ang), rng.normal(0.0, 0.5, size=200)), axis=1)
+    ch3 = 170e6 + NP.arange(64) * 40e3
+    dc3 = O.altaz2dircos(NP.stack((NP.sort(alt)[::-1], rng.uniform(0, 360, nsrc)), axis=1))
+    pb3 = rng.uniform(0.5, 10.0, size=(nsrc, 1)) * rng.uniform(0.5, 1.0, size=(nsrc, ch3.size))
+    fw3 = NP.full(nsrc, 0.916)
+    ref3 = CO.skyvis(bl, ch3, dc3, pb3, pc, fwhm_deg=fw3)
+    ctx.set_array(bl, ch3)
+    ctx.set_sky(dc3, pb3, pc, fwhm_deg=fw3)
+    for ct, nsplit in ((16, 6), (32, 3)):
+        ctx.set_tuning(ct, 0, nsplit)
+        ctx.compute(precision=_abi.PRISIM_FP64)
+        assert relerr(ctx.get_vis(), ref3, pb3) <= TOL[_abi.PRISIM_FP64], (ct, nsplit, ctx.timing())
+        assert ctx.timing()['last_culled_fraction'] > 0.05, ctx.timing()
+    ctx.set_tuning(0, 0, 0)
+
+
 @pytest.mark.parametrize('taper', [False, True])
 def test_fp32_single_source_worst_case_per_term(ctx, taper):
     """One source, so nothing averages: the error of every (baseline, channel) term against the fp64 oracle must stay inside the
