@@ -530,7 +530,9 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
       }
     }
   }
-  if (!ctx->tune_chunk) {
+  if (!ctx->tune_chunk && (!pl.f32 || ctx->tune_nsplit)) {
+    // (fp64; the packed fp32 kernel's time barely moves with the split count -- 40.3 us at 47 splits against 42.2 at 24 on config 2 -- and
+    // every split costs its share of k_reduce_partials: 65.7 us per snapshot against 61.7, r04_cfg2_probe_f32.jsonl.)
     // A small sky cut into many pieces (config 2: 1504 sources, 32 splits fill the 512 block slots exactly): 64-source chunks would cap
     // the split count at nsrc / 64 = 24 -- 62 us against 76 with 16-source chunks and 32 splits (tools/config2_fullwave_probe.py)
     auto realised = [&](int c) {          // split count a chunk size allows: whole chunks per split
@@ -1227,7 +1229,7 @@ static bool wave_items(const prisim_ctx* ctx, const Plan& pl) {
   return on;
 }
 
-static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp, bool timed) {
+static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp, bool timed, bool prep = false) {
   SkyvisParams p{};
   fill_params(ctx, pl, p);
   p.scale_comp = scale_comp;
@@ -1244,8 +1246,13 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   // form, k_skyvis_rec<double, CT, true> -- the A/B baseline and the 8-channel tiles' kernel)
   bool g64 = !pl.f32 && ctx->taper && (pl.ct == 16 || pl.ct == 32);
   if (const char* env = getenv("PRISIM_HIP_TAPER_F64_GROUP")) g64 = g64 && atoi(env) != 0;
-  HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
-                          pl.ntiles, (const double*)ctx->dirs.p, scale_comp, g64 ? 0 : 1, ctx->stream));
+  if (prep && scale_comp < 0)      // the snapshot's first pass: rows and directions in one launch
+    HIPCHK(ctx, launch_pack_prep((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
+                                 g64 ? 0 : 1, (const double*)ctx->dirs.p, (double*)ctx->dirs_prep.p, ctx->pc[0], ctx->pc[1], ctx->pc[2],
+                                 1.0 / kC, ctx->stream));
+  else
+    HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
+                            pl.ntiles, (const double*)ctx->dirs.p, scale_comp, g64 ? 0 : 1, ctx->stream));
   p.out = pl.nsplit > 1 ? (double*)ctx->partial.p : dst;
   // fp32 kernels whose splits each flush exactly once store their partial sums as complex64: half the partial traffic
   const bool part_f32 = pl.nsplit > 1 && pl.f32 && pl.kernel == PRISIM_KERNEL_RECURRENCE && pl.src_per_split <= (int64_t)p.flush_src;
@@ -1455,9 +1462,9 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     }
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev_c0[ctx->ring_head], ctx->stream));
-  if (pl.kernel == PRISIM_KERNEL_RECURRENCE) {
+  if (pl.kernel == PRISIM_KERNEL_RECURRENCE && fused_grad) {
     float* c32 = nullptr;
-    if (fused_grad && pl.f32) {
+    if (pl.f32) {
       if ((rc = ensure(ctx, ctx->dirs_c32, (size_t)pl.nsrc_pad * 8 * sizeof(float)))) return rc;
       c32 = (float*)ctx->dirs_c32.p;
     }
@@ -1466,7 +1473,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   }
   if (fused_grad) {
     if ((rc = run_grad_pass(ctx, pl, dst, (double*)ctx->grad.p + (size_t)slot * 3 * slot_elems))) return rc;
-  } else if ((rc = run_pass(ctx, pl, dst, -1, true))) {
+  } else if ((rc = run_pass(ctx, pl, dst, -1, true, /*prep=*/true))) {      // (prepares the directions with its first launch)
     return rc;
   }
   if (want_grad && !fused_grad) {

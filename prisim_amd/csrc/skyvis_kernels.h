@@ -93,6 +93,10 @@ hipError_t launch_skyvis_direct(const SkyvisParams& p, const double* freqs, cons
 hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct,
                        int ntiles, const double* dirs, int scale_comp, int interleave, hipStream_t stream, int64_t s_lo = 0, int64_t s_hi = -1);
 // rows of the fused fp32 gradient kernel without the taper: [ntiles(16 ch)][nsrc_pad][64] floats, pre-multiplied by (1, l, m, n)
+// launch_pack (whole sky, no scaling) + launch_prep_dirs (no c32) in one launch
+hipError_t launch_pack_prep(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct, int ntiles,
+                            int interleave, const double* dirs, double* prep, double pcx, double pcy, double pcz, double inv_c,
+                            hipStream_t stream);
 hipError_t launch_pack_grad(const double* pb, float* packed, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ntiles, const double* dirs,
                             hipStream_t stream);
 hipError_t launch_prep_dirs(const double* dirs, double* prep, float* c32 /*[nsrc_pad][8] or NULL*/, int64_t nsrc, int64_t nsrc_pad, double pcx,

@@ -1842,12 +1842,12 @@ void k_skyvis_direct(const SkyvisParams p, const double* __restrict__ freqs,
 // Only the rows of sources [s_lo, s_hi) are written (the whole padded range: 0, nsrc_pad): a run of a mixed sky can be re-packed in the
 // layout its kernel wants.
 template <typename T>
-__global__ void k_pack(const double* __restrict__ pb, T* __restrict__ packed, int64_t nsrc, int64_t nsrc_pad,
-                       int64_t nchan, int ct, int ntiles, const double* __restrict__ dirs, int scale_comp,
-                       int interleave, int64_t s_lo, int64_t s_hi) {
+__device__ __forceinline__ void pack_rows(const double* __restrict__ pb, T* __restrict__ packed, int64_t nsrc, int64_t nsrc_pad,
+                                          int64_t nchan, int ct, int ntiles, const double* __restrict__ dirs, int scale_comp,
+                                          int interleave, int64_t s_lo, int64_t s_hi, unsigned bid, unsigned nblocks) {
   const int64_t nrow = s_hi - s_lo;
   const int64_t total = (int64_t)ntiles * nrow * ct;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblocks * blockDim.x) {
     const int cpos = (int)(i % ct);
     int c = cpos;
     if (interleave) c = (c & 1) ? (ct / 2 - 1 - (c >> 1)) : (ct / 2 + (c >> 1));
@@ -1861,6 +1861,13 @@ __global__ void k_pack(const double* __restrict__ pb, T* __restrict__ packed, in
     }
     packed[((size_t)tile * nsrc_pad + (size_t)s) * ct + cpos] = (T)v;
   }
+}
+
+template <typename T>
+__global__ void k_pack(const double* __restrict__ pb, T* __restrict__ packed, int64_t nsrc, int64_t nsrc_pad,
+                       int64_t nchan, int ct, int ntiles, const double* __restrict__ dirs, int scale_comp,
+                       int interleave, int64_t s_lo, int64_t s_hi) {
+  pack_rows<T>(pb, packed, nsrc, nsrc_pad, nchan, ct, ntiles, dirs, scale_comp, interleave, s_lo, s_hi, blockIdx.x, gridDim.x);
 }
 
 // Rows of the fused fp32 gradient kernel without the taper (GPK bodies, 16-channel tiles): packed[tile][s][pair j][set r][up / down] =
@@ -1885,9 +1892,9 @@ __global__ void k_pack_grad(const double* __restrict__ pb, float* __restrict__ p
 
 // dirs_prep[s] = ((l,m,n) - s_pc)/c, kappa   for s < nsrc;  zeros for nsrc <= s < nsrc_pad
 // c32 (optional): [nsrc_pad][8] floats (l, l, m, m, n, n, 0, 0): the gradient coefficients as ready SGPR-pair operands
-__global__ void k_prep_dirs(const double* __restrict__ dirs, double* __restrict__ prep, float* __restrict__ c32, int64_t nsrc,
-                            int64_t nsrc_pad, double pcx, double pcy, double pcz, double inv_c) {
-  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nsrc_pad; s += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void prep_dirs(const double* __restrict__ dirs, double* __restrict__ prep, float* __restrict__ c32, int64_t nsrc,
+                                          int64_t nsrc_pad, double pcx, double pcy, double pcz, double inv_c, unsigned bid, unsigned nblocks) {
+  for (int64_t s = (int64_t)bid * blockDim.x + threadIdx.x; s < nsrc_pad; s += (int64_t)nblocks * blockDim.x) {
     double4 v = make_double4(0, 0, 0, 0);
     float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (s < nsrc) {
@@ -1902,6 +1909,21 @@ __global__ void k_prep_dirs(const double* __restrict__ dirs, double* __restrict_
       reinterpret_cast<float4*>(c32)[2 * s + 1] = c1;
     }
   }
+}
+
+__global__ void k_prep_dirs(const double* __restrict__ dirs, double* __restrict__ prep, float* __restrict__ c32, int64_t nsrc,
+                            int64_t nsrc_pad, double pcx, double pcy, double pcz, double inv_c) {
+  prep_dirs(dirs, prep, c32, nsrc, nsrc_pad, pcx, pcy, pcz, inv_c, blockIdx.x, gridDim.x);
+}
+
+// Both per-snapshot pre-passes in ONE launch (the first gpack blocks pack the rows, the rest prepare the directions; neither reads what
+// the other writes): a launch and its gap are ~6 us of a small problem's snapshot (config 2: 81 us).
+template <typename T>
+__global__ void k_pack_prep(const double* __restrict__ pb, T* __restrict__ packed, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct,
+                            int ntiles, int interleave, const double* __restrict__ dirs, double* __restrict__ prep, double pcx, double pcy,
+                            double pcz, double inv_c, unsigned gpack) {
+  if (blockIdx.x < gpack) pack_rows<T>(pb, packed, nsrc, nsrc_pad, nchan, ct, ntiles, nullptr, -1, interleave, 0, nsrc_pad, blockIdx.x, gpack);
+  else prep_dirs(dirs, prep, nullptr, nsrc, nsrc_pad, pcx, pcy, pcz, inv_c, blockIdx.x - gpack, gridDim.x - gpack);
 }
 
 // sum nsplit partial cubes [nsplit][n] (complex as 2 doubles, or 2 floats for the fp32 kernels' single-flush partials) -> out[n];
@@ -2097,6 +2119,21 @@ hipError_t launch_pack(const double* pb, void* packed, bool f32, int64_t nsrc, i
   else
     hipLaunchKernelGGL(k_pack<double>, dim3(grid_for(total)), dim3(256), 0, stream, pb, (double*)packed, nsrc, nsrc_pad,
                        nchan, ct, ntiles, dirs, scale_comp, interleave, s_lo, s_hi);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_prep(const double* pb, void* packed, bool f32, int64_t nsrc, int64_t nsrc_pad, int64_t nchan, int ct, int ntiles,
+                            int interleave, const double* dirs, double* prep, double pcx, double pcy, double pcz, double inv_c,
+                            hipStream_t stream) {
+  const int64_t total = (int64_t)ntiles * nsrc_pad * ct;
+  if (total == 0) return hipSuccess;
+  const unsigned gpack = grid_for(total), gprep = grid_for(nsrc_pad);
+  if (f32)
+    hipLaunchKernelGGL(k_pack_prep<float>, dim3(gpack + gprep), dim3(256), 0, stream, pb, (float*)packed, nsrc, nsrc_pad, nchan, ct, ntiles,
+                       interleave, dirs, prep, pcx, pcy, pcz, inv_c, gpack);
+  else
+    hipLaunchKernelGGL(k_pack_prep<double>, dim3(gpack + gprep), dim3(256), 0, stream, pb, (double*)packed, nsrc, nsrc_pad, nchan, ct, ntiles,
+                       interleave, dirs, prep, pcx, pcy, pcz, inv_c, gpack);
   return hipGetLastError();
 }
 
