@@ -132,6 +132,47 @@ def test_config5_two_lsts_and_delay_transform():
     assert NP.max(NP.abs(lag - ref_lag)) <= 1e-10 * NP.max(NP.abs(ref_lag))
 
 
+def test_config5_all_120_lsts_on_a_coarse_sky():
+    """Config 5's full time axis inside the suite: HERA-350 x 1024 channels x ALL 120 LSTs of 10.7 s drift, fp32, with the sky coarsened
+    to nside 32 (6.1e3 pixels instead of 3.9e5, so that the 120 sky-sums take seconds; the full sky runs in tools/run_config5_full.py:
+    364 s fp32 / 846 s fp64).  The 120 GB cube (7.3e6 rows) stays in HBM; then the delay POWER spectra of every row on the device
+    (K^2 (Mpc/h)^3, delay_spectrum.py:3659-3663, 3992).  Spot checks against the oracles: visibilities of the first, a middle and the last
+    LST on 3 baselines, and their delay power against the oracle's transform of those rows."""
+    from prisim_amd import delay_spectrum as DSM
+    n_lst = 120
+    cfg = W.config5(n_acc=n_lst, nside=32)
+    bl, ch, sky, lat = cfg['baselines'], cfg['channels'], cfg['sky'], cfg['latitude']
+    lst0 = 15.0
+    skymod = _radec_skymodel(sky, lat, lst0)
+    ia = RI.InterferometerArray(['b%d' % i for i in range(bl.shape[0])], bl, ch, telescope={'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'},
+                                latitude=lat, skycoords='radec', pointing_coords='hadec')
+    ia.reserve(n_lst)
+    for j in range(n_lst):
+        ia.observe((2457000.5 + j * cfg['t_acc'] / 86400.0, lst0 + j * cfg['t_acc'] * SIDEREAL_DEG_PER_SEC), {'Tnet': 100.0}, NP.ones(ch.size),
+                   [0.0, lat], skymod, cfg['t_acc'], memsave=True)
+    ia._ctx.sync()
+    assert ia.n_acc == n_lst and all(isinstance(s, RI._DeviceSlot) for s in ia._cube)       # nothing left the device while observing
+    sel = _spot(bl, 3)
+    zen = NP.array([0.0, 0.0, 1.0])
+    w = NP.blackman(ch.size) + 0.01
+    k = DSM.power_constants(ch, {'id': 'hera'}, freq_wts=w)['factor']
+    ia._ctx.delay_transform_device(n_lst, bpwts=w, pad=1.0, want_lag=False, want_power=True, power_scale=k)
+    for j in (0, 61, n_lst - 1):
+        dc, altaz, keep = W.drift_snapshot_directions(sky, lat, j * cfg['t_acc'] * SIDEREAL_DEG_PER_SEC)
+        assert ia.obs_catalog_indices[j].size == int(keep.sum())
+        pb = BO.airy_disk_pattern(14.0, altaz, ch, pointing_altaz=[90.0, 270.0]) \
+            * (sky['flux_ref'][keep, None] * (ch[None, :] / sky['ref_freq']) ** sky['spindex'][keep, None])
+        ref = CO.skyvis(bl[sel], ch, dc, pb, zen, fwhm_deg=sky['fwhm_deg'][keep])
+        vis = ia._ctx.get_vis(slot=j)[sel]
+        assert NP.max(NP.abs(vis - ref) / NP.sum(NP.abs(pb), axis=0)[None, :]) <= 5e-6, j
+        ref_lag, _ = DO.delay_transform(vis[:, :, None], NP.ones((sel.size, ch.size, 1)), NP.repeat(w[None, :, None], sel.size, axis=0),
+                                        ia.freq_resolution, pad=1.0)
+        pw = ia._ctx.get_delay_power(j, 1, rows=sel)[0]                                    # (3, nlag)
+        ref_pw = NP.abs(ref_lag[:, :, 0]) ** 2 * k
+        assert pw.shape == ref_pw.shape and NP.all(NP.isfinite(pw))
+        assert NP.max(NP.abs(pw - ref_pw)) <= 1e-9 * NP.max(ref_pw), j
+
+
 @pytest.mark.parametrize('taper', [False, True])
 def test_fused_gradient_at_config3_array_size(taper):
     """The fused V + baseline-gradient kernels (interferometry.py:6330, 6338, 6343) on the full HERA-350 array x 1024 channels -- every
