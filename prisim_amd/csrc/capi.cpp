@@ -409,6 +409,8 @@ int ensure_copy_stream(prisim_ctx* ctx) {
   return PRISIM_OK;
 }
 
+constexpr int kMaxRunSets = 8;       // runs of one source size a split sky may have and still be summed run by run (partial-cube sets)
+
 struct Plan {
   int kernel;      // PRISIM_KERNEL_*
   bool f32;
@@ -1174,8 +1176,8 @@ static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams
   ctx->timing.last_taper_split = 0;
   ctx->timing.last_split_uncorrected_groups = 0;
   if (!(pl.pk && ctx->taper && pl.ct == 64 && p.taper_group && !ctx->kappa_runs.empty())) return false;
-  // with a source split (partial cubes, written once per split) only a sky that is ONE run: later runs could not add to the partials
-  if (pl.nsplit > 1 && !(ctx->kappa_runs.size() == 1 && ctx->kappa_runs[0].kappa > 0.0)) return false;
+  // (with a source split every run of the sky writes its own set of partial cubes: run_pass)
+  if (ctx->kappa_runs.size() > (size_t)kMaxRunSets) return false;
   if (const char* env = getenv("PRISIM_HIP_TAPER_SPLIT")) { if (atoi(env) == 0) return false; }      // A/B hook
   const double fmax = std::max(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
   const double fmin = std::min(std::fabs(ctx->f0), std::fabs(ctx->f0 + ctx->df * (double)(ctx->nchan - 1)));
@@ -1253,13 +1255,33 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   else
     HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
                             pl.ntiles, (const double*)ctx->dirs.p, scale_comp, g64 ? 0 : 1, ctx->stream));
-  p.out = pl.nsplit > 1 ? (double*)ctx->partial.p : dst;
-  // fp32 kernels whose splits each flush exactly once store their partial sums as complex64: half the partial traffic
-  const bool part_f32 = pl.nsplit > 1 && pl.f32 && pl.kernel == PRISIM_KERNEL_RECURRENCE && pl.src_per_split <= (int64_t)p.flush_src;
-  p.out_f32 = part_f32 ? 1 : 0;
   // Packed fp32 taper on a sky whose sources come in a few runs of one size each (every HEALPix sky; point sources + diffuse): the
   // split form, run by run (skyvis_kernels.hip: TGROUP 2 / 3) -- size-0 runs take the plain (no-taper) bodies.
   const bool split = scale_comp < 0 && taper_split_plan(ctx, pl, p);
+  // Run by run under a SOURCE SPLIT (baseline shards of a mixed sky: point sources + a diffuse map): every run is cut into nsplit pieces
+  // of its own and writes its own set of nsplit partial cubes; k_reduce_partials then sums nruns x nsplit of them, in fixed order.
+  // (Before, a split sky of several runs fell back to ONE launch of the unsplit-form kernels over the whole sky: 510 ms against
+  // 453 ideal for one rank's half of config 3 + diffuse, profiles/r04_shard_balance.json.)
+  const size_t nruns_sky = ctx->kappa_runs.size();
+  const bool by_run = (split || g64) && nruns_sky > 1 && nruns_sky <= (size_t)kMaxRunSets;
+  const int nsets = (pl.nsplit > 1 && by_run) ? (int)nruns_sky : 1;
+  auto run_per_split = [&](const prisim_ctx::KappaRun& run) {
+    return round_up(((run.hi - run.lo) + pl.nsplit - 1) / pl.nsplit, pl.chunk);
+  };
+  int64_t max_per = pl.src_per_split;
+  if (nsets > 1) {
+    max_per = 0;
+    for (const auto& run : ctx->kappa_runs) max_per = std::max(max_per, run_per_split(run));
+  }
+  p.out = pl.nsplit > 1 ? (double*)ctx->partial.p : dst;
+  // fp32 kernels whose splits each flush exactly once store their partial sums as complex64: half the partial traffic
+  const bool part_f32 = pl.nsplit > 1 && pl.f32 && pl.kernel == PRISIM_KERNEL_RECURRENCE && max_per <= (int64_t)p.flush_src;
+  p.out_f32 = part_f32 ? 1 : 0;
+  const size_t set_reals = (size_t)pl.nsplit * (size_t)ctx->nbl * (size_t)ctx->nchan * 2;       // reals of one run's partial cubes
+  auto set_out = [&](size_t r) -> double* {
+    if (nsets == 1) return p.out;
+    return part_f32 ? (double*)((float*)ctx->partial.p + r * set_reals) : (double*)ctx->partial.p + r * set_reals;
+  };
   // taper culling: per baseline group the first source it still has to sum (tables staged by set_sky_*); a launch over the whole sky
   // can only skip the leading sources of the FIRST run
   const int cpr = pl.f32 ? 1 : 0;
@@ -1275,8 +1297,10 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
       const prisim_ctx::KappaRun& run = ctx->kappa_runs[r];
       SkyvisParams q = p;
       q.src_lo = run.lo; q.src_hi = run.hi;
-      if (pl.nsplit == 1) q.src_per_split = round_up(run.hi - run.lo, pl.chunk);       // (a split sky is one run: the plan's pieces stand)
-      q.accumulate = launches > 0 ? 1 : 0;
+      if (pl.nsplit == 1) q.src_per_split = round_up(run.hi - run.lo, pl.chunk);
+      else if (nsets > 1) q.src_per_split = run_per_split(run);                        // (a split sky of ONE run: the plan's pieces stand)
+      q.accumulate = (launches > 0 && nsets == 1) ? 1 : 0;
+      q.out = set_out(r);
       if (run.kappa > 0.0) {
         q.kappa0 = run.kappa;
         if (cull) q.src_first = cull_table(r);
@@ -1306,15 +1330,22 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     // run by run when the sky comes in runs of one source size (so that every run's leading sources can be culled); with a source
     // split (partial cubes, written once per split) only a sky that is one run -- otherwise one launch over the whole sky
     const size_t nruns = ctx->kappa_runs.size();
-    if (nruns > 1 && pl.nsplit == 1) {
+    if (by_run) {
       for (size_t r = 0; r < nruns; ++r) {
         const prisim_ctx::KappaRun& run = ctx->kappa_runs[r];
         SkyvisParams q = p;
         q.src_lo = run.lo; q.src_hi = run.hi;
-        q.src_per_split = round_up(run.hi - run.lo, pl.chunk);
-        q.accumulate = r > 0 ? 1 : 0;
+        q.src_per_split = pl.nsplit == 1 ? round_up(run.hi - run.lo, pl.chunk) : run_per_split(run);
+        q.accumulate = (r > 0 && nsets == 1) ? 1 : 0;
+        q.out = set_out(r);
         q.src_first = cull ? cull_table(r) : nullptr;
         if (run.kappa > 0.0) {
+          if (wave_items(ctx, pl)) {
+            q.wave_nbw = (int32_t)((ctx->nbl + 63) / 64);
+            q.wave_nsplit = pl.nsplit;
+            q.nsplit = 1;
+            q.nbgroups = (q.wave_nbw * pl.nsplit + kBlockThreads / 64 - 1) / (kBlockThreads / 64);
+          }
           HIPCHK(ctx, launch_skyvis_taper_f64(q, pl.ct, ctx->stream));
         } else {
           // point sources (w = 1, :6270 sigma = inf): the fp64 kernel without the taper (6.2 instead of 9.8 instructions per term); its
@@ -1342,7 +1373,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   }
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
   if (pl.nsplit > 1)
-    HIPCHK(ctx, launch_reduce_partials(ctx->partial.p, part_f32, dst, ctx->nbl * ctx->nchan * 2, pl.nsplit, ctx->stream));
+    HIPCHK(ctx, launch_reduce_partials(ctx->partial.p, part_f32, dst, ctx->nbl * ctx->nchan * 2, pl.nsplit * nsets, ctx->stream));
   return PRISIM_OK;
 }
 
@@ -1432,7 +1463,9 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     const size_t pbytes = (size_t)pl.ntiles * pl.nsrc_pad * pl.ct * (pl.f32 ? 4 : 8);
     if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;
     if ((rc = ensure(ctx, ctx->dirs_prep, (size_t)pl.nsrc_pad * 4 * sizeof(double)))) return rc;
-    if (pl.nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)pl.nsplit * slot_elems * sizeof(double)))) return rc;
+    // (a sky of several runs of one source size writes one set of partial cubes per run: run_pass)
+    const size_t part_sets = (ctx->taper && ctx->kappa_runs.size() > 1 && ctx->kappa_runs.size() <= (size_t)kMaxRunSets) ? ctx->kappa_runs.size() : 1;
+    if (pl.nsplit > 1 && (rc = ensure(ctx, ctx->partial, part_sets * (size_t)pl.nsplit * slot_elems * sizeof(double)))) return rc;
     {
       // lifting rotation is used for a baseline group only when |step phase| <= 1/8 cycle (fp32; 1/4 cycle in fp64, where the
       // angle error alpha*eps is irrelevant and only tan(alpha/2) must stay bounded) is guaranteed for every source:

@@ -235,10 +235,19 @@ def test_fp32_split_taper_runs_of_one_source_size(ctx, monkeypatch):
         tm = ctx.timing()
         assert tm['last_taper_split'] == 1 and tm['last_nsplit'] == nsplit, tm
         assert relerr(ctx.get_vis(), ref1, pb) <= TOL[_abi.PRISIM_FP32], nsplit
-    ctx.set_tuning(64, 0, 2)
-    ctx.set_sky(dc, pb, pc, fwhm_deg=fw)                                  # two runs + a source split: the unsplit kernel
+    # two runs + a source split (a baseline shard of a mixed sky): still run by run, every run into its own set of partial cubes
+    ref2 = CO.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw)
+    ctx.set_sky(dc, pb, pc, fwhm_deg=fw)
+    for nsplit in (2, 3):
+        ctx.set_tuning(64, 0, nsplit)
+        ctx.compute(precision=_abi.PRISIM_FP32)
+        tm = ctx.timing()
+        assert tm['last_taper_split'] == 2 and tm['last_nsplit'] == nsplit, tm
+        assert relerr(ctx.get_vis(), ref2, pb) <= TOL[_abi.PRISIM_FP32], nsplit
+    monkeypatch.delenv('PRISIM_HIP_FLUSH_SRC')                            # ... and with single-flush (complex64) partials
     ctx.compute(precision=_abi.PRISIM_FP32)
-    assert ctx.timing()['last_taper_split'] == 0
+    assert ctx.timing()['last_taper_split'] == 2 and relerr(ctx.get_vis(), ref2, pb) <= TOL[_abi.PRISIM_FP32]
+    monkeypatch.setenv('PRISIM_HIP_FLUSH_SRC', '97')
     ctx.set_tuning(64, 0, 1)
     # sizes that vary from source to source: no runs, the unsplit kernel
     fw = rng.uniform(0.05, 0.4, n_pt + n_df)
@@ -381,6 +390,17 @@ def test_fp64_taper_wave_items_on_small_arrays(ctx, monkeypatch):
             ctx.compute(precision=_abi.PRISIM_FP64)
             assert relerr(ctx.get_vis(), vw, pb) <= 1e-13, (nbl, ct, nsplit)
             monkeypatch.delenv('PRISIM_HIP_WAVE_ITEMS')
+    # a mixed sky (point sources, then two pixel sizes) on 171 baselines with split sources: run by run, every run into its own set of
+    # partial cubes -- the taper runs as wave items, the point-source run through the fp64 kernel without the taper (block items)
+    fw_runs = NP.concatenate((NP.zeros(90), NP.full(143, 3.66), NP.full(100, 1.83)))
+    bl = rng.uniform(-60.0, 60.0, size=(171, 3)); bl[:, 2] *= 0.02
+    ref = CO.skyvis(bl, ch, dc, pb, pc, fwhm_deg=fw_runs)
+    ctx.set_array(bl, ch)
+    ctx.set_sky(dc, pb, pc, fwhm_deg=fw_runs)
+    for ct, nsplit in ((16, 4), (32, 3), (0, 0)):
+        ctx.set_tuning(ct, 0, nsplit)
+        ctx.compute(precision=_abi.PRISIM_FP64)
+        assert relerr(ctx.get_vis(), ref, pb) <= TOL[_abi.PRISIM_FP64], (ct, nsplit, ctx.timing())
     # culling: large pixels by decreasing altitude under 1.5 km baselines, sources split
     ang, rad = rng.uniform(0, 2 * NP.pi, 200), rng.uniform(1200.0, 1500.0, 200)       # every baseline long: the one group sheds sources
     bl = NP.stack((rad * NP.cos(ang), rad * NP.sin(ang), rng.normal(0.0, 0.5, size=200)), axis=1)

@@ -2,7 +2,8 @@
 length, so CONTIGUOUS shards (the reference's chunks, scripts/run_prisim.py:1775-1791) give the last rank all the long baselines -- the
 groups that cannot use the lifting rotation (and, with the taper, the re-anchored bodies) -- and the job runs at the slowest rank's pace.
 Shards dealt round-robin in groups of 256 baselines give every rank its share.  Prints the step time (hipEvents, whole compute()) of
-every rank's shard for both schemes."""
+every rank's shard for both schemes.
+    python tools/shard_balance.py N [taper | cfg5]"""
 import json
 import os
 import sys
@@ -14,8 +15,8 @@ import bench
 from prisim_amd import _abi, workloads as W
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-taper = len(sys.argv) > 2 and sys.argv[2] == 'taper'
-cfg = W.config3(with_diffuse=taper)
+taper = len(sys.argv) > 2 and sys.argv[2] in ('taper', 'cfg5')
+cfg = W.config5(n_acc=1) if (len(sys.argv) > 2 and sys.argv[2] == 'cfg5') else W.config3(with_diffuse=taper)      # cfg5: one run of one pixel size
 bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
 zen = NP.array([0.0, 0.0, 1.0])
 ctx = _abi.Context(0)
