@@ -3,7 +3,7 @@ length, so CONTIGUOUS shards (the reference's chunks, scripts/run_prisim.py:1775
 groups that cannot use the lifting rotation (and, with the taper, the re-anchored bodies) -- and the job runs at the slowest rank's pace.
 Shards dealt round-robin in groups of 256 baselines give every rank its share.  Prints the step time (hipEvents, whole compute()) of
 every rank's shard for both schemes.
-    python tools/shard_balance.py N [taper | cfg5]"""
+    python tools/shard_balance.py N [taper | cfg5 | plain] [fp64]"""
 import json
 import os
 import sys
@@ -19,8 +19,9 @@ taper = len(sys.argv) > 2 and sys.argv[2] in ('taper', 'cfg5')
 cfg = W.config5(n_acc=1) if (len(sys.argv) > 2 and sys.argv[2] == 'cfg5') else W.config3(with_diffuse=taper)      # cfg5: one run of one pixel size
 bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
 zen = NP.array([0.0, 0.0, 1.0])
+PREC = _abi.PRISIM_FP64 if 'fp64' in sys.argv[2:] else _abi.PRISIM_FP32
 ctx = _abi.Context(0)
-out = {'n': N, 'workload': cfg['name'], 'taper': taper}
+out = {'n': N, 'workload': cfg['name'], 'taper': taper, 'precision': 'fp64' if PREC == _abi.PRISIM_FP64 else 'fp32'}
 for scheme in ('contiguous', 'interleaved'):
     times = []
     for r in range(N):
@@ -30,7 +31,7 @@ for scheme in ('contiguous', 'interleaved'):
                              fwhm_deg=(sky['fwhm_deg'] if taper else None))
         best = 1e9
         for rep in range(4):
-            ctx.compute(precision=_abi.PRISIM_FP32)
+            ctx.compute(precision=PREC)
             ctx.sync()
             best = min(best, ctx.timing()['last_compute_ms'])
         times.append(best)
