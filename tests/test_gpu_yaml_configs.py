@@ -41,10 +41,42 @@ def _spot(nbl, n=4):
     return NP.unique(NP.linspace(0, nbl - 1, n).astype(int))
 
 
+def _fake_rccl(tmp_path):
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    fake = tmp_path / 'libfake_rccl.so'
+    res = subprocess.run([hipcc, '-O2', '-std=c++17', '-fPIC', '-shared', '-x', 'hip', '--offload-arch=gfx950', '-I/opt/rocm/include',
+                          os.path.join(ROOT, 'tests', 'fake_rccl', 'fake_rccl.cpp'), '-o', str(fake)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return str(fake)
+
+
+def _run_two_ranks(path, fake):
+    env = dict(os.environ, PRISIM_RCCL_LIB=fake, PRISIM_DEVICE='0', OMP_NUM_THREADS='2')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PRISIM_RDZV_FILE', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_prisim.py'), '-n', '2', '-i', path], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 def test_config3_yaml(tmp_path):
     """examples/config3.yaml: HERA-350 x 1024 channels x (1e4 point sources + nside-128 diffuse), one LST, fp32."""
     path, npz, p = _yaml(tmp_path, 'config3', {})
     assert driver.main(['-i', path]) == 0
+    _check_config3(npz)
+
+
+def test_config3_yaml_two_ranks_on_one_gpu(tmp_path):
+    """The same YAML as `run_prisim.py -n 2`: every rank's half of the baselines needs its sources split, and a sky of two runs (point
+    sources + diffuse map) is then summed run by run into one set of partial cubes per run (capi.cpp run_pass) -- the product path of
+    profiles/r04_shard_balance.json's taper rows.  Both ranks on the one GPU of the test box, only librccl replaced."""
+    fake = _fake_rccl(tmp_path)
+    path, npz, p = _yaml(tmp_path, 'config3', {'dirstruct': {'simid': 'cfg3_2ranks'}})
+    _run_two_ranks(path, fake)
+    _check_config3(npz)
+
+
+def _check_config3(npz):
     out = NP.load(npz)
     cfg = W.config3(with_diffuse=True)
     bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
@@ -114,20 +146,11 @@ def test_config4_yaml_all_32_accumulations(tmp_path):
 def test_config4_yaml_two_ranks_on_one_gpu(tmp_path):
     """The same YAML as `run_prisim.py -n 2` (baselines sharded, communicator + self-test, gather to rank 0, pp.gather: root), both ranks
     on the one GPU of the test box with only librccl replaced."""
-    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    fake = tmp_path / 'libfake_rccl.so'
-    res = subprocess.run([hipcc, '-O2', '-std=c++17', '-fPIC', '-shared', '-x', 'hip', '--offload-arch=gfx950', '-I/opt/rocm/include',
-                          os.path.join(ROOT, 'tests', 'fake_rccl', 'fake_rccl.cpp'), '-o', str(fake)], capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
+    fake = _fake_rccl(tmp_path)
     beam = _config4_inputs(tmp_path)
     path, npz, p = _yaml(tmp_path, 'config4', {'obsparm': {'n_acc': 2}, 'beam': {'file': beam}, 'dirstruct': {'simid': 'cfg4_2ranks'}})
     assert p['pp']['gather'] == 'root'
-    env = dict(os.environ, PRISIM_RCCL_LIB=str(fake), PRISIM_DEVICE='0', OMP_NUM_THREADS='2')
-    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PRISIM_RDZV_FILE', 'MASTER_PORT'):
-        env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_prisim.py'), '-n', '2', '-i', path], env=env, cwd=ROOT,
-                       capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stderr[-3000:]
+    _run_two_ranks(path, fake)
     _check_config4(npz, 2)
 
 
