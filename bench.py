@@ -34,6 +34,8 @@ Rank 0 prints ONE JSON line.  Beside the contract's keys it carries (N = 1 only,
   other_kernels             min / median of 5 timed launches each of the fp64 kernel (headline sky), the fused gradient kernels, and -- on config 3
                             with its nside-128 diffuse half -- the packed fp32 taper kernel and the grouped fp64 taper kernel: the kernels the
                             headline workload itself does not run
+  shard_estimate            rank 0's share of this workload at N = 1, 2, 4, 8 measured on this GPU (queued snapshots, wall clock): the kernel-side
+                            strong-scaling efficiency a multi-GPU run starts from
   config2                   BASELINE config 2 (HERA-19 x 256 ch x nside-16 diffuse, fp64): device time of one snapshot, min / median of 20
 """
 import argparse
@@ -383,6 +385,40 @@ def config2_step(nlaunch=20):
                 'compute_us_min': 1e3 * min(cs), 'compute_us_median': 1e3 * float(NP.median(cs)),
                 'roofline_frac_10flop': terms * FLOPS_PER_TERM / (min(ks) * 1e-3) / 1e12 / PEAK_TFLOPS['f64'],
                 'terms_per_s_whole_compute': terms / (min(cs) * 1e-3)}
+
+
+def shard_estimate(cfg, zen, prec, device, ranks=(1, 2, 4, 8), nqueue=6):
+    """What one rank of an N-GPU run of this workload would spend per snapshot before any communication, measured on THIS GPU: rank 0's
+    share of the baselines (prisim_amd/sharding.py), `nqueue` snapshots queued back to back, wall clock per snapshot (sky-sum + pack +
+    partial-cube reduction), against the N = 1 figure of the same loop divided by N.  The strong-scaling curve of the driver's multi-GPU
+    run cannot be better than this; the all-gather is overlapped on top."""
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    res = {}
+    with _abi.Context(device) as c:
+        for n in ranks:
+            mine = shard_baselines(bl, n, 0)[0]
+            c.set_array(mine, ch, nt_max=1)
+            c.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, cfg['diameter'], zen, zen,
+                               fwhm_deg=(sky['fwhm_deg'] if cfg['taper'] else None))
+            for rep in range(3):                           # clock ramp, first-use costs
+                c.compute(precision=prec)
+            c.sync()
+            best = None
+            for rep in range(3):
+                t0 = time.perf_counter()
+                for k in range(nqueue):
+                    c.compute(precision=prec)
+                c.sync()
+                dt = (time.perf_counter() - t0) / nqueue * 1e3
+                best = dt if best is None else min(best, dt)
+            tm = c.timing()
+            res[str(n)] = {'nbl': int(mine.shape[0]), 'ms_per_snapshot': best, 'nsplit': tm['last_nsplit'], 'chan_tile': tm['last_chan_tile']}
+    t1 = res[str(ranks[0])]['ms_per_snapshot'] * ranks[0]
+    for n in ranks:
+        res[str(n)]['over_ideal'] = res[str(n)]['ms_per_snapshot'] / (t1 / n)
+        res[str(n)]['kernel_side_efficiency'] = (t1 / n) / res[str(n)]['ms_per_snapshot']
+    res['what'] = ('rank 0 of N, measured on one GPU: wall ms per snapshot of %d queued back to back; ideal = the N = 1 figure / N; no communication in it' % nqueue)
+    return res
 
 
 def _smi_sample():
@@ -735,6 +771,10 @@ def main():
                 out['config2'] = config2_step()
             except Exception as exc:
                 out['config2'] = {'error': repr(exc)}
+            try:
+                out['shard_estimate'] = shard_estimate(cfg, zen, prec, device)
+            except Exception as exc:
+                out['shard_estimate'] = {'error': repr(exc)}
             try:
                 out['e2e'] = e2e_observe(cfg, 8, device, memsave=(prec == _abi.PRISIM_FP32))
             except Exception as exc:
