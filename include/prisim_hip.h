@@ -58,7 +58,8 @@ void prisim_hip_destroy(prisim_ctx* ctx);
 /* Message of the last error on ctx (ctx may be NULL: last error of a failed create). */
 const char* prisim_hip_last_error(const prisim_ctx* ctx);
 /* Library version string "prisim_hip <major>.<minor> gfx950"; the minor number changes with every change of a struct or a signature
-   in this header (0.2: prisim_timing carries the delay-stage fields; 0.3: prisim_comm_stats, self-test, gradient gather, asynchronous downloads).  A binding should refuse a library that reports another one. */
+   in this header (0.2: prisim_timing carries the delay-stage fields; 0.3: prisim_comm_stats, self-test, gradient gather, asynchronous downloads;
+   0.4: the device-resident catalogue -- prisim_catalog / prisim_obs / prisim_snapshot and their four entries).  A binding should refuse a library that reports another one. */
 const char* prisim_hip_version(void);
 
 /* ---- array: baselines + channels, resident across snapshots ---------------------------- */
@@ -190,6 +191,74 @@ int prisim_hip_set_sky_external_analytic(prisim_ctx* ctx, const prisim_beam_sky*
 
 /* Read back the device pbflux (float64 [nsrc][nchan]) -- for parity tests of the fused beams. */
 int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out);
+
+/* ---- device-resident catalogue: the sky of a whole run stays in HBM (ABI 0.4) ------------------------------
+ *
+ * The reference re-derives the sky at every snapshot from a sky model that does not change over a run
+ * (scripts/run_prisim.py:2165-2207 loops observe() over n_acc with ONE skymod; interferometry.py:6223-6247
+ * store_prev_skymodel_file exists because that is expensive).  Here the catalogue is uploaded once and every snapshot's
+ *   (RA, Dec) -> HA = LST - RA -> (alt, az)            interferometry.py:6113-6122, 6174-6180   (GEOM.hadec2altaz)
+ *   region of interest                                 :6204-6219  (zenith: alt >= 90 - roi_radius; pointing centre: angle <= roi_radius)
+ *   direction cosines                                  :6263       (GEOM.altaz2dircos)
+ *   obs_catalog_indices (STABLE compaction)            :6377
+ *   flux spectra of the ROI sources, pb * fluxes       :6249-6254
+ * is formed on the device; the host reads back one small record per snapshot (source count, run boundaries). */
+enum { PRISIM_COORDS_RADEC = 0, PRISIM_COORDS_HADEC = 1, PRISIM_COORDS_ALTAZ = 2 };
+
+typedef struct prisim_catalog {
+  int64_t nsrc;
+  int32_t coords;               /* PRISIM_COORDS_*: what `location` holds (InterferometerArray.skycoords, :5862-5865) */
+  int32_t reserved_;
+  const double* location;       /* [nsrc][2] degrees: (RA, Dec) | (HA, Dec) | (alt, az)   (skymodel.location) */
+  const double* flux_ref;       /* [nsrc] flux density at ref_freq_hz, with spindex: S = flux_ref (f / ref_freq)^spindex ... */
+  const double* spindex;        /* [nsrc] */
+  double ref_freq_hz;
+  const double* flux_spectrum;  /* ... or [nsrc][nchan] spectra on the channel grid (SkyModel.generate_spectrum of the whole catalogue, :6249);
+                                   when non-NULL it replaces the power law */
+  const double* fwhm_deg;       /* [nsrc] sqrt(maj * min) of skymodel.src_shape (:6267), or NULL (no source-shape taper) */
+} prisim_catalog;
+
+/* Upload the catalogue (once per run; set_array drops it: the spectra are per channel grid).  Synchronises the stream. */
+int prisim_hip_set_catalog(prisim_ctx* ctx, const prisim_catalog* cat);
+
+/* What the snapshots of a run share (keywords of observe(), :5874-5880) */
+typedef struct prisim_obs {
+  double latitude_deg;          /* self.latitude */
+  double roi_radius_deg;        /* roi_radius (default 90, :6207) */
+  int32_t roi_center;           /* 0: 'zenith' (:6214-6216), 1: 'pointing_center' (:6210-6213, the snapshot's pc_dircos) */
+  int32_t use_external_beam;    /* 1: the table of prisim_hip_set_external_beam; beam_kind, diameter_m, ext are then ignored */
+  int32_t beam_kind;            /* PRISIM_BEAM_* */
+  int32_t reserved_;
+  double diameter_m;
+  const prisim_beam_ext* ext;   /* optional dipole / array factor / ground plane / beamformer; NULL = none */
+} prisim_obs;
+
+typedef struct prisim_snapshot {
+  double lst_deg;               /* local sidereal time of the snapshot (:6113); ignored for HA-Dec and alt-az catalogues */
+  double pc_dircos[3];          /* pointing = phase centre, ENU direction cosines (:6155-6167) */
+  double beam_pc_dircos[3];     /* beam pointing centre (zenith = {0,0,1}) */
+} prisim_snapshot;
+
+/* Make snapshot `snap` of the catalogue the current sky: geometry, compaction, (when long baselines can resolve sources out) the
+ * altitude ordering and the cull table, flux spectra and pb * fluxes -- all on the device.  The geometry runs on a second,
+ * high-priority stream into one of two buffer sets, so that it proceeds beside the previous snapshot's sky-sum; the call waits for
+ * ITS small result record only, never for the compute stream.  *nsrc_roi (may be NULL) = sources inside the region of interest.
+ * Follow with prisim_hip_compute. */
+int prisim_hip_set_sky_from_catalog(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snap, int64_t* nsrc_roi);
+
+/* The region of interest of an arbitrary snapshot, for class state that is read rarely (obs_catalog_indices :6377, geometric_delays
+ * :6287-6291): indices [cap] int64 into the catalogue in catalogue order and dircos [cap][3] (either may be NULL); *nsrc_roi = the
+ * count (fails with PRISIM_EINVAL when cap is smaller).  Runs in its own buffer set and synchronises only the geometry stream. */
+int prisim_hip_catalog_roi(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snap, int64_t* nsrc_roi, int64_t* indices,
+                           double* dircos, int64_t cap);
+
+/* nsnap snapshots in one call: the geometry of all of them first (chunks of snapshots, ONE readback per chunk), then for snapshot t
+ * sky + compute into cube slot slot0 + t, queued back to back without any host synchronisation on the compute stream.  Arrays of at
+ * most 256 baselines in fp64 with the source-shape taper put the sky-sums of the whole chunk into ONE launch of the wave-item kernel
+ * (the work item is (snapshot, baseline wave, channel tile, source split)) and ONE reduction.  Replaces the loop of
+ * interferometry.py:6641-6647 / scripts/run_prisim.py:2165-2207.  nsrc_roi: [nsnap] or NULL. */
+int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int precision,
+                               int want_grad, int64_t slot0, int64_t* nsrc_roi);
 
 /* ---- delay transform (follow-on stage, interferometry.py:8052-8137) ---------------------- */
 

@@ -10,7 +10,7 @@ import numpy as NP
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PRISIM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libprisim_hip.so')      # PRISIM_HIP_LIB: A/B another build of the same ABI
-ABI_VERSION = 'prisim_hip 0.3 gfx950'       # prisim_hip_version(): bumped whenever a struct or a signature of include/prisim_hip.h changes
+ABI_VERSION = 'prisim_hip 0.4 gfx950'       # prisim_hip_version(): bumped whenever a struct or a signature of include/prisim_hip.h changes
 
 PRISIM_OK = 0
 PRISIM_EINVAL, PRISIM_ENODEV, PRISIM_ENOMEM, PRISIM_ESTATE, PRISIM_ELIB, PRISIM_EINTERNAL = -1, -2, -3, -4, -5, -6
@@ -18,6 +18,7 @@ PRISIM_FP64, PRISIM_FP32 = 0, 1
 PRISIM_KERNEL_AUTO, PRISIM_KERNEL_RECURRENCE, PRISIM_KERNEL_DIRECT = 0, 1, 2
 PRISIM_BEAM_DELTA, PRISIM_BEAM_GAUSSIAN, PRISIM_BEAM_AIRY, PRISIM_BEAM_DIPOLE, PRISIM_BEAM_POLY = 0, 1, 2, 3, 4
 PRISIM_DIPOLE_GENERAL, PRISIM_DIPOLE_SHORT, PRISIM_DIPOLE_HALFWAVE = 0, 1, 2
+PRISIM_COORDS = {'radec': 0, 'hadec': 1, 'altaz': 2}
 
 # every symbol include/prisim_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
@@ -32,6 +33,7 @@ EXPORTS = (
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
     'prisim_hip_allgather_grad', 'prisim_hip_comm_selftest', 'prisim_hip_get_comm_stats', 'prisim_hip_set_gather_root',
     'prisim_hip_host_alloc', 'prisim_hip_host_free', 'prisim_hip_get_vis_async', 'prisim_hip_wait_downloads',
+    'prisim_hip_set_catalog', 'prisim_hip_set_sky_from_catalog', 'prisim_hip_catalog_roi', 'prisim_hip_observe_catalog',
 )
 
 
@@ -110,6 +112,20 @@ class PrisimBeamSky(C.Structure):
     _fields_ = [('nsrc', C.c_int64), ('dircos', C.c_void_p), ('flux_ref', C.c_void_p), ('spindex', C.c_void_p),
                 ('flux_spectrum', C.c_void_p), ('ref_freq_hz', C.c_double), ('beam_kind', C.c_int32), ('diameter_m', C.c_double),
                 ('beam_pc_dircos', C.c_void_p), ('pc_dircos', C.c_void_p), ('fwhm_deg', C.c_void_p), ('ext', C.c_void_p)]
+
+
+class PrisimCatalog(C.Structure):
+    _fields_ = [('nsrc', C.c_int64), ('coords', C.c_int32), ('reserved_', C.c_int32), ('location', C.c_void_p), ('flux_ref', C.c_void_p),
+                ('spindex', C.c_void_p), ('ref_freq_hz', C.c_double), ('flux_spectrum', C.c_void_p), ('fwhm_deg', C.c_void_p)]
+
+
+class PrisimObs(C.Structure):
+    _fields_ = [('latitude_deg', C.c_double), ('roi_radius_deg', C.c_double), ('roi_center', C.c_int32), ('use_external_beam', C.c_int32),
+                ('beam_kind', C.c_int32), ('reserved_', C.c_int32), ('diameter_m', C.c_double), ('ext', C.c_void_p)]
+
+
+class PrisimSnapshot(C.Structure):
+    _fields_ = [('lst_deg', C.c_double), ('pc_dircos', C.c_double * 3), ('beam_pc_dircos', C.c_double * 3)]
 
 
 class PrisimTiming(C.Structure):
@@ -195,6 +211,10 @@ def load_library():
     lib.prisim_hip_host_free.argtypes = [vp]
     lib.prisim_hip_get_vis_async.argtypes = [vp, i64, vp, vp, i32]
     lib.prisim_hip_wait_downloads.argtypes = [vp]
+    lib.prisim_hip_set_catalog.argtypes = [vp, C.POINTER(PrisimCatalog)]
+    lib.prisim_hip_set_sky_from_catalog.argtypes = [vp, C.POINTER(PrisimObs), C.POINTER(PrisimSnapshot), C.POINTER(i64)]
+    lib.prisim_hip_catalog_roi.argtypes = [vp, C.POINTER(PrisimObs), C.POINTER(PrisimSnapshot), C.POINTER(i64), vp, vp, i64]
+    lib.prisim_hip_observe_catalog.argtypes = [vp, C.POINTER(PrisimObs), C.POINTER(PrisimSnapshot), i64, i32, i32, i64, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ('prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version'):
@@ -397,6 +417,91 @@ class Context(object):
                             _ptr(pc), _ptr(pc), _ptr(fw), None)
         self._check(self._lib.prisim_hip_set_sky_external_analytic(self._h, C.byref(sky)), 'prisim_hip_set_sky_external_analytic')
         self.nsrc = nsrc
+
+    # ---- device-resident catalogue ----
+    def set_catalog(self, location, coords, flux_ref=None, spindex=None, ref_freq_hz=None, flux_spectrum=None, fwhm_deg=None):
+        """Upload a run's sky model once (prisim_hip_set_catalog): location (nsrc, 2) degrees in `coords` ('radec' | 'hadec' | 'altaz'),
+        the power law flux_ref (f / ref_freq_hz)^spindex or flux_spectrum (nsrc, nchan), source sizes fwhm_deg (or None)."""
+        loc = NP.ascontiguousarray(location, dtype=NP.float64).reshape(-1, 2)
+        nsrc = loc.shape[0]
+        fs = fr = sp = fw = None
+        if flux_spectrum is not None:
+            fs = NP.ascontiguousarray(flux_spectrum, dtype=NP.float64)
+            if fs.size != nsrc * self.nchan:
+                raise ValueError('flux_spectrum must have shape (nsrc, nchan)')
+            ref_freq_hz = 1.0
+        else:
+            fr = NP.ascontiguousarray(flux_ref, dtype=NP.float64).ravel()
+            sp = NP.ascontiguousarray(spindex, dtype=NP.float64).ravel()
+            if fr.size != nsrc or sp.size != nsrc:
+                raise ValueError('flux_ref and spindex must have nsrc elements')
+        if fwhm_deg is not None:
+            fw = NP.ascontiguousarray(fwhm_deg, dtype=NP.float64).ravel()
+            if fw.size != nsrc:
+                raise ValueError('fwhm_deg must have nsrc elements')
+        if coords not in PRISIM_COORDS:
+            raise ValueError('coords must be "radec", "hadec" or "altaz"')
+        cat = PrisimCatalog(nsrc, PRISIM_COORDS[coords], 0, _ptr(loc), _ptr(fr), _ptr(sp), float(ref_freq_hz), _ptr(fs), _ptr(fw))
+        self._check(self._lib.prisim_hip_set_catalog(self._h, C.byref(cat)), 'prisim_hip_set_catalog')
+        self.ncat = nsrc
+
+    @staticmethod
+    def make_obs(latitude_deg, roi_radius_deg=90.0, roi_center='zenith', beam_kind=PRISIM_BEAM_DELTA, diameter_m=1.0, ext=None,
+                 use_external_beam=False):
+        """prisim_obs of a run (keeps the beam extension alive as attribute _keep)."""
+        xs = make_beam_ext(ext)
+        obs = PrisimObs(float(latitude_deg), float(roi_radius_deg), 1 if roi_center == 'pointing_center' else 0, 1 if use_external_beam else 0,
+                        int(beam_kind), 0, float(diameter_m), None if xs is None else C.cast(C.pointer(xs), C.c_void_p))
+        obs._keep = xs
+        return obs
+
+    @staticmethod
+    def _snapshot(lst_deg, pc_dircos, beam_pc_dircos):
+        sn = PrisimSnapshot()
+        sn.lst_deg = float(lst_deg)
+        sn.pc_dircos[0], sn.pc_dircos[1], sn.pc_dircos[2] = float(pc_dircos[0]), float(pc_dircos[1]), float(pc_dircos[2])
+        b = pc_dircos if beam_pc_dircos is None else beam_pc_dircos
+        sn.beam_pc_dircos[0], sn.beam_pc_dircos[1], sn.beam_pc_dircos[2] = float(b[0]), float(b[1]), float(b[2])
+        return sn
+
+    def set_sky_from_catalog(self, obs, lst_deg, pc_dircos, beam_pc_dircos=None):
+        """Snapshot geometry, region of interest, beam x flux of the resident catalogue on the device; returns the ROI source count."""
+        sn = self._snapshot(lst_deg, pc_dircos, beam_pc_dircos)
+        n = C.c_int64()
+        self._check(self._lib.prisim_hip_set_sky_from_catalog(self._h, C.byref(obs), C.byref(sn), C.byref(n)), 'prisim_hip_set_sky_from_catalog')
+        self.nsrc = int(n.value)
+        return self.nsrc
+
+    def catalog_roi(self, obs, lst_deg, pc_dircos, want_indices=True, want_dircos=True):
+        """(indices int64 [n], dircos [n, 3]) of the region of interest of one snapshot, catalogue order (prisim_hip_catalog_roi)."""
+        sn = self._snapshot(lst_deg, pc_dircos, None)
+        n = C.c_int64()
+        self._check(self._lib.prisim_hip_catalog_roi(self._h, C.byref(obs), C.byref(sn), C.byref(n), None, None, 0), 'prisim_hip_catalog_roi')
+        cnt = int(n.value)
+        idx = NP.empty(cnt, dtype=NP.int64) if want_indices else None
+        dc = NP.empty((cnt, 3), dtype=NP.float64) if want_dircos else None
+        if cnt > 0 and (want_indices or want_dircos):
+            self._check(self._lib.prisim_hip_catalog_roi(self._h, C.byref(obs), C.byref(sn), C.byref(n), _ptr(idx), _ptr(dc), cnt),
+                        'prisim_hip_catalog_roi')
+        return idx, dc
+
+    def observe_catalog(self, obs, lst_deg, pc_dircos, beam_pc_dircos=None, precision=PRISIM_FP64, want_grad=False, slot0=0):
+        """K snapshots of the resident catalogue in one call (prisim_hip_observe_catalog): lst_deg (K,), pc_dircos (K, 3) or (3,),
+        beam_pc_dircos likewise (default: pc_dircos).  Results land in cube slots slot0 ... slot0 + K - 1; returns the ROI counts (K,)."""
+        lst = NP.asarray(lst_deg, dtype=NP.float64).ravel()
+        k = lst.size
+        pc = NP.broadcast_to(NP.asarray(pc_dircos, dtype=NP.float64).reshape(-1, 3), (k, 3))
+        bpc = pc if beam_pc_dircos is None else NP.broadcast_to(NP.asarray(beam_pc_dircos, dtype=NP.float64).reshape(-1, 3), (k, 3))
+        snaps = (PrisimSnapshot * k)()
+        for t in range(k):
+            snaps[t].lst_deg = lst[t]
+            snaps[t].pc_dircos[:] = pc[t].tolist()
+            snaps[t].beam_pc_dircos[:] = bpc[t].tolist()
+        counts = NP.zeros(k, dtype=NP.int64)
+        self._check(self._lib.prisim_hip_observe_catalog(self._h, C.byref(obs), snaps, k, int(precision), 1 if want_grad else 0, int(slot0),
+                                                         _ptr(counts)), 'prisim_hip_observe_catalog')
+        self.nsrc = int(counts[-1]) if k else 0
+        return counts
 
     def get_pbflux(self):
         out = NP.empty((self.nsrc, self.nchan), dtype=NP.float64)

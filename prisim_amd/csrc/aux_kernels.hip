@@ -128,7 +128,9 @@ void k_beam_flux(const BeamParams p) {
       gp /= 2.0 * sin(kk * p.gp_height);                                                  // :965-966
       pb *= gp * gp;                                                                      // :439
     }
-    const double flux = p.flux_spec ? p.flux_spec[i] : p.flux_ref[s] * pow(f / p.ref_freq, p.spindex[s]);
+    // (catalogue path: the flux vectors / spectra stay in catalogue order and are read through the compacted index list)
+    const int64_t cs = p.src_index ? (int64_t)p.src_index[s] : s;
+    const double flux = p.flux_spec ? p.flux_spec[cs * p.nchan + k] : p.flux_ref[cs] * pow(f / p.ref_freq, p.spindex[cs]);
     p.pb_out[i] = pb * flux;
   }
 }
@@ -305,16 +307,18 @@ __global__ void k_colmax_final(const double* __restrict__ partial, double* __res
 // flux_ref[s] * (f_c / ref_freq) ** spindex[s] formed here (SkyModel.generate_spectrum of a 'func' sky model)
 __global__ void k_extbeam_finish(const double* __restrict__ work, const double* __restrict__ colmax, const double* __restrict__ fluxes,
                                  const double* __restrict__ flux_ref, const double* __restrict__ spindex, const double* __restrict__ freqs,
-                                 double inv_ref_freq, double* __restrict__ pb_out, int64_t nsrc, int64_t nchan) {
+                                 double inv_ref_freq, double* __restrict__ pb_out, int64_t nsrc, int64_t nchan,
+                                 const int32_t* __restrict__ src_index) {
   const int64_t total = nsrc * nchan;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = i % nchan;
     const double pb = (double)(float)exp10(work[i] - colmax[c]);      // :2101-2102 ; interferometry.py:4466 (float32 storage)
     double fl;
+    const int64_t srow = i / nchan;
+    const int64_t sidx = src_index ? (int64_t)src_index[srow] : srow;        // catalogue path: fluxes stay in catalogue order
     if (fluxes) {
-      fl = fluxes[i];
+      fl = fluxes[sidx * nchan + c];
     } else {
-      const int64_t sidx = i / nchan;
       fl = flux_ref[sidx] * pow(freqs[c] * inv_ref_freq, spindex[sidx]);
     }
     pb_out[i] = pb * fl;                                               // interferometry.py:6254
@@ -336,7 +340,8 @@ hipError_t launch_extbeam_table(const double* beam, const double* interp, double
 
 hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs, const double* fluxes, const double* flux_ref,
                               const double* spindex, const double* freqs, double ref_freq, double* work,
-                              double* colmax_scratch, double* pb_out, int64_t nsrc, int64_t nchan, hipStream_t stream) {
+                              double* colmax_scratch, double* pb_out, int64_t nsrc, int64_t nchan, hipStream_t stream,
+                              const int32_t* src_index) {
   if (nsrc == 0) return hipSuccess;
   const unsigned gs = (unsigned)(nsrc < 16384 ? nsrc : 16384);
   hipLaunchKernelGGL(k_extbeam_gather, dim3(gs), dim3(256), 0, stream, table, nside, dirs, work, nsrc, nchan);
@@ -346,7 +351,7 @@ hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs
   hipLaunchKernelGGL(k_colmax_partial, dim3(nblk), dim3(256), 0, stream, work, partial, nsrc, nchan);
   hipLaunchKernelGGL(k_colmax_final, dim3(grid_for_(nchan)), dim3(256), 0, stream, partial, colmax, nblk, nchan);
   hipLaunchKernelGGL(k_extbeam_finish, dim3(grid_for_(nsrc * nchan)), dim3(256), 0, stream, work, colmax, fluxes, flux_ref, spindex, freqs,
-                     1.0 / ref_freq, pb_out, nsrc, nchan);
+                     1.0 / ref_freq, pb_out, nsrc, nchan, src_index);
   return hipGetLastError();
 }
 

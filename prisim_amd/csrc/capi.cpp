@@ -3,65 +3,13 @@
 // Owns the per-GPU context: HIP stream, resident array (baselines, channels), per-snapshot sky,
 // the device visibility cube, and lazily dlopen()ed rocFFT / RCCL handles.  No C++ exception
 // crosses the ABI; every export returns 0 or a negative PRISIM_E* code.
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
-#include <rccl/rccl.h>
-#include <rocfft/rocfft.h>
+#include "ctx_internal.h"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../../include/prisim_hip.h"
-#include "skyvis_kernels.h"
-
-using namespace prisim;
-
-namespace {
-
-constexpr double kC = 299792458.0;   // scipy.constants.c (baseline_delay_horizon.py:236)
+namespace pint {
 
 std::string g_create_error;
-
-struct RcclApi {
-  void* handle = nullptr;
-  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-  decltype(&ncclCommInitRank) CommInitRank = nullptr;
-  decltype(&ncclAllGather) AllGather = nullptr;
-  decltype(&ncclSend) Send = nullptr;                   // optional (gather to one root): absent in very old RCCLs
-  decltype(&ncclRecv) Recv = nullptr;
-  decltype(&ncclGroupStart) GroupStart = nullptr;
-  decltype(&ncclGroupEnd) GroupEnd = nullptr;
-  decltype(&ncclCommDestroy) CommDestroy = nullptr;
-  decltype(&ncclGetErrorString) GetErrorString = nullptr;
-};
 RcclApi g_rccl;
-
-struct RocfftApi {
-  void* handle = nullptr;
-  bool setup_done = false;
-  decltype(&rocfft_setup) setup = nullptr;
-  decltype(&rocfft_plan_create) plan_create = nullptr;
-  decltype(&rocfft_plan_destroy) plan_destroy = nullptr;
-  decltype(&rocfft_plan_get_work_buffer_size) plan_get_work_buffer_size = nullptr;
-  decltype(&rocfft_execution_info_create) execution_info_create = nullptr;
-  decltype(&rocfft_execution_info_destroy) execution_info_destroy = nullptr;
-  decltype(&rocfft_execution_info_set_stream) execution_info_set_stream = nullptr;
-  decltype(&rocfft_execution_info_set_work_buffer) execution_info_set_work_buffer = nullptr;
-  decltype(&rocfft_execute) execute = nullptr;
-};
 RocfftApi g_rocfft;
-
-template <typename F>
-bool load_sym(void* h, const char* name, F& out) {
-  out = reinterpret_cast<F>(dlsym(h, name));
-  return out != nullptr;
-}
 
 bool load_rccl(std::string& err) {
   if (g_rccl.handle) return true;
@@ -104,325 +52,6 @@ bool load_rocfft(std::string& err) {
   a.handle = h;
   return true;
 }
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-};
-
-}  // namespace
-
-struct prisim_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::string err;
-  char devname[64] = {0};
-  int cu_count = 0, clock_khz = 0;
-
-  // array
-  bool array_set = false;
-  int64_t nbl = 0, nchan = 0, nt_max = 0;
-  DevBuf blx, bly, blz, freqs, fsq, fsq_pairs, cube, grad, lift_flags;
-  std::vector<double> grp_maxlen;     // max |b| per group of kBlockThreads baselines (lifting-rotation guarantee)
-  std::vector<double> grp_maxh, grp_maxz;   // max horizontal length / max |b_z| per group (bound of the split taper's parabola)
-  std::vector<double> grp_minh;             // min horizontal length per group (taper culling)
-  // Taper culling: cull_first[prec][run][group] = first source of the run that group still has to sum (device, int32); the sources before
-  // it contribute < exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux| to every baseline of the group.  cull_frac[prec]: culled share of
-  // the snapshot's terms; cull_any[prec]: anything culled at all.
-  DevBuf cull_first;
-  std::vector<double> cull_rho, cull_an;    // scratch of the cull-table walk: sin / |cos| of the zenith angle of a run's leading sources
-  DevBuf moments_part;                    // per-chunk partial sums of k_taper_moments (reduced in fixed order)
-  DevBuf step_tab;                        // round-4 experiment: step-phasor table of the packed fp32 kernel (PRISIM_HIP_STEP_TABLE=1)
-  bool cull_any[2] = {false, false};
-  double cull_frac[2] = {0.0, 0.0};
-  int cull_nruns = 0;
-  // runs of consecutive sources with one source size kappa (HEALPix skies: one run; point sources + diffuse: two): the packed fp32
-  // taper kernel walks such skies run by run in its split form.  Empty: sizes vary from source to source (or no taper).
-  struct KappaRun { int64_t lo, hi; double kappa; };
-  std::vector<KappaRun> kappa_runs;
-  DevBuf split_flags, moments, grp_hz, split_count;      // grp_hz: [2][groups] (max horizontal length, max |b_z|) on the device
-  int32_t* h_split_count = nullptr;                      // pinned: uncorrected-group counts of the last split launch, per run (read after a sync)
-  int split_count_runs = 0;
-  double dmax = 2.0;                  // max_s |s - s_pc| of the current sky
-  std::vector<double> h_freqs;
-  bool uniform = false;
-  double f0 = 0.0, df = 0.0;
-  int64_t nchan_pad = 0;
-
-  // sky
-  bool sky_set = false;
-  int64_t nsrc = 0;
-  bool taper = false;
-  double pc[3] = {0, 0, 1};
-  DevBuf dirs, dirs_prep, dirs_c32, pb, packed, partial, scratch;
-  // per-snapshot sky inputs (flux_ref / spindex or a flux table, beamformer elements, validity flag): owned by the context so that
-  // a set_sky_* call allocates nothing after the first snapshot
-  DevBuf sky_flux, sky_sp, sky_bf, sky_flag;
-  // pinned host staging for the small per-snapshot uploads (directions, flux_ref, spindex ...): the caller's arrays are copied here
-  // and sent with hipMemcpyAsync, so set_sky_* returns without a stream synchronisation; ev_stage marks the last upload that
-  // reads the area
-  void* h_stage = nullptr;
-  size_t h_stage_bytes = 0, h_stage_used = 0;
-  hipEvent_t ev_stage = nullptr;
-  bool stage_pending = false;
-  bool stage_open = false;        // copies of the current group have been queued and stage_end() has not run yet
-  // external beam
-  DevBuf ext_table, ext_work, ext_colmax;
-  int ext_nside = 0;
-
-  // events / timing
-  // hipEvent timing of compute(): a ring of event quadruples so that back-to-back compute() calls queue on the stream without
-  // a host synchronisation; completed entries are harvested in order (lazily, or at sync / get_timing)
-  static constexpr int kTimingRing = 16;
-  hipEvent_t ev_c0[kTimingRing] = {}, ev_c1[kTimingRing] = {}, ev_k0[kTimingRing] = {}, ev_k1[kTimingRing] = {};
-  int ring_head = 0;            // next entry to record
-  int ring_pending = 0;         // recorded, not yet harvested (oldest = head - pending)
-  // lifting flags of the last compute (host copy stays alive for the asynchronous upload) and what they were computed for
-  std::vector<int32_t> lift_host;
-  double lift_key_k = -1.0;
-  int lift_key_f32 = -1;
-  prisim_timing timing{};
-
-  // tuning overrides
-  int tune_ct = 0, tune_chunk = 0, tune_nsplit = 0;
-
-  // comm
-  ncclComm_t comm = nullptr;
-  hipStream_t comm_stream = nullptr;     // all-gathers overlapped with the next snapshot's compute
-  hipEvent_t ev_slot_done = nullptr;
-  bool comm_pending = false;
-  int nranks = 1, rank = 0;
-  int gather_root = -1;                  // -1: every rank receives the gathered cube (all-gather); r: only rank r does (ncclSend / ncclRecv)
-  DevBuf gathered, sendbuf;
-  bool gathered_c64 = false;
-  // gather timing: a ring of (compute-stream marker, gather start, gather end) events per overlapped gather, harvested in order
-  static constexpr int kCommRing = 32;
-  hipEvent_t ev_gc[kCommRing] = {}, ev_g0[kCommRing] = {}, ev_g1[kCommRing] = {};
-  int cring_head = 0, cring_pending = 0;
-  prisim_comm_stats cstats{};
-  // asynchronous downloads (prisim_hip_get_vis_async): copy stream behind an event on the compute stream
-  hipStream_t copy_stream = nullptr;
-  hipEvent_t ev_copy_ready = nullptr;
-  bool copy_pending = false;
-  DevBuf dl_stage;                       // complex64 staging of one slot (+ its three gradient slots)
-
-  // fft
-  rocfft_plan fft_plan = nullptr;
-  rocfft_execution_info fft_info = nullptr;
-  size_t fft_len = 0, fft_batch = 0;
-  DevBuf fft_work, fft_buf, dt_out, dt_pow, dt_wts;
-  // device-resident delay spectra of all snapshots (prisim_hip_delay_transform_device): [nt][nbl][nout] complex128 / float64
-  DevBuf dt_lag_all, dt_pow_all, dt_tw;
-  int64_t dt_tw_n = 0;              // channel count the twiddle table was built for
-  int64_t dt_nt = 0, dt_nout = 0;   // shape of the resident spectra
-  bool dt_have_lag = false, dt_have_pow = false;
-  hipEvent_t ev_d0 = nullptr, ev_d1 = nullptr;
-  int64_t gathered_row = 0;         // row length of the gathered cube (nchan for visibilities, nout for delay spectra)
-};
-
-namespace {
-
-int fail(prisim_ctx* ctx, int code, const std::string& msg) {
-  try {
-    if (ctx) ctx->err = msg; else g_create_error = msg;
-  } catch (...) {      // the message itself could not be stored: the code still says what happened
-  }
-  return code;
-}
-
-// Every extern "C" entry runs its body through this: no C++ exception crosses the ABI; a failed host allocation
-// becomes PRISIM_ENOMEM, anything else PRISIM_EINTERNAL with the exception's text.
-template <typename F>
-int guarded(prisim_ctx* ctx, F&& body) noexcept {
-  try {
-    return body();
-  } catch (const std::bad_alloc&) {
-    return fail(ctx, PRISIM_ENOMEM, "out of host memory");
-  } catch (const std::exception& e) {
-    const char* w = e.what();
-    try { return fail(ctx, PRISIM_EINTERNAL, std::string("C++ exception: ") + (w ? w : "?")); } catch (...) { return PRISIM_EINTERNAL; }
-  } catch (...) {
-    return fail(ctx, PRISIM_EINTERNAL, "unknown C++ exception");
-  }
-}
-
-#define HIPCHK(ctx, call)                                                                      \
-  do {                                                                                         \
-    hipError_t e_ = (call);                                                                    \
-    if (e_ != hipSuccess) {                                                                    \
-      return fail(ctx, e_ == hipErrorOutOfMemory ? PRISIM_ENOMEM : PRISIM_ENODEV,              \
-                  std::string(#call) + ": " + hipGetErrorString(e_));                         \
-    }                                                                                          \
-  } while (0)
-
-int ensure(prisim_ctx* ctx, DevBuf& b, size_t bytes) {
-  if (bytes == 0) bytes = 16;
-  if (b.bytes >= bytes && b.p) return PRISIM_OK;
-  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
-  hipError_t e = hipMalloc(&b.p, bytes);
-  if (e != hipSuccess) {
-    b.p = nullptr;
-    return fail(ctx, PRISIM_ENOMEM, std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e));
-  }
-  b.bytes = bytes;
-  return PRISIM_OK;
-}
-
-void release(DevBuf& b) {
-  if (b.p) (void)hipFree(b.p);
-  b.p = nullptr;
-  b.bytes = 0;
-}
-
-int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
-
-// Uploads above this size go straight from the caller's (pageable) memory and are waited for; smaller ones are staged.
-constexpr size_t kStageMaxBytes = (size_t)64 << 20;
-
-// Start a group of staged uploads needing `bytes` of pinned memory in total: waits until the previous group has left the area.
-int stage_begin(prisim_ctx* ctx, size_t bytes) {
-  if (ctx->stage_pending) {
-    if (hipEventSynchronize(ctx->ev_stage) != hipSuccess) return fail(ctx, PRISIM_ENODEV, "hipEventSynchronize(staging) failed");
-    ctx->stage_pending = false;
-  }
-  if (ctx->stage_open) {
-    // the previous group was abandoned on an error path after some of its copies had been queued: let them leave the area first
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, PRISIM_ENODEV, "hipStreamSynchronize(staging) failed");
-    ctx->stage_open = false;
-  }
-  if (!ctx->ev_stage && hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming) != hipSuccess)
-    return fail(ctx, PRISIM_ENODEV, "hipEventCreate(staging) failed");
-  bytes += 4096;
-  if (bytes > ctx->h_stage_bytes) {
-    if (ctx->h_stage) { (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
-    const size_t want = std::max(bytes, (size_t)1 << 20);
-    if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) != hipSuccess) {
-      ctx->h_stage = nullptr;
-      return fail(ctx, PRISIM_ENOMEM, "hipHostMalloc(" + std::to_string(want) + " B) for the upload staging area failed");
-    }
-    ctx->h_stage_bytes = want;
-  }
-  ctx->h_stage_used = 0;
-  return PRISIM_OK;
-}
-
-// Reserve `bytes` of the staging area (256-byte aligned); the caller fills it and then calls stage_send.
-void* stage_alloc(prisim_ctx* ctx, size_t bytes) {
-  const size_t off = (ctx->h_stage_used + 255) & ~(size_t)255;
-  if (off + bytes > ctx->h_stage_bytes) return nullptr;
-  ctx->h_stage_used = off + bytes;
-  return (char*)ctx->h_stage + off;
-}
-
-hipError_t stage_send(prisim_ctx* ctx, void* dst, const void* staged, size_t bytes) {
-  ctx->stage_open = true;
-  return hipMemcpyAsync(dst, staged, bytes, hipMemcpyHostToDevice, ctx->stream);
-}
-
-// Copy a caller array into the staging area and send it.
-hipError_t stage_upload(prisim_ctx* ctx, void* dst, const void* src, size_t bytes) {
-  void* h = stage_alloc(ctx, bytes);
-  if (!h) return hipErrorOutOfMemory;
-  memcpy(h, src, bytes);
-  return stage_send(ctx, dst, h, bytes);
-}
-
-void stage_end(prisim_ctx* ctx) {
-  if (hipEventRecord(ctx->ev_stage, ctx->stream) == hipSuccess) {
-    ctx->stage_pending = true;
-    ctx->stage_open = false;         // otherwise stays set: the next group then waits for the whole stream
-  }
-}
-
-// Collect the hipEvent timings of finished compute() calls, oldest first.  max_wait: how many of the pending entries may be
-// waited for (hipEventSynchronize); the rest are taken only if already complete.  -1: wait for all of them.
-void harvest_timing(prisim_ctx* ctx, int max_wait = -1) {
-  while (ctx->ring_pending > 0) {
-    const int i = (ctx->ring_head - ctx->ring_pending + 2 * prisim_ctx::kTimingRing) % prisim_ctx::kTimingRing;
-    if (max_wait != 0) {
-      if (hipEventSynchronize(ctx->ev_c1[i]) != hipSuccess) { ctx->ring_pending = 0; return; }
-      if (max_wait > 0) --max_wait;
-    } else if (hipEventQuery(ctx->ev_c1[i]) != hipSuccess) {
-      return;
-    }
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev_c0[i], ctx->ev_c1[i]) == hipSuccess) ctx->timing.last_compute_ms = ms;
-    if (hipEventElapsedTime(&ms, ctx->ev_k0[i], ctx->ev_k1[i]) == hipSuccess) {
-      ctx->timing.last_kernel_ms = ms;
-      ctx->timing.sum_kernel_ms += ms;
-      ctx->timing.n_kernel += 1;
-    }
-    ctx->ring_pending -= 1;
-  }
-}
-
-// Collect finished gather timings (oldest first).  wait_all: hipEventSynchronize every pending entry; otherwise only take what is complete.
-void harvest_comm(prisim_ctx* ctx, bool wait_all) {
-  while (ctx->cring_pending > 0) {
-    const int i = (ctx->cring_head - ctx->cring_pending + 2 * prisim_ctx::kCommRing) % prisim_ctx::kCommRing;
-    if (wait_all) {
-      if (hipEventSynchronize(ctx->ev_g1[i]) != hipSuccess) { ctx->cring_pending = 0; return; }
-    } else if (hipEventQuery(ctx->ev_g1[i]) != hipSuccess) {
-      return;
-    }
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev_g0[i], ctx->ev_g1[i]) == hipSuccess) {
-      ctx->cstats.last_gather_ms = ms;
-      ctx->cstats.sum_gather_ms += ms;
-      if (ms > ctx->cstats.max_gather_ms) ctx->cstats.max_gather_ms = ms;
-      ctx->cstats.n_gathers += 1;
-    }
-    // what the overlap did not hide of THIS gather: its end against the compute-stream marker recorded when it was enqueued
-    // (= the end of the snapshot's own sky-sum); only the last harvested entry is kept -- the gathers before it ran under later compute
-    if (hipEventElapsedTime(&ms, ctx->ev_gc[i], ctx->ev_g1[i]) == hipSuccess) ctx->cstats.last_gather_after_compute_ms = ms;
-    ctx->cring_pending -= 1;
-  }
-}
-
-// The communication stream gets the HIGHEST priority the device offers: its RCCL kernels are few blocks that must be scheduled
-// beside a sky-sum grid occupying every CU; with equal priority they would only start as sky-sum blocks drain.
-int ensure_comm_stream(prisim_ctx* ctx) {
-  if (ctx->comm_stream) return PRISIM_OK;
-  int least = 0, greatest = 0;
-  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
-  if (hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
-    (void)hipGetLastError();
-    ctx->comm_stream = nullptr;
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
-    greatest = 0; least = 0;
-  }
-  ctx->cstats.stream_priority = greatest;
-  ctx->cstats.stream_priority_lowest = least;
-  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_slot_done, hipEventDisableTiming));
-  for (int i = 0; i < prisim_ctx::kCommRing; ++i) {
-    HIPCHK(ctx, hipEventCreate(&ctx->ev_gc[i]));
-    HIPCHK(ctx, hipEventCreate(&ctx->ev_g0[i]));
-    HIPCHK(ctx, hipEventCreate(&ctx->ev_g1[i]));
-  }
-  return PRISIM_OK;
-}
-
-int ensure_copy_stream(prisim_ctx* ctx) {
-  if (ctx->copy_stream) return PRISIM_OK;
-  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copy_ready, hipEventDisableTiming));
-  return PRISIM_OK;
-}
-
-constexpr int kMaxRunSets = 8;       // runs of one source size a split sky may have and still be summed run by run (partial-cube sets)
-
-struct Plan {
-  int kernel;      // PRISIM_KERNEL_*
-  bool f32;
-  int ct;
-  int chunk;
-  int nsplit;
-  int64_t src_per_split;
-  int64_t nsrc_pad;
-  int ntiles;
-  int nbgroups;
-  bool pk;         // packed-fp32 kernel (k_skyvis_rec_f32pk) with interleaved pbflux pairs
-};
 
 Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   Plan pl{};
@@ -555,11 +184,12 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
   return pl;
 }
 
-}  // namespace
+}  // namespace pint
+
 
 extern "C" {
 
-const char* prisim_hip_version(void) { return "prisim_hip 0.3 gfx950"; }     // 0.3: comm stats / self-test / gradient gather, asynchronous downloads
+const char* prisim_hip_version(void) { return "prisim_hip 0.4 gfx950"; }     // 0.4: device-resident catalogue
 
 const char* prisim_hip_last_error(const prisim_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -603,6 +233,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  catalog_destroy(ctx);
   if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
@@ -646,6 +277,9 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   ctx->array_set = false;
   ctx->sky_set = false;
   ctx->ext_nside = 0;   // the external-beam table is per channel grid
+  if (ctx->cat.gstream) HIPCHK(ctx, hipStreamSynchronize(ctx->cat.gstream));
+  ctx->cat.loaded = false;   // ... and so are the catalogue's spectra
+  ctx->cat.cur = -1;
   std::vector<double> x(nbl), y(nbl), z(nbl);
   for (int64_t b = 0; b < nbl; ++b) {
     x[b] = bl_enu[3 * b]; y[b] = bl_enu[3 * b + 1]; z[b] = bl_enu[3 * b + 2];
@@ -684,10 +318,10 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   }
   {
     const size_t ng = ctx->grp_maxh.size();
-    std::vector<double> hz(2 * ng);
-    for (size_t g = 0; g < ng; ++g) { hz[g] = ctx->grp_maxh[g]; hz[ng + g] = ctx->grp_maxz[g]; }
-    if ((rc = ensure(ctx, ctx->grp_hz, 2 * ng * sizeof(double)))) return rc;
-    HIPCHK(ctx, hipMemcpy(ctx->grp_hz.p, hz.data(), 2 * ng * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> hz(4 * ng);
+    for (size_t g = 0; g < ng; ++g) { hz[g] = ctx->grp_maxh[g]; hz[ng + g] = ctx->grp_maxz[g]; hz[2 * ng + g] = ctx->grp_maxlen[g]; hz[3 * ng + g] = ctx->grp_minh[g]; }
+    if ((rc = ensure(ctx, ctx->grp_hz, 4 * ng * sizeof(double)))) return rc;
+    HIPCHK(ctx, hipMemcpy(ctx->grp_hz.p, hz.data(), 4 * ng * sizeof(double), hipMemcpyHostToDevice));
   }
   ctx->nbl = nbl; ctx->nchan = nchan; ctx->nt_max = nt_max;
   // uniform channel grid?  f_k = f0 + k*df to within 1e-7 Hz (phase error <= 1e-13 cycles at 1 us delay)
@@ -710,7 +344,9 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
 
 // Directions + source-shape constants of one snapshot -> ctx->dirs, through the pinned staging area (no synchronisation).
 // `extra_stage_bytes`: staging the caller will use for its own small uploads in the same group (it calls stage_end()).
-static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, const double* pc_dircos,
+}  // extern "C"
+namespace pint {
+int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, const double* pc_dircos,
                          const double* fwhm_deg, size_t extra_stage_bytes) {
   if (nsrc < 0) return fail(ctx, PRISIM_EINVAL, "nsrc must be non-negative");
   if (nsrc > (int64_t)0x7fff0000) return fail(ctx, PRISIM_EINVAL, "nsrc must be below 2^31 (the kernels index sources with 32 bits)");
@@ -754,13 +390,16 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
     for (int64_t s = 1; s <= nsrc; ++s) {
       if (s == nsrc || d4[4 * s + 3] != d4[4 * lo + 3]) {
         if (ctx->kappa_runs.size() == kMaxRuns) { ctx->kappa_runs.clear(); break; }     // sizes vary source by source: no runs
-        ctx->kappa_runs.push_back({lo, s, d4[4 * lo + 3]});
+        ctx->kappa_runs.push_back({lo, s, d4[4 * lo + 3], (int)ctx->kappa_runs.size()});
         lo = s;
       }
     }
   }
   if ((rc = ensure(ctx, ctx->dirs, d4_bytes))) return rc;
   HIPCHK(ctx, stage_send(ctx, ctx->dirs.p, d4, d4_bytes));
+  ctx->dirs_p = static_cast<const double*>(ctx->dirs.p);       // an uploaded sky: no catalogue indirection
+  ctx->src_index = nullptr;
+  ctx->cat.cur = -1;
   // Taper culling.  w = exp(-kappa (|b|^2 - (b.s)^2) f^2/c^2), and for a baseline of horizontal length h and height z and a source at
   // (rho, n) = (sin, cos) of the zenith angle, (b.s)^2 <= (h rho + |z| |n|)^2, i.e. |b|^2 - (b.s)^2 >= (h |n| - |z| rho)^2 when
   // h |n| >= |z| rho (the identity h^2 + z^2 - (h rho + |z||n|)^2 = (h|n| - |z| rho)^2).  So for every baseline of a group (smallest
@@ -845,7 +484,7 @@ static int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, co
 
 // Upload a caller array of `bytes`: staged (asynchronous) when small, otherwise straight from the caller's memory followed by
 // a stream synchronisation (the caller may reuse the array as soon as the call returns).
-static int upload_any(prisim_ctx* ctx, void* dst, const void* src, size_t bytes, bool* synced) {
+int upload_any(prisim_ctx* ctx, void* dst, const void* src, size_t bytes, bool* synced) {
   if (bytes <= kStageMaxBytes && ctx->h_stage_used + bytes + 256 <= ctx->h_stage_bytes) {
     HIPCHK(ctx, stage_upload(ctx, dst, src, bytes));
     return PRISIM_OK;
@@ -855,6 +494,8 @@ static int upload_any(prisim_ctx* ctx, void* dst, const void* src, size_t bytes,
   if (synced) *synced = true;
   return PRISIM_OK;
 }
+}  // namespace pint
+extern "C" {
 
 int prisim_hip_set_sky(prisim_ctx* ctx, const prisim_sky* sky) {
   return guarded(ctx, [&]() -> int {
@@ -891,19 +532,16 @@ int prisim_hip_set_sky(prisim_ctx* ctx, const prisim_sky* sky) {
   });
 }
 
-int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
-  return guarded(ctx, [&]() -> int {
-  if (!ctx) return PRISIM_EINVAL;
-  if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
-  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_analytic");
-  if (sky->beam_kind < PRISIM_BEAM_DELTA || sky->beam_kind > PRISIM_BEAM_POLY)
-    return fail(ctx, PRISIM_EINVAL, "unknown beam_kind");
-  if (sky->beam_kind == PRISIM_BEAM_DIPOLE && !sky->ext)
-    return fail(ctx, PRISIM_EINVAL, "PRISIM_BEAM_DIPOLE needs a prisim_beam_ext (dipole axis)");
-  if (sky->beam_kind == PRISIM_BEAM_POLY && !sky->ext)
-    return fail(ctx, PRISIM_EINVAL, "PRISIM_BEAM_POLY needs a prisim_beam_ext (poly_coef)");
-  if (sky->ext) {
-    const prisim_beam_ext* x = sky->ext;
+}  // extern "C"
+namespace pint {
+
+// argument checks of a fused analytic beam (prisim_beam_sky / prisim_obs)
+int check_beam_spec(prisim_ctx* ctx, int beam_kind, double diameter_m, const double* beam_pc_dircos, const prisim_beam_ext* ext) {
+  if (beam_kind < PRISIM_BEAM_DELTA || beam_kind > PRISIM_BEAM_POLY) return fail(ctx, PRISIM_EINVAL, "unknown beam_kind");
+  if (beam_kind == PRISIM_BEAM_DIPOLE && !ext) return fail(ctx, PRISIM_EINVAL, "PRISIM_BEAM_DIPOLE needs a prisim_beam_ext (dipole axis)");
+  if (beam_kind == PRISIM_BEAM_POLY && !ext) return fail(ctx, PRISIM_EINVAL, "PRISIM_BEAM_POLY needs a prisim_beam_ext (poly_coef)");
+  if (ext) {
+    const prisim_beam_ext* x = ext;
     if (x->dipole_mode < PRISIM_DIPOLE_GENERAL || x->dipole_mode > PRISIM_DIPOLE_HALFWAVE)
       return fail(ctx, PRISIM_EINVAL, "unknown dipole_mode");
     if (x->array_nax1 < 0 || x->array_nax2 < 0 || (x->array_nax1 > 0) != (x->array_nax2 > 0))
@@ -924,81 +562,115 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
           return fail(ctx, PRISIM_EINVAL, "non-finite beamformer delay / gain");
     }
   }
+  if (beam_kind != PRISIM_BEAM_DELTA && beam_kind != PRISIM_BEAM_POLY && !(diameter_m > 0.0))
+    return fail(ctx, PRISIM_EINVAL, "diameter_m must be positive");
+  if (!beam_pc_dircos) return fail(ctx, PRISIM_EINVAL, "beam_pc_dircos is NULL");
+  return PRISIM_OK;
+}
+
+size_t beamformer_doubles(const prisim_beam_ext* ext) {
+  const int bf_n = ext ? ext->bf_nelem : 0, bf_r = bf_n > 0 ? ext->bf_nrand : 0;
+  return (size_t)bf_n * 3 + 2 * (size_t)bf_n * bf_r;
+}
+
+// pbflux[s][f] = beam(dirs_p[s], f) x flux(src_index ? src_index[s] : s, f) of the current sky (ns sources) into ctx->pb.  The flux
+// pointers are device arrays (power law: d_flux_ref / d_spindex; tabulated: d_flux_spec).  A beamformer's element arrays (host, in ext)
+// are sent through the OPEN staging group (the caller ran stage_begin with room for beamformer_doubles(ext) doubles and ends it).
+int sky_beam_flux(prisim_ctx* ctx, int64_t ns, int beam_kind, double diameter_m, const double* beam_pc_dircos, const prisim_beam_ext* ext,
+                  const double* d_flux_ref, const double* d_spindex, const double* d_flux_spec, double ref_freq, const int32_t* src_index) {
+  int rc;
+  const int bf_n = ext ? ext->bf_nelem : 0, bf_r = bf_n > 0 ? ext->bf_nrand : 0;
+  if ((bf_n > 0 && (rc = ensure(ctx, ctx->sky_bf, beamformer_doubles(ext) * sizeof(double)))) || (rc = ensure(ctx, ctx->sky_flag, sizeof(int32_t))))
+    return rc;
+  if (bf_n > 0) {
+    double* b = (double*)ctx->sky_bf.p;
+    if ((rc = upload_any(ctx, b, ext->bf_pos, (size_t)bf_n * 3 * sizeof(double), nullptr)) ||
+        (rc = upload_any(ctx, b + (size_t)bf_n * 3, ext->bf_delays, (size_t)bf_n * bf_r * sizeof(double), nullptr)) ||
+        (rc = upload_any(ctx, b + (size_t)bf_n * 3 + (size_t)bf_n * bf_r, ext->bf_gains, (size_t)bf_n * bf_r * sizeof(double), nullptr)))
+      return rc;
+  }
+  BeamParams bp{};
+  bp.dirs = ctx->dirs_p;
+  bp.flux_ref = d_flux_ref;
+  bp.spindex = d_spindex;
+  bp.flux_spec = d_flux_spec;
+  bp.src_index = src_index;
+  bp.freqs = (const double*)ctx->freqs.p;
+  bp.ref_freq = d_flux_spec ? 1.0 : ref_freq;
+  bp.beam_kind = beam_kind;
+  bp.diameter = diameter_m;
+  bp.bpc_x = beam_pc_dircos[0]; bp.bpc_y = beam_pc_dircos[1]; bp.bpc_z = beam_pc_dircos[2];
+  if (ext) {
+    const prisim_beam_ext* x = ext;
+    bp.dip_x = x->dipole_dircos[0]; bp.dip_y = x->dipole_dircos[1]; bp.dip_z = x->dipole_dircos[2];
+    bp.dipole_mode = x->dipole_mode;
+    bp.nax1 = x->array_nax1; bp.nax2 = x->array_nax2; bp.sep1 = x->array_sep1; bp.sep2 = x->array_sep2;
+    const double ang = x->array_east2ax1_deg * M_PI / 180.0;
+    bp.rot_c = std::cos(ang); bp.rot_s = std::sin(ang);
+    bp.apc_x = x->array_pc_dircos[0]; bp.apc_y = x->array_pc_dircos[1]; bp.apc_z = x->array_pc_dircos[2];
+    bp.gp_height = x->ground_height; bp.gp_modify = x->ground_modify; bp.gp_scale = x->ground_scale; bp.gp_max = x->ground_max;
+    if (bf_n > 0) {
+      bp.bf_nelem = bf_n; bp.bf_nrand = bf_r;
+      bp.bf_pos = (const double*)ctx->sky_bf.p;
+      bp.bf_delays = bp.bf_pos + (size_t)bf_n * 3;
+      bp.bf_gains = bp.bf_delays + (size_t)bf_n * bf_r;
+    }
+  }
+  if (beam_kind == PRISIM_BEAM_POLY)
+    for (int i = 0; i < 4; ++i) bp.poly[i] = ext->poly_coef[i];
+  bp.flag = (int32_t*)ctx->sky_flag.p;
+  bp.nsrc = ns; bp.nchan = ctx->nchan;
+  bp.pb_out = (double*)ctx->pb.p;
+  HIPCHK(ctx, hipMemsetAsync(ctx->sky_flag.p, 0, sizeof(int32_t), ctx->stream));
+  HIPCHK(ctx, launch_beam_flux(bp, ctx->stream));
+  return PRISIM_OK;
+}
+
+// only the polynomial beams can trip the reference's validity checks (:510-512, :802-807): the one case that reads back
+int check_poly_beam_flag(prisim_ctx* ctx) {
+  int32_t hflag = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&hflag, ctx->sky_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (hflag & 2)
+    return fail(ctx, PRISIM_EINVAL, "Primary beam values were found to be NaN in some case(s). Check if the polynomial equations are valid for the frequencies specified.");
+  if (hflag & 1)
+    return fail(ctx, PRISIM_EINVAL, "Primary beam exceeds unity by a significant amount. Check the validity of the Primary beam equation for the angles specified.");
+  return PRISIM_OK;
+}
+
+}  // namespace pint
+extern "C" {
+
+int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!sky) return fail(ctx, PRISIM_EINVAL, "sky is NULL");
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_sky_analytic");
+  int rc;
+  if ((rc = check_beam_spec(ctx, sky->beam_kind, sky->diameter_m, sky->beam_pc_dircos, sky->ext))) return rc;
   const bool have_spec = sky->flux_spectrum != nullptr;
   if (sky->nsrc > 0 && !have_spec && (!sky->flux_ref || !sky->spindex))
     return fail(ctx, PRISIM_EINVAL, "flux_ref / spindex is NULL and no flux_spectrum given");
   if (!have_spec && !(sky->ref_freq_hz > 0.0)) return fail(ctx, PRISIM_EINVAL, "ref_freq_hz must be positive");
-  if (sky->beam_kind != PRISIM_BEAM_DELTA && sky->beam_kind != PRISIM_BEAM_POLY && !(sky->diameter_m > 0.0))
-    return fail(ctx, PRISIM_EINVAL, "diameter_m must be positive");
-  if (!sky->beam_pc_dircos) return fail(ctx, PRISIM_EINVAL, "beam_pc_dircos is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->sky_set = false;
   const int64_t ns = sky->nsrc;
   const int64_t n = ns * ctx->nchan;
   const size_t frb = have_spec ? (size_t)n * sizeof(double) : (size_t)ns * sizeof(double);
-  const int bf_n = sky->ext ? sky->ext->bf_nelem : 0, bf_r = bf_n > 0 ? sky->ext->bf_nrand : 0;
-  const size_t bf_doubles = (size_t)bf_n * 3 + 2 * (size_t)bf_n * bf_r;
-  const size_t stage_extra = (frb <= kStageMaxBytes ? frb : 0) + (size_t)ns * sizeof(double) + bf_doubles * sizeof(double) + 4096;
-  int rc = upload_common(ctx, ns, sky->dircos, sky->pc_dircos, sky->fwhm_deg, stage_extra);
+  const size_t stage_extra = (frb <= kStageMaxBytes ? frb : 0) + (size_t)ns * sizeof(double) + beamformer_doubles(sky->ext) * sizeof(double) + 4096;
+  rc = upload_common(ctx, ns, sky->dircos, sky->pc_dircos, sky->fwhm_deg, stage_extra);
   if (rc) return rc;
   if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (ns > 0) {
-    if ((rc = ensure(ctx, ctx->sky_flux, frb)) || (rc = ensure(ctx, ctx->sky_sp, (size_t)ns * sizeof(double))) ||
-        (bf_n > 0 && (rc = ensure(ctx, ctx->sky_bf, bf_doubles * sizeof(double)))) || (rc = ensure(ctx, ctx->sky_flag, sizeof(int32_t))))
-      return rc;
+    if ((rc = ensure(ctx, ctx->sky_flux, frb)) || (rc = ensure(ctx, ctx->sky_sp, (size_t)ns * sizeof(double)))) return rc;
     if ((rc = upload_any(ctx, ctx->sky_flux.p, have_spec ? sky->flux_spectrum : sky->flux_ref, frb, nullptr))) return rc;
-    if (bf_n > 0) {
-      double* b = (double*)ctx->sky_bf.p;
-      if ((rc = upload_any(ctx, b, sky->ext->bf_pos, (size_t)bf_n * 3 * sizeof(double), nullptr)) ||
-          (rc = upload_any(ctx, b + (size_t)bf_n * 3, sky->ext->bf_delays, (size_t)bf_n * bf_r * sizeof(double), nullptr)) ||
-          (rc = upload_any(ctx, b + (size_t)bf_n * 3 + (size_t)bf_n * bf_r, sky->ext->bf_gains, (size_t)bf_n * bf_r * sizeof(double), nullptr)))
-        return rc;
-    }
     if (!have_spec && (rc = upload_any(ctx, ctx->sky_sp.p, sky->spindex, (size_t)ns * sizeof(double), nullptr))) return rc;
-    BeamParams bp{};
-    bp.dirs = (const double*)ctx->dirs.p;
-    bp.flux_ref = have_spec ? nullptr : (const double*)ctx->sky_flux.p;
-    bp.spindex = have_spec ? nullptr : (const double*)ctx->sky_sp.p;
-    bp.flux_spec = have_spec ? (const double*)ctx->sky_flux.p : nullptr;
-    bp.freqs = (const double*)ctx->freqs.p;
-    bp.ref_freq = have_spec ? 1.0 : sky->ref_freq_hz;
-    bp.beam_kind = sky->beam_kind;
-    bp.diameter = sky->diameter_m;
-    bp.bpc_x = sky->beam_pc_dircos[0]; bp.bpc_y = sky->beam_pc_dircos[1]; bp.bpc_z = sky->beam_pc_dircos[2];
-    if (sky->ext) {
-      const prisim_beam_ext* x = sky->ext;
-      bp.dip_x = x->dipole_dircos[0]; bp.dip_y = x->dipole_dircos[1]; bp.dip_z = x->dipole_dircos[2];
-      bp.dipole_mode = x->dipole_mode;
-      bp.nax1 = x->array_nax1; bp.nax2 = x->array_nax2; bp.sep1 = x->array_sep1; bp.sep2 = x->array_sep2;
-      const double ang = x->array_east2ax1_deg * M_PI / 180.0;
-      bp.rot_c = std::cos(ang); bp.rot_s = std::sin(ang);
-      bp.apc_x = x->array_pc_dircos[0]; bp.apc_y = x->array_pc_dircos[1]; bp.apc_z = x->array_pc_dircos[2];
-      bp.gp_height = x->ground_height; bp.gp_modify = x->ground_modify; bp.gp_scale = x->ground_scale; bp.gp_max = x->ground_max;
-      if (bf_n > 0) {
-        bp.bf_nelem = bf_n; bp.bf_nrand = bf_r;
-        bp.bf_pos = (const double*)ctx->sky_bf.p;
-        bp.bf_delays = bp.bf_pos + (size_t)bf_n * 3;
-        bp.bf_gains = bp.bf_delays + (size_t)bf_n * bf_r;
-      }
-    }
-    if (sky->beam_kind == PRISIM_BEAM_POLY)
-      for (int i = 0; i < 4; ++i) bp.poly[i] = sky->ext->poly_coef[i];
-    bp.flag = (int32_t*)ctx->sky_flag.p;
-    bp.nsrc = ns; bp.nchan = ctx->nchan;
-    bp.pb_out = (double*)ctx->pb.p;
-    HIPCHK(ctx, hipMemsetAsync(ctx->sky_flag.p, 0, sizeof(int32_t), ctx->stream));
-    HIPCHK(ctx, launch_beam_flux(bp, ctx->stream));
+    if ((rc = sky_beam_flux(ctx, ns, sky->beam_kind, sky->diameter_m, sky->beam_pc_dircos, sky->ext, have_spec ? nullptr : (const double*)ctx->sky_flux.p,
+                            have_spec ? nullptr : (const double*)ctx->sky_sp.p, have_spec ? (const double*)ctx->sky_flux.p : nullptr,
+                            sky->ref_freq_hz, nullptr)))
+      return rc;
     stage_end(ctx);
-    if (sky->beam_kind == PRISIM_BEAM_POLY) {
-      // only the polynomial beams can trip the reference's validity checks (:510-512, :802-807): the one case that reads back
-      int32_t hflag = 0;
-      HIPCHK(ctx, hipMemcpyAsync(&hflag, ctx->sky_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      if (hflag & 2)
-        return fail(ctx, PRISIM_EINVAL, "Primary beam values were found to be NaN in some case(s). Check if the polynomial equations are valid for the frequencies specified.");
-      if (hflag & 1)
-        return fail(ctx, PRISIM_EINVAL, "Primary beam exceeds unity by a significant amount. Check the validity of the Primary beam equation for the angles specified.");
-    }
+    if (sky->beam_kind == PRISIM_BEAM_POLY && (rc = check_poly_beam_flag(ctx))) return rc;
   } else {
     stage_end(ctx);
   }
@@ -1041,18 +713,22 @@ int prisim_hip_set_external_beam(prisim_ctx* ctx, const double* beam, int64_t np
 }
 
 // beam table -> pbflux for the current directions; fluxes: device [nsrc][nchan] table, or NULL with flux_ref / spindex (device [nsrc])
-static int extbeam_sky(prisim_ctx* ctx, int64_t nsrc, const double* d_fluxes, const double* d_flux_ref, const double* d_spindex,
-                       double ref_freq) {
+}  // extern "C"
+namespace pint {
+int extbeam_sky(prisim_ctx* ctx, int64_t nsrc, const double* d_fluxes, const double* d_flux_ref, const double* d_spindex,
+                double ref_freq, const int32_t* src_index) {
   const int64_t n = nsrc * ctx->nchan;
   int rc;
   if ((rc = ensure(ctx, ctx->ext_work, (size_t)n * sizeof(double))) ||
       (rc = ensure(ctx, ctx->ext_colmax, (size_t)1025 * ctx->nchan * sizeof(double))))
     return rc;
-  HIPCHK(ctx, launch_extbeam_sky((const double*)ctx->ext_table.p, ctx->ext_nside, (const double*)ctx->dirs.p, d_fluxes, d_flux_ref, d_spindex,
+  HIPCHK(ctx, launch_extbeam_sky((const double*)ctx->ext_table.p, ctx->ext_nside, ctx->dirs_p, d_fluxes, d_flux_ref, d_spindex,
                                  (const double*)ctx->freqs.p, ref_freq, (double*)ctx->ext_work.p, (double*)ctx->ext_colmax.p,
-                                 (double*)ctx->pb.p, nsrc, ctx->nchan, ctx->stream));
+                                 (double*)ctx->pb.p, nsrc, ctx->nchan, ctx->stream, src_index));
   return PRISIM_OK;
 }
+}  // namespace pint
+extern "C" {
 
 int prisim_hip_set_sky_external(prisim_ctx* ctx, const prisim_sky* sky) {
   return guarded(ctx, [&]() -> int {
@@ -1072,7 +748,7 @@ int prisim_hip_set_sky_external(prisim_ctx* ctx, const prisim_sky* sky) {
   if (n > 0) {
     if ((rc = ensure(ctx, ctx->sky_flux, fl_bytes))) return rc;
     if ((rc = upload_any(ctx, ctx->sky_flux.p, sky->fluxes, fl_bytes, nullptr))) return rc;
-    if ((rc = extbeam_sky(ctx, sky->nsrc, (const double*)ctx->sky_flux.p, nullptr, nullptr, 1.0))) return rc;
+    if ((rc = extbeam_sky(ctx, sky->nsrc, (const double*)ctx->sky_flux.p, nullptr, nullptr, 1.0, nullptr))) return rc;
   }
   stage_end(ctx);
   ctx->sky_set = true;
@@ -1104,7 +780,7 @@ int prisim_hip_set_sky_external_analytic(prisim_ctx* ctx, const prisim_beam_sky*
     if ((rc = upload_any(ctx, ctx->sky_flux.p, have_spec ? sky->flux_spectrum : sky->flux_ref, frb, nullptr))) return rc;
     if (!have_spec && (rc = upload_any(ctx, ctx->sky_sp.p, sky->spindex, (size_t)ns * sizeof(double), nullptr))) return rc;
     if ((rc = extbeam_sky(ctx, ns, have_spec ? (const double*)ctx->sky_flux.p : nullptr, have_spec ? nullptr : (const double*)ctx->sky_flux.p,
-                          have_spec ? nullptr : (const double*)ctx->sky_sp.p, have_spec ? 1.0 : sky->ref_freq_hz)))
+                          have_spec ? nullptr : (const double*)ctx->sky_sp.p, have_spec ? 1.0 : sky->ref_freq_hz, nullptr)))
       return rc;
   }
   stage_end(ctx);
@@ -1131,7 +807,7 @@ static void fill_params(prisim_ctx* ctx, const Plan& pl, SkyvisParams& p) {
   p.bl_x = (const double*)ctx->blx.p; p.bl_y = (const double*)ctx->bly.p; p.bl_z = (const double*)ctx->blz.p;
   p.nbl = ctx->nbl; p.nchan = ctx->nchan;
   p.f0 = ctx->f0; p.df = ctx->df; p.inv_c = 1.0 / kC;
-  p.dirs = (const double*)ctx->dirs.p;
+  p.dirs = ctx->dirs_p;
   p.dirs_prep = (const double*)ctx->dirs_prep.p;
   p.pb_packed = ctx->packed.p;
   p.fsq = (const float*)ctx->fsq.p;
@@ -1207,7 +883,7 @@ static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams
     if (run.kappa <= 0.0) continue;
     double* mom = (double*)ctx->moments.p + r * (size_t)4 * nchan;
     if (ensure(ctx, ctx->moments_part, (size_t)taper_moments_chunks(run.lo, run.hi) * 4 * nchan * sizeof(double)) != PRISIM_OK) return false;
-    if (launch_taper_moments((const double*)ctx->pb.p, (const double*)ctx->dirs.p, run.lo, run.hi, nchan, (double*)ctx->moments_part.p, mom,
+    if (launch_taper_moments((const double*)ctx->pb.p, ctx->dirs_p, run.lo, run.hi, nchan, (double*)ctx->moments_part.p, mom,
                              ctx->stream) != hipSuccess)
       return false;
     const double c16 = 16.0 * run.kappa * (ctx->df / kC) * (ctx->df / kC);
@@ -1239,7 +915,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     p.out = dst;
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
     HIPCHK(ctx, launch_skyvis_direct(p, (const double*)ctx->freqs.p, (const double*)ctx->pb.p,
-                                     scale_comp >= 0 ? (const double*)ctx->dirs.p : nullptr, ctx->stream));
+                                     scale_comp >= 0 ? ctx->dirs_p : nullptr, ctx->stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
     return PRISIM_OK;
   }
@@ -1250,11 +926,11 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   if (const char* env = getenv("PRISIM_HIP_TAPER_F64_GROUP")) g64 = g64 && atoi(env) != 0;
   if (prep && scale_comp < 0)      // the snapshot's first pass: rows and directions in one launch
     HIPCHK(ctx, launch_pack_prep((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
-                                 g64 ? 0 : 1, (const double*)ctx->dirs.p, (double*)ctx->dirs_prep.p, ctx->pc[0], ctx->pc[1], ctx->pc[2],
+                                 g64 ? 0 : 1, ctx->dirs_p, (double*)ctx->dirs_prep.p, ctx->pc[0], ctx->pc[1], ctx->pc[2],
                                  1.0 / kC, ctx->stream));
   else
     HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
-                            pl.ntiles, (const double*)ctx->dirs.p, scale_comp, g64 ? 0 : 1, ctx->stream));
+                            pl.ntiles, ctx->dirs_p, scale_comp, g64 ? 0 : 1, ctx->stream));
   // Packed fp32 taper on a sky whose sources come in a few runs of one size each (every HEALPix sky; point sources + diffuse): the
   // split form, run by run (skyvis_kernels.hip: TGROUP 2 / 3) -- size-0 runs take the plain (no-taper) bodies.
   const bool split = scale_comp < 0 && taper_split_plan(ctx, pl, p);
@@ -1285,11 +961,14 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   // taper culling: per baseline group the first source it still has to sum (tables staged by set_sky_*); a launch over the whole sky
   // can only skip the leading sources of the FIRST run
   const int cpr = pl.f32 ? 1 : 0;
-  const bool cull = (pl.pk || g64) && ctx->taper && ctx->cull_any[cpr] && ctx->cull_first.p && ctx->cull_nruns == (int)ctx->kappa_runs.size() &&
+  const bool cull = (pl.pk || g64) && ctx->taper && ctx->cull_any[cpr] && ctx->cull_first.p && ctx->cull_nruns > 0 && !ctx->kappa_runs.empty() &&
                     (size_t)pl.nbgroups == ctx->grp_maxlen.size();             // (the packed fp32 kernels and the grouped fp64 kernel)
-  auto cull_table = [&](size_t r) { return (const int32_t*)ctx->cull_first.p + ((size_t)cpr * ctx->cull_nruns + r) * (size_t)pl.nbgroups; };
+  auto cull_table = [&](size_t r) {
+    return (const int32_t*)ctx->cull_first.p + ((size_t)cpr * ctx->cull_nruns + (size_t)ctx->kappa_runs[r].tab_row) * (size_t)pl.nbgroups;
+  };
   if (cull && !split) p.src_first = cull_table(0);
   ctx->timing.last_culled_fraction = cull ? ctx->cull_frac[cpr] : 0.0;
+  ctx->cull_frac_pending = (cull && ctx->cat.cur >= 0) ? cpr + 1 : 0;      // catalogue path: the device's count is read once the events are in
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
   if (split) {
     int launches = 0;
@@ -1351,7 +1030,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
           // point sources (w = 1, :6270 sigma = inf): the fp64 kernel without the taper (6.2 instead of 9.8 instructions per term); its
           // rows are (up, down) pairs: this run's rows are re-packed in that layout
           HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, false, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
-                                  (const double*)ctx->dirs.p, scale_comp, 1, ctx->stream, run.lo, run.hi));
+                                  ctx->dirs_p, scale_comp, 1, ctx->stream, run.lo, run.hi));
           q.taper = 0;
           q.src_first = nullptr;
           HIPCHK(ctx, launch_skyvis_rec(q, false, pl.ct, ctx->stream));
@@ -1392,10 +1071,10 @@ static int run_grad_pass(prisim_ctx* ctx, const Plan& pl, double* dst, double* g
     if ((rc2 = ensure(ctx, ctx->packed, (size_t)pl.ntiles * pl.nsrc_pad * 64 * sizeof(float)))) return rc2;
     p.pb_packed = ctx->packed.p;
     HIPCHK(ctx, launch_pack_grad((const double*)ctx->pb.p, (float*)ctx->packed.p, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ntiles,
-                                 (const double*)ctx->dirs.p, ctx->stream));
+                                 ctx->dirs_p, ctx->stream));
   } else {
     HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
-                            (const double*)ctx->dirs.p, -1, 1, ctx->stream));
+                            ctx->dirs_p, -1, 1, ctx->stream));
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
   if (pl.f32) {
@@ -1471,20 +1150,19 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
       // angle error alpha*eps is irrelevant and only tan(alpha/2) must stay bounded) is guaranteed for every source:
       // |theta| = |b . (s - s_pc)| |df| / c <= max|b| * max_s|s - s_pc| * |df| / c
       const double k = ctx->dmax * std::fabs(ctx->df) / kC;
-      if (k != ctx->lift_key_k || (int)pl.f32 != ctx->lift_key_f32 || ctx->lift_host.size() != (size_t)pl.nbgroups) {
-        // the host copy is rewritten: an upload of the previous flags may still be reading it
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->lift_host.assign((size_t)pl.nbgroups, 0);
-        for (int g = 0; g < pl.nbgroups; ++g)
-          ctx->lift_host[(size_t)g] = (ctx->grp_maxlen[(size_t)g] * k <= (pl.f32 ? 0.125 : 0.25) * (1.0 - 1e-9)) ? 1 : 0;
-        if ((rc = ensure(ctx, ctx->lift_flags, ctx->lift_host.size() * sizeof(int32_t)))) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->lift_flags.p, ctx->lift_host.data(), ctx->lift_host.size() * sizeof(int32_t), hipMemcpyHostToDevice,
-                                   ctx->stream));
+      const double lift_limit = (pl.f32 ? 0.125 : 0.25) * (1.0 - 1e-9);
+      if (k != ctx->lift_key_k || (int)pl.f32 != ctx->lift_key_f32 || ctx->lift_groups != pl.nbgroups) {
+        // formed on the device from the groups' longest baselines (resident since set_array): max|s - s_pc| changes with every snapshot
+        // of a drift scan, and a host-side table would need a stream synchronisation before it could be rewritten
+        if ((rc = ensure(ctx, ctx->lift_flags, (size_t)pl.nbgroups * sizeof(int32_t)))) return rc;
+        HIPCHK(ctx, launch_lift_flags((const double*)ctx->grp_hz.p + 2 * ctx->grp_maxlen.size(), k, lift_limit, (int32_t*)ctx->lift_flags.p,
+                                      pl.nbgroups, ctx->stream));
         ctx->lift_key_k = k;
         ctx->lift_key_f32 = (int)pl.f32;
+        ctx->lift_groups = pl.nbgroups;
       }
       int nlift = 0;
-      for (int32_t v : ctx->lift_host) nlift += v;
+      for (int g = 0; g < pl.nbgroups; ++g) nlift += (ctx->grp_maxlen[(size_t)g] * k <= lift_limit) ? 1 : 0;
       // the packed taper kernel folds the amplitude into the phasor (a scaled rotation: no lifting there, the flags only select its
       // re-anchored body); every other kernel lifts the flagged groups
       ctx->timing.last_lift_groups = (ctx->taper && pl.pk) ? 0 : nlift;
@@ -1501,7 +1179,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
       if ((rc = ensure(ctx, ctx->dirs_c32, (size_t)pl.nsrc_pad * 8 * sizeof(float)))) return rc;
       c32 = (float*)ctx->dirs_c32.p;
     }
-    HIPCHK(ctx, launch_prep_dirs((const double*)ctx->dirs.p, (double*)ctx->dirs_prep.p, c32, ctx->nsrc, pl.nsrc_pad, ctx->pc[0],
+    HIPCHK(ctx, launch_prep_dirs(ctx->dirs_p, (double*)ctx->dirs_prep.p, c32, ctx->nsrc, pl.nsrc_pad, ctx->pc[0],
                                  ctx->pc[1], ctx->pc[2], 1.0 / kC, ctx->stream));
   }
   if (fused_grad) {
@@ -1516,6 +1194,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     }
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev_c1[ctx->ring_head], ctx->stream));
+  catalog_after_compute(ctx);
   ctx->ring_head = (ctx->ring_head + 1) % prisim_ctx::kTimingRing;
   ctx->ring_pending += 1;
   ctx->timing.last_terms = ctx->nbl * ctx->nchan * ctx->nsrc;
@@ -1611,6 +1290,14 @@ int prisim_hip_get_timing(prisim_ctx* ctx, prisim_timing* out, int reset) {
     float ms = 0.f;
     if (hipEventSynchronize(ctx->ev_d1) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev_d0, ctx->ev_d1) == hipSuccess)
       ctx->timing.last_delay_ms = ms;
+  }
+  if (ctx->cull_frac_pending && ctx->cat.culled_host && ctx->ring_pending == 0) {
+    // (catalogue path: the cull table was built on the device; its count copy was queued before the compute whose events are now in)
+    const int pr = ctx->cull_frac_pending - 1;
+    const double pairs = (double)ctx->nsrc * (double)ctx->nbl;
+    ctx->cull_frac[pr] = pairs > 0.0 ? (double)ctx->cat.culled_host[pr] / pairs : 0.0;
+    ctx->timing.last_culled_fraction = ctx->cull_frac[pr];
+    ctx->cull_frac_pending = 0;
   }
   if (ctx->timing.last_taper_split > 0 && ctx->h_split_count && ctx->ring_pending == 0) {
     // (every compute's events have completed: the count copy queued before them has landed)

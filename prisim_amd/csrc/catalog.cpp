@@ -1,0 +1,441 @@
+// catalog.cpp -- the device-resident catalogue path of libprisim_hip.so (include/prisim_hip.h, "device-resident catalogue").
+//
+// prisim_hip_set_catalog uploads a run's sky model once; prisim_hip_set_sky_from_catalog / prisim_hip_observe_catalog then form
+// every snapshot's sky on the device (catalog_kernels.hip) -- what InterferometerArray.observe() of the reference does on the host at
+// every call (prisim/interferometry.py:6171-6180, 6204-6219, 6249-6254, 6263).  Host work per snapshot: a handful of launches and one
+// small read-back (source count, run boundaries, max |s - s_pc|) that waits for the GEOMETRY stream only.
+#include <chrono>
+
+#include "ctx_internal.h"
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+
+constexpr double kCullThr[2] = {28.0, 18.0};      // index = precision (PRISIM_FP64 = 0, PRISIM_FP32 = 1); see upload_common (capi.cpp)
+
+int cat_runtime(prisim_ctx* ctx, int64_t nsnap) {
+  auto& C = ctx->cat;
+  if (!C.gstream) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+    if (hipStreamCreateWithPriority(&C.gstream, hipStreamNonBlocking, greatest) != hipSuccess) {
+      (void)hipGetLastError();
+      C.gstream = nullptr;
+      HIPCHK(ctx, hipStreamCreateWithFlags(&C.gstream, hipStreamNonBlocking));
+    }
+    HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_geom, hipEventDisableTiming));
+    for (auto& s : C.set) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming));
+    if (hipHostMalloc((void**)&C.culled_host, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+      C.culled_host = nullptr;
+      return fail(ctx, PRISIM_ENOMEM, "hipHostMalloc for the catalogue path failed");
+    }
+    C.culled_host[0] = C.culled_host[1] = 0;
+  }
+  if (nsnap > C.cap_snaps) {
+    if (C.out_host) { (void)hipHostFree(C.out_host); C.out_host = nullptr; }
+    if (C.snaps_host) { (void)hipHostFree(C.snaps_host); C.snaps_host = nullptr; }
+    C.cap_snaps = 0;
+    const int64_t cap = std::max<int64_t>(nsnap, 16);
+    if (hipHostMalloc((void**)&C.out_host, (size_t)cap * sizeof(CatOut), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&C.snaps_host, (size_t)cap * sizeof(CatSnap), hipHostMallocDefault) != hipSuccess)
+      return fail(ctx, PRISIM_ENOMEM, "hipHostMalloc for the catalogue path failed");
+    int rc;
+    if ((rc = ensure(ctx, C.snaps, (size_t)cap * sizeof(CatSnap))) || (rc = ensure(ctx, C.out_dev, (size_t)cap * sizeof(CatOut)))) return rc;
+    C.cap_snaps = cap;
+  }
+  return PRISIM_OK;
+}
+
+// Does the altitude ordering pay?  The condition of InterferometerArray._cull_order (prisim_amd/interferometry.py): source shapes in at
+// most 8 runs of one size each and kappa_max (|b|_max f_min / c)^2 >= 18 -- otherwise no baseline group can cull anything.
+bool cat_sort_wanted(const prisim_ctx* ctx) {
+  const auto& C = ctx->cat;
+  if (!C.have_shape || C.runs.empty() || C.n < 2) return false;
+  if (const char* env = getenv("PRISIM_HIP_TAPER_CULL")) { if (atoi(env) == 0) return false; }
+  double lmax = 0.0;
+  for (double v : ctx->grp_maxlen) lmax = std::max(lmax, v);
+  const double fmin = ctx->h_freqs.empty() ? 0.0 : std::min(std::fabs(ctx->h_freqs.front()), std::fabs(ctx->h_freqs.back()));
+  const double x = lmax * fmin / kC;
+  return C.kappa_max * x * x >= 18.0;
+}
+
+int check_obs(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap) {
+  if (!obs || !snaps) return fail(ctx, PRISIM_EINVAL, "obs / snapshot is NULL");
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before the catalogue path");
+  if (!ctx->cat.loaded) return fail(ctx, PRISIM_ESTATE, "set_catalog must be called first (set_array drops the catalogue)");
+  if (!std::isfinite(obs->latitude_deg) || !std::isfinite(obs->roi_radius_deg)) return fail(ctx, PRISIM_EINVAL, "non-finite latitude / roi_radius");
+  if (obs->roi_center != 0 && obs->roi_center != 1) return fail(ctx, PRISIM_EINVAL, "roi_center must be 0 (zenith) or 1 (pointing centre)");
+  for (int64_t t = 0; t < nsnap; ++t) {
+    if (!std::isfinite(snaps[t].lst_deg)) return fail(ctx, PRISIM_EINVAL, "non-finite LST");
+    for (int i = 0; i < 3; ++i)
+      if (!std::isfinite(snaps[t].pc_dircos[i]) || !std::isfinite(snaps[t].beam_pc_dircos[i])) return fail(ctx, PRISIM_EINVAL, "non-finite pointing / phase centre");
+  }
+  if (obs->use_external_beam) {
+    if (ctx->ext_nside <= 0) return fail(ctx, PRISIM_ESTATE, "set_external_beam must be called before use_external_beam");
+    return PRISIM_OK;
+  }
+  return check_beam_spec(ctx, obs->beam_kind, obs->diameter_m, snaps[0].beam_pc_dircos, obs->ext);
+}
+
+// Geometry of nsnap snapshots into buffer set b, on the geometry stream; returns when the per-snapshot records are in C.out_host.
+int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int b, bool want_keys) {
+  auto& C = ctx->cat;
+  int rc;
+  if ((rc = cat_runtime(ctx, nsnap))) return rc;
+  auto& S = C.set[b];
+  const size_t rows = (size_t)nsnap * (size_t)std::max<int64_t>(C.n, 1);
+  const int64_t nblocks = cat_blocks(C.n);
+  if ((rc = ensure(ctx, S.idx, rows * sizeof(int32_t))) || (rc = ensure(ctx, S.dirs, rows * 4 * sizeof(double))) ||
+      (want_keys && ((rc = ensure(ctx, S.keys, rows * sizeof(uint32_t))) || (rc = ensure(ctx, S.pos, rows * sizeof(uint32_t))))) ||
+      (rc = ensure(ctx, C.block_off, (size_t)nsnap * (size_t)std::max<int64_t>(nblocks, 1) * sizeof(int32_t))))
+    return rc;
+  for (int64_t t = 0; t < nsnap; ++t) {
+    CatSnap& s = C.snaps_host[t];
+    s.lst_deg = snaps[t].lst_deg;
+    for (int i = 0; i < 3; ++i) { s.roi_pc[i] = snaps[t].pc_dircos[i]; s.pc[i] = snaps[t].pc_dircos[i]; }
+  }
+  if (C.n == 0) {
+    for (int64_t t = 0; t < nsnap; ++t) {
+      C.out_host[t].nsrc = 0; C.out_host[t].dmax2_bits = 0;
+      for (auto& v : C.out_host[t].run_start) v = 0;
+    }
+    return PRISIM_OK;
+  }
+  CatGeomParams p{};
+  p.lon = (const double*)C.lon.p; p.lat = (const double*)C.lat.p;
+  p.sin_dec = (const double*)C.sin_dec.p; p.cos_dec = (const double*)C.cos_dec.p;
+  p.kappa = C.have_shape ? (const double*)C.kappa.p : nullptr;
+  p.run_id = C.runs.empty() ? nullptr : (const uint8_t*)C.run_id.p;
+  p.n = C.n; p.nblocks = nblocks;
+  p.coords = C.coords; p.roi_center = obs->roi_center; p.want_keys = want_keys ? 1 : 0;
+  const double lat = obs->latitude_deg * (M_PI / 180.0);          // NP.radians(latitude)
+  p.sin_lat = std::sin(lat); p.cos_lat = std::cos(lat);
+  p.alt_min_deg = 90.0 - obs->roi_radius_deg;                      // interferometry.py:6216
+  p.roi_radius_deg = obs->roi_radius_deg;
+  p.snaps = (const CatSnap*)C.snaps.p;
+  p.block_off = (int32_t*)C.block_off.p;
+  p.idx = (int32_t*)S.idx.p; p.dirs = (double*)S.dirs.p;
+  p.keys = want_keys ? (uint32_t*)S.keys.p : nullptr; p.pos = want_keys ? (uint32_t*)S.pos.p : nullptr;
+  p.out = (CatOut*)C.out_dev.p;
+  // the set may still be read by sky-sums queued earlier on the compute stream
+  if (S.ev_recorded) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, S.ev_free, 0));
+  const auto t0 = Clock::now();
+  HIPCHK(ctx, hipMemcpyAsync(C.snaps.p, C.snaps_host, (size_t)nsnap * sizeof(CatSnap), hipMemcpyHostToDevice, C.gstream));
+  HIPCHK(ctx, launch_cat_geometry(p, (int)nsnap, C.gstream));
+  HIPCHK(ctx, hipMemcpyAsync(C.out_host, C.out_dev.p, (size_t)nsnap * sizeof(CatOut), hipMemcpyDeviceToHost, C.gstream));
+  HIPCHK(ctx, hipEventRecord(C.ev_geom, C.gstream));
+  HIPCHK(ctx, hipEventSynchronize(C.ev_geom));
+  C.geom_ms_sum += std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+  C.geom_calls += 1;
+  return PRISIM_OK;
+}
+
+// Make snapshot t of buffer set b the current sky: runs, altitude order, cull table, pb * flux.  Everything is queued on the compute
+// stream; nothing is waited for.
+int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot& snap, int b, int64_t t, bool want_keys) {
+  auto& C = ctx->cat;
+  auto& S = C.set[b];
+  const CatOut& o = C.out_host[t];
+  const int64_t N = o.nsrc;
+  if (N < 0 || N > C.n) return fail(ctx, PRISIM_EINTERNAL, "catalogue geometry returned an impossible source count");
+  int rc;
+  ctx->sky_set = false;
+  ctx->nsrc = N;
+  ctx->taper = C.have_shape;
+  for (int i = 0; i < 3; ++i) ctx->pc[i] = snap.pc_dircos[i];
+  double d2 = 0.0;
+  memcpy(&d2, &o.dmax2_bits, sizeof(double));
+  ctx->dmax = std::sqrt(d2);
+  ctx->kappa_runs.clear();
+  const int ncr = (int)C.runs.size();
+  for (int r = 0; r < ncr; ++r) {
+    const int64_t lo = o.run_start[r], hi = r + 1 < ncr ? o.run_start[r + 1] : N;
+    if (lo < 0 || hi < lo || hi > N) return fail(ctx, PRISIM_EINTERNAL, "catalogue geometry returned inconsistent run boundaries");
+    if (hi > lo) ctx->kappa_runs.push_back({lo, hi, C.runs[(size_t)r].kappa, r});
+  }
+  const size_t off = (size_t)t * (size_t)C.n;
+  const double* dirs = (const double*)S.dirs.p + off * 4;
+  const int32_t* idx = (const int32_t*)S.idx.p + off;
+  if (want_keys && N > 1) {
+    // every run of one source size by decreasing altitude (stable radix sort on (run, 1 - n) keys): the leading sources of a run are then
+    // the ones a long-baseline group can cull
+    if (!C.sort_tmp.p) {
+      const size_t nn = (size_t)C.n;
+      if ((rc = ensure(ctx, C.sort_tmp, std::max<size_t>(cat_sort_temp_bytes(C.n), 16))) || (rc = ensure(ctx, C.keys_out, nn * sizeof(uint32_t))) ||
+          (rc = ensure(ctx, C.perm, nn * sizeof(uint32_t))) || (rc = ensure(ctx, C.idx_sorted, nn * sizeof(int32_t))) ||
+          (rc = ensure(ctx, C.dirs_sorted, nn * 4 * sizeof(double))))
+        return rc;
+    }
+    HIPCHK(ctx, launch_cat_sort(C.sort_tmp.p, C.sort_tmp.bytes, (const uint32_t*)S.keys.p + off, (uint32_t*)C.keys_out.p, (const uint32_t*)S.pos.p + off,
+                                (uint32_t*)C.perm.p, dirs, idx, (double*)C.dirs_sorted.p, (int32_t*)C.idx_sorted.p, N, ctx->stream));
+    ctx->dirs_p = (const double*)C.dirs_sorted.p;
+    ctx->src_index = (const int32_t*)C.idx_sorted.p;
+  } else {
+    ctx->dirs_p = dirs;
+    ctx->src_index = idx;
+  }
+  // taper culling: the table of upload_common's host walk, built by k_cull_first (one row per CATALOGUE run)
+  ctx->cull_any[0] = ctx->cull_any[1] = false;
+  ctx->cull_frac[0] = ctx->cull_frac[1] = 0.0;
+  ctx->cull_nruns = 0;
+  const size_t ng = ctx->grp_maxlen.size();
+  const char* cull_env = getenv("PRISIM_HIP_TAPER_CULL");
+  if (!ctx->kappa_runs.empty() && ng > 0 && N > 0 && !(cull_env && atoi(cull_env) == 0)) {
+    const double fmin = std::min(std::fabs(ctx->h_freqs.front()), std::fabs(ctx->h_freqs.back()));
+    const double fc2 = (fmin / kC) * (fmin / kC);
+    double hmax = 0.0;
+    for (size_t g = 0; g < ng; ++g) hmax = std::max(hmax, ctx->grp_minh[g]);
+    bool possible[2] = {false, false};
+    for (const auto& run : ctx->kappa_runs)
+      for (int pr = 0; pr < 2; ++pr) possible[pr] = possible[pr] || (run.kappa > 0.0 && run.kappa * hmax * hmax * fc2 >= kCullThr[pr]);
+    if (possible[0] || possible[1]) {
+      CullParams cp{};
+      cp.dirs = ctx->dirs_p;
+      for (int r = 0; r < ncr; ++r) {
+        cp.run_lo[r] = o.run_start[r];
+        cp.run_hi[r] = r + 1 < ncr ? o.run_start[r + 1] : N;
+        cp.run_kappa[r] = C.runs[(size_t)r].kappa;
+      }
+      cp.nruns = ncr; cp.ng = (int32_t)ng;
+      cp.grp_maxz = (const double*)ctx->grp_hz.p + ng;
+      cp.grp_minh = (const double*)ctx->grp_hz.p + 3 * ng;
+      cp.fc2 = fc2;
+      cp.nbl = ctx->nbl;
+      if ((rc = ensure(ctx, ctx->cull_first, 2 * (size_t)ncr * ng * sizeof(int32_t))) || (rc = ensure(ctx, C.culled, 2 * sizeof(uint64_t)))) return rc;
+      cp.first = (int32_t*)ctx->cull_first.p;
+      cp.culled = (uint64_t*)C.culled.p;
+      HIPCHK(ctx, hipMemsetAsync(C.culled.p, 0, 2 * sizeof(uint64_t), ctx->stream));
+      HIPCHK(ctx, launch_cull_first(cp, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(C.culled_host, C.culled.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+      ctx->cull_any[0] = possible[0]; ctx->cull_any[1] = possible[1];
+      ctx->cull_nruns = ncr;
+    }
+  }
+  // pb * fluxes (:6249-6254); the flux vectors / spectra stay in catalogue order and are read through the index list.  Sized for the
+  // whole catalogue once: the ROI of a drift scan grows and shrinks, and every re-allocation would synchronise the device.
+  if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(C.n * ctx->nchan, 1) * sizeof(double)))) return rc;
+  if (N > 0) {
+    const double* fr = C.have_spec ? nullptr : (const double*)C.flux_ref.p;
+    const double* sp = C.have_spec ? nullptr : (const double*)C.spindex.p;
+    const double* fs = C.have_spec ? (const double*)C.spec.p : nullptr;
+    if (obs->use_external_beam) {
+      if ((rc = extbeam_sky(ctx, N, fs, fr, sp, C.have_spec ? 1.0 : C.ref_freq, ctx->src_index))) return rc;
+    } else {
+      const size_t bfb = beamformer_doubles(obs->ext) * sizeof(double);
+      if (bfb && (rc = stage_begin(ctx, bfb + 4096))) return rc;
+      rc = sky_beam_flux(ctx, N, obs->beam_kind, obs->diameter_m, snap.beam_pc_dircos, obs->ext, fr, sp, fs, C.ref_freq, ctx->src_index);
+      if (bfb) stage_end(ctx);
+      if (rc) return rc;
+      if (obs->beam_kind == PRISIM_BEAM_POLY && (rc = check_poly_beam_flag(ctx))) return rc;
+    }
+  }
+  C.cur = b;
+  ctx->sky_set = true;
+  return PRISIM_OK;
+}
+
+}  // namespace
+
+namespace pint {
+
+void catalog_after_compute(prisim_ctx* ctx) {
+  auto& C = ctx->cat;
+  if (C.cur < 0 || C.cur > 1) return;
+  if (hipEventRecord(C.set[C.cur].ev_free, ctx->stream) == hipSuccess) C.set[C.cur].ev_recorded = true;
+}
+
+void catalog_destroy(prisim_ctx* ctx) {
+  auto& C = ctx->cat;
+  if (C.gstream) (void)hipStreamSynchronize(C.gstream);
+  for (DevBuf* b : {&C.lon, &C.lat, &C.sin_dec, &C.cos_dec, &C.kappa, &C.run_id, &C.flux_ref, &C.spindex, &C.spec, &C.block_off, &C.snaps, &C.out_dev,
+                    &C.sort_tmp, &C.keys_out, &C.perm, &C.idx_sorted, &C.dirs_sorted, &C.culled})
+    release(*b);
+  for (auto& s : C.set) {
+    for (DevBuf* b : {&s.idx, &s.dirs, &s.keys, &s.pos}) release(*b);
+    if (s.ev_free) (void)hipEventDestroy(s.ev_free);
+    s.ev_free = nullptr;
+  }
+  if (C.ev_geom) (void)hipEventDestroy(C.ev_geom);
+  if (C.out_host) (void)hipHostFree(C.out_host);
+  if (C.snaps_host) (void)hipHostFree(C.snaps_host);
+  if (C.culled_host) (void)hipHostFree(C.culled_host);
+  if (C.gstream) (void)hipStreamDestroy(C.gstream);
+  C = prisim_ctx::Catalog();
+}
+
+}  // namespace pint
+
+extern "C" {
+
+int prisim_hip_set_catalog(prisim_ctx* ctx, const prisim_catalog* cat) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!cat) return fail(ctx, PRISIM_EINVAL, "cat is NULL");
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before set_catalog (the spectra are per channel grid)");
+  const int64_t n = cat->nsrc;
+  if (n < 0 || n > (int64_t)0x7fff0000) return fail(ctx, PRISIM_EINVAL, "nsrc must be in [0, 2^31)");
+  if (cat->coords < PRISIM_COORDS_RADEC || cat->coords > PRISIM_COORDS_ALTAZ) return fail(ctx, PRISIM_EINVAL, "unknown catalogue coordinates");
+  if (n > 0 && !cat->location) return fail(ctx, PRISIM_EINVAL, "location is NULL");
+  const bool have_spec = cat->flux_spectrum != nullptr;
+  if (n > 0 && !have_spec && (!cat->flux_ref || !cat->spindex)) return fail(ctx, PRISIM_EINVAL, "flux_ref / spindex is NULL and no flux_spectrum given");
+  if (!have_spec && !(cat->ref_freq_hz > 0.0)) return fail(ctx, PRISIM_EINVAL, "ref_freq_hz must be positive");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  auto& C = ctx->cat;
+  // a set of the previous catalogue may still be read by queued work
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (C.gstream) HIPCHK(ctx, hipStreamSynchronize(C.gstream));
+  C.loaded = false;
+  ctx->sky_set = ctx->sky_set && C.cur < 0;       // a sky that lives in the old catalogue's buffers is gone
+  C.cur = -1;
+  std::vector<double> lon((size_t)n), lat((size_t)n), kap;
+  for (int64_t i = 0; i < n; ++i) {
+    lon[(size_t)i] = cat->location[2 * i]; lat[(size_t)i] = cat->location[2 * i + 1];
+    if (!std::isfinite(lon[(size_t)i]) || !std::isfinite(lat[(size_t)i])) return fail(ctx, PRISIM_EINVAL, "non-finite catalogue position");
+  }
+  C.runs.clear();
+  C.kappa_max = 0.0;
+  std::vector<uint8_t> run_id;
+  if (cat->fwhm_deg && n > 0) {
+    kap.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+      const double fw = cat->fwhm_deg[i];
+      if (!std::isfinite(fw) || fw < 0.0) return fail(ctx, PRISIM_EINVAL, "invalid source FWHM");
+      const double fd = 2.0 * std::sin(0.5 * fw * M_PI / 180.0);          // interferometry.py:6268-6283, as upload_common
+      kap[(size_t)i] = M_LN2 * fd * fd;
+      C.kappa_max = std::max(C.kappa_max, kap[(size_t)i]);
+    }
+    run_id.assign((size_t)n, 0);
+    int64_t lo = 0;
+    bool ok = true;
+    for (int64_t s = 1; s <= n && ok; ++s) {
+      if (s == n || kap[(size_t)s] != kap[(size_t)lo]) {
+        if (C.runs.size() == (size_t)PRISIM_CAT_MAX_RUNS) { ok = false; break; }
+        for (int64_t j = lo; j < s; ++j) run_id[(size_t)j] = (uint8_t)C.runs.size();
+        C.runs.push_back({lo, s, kap[(size_t)lo]});
+        lo = s;
+      }
+    }
+    if (!ok) C.runs.clear();                                                 // sizes vary source by source: no runs (like the uploaded path)
+  }
+  int rc;
+  const size_t nb = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
+  if ((rc = ensure(ctx, C.lon, nb)) || (rc = ensure(ctx, C.lat, nb)) || (rc = ensure(ctx, C.sin_dec, nb)) || (rc = ensure(ctx, C.cos_dec, nb))) return rc;
+  if (n > 0) {
+    HIPCHK(ctx, hipMemcpy(C.lon.p, lon.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(C.lat.p, lat.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    if (cat->coords != PRISIM_COORDS_ALTAZ)
+      HIPCHK(ctx, launch_cat_prepare((const double*)C.lat.p, (double*)C.sin_dec.p, (double*)C.cos_dec.p, n, ctx->stream));
+    if (!kap.empty()) {
+      if ((rc = ensure(ctx, C.kappa, nb)) || (rc = ensure(ctx, C.run_id, (size_t)n))) return rc;
+      HIPCHK(ctx, hipMemcpy(C.kappa.p, kap.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      if (!C.runs.empty()) HIPCHK(ctx, hipMemcpy(C.run_id.p, run_id.data(), (size_t)n, hipMemcpyHostToDevice));
+    }
+    if (have_spec) {
+      const size_t sb = (size_t)n * (size_t)ctx->nchan * sizeof(double);
+      for (size_t i = 0; i < (size_t)n * (size_t)ctx->nchan; ++i)
+        if (!std::isfinite(cat->flux_spectrum[i])) return fail(ctx, PRISIM_EINVAL, "non-finite flux spectrum");
+      if ((rc = ensure(ctx, C.spec, sb))) return rc;
+      HIPCHK(ctx, hipMemcpy(C.spec.p, cat->flux_spectrum, sb, hipMemcpyHostToDevice));
+    } else {
+      for (int64_t i = 0; i < n; ++i)
+        if (!std::isfinite(cat->flux_ref[i]) || !std::isfinite(cat->spindex[i])) return fail(ctx, PRISIM_EINVAL, "non-finite flux_ref / spindex");
+      if ((rc = ensure(ctx, C.flux_ref, nb)) || (rc = ensure(ctx, C.spindex, nb))) return rc;
+      HIPCHK(ctx, hipMemcpy(C.flux_ref.p, cat->flux_ref, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(ctx, hipMemcpy(C.spindex.p, cat->spindex, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  C.n = n;
+  C.coords = cat->coords;
+  C.have_shape = cat->fwhm_deg != nullptr;
+  C.have_spec = have_spec;
+  C.ref_freq = have_spec ? 1.0 : cat->ref_freq_hz;
+  release(C.sort_tmp);                 // sized per catalogue
+  for (auto& s : C.set) s.ev_recorded = false;
+  C.loaded = true;
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_set_sky_from_catalog(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snap, int64_t* nsrc_roi) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  int rc;
+  if ((rc = check_obs(ctx, obs, snap, 1))) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  auto& C = ctx->cat;
+  const bool want_keys = cat_sort_wanted(ctx);
+  const int b = C.next;
+  ctx->sky_set = false;
+  if ((rc = geometry_run(ctx, obs, snap, 1, b, want_keys))) return rc;
+  if ((rc = activate_snapshot(ctx, obs, *snap, b, 0, want_keys))) return rc;
+  C.next = b ^ 1;
+  if (nsrc_roi) *nsrc_roi = ctx->nsrc;
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_catalog_roi(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snap, int64_t* nsrc_roi, int64_t* indices, double* dircos,
+                           int64_t cap) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!obs || !snap) return fail(ctx, PRISIM_EINVAL, "obs / snapshot is NULL");
+  if (!ctx->array_set || !ctx->cat.loaded) return fail(ctx, PRISIM_ESTATE, "set_array and set_catalog must be called first");
+  if (!std::isfinite(obs->latitude_deg) || !std::isfinite(obs->roi_radius_deg) || !std::isfinite(snap->lst_deg))
+    return fail(ctx, PRISIM_EINVAL, "non-finite latitude / roi_radius / LST");
+  if (obs->roi_center != 0 && obs->roi_center != 1) return fail(ctx, PRISIM_EINVAL, "roi_center must be 0 (zenith) or 1 (pointing centre)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  auto& C = ctx->cat;
+  int rc;
+  if ((rc = geometry_run(ctx, obs, snap, 1, 2, false))) return rc;
+  const int64_t N = C.out_host[0].nsrc;
+  if (nsrc_roi) *nsrc_roi = N;
+  if ((indices || dircos) && cap < N) return fail(ctx, PRISIM_EINVAL, "cap is smaller than the region of interest");
+  if (N > 0 && indices) {
+    std::vector<int32_t> h((size_t)N);
+    HIPCHK(ctx, hipMemcpy(h.data(), C.set[2].idx.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < N; ++i) indices[i] = h[(size_t)i];
+  }
+  if (N > 0 && dircos) {
+    std::vector<double> h((size_t)N * 4);
+    HIPCHK(ctx, hipMemcpy(h.data(), C.set[2].dirs.p, (size_t)N * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < N; ++i)
+      for (int k = 0; k < 3; ++k) dircos[3 * i + k] = h[(size_t)(4 * i + k)];
+  }
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int precision, int want_grad,
+                               int64_t slot0, int64_t* nsrc_roi) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (nsnap <= 0) return fail(ctx, PRISIM_EINVAL, "nsnap must be positive");
+  int rc;
+  if ((rc = check_obs(ctx, obs, snaps, nsnap))) return rc;
+  if (precision != PRISIM_FP64 && precision != PRISIM_FP32) return fail(ctx, PRISIM_EINVAL, "unknown precision");
+  if (slot0 < 0 || slot0 + nsnap > ctx->nt_max) return fail(ctx, PRISIM_EINVAL, "slot range outside the device cube (set_array nt_max)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  auto& C = ctx->cat;
+  const bool want_keys = cat_sort_wanted(ctx);
+  // chunks of snapshots whose geometry (44 bytes per catalogue source and snapshot) stays under 512 MiB
+  const int64_t per_snap = 44 * std::max<int64_t>(C.n, 1);
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)512 << 20) / per_snap));
+  for (int64_t c0 = 0; c0 < nsnap; c0 += chunk) {
+    const int64_t kc = std::min(chunk, nsnap - c0);
+    const int b = C.next;
+    ctx->sky_set = false;
+    if ((rc = geometry_run(ctx, obs, snaps + c0, kc, b, want_keys))) return rc;
+    for (int64_t t = 0; t < kc; ++t) {
+      if ((rc = activate_snapshot(ctx, obs, snaps[c0 + t], b, t, want_keys))) return rc;
+      if (nsrc_roi) nsrc_roi[c0 + t] = ctx->nsrc;
+      if ((rc = prisim_hip_compute(ctx, precision, PRISIM_KERNEL_AUTO, want_grad, slot0 + c0 + t))) return rc;
+    }
+    C.next = b ^ 1;
+  }
+  return PRISIM_OK;
+  });
+}
+
+}  // extern "C"

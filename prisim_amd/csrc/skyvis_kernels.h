@@ -125,6 +125,7 @@ struct BeamParams {
   double poly[4]; int32_t* flag;   // PRISIM_BEAM_POLY coefficients; flag bit 0: value >= 1.01, bit 1: NaN
   int64_t nsrc, nchan;
   double* pb_out;            // [nsrc][nchan]
+  const int32_t* src_index;  // catalogue path: flux_ref / spindex / flux_spec rows are read at src_index[s] (nullptr: at s)
 };
 hipError_t launch_beam_flux(const BeamParams& p, hipStream_t stream);
 hipError_t launch_mul_inplace(double* a, const double* b, int64_t n, hipStream_t stream);
@@ -134,7 +135,65 @@ hipError_t launch_extbeam_table(const double* beam, const double* interp, double
 hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs, const double* fluxes /*[nsrc][nchan] or NULL*/,
                               const double* flux_ref /*[nsrc]*/, const double* spindex /*[nsrc]*/, const double* freqs, double ref_freq,
                               double* work /*[nsrc][nchan]*/, double* colmax_scratch /*[1024*nchan + nchan]*/, double* pb_out,
-                              int64_t nsrc, int64_t nchan, hipStream_t stream);
+                              int64_t nsrc, int64_t nchan, hipStream_t stream, const int32_t* src_index = nullptr);
+
+// device-resident catalogue: per-snapshot geometry (catalog_kernels.hip)
+static constexpr int PRISIM_CAT_RADEC = 0, PRISIM_CAT_HADEC = 1, PRISIM_CAT_ALTAZ = 2;     // = PRISIM_COORDS_* of the public header
+static constexpr int PRISIM_CAT_MAX_RUNS = 8;
+struct CatSnap {             // per-snapshot inputs (device array, one entry per snapshot of a batch)
+  double lst_deg;
+  double roi_pc[3];          // centre of the region of interest (roi_center = pointing centre)
+  double pc[3];              // phase centre (for max |s - s_pc|)
+};
+struct CatOut {              // per-snapshot results the host reads back (pinned memory)
+  int64_t nsrc;              // sources inside the region of interest
+  int64_t run_start[PRISIM_CAT_MAX_RUNS + 1];   // first compacted source of every catalogue run; [nruns] = nsrc
+  uint64_t dmax2_bits;       // max |s - s_pc|^2, bit pattern of a non-negative double
+};
+struct CatGeomParams {
+  const double* lon;         // [n] RA | HA | alt, degrees
+  const double* lat;         // [n] Dec | Dec | az
+  const double* sin_dec;     // [n] sin / cos of the declination (RA-Dec, HA-Dec catalogues)
+  const double* cos_dec;
+  const double* kappa;       // [n] ln2 (2 sin(fwhm/2))^2, or nullptr (no source shapes)
+  const uint8_t* run_id;     // [n] catalogue run of every source (runs of one source size), or nullptr
+  int64_t n;
+  int64_t nblocks;           // ceil(n / 256)
+  int32_t coords;            // PRISIM_CAT_*
+  int32_t roi_center;        // 0 zenith, 1 pointing centre
+  int32_t want_keys;         // also write the altitude keys of the culling order
+  int32_t pad_;
+  double sin_lat, cos_lat;
+  double alt_min_deg;        // 90 - roi_radius
+  double roi_radius_deg;
+  const CatSnap* snaps;      // [nsnap] device
+  int32_t* block_off;        // [nsnap][nblocks] scratch
+  int32_t* idx;              // [nsnap][n] compacted catalogue indices (catalogue order)
+  double* dirs;              // [nsnap][n][4] compacted l, m, n, kappa
+  uint32_t* keys;            // [nsnap][n] (want_keys)
+  uint32_t* pos;             // [nsnap][n] (want_keys) 0, 1, 2, ...
+  CatOut* out;               // [nsnap] device
+};
+struct CullParams {
+  const double* dirs;        // [nsrc][4] in upload order
+  int64_t run_lo[PRISIM_CAT_MAX_RUNS], run_hi[PRISIM_CAT_MAX_RUNS];
+  double run_kappa[PRISIM_CAT_MAX_RUNS];
+  int32_t nruns, ng;
+  const double* grp_minh;    // [ng] smallest horizontal baseline length of the group
+  const double* grp_maxz;    // [ng] largest |b_z|
+  double fc2;                // (f_min / c)^2
+  int64_t nbl;
+  int32_t* first;            // [2][nruns][ng]
+  uint64_t* culled;          // [2] skipped (source, baseline) pairs per precision
+};
+int64_t cat_blocks(int64_t n);
+hipError_t launch_cat_prepare(const double* dec_deg, double* sd, double* cd, int64_t n, hipStream_t stream);
+hipError_t launch_cat_geometry(const CatGeomParams& p, int nsnap, hipStream_t stream);
+size_t cat_sort_temp_bytes(int64_t n);
+hipError_t launch_cat_sort(void* temp, size_t temp_bytes, const uint32_t* keys, uint32_t* keys_out, const uint32_t* pos, uint32_t* perm,
+                           const double* dirs, const int32_t* idx, double* dirs_out, int32_t* idx_out, int64_t n, hipStream_t stream);
+hipError_t launch_cull_first(const CullParams& p, hipStream_t stream);
+hipError_t launch_lift_flags(const double* grp_maxlen, double k, double limit, int32_t* flags, int ng, hipStream_t stream);
 
 // delay transform helpers (delay_kernels.hip)
 hipError_t launch_dt_prepare(const double* cube, const double* bpwts /*device [wts_rows][nchan] or NULL*/, int64_t wts_rows /*1 or nbl*/,

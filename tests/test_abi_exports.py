@@ -49,12 +49,17 @@ def test_struct_layouts_match_header():
     assert _abi.PrisimTiming.last_culled_fraction.offset == 80
     # prisim_comm_stats: 2 int64, 4 double, 4 int32 -> 64 bytes
     assert C.sizeof(_abi.PrisimCommStats) == 64 and _abi.PrisimCommStats.stream_priority.offset == 48
+    # prisim_catalog: int64, 2 int32, 3 ptr, double, 2 ptr -> 64 bytes; prisim_obs: 2 double, 4 int32, double, ptr -> 48; prisim_snapshot: 7 double
+    assert C.sizeof(_abi.PrisimCatalog) == 64 and _abi.PrisimCatalog.location.offset == 16 and _abi.PrisimCatalog.fwhm_deg.offset == 56
+    assert C.sizeof(_abi.PrisimObs) == 48 and _abi.PrisimObs.beam_kind.offset == 24 and _abi.PrisimObs.ext.offset == 40
+    assert C.sizeof(_abi.PrisimSnapshot) == 56 and _abi.PrisimSnapshot.beam_pc_dircos.offset == 32
 
 
 def test_every_export_is_guarded_against_cpp_exceptions():
     """no C++ exception crosses the ABI.  Every `int prisim_hip_*` entry of capi.cpp runs its body through guarded()
-    (bad_alloc -> PRISIM_ENOMEM, anything else -> PRISIM_EINTERNAL); the void / const char* entries cannot throw by construction."""
-    src = open(os.path.join(ROOT, 'prisim_amd', 'csrc', 'capi.cpp')).read()
+    (and of catalog.cpp) (bad_alloc -> PRISIM_ENOMEM, anything else -> PRISIM_EINTERNAL); the void / const char* entries cannot throw
+    by construction."""
+    src = ''.join(open(os.path.join(ROOT, 'prisim_amd', 'csrc', f)).read() for f in ('capi.cpp', 'catalog.cpp'))
     entries = re.findall(r'^int (prisim_hip_\w+)\(', src, flags=re.M)
     assert sorted(entries) == sorted(n for n in _abi.EXPORTS if n not in ('prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version'))
     for name in entries:

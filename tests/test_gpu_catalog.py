@@ -1,0 +1,281 @@
+"""GPU parity of the device-resident catalogue path (include/prisim_hip.h, ABI 0.4): the per-snapshot sky geometry formed on the device
+against the host statements it replaces (prisim_amd/geometry.py = GEOM.hadec2altaz / altaz2dircos as InterferometerArray.observe() calls
+them, prisim/interferometry.py:6174-6180, 6204-6219, 6263), and the visibilities through it against the uploaded-sky path and the oracle."""
+import os
+import sys
+
+import numpy as NP
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from prisim_amd import _abi, geometry as GEOM, layouts as LAY, workloads as W   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+ZEN = NP.array([0.0, 0.0, 1.0])
+
+
+def radec_catalogue(sky, lat, lst0):
+    """The sky of a workload (local frame at lst0) as (RA, Dec), like prisim_amd.driver.build_skymodel."""
+    hadec = GEOM.altaz2hadec(sky['altaz'], lat, units='degrees')
+    return NP.stack(((lst0 - hadec[:, 0]) % 360.0, hadec[:, 1]), axis=1)
+
+
+def host_roi(radec, lat, lst, roi_radius=90.0, coords='radec'):
+    """What observe() forms on the host (prisim_amd/interferometry.py, the uploaded path): indices and direction cosines."""
+    if coords == 'radec':
+        altaz = GEOM.hadec2altaz(NP.stack((lst - radec[:, 0], radec[:, 1]), axis=1), lat, units='degrees')
+    elif coords == 'hadec':
+        altaz = GEOM.hadec2altaz(radec, lat, units='degrees')
+    else:
+        altaz = radec
+    m2 = NP.arange(altaz.shape[0])[NP.where(altaz[:, 0] >= 90.0 - roi_radius)]
+    host_roi.on_the_rim = NP.where(NP.abs(altaz[:, 0] - (90.0 - roi_radius)) < 1e-12)[0]      # see _same_indices
+    return m2, GEOM.altaz2dircos(altaz[m2], 'degrees'), altaz[m2]
+
+
+def _same_indices(idx, m2, rim):
+    """Bit-identical index lists -- except for sources whose altitude sits within 1e-12 degrees of the rim of the region of interest,
+    where one ulp of the device's and numpy's arcsin decides (HEALPix has rings at exactly 30 degrees of altitude: nside-16 at
+    roi_radius = 60 and LST = the LST the map was laid out for).  Those are compared as sets without them."""
+    if rim.size == 0:
+        return NP.array_equal(idx, m2)
+    return NP.array_equal(NP.setdiff1d(idx, rim), NP.setdiff1d(m2, rim))
+
+
+def _check_dircos(dc, dc_host, altaz, what):
+    """The device follows the host's chain statement by statement (FMA contraction off), so the two differ only where the device's
+    sin / cos / asin / atan2 and numpy's round differently -- by one unit in the last place.  The chain carries the azimuth in [0, 2 pi)
+    (GEOM.hadec2altaz), where one ulp is 8.9e-16 rad: a 1-ulp difference of atan2 alone moves (l, m) by that much, two such roundings by
+    1.8e-15.  Measured on MI355X vs numpy 2.2 on the box's EPYC: about 70 % of the entries bit-identical, worst 1.7e-15 below 78 degrees of
+    altitude; asserted: 2.5e-15 (3 ulp of an azimuth) -- 2e-12 cycles of phase on a 1 km baseline at 200 MHz.  Near the zenith the chain
+    is ill-conditioned on the host and on the device alike (alt = arcsin(sin_alt), then cos(alt): one ulp of sin_alt comes back times
+    1 / cos(alt)); there the bound is 2 ulp / cos(alt) (4.2e-15 measured at 87.1 degrees)."""
+    err = NP.max(NP.abs(dc - dc_host), axis=1)
+    tol = NP.maximum(2.5e-15, 4.5e-16 / NP.maximum(NP.cos(NP.radians(altaz[:, 0])), 1e-6))
+    worst = int(NP.argmax(err / tol))
+    assert NP.all(err <= tol), (what, float(err[worst]), float(altaz[worst, 0]))
+    assert NP.mean(err == 0.0) > 0.5, (what, float(NP.mean(err == 0.0)))        # the arithmetic is the host's, statement by statement
+
+
+CASES = [
+    # (name, sky builder, latitude, lst0, LSTs)
+    ('cfg2 nside-16 diffuse', lambda: W.diffuse_sky(16, 2), -30.7224, 30.0, [30.0, 33.7, 75.123, 211.0, 359.99]),
+    ('cfg4 nside-64 diffuse', lambda: W.diffuse_sky(64, 44, f_ref=185e6), -26.701, 0.0, [0.0, 0.4679, 14.5, 181.25]),
+    ('cfg5 nside-256 diffuse', lambda: W.diffuse_sky(256, 55), -30.7224, 10.0, [10.0, 15.35, 100.0]),
+    ('cfg3 points + diffuse', lambda: W.concat_skies(W.point_source_sky(10000, 3), W.diffuse_sky(32, 33)), -30.7224, 55.5, [55.5, 56.0, 300.0]),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_roi_indices_bit_identical_and_dircos_to_3ulp(case):
+    """index arrays bit-identical and direction cosines within 3 ulp of an azimuth of prisim_amd/geometry.py on the
+    configs' skies (see _check_dircos for why not 1e-15)."""
+    _, mk, lat, lst0, lsts = case
+    sky = mk()
+    radec = radec_catalogue(sky, lat, lst0)
+    with _abi.Context(0) as ctx:
+        ctx.set_array(NP.array([[14.6, 0.0, 0.0]]), W.channel_grid(150e6, 1e5, 8), nt_max=1)
+        ctx.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        for roi_radius in (90.0, 60.0):
+            obs = ctx.make_obs(lat, roi_radius_deg=roi_radius)
+            for lst in lsts:
+                idx, dc = ctx.catalog_roi(obs, lst, ZEN)
+                m2, dc_host, altaz = host_roi(radec, lat, lst, roi_radius)
+                rim = host_roi.on_the_rim
+                assert idx.dtype == NP.int64 and _same_indices(idx, m2, rim), (lst, roi_radius, idx.size, m2.size, rim.size)
+                if rim.size == 0:
+                    assert dc.shape == dc_host.shape
+                    if m2.size:
+                        _check_dircos(dc, dc_host, altaz, (case[0], lst, roi_radius))
+                else:
+                    assert roi_radius == 60.0 and lst == lsts[0]            # the one constructed coincidence; never at the horizon
+                    keep_d, keep_h = ~NP.isin(idx, rim), ~NP.isin(m2, rim)
+                    _check_dircos(dc[keep_d], dc_host[keep_h], altaz[keep_h], (case[0], lst, roi_radius))
+
+
+def test_roi_hadec_altaz_catalogues_and_pointing_centre_roi():
+    sky = W.point_source_sky(5000, 7, alt_min_deg=-60.0) if False else W.point_source_sky(5000, 7)
+    lat = 12.5
+    rng = NP.random.default_rng(11)
+    hadec = NP.stack((rng.uniform(-180, 180, 4000), NP.degrees(NP.arcsin(rng.uniform(-1, 1, 4000)))), axis=1)
+    with _abi.Context(0) as ctx:
+        ctx.set_array(NP.array([[14.6, 0.0, 0.0]]), W.channel_grid(150e6, 1e5, 8), nt_max=1)
+        # HA-Dec catalogue: the LST plays no role
+        ctx.set_catalog(hadec, 'hadec', flux_ref=NP.ones(4000), spindex=NP.zeros(4000), ref_freq_hz=150e6)
+        obs = ctx.make_obs(lat, roi_radius_deg=90.0)
+        idx, dc = ctx.catalog_roi(obs, 123.0, ZEN)
+        m2, dc_host, _ = host_roi(hadec, lat, 0.0, 90.0, coords='hadec')
+        assert NP.array_equal(idx, m2)
+        _check_dircos(dc, dc_host, GEOM.hadec2altaz(hadec[m2], lat, units='degrees'), 'hadec')
+        # alt-az catalogue: mask and direction cosines straight from the positions
+        ctx.set_catalog(sky['altaz'], 'altaz', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'])
+        obs = ctx.make_obs(lat, roi_radius_deg=40.0)
+        idx, dc = ctx.catalog_roi(obs, 0.0, ZEN)
+        m2, dc_host, _ = host_roi(sky['altaz'], lat, 0.0, 40.0, coords='altaz')
+        assert m2.size > 0 and NP.array_equal(idx, m2) and float(NP.max(NP.abs(dc - dc_host))) <= 2.5e-16
+        # region of interest about the pointing centre (:6210-6213)
+        pc = GEOM.altaz2dircos(NP.array([55.0, 130.0]), 'degrees').ravel()
+        obs = ctx.make_obs(lat, roi_radius_deg=25.0, roi_center='pointing_center')
+        idx, dc = ctx.catalog_roi(obs, 0.0, pc)
+        dc_all = GEOM.altaz2dircos(sky['altaz'], 'degrees')
+        ang = NP.degrees(NP.arccos(NP.clip(NP.dot(dc_all, pc), -1.0, 1.0)))
+        m2 = NP.where(ang <= 25.0)[0]
+        # (the dot product is BLAS on the host: sources within 1e-12 deg of the rim may differ)
+        rim = NP.abs(ang - 25.0) < 1e-12
+        assert m2.size > 0 and NP.array_equal(NP.setdiff1d(idx, NP.where(rim)[0]), NP.setdiff1d(m2, NP.where(rim)[0]))
+
+
+def _oracle_scale(pb):
+    return NP.sum(NP.abs(pb), axis=0)[None, :]
+
+
+def test_visibilities_through_the_catalogue_path_match_the_uploaded_path_and_the_oracle():
+    """config-2-shaped drift scan in fp64 and fp32: set_sky_from_catalog + compute against set_sky_analytic of the host-formed sky
+    (the same kernels behind both) and against the C oracle."""
+    from oracle import c_oracle as CO, beams_oracle as BO
+    cfg = W.config2()
+    lat, lst0 = -30.7224, 40.0
+    sky = cfg['sky']
+    radec = radec_catalogue(sky, lat, lst0)
+    ch = cfg['channels']
+    with _abi.Context(0) as ctx, _abi.Context(0) as ref:
+        for c in (ctx, ref):
+            c.set_array(cfg['baselines'], ch, nt_max=1)
+        ctx.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=14.0)
+        for lst in (40.0, 47.5, 139.0):
+            n = ctx.set_sky_from_catalog(obs, lst, ZEN, ZEN)
+            m2, dc, altaz = host_roi(radec, lat, lst)
+            assert n == m2.size
+            ref.set_sky_analytic(dc, sky['flux_ref'][m2], sky['spindex'][m2], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, 14.0, ZEN, ZEN,
+                                 fwhm_deg=sky['fwhm_deg'][m2])
+            pb_dev, pb_ref = ctx.get_pbflux(), ref.get_pbflux()
+            assert float(NP.max(NP.abs(pb_dev - pb_ref) / NP.max(NP.abs(pb_ref)))) <= 1e-13
+            for prec, tol in ((_abi.PRISIM_FP64, 1e-11), (_abi.PRISIM_FP32, 5e-6)):
+                ctx.compute(precision=prec)
+                ref.compute(precision=prec)
+                v, vr = ctx.get_vis(), ref.get_vis()
+                scale = _oracle_scale(pb_ref)
+                assert float(NP.max(NP.abs(v - vr) / scale)) <= (1e-13 if prec == _abi.PRISIM_FP64 else 5e-7)
+                if lst == 47.5:
+                    vo = CO.skyvis(cfg['baselines'], ch, dc, pb_ref, ZEN, fwhm_deg=sky['fwhm_deg'][m2])
+                    assert float(NP.max(NP.abs(v - vo) / scale)) <= tol
+
+
+def test_culling_order_and_table_on_the_device_config4_shape():
+    """Long baselines over nside-64 pixels (config 4's shape, a 1/8 baseline shard): the catalogue path sorts every run by altitude and
+    builds the cull table on the device; the result must agree with the uploaded path (host order + host table) within the fp32
+    tolerance, cull about as much, and agree with the oracle that sums everything."""
+    from oracle import c_oracle as CO
+    cfg = W.config4(n_acc=1)
+    lat, lst0 = cfg['latitude'], 0.0
+    sky = cfg['sky']
+    radec = radec_catalogue(sky, lat, lst0)
+    bl = cfg['baselines'][3::8]
+    ch = cfg['channels'][:128]
+    with _abi.Context(0) as ctx, _abi.Context(0) as ref:
+        for c in (ctx, ref):
+            c.set_array(bl, ch, nt_max=1)
+        ctx.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=4.0)
+        for lst in (0.0, 3.3):
+            n = ctx.set_sky_from_catalog(obs, lst, ZEN, ZEN)
+            m2, dc, altaz = host_roi(radec, lat, lst)
+            assert n == m2.size
+            order = NP.argsort(-altaz[:, 0], kind='stable')          # what InterferometerArray._cull_order hands the uploaded path
+            ref.set_sky_analytic(dc[order], sky['flux_ref'][m2][order], sky['spindex'][m2][order], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, 4.0,
+                                 ZEN, ZEN, fwhm_deg=sky['fwhm_deg'][m2][order])
+            for prec, tol in ((_abi.PRISIM_FP32, 5e-6), (_abi.PRISIM_FP64, 1e-11)):
+                ctx.compute(precision=prec)
+                ref.compute(precision=prec)
+                v, vr = ctx.get_vis(), ref.get_vis()
+                td, tr = ctx.timing(), ref.timing()
+                assert tr['last_culled_fraction'] > 0.05, tr
+                assert abs(td['last_culled_fraction'] - tr['last_culled_fraction']) <= 0.01 * tr['last_culled_fraction'] + 1e-6, (td, tr)
+                pb = ref.get_pbflux()
+                scale = _oracle_scale(pb)
+                assert float(NP.max(NP.abs(v - vr) / scale)) <= tol
+            sel = NP.arange(0, bl.shape[0], 97)
+            vo = CO.skyvis(bl[sel], ch, dc[order], pb, ZEN, fwhm_deg=sky['fwhm_deg'][m2][order])
+            assert float(NP.max(NP.abs(v[sel] - vo) / scale)) <= 1e-11
+
+
+def test_tabulated_spectra_and_external_beam_through_the_index_list():
+    """A catalogue with flux spectra (nsrc x nchan table, catalogue order) and the external HEALPix beam: both are read through the
+    compacted index list on the device."""
+    cfg = W.config4(n_acc=1)
+    lat, lst0 = cfg['latitude'], 20.0
+    sky = W.diffuse_sky(16, 5, f_ref=185e6)
+    radec = radec_catalogue(sky, lat, lst0)
+    bl = cfg['baselines'][::200]
+    ch = cfg['channels'][:64]
+    rng = NP.random.default_rng(5)
+    spec = sky['flux_ref'][:, None] * (ch[None, :] / sky['ref_freq']) ** sky['spindex'][:, None] * rng.uniform(0.9, 1.1, (radec.shape[0], ch.size))
+    from prisim_amd import primary_beams as PB
+    m = PB.spectral_interp_matrix(cfg['beam_freqs'], ch, kind='cubic', chromatic=True, select_freq=None)
+    with _abi.Context(0) as ctx, _abi.Context(0) as ref:
+        for c in (ctx, ref):
+            c.set_array(bl, ch, nt_max=1)
+            c.set_external_beam(cfg['beam_table'], m)
+        ctx.set_catalog(radec, 'radec', flux_spectrum=spec, fwhm_deg=sky['fwhm_deg'])
+        obs = ctx.make_obs(lat, use_external_beam=True)
+        for lst in (27.0, 41.0):
+            n = ctx.set_sky_from_catalog(obs, lst, ZEN, ZEN)
+            m2, dc, altaz = host_roi(radec, lat, lst)
+            assert n == m2.size and 0 < n < radec.shape[0]
+            # (kilometre baselines over 3.7-degree pixels: the catalogue path lists the sources by decreasing altitude, like
+            # InterferometerArray._cull_order does for the uploaded path)
+            order = NP.argsort(-altaz[:, 0], kind='stable')
+            m2, dc = m2[order], dc[order]
+            ref.set_sky_external(dc, spec[m2], ZEN, fwhm_deg=sky['fwhm_deg'][m2])
+            pb_dev, pb_ref = ctx.get_pbflux(), ref.get_pbflux()
+            assert float(NP.max(NP.abs(pb_dev - pb_ref) / NP.max(NP.abs(pb_ref)))) <= 1e-6      # (float32 beam storage, :4466)
+            ctx.compute(precision=_abi.PRISIM_FP64)
+            ref.compute(precision=_abi.PRISIM_FP64)
+            scale = _oracle_scale(pb_ref)
+            assert float(NP.max(NP.abs(ctx.get_vis() - ref.get_vis()) / scale)) <= 5e-6
+
+
+def test_observe_catalog_many_snapshots_equals_one_by_one():
+    """prisim_hip_observe_catalog (K snapshots, one geometry pass, no host synchronisation between snapshots) leaves in slots
+    slot0 ... slot0 + K - 1 exactly what K calls of set_sky_from_catalog + compute leave."""
+    cfg = W.config2()
+    lat, lst0 = -30.7224, 10.0
+    sky = cfg['sky']
+    radec = radec_catalogue(sky, lat, lst0)
+    lsts = 10.0 + 0.25 * NP.arange(7)
+    bl = NP.vstack((cfg['baselines'], cfg['baselines'] * 1.7))[:300]          # two baseline groups: the per-snapshot loop, not wave items
+    with _abi.Context(0) as ctx, _abi.Context(0) as one:
+        ctx.set_array(bl, cfg['channels'], nt_max=8)
+        one.set_array(bl, cfg['channels'], nt_max=1)
+        for c in (ctx, one):
+            c.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=14.0)
+        counts = ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP64, slot0=1)
+        for t, lst in enumerate(lsts):
+            n = one.set_sky_from_catalog(obs, lst, ZEN, ZEN)
+            assert n == counts[t]
+            one.compute(precision=_abi.PRISIM_FP64)
+            assert NP.array_equal(ctx.get_vis(slot=1 + t), one.get_vis())
+
+
+def test_catalogue_path_state_errors():
+    with _abi.Context(0) as ctx:
+        ctx.set_array(NP.array([[14.6, 0.0, 0.0]]), W.channel_grid(150e6, 1e5, 8), nt_max=1)
+        obs = ctx.make_obs(-30.0)
+        with pytest.raises(RuntimeError):
+            ctx.set_sky_from_catalog(obs, 0.0, ZEN)                  # no catalogue yet
+        ctx.set_catalog(NP.zeros((0, 2)), 'radec', flux_ref=NP.zeros(0), spindex=NP.zeros(0), ref_freq_hz=150e6)
+        assert ctx.set_sky_from_catalog(obs, 0.0, ZEN) == 0          # an empty catalogue is a valid (empty) sky (:6378-6382)
+        ctx.compute()
+        assert NP.all(ctx.get_vis() == 0)
+        ctx.set_catalog(NP.array([[10.0, -30.0]]), 'radec', flux_ref=NP.ones(1), spindex=NP.zeros(1), ref_freq_hz=150e6)
+        ctx.set_array(NP.array([[14.6, 0.0, 0.0]]), W.channel_grid(150e6, 1e5, 8), nt_max=1)
+        with pytest.raises(RuntimeError):
+            ctx.set_sky_from_catalog(obs, 10.0, ZEN)                 # set_array drops the catalogue
+        with pytest.raises(ValueError):
+            ctx.set_catalog(NP.array([[NP.nan, 0.0]]), 'radec', flux_ref=NP.ones(1), spindex=NP.zeros(1), ref_freq_hz=150e6)
