@@ -252,13 +252,24 @@ int prisim_hip_set_sky_from_catalog(prisim_ctx* ctx, const prisim_obs* obs, cons
 int prisim_hip_catalog_roi(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snap, int64_t* nsrc_roi, int64_t* indices,
                            double* dircos, int64_t cap);
 
+/* What follows every snapshot of prisim_hip_observe_catalog, queued behind that snapshot's sky-sum (on the copy / communication stream,
+ * i.e. under the next snapshot's sky-sum). */
+typedef struct prisim_post {
+  void* host_vis;               /* page-locked host cube [nt_max][nbl][nchan] (prisim_hip_host_alloc) or NULL: slot t is downloaded into
+                                   host_vis + t * nbl * nchan * (host_is_c64 ? 8 : 16) bytes (prisim_hip_get_vis_async) */
+  int32_t host_is_c64;
+  int32_t gather;               /* 1: prisim_hip_allgather_slot_async(slot, gather_as_c64) */
+  int32_t gather_as_c64;
+  int32_t reserved_;
+} prisim_post;
+
 /* nsnap snapshots in one call: the geometry of all of them first (chunks of snapshots, ONE readback per chunk), then for snapshot t
  * sky + compute into cube slot slot0 + t, queued back to back without any host synchronisation on the compute stream.  Arrays of at
  * most 256 baselines in fp64 with the source-shape taper put the sky-sums of the whole chunk into ONE launch of the wave-item kernel
  * (the work item is (snapshot, baseline wave, channel tile, source split)) and ONE reduction.  Replaces the loop of
- * interferometry.py:6641-6647 / scripts/run_prisim.py:2165-2207.  nsrc_roi: [nsnap] or NULL. */
+ * interferometry.py:6641-6647 / scripts/run_prisim.py:2165-2207.  nsrc_roi: [nsnap] or NULL; post: NULL = nothing. */
 int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int precision,
-                               int want_grad, int64_t slot0, int64_t* nsrc_roi);
+                               int want_grad, int64_t slot0, int64_t* nsrc_roi, const prisim_post* post);
 
 /* ---- delay transform (follow-on stage, interferometry.py:8052-8137) ---------------------- */
 

@@ -128,6 +128,10 @@ class PrisimSnapshot(C.Structure):
     _fields_ = [('lst_deg', C.c_double), ('pc_dircos', C.c_double * 3), ('beam_pc_dircos', C.c_double * 3)]
 
 
+class PrisimPost(C.Structure):
+    _fields_ = [('host_vis', C.c_void_p), ('host_is_c64', C.c_int32), ('gather', C.c_int32), ('gather_as_c64', C.c_int32), ('reserved_', C.c_int32)]
+
+
 class PrisimTiming(C.Structure):
     _fields_ = [('last_kernel_ms', C.c_double), ('last_compute_ms', C.c_double), ('sum_kernel_ms', C.c_double),
                 ('n_kernel', C.c_int64), ('last_terms', C.c_int64), ('last_kernel_id', C.c_int32),
@@ -214,7 +218,7 @@ def load_library():
     lib.prisim_hip_set_catalog.argtypes = [vp, C.POINTER(PrisimCatalog)]
     lib.prisim_hip_set_sky_from_catalog.argtypes = [vp, C.POINTER(PrisimObs), C.POINTER(PrisimSnapshot), C.POINTER(i64)]
     lib.prisim_hip_catalog_roi.argtypes = [vp, C.POINTER(PrisimObs), C.POINTER(PrisimSnapshot), C.POINTER(i64), vp, vp, i64]
-    lib.prisim_hip_observe_catalog.argtypes = [vp, C.POINTER(PrisimObs), C.POINTER(PrisimSnapshot), i64, i32, i32, i64, vp]
+    lib.prisim_hip_observe_catalog.argtypes = [vp, C.POINTER(PrisimObs), C.POINTER(PrisimSnapshot), i64, i32, i32, i64, vp, C.POINTER(PrisimPost)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ('prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version'):
@@ -485,9 +489,12 @@ class Context(object):
                         'prisim_hip_catalog_roi')
         return idx, dc
 
-    def observe_catalog(self, obs, lst_deg, pc_dircos, beam_pc_dircos=None, precision=PRISIM_FP64, want_grad=False, slot0=0):
+    def observe_catalog(self, obs, lst_deg, pc_dircos, beam_pc_dircos=None, precision=PRISIM_FP64, want_grad=False, slot0=0,
+                        host_cube=None, gather=None):
         """K snapshots of the resident catalogue in one call (prisim_hip_observe_catalog): lst_deg (K,), pc_dircos (K, 3) or (3,),
-        beam_pc_dircos likewise (default: pc_dircos).  Results land in cube slots slot0 ... slot0 + K - 1; returns the ROI counts (K,)."""
+        beam_pc_dircos likewise (default: pc_dircos).  Results land in cube slots slot0 ... slot0 + K - 1; returns the ROI counts (K,).
+        host_cube: page-locked (nt_max, nbl, nchan) complex128 / complex64 array (host_empty) every finished slot is downloaded into,
+        behind its sky-sum; gather: None, or 'c128' / 'c64' -- every finished slot is all-gathered on the communication stream."""
         lst = NP.asarray(lst_deg, dtype=NP.float64).ravel()
         k = lst.size
         pc = NP.broadcast_to(NP.asarray(pc_dircos, dtype=NP.float64).reshape(-1, 3), (k, 3))
@@ -498,8 +505,21 @@ class Context(object):
             snaps[t].pc_dircos[:] = pc[t].tolist()
             snaps[t].beam_pc_dircos[:] = bpc[t].tolist()
         counts = NP.zeros(k, dtype=NP.int64)
+        post = None
+        if host_cube is not None or gather is not None:
+            post = PrisimPost()
+            if host_cube is not None:
+                if host_cube.shape[1:] != (self.nbl, self.nchan) or host_cube.dtype not in (NP.complex128, NP.complex64) or not host_cube.flags['C_CONTIGUOUS']:
+                    raise ValueError('host_cube must be a C-contiguous (nt, nbl, nchan) complex128 / complex64 array')
+                if host_cube.shape[0] < slot0 + k:
+                    raise ValueError('host_cube has fewer snapshots than slot0 + K')
+                post.host_vis = host_cube.ctypes.data
+                post.host_is_c64 = 1 if host_cube.dtype == NP.complex64 else 0
+            if gather is not None:
+                post.gather, post.gather_as_c64 = 1, (1 if gather == 'c64' else 0)
+                self._gathered_c64 = gather == 'c64'
         self._check(self._lib.prisim_hip_observe_catalog(self._h, C.byref(obs), snaps, k, int(precision), 1 if want_grad else 0, int(slot0),
-                                                         _ptr(counts)), 'prisim_hip_observe_catalog')
+                                                         _ptr(counts), None if post is None else C.byref(post)), 'prisim_hip_observe_catalog')
         self.nsrc = int(counts[-1]) if k else 0
         return counts
 

@@ -290,14 +290,27 @@ void k_colmax_partial(const double* __restrict__ work, double* __restrict__ part
   }
 }
 
-__global__ void k_colmax_final(const double* __restrict__ partial, double* __restrict__ colmax, int nblk, int64_t nchan) {
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchan; c += (int64_t)gridDim.x * blockDim.x) {
-    double m = -INFINITY;
-    bool any = false;
-    for (int b = 0; b < nblk; ++b) {
+// colmax[c] = max(nan-ignoring maximum of the partial rows, 0).  32 channels x 8 row lanes per block: the partial rows are read
+// coalesced along the channel and 8 at a time (one thread per channel walking 1024 rows took 0.28 ms per snapshot at config 4).
+__global__ __launch_bounds__(256)
+void k_colmax_final(const double* __restrict__ partial, double* __restrict__ colmax, int nblk, int64_t nchan) {
+  __shared__ double sm[8][32];
+  __shared__ int sa[8][32];
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int64_t c = (int64_t)blockIdx.x * 32 + cx;
+  double m = -INFINITY;
+  bool any = false;
+  if (c < nchan) {
+    for (int b = py; b < nblk; b += 8) {
       const double v = partial[(int64_t)b * nchan + c];
       if (!isnan(v)) { m = any ? (v > m ? v : m) : v; any = true; }
     }
+  }
+  sm[py][cx] = m; sa[py][cx] = any ? 1 : 0;
+  __syncthreads();
+  if (py == 0 && c < nchan) {
+    for (int q = 1; q < 8; ++q)
+      if (sa[q][cx]) { m = any ? (sm[q][cx] > m ? sm[q][cx] : m) : sm[q][cx]; any = true; }
     m = any ? m : NAN;
     colmax[c] = (m <= 0.0) ? 0.0 : m;                   // run_prisim.py:2099-2100 (NaN stays NaN, as numpy's comparison leaves it)
   }
@@ -345,11 +358,11 @@ hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs
   if (nsrc == 0) return hipSuccess;
   const unsigned gs = (unsigned)(nsrc < 16384 ? nsrc : 16384);
   hipLaunchKernelGGL(k_extbeam_gather, dim3(gs), dim3(256), 0, stream, table, nside, dirs, work, nsrc, nchan);
-  const int nblk = (int)(nsrc < 1024 ? nsrc : 1024);
+  const int nblk = (int)(nsrc < 256 ? nsrc : 256);
   double* partial = colmax_scratch;
   double* colmax = colmax_scratch + (size_t)1024 * nchan;
   hipLaunchKernelGGL(k_colmax_partial, dim3(nblk), dim3(256), 0, stream, work, partial, nsrc, nchan);
-  hipLaunchKernelGGL(k_colmax_final, dim3(grid_for_(nchan)), dim3(256), 0, stream, partial, colmax, nblk, nchan);
+  hipLaunchKernelGGL(k_colmax_final, dim3((unsigned)((nchan + 31) / 32)), dim3(256), 0, stream, partial, colmax, nblk, nchan);
   hipLaunchKernelGGL(k_extbeam_finish, dim3(grid_for_(nsrc * nchan)), dim3(256), 0, stream, work, colmax, fluxes, flux_ref, spindex, freqs,
                      1.0 / ref_freq, pb_out, nsrc, nchan, src_index);
   return hipGetLastError();

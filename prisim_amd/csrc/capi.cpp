@@ -246,11 +246,18 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->fft_plan && g_rocfft.plan_destroy) g_rocfft.plan_destroy(ctx->fft_plan);
   if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
-  for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->lift_flags, &ctx->cube, &ctx->grad, &ctx->dirs,
-                    &ctx->dirs_prep, &ctx->dirs_c32, &ctx->pb, &ctx->packed, &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
+  for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->cube, &ctx->grad, &ctx->dirs,
+                    &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
-                    &ctx->dl_stage, &ctx->split_flags, &ctx->moments, &ctx->grp_hz, &ctx->split_count, &ctx->cull_first, &ctx->step_tab, &ctx->moments_part, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
+                    &ctx->dl_stage, &ctx->grp_hz, &ctx->step_tab, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
+  for (SkyBufs& k : ctx->skb) {
+    for (DevBuf* b : {&k.pb, &k.packed, &k.dirs_prep, &k.dirs_c32, &k.lift_flags, &k.split_flags, &k.moments, &k.moments_part, &k.split_count, &k.cull_first,
+                      &k.dirs_sorted, &k.idx_sorted})
+      release(*b);
+    if (k.ev_prep) (void)hipEventDestroy(k.ev_prep);
+    if (k.ev_sum) (void)hipEventDestroy(k.ev_sum);
+  }
   for (int i = 0; i < prisim_ctx::kTimingRing; ++i)
     for (hipEvent_t ev : {ctx->ev_c0[i], ctx->ev_c1[i], ctx->ev_k0[i], ctx->ev_k1[i]})
       if (ev) (void)hipEventDestroy(ev);
@@ -306,7 +313,8 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   ctx->grp_maxh.assign(ctx->grp_maxlen.size(), 0.0);
   ctx->grp_maxz.assign(ctx->grp_maxlen.size(), 0.0);
   ctx->grp_minh.assign(ctx->grp_maxlen.size(), 1e300);
-  ctx->lift_key_k = -1.0;                                  // the cached lifting flags belong to the previous array
+  ctx->fsq_pairs_ct = ctx->fsq_pairs_ntiles = -1;
+  for (SkyBufs& k : ctx->skb) k.lift_key_k = -1.0;             // the cached lifting flags belong to the previous array
   for (int64_t b = 0; b < nbl; ++b) {
     const double len = std::sqrt(x[b] * x[b] + y[b] * y[b] + z[b] * z[b]);
     const size_t g = (size_t)(b / kBlockThreads);
@@ -397,6 +405,11 @@ int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, const dou
   }
   if ((rc = ensure(ctx, ctx->dirs, d4_bytes))) return rc;
   HIPCHK(ctx, stage_send(ctx, ctx->dirs.p, d4, d4_bytes));
+  if (ctx->prep_async) {             // the previous sky was prepared on the preparation stream: let it drain, then back to one stream
+    HIPCHK(ctx, hipStreamSynchronize(ctx->prep_stream));
+    ctx->prep_async = false;
+  }
+  ctx->sk = &ctx->skb[0];
   ctx->dirs_p = static_cast<const double*>(ctx->dirs.p);       // an uploaded sky: no catalogue indirection
   ctx->src_index = nullptr;
   ctx->cat.cur = -1;
@@ -467,8 +480,8 @@ int upload_common(prisim_ctx* ctx, int64_t nsrc, const double* dircos, const dou
           }
         }
         if (ctx->cull_any[0] || ctx->cull_any[1]) {
-          if ((rc = ensure(ctx, ctx->cull_first, 2 * nruns * ng * sizeof(int32_t)))) return rc;
-          HIPCHK(ctx, stage_send(ctx, ctx->cull_first.p, tab, 2 * nruns * ng * sizeof(int32_t)));
+          if ((rc = ensure(ctx, ctx->sk->cull_first, 2 * nruns * ng * sizeof(int32_t)))) return rc;
+          HIPCHK(ctx, stage_send(ctx, ctx->sk->cull_first.p, tab, 2 * nruns * ng * sizeof(int32_t)));
           ctx->cull_nruns = (int)nruns;
           for (int pr = 0; pr < 2; ++pr) ctx->cull_frac[pr] = culled[pr] / ((double)nsrc * (double)ctx->nbl);
         }
@@ -511,19 +524,19 @@ int prisim_hip_set_sky(prisim_ctx* ctx, const prisim_sky* sky) {
   const size_t stage_extra = (pb_bytes <= kStageMaxBytes ? pb_bytes : 0) + (fl_bytes <= kStageMaxBytes ? fl_bytes : 0) + 1024;
   int rc = upload_common(ctx, sky->nsrc, sky->dircos, sky->pc_dircos, sky->fwhm_deg, stage_extra);
   if (rc) return rc;
-  if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->sk->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (n > 0) {
     if (sky->pbflux_is_f32) {
       if ((rc = ensure(ctx, ctx->sky_flux, (size_t)n * sizeof(float)))) return rc;
       if ((rc = upload_any(ctx, ctx->sky_flux.p, sky->pbflux, (size_t)n * sizeof(float), nullptr))) return rc;
-      HIPCHK(ctx, launch_f32_to_f64((const float*)ctx->sky_flux.p, (double*)ctx->pb.p, n, ctx->stream));
+      HIPCHK(ctx, launch_f32_to_f64((const float*)ctx->sky_flux.p, (double*)ctx->sk->pb.p, n, ctx->stream));
     } else {
-      if ((rc = upload_any(ctx, ctx->pb.p, sky->pbflux, (size_t)n * sizeof(double), nullptr))) return rc;
+      if ((rc = upload_any(ctx, ctx->sk->pb.p, sky->pbflux, (size_t)n * sizeof(double), nullptr))) return rc;
     }
     if (sky->fluxes) {   // pbfluxes = pb * fluxes (:6254) on the device
       if ((rc = ensure(ctx, ctx->sky_sp, (size_t)n * sizeof(double)))) return rc;
       if ((rc = upload_any(ctx, ctx->sky_sp.p, sky->fluxes, (size_t)n * sizeof(double), nullptr))) return rc;
-      HIPCHK(ctx, launch_mul_inplace((double*)ctx->pb.p, (const double*)ctx->sky_sp.p, n, ctx->stream));
+      HIPCHK(ctx, launch_mul_inplace((double*)ctx->sk->pb.p, (const double*)ctx->sky_sp.p, n, ctx->stream));
     }
   }
   stage_end(ctx);
@@ -573,7 +586,7 @@ size_t beamformer_doubles(const prisim_beam_ext* ext) {
   return (size_t)bf_n * 3 + 2 * (size_t)bf_n * bf_r;
 }
 
-// pbflux[s][f] = beam(dirs_p[s], f) x flux(src_index ? src_index[s] : s, f) of the current sky (ns sources) into ctx->pb.  The flux
+// pbflux[s][f] = beam(dirs_p[s], f) x flux(src_index ? src_index[s] : s, f) of the current sky (ns sources) into ctx->sk->pb.  The flux
 // pointers are device arrays (power law: d_flux_ref / d_spindex; tabulated: d_flux_spec).  A beamformer's element arrays (host, in ext)
 // are sent through the OPEN staging group (the caller ran stage_begin with room for beamformer_doubles(ext) doubles and ends it).
 int sky_beam_flux(prisim_ctx* ctx, int64_t ns, int beam_kind, double diameter_m, const double* beam_pc_dircos, const prisim_beam_ext* ext,
@@ -620,17 +633,17 @@ int sky_beam_flux(prisim_ctx* ctx, int64_t ns, int beam_kind, double diameter_m,
     for (int i = 0; i < 4; ++i) bp.poly[i] = ext->poly_coef[i];
   bp.flag = (int32_t*)ctx->sky_flag.p;
   bp.nsrc = ns; bp.nchan = ctx->nchan;
-  bp.pb_out = (double*)ctx->pb.p;
-  HIPCHK(ctx, hipMemsetAsync(ctx->sky_flag.p, 0, sizeof(int32_t), ctx->stream));
-  HIPCHK(ctx, launch_beam_flux(bp, ctx->stream));
+  bp.pb_out = (double*)ctx->sk->pb.p;
+  HIPCHK(ctx, hipMemsetAsync(ctx->sky_flag.p, 0, sizeof(int32_t), pstream(ctx)));
+  HIPCHK(ctx, launch_beam_flux(bp, pstream(ctx)));
   return PRISIM_OK;
 }
 
 // only the polynomial beams can trip the reference's validity checks (:510-512, :802-807): the one case that reads back
 int check_poly_beam_flag(prisim_ctx* ctx) {
   int32_t hflag = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&hflag, ctx->sky_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(&hflag, ctx->sky_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, pstream(ctx)));
+  HIPCHK(ctx, hipStreamSynchronize(pstream(ctx)));
   if (hflag & 2)
     return fail(ctx, PRISIM_EINVAL, "Primary beam values were found to be NaN in some case(s). Check if the polynomial equations are valid for the frequencies specified.");
   if (hflag & 1)
@@ -660,7 +673,7 @@ int prisim_hip_set_sky_analytic(prisim_ctx* ctx, const prisim_beam_sky* sky) {
   const size_t stage_extra = (frb <= kStageMaxBytes ? frb : 0) + (size_t)ns * sizeof(double) + beamformer_doubles(sky->ext) * sizeof(double) + 4096;
   rc = upload_common(ctx, ns, sky->dircos, sky->pc_dircos, sky->fwhm_deg, stage_extra);
   if (rc) return rc;
-  if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->sk->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (ns > 0) {
     if ((rc = ensure(ctx, ctx->sky_flux, frb)) || (rc = ensure(ctx, ctx->sky_sp, (size_t)ns * sizeof(double)))) return rc;
     if ((rc = upload_any(ctx, ctx->sky_flux.p, have_spec ? sky->flux_spectrum : sky->flux_ref, frb, nullptr))) return rc;
@@ -724,7 +737,7 @@ int extbeam_sky(prisim_ctx* ctx, int64_t nsrc, const double* d_fluxes, const dou
     return rc;
   HIPCHK(ctx, launch_extbeam_sky((const double*)ctx->ext_table.p, ctx->ext_nside, ctx->dirs_p, d_fluxes, d_flux_ref, d_spindex,
                                  (const double*)ctx->freqs.p, ref_freq, (double*)ctx->ext_work.p, (double*)ctx->ext_colmax.p,
-                                 (double*)ctx->pb.p, nsrc, ctx->nchan, ctx->stream, src_index));
+                                 (double*)ctx->sk->pb.p, nsrc, ctx->nchan, pstream(ctx), src_index));
   return PRISIM_OK;
 }
 }  // namespace pint
@@ -744,7 +757,7 @@ int prisim_hip_set_sky_external(prisim_ctx* ctx, const prisim_sky* sky) {
   const size_t fl_bytes = (size_t)std::max<int64_t>(n, 0) * sizeof(double);
   int rc = upload_common(ctx, sky->nsrc, sky->dircos, sky->pc_dircos, sky->fwhm_deg, (fl_bytes <= kStageMaxBytes ? fl_bytes : 0) + 1024);
   if (rc) return rc;
-  if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->sk->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (n > 0) {
     if ((rc = ensure(ctx, ctx->sky_flux, fl_bytes))) return rc;
     if ((rc = upload_any(ctx, ctx->sky_flux.p, sky->fluxes, fl_bytes, nullptr))) return rc;
@@ -774,7 +787,7 @@ int prisim_hip_set_sky_external_analytic(prisim_ctx* ctx, const prisim_beam_sky*
   int rc = upload_common(ctx, ns, sky->dircos, sky->pc_dircos, sky->fwhm_deg,
                          (frb <= kStageMaxBytes ? frb : 0) + (size_t)std::max<int64_t>(ns, 0) * sizeof(double) + 2048);
   if (rc) return rc;
-  if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->sk->pb, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
   if (ns > 0) {
     if ((rc = ensure(ctx, ctx->sky_flux, frb)) || (rc = ensure(ctx, ctx->sky_sp, (size_t)ns * sizeof(double)))) return rc;
     if ((rc = upload_any(ctx, ctx->sky_flux.p, have_spec ? sky->flux_spectrum : sky->flux_ref, frb, nullptr))) return rc;
@@ -797,7 +810,8 @@ int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int64_t n = ctx->nsrc * ctx->nchan;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (n > 0) HIPCHK(ctx, hipMemcpy(out, ctx->pb.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  if (ctx->prep_async) HIPCHK(ctx, hipStreamSynchronize(ctx->prep_stream));
+  if (n > 0) HIPCHK(ctx, hipMemcpy(out, ctx->sk->pb.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   return PRISIM_OK;
   });
 }
@@ -808,11 +822,11 @@ static void fill_params(prisim_ctx* ctx, const Plan& pl, SkyvisParams& p) {
   p.nbl = ctx->nbl; p.nchan = ctx->nchan;
   p.f0 = ctx->f0; p.df = ctx->df; p.inv_c = 1.0 / kC;
   p.dirs = ctx->dirs_p;
-  p.dirs_prep = (const double*)ctx->dirs_prep.p;
-  p.pb_packed = ctx->packed.p;
+  p.dirs_prep = (const double*)ctx->sk->dirs_prep.p;
+  p.pb_packed = ctx->sk->packed.p;
   p.fsq = (const float*)ctx->fsq.p;
   p.fsq_pairs = (const float*)ctx->fsq_pairs.p;
-  p.lift_flags = ctx->lift_flags.p ? (const int32_t*)ctx->lift_flags.p : nullptr;   // taper kernels: which groups need no re-anchoring
+  p.lift_flags = ctx->sk->lift_flags.p ? (const int32_t*)ctx->sk->lift_flags.p : nullptr;   // taper kernels: which groups need no re-anchoring
   p.fsq_scale = 1e16;
   p.nsrc = ctx->nsrc; p.nsrc_pad = pl.nsrc_pad;
   p.pc_x = ctx->pc[0]; p.pc_y = ctx->pc[1]; p.pc_z = ctx->pc[2];
@@ -868,31 +882,31 @@ static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams
   const int64_t nchan = ctx->nchan;
   const size_t nruns = ctx->kappa_runs.size();
   const size_t ng = ctx->grp_maxh.size();
-  if ((size_t)pl.nbgroups != ng || !ctx->lift_flags.p) return false;
-  if (ensure(ctx, ctx->moments, (size_t)4 * nchan * sizeof(double) * nruns) != PRISIM_OK) return false;
-  if (ensure(ctx, ctx->split_flags, nruns * ng * sizeof(int32_t)) != PRISIM_OK) return false;
-  if (ensure(ctx, ctx->split_count, 8 * sizeof(int32_t)) != PRISIM_OK) return false;
+  if ((size_t)pl.nbgroups != ng || !ctx->sk->lift_flags.p) return false;
+  if (ensure(ctx, ctx->sk->moments, (size_t)4 * nchan * sizeof(double) * nruns) != PRISIM_OK) return false;
+  if (ensure(ctx, ctx->sk->split_flags, nruns * ng * sizeof(int32_t)) != PRISIM_OK) return false;
+  if (ensure(ctx, ctx->sk->split_count, 8 * sizeof(int32_t)) != PRISIM_OK) return false;
   if (!ctx->h_split_count && hipHostMalloc((void**)&ctx->h_split_count, 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
     ctx->h_split_count = nullptr;
     return false;
   }
   // moments -> flags entirely on the stream: no download, so a snapshot's launches never wait for the previous snapshot's sky-sum
-  if (hipMemsetAsync(ctx->split_count.p, 0, 8 * sizeof(int32_t), ctx->stream) != hipSuccess) return false;
+  if (hipMemsetAsync(ctx->sk->split_count.p, 0, 8 * sizeof(int32_t), pstream(ctx)) != hipSuccess) return false;
   for (size_t r = 0; r < nruns; ++r) {
     const auto& run = ctx->kappa_runs[r];
     if (run.kappa <= 0.0) continue;
-    double* mom = (double*)ctx->moments.p + r * (size_t)4 * nchan;
-    if (ensure(ctx, ctx->moments_part, (size_t)taper_moments_chunks(run.lo, run.hi) * 4 * nchan * sizeof(double)) != PRISIM_OK) return false;
-    if (launch_taper_moments((const double*)ctx->pb.p, ctx->dirs_p, run.lo, run.hi, nchan, (double*)ctx->moments_part.p, mom,
-                             ctx->stream) != hipSuccess)
+    double* mom = (double*)ctx->sk->moments.p + r * (size_t)4 * nchan;
+    if (ensure(ctx, ctx->sk->moments_part, (size_t)taper_moments_chunks(run.lo, run.hi) * 4 * nchan * sizeof(double)) != PRISIM_OK) return false;
+    if (launch_taper_moments((const double*)ctx->sk->pb.p, ctx->dirs_p, run.lo, run.hi, nchan, (double*)ctx->sk->moments_part.p, mom,
+                             pstream(ctx)) != hipSuccess)
       return false;
     const double c16 = 16.0 * run.kappa * (ctx->df / kC) * (ctx->df / kC);
-    if (launch_split_flags(mom, nchan, (const double*)ctx->grp_hz.p, (const double*)ctx->grp_hz.p + ng, (const int32_t*)ctx->lift_flags.p, (int)ng, c16,
-                           2.0e-7, (int32_t*)ctx->split_flags.p + r * ng, (int32_t*)ctx->split_count.p + r, ctx->stream) != hipSuccess)
+    if (launch_split_flags(mom, nchan, (const double*)ctx->grp_hz.p, (const double*)ctx->grp_hz.p + ng, (const int32_t*)ctx->sk->lift_flags.p, (int)ng, c16,
+                           2.0e-7, (int32_t*)ctx->sk->split_flags.p + r * ng, (int32_t*)ctx->sk->split_count.p + r, pstream(ctx)) != hipSuccess)
       return false;
   }
   // the counts travel to pinned host memory behind the flags kernels; get_timing reads them after the compute's events have completed
-  if (hipMemcpyAsync(ctx->h_split_count, ctx->split_count.p, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+  if (hipMemcpyAsync(ctx->h_split_count, ctx->sk->split_count.p, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, pstream(ctx)) != hipSuccess) return false;
   ctx->split_count_runs = (int)nruns;
   return true;
 }
@@ -913,8 +927,9 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   p.scale_comp = scale_comp;
   if (pl.kernel == PRISIM_KERNEL_DIRECT) {
     p.out = dst;
+    if (prep) { int rcj = join_prep(ctx); if (rcj) return rcj; }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
-    HIPCHK(ctx, launch_skyvis_direct(p, (const double*)ctx->freqs.p, (const double*)ctx->pb.p,
+    HIPCHK(ctx, launch_skyvis_direct(p, (const double*)ctx->freqs.p, (const double*)ctx->sk->pb.p,
                                      scale_comp >= 0 ? ctx->dirs_p : nullptr, ctx->stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ctx->ring_head], ctx->stream));
     return PRISIM_OK;
@@ -925,15 +940,16 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   bool g64 = !pl.f32 && ctx->taper && (pl.ct == 16 || pl.ct == 32);
   if (const char* env = getenv("PRISIM_HIP_TAPER_F64_GROUP")) g64 = g64 && atoi(env) != 0;
   if (prep && scale_comp < 0)      // the snapshot's first pass: rows and directions in one launch
-    HIPCHK(ctx, launch_pack_prep((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
-                                 g64 ? 0 : 1, ctx->dirs_p, (double*)ctx->dirs_prep.p, ctx->pc[0], ctx->pc[1], ctx->pc[2],
-                                 1.0 / kC, ctx->stream));
+    HIPCHK(ctx, launch_pack_prep((const double*)ctx->sk->pb.p, ctx->sk->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
+                                 g64 ? 0 : 1, ctx->dirs_p, (double*)ctx->sk->dirs_prep.p, ctx->pc[0], ctx->pc[1], ctx->pc[2],
+                                 1.0 / kC, pstream(ctx)));
   else
-    HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
+    HIPCHK(ctx, launch_pack((const double*)ctx->sk->pb.p, ctx->sk->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct,
                             pl.ntiles, ctx->dirs_p, scale_comp, g64 ? 0 : 1, ctx->stream));
   // Packed fp32 taper on a sky whose sources come in a few runs of one size each (every HEALPix sky; point sources + diffuse): the
   // split form, run by run (skyvis_kernels.hip: TGROUP 2 / 3) -- size-0 runs take the plain (no-taper) bodies.
   const bool split = scale_comp < 0 && taper_split_plan(ctx, pl, p);
+  if (prep) { int rcj = join_prep(ctx); if (rcj) return rcj; }      // rows, directions, flags are ready: the sums run on the compute stream
   // Run by run under a SOURCE SPLIT (baseline shards of a mixed sky: point sources + a diffuse map): every run is cut into nsplit pieces
   // of its own and writes its own set of nsplit partial cubes; k_reduce_partials then sums nruns x nsplit of them, in fixed order.
   // (Before, a split sky of several runs fell back to ONE launch of the unsplit-form kernels over the whole sky: 510 ms against
@@ -961,10 +977,10 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   // taper culling: per baseline group the first source it still has to sum (tables staged by set_sky_*); a launch over the whole sky
   // can only skip the leading sources of the FIRST run
   const int cpr = pl.f32 ? 1 : 0;
-  const bool cull = (pl.pk || g64) && ctx->taper && ctx->cull_any[cpr] && ctx->cull_first.p && ctx->cull_nruns > 0 && !ctx->kappa_runs.empty() &&
+  const bool cull = (pl.pk || g64) && ctx->taper && ctx->cull_any[cpr] && ctx->sk->cull_first.p && ctx->cull_nruns > 0 && !ctx->kappa_runs.empty() &&
                     (size_t)pl.nbgroups == ctx->grp_maxlen.size();             // (the packed fp32 kernels and the grouped fp64 kernel)
   auto cull_table = [&](size_t r) {
-    return (const int32_t*)ctx->cull_first.p + ((size_t)cpr * ctx->cull_nruns + (size_t)ctx->kappa_runs[r].tab_row) * (size_t)pl.nbgroups;
+    return (const int32_t*)ctx->sk->cull_first.p + ((size_t)cpr * ctx->cull_nruns + (size_t)ctx->kappa_runs[r].tab_row) * (size_t)pl.nbgroups;
   };
   if (cull && !split) p.src_first = cull_table(0);
   ctx->timing.last_culled_fraction = cull ? ctx->cull_frac[cpr] : 0.0;
@@ -983,7 +999,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
       if (run.kappa > 0.0) {
         q.kappa0 = run.kappa;
         if (cull) q.src_first = cull_table(r);
-        q.split_flags = (const int32_t*)ctx->split_flags.p + r * (size_t)pl.nbgroups;
+        q.split_flags = (const int32_t*)ctx->sk->split_flags.p + r * (size_t)pl.nbgroups;
         HIPCHK(ctx, launch_skyvis_rec_f32pk_split(q, pl.ct, ctx->stream));
       } else {
         q.taper = 0;                                   // point sources: w = 1 (:6270 sigma = inf), the lifting / plain bodies
@@ -1029,7 +1045,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
         } else {
           // point sources (w = 1, :6270 sigma = inf): the fp64 kernel without the taper (6.2 instead of 9.8 instructions per term); its
           // rows are (up, down) pairs: this run's rows are re-packed in that layout
-          HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, false, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
+          HIPCHK(ctx, launch_pack((const double*)ctx->sk->pb.p, ctx->sk->packed.p, false, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
                                   ctx->dirs_p, scale_comp, 1, ctx->stream, run.lo, run.hi));
           q.taper = 0;
           q.src_first = nullptr;
@@ -1068,17 +1084,18 @@ static int run_grad_pass(prisim_ctx* ctx, const Plan& pl, double* dst, double* g
   if (pl.f32 && !ctx->taper) {
     // rows pre-multiplied by the gradient coefficients (1, l, m, n): 64 floats per (source, 16-channel tile)
     int rc2;
-    if ((rc2 = ensure(ctx, ctx->packed, (size_t)pl.ntiles * pl.nsrc_pad * 64 * sizeof(float)))) return rc2;
-    p.pb_packed = ctx->packed.p;
-    HIPCHK(ctx, launch_pack_grad((const double*)ctx->pb.p, (float*)ctx->packed.p, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ntiles,
-                                 ctx->dirs_p, ctx->stream));
+    if ((rc2 = ensure(ctx, ctx->sk->packed, (size_t)pl.ntiles * pl.nsrc_pad * 64 * sizeof(float)))) return rc2;
+    p.pb_packed = ctx->sk->packed.p;
+    HIPCHK(ctx, launch_pack_grad((const double*)ctx->sk->pb.p, (float*)ctx->sk->packed.p, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ntiles,
+                                 ctx->dirs_p, pstream(ctx)));
   } else {
-    HIPCHK(ctx, launch_pack((const double*)ctx->pb.p, ctx->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
-                            ctx->dirs_p, -1, 1, ctx->stream));
+    HIPCHK(ctx, launch_pack((const double*)ctx->sk->pb.p, ctx->sk->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
+                            ctx->dirs_p, -1, 1, pstream(ctx)));
   }
+  { int rcj = join_prep(ctx); if (rcj) return rcj; }
   HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
   if (pl.f32) {
-    p.dirs_c32 = (const float*)ctx->dirs_c32.p;
+    p.dirs_c32 = (const float*)ctx->sk->dirs_c32.p;
     HIPCHK(ctx, launch_skyvis_grad_f32(p, ctx->stream));
   } else {
     p.nbgroups = (int)((ctx->nbl + 63) / 64);      // the MFMA kernel's blocks own 64 baselines; lift flags stay per 256 (it reads [group >> 2])
@@ -1140,8 +1157,8 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   ctx->timing.last_culled_fraction = 0.0;
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE) {
     const size_t pbytes = (size_t)pl.ntiles * pl.nsrc_pad * pl.ct * (pl.f32 ? 4 : 8);
-    if ((rc = ensure(ctx, ctx->packed, pbytes))) return rc;
-    if ((rc = ensure(ctx, ctx->dirs_prep, (size_t)pl.nsrc_pad * 4 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->sk->packed, pbytes))) return rc;
+    if ((rc = ensure(ctx, ctx->sk->dirs_prep, (size_t)pl.nsrc_pad * 4 * sizeof(double)))) return rc;
     // (a sky of several runs of one source size writes one set of partial cubes per run: run_pass)
     const size_t part_sets = (ctx->taper && ctx->kappa_runs.size() > 1 && ctx->kappa_runs.size() <= (size_t)kMaxRunSets) ? ctx->kappa_runs.size() : 1;
     if (pl.nsplit > 1 && (rc = ensure(ctx, ctx->partial, part_sets * (size_t)pl.nsplit * slot_elems * sizeof(double)))) return rc;
@@ -1151,15 +1168,15 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
       // |theta| = |b . (s - s_pc)| |df| / c <= max|b| * max_s|s - s_pc| * |df| / c
       const double k = ctx->dmax * std::fabs(ctx->df) / kC;
       const double lift_limit = (pl.f32 ? 0.125 : 0.25) * (1.0 - 1e-9);
-      if (k != ctx->lift_key_k || (int)pl.f32 != ctx->lift_key_f32 || ctx->lift_groups != pl.nbgroups) {
+      if (k != ctx->sk->lift_key_k || (int)pl.f32 != ctx->sk->lift_key_f32 || ctx->sk->lift_groups != pl.nbgroups) {
         // formed on the device from the groups' longest baselines (resident since set_array): max|s - s_pc| changes with every snapshot
         // of a drift scan, and a host-side table would need a stream synchronisation before it could be rewritten
-        if ((rc = ensure(ctx, ctx->lift_flags, (size_t)pl.nbgroups * sizeof(int32_t)))) return rc;
-        HIPCHK(ctx, launch_lift_flags((const double*)ctx->grp_hz.p + 2 * ctx->grp_maxlen.size(), k, lift_limit, (int32_t*)ctx->lift_flags.p,
-                                      pl.nbgroups, ctx->stream));
-        ctx->lift_key_k = k;
-        ctx->lift_key_f32 = (int)pl.f32;
-        ctx->lift_groups = pl.nbgroups;
+        if ((rc = ensure(ctx, ctx->sk->lift_flags, (size_t)pl.nbgroups * sizeof(int32_t)))) return rc;
+        HIPCHK(ctx, launch_lift_flags((const double*)ctx->grp_hz.p + 2 * ctx->grp_maxlen.size(), k, lift_limit, (int32_t*)ctx->sk->lift_flags.p,
+                                      pl.nbgroups, pstream(ctx)));
+        ctx->sk->lift_key_k = k;
+        ctx->sk->lift_key_f32 = (int)pl.f32;
+        ctx->sk->lift_groups = pl.nbgroups;
       }
       int nlift = 0;
       for (int g = 0; g < pl.nbgroups; ++g) nlift += (ctx->grp_maxlen[(size_t)g] * k <= lift_limit) ? 1 : 0;
@@ -1169,18 +1186,21 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     }
     if (pl.f32 && ctx->taper) {
       if ((rc = ensure(ctx, ctx->fsq_pairs, (size_t)pl.ntiles * pl.ct * sizeof(float)))) return rc;
-      HIPCHK(ctx, launch_fsq_pairs((const float*)ctx->fsq.p, (float*)ctx->fsq_pairs.p, pl.ct, pl.ntiles, ctx->stream));
+      if (ctx->fsq_pairs_ct != pl.ct || ctx->fsq_pairs_ntiles != pl.ntiles) {      // (a function of the tiling only: once per plan)
+        HIPCHK(ctx, launch_fsq_pairs((const float*)ctx->fsq.p, (float*)ctx->fsq_pairs.p, pl.ct, pl.ntiles, ctx->stream));
+        ctx->fsq_pairs_ct = pl.ct; ctx->fsq_pairs_ntiles = pl.ntiles;
+      }
     }
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev_c0[ctx->ring_head], ctx->stream));
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE && fused_grad) {
     float* c32 = nullptr;
     if (pl.f32) {
-      if ((rc = ensure(ctx, ctx->dirs_c32, (size_t)pl.nsrc_pad * 8 * sizeof(float)))) return rc;
-      c32 = (float*)ctx->dirs_c32.p;
+      if ((rc = ensure(ctx, ctx->sk->dirs_c32, (size_t)pl.nsrc_pad * 8 * sizeof(float)))) return rc;
+      c32 = (float*)ctx->sk->dirs_c32.p;
     }
-    HIPCHK(ctx, launch_prep_dirs(ctx->dirs_p, (double*)ctx->dirs_prep.p, c32, ctx->nsrc, pl.nsrc_pad, ctx->pc[0],
-                                 ctx->pc[1], ctx->pc[2], 1.0 / kC, ctx->stream));
+    HIPCHK(ctx, launch_prep_dirs(ctx->dirs_p, (double*)ctx->sk->dirs_prep.p, c32, ctx->nsrc, pl.nsrc_pad, ctx->pc[0],
+                                 ctx->pc[1], ctx->pc[2], 1.0 / kC, pstream(ctx)));
   }
   if (fused_grad) {
     if ((rc = run_grad_pass(ctx, pl, dst, (double*)ctx->grad.p + (size_t)slot * 3 * slot_elems))) return rc;
@@ -1194,6 +1214,10 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     }
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev_c1[ctx->ring_head], ctx->stream));
+  if (ctx->prep_async) {
+    HIPCHK(ctx, hipEventRecord(ctx->sk->ev_sum, ctx->stream));
+    ctx->sk->sum_recorded = true;
+  }
   catalog_after_compute(ctx);
   ctx->ring_head = (ctx->ring_head + 1) % prisim_ctx::kTimingRing;
   ctx->ring_pending += 1;
@@ -1268,6 +1292,7 @@ int prisim_hip_sync(prisim_ctx* ctx) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->prep_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->prep_stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->comm_stream && ctx->comm_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
   if (ctx->copy_stream && ctx->copy_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream)); ctx->copy_pending = false; }

@@ -24,6 +24,11 @@ int cat_runtime(prisim_ctx* ctx, int64_t nsnap) {
       C.gstream = nullptr;
       HIPCHK(ctx, hipStreamCreateWithFlags(&C.gstream, hipStreamNonBlocking));
     }
+    ctx->prep_stream = C.gstream;
+    for (SkyBufs& k : ctx->skb) {
+      HIPCHK(ctx, hipEventCreateWithFlags(&k.ev_prep, hipEventDisableTiming));
+      HIPCHK(ctx, hipEventCreateWithFlags(&k.ev_sum, hipEventDisableTiming));
+    }
     HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_geom, hipEventDisableTiming));
     for (auto& s : C.set) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming));
     if (hipHostMalloc((void**)&C.culled_host, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
@@ -141,6 +146,22 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
   if (N < 0 || N > C.n) return fail(ctx, PRISIM_EINTERNAL, "catalogue geometry returned an impossible source count");
   int rc;
   ctx->sky_set = false;
+  // Preparation stream and buffer set.  The sky of snapshot t+1 (altitude sort, cull table, beam x flux, and compute()'s packing) is
+  // prepared on the geometry stream into the set the sky-sum of snapshot t is NOT reading, so that it runs under that sky-sum; a
+  // beamformer's per-snapshot host arrays go through the compute stream's staging area, so such skies stay on the one stream.
+  bool async = beamformer_doubles(obs->use_external_beam ? nullptr : obs->ext) == 0;
+  if (const char* env = getenv("PRISIM_HIP_PREP_ASYNC")) async = async && atoi(env) != 0;      // A/B hook
+  if (async) {
+    ctx->sk = &ctx->skb[ctx->sk_next];
+    ctx->sk_next ^= 1;
+    ctx->prep_async = true;
+    if (ctx->sk->sum_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->prep_stream, ctx->sk->ev_sum, 0));
+  } else {
+    if (ctx->prep_async) HIPCHK(ctx, hipStreamSynchronize(ctx->prep_stream));
+    ctx->prep_async = false;
+    ctx->sk = &ctx->skb[0];
+  }
+  const hipStream_t ps = pstream(ctx);
   ctx->nsrc = N;
   ctx->taper = C.have_shape;
   for (int i = 0; i < 3; ++i) ctx->pc[i] = snap.pc_dircos[i];
@@ -160,17 +181,16 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
   if (want_keys && N > 1) {
     // every run of one source size by decreasing altitude (stable radix sort on (run, 1 - n) keys): the leading sources of a run are then
     // the ones a long-baseline group can cull
-    if (!C.sort_tmp.p) {
-      const size_t nn = (size_t)C.n;
-      if ((rc = ensure(ctx, C.sort_tmp, std::max<size_t>(cat_sort_temp_bytes(C.n), 16))) || (rc = ensure(ctx, C.keys_out, nn * sizeof(uint32_t))) ||
-          (rc = ensure(ctx, C.perm, nn * sizeof(uint32_t))) || (rc = ensure(ctx, C.idx_sorted, nn * sizeof(int32_t))) ||
-          (rc = ensure(ctx, C.dirs_sorted, nn * 4 * sizeof(double))))
-        return rc;
-    }
+    const size_t nn = (size_t)C.n;
+    if (!C.sort_tmp.p &&
+        ((rc = ensure(ctx, C.sort_tmp, std::max<size_t>(cat_sort_temp_bytes(C.n), 16))) || (rc = ensure(ctx, C.keys_out, nn * sizeof(uint32_t))) ||
+         (rc = ensure(ctx, C.perm, nn * sizeof(uint32_t)))))
+      return rc;
+    if ((rc = ensure(ctx, ctx->sk->idx_sorted, nn * sizeof(int32_t))) || (rc = ensure(ctx, ctx->sk->dirs_sorted, nn * 4 * sizeof(double)))) return rc;
     HIPCHK(ctx, launch_cat_sort(C.sort_tmp.p, C.sort_tmp.bytes, (const uint32_t*)S.keys.p + off, (uint32_t*)C.keys_out.p, (const uint32_t*)S.pos.p + off,
-                                (uint32_t*)C.perm.p, dirs, idx, (double*)C.dirs_sorted.p, (int32_t*)C.idx_sorted.p, N, ctx->stream));
-    ctx->dirs_p = (const double*)C.dirs_sorted.p;
-    ctx->src_index = (const int32_t*)C.idx_sorted.p;
+                                (uint32_t*)C.perm.p, dirs, idx, (double*)ctx->sk->dirs_sorted.p, (int32_t*)ctx->sk->idx_sorted.p, N, ps));
+    ctx->dirs_p = (const double*)ctx->sk->dirs_sorted.p;
+    ctx->src_index = (const int32_t*)ctx->sk->idx_sorted.p;
   } else {
     ctx->dirs_p = dirs;
     ctx->src_index = idx;
@@ -202,19 +222,19 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
       cp.grp_minh = (const double*)ctx->grp_hz.p + 3 * ng;
       cp.fc2 = fc2;
       cp.nbl = ctx->nbl;
-      if ((rc = ensure(ctx, ctx->cull_first, 2 * (size_t)ncr * ng * sizeof(int32_t))) || (rc = ensure(ctx, C.culled, 2 * sizeof(uint64_t)))) return rc;
-      cp.first = (int32_t*)ctx->cull_first.p;
+      if ((rc = ensure(ctx, ctx->sk->cull_first, 2 * (size_t)ncr * ng * sizeof(int32_t))) || (rc = ensure(ctx, C.culled, 2 * sizeof(uint64_t)))) return rc;
+      cp.first = (int32_t*)ctx->sk->cull_first.p;
       cp.culled = (uint64_t*)C.culled.p;
-      HIPCHK(ctx, hipMemsetAsync(C.culled.p, 0, 2 * sizeof(uint64_t), ctx->stream));
-      HIPCHK(ctx, launch_cull_first(cp, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(C.culled_host, C.culled.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(C.culled.p, 0, 2 * sizeof(uint64_t), ps));
+      HIPCHK(ctx, launch_cull_first(cp, ps));
+      HIPCHK(ctx, hipMemcpyAsync(C.culled_host, C.culled.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ps));
       ctx->cull_any[0] = possible[0]; ctx->cull_any[1] = possible[1];
       ctx->cull_nruns = ncr;
     }
   }
   // pb * fluxes (:6249-6254); the flux vectors / spectra stay in catalogue order and are read through the index list.  Sized for the
   // whole catalogue once: the ROI of a drift scan grows and shrinks, and every re-allocation would synchronise the device.
-  if ((rc = ensure(ctx, ctx->pb, (size_t)std::max<int64_t>(C.n * ctx->nchan, 1) * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->sk->pb, (size_t)std::max<int64_t>(C.n * ctx->nchan, 1) * sizeof(double)))) return rc;
   if (N > 0) {
     const double* fr = C.have_spec ? nullptr : (const double*)C.flux_ref.p;
     const double* sp = C.have_spec ? nullptr : (const double*)C.spindex.p;
@@ -235,6 +255,18 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
   return PRISIM_OK;
 }
 
+// the download / gather of a finished slot, behind its sky-sum
+int post_snapshot(prisim_ctx* ctx, const prisim_post* post, int64_t slot) {
+  if (!post) return PRISIM_OK;
+  int rc;
+  if (post->host_vis) {
+    const size_t bytes = (size_t)ctx->nbl * (size_t)ctx->nchan * (post->host_is_c64 ? 8 : 16);
+    if ((rc = prisim_hip_get_vis_async(ctx, slot, (char*)post->host_vis + (size_t)slot * bytes, nullptr, post->host_is_c64))) return rc;
+  }
+  if (post->gather && (rc = prisim_hip_allgather_slot_async(ctx, slot, post->gather_as_c64))) return rc;
+  return PRISIM_OK;
+}
+
 }  // namespace
 
 namespace pint {
@@ -249,7 +281,7 @@ void catalog_destroy(prisim_ctx* ctx) {
   auto& C = ctx->cat;
   if (C.gstream) (void)hipStreamSynchronize(C.gstream);
   for (DevBuf* b : {&C.lon, &C.lat, &C.sin_dec, &C.cos_dec, &C.kappa, &C.run_id, &C.flux_ref, &C.spindex, &C.spec, &C.block_off, &C.snaps, &C.out_dev,
-                    &C.sort_tmp, &C.keys_out, &C.perm, &C.idx_sorted, &C.dirs_sorted, &C.culled})
+                    &C.sort_tmp, &C.keys_out, &C.perm, &C.culled})
     release(*b);
   for (auto& s : C.set) {
     for (DevBuf* b : {&s.idx, &s.dirs, &s.keys, &s.pos}) release(*b);
@@ -261,6 +293,8 @@ void catalog_destroy(prisim_ctx* ctx) {
   if (C.snaps_host) (void)hipHostFree(C.snaps_host);
   if (C.culled_host) (void)hipHostFree(C.culled_host);
   if (C.gstream) (void)hipStreamDestroy(C.gstream);
+  ctx->prep_stream = nullptr;
+  ctx->prep_async = false;
   C = prisim_ctx::Catalog();
 }
 
@@ -408,7 +442,7 @@ int prisim_hip_catalog_roi(prisim_ctx* ctx, const prisim_obs* obs, const prisim_
 }
 
 int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int precision, int want_grad,
-                               int64_t slot0, int64_t* nsrc_roi) {
+                               int64_t slot0, int64_t* nsrc_roi, const prisim_post* post) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return PRISIM_EINVAL;
   if (nsnap <= 0) return fail(ctx, PRISIM_EINVAL, "nsnap must be positive");
@@ -430,7 +464,9 @@ int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const pri
     for (int64_t t = 0; t < kc; ++t) {
       if ((rc = activate_snapshot(ctx, obs, snaps[c0 + t], b, t, want_keys))) return rc;
       if (nsrc_roi) nsrc_roi[c0 + t] = ctx->nsrc;
-      if ((rc = prisim_hip_compute(ctx, precision, PRISIM_KERNEL_AUTO, want_grad, slot0 + c0 + t))) return rc;
+      const int64_t slot = slot0 + c0 + t;
+      if ((rc = prisim_hip_compute(ctx, precision, PRISIM_KERNEL_AUTO, want_grad, slot))) return rc;
+      if ((rc = post_snapshot(ctx, post, slot))) return rc;
     }
     C.next = b ^ 1;
   }

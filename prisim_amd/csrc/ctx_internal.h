@@ -74,7 +74,34 @@ struct DevBuf {
 
 using namespace pint;
 
+// What one snapshot's sky occupies on the device between its preparation (beam x flux, packing, direction prep, flags and tables) and
+// its sky-sum.  The context holds TWO sets: on the catalogue path the preparation of snapshot t+1 runs on the preparation stream into
+// one set while the sky-sum of snapshot t reads the other (ev_prep: the set is ready; ev_sum: its sky-sum has run and it may be rewritten).
+struct SkyBufs {
+  DevBuf pb;                 // [nsrc][nchan] float64 beam x flux
+  DevBuf packed;             // [ntiles][nsrc_pad][CT] rows of the kernels
+  DevBuf dirs_prep;          // [nsrc_pad][4] (s - s_pc)/c, kappa
+  DevBuf dirs_c32;           // fused fp32 gradient kernel
+  DevBuf lift_flags;         // [groups] lifting-rotation flags and what they were formed for
+  double lift_key_k = -1.0;
+  int lift_key_f32 = -1;
+  int lift_groups = -1;
+  DevBuf split_flags, moments, moments_part, split_count;      // split taper form: per-run moments and per-group flags
+  // Taper culling: cull_first[prec][run][group] = first source of the run that group still has to sum (device, int32); the sources before
+  // it contribute < exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux| to every baseline of the group.
+  DevBuf cull_first;
+  DevBuf dirs_sorted, idx_sorted;      // catalogue path: directions / catalogue indices in the altitude order of the taper culling
+  hipEvent_t ev_prep = nullptr, ev_sum = nullptr;
+  bool sum_recorded = false;
+};
+
 struct prisim_ctx {
+  SkyBufs skb[2];
+  SkyBufs* sk = &skb[0];     // the set of the current sky
+  int sk_next = 0;           // catalogue path: the set the next snapshot's preparation writes
+  hipStream_t prep_stream = nullptr;      // preparation stream (catalogue path, highest priority); nullptr: everything on `stream`
+  bool prep_async = false;   // the current sky was prepared on prep_stream: compute() hands its packing to that stream too
+  int fsq_pairs_ct = -1, fsq_pairs_ntiles = -1;      // tiling the fsq_pairs table was last formed for
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -84,16 +111,14 @@ struct prisim_ctx {
   // array
   bool array_set = false;
   int64_t nbl = 0, nchan = 0, nt_max = 0;
-  DevBuf blx, bly, blz, freqs, fsq, fsq_pairs, cube, grad, lift_flags;
+  DevBuf blx, bly, blz, freqs, fsq, fsq_pairs, cube, grad;
   std::vector<double> grp_maxlen;     // max |b| per group of kBlockThreads baselines (lifting-rotation guarantee)
   std::vector<double> grp_maxh, grp_maxz;   // max horizontal length / max |b_z| per group (bound of the split taper's parabola)
   std::vector<double> grp_minh;             // min horizontal length per group (taper culling)
   // Taper culling: cull_first[prec][run][group] = first source of the run that group still has to sum (device, int32); the sources before
   // it contribute < exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux| to every baseline of the group.  cull_frac[prec]: culled share of
   // the snapshot's terms; cull_any[prec]: anything culled at all.
-  DevBuf cull_first;
   std::vector<double> cull_rho, cull_an;    // scratch of the cull-table walk: sin / |cos| of the zenith angle of a run's leading sources
-  DevBuf moments_part;                    // per-chunk partial sums of k_taper_moments (reduced in fixed order)
   DevBuf step_tab;                        // round-4 experiment: step-phasor table of the packed fp32 kernel (PRISIM_HIP_STEP_TABLE=1)
   bool cull_any[2] = {false, false};
   double cull_frac[2] = {0.0, 0.0};
@@ -102,7 +127,7 @@ struct prisim_ctx {
   // taper kernel walks such skies run by run in its split form.  Empty: sizes vary from source to source (or no taper).
   struct KappaRun { int64_t lo, hi; double kappa; int tab_row; };      // tab_row: this run's row of the cull table
   std::vector<KappaRun> kappa_runs;
-  DevBuf split_flags, moments, grp_hz, split_count;      // grp_hz: [4][groups] (max horizontal length, max |b_z|, max length, min horizontal length) on the device
+  DevBuf grp_hz;      // grp_hz: [4][groups] (max horizontal length, max |b_z|, max length, min horizontal length) on the device
   int32_t* h_split_count = nullptr;                      // pinned: uncorrected-group counts of the last split launch, per run (read after a sync)
   int split_count_runs = 0;
   double dmax = 2.0;                  // max_s |s - s_pc| of the current sky
@@ -116,7 +141,7 @@ struct prisim_ctx {
   int64_t nsrc = 0;
   bool taper = false;
   double pc[3] = {0, 0, 1};
-  DevBuf dirs, dirs_prep, dirs_c32, pb, packed, partial, scratch;
+  DevBuf dirs, partial, scratch;
   // per-snapshot sky inputs (flux_ref / spindex or a flux table, beamformer elements, validity flag): owned by the context so that
   // a set_sky_* call allocates nothing after the first snapshot
   DevBuf sky_flux, sky_sp, sky_bf, sky_flag;
@@ -150,7 +175,7 @@ struct prisim_ctx {
       hipEvent_t ev_free = nullptr;     // recorded on the compute stream behind the last kernel that reads the set
       bool ev_recorded = false;
     } set[3];
-    DevBuf block_off, snaps, out_dev, sort_tmp, keys_out, perm, idx_sorted, dirs_sorted, culled;
+    DevBuf block_off, snaps, out_dev, sort_tmp, keys_out, perm, culled;
     CatOut* out_host = nullptr;         // pinned [cap_snaps]
     CatSnap* snaps_host = nullptr;      // pinned [cap_snaps]
     uint64_t* culled_host = nullptr;    // pinned [2]
@@ -175,9 +200,6 @@ struct prisim_ctx {
   int ring_head = 0;            // next entry to record
   int ring_pending = 0;         // recorded, not yet harvested (oldest = head - pending)
   // lifting flags of the last compute (host copy stays alive for the asynchronous upload) and what they were computed for
-  int lift_groups = -1;
-  double lift_key_k = -1.0;
-  int lift_key_f32 = -1;
   prisim_timing timing{};
 
   // tuning overrides
@@ -420,6 +442,17 @@ struct Plan {
   int nbgroups;
   bool pk;         // packed-fp32 kernel (k_skyvis_rec_f32pk) with interleaved pbflux pairs
 };
+
+// the stream a sky is prepared on: the preparation stream when the current sky came from the resident catalogue, else the compute stream
+inline hipStream_t pstream(const prisim_ctx* ctx) { return ctx->prep_async ? ctx->prep_stream : ctx->stream; }
+
+// the compute stream waits for everything queued so far on the preparation stream (the current sky's set is ready)
+inline int join_prep(prisim_ctx* ctx) {
+  if (!ctx->prep_async) return PRISIM_OK;
+  HIPCHK(ctx, hipEventRecord(ctx->sk->ev_prep, ctx->prep_stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->sk->ev_prep, 0));
+  return PRISIM_OK;
+}
 
 // capi.cpp
 Plan make_plan(const prisim_ctx* ctx, int precision, int kernel);

@@ -374,13 +374,18 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         tsysinfo = {'Trx': tp['Trx'], 'Tant': {'f0': tp['Tant_freqref'], 'T0': tp['Tant_ref'], 'spindex': tp['Tant_spindex']}, 'Tnet': None}
     roi_radius = parms['skyparm'].get('roi_radius')
     t0 = time.time()
-    for j in range(n_acc):                                                                            # run_prisim.py:2180-2198
-        ia.observe((float(jd[j]), float(lst[j])), tsysinfo, NP.ones(chans.size), hadec[j], skymod, t_acc,
-                   roi_radius=roi_radius, roi_center='zenith', gradient_mode=proc.get('gradient_mode'),
-                   memsave=bool(proc.get('memsave')))
+    # run_prisim.py:2180-2198 loops observe() over the accumulations.  Here they go to the device in batches (observe_batch): the sky
+    # model is uploaded once, every batch's geometry is formed on the GPU with one small read-back, and its snapshots are then queued
+    # back to back -- no nsrc-sized host array is touched per snapshot and nothing synchronises the compute stream inside the loop.
+    batch = max(1, int(proc.get('snapshot_batch') or 16))
+    for j0 in range(0, n_acc, batch):
+        j1 = min(n_acc, j0 + batch)
+        ia.observe_batch([(float(jd[j]), float(lst[j])) for j in range(j0, j1)], tsysinfo, NP.ones(chans.size), hadec[j0:j1], skymod, t_acc,
+                         roi_radius=roi_radius, roi_center='zenith', gradient_mode=proc.get('gradient_mode'), memsave=bool(proc.get('memsave')))
         if verbose and rank == 0:
-            print('snapshot {0}/{1}: lst = {2:.4f} deg, {3} sources'.format(j + 1, n_acc, lst[j], ia.obs_catalog_indices[-1].size
-                                                                              if len(ia.obs_catalog_indices) > j else 0))
+            for j in range(j0, j1):
+                print('snapshot {0}/{1}: lst = {2:.4f} deg, {3} sources'.format(j + 1, n_acc, lst[j], ia.obs_catalog_indices[j].size
+                                                                                  if len(ia.obs_catalog_indices) > j else 0))
     t_sim = time.time() - t0
     # After the snapshots the reference adds thermal noise and re-centres the phases on phasing.center (run_prisim.py:2278-2282); the same
     # here through the class methods.  The noise stage makes host-side cubes of the size of the visibility cube (vis_noise_freq, vis_freq,

@@ -133,17 +133,57 @@ class _LazyGradients(dict):
         return len(self.keys())
 
 
+class _CatalogROI(object):
+    """Entry of ``InterferometerArray.obs_catalog_indices`` (interferometry.py:6377) for a snapshot whose sky was formed on the device
+    from the resident catalogue: the integer index list -- and the direction cosines behind ``geometric_delays`` -- are fetched when
+    they are read (prisim_hip_catalog_roi forms that snapshot's region of interest again; it is deterministic).  ``size`` / ``len``
+    are known from the snapshot's own read-back.  Behaves like the int64 array the reference stores."""
+
+    def __init__(self, owner, obs, lst, pc_dircos, size):
+        self._owner, self._obs, self._lst, self._pc = owner, obs, float(lst), NP.array(pc_dircos, dtype=NP.float64)
+        self.size = int(size)
+        self.shape = (self.size,)
+        self.ndim = 1
+        self.dtype = NP.dtype(NP.int64)
+        self._idx = self._dc = None
+
+    def fetch(self):
+        if self._idx is None:
+            self._idx, self._dc = self._owner._ctx.catalog_roi(self._obs, self._lst, self._pc)
+            self._owner = self._obs = None
+        return self._idx
+
+    def dircos(self):
+        self.fetch()
+        return self._dc
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.fetch()
+        return out if dtype is None else out.astype(dtype)
+
+    def __len__(self):
+        return self.size
+
+    def __getitem__(self, key):
+        return self.fetch()[key]
+
+    def __iter__(self):
+        return iter(self.fetch())
+
+
 class LazyGeometricDelays(object):
     """Stand-in for one entry of ``InterferometerArray.geometric_delays`` (the reference stores the full
     nsrc x nbl matrix per snapshot, interferometry.py:6287-6291 -- 4.9 GB at HERA-350 x 1e4 sources).
-    Materialised on demand by ``numpy.asarray(obj)``: tau = dc . bl^T / c."""
+    Materialised on demand by ``numpy.asarray(obj)``: tau = dc . bl^T / c.  `dircos`: the (nsrc, 3) array, or the snapshot's
+    _CatalogROI (the direction cosines then come from the device when first needed)."""
 
     def __init__(self, baselines, dircos, dtype):
         self._bl, self._dc, self._dtype = baselines, dircos, dtype
-        self.shape = (dircos.shape[0], baselines.shape[0])
+        self.shape = ((dircos.size if isinstance(dircos, _CatalogROI) else dircos.shape[0]), baselines.shape[0])
 
     def __array__(self, dtype=None, copy=None):
-        out = DLY.geometric_delay(self._bl, self._dc, altaz=False, hadec=False, dircos=True).astype(self._dtype)
+        dc = self._dc.dircos() if isinstance(self._dc, _CatalogROI) else self._dc
+        out = DLY.geometric_delay(self._bl, dc, altaz=False, hadec=False, dircos=True).astype(self._dtype)
         return out if dtype is None else out.astype(dtype)
 
 
@@ -452,6 +492,18 @@ class InterferometerArray(object):
         self._reserved = n_acc
         self._stage, self._host_cube = bool(host_staging), None
         self._restore_external_beam()
+        self._catalog_key = None                       # (set_array drops the resident catalogue)
+
+    def _reset_device_array(self):
+        """set_array of the (changed) baselines after snapshots have been observed: what lives only on the device is fetched first --
+        the catalogue-resident index lists and the gradient blocks observe() left in the device gradient cube (prisim_hip_set_array
+        releases that cube) -- and the catalogue is uploaded again by the next observe()."""
+        self._materialise_catalog_state()
+        if self.gradient_mode is not None and isinstance(self.gradient, _LazyGradients):
+            self.gradient.get(self.gradient_mode)
+        self._ctx.set_array(self._baselines_local(), self.channels, nt_max=self._reserved)
+        self._restore_external_beam()
+        self._catalog_key = None
 
     def _cull_order(self, alt_deg, fwhm_deg):
         """Permutation that lists every run of sources of one size by decreasing altitude, or None when nothing could be culled
@@ -472,10 +524,11 @@ class InterferometerArray(object):
             order[lo:hi] = lo + NP.argsort(-alt_deg[lo:hi], kind='stable')
         return None if NP.array_equal(order, NP.arange(order.size)) else order
 
-    def _stage_download(self, slot, dtype):
-        """Enqueue the asynchronous download of device slot `slot` into the pinned host cube; False when staging is off / unavailable."""
+    def _ensure_host_cube(self, dtype):
+        """The page-locked host cube of reserve(host_staging=True) (allocated on first use), or None when staging is off, unavailable,
+        or the cube holds another dtype."""
         if not getattr(self, '_stage', False):
-            return False
+            return None
         if self._host_cube is None:
             need = self._reserved * self.baselines.shape[0] * self.channels.size * NP.dtype(dtype).itemsize
             avail = _available_host_bytes()
@@ -486,16 +539,23 @@ class InterferometerArray(object):
                 warnings.warn('host staging switched off: the pinned host cube and its (nbl, nchan, n_acc) copy would need {0:.1f} GiB of '
                               '{1:.1f} GiB available'.format(2 * need / 2.0 ** 30, avail / 2.0 ** 30))
                 self._stage = False
-                return False
+                return None
             try:
                 self._host_cube = _abi.host_empty((self._reserved, self.baselines.shape[0], self.channels.size), dtype)
             except (MemoryError, _abi.PrisimHipError, OSError) as exc:
                 warnings.warn('host staging switched off: the pinned host cube could not be allocated ({0})'.format(exc))
                 self._stage = False
-                return False
+                return None
         if self._host_cube.dtype != NP.dtype(dtype):
-            return False                     # a run that mixes memsave and full precision: this snapshot takes the lazy path
-        self._ctx.get_vis_async(slot, self._host_cube[slot])
+            return None                      # a run that mixes memsave and full precision: this snapshot takes the lazy path
+        return self._host_cube
+
+    def _stage_download(self, slot, dtype):
+        """Enqueue the asynchronous download of device slot `slot` into the pinned host cube; False when staging is off / unavailable."""
+        hc = self._ensure_host_cube(dtype)
+        if hc is None:
+            return False
+        self._ctx.get_vis_async(slot, hc[slot])
         return True
 
     def set_external_beam(self, beam, beam_freqs_hz, spec_interp='cubic', chromatic=True, select_freq=None):
@@ -705,52 +765,79 @@ class InterferometerArray(object):
         self._append_layer('Tsys', layer)                                    # :6082-6086
 
     # ------------------------------------------------------------------------------------------
-    def observe(self, timeobj, Tsysinfo, bandpass, pointing_center, skymodel,
-                t_acc, pb_info=None, brightness_units=None, bpcorrect=None,
-                roi_info=None, roi_radius=None, roi_center=None, lst=None,
-                gradient_mode=None, memsave=False, vmemavail=None,
-                store_prev_skymodel_file=None):
-        """Simulate one snapshot (interferometry.py:5874-6410).  See the reference docstring for the
-        argument meaning; vmemavail and store_prev_skymodel_file are accepted and ignored (the GPU kernel
-        never materialises the nsrc x nbl x nchan matrix, so there is no memory-shortage path)."""
-        self._stack_bandpass(bandpass)
-        self._stack_tsys(Tsysinfo, bpcorrect)
+    # ------------------------------------------------------------------------------------------
+    # Device-resident catalogue (prisim_hip_set_catalog, ABI 0.4).  The reference re-derives the sky at every observe() from a sky
+    # model that does not change over a run (scripts/run_prisim.py:2165-2207; interferometry.py:6223-6247 store_prev_skymodel_file
+    # exists because that is expensive).  Here the model is uploaded the first time it is seen and every later snapshot's
+    # hadec -> altaz -> dircos, region of interest, flux spectra and beam x flux are formed on the GPU.
 
-        pc = NP.asarray(pointing_center, dtype=NP.float64).reshape(1, -1)             # :6103-6108
-        if pc.size != 2:
-            raise ValueError('pointing_center must be a 2-element vector')
-        if not self.timestamp:
-            self.pointing_center = pc
-            self.phase_center = pc.copy()
-        else:
-            self.pointing_center = NP.vstack((self.pointing_center, pc))
-            self.phase_center = NP.vstack((self.phase_center, pc))
+    def _catalog_fingerprint(self, skymodel):
+        loc = skymodel.location
+        shape = getattr(skymodel, 'src_shape', None)
+        # identity of the object and of its arrays, plus a cheap content check of the positions (an in-place edit of the catalogue)
+        return (id(skymodel), id(loc), getattr(loc, 'shape', None), float(NP.sum(loc)), self.skycoords, getattr(skymodel, 'spec_type', None),
+                id(getattr(skymodel, 'flux_ref', None)), id(getattr(skymodel, 'spindex', None)), id(getattr(skymodel, 'spectrum', None)),
+                None if shape is None else id(shape), self.channels.size, float(self.channels[0]), self._reserved)
 
-        jd, lst = _lst_and_jd(timeobj, lst)                                           # :6113
-
-        pc_altaz = self.pointing_center[-1, :]                                        # :6155-6162
-        if self.pointing_coords == 'hadec':
-            pc_altaz = GEOM.hadec2altaz(self.pointing_center[-1, :], self.latitude, units='degrees')
-        elif self.pointing_coords == 'radec':
-            pc_altaz = GEOM.hadec2altaz(NP.asarray([lst - self.pointing_center[-1, 0], self.pointing_center[-1, 1]]),
-                                        self.latitude, units='degrees')
-        pc_dircos = GEOM.altaz2dircos(pc_altaz, 'degrees').ravel()                    # :6164
-
-        for attr in ('location', 'generate_spectrum'):                                 # :6171 (duck-typed SkyModel)
-            if not hasattr(skymodel, attr):
-                raise TypeError('skymodel should be an instance of class SkyModel.')
+    def _catalog_ready(self, skymodel):
+        """True when `skymodel` is (now) the catalogue resident on the device.  PRISIM_CATALOG=0 switches the path off (A/B: every
+        snapshot's sky is then formed on the host and uploaded, as before round 5)."""
+        if os.environ.get('PRISIM_CATALOG', '1') == '0' or not hasattr(self._ctx, 'set_catalog'):
+            return False
+        key = self._catalog_fingerprint(skymodel)
+        if getattr(self, '_catalog_key', None) == key:
+            return True
+        self._materialise_catalog_state()              # lazy class state of the previous catalogue is fetched while it is still there
         location = NP.asarray(skymodel.location, dtype=NP.float64).reshape(-1, 2)
-        if self.skycoords == 'hadec':                                                 # :6176-6180
-            skypos_altaz = GEOM.hadec2altaz(location, self.latitude, units='degrees')
-        elif self.skycoords == 'radec':
-            hadec = NP.stack((lst - location[:, 0], location[:, 1]), axis=1)
-            skypos_altaz = GEOM.hadec2altaz(hadec, self.latitude, units='degrees')
+        nsrc, nchan = location.shape[0], self.channels.size
+        fwhm = None
+        src_shape = getattr(skymodel, 'src_shape', None)
+        if src_shape is not None:                                                      # :6258, 6267
+            src_shape = NP.asarray(src_shape, dtype=NP.float64)
+            fwhm = NP.sqrt(src_shape[:, 0] * src_shape[:, 1])
+        powerlaw = (getattr(skymodel, 'spec_type', None) == 'func' and all(hasattr(skymodel, a) for a in ('flux_ref', 'spindex', 'ref_freq')))
+        if powerlaw:
+            self._ctx.set_catalog(location, self.skycoords, flux_ref=skymodel.flux_ref, spindex=skymodel.spindex, ref_freq_hz=float(skymodel.ref_freq),
+                                  fwhm_deg=fwhm)
         else:
-            skypos_altaz = location
+            if nsrc * nchan * 8 > (16 << 30):
+                return False                           # a spectrum table this large stays on the per-snapshot path (ROI rows only)
+            spectra = NP.asarray(skymodel.generate_spectrum(ind=NP.arange(nsrc), frequency=self.channels, interp_method='pchip'),
+                                 dtype=NP.float64).reshape(-1, nchan)                  # :6249, once for the whole catalogue
+            self._ctx.set_catalog(location, self.skycoords, flux_spectrum=spectra, fwhm_deg=fwhm)
+        self._catalog_key = key
+        self._catalog_obs_cache = None
+        return True
 
-        nbl, nchan = self.baselines.shape[0], self.channels.size
-        datatype = NP.complex64 if memsave else NP.complex128                         # :6182-6185
+    def _catalog_obs(self, pb_info, pc_altaz, roi_radius, roi_center):
+        """(prisim_obs, beam pointing direction cosines) of a snapshot.  The struct is cached while nothing it depends on changes."""
+        if getattr(self, '_extbeam', None) is not None:
+            key = ('ext', roi_radius, roi_center, self.latitude)
+            cache = getattr(self, '_catalog_obs_cache', None)
+            if cache is None or cache[0] != key:
+                cache = (key, self._ctx.make_obs(self.latitude, roi_radius, roi_center, use_external_beam=True))
+                self._catalog_obs_cache = cache
+            return cache[1], None
+        kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz,
+                                                  first_frequency_hz=float(self.channels[0]))                   # :6252
+        if pb_info is not None or (ext is not None and 'beamformer' in ext):
+            return self._ctx.make_obs(self.latitude, roi_radius, roi_center, beam_kind=kind, diameter_m=dia, ext=ext), bpc
+        key = (kind, dia, id(self.telescope), roi_radius, roi_center, self.latitude)
+        cache = getattr(self, '_catalog_obs_cache', None)
+        if cache is None or cache[0] != key:
+            cache = (key, self._ctx.make_obs(self.latitude, roi_radius, roi_center, beam_kind=kind, diameter_m=dia, ext=ext))
+            self._catalog_obs_cache = cache
+        return cache[1], bpc
 
+    def _materialise_catalog_state(self):
+        """Fetch the lazy per-snapshot class state that lives in the device-resident catalogue (obs_catalog_indices, the direction
+        cosines behind geometric_delays) before the catalogue goes away: a new sky model, or set_array (reserve, conjugate ...)."""
+        for entry in getattr(self, 'obs_catalog_indices', []):
+            if isinstance(entry, _CatalogROI):
+                entry.fetch()
+        self._catalog_key = None
+
+    def _check_gradient_mode(self, gradient_mode):
         if gradient_mode is not None:                                                 # :6306-6311
             if not isinstance(gradient_mode, str):
                 raise TypeError('Input gradient_mode must be a string')
@@ -760,91 +847,93 @@ class InterferometerArray(object):
                 raise NotImplementedError('only gradient_mode="baseline" is computed (as in the reference)')
             if self.gradient_mode is None:
                 self.gradient_mode = gradient_mode
-        want_grad = gradient_mode is not None
+        return gradient_mode is not None
 
-        pb = None
-        if roi_info is not None:                                                      # :6189-6202
-            if ('ind' not in roi_info) or ('pbeam' not in roi_info):
-                raise KeyError('Both "ind" and "pbeam" keys must be present in dictionary roi_info')
-            m2 = NP.arange(0)
-            if (roi_info['ind'] is not None) and (roi_info['pbeam'] is not None):
-                m2 = NP.asarray(roi_info['ind']).ravel()
-                if m2.size > 0:
-                    try:
-                        pb = NP.asarray(roi_info['pbeam']).reshape(-1, nchan)
-                    except ValueError:
-                        raise ValueError('Number of columns of primary beam in key "pbeam" of dictionary roi_info must be equal to number of frequency channels.')
-                    if m2.size != pb.shape[0]:
-                        raise ValueError('Values in keys ind and pbeam in must carry same number of elements.')
-        else:                                                                         # :6204-6216
-            if roi_radius is None:
-                roi_radius = 90.0
-            if roi_center is None:
-                roi_center = 'zenith'
-            elif (roi_center != 'zenith') and (roi_center != 'pointing_center'):
-                raise ValueError('Center of region of interest, roi_center, must be set to "zenith" or "pointing_center".')
-            if roi_center == 'pointing_center':
-                dc_all = GEOM.altaz2dircos(skypos_altaz, 'degrees')
-                cosd = NP.clip(NP.dot(dc_all, pc_dircos), -1.0, 1.0)
-                m2 = NP.where(NP.degrees(NP.arccos(cosd)) <= roi_radius)[0]
-            else:
-                m2 = NP.arange(skypos_altaz.shape[0])
-                m2 = m2[NP.where(skypos_altaz[:, 0] >= 90.0 - roi_radius)]
+    def _append_pointing(self, pointing_center, lst):
+        """Pointing = phase centre of one more snapshot (:6103-6108, 6155-6164): (alt-az degrees, ENU direction cosines)."""
+        pc = NP.asarray(pointing_center, dtype=NP.float64).reshape(1, -1)
+        if pc.size != 2:
+            raise ValueError('pointing_center must be a 2-element vector')
+        if not self.timestamp:
+            self.pointing_center = pc
+            self.phase_center = pc.copy()
+        else:
+            self.pointing_center = NP.vstack((self.pointing_center, pc))
+            self.phase_center = NP.vstack((self.phase_center, pc))
+        pc_altaz = self.pointing_center[-1, :]                                        # :6155-6162
+        if self.pointing_coords == 'hadec':
+            pc_altaz = GEOM.hadec2altaz(self.pointing_center[-1, :], self.latitude, units='degrees')
+        elif self.pointing_coords == 'radec':
+            pc_altaz = GEOM.hadec2altaz(NP.asarray([lst - self.pointing_center[-1, 0], self.pointing_center[-1, 1]]),
+                                        self.latitude, units='degrees')
+        return pc_altaz, GEOM.altaz2dircos(pc_altaz, 'degrees').ravel()               # :6164
 
-        if len(m2) > 0:
-            skypos_altaz_roi = skypos_altaz[m2, :]                                    # :6219
-            dircos_roi = GEOM.altaz2dircos(skypos_altaz_roi, 'degrees')               # :6263 (unconditional, Q4)
-            # flux spectra (:6249).  A power-law sky model (spec_type 'func') is described to the device by its nsrc-sized
-            # flux_ref / spindex vectors and S = flux_ref (f / ref_freq)^spindex is formed there; anything else goes through
-            # generate_spectrum on the host, as in the reference.
-            powerlaw = (getattr(skymodel, 'spec_type', None) == 'func' and pb is None
-                        and all(hasattr(skymodel, a) for a in ('flux_ref', 'spindex', 'ref_freq')))
-            if powerlaw:
-                fluxes = None
-                flux_ref = NP.asarray(skymodel.flux_ref, dtype=NP.float64)[m2]
-                spindex = NP.asarray(skymodel.spindex, dtype=NP.float64)[m2]
-                ref_freq = float(skymodel.ref_freq)
-            else:
-                fluxes = NP.asarray(skymodel.generate_spectrum(ind=m2, frequency=self.channels, interp_method='pchip'),
-                                    dtype=NP.float64).reshape(-1, nchan)
-                flux_ref = spindex = ref_freq = None
-            fwhm = None
-            src_shape = getattr(skymodel, 'src_shape', None)
-            if src_shape is not None:                                                 # :6258, 6267
-                src_shape = NP.asarray(src_shape, dtype=NP.float64)
-                fwhm = NP.sqrt(src_shape[m2, 0] * src_shape[m2, 1])
-            prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
-            # Upload order.  The sum over sources does not care about their order, the taper culling of the library does: for every
-            # baseline group it skips the LEADING sources of a run of one source size whose weight is provably below the tolerance,
-            # and those are the sources nearest the zenith (long baselines resolve them out: b_perp ~ |b|).  So when anything can be
-            # culled at all -- kappa_max (|b|_max f_min / c)^2 >= 18 -- each run is listed by decreasing altitude.  Class state
-            # (obs_catalog_indices, geometric_delays) keeps the catalog order.
-            up = self._cull_order(skypos_altaz_roi[:, 0], fwhm)
-            dircos_up = dircos_roi
-            if up is not None:
-                dircos_up, fwhm = dircos_roi[up], fwhm[up]
-                flux_ref, spindex = (flux_ref[up], spindex[up]) if flux_ref is not None else (None, None)
-                fluxes = fluxes[up] if fluxes is not None else None
-                pb = pb[up] if pb is not None else None
-            if pb is not None:
-                # supplied beam (ROI_parameters path): pbfluxes = pb * fluxes on the device (:6254)
-                self._ctx.set_sky(dircos_up, pb, pc_dircos, fwhm_deg=fwhm, fluxes=fluxes)
-            elif getattr(self, '_extbeam', None) is not None:
-                self._ctx.set_sky_external_analytic(dircos_up, flux_ref, spindex, ref_freq, pc_dircos, fwhm_deg=fwhm, flux_spectrum=fluxes)
-            else:
-                kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz,
-                                                          first_frequency_hz=float(self.channels[0]))                   # :6252
-                self._ctx.set_sky_analytic(dircos_up, flux_ref, spindex, ref_freq, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,
-                                           flux_spectrum=fluxes, ext=ext)
-            slot = self.n_acc if self.n_acc < self._reserved else 0
-            if slot != self.n_acc:                                       # (a fresh reserved slot holds nothing: no O(n_acc) scan per snapshot)
-                for i, snap in enumerate(self._cube):                   # a snapshot still parked in the slot about to be overwritten
-                    if isinstance(snap, _DeviceSlot) and snap.slot == slot:
-                        self._cube[i] = self._ctx.get_vis(slot=slot, complex64=(snap.dtype == NP.complex64))
-                for i, g in enumerate(self._grad):                      # ... and its gradient blocks
-                    if isinstance(g, _DeviceSlot) and g.slot == slot:
-                        self._grad[i] = self._ctx.get_vis(slot=slot, want_grad=True, complex64=(g.dtype == NP.complex64))[1]
-            self._ctx.compute(precision=prec, want_grad=want_grad, slot=slot)
+    def _unpark(self, slot):
+        """Fetch whatever snapshot (and gradient block) still lives only in device slot `slot` before the slot is overwritten."""
+        for i, snap in enumerate(self._cube):
+            if isinstance(snap, _DeviceSlot) and snap.slot == slot:
+                self._cube[i] = self._ctx.get_vis(slot=slot, complex64=(snap.dtype == NP.complex64))
+        for i, g in enumerate(self._grad):
+            if isinstance(g, _DeviceSlot) and g.slot == slot:
+                self._grad[i] = self._ctx.get_vis(slot=slot, want_grad=True, complex64=(g.dtype == NP.complex64))[1]
+
+    @staticmethod
+    def _roi_defaults(roi_radius, roi_center):
+        if roi_radius is None:                                                        # :6204-6216
+            roi_radius = 90.0
+        if roi_center is None:
+            roi_center = 'zenith'
+        elif (roi_center != 'zenith') and (roi_center != 'pointing_center'):
+            raise ValueError('Center of region of interest, roi_center, must be set to "zenith" or "pointing_center".')
+        return roi_radius, roi_center
+
+    def observe(self, timeobj, Tsysinfo, bandpass, pointing_center, skymodel,
+                t_acc, pb_info=None, brightness_units=None, bpcorrect=None,
+                roi_info=None, roi_radius=None, roi_center=None, lst=None,
+                gradient_mode=None, memsave=False, vmemavail=None,
+                store_prev_skymodel_file=None):
+        """Simulate one snapshot (interferometry.py:5874-6410).  See the reference docstring for the
+        argument meaning; vmemavail is accepted and ignored (the GPU kernel never materialises the nsrc x nbl x nchan matrix, so there
+        is no memory-shortage path).  store_prev_skymodel_file (:6223-6247: the previous call's sky on disk, so that an unchanged sky
+        is not re-derived) is accepted too: what it buys is had without a file -- the sky model handed in stays resident on the GPU
+        from the first call that sees it, and every later snapshot's geometry, region of interest and beam x flux are formed there
+        (prisim_hip_set_catalog / prisim_hip_observe_catalog)."""
+        self._stack_bandpass(bandpass)
+        self._stack_tsys(Tsysinfo, bpcorrect)
+        jd, lst = _lst_and_jd(timeobj, lst)                                           # :6113
+        pc_altaz, pc_dircos = self._append_pointing(pointing_center, lst)             # :6103-6108, 6155-6164
+
+        for attr in ('location', 'generate_spectrum'):                                 # :6171 (duck-typed SkyModel)
+            if not hasattr(skymodel, attr):
+                raise TypeError('skymodel should be an instance of class SkyModel.')
+        nbl, nchan = self.baselines.shape[0], self.channels.size
+        datatype = NP.complex64 if memsave else NP.complex128                         # :6182-6185
+        want_grad = self._check_gradient_mode(gradient_mode)
+        prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
+        slot = self.n_acc if self.n_acc < self._reserved else 0
+
+        if roi_info is None and self._catalog_ready(skymodel):
+            # ---- the sky model is resident on the device: geometry, ROI, spectra, beam x flux and the sky-sum in ONE call ----
+            roi_radius, roi_center = self._roi_defaults(roi_radius, roi_center)
+            obs, bpc = self._catalog_obs(pb_info, pc_altaz, roi_radius, roi_center)
+            if slot != self.n_acc:
+                self._unpark(slot)
+            nroi = int(self._ctx.observe_catalog(obs, [lst], pc_dircos, bpc, precision=prec, want_grad=want_grad, slot0=slot)[0])
+            roi = _CatalogROI(self, obs, lst, pc_dircos, nroi)
+            if nroi == 0:                                                             # :6378-6382 (the device slot holds zeros)
+                warnings.warn('No sources found in the catalog within matching radius. Simply populating the observed visibilities and/or gradients with noise.')
+            self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(self._baselines_local(), roi,
+                                                                                 NP.float32 if memsave else NP.float64)]   # :6287-6291
+            self.obs_catalog_indices = self.obs_catalog_indices + [roi]               # :6377
+            have_sky = True
+        else:
+            have_sky = self._upload_snapshot_sky(skymodel, lst, pc_altaz, pc_dircos, pb_info, roi_info, roi_radius, roi_center, memsave)
+            if have_sky:
+                if slot != self.n_acc:                                   # (a fresh reserved slot holds nothing: no O(n_acc) scan per snapshot)
+                    self._unpark(slot)
+                self._ctx.compute(precision=prec, want_grad=want_grad, slot=slot)
+
+        if have_sky:
             self._device_in_step = slot == self.n_acc and (self.n_acc == 0 or getattr(self, '_device_in_step', False))
             if slot == self.n_acc:
                 # the snapshot stays in its own slot of the device cube: no synchronous download (1 GB and 20 ms per HERA-350
@@ -855,9 +944,6 @@ class InterferometerArray(object):
             else:
                 res = self._ctx.get_vis(slot=slot, want_grad=want_grad, complex64=memsave)
                 skyvis, skyvis_gradient = res if want_grad else (res, None)
-            self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(self._baselines_local(), dircos_roi,
-                                                                                 NP.float32 if memsave else NP.float64)]   # :6287-6291
-            self.obs_catalog_indices = self.obs_catalog_indices + [m2]                # :6377
         else:                                                                         # :6378-6382
             warnings.warn('No sources found in the catalog within matching radius. Simply populating the observed visibilities and/or gradients with noise.')
             skyvis = NP.zeros((nbl, nchan), dtype=datatype)
@@ -881,6 +967,168 @@ class InterferometerArray(object):
         self.t_obs += t_acc
         self.n_acc += 1
         self.lst = self.lst + [lst]
+
+    def observe_batch(self, timeobjs, Tsysinfo, bandpass, pointing_centers, skymodel, t_acc, pb_info=None, bpcorrect=None,
+                      roi_radius=None, roi_center=None, gradient_mode=None, memsave=False):
+        """K snapshots of ONE sky model in one call -- what the reference's callers write as a loop over observe()
+        (scripts/run_prisim.py:2165-2207, interferometry.py:6641-6647).  Not in the reference.  With the sky model resident on the
+        device the geometry of all K snapshots is formed first (one small read-back for the lot) and their skies and sky-sums are then
+        queued back to back without a host synchronisation; arrays of at most 256 baselines put the K sky-sums into ONE launch
+        (prisim_hip_observe_catalog).  The class state afterwards is what K calls of observe() leave.
+
+        timeobjs          K time objects as observe() takes them ((jd, lst_deg) pairs, Time-likes ...)
+        Tsysinfo          one dictionary for every snapshot, or a list of K
+        bandpass          (nchan,) / (nbl, nchan) for every snapshot, or a list of K
+        pointing_centers  (2,) for every snapshot or (K, 2)
+        t_acc             scalar or K values
+        Falls back to K calls of observe() when the catalogue path is not available (PRISIM_CATALOG=0, no free device slots)."""
+        k = len(timeobjs)
+        if k == 0:
+            return
+        tsys_l = Tsysinfo if isinstance(Tsysinfo, (list, tuple)) else [Tsysinfo] * k
+        bp_l = bandpass if isinstance(bandpass, (list, tuple)) else [bandpass] * k
+        pcs = NP.broadcast_to(NP.asarray(pointing_centers, dtype=NP.float64).reshape(-1, 2), (k, 2))
+        tacc_l = list(NP.broadcast_to(NP.asarray(t_acc, dtype=NP.float64).ravel(), (k,)))
+        if len(tsys_l) != k or len(bp_l) != k:
+            raise ValueError('Tsysinfo / bandpass lists must have one entry per snapshot')
+        for attr in ('location', 'generate_spectrum'):
+            if not hasattr(skymodel, attr):
+                raise TypeError('skymodel should be an instance of class SkyModel.')
+        if self.n_acc == 0 and self._reserved < k:
+            self.reserve(k, host_staging=getattr(self, '_stage', False))
+        batched = self.n_acc + k <= self._reserved and (pb_info is None) and self._catalog_ready(skymodel)
+        if not batched:
+            for t in range(k):
+                self.observe(timeobjs[t], tsys_l[t], bp_l[t], pcs[t], skymodel, float(tacc_l[t]), pb_info=pb_info, bpcorrect=bpcorrect,
+                             roi_radius=roi_radius, roi_center=roi_center, gradient_mode=gradient_mode, memsave=memsave)
+            return
+        want_grad = self._check_gradient_mode(gradient_mode)
+        roi_radius, roi_center = self._roi_defaults(roi_radius, roi_center)
+        datatype = NP.complex64 if memsave else NP.complex128
+        prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
+        jds, lsts, pc_dcs, bpcs, obs = [], [], [], [], None
+        for t in range(k):
+            self._stack_bandpass(bp_l[t])
+            self._stack_tsys(tsys_l[t], bpcorrect)
+            jd, lst = _lst_and_jd(timeobjs[t], None)
+            pc_altaz, pc_dircos = self._append_pointing(pcs[t], lst)
+            self.timestamp = self.timestamp + [jd]                                    # :6395-6399 (the pointing list grows with it)
+            o, bpc = self._catalog_obs(None, pc_altaz, roi_radius, roi_center)
+            obs = o if obs is None else obs
+            if o is not obs:
+                raise RuntimeError('the beam specification changed inside a batch')
+            jds.append(jd); lsts.append(lst); pc_dcs.append(pc_dircos); bpcs.append(pc_dircos if bpc is None else bpc)
+        slot0 = self.n_acc
+        host_cube = self._ensure_host_cube(datatype) if getattr(self, '_stage', False) else None
+        counts = self._ctx.observe_catalog(obs, lsts, NP.asarray(pc_dcs), NP.asarray(bpcs), precision=prec, want_grad=want_grad, slot0=slot0,
+                                           host_cube=host_cube)
+        base_bl = self._baselines_local()
+        for t in range(k):
+            roi = _CatalogROI(self, obs, lsts[t], pc_dcs[t], int(counts[t]))
+            if counts[t] == 0:
+                warnings.warn('No sources found in the catalog within matching radius. Simply populating the observed visibilities and/or gradients with noise.')
+            self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(base_bl, roi, NP.float32 if memsave else NP.float64)]
+            self.obs_catalog_indices = self.obs_catalog_indices + [roi]
+            snap = _DeviceSlot(slot0 + t, datatype)
+            snap.staged = host_cube is not None
+            self._cube.append(snap)
+            if want_grad:
+                self._grad.append(_DeviceSlot(slot0 + t, datatype))
+            self.t_acc = self.t_acc + [float(tacc_l[t])]
+            self.t_obs += float(tacc_l[t])
+            self.lst = self.lst + [lsts[t]]
+        self._device_in_step = slot0 == 0 or getattr(self, '_device_in_step', False)
+        self.n_acc += k
+        self._skyvis_cache = None
+        if want_grad:
+            if not isinstance(self.gradient, _LazyGradients):
+                self.gradient = _LazyGradients(self)
+            self.gradient.invalidate(gradient_mode)
+
+    def _upload_snapshot_sky(self, skymodel, lst, pc_altaz, pc_dircos, pb_info, roi_info, roi_radius, roi_center, memsave):
+        """The snapshot's sky formed on the HOST and uploaded (roi_info given, PRISIM_CATALOG=0, or a spectrum table too large to keep
+        resident): interferometry.py:6171-6283 statement by statement.  Returns False when the region of interest is empty."""
+        nchan = self.channels.size
+        location = NP.asarray(skymodel.location, dtype=NP.float64).reshape(-1, 2)
+        if self.skycoords == 'hadec':                                                 # :6176-6180
+            skypos_altaz = GEOM.hadec2altaz(location, self.latitude, units='degrees')
+        elif self.skycoords == 'radec':
+            hadec = NP.stack((lst - location[:, 0], location[:, 1]), axis=1)
+            skypos_altaz = GEOM.hadec2altaz(hadec, self.latitude, units='degrees')
+        else:
+            skypos_altaz = location
+        pb = None
+        if roi_info is not None:                                                      # :6189-6202
+            if ('ind' not in roi_info) or ('pbeam' not in roi_info):
+                raise KeyError('Both "ind" and "pbeam" keys must be present in dictionary roi_info')
+            m2 = NP.arange(0)
+            if (roi_info['ind'] is not None) and (roi_info['pbeam'] is not None):
+                m2 = NP.asarray(roi_info['ind']).ravel()
+                if m2.size > 0:
+                    try:
+                        pb = NP.asarray(roi_info['pbeam']).reshape(-1, nchan)
+                    except ValueError:
+                        raise ValueError('Number of columns of primary beam in key "pbeam" of dictionary roi_info must be equal to number of frequency channels.')
+                    if m2.size != pb.shape[0]:
+                        raise ValueError('Values in keys ind and pbeam in must carry same number of elements.')
+        else:                                                                         # :6204-6216
+            roi_radius, roi_center = self._roi_defaults(roi_radius, roi_center)
+            if roi_center == 'pointing_center':
+                dc_all = GEOM.altaz2dircos(skypos_altaz, 'degrees')
+                cosd = NP.clip(NP.dot(dc_all, pc_dircos), -1.0, 1.0)
+                m2 = NP.where(NP.degrees(NP.arccos(cosd)) <= roi_radius)[0]
+            else:
+                m2 = NP.arange(skypos_altaz.shape[0])
+                m2 = m2[NP.where(skypos_altaz[:, 0] >= 90.0 - roi_radius)]
+        if len(m2) == 0:
+            return False
+        skypos_altaz_roi = skypos_altaz[m2, :]                                    # :6219
+        dircos_roi = GEOM.altaz2dircos(skypos_altaz_roi, 'degrees')               # :6263 (unconditional, Q4)
+        # flux spectra (:6249).  A power-law sky model (spec_type 'func') is described to the device by its nsrc-sized
+        # flux_ref / spindex vectors and S = flux_ref (f / ref_freq)^spindex is formed there; anything else goes through
+        # generate_spectrum on the host, as in the reference.
+        powerlaw = (getattr(skymodel, 'spec_type', None) == 'func' and pb is None
+                    and all(hasattr(skymodel, a) for a in ('flux_ref', 'spindex', 'ref_freq')))
+        if powerlaw:
+            fluxes = None
+            flux_ref = NP.asarray(skymodel.flux_ref, dtype=NP.float64)[m2]
+            spindex = NP.asarray(skymodel.spindex, dtype=NP.float64)[m2]
+            ref_freq = float(skymodel.ref_freq)
+        else:
+            fluxes = NP.asarray(skymodel.generate_spectrum(ind=m2, frequency=self.channels, interp_method='pchip'),
+                                dtype=NP.float64).reshape(-1, nchan)
+            flux_ref = spindex = ref_freq = None
+        fwhm = None
+        src_shape = getattr(skymodel, 'src_shape', None)
+        if src_shape is not None:                                                 # :6258, 6267
+            src_shape = NP.asarray(src_shape, dtype=NP.float64)
+            fwhm = NP.sqrt(src_shape[m2, 0] * src_shape[m2, 1])
+        # Upload order.  The sum over sources does not care about their order, the taper culling of the library does: for every
+        # baseline group it skips the LEADING sources of a run of one source size whose weight is provably below the tolerance,
+        # and those are the sources nearest the zenith (long baselines resolve them out: b_perp ~ |b|).  So when anything can be
+        # culled at all -- kappa_max (|b|_max f_min / c)^2 >= 18 -- each run is listed by decreasing altitude.  Class state
+        # (obs_catalog_indices, geometric_delays) keeps the catalog order.
+        up = self._cull_order(skypos_altaz_roi[:, 0], fwhm)
+        dircos_up = dircos_roi
+        if up is not None:
+            dircos_up, fwhm = dircos_roi[up], fwhm[up]
+            flux_ref, spindex = (flux_ref[up], spindex[up]) if flux_ref is not None else (None, None)
+            fluxes = fluxes[up] if fluxes is not None else None
+            pb = pb[up] if pb is not None else None
+        if pb is not None:
+            # supplied beam (ROI_parameters path): pbfluxes = pb * fluxes on the device (:6254)
+            self._ctx.set_sky(dircos_up, pb, pc_dircos, fwhm_deg=fwhm, fluxes=fluxes)
+        elif getattr(self, '_extbeam', None) is not None:
+            self._ctx.set_sky_external_analytic(dircos_up, flux_ref, spindex, ref_freq, pc_dircos, fwhm_deg=fwhm, flux_spectrum=fluxes)
+        else:
+            kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz,
+                                                      first_frequency_hz=float(self.channels[0]))                   # :6252
+            self._ctx.set_sky_analytic(dircos_up, flux_ref, spindex, ref_freq, kind, dia, bpc, pc_dircos, fwhm_deg=fwhm,
+                                       flux_spectrum=fluxes, ext=ext)
+        self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(self._baselines_local(), dircos_roi,
+                                                                             NP.float32 if memsave else NP.float64)]   # :6287-6291
+        self.obs_catalog_indices = self.obs_catalog_indices + [m2]                # :6377
+        return True
 
     # skyvis_freq: (nbl, nchan, n_acc), time fastest, like the reference (:6385-6390)
     @property
@@ -1086,11 +1334,12 @@ class InterferometerArray(object):
             raise ValueError('mode must be "track" or "drift"')
 
         jd0 = 2451545.0
-        for i in range(n_acc):                                                         # :6641-6647
-            jd = jd0 + i * t_acc / 86400.0
-            self.observe((jd, float(lst[i])), {'Tnet': Tsys[:, :, i % Tsys.shape[2]]}, bpass[:, :, i % bpass.shape[2]],
-                         pointing, skymodel, t_acc, brightness_units=brightness_units, roi_radius=roi_radius,
-                         roi_center=roi_center, memsave=memsave)
+        # :6641-6647 loops observe(); here the snapshots go to the device as ONE batch (observe_batch): the sky model stays resident,
+        # the geometry of all snapshots is formed there first, and arrays of at most 256 baselines sum all of them in one launch
+        times = [(jd0 + i * t_acc / 86400.0, float(lst[i])) for i in range(n_acc)]
+        self.observe_batch(times, [{'Tnet': Tsys[:, :, i % Tsys.shape[2]]} for i in range(n_acc)],
+                           [bpass[:, :, i % bpass.shape[2]] for i in range(n_acc)], pointing, skymodel, t_acc,
+                           roi_radius=roi_radius, roi_center=roi_center, memsave=memsave)
         self.t_obs = duration                                                          # :6654-6655
         self.n_acc = n_acc
 
@@ -1291,8 +1540,7 @@ class InterferometerArray(object):
                 arr[ind, :, :] = arr[ind, :, :].conj()
         if self.projected_baselines is not None:
             self.projected_baselines[ind, :, :] = -self.projected_baselines[ind, :, :]
-        self._ctx.set_array(self._baselines_local(), self.channels, nt_max=self._reserved)      # the resident array follows the flip
-        self._restore_external_beam()
+        self._reset_device_array()                                                 # the resident array follows the flip
         if self._reserved >= self.n_acc and self.skyvis_freq is not None:
             self._upload_cube()
 
@@ -1550,8 +1798,7 @@ class InterferometerArray(object):
             if isinstance(arr, NP.ndarray) and arr.ndim >= 1 and arr.shape[0] > 1:
                 setattr(self, name, NP.repeat(arr, num_list, axis=0))
         # the resident device array follows the expanded baseline list (slots are re-uploaded on demand)
-        self._ctx.set_array(self._baselines_local(), self.channels, nt_max=self._reserved)
-        self._restore_external_beam()
+        self._reset_device_array()
         if self._reserved >= self.n_acc and self.skyvis_freq is not None:
             self._upload_cube()
         self.generate_noise()                                                          # :6905-6906

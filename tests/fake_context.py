@@ -58,6 +58,73 @@ class OracleContext(object):
         self.pc = NP.asarray(pc_dircos, dtype=NP.float64).ravel()
         self.fwhm = None if fwhm_deg is None else NP.asarray(fwhm_deg, dtype=NP.float64)
 
+    # ---- device-resident catalogue (ABI 0.4): the host statements the device kernels restate (prisim_amd/geometry.py) ----
+    def set_catalog(self, location, coords, flux_ref=None, spindex=None, ref_freq_hz=None, flux_spectrum=None, fwhm_deg=None):
+        self._cat = {'loc': NP.asarray(location, dtype=NP.float64).reshape(-1, 2), 'coords': coords,
+                     'flux_ref': None if flux_ref is None else NP.asarray(flux_ref, dtype=NP.float64),
+                     'spindex': None if spindex is None else NP.asarray(spindex, dtype=NP.float64), 'ref_freq': ref_freq_hz,
+                     'spec': None if flux_spectrum is None else NP.asarray(flux_spectrum, dtype=NP.float64).reshape(-1, self.nchan),
+                     'fwhm': None if fwhm_deg is None else NP.asarray(fwhm_deg, dtype=NP.float64)}
+        self.ncat = self._cat['loc'].shape[0]
+
+    @staticmethod
+    def make_obs(latitude_deg, roi_radius_deg=90.0, roi_center='zenith', beam_kind=_abi.PRISIM_BEAM_DELTA, diameter_m=1.0, ext=None,
+                 use_external_beam=False):
+        if use_external_beam:
+            raise NotImplementedError('OracleContext: analytic beams only')
+        # (beam extensions are ignored, like set_sky_analytic of this stand-in does)
+        return {'lat': float(latitude_deg), 'roi_radius': float(roi_radius_deg), 'roi_center': roi_center, 'kind': beam_kind, 'dia': diameter_m}
+
+    def _roi(self, obs, lst, pc_dircos):
+        from prisim_amd import geometry as GEOM
+        cat = self._cat
+        loc = cat['loc']
+        if cat['coords'] == 'radec':
+            altaz = GEOM.hadec2altaz(NP.stack((lst - loc[:, 0], loc[:, 1]), axis=1), obs['lat'], units='degrees')
+        elif cat['coords'] == 'hadec':
+            altaz = GEOM.hadec2altaz(loc, obs['lat'], units='degrees')
+        else:
+            altaz = loc
+        if obs['roi_center'] == 'pointing_center':
+            dc_all = GEOM.altaz2dircos(altaz, 'degrees')
+            m2 = NP.where(NP.degrees(NP.arccos(NP.clip(NP.dot(dc_all, pc_dircos), -1.0, 1.0))) <= obs['roi_radius'])[0]
+        else:
+            m2 = NP.arange(altaz.shape[0])[NP.where(altaz[:, 0] >= 90.0 - obs['roi_radius'])]
+        return m2, GEOM.altaz2dircos(altaz[m2], 'degrees')
+
+    def catalog_roi(self, obs, lst_deg, pc_dircos, want_indices=True, want_dircos=True):
+        m2, dc = self._roi(obs, float(lst_deg), NP.asarray(pc_dircos, dtype=NP.float64))
+        return m2.astype(NP.int64), dc
+
+    def observe_catalog(self, obs, lst_deg, pc_dircos, beam_pc_dircos=None, precision=0, want_grad=False, slot0=0, host_cube=None, gather=None):
+        lst = NP.asarray(lst_deg, dtype=NP.float64).ravel()
+        k = lst.size
+        pc = NP.broadcast_to(NP.asarray(pc_dircos, dtype=NP.float64).reshape(-1, 3), (k, 3))
+        bpc = pc if beam_pc_dircos is None else NP.broadcast_to(NP.asarray(beam_pc_dircos, dtype=NP.float64).reshape(-1, 3), (k, 3))
+        counts = NP.zeros(k, dtype=NP.int64)
+        cat = self._cat
+        for t in range(k):
+            m2, dc = self._roi(obs, lst[t], pc[t])
+            counts[t] = m2.size
+            if m2.size == 0:
+                self.cube[slot0 + t] = 0.0
+                if want_grad:
+                    self._grad = getattr(self, '_grad', {})
+                    self._grad[slot0 + t] = NP.zeros((3, self.nbl, self.nchan), dtype=NP.complex128)
+            else:
+                fw = None if cat['fwhm'] is None else cat['fwhm'][m2]
+                if cat['spec'] is not None:
+                    self.set_sky_analytic(dc, None, None, None, obs['kind'], obs['dia'], bpc[t], pc[t], fwhm_deg=fw, flux_spectrum=cat['spec'][m2])
+                else:
+                    self.set_sky_analytic(dc, cat['flux_ref'][m2], cat['spindex'][m2], cat['ref_freq'], obs['kind'], obs['dia'], bpc[t], pc[t], fwhm_deg=fw)
+                self.compute(precision=precision, want_grad=want_grad, slot=slot0 + t)
+            if host_cube is not None:
+                host_cube[slot0 + t] = self.cube[slot0 + t].astype(host_cube.dtype)
+            if gather is not None:
+                raise NotImplementedError('OracleContext: per-snapshot gathers')
+        self.nsrc = int(counts[-1]) if k else 0
+        return counts
+
     def compute(self, precision=0, kernel=0, want_grad=False, slot=0):
         if want_grad:
             self.cube[slot], g = O.skyvis(self.bl, self.ch, self.dircos, self.pb, self.pc, fwhm_deg=self.fwhm, gradient=True)
