@@ -401,6 +401,9 @@ typedef struct prisim_timing {
   double last_culled_fraction;             /* share of the snapshot's (source, baseline) pairs the taper culling skipped (packed fp32
                                               kernels, grouped fp64 taper kernel): their summed contribution is below exp(-18) (fp32) /
                                               exp(-28) (fp64) of sum|pbflux| (0: none) */
+  int32_t last_batch_snapshots;            /* snapshots whose sky-sums shared the last launch (prisim_hip_observe_catalog on arrays of at most
+                                              256 baselines: the whole chunk in one launch; last_terms and the kernel times then cover all of them) */
+  int32_t reserved_;
 } prisim_timing;
 
 int prisim_hip_sync(prisim_ctx* ctx);

@@ -137,7 +137,8 @@ class PrisimTiming(C.Structure):
                 ('n_kernel', C.c_int64), ('last_terms', C.c_int64), ('last_kernel_id', C.c_int32),
                 ('last_chan_tile', C.c_int32), ('last_nsplit', C.c_int32), ('last_lift_groups', C.c_int32),
                 ('last_taper_group', C.c_int32), ('last_delay_fused', C.c_int32), ('last_delay_ms', C.c_double),
-                ('last_taper_split', C.c_int32), ('last_split_uncorrected_groups', C.c_int32), ('last_culled_fraction', C.c_double)]
+                ('last_taper_split', C.c_int32), ('last_split_uncorrected_groups', C.c_int32), ('last_culled_fraction', C.c_double),
+                ('last_batch_snapshots', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class PrisimCommStats(C.Structure):
@@ -734,7 +735,7 @@ class Context(object):
     def timing(self, reset=False):
         t = PrisimTiming()
         self._check(self._lib.prisim_hip_get_timing(self._h, C.byref(t), 1 if reset else 0), 'prisim_hip_get_timing')
-        return {k: getattr(t, k) for k, _ in PrisimTiming._fields_}
+        return {k: getattr(t, k) for k, _ in PrisimTiming._fields_ if k != 'reserved_'}
 
     def device_info(self):
         cu, clk = C.c_int(), C.c_int()

@@ -9,6 +9,7 @@
 //   delay power           prisim/delay_spectrum.py:3992-3993
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "skyvis_kernels.h"
 #include "../../include/prisim_hip.h"
 
@@ -17,15 +18,42 @@ namespace prisim {
 static constexpr double kC = 299792458.0;
 static constexpr double kPi = 3.14159265358979323846;
 
-// thread per (source, channel); channel fastest (coalesced store of pb_out[s][f])
+// thread per (source, channel); channel fastest (coalesced store of pb_out[s][f]).  The launchers make the total thread count a
+// multiple of nchan, so a thread keeps ONE channel over its whole grid-stride loop and everything that depends on the frequency alone
+// -- the wavenumber, the on-axis normalisation 2 J1(x0) / x0 of the Airy pattern (a second Bessel function per element otherwise), the
+// Gaussian's width, the ground plane's denominator -- is formed once per thread (config 2 x 64 snapshots: 1.40 -> see DESIGN 4.4).
 __global__ __launch_bounds__(256)
-void k_beam_flux(const BeamParams p) {
+void k_beam_flux(BeamParams p) {
+  if (p.batch != nullptr) {            // one snapshot of a batch per blockIdx.y: its rows of the geometry set and of pb, its beam pointing
+    const BatchSnap sn = p.batch[blockIdx.y];
+    p.dirs += sn.dir0 * 4;
+    if (p.src_index) p.src_index += sn.dir0;
+    p.pb_out += sn.pb0 * p.nchan;
+    p.nsrc = sn.nsrc;
+    p.bpc_x = sn.bpc[0]; p.bpc_y = sn.bpc[1]; p.bpc_z = sn.bpc[2];
+  }
   const int64_t total = p.nsrc * p.nchan;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = i / p.nchan;
-    const int64_t k = i - s * p.nchan;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;            // a multiple of nchan (launch_beam_flux)
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 >= total) return;
+  const int64_t k = i0 % p.nchan;
+  const int64_t ds = stride / p.nchan;                               // sources per step of the loop
+  const double f = p.freqs[k];
+  const double kk = 2.0 * kPi * f / kC;                              // :609, :950
+  const double lam = kC / f;
+  // Airy: small-angle floor and on-axis value (:611-618)
+  const double sin_tol = sin(1e-10);
+  const double a0 = kk * 0.5 * p.diameter * sin_tol;
+  const double mx_airy = p.beam_kind == PRISIM_BEAM_AIRY ? 2.0 * j1(a0) / a0 : 1.0;
+  // Gaussian (:717-721)
+  const double sigma_aprtr = p.diameter / (2.0 * sqrt(2.0 * log(2.0))) / lam;
+  const double sigma_dircos = 1.0 / (2.0 * kPi * sigma_aprtr);
+  const double kh = kk * 0.5 * p.diameter;                           // dipole: k h, h = L/2 (:1203-1204)
+  const double gp_den = p.gp_height > 0.0 ? 2.0 * sin(kk * p.gp_height) : 1.0;      // :965-966
+  const double fr = f / p.ref_freq;
+  int64_t s = i0 / p.nchan;
+  for (int64_t i = i0; i < total; i += stride, s += ds) {
     const double4 d = reinterpret_cast<const double4*>(p.dirs)[s];
-    const double f = p.freqs[k];
     // angle to the beam pointing centre: cos = s.p, sin = |s x p|
     const double cx = d.y * p.bpc_z - d.z * p.bpc_y;
     const double cy = d.z * p.bpc_x - d.x * p.bpc_z;
@@ -37,22 +65,14 @@ void k_beam_flux(const BeamParams p) {
     // element FIELD pattern
     double ep = 1.0;
     if (p.beam_kind == PRISIM_BEAM_GAUSSIAN) {
-      const double sigma_aprtr = p.diameter / (2.0 * sqrt(2.0 * log(2.0))) / (kC / f);   // :717
-      const double sigma_dircos = 1.0 / (2.0 * kPi * sigma_aprtr);                        // :721
       const double r = sinx / sigma_dircos;
       ep = blank ? 0.0 : exp(-0.5 * r * r);                                               // :724-725
     } else if (p.beam_kind == PRISIM_BEAM_AIRY) {
-      const double kk = 2.0 * kPi * f / kC;                                               // :609
-      const double tol = 1e-10;                                                           // small_angle_tol
-      const double sin_tol = sin(tol);
       const double sx = sinx < sin_tol ? sin_tol : sinx;                                  // :611-612 (x >= tol)
       const double a = kk * 0.5 * p.diameter * sx;
-      const double a0 = kk * 0.5 * p.diameter * sin_tol;
       const double pat = 2.0 * j1(a) / a;                                                 // :614
-      const double mx = 2.0 * j1(a0) / a0;                                                // :618
-      ep = blank ? 0.0 : pat / mx;                                                        // :616, :623
+      ep = blank ? 0.0 : pat / mx_airy;                                                   // :616, :623
     } else if (p.beam_kind == PRISIM_BEAM_DIPOLE) {
-      const double kh = 2.0 * kPi * f / kC * 0.5 * p.diameter;                            // k*h, h = L/2 (:1203-1204)
       double dot = p.dip_x * d.x + p.dip_y * d.y + p.dip_z * d.z;                         // :1205
       dot = dot > 1.0 ? 1.0 : (dot < -1.0 ? -1.0 : dot);
       const double ang = acos(dot);                                                       // :1206
@@ -74,7 +94,6 @@ void k_beam_flux(const BeamParams p) {
     // isotropic-radiator array factor (:1436-1475)
     double af = 1.0;
     if (p.nax1 > 0) {
-      const double lam = kC / f;
       const double rx = (p.rot_c * d.x + p.rot_s * d.y) - (p.rot_c * p.apc_x + p.rot_s * p.apc_y);      // :1443-1449
       const double ry = (-p.rot_s * d.x + p.rot_c * d.y) - (-p.rot_s * p.apc_x + p.rot_c * p.apc_y);
       const double phi = 2.0 * kPi * p.sep1 * rx / lam;                                   // :1458
@@ -90,7 +109,7 @@ void k_beam_flux(const BeamParams p) {
       // jitter realisations (:317, :416).  fp64 here; the reference forms the same sum in float32 / complex64.
       double acc = 0.0;
       for (int r = 0; r < p.bf_nrand; ++r) {
-        double fr = 0.0, fi = 0.0;
+        double fre = 0.0, fi = 0.0;
         for (int e = 0; e < p.bf_nelem; ++e) {
           const double geo = -(p.bf_pos[3 * e] * d.x + p.bf_pos[3 * e + 1] * d.y + p.bf_pos[3 * e + 2] * d.z) / kC;
           double ph = f * (geo + p.bf_delays[(size_t)e * p.bf_nrand + r]);               // cycles
@@ -98,10 +117,10 @@ void k_beam_flux(const BeamParams p) {
           double sn, cs;
           sincospi(2.0 * ph, &sn, &cs);
           const double g = p.bf_gains[(size_t)e * p.bf_nrand + r];
-          fr = fma(g, cs, fr);
+          fre = fma(g, cs, fre);
           fi = fma(g, sn, fi);
         }
-        acc += fr * fr + fi * fi;
+        acc += fre * fre + fi * fi;
       }
       const double n2 = (double)p.bf_nelem * (double)p.bf_nelem;
       pb = ep * ep * acc / (n2 * (double)p.bf_nrand);
@@ -116,7 +135,6 @@ void k_beam_flux(const BeamParams p) {
       else if (pb >= 1.01) atomicOr(p.flag, 1);
     }
     if (p.gp_height > 0.0) {                                                              // ground plane (:950-966)
-      const double kk = 2.0 * kPi * f / kC;
       const double nz = d.z < -1.0 ? -1.0 : (d.z > 1.0 ? 1.0 : d.z);                      // sin(alt) = n
       double gp = 2.0 * sin(kk * p.gp_height * nz);                                       // :953
       if (p.gp_modify & 1) {
@@ -125,22 +143,43 @@ void k_beam_flux(const BeamParams p) {
         if (p.gp_modify & 4) val = val < 0.0 ? 0.0 : (val > p.gp_max ? p.gp_max : val);   // :960-961
         gp *= val;
       }
-      gp /= 2.0 * sin(kk * p.gp_height);                                                  // :965-966
+      gp /= gp_den;                                                                       // :965-966
       pb *= gp * gp;                                                                      // :439
     }
     // (catalogue path: the flux vectors / spectra stay in catalogue order and are read through the compacted index list)
     const int64_t cs = p.src_index ? (int64_t)p.src_index[s] : s;
-    const double flux = p.flux_spec ? p.flux_spec[cs * p.nchan + k] : p.flux_ref[cs] * pow(f / p.ref_freq, p.spindex[cs]);
+    const double flux = p.flux_spec ? p.flux_spec[cs * p.nchan + k] : p.flux_ref[cs] * pow(fr, p.spindex[cs]);
     p.pb_out[i] = pb * flux;
   }
+}
+
+// grid of a beam launch: as many blocks as the work wants, rounded to a whole number of channel periods (blocks x 256 threads a
+// multiple of nchan) so that every thread keeps its channel
+static unsigned beam_grid(int64_t total, int64_t nchan, int64_t cap, int64_t rows) {
+  // a thread amortises its per-channel constants over ~16 sources as long as `rows` launches of this grid (snapshots of a batch)
+  // still put >= 1024 blocks on the chip
+  int64_t g = (total + 255) / 256;
+  const int64_t want = std::max<int64_t>((g + 15) / 16, std::min<int64_t>(g, (1024 + rows - 1) / rows));
+  g = std::min(want, cap);
+  int64_t a = nchan, b = 256;
+  while (b) { const int64_t t = a % b; a = b; b = t; }               // gcd(nchan, 256)
+  const int64_t period = nchan / a;                                  // blocks per channel period
+  g = (g + period - 1) / period * period;
+  return (unsigned)g;
 }
 
 hipError_t launch_beam_flux(const BeamParams& p, hipStream_t stream) {
   const int64_t total = p.nsrc * p.nchan;
   if (total == 0) return hipSuccess;
-  int64_t g = (total + 255) / 256;
-  if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(k_beam_flux, dim3((unsigned)g), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(k_beam_flux, dim3(beam_grid(total, p.nchan, 16384, 1)), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+// p.batch[nsnap] set, p.nsrc = the largest source count of the batch (sizes the grid)
+hipError_t launch_beam_flux_batch(const BeamParams& p, int nsnap, hipStream_t stream) {
+  const int64_t total = p.nsrc * p.nchan;
+  if (total == 0 || nsnap <= 0 || !p.batch) return hipSuccess;
+  hipLaunchKernelGGL(k_beam_flux, dim3(beam_grid(total, p.nchan, 4096, nsnap), (unsigned)nsnap), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 

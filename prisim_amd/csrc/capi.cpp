@@ -144,21 +144,29 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
       if (want > 16) want = std::max<int64_t>(16, std::min<int64_t>((3 * slots / 2 + base / 2) / std::max<int64_t>(base, 1), cap));
     }
     nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, 64));
-    if (!pl.f32 && ctx->taper && (ct == 16 || ct == 32) && pl.kernel == PRISIM_KERNEL_RECURRENCE && nbl <= kBlockThreads && !ctx->tune_chunk) {
-      // One baseline group, fp64 with the taper: wave items (run_pass) -- two wavefronts on every SIMD, and at least 16 sources per
-      // item.  Config 2 (3 baseline waves x 16 tiles): 42 splits of 36 sources = 2016 wavefronts in 512 blocks.
-      const int64_t nbw = (nbl + 63) / 64;
+  }
+  if (!pl.f32 && ctx->taper && (ct == 16 || ct == 32) && pl.kernel == PRISIM_KERNEL_RECURRENCE && nbl <= kBlockThreads && !ctx->tune_chunk &&
+      taper_f64_grouped_enabled()) {
+    // One baseline group, fp64 with the taper: wave items (run_pass) -- two wavefronts on every SIMD, and at least 16 sources per
+    // item.  Config 2 (3 baseline waves x 16 tiles): 42 splits of 36 sources = 2016 wavefronts in 512 blocks.  A requested split
+    // count (set_tuning) is cut by the same rule: a single launch then partitions a sky exactly as a batched launch
+    // (prisim_hip_observe_catalog) with that split count does.
+    const int64_t nbw = (nbl + 63) / 64;
+    int64_t s_want;
+    if (ctx->tune_nsplit) {
+      s_want = ctx->tune_nsplit;
+    } else {
       const int64_t waves = 2LL * 4 * std::max(ctx->cu_count, 1);
-      int64_t s_want = std::max<int64_t>(1, waves / (pl.ntiles * nbw));
+      s_want = std::max<int64_t>(1, waves / (pl.ntiles * nbw));
       s_want = std::min<int64_t>(s_want, std::max<int64_t>(1, nsrc / 16));
-      if (s_want > 1) {
-        const int64_t per = round_up((nsrc + s_want - 1) / s_want, 4);
-        pl.chunk = 4;
-        pl.nsrc_pad = round_up(std::max<int64_t>(nsrc, 1), 16);
-        pl.src_per_split = per;
-        pl.nsplit = (int)((nsrc + per - 1) / per);
-        return pl;
-      }
+    }
+    if (s_want > 1) {
+      const int64_t per = wave_split_sources(nsrc, s_want);
+      pl.chunk = 4;
+      pl.nsrc_pad = round_up(std::max<int64_t>(nsrc, 1), 16);
+      pl.src_per_split = per;
+      pl.nsplit = (int)std::max<int64_t>(1, (nsrc + per - 1) / per);
+      return pl;
     }
   }
   if (!ctx->tune_chunk && (!pl.f32 || ctx->tune_nsplit)) {
@@ -253,7 +261,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
     release(*b);
   for (SkyBufs& k : ctx->skb) {
     for (DevBuf* b : {&k.pb, &k.packed, &k.dirs_prep, &k.dirs_c32, &k.lift_flags, &k.split_flags, &k.moments, &k.moments_part, &k.split_count, &k.cull_first,
-                      &k.dirs_sorted, &k.idx_sorted})
+                      &k.dirs_sorted, &k.idx_sorted, &k.batch_tab})
       release(*b);
     if (k.ev_prep) (void)hipEventDestroy(k.ev_prep);
     if (k.ev_sum) (void)hipEventDestroy(k.ev_sum);
@@ -937,8 +945,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
   // fp64 with the source-shape taper (the reference's default precision on every run_prisim.py sky): the grouped kernel
   // k_skyvis_taper_f64 on 16- / 32-channel tiles, rows in natural channel order (PRISIM_HIP_TAPER_F64_GROUP=0: the exact second-order
   // form, k_skyvis_rec<double, CT, true> -- the A/B baseline and the 8-channel tiles' kernel)
-  bool g64 = !pl.f32 && ctx->taper && (pl.ct == 16 || pl.ct == 32);
-  if (const char* env = getenv("PRISIM_HIP_TAPER_F64_GROUP")) g64 = g64 && atoi(env) != 0;
+  const bool g64 = !pl.f32 && ctx->taper && (pl.ct == 16 || pl.ct == 32) && taper_f64_grouped_enabled();
   if (prep && scale_comp < 0)      // the snapshot's first pass: rows and directions in one launch
     HIPCHK(ctx, launch_pack_prep((const double*)ctx->sk->pb.p, ctx->sk->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
                                  g64 ? 0 : 1, ctx->dirs_p, (double*)ctx->sk->dirs_prep.p, ctx->pc[0], ctx->pc[1], ctx->pc[2],
@@ -1155,6 +1162,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
   ctx->timing.last_taper_split = 0;
   ctx->timing.last_split_uncorrected_groups = 0;
   ctx->timing.last_culled_fraction = 0.0;
+  ctx->timing.last_batch_snapshots = 1;
   if (pl.kernel == PRISIM_KERNEL_RECURRENCE) {
     const size_t pbytes = (size_t)pl.ntiles * pl.nsrc_pad * pl.ct * (pl.f32 ? 4 : 8);
     if ((rc = ensure(ctx, ctx->sk->packed, pbytes))) return rc;

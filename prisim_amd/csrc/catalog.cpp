@@ -255,6 +255,186 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
   return PRISIM_OK;
 }
 
+
+// ---- many snapshots of a small array in ONE launch -------------------------------------------------------------------------------
+// Arrays of at most 256 baselines (HERA-19: 171 = 3 baseline waves) cannot fill the chip with one snapshot: config 2's sky-sum is a
+// 50 us launch at 0.17 of the fp64 roofline, three more launches per snapshot, and ~0.2 ms of host time around them.  With the
+// catalogue resident the snapshots of a chunk are independent work items: their beam x flux, their packing and their sky-sums each go
+// into ONE launch over (snapshot, ...) and one reduction -- the work item of the sky-sum is (snapshot, baseline wave, channel tile,
+// source split).  Eligible: fp64 with the source-shape taper (the grouped kernel), a uniform channel grid, one source run at most,
+// nothing the taper culling could skip, an analytic beam without a beamformer, no gradient.  Everything else takes the per-snapshot loop.
+bool wave_batch_eligible(const prisim_ctx* ctx, const prisim_obs* obs, int precision, int want_grad, int64_t kc) {
+  const auto& C = ctx->cat;
+  if (const char* env = getenv("PRISIM_HIP_WAVE_BATCH")) { if (atoi(env) == 0) return false; }
+  if (const char* env = getenv("PRISIM_HIP_WAVE_ITEMS")) { if (atoi(env) == 0) return false; }
+  if (kc < 2 || precision != PRISIM_FP64 || want_grad || !ctx->uniform || ctx->nbl > kBlockThreads || ctx->nchan < 16) return false;
+  if (!C.have_shape || C.runs.size() > 1 || !taper_f64_grouped_enabled()) return false;      // (no runs at all: sizes vary source by source -- one launch too)
+  if (obs->use_external_beam || beamformer_doubles(obs->ext) != 0 || obs->beam_kind == PRISIM_BEAM_POLY) return false;
+  if (ctx->tune_chunk) return false;
+  if (cat_sort_wanted(ctx)) return false;
+  // nothing to cull for any precision (the cull table is per snapshot)
+  if (!C.runs.empty()) {
+    const double fmin = std::min(std::fabs(ctx->h_freqs.front()), std::fabs(ctx->h_freqs.back()));
+    double hmax = 0.0;
+    for (double v : ctx->grp_minh) hmax = std::max(hmax, v);
+    if (C.kappa_max * hmax * hmax * (fmin / kC) * (fmin / kC) >= kCullThr[1]) return false;
+  }
+  return true;
+}
+
+int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int b, int64_t kc, int64_t slot0, int64_t* nsrc_roi) {
+  auto& C = ctx->cat;
+  auto& S = C.set[b];
+  int rc;
+  // buffer set and preparation stream, as activate_snapshot
+  bool async = true;
+  if (const char* env = getenv("PRISIM_HIP_PREP_ASYNC")) async = atoi(env) != 0;
+  if (async) {
+    ctx->sk = &ctx->skb[ctx->sk_next];
+    ctx->sk_next ^= 1;
+    ctx->prep_async = true;
+    if (ctx->sk->sum_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->prep_stream, ctx->sk->ev_sum, 0));
+  } else {
+    if (ctx->prep_async) HIPCHK(ctx, hipStreamSynchronize(ctx->prep_stream));
+    ctx->prep_async = false;
+    ctx->sk = &ctx->skb[0];
+  }
+  const hipStream_t ps = pstream(ctx);
+  SkyBufs& K = *ctx->sk;
+  // plan: 32-channel tiles (the seed of a (source, baseline, tile) triple is 26 % of a 32-channel tile's instructions, 41 % of a
+  // 16-channel tile's), source splits so that the grid is about three rounds of two wavefronts per SIMD
+  int ct = ctx->tune_ct ? ctx->tune_ct : (ctx->nchan >= 32 ? 32 : 16);
+  if (ct != 16 && ct != 32) ct = 32;
+  const int ntiles = (int)((ctx->nchan + ct - 1) / ct);
+  const int nbw = (int)((ctx->nbl + 63) / 64);
+  int64_t nmax = 0, ntot = 0;
+  for (int64_t t = 0; t < kc; ++t) { nmax = std::max(nmax, C.out_host[t].nsrc); ntot += C.out_host[t].nsrc; }
+  int64_t nsplit = ctx->tune_nsplit;
+  if (nsplit == 0) {
+    const int64_t slots = 2LL * 4 * std::max(ctx->cu_count, 1);
+    const int64_t items0 = kc * nbw * ntiles;
+    nsplit = std::max<int64_t>(1, (5 * slots / 2 + items0 - 1) / items0);
+    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, nmax / 16));
+    nsplit = std::min<int64_t>(nsplit, 64);
+  }
+  const size_t slot_elems = (size_t)ctx->nbl * ctx->nchan * 2;
+  // per-snapshot layout
+  if ((rc = ensure(ctx, K.batch_tab, (size_t)kc * sizeof(BatchSnap)))) return rc;
+  if (kc > C.cap_batch_host) {
+    if (C.batch_host) (void)hipHostFree(C.batch_host);
+    C.batch_host = nullptr; C.cap_batch_host = 0;
+    if (hipHostMalloc((void**)&C.batch_host, (size_t)std::max<int64_t>(kc, 64) * 2 * sizeof(BatchSnap), hipHostMallocDefault) != hipSuccess) {
+      C.batch_host = nullptr;
+      return fail(ctx, PRISIM_ENOMEM, "hipHostMalloc for the batch table failed");
+    }
+    C.cap_batch_host = std::max<int64_t>(kc, 64);
+  }
+  // (two halves of the pinned table alternate with the buffer sets: the copy of chunk c may still be in flight when chunk c+1 is laid out)
+  BatchSnap* tab = C.batch_host + (size_t)(ctx->sk == &ctx->skb[1] ? C.cap_batch_host : 0);
+  if (nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)kc * (size_t)nsplit * slot_elems * sizeof(double)))) return rc;
+  int64_t row = 0, pb0 = 0, max_nrow = 0;
+  for (int64_t t = 0; t < kc; ++t) {
+    const int64_t N = C.out_host[t].nsrc;
+    if (N < 0 || N > C.n) return fail(ctx, PRISIM_EINTERNAL, "catalogue geometry returned an impossible source count");
+    BatchSnap& e = tab[t];
+    e.dir0 = t * C.n; e.nsrc = N; e.pb0 = pb0; e.row0 = row;
+    e.nrow = round_up(std::max<int64_t>(N, 1), 4);
+    e.src_per_split = wave_split_sources(N, nsplit);
+    for (int i = 0; i < 3; ++i) { e.pc[i] = snaps[t].pc_dircos[i]; e.bpc[i] = snaps[t].beam_pc_dircos[i]; }
+    e.out = nsplit > 1 ? (double*)ctx->partial.p + (size_t)t * (size_t)nsplit * slot_elems : (double*)ctx->cube.p + (size_t)(slot0 + t) * slot_elems;
+    row += e.nrow; pb0 += N;
+    max_nrow = std::max(max_nrow, e.nrow);
+    if (nsrc_roi) nsrc_roi[t] = N;
+  }
+  const int64_t pitch = row;
+  if ((rc = ensure(ctx, K.pb, (size_t)std::max<int64_t>(ntot * ctx->nchan, 1) * sizeof(double))) ||
+      (rc = ensure(ctx, K.packed, (size_t)ntiles * (size_t)pitch * ct * sizeof(double))) ||
+      (rc = ensure(ctx, K.dirs_prep, (size_t)pitch * 4 * sizeof(double))) || (rc = ensure(ctx, ctx->sky_flag, sizeof(int32_t))))
+    return rc;
+  HIPCHK(ctx, hipMemcpyAsync(K.batch_tab.p, tab, (size_t)kc * sizeof(BatchSnap), hipMemcpyHostToDevice, ps));
+  // beam x flux of all snapshots (:6249-6254), then rows + prepared directions of all snapshots
+  if (ntot > 0) {
+    BeamParams bp{};
+    bp.dirs = (const double*)S.dirs.p;
+    bp.src_index = (const int32_t*)S.idx.p;
+    bp.flux_ref = C.have_spec ? nullptr : (const double*)C.flux_ref.p;
+    bp.spindex = C.have_spec ? nullptr : (const double*)C.spindex.p;
+    bp.flux_spec = C.have_spec ? (const double*)C.spec.p : nullptr;
+    bp.freqs = (const double*)ctx->freqs.p;
+    bp.ref_freq = C.have_spec ? 1.0 : C.ref_freq;
+    bp.beam_kind = obs->beam_kind;
+    bp.diameter = obs->diameter_m;
+    if (obs->ext) {
+      const prisim_beam_ext* x = obs->ext;
+      bp.dip_x = x->dipole_dircos[0]; bp.dip_y = x->dipole_dircos[1]; bp.dip_z = x->dipole_dircos[2];
+      bp.dipole_mode = x->dipole_mode;
+      bp.nax1 = x->array_nax1; bp.nax2 = x->array_nax2; bp.sep1 = x->array_sep1; bp.sep2 = x->array_sep2;
+      const double ang = x->array_east2ax1_deg * M_PI / 180.0;
+      bp.rot_c = std::cos(ang); bp.rot_s = std::sin(ang);
+      bp.apc_x = x->array_pc_dircos[0]; bp.apc_y = x->array_pc_dircos[1]; bp.apc_z = x->array_pc_dircos[2];
+      bp.gp_height = x->ground_height; bp.gp_modify = x->ground_modify; bp.gp_scale = x->ground_scale; bp.gp_max = x->ground_max;
+    }
+    bp.flag = (int32_t*)ctx->sky_flag.p;
+    bp.nsrc = nmax; bp.nchan = ctx->nchan;
+    bp.pb_out = (double*)K.pb.p;
+    bp.batch = (const BatchSnap*)K.batch_tab.p;
+    HIPCHK(ctx, launch_beam_flux_batch(bp, (int)kc, ps));
+  }
+  HIPCHK(ctx, launch_pack_prep_batch((const double*)K.pb.p, (double*)K.packed.p, pitch, max_nrow, ctx->nchan, ct, ntiles, (const double*)S.dirs.p,
+                                     (double*)K.dirs_prep.p, 1.0 / kC, (const BatchSnap*)K.batch_tab.p, (int)kc, ps));
+  if ((rc = join_prep(ctx))) return rc;
+  // the sky-sums of the whole chunk: ONE launch, ONE reduction
+  harvest_timing(ctx, ctx->ring_pending >= prisim_ctx::kTimingRing ? 1 : 0);
+  SkyvisParams p{};
+  p.bl_x = (const double*)ctx->blx.p; p.bl_y = (const double*)ctx->bly.p; p.bl_z = (const double*)ctx->blz.p;
+  p.nbl = ctx->nbl; p.nchan = ctx->nchan;
+  p.f0 = ctx->f0; p.df = ctx->df; p.inv_c = 1.0 / kC;
+  p.dirs = (const double*)S.dirs.p;
+  p.dirs_prep = (const double*)K.dirs_prep.p;
+  p.pb_packed = K.packed.p;
+  p.fsq = (const float*)ctx->fsq.p;
+  p.fsq_scale = 1e16;
+  p.nsrc = pitch; p.nsrc_pad = pitch;                       // (the slab pitch: every snapshot's rows are a range of it)
+  p.taper = 1;
+  p.ntiles = ntiles; p.nsplit = 1; p.src_per_split = 0; p.src_chunk = 4;
+  p.flush_src = 16384; p.scale_comp = -1;
+  p.wave_nbw = nbw; p.wave_nsplit = (int32_t)nsplit;
+  p.wave_snaps = (const BatchSnap*)K.batch_tab.p; p.wave_nsnap = (int32_t)kc;
+  p.nbgroups = (int32_t)((kc * nbw * nsplit + kBlockThreads / 64 - 1) / (kBlockThreads / 64));
+  p.out = (double*)ctx->cube.p;
+  const int ri = ctx->ring_head;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_c0[ri], ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ri], ctx->stream));
+  HIPCHK(ctx, launch_skyvis_taper_f64_wave_batch(p, ct, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ri], ctx->stream));
+  if (nsplit > 1)
+    HIPCHK(ctx, launch_reduce_partials_batch((const double*)ctx->partial.p, (double*)ctx->cube.p + (size_t)slot0 * slot_elems, (int64_t)slot_elems, (int)nsplit,
+                                             (int)kc, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_c1[ri], ctx->stream));
+  if (ctx->prep_async) {
+    HIPCHK(ctx, hipEventRecord(K.ev_sum, ctx->stream));
+    K.sum_recorded = true;
+  }
+  C.cur = b;
+  catalog_after_compute(ctx);
+  ctx->ring_head = (ctx->ring_head + 1) % prisim_ctx::kTimingRing;
+  ctx->ring_pending += 1;
+  ctx->timing.last_terms = ctx->nbl * ctx->nchan * ntot;
+  ctx->timing.last_kernel_id = PRISIM_KERNEL_RECURRENCE;
+  ctx->timing.last_chan_tile = ct;
+  ctx->timing.last_nsplit = (int32_t)nsplit;
+  ctx->timing.last_lift_groups = 0;
+  ctx->timing.last_taper_group = 0;
+  ctx->timing.last_taper_split = 0;
+  ctx->timing.last_split_uncorrected_groups = 0;
+  ctx->timing.last_culled_fraction = 0.0;
+  ctx->timing.last_batch_snapshots = (int32_t)kc;
+  // no single snapshot is "the current sky" afterwards
+  ctx->sky_set = false;
+  ctx->nsrc = C.out_host[kc - 1].nsrc;
+  return PRISIM_OK;
+}
+
 // the download / gather of a finished slot, behind its sky-sum
 int post_snapshot(prisim_ctx* ctx, const prisim_post* post, int64_t slot) {
   if (!post) return PRISIM_OK;
@@ -292,6 +472,7 @@ void catalog_destroy(prisim_ctx* ctx) {
   if (C.out_host) (void)hipHostFree(C.out_host);
   if (C.snaps_host) (void)hipHostFree(C.snaps_host);
   if (C.culled_host) (void)hipHostFree(C.culled_host);
+  if (C.batch_host) (void)hipHostFree(C.batch_host);
   if (C.gstream) (void)hipStreamDestroy(C.gstream);
   ctx->prep_stream = nullptr;
   ctx->prep_async = false;
@@ -461,6 +642,13 @@ int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const pri
     const int b = C.next;
     ctx->sky_set = false;
     if ((rc = geometry_run(ctx, obs, snaps + c0, kc, b, want_keys))) return rc;
+    if (wave_batch_eligible(ctx, obs, precision, want_grad, kc)) {
+      if ((rc = run_wave_batch(ctx, obs, snaps + c0, b, kc, slot0 + c0, nsrc_roi ? nsrc_roi + c0 : nullptr))) return rc;
+      for (int64_t t = 0; t < kc; ++t)
+        if ((rc = post_snapshot(ctx, post, slot0 + c0 + t))) return rc;
+      C.next = b ^ 1;
+      continue;
+    }
     for (int64_t t = 0; t < kc; ++t) {
       if ((rc = activate_snapshot(ctx, obs, snaps[c0 + t], b, t, want_keys))) return rc;
       if (nsrc_roi) nsrc_roi[c0 + t] = ctx->nsrc;

@@ -90,6 +90,7 @@ struct SkyBufs {
   // Taper culling: cull_first[prec][run][group] = first source of the run that group still has to sum (device, int32); the sources before
   // it contribute < exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux| to every baseline of the group.
   DevBuf cull_first;
+  DevBuf batch_tab;                    // many snapshots per launch: the BatchSnap table of the chunk
   DevBuf dirs_sorted, idx_sorted;      // catalogue path: directions / catalogue indices in the altitude order of the taper culling
   hipEvent_t ev_prep = nullptr, ev_sum = nullptr;
   bool sum_recorded = false;
@@ -179,6 +180,8 @@ struct prisim_ctx {
     CatOut* out_host = nullptr;         // pinned [cap_snaps]
     CatSnap* snaps_host = nullptr;      // pinned [cap_snaps]
     uint64_t* culled_host = nullptr;    // pinned [2]
+    BatchSnap* batch_host = nullptr;    // pinned [2][cap_batch_host]: per-snapshot layout of a batched chunk
+    int64_t cap_batch_host = 0;
     int64_t cap_snaps = 0;
     hipStream_t gstream = nullptr;      // geometry stream (highest priority: a few small kernels beside a sky-sum grid)
     hipEvent_t ev_geom = nullptr;
@@ -442,6 +445,17 @@ struct Plan {
   int nbgroups;
   bool pk;         // packed-fp32 kernel (k_skyvis_rec_f32pk) with interleaved pbflux pairs
 };
+
+// wave items (arrays of at most 256 baselines, grouped fp64 taper kernel): sources per split when nsrc sources are cut into s_want pieces
+inline int64_t wave_split_sources(int64_t nsrc, int64_t s_want) {
+  return round_up((std::max<int64_t>(nsrc, 1) + s_want - 1) / std::max<int64_t>(s_want, 1), 4);
+}
+
+// PRISIM_HIP_TAPER_F64_GROUP=0 (A/B hook): fp64 taper requests run the exact second-order kernel instead of the grouped one
+inline bool taper_f64_grouped_enabled() {
+  const char* env = getenv("PRISIM_HIP_TAPER_F64_GROUP");
+  return !(env && atoi(env) == 0);
+}
 
 // the stream a sky is prepared on: the preparation stream when the current sky came from the resident catalogue, else the compute stream
 inline hipStream_t pstream(const prisim_ctx* ctx) { return ctx->prep_async ? ctx->prep_stream : ctx->stream; }

@@ -8,6 +8,19 @@ namespace prisim {
 
 static constexpr int kBlockThreads = 256;   // 4 wavefronts; lanes = baselines
 
+// One snapshot of a batched pass (many snapshots per launch; device table, one entry per snapshot)
+struct BatchSnap {
+  int64_t dir0;              // first row of the snapshot's directions / catalogue indices in the geometry set
+  int64_t nsrc;              // sources inside its region of interest
+  int64_t pb0;               // first row of its beam x flux block in pb
+  int64_t row0;              // first row of its block in the packed rows / prepared directions
+  int64_t nrow;              // rows of that block (nsrc rounded up; zero rows past nsrc)
+  int64_t src_per_split;     // wave items: sources per split
+  double pc[3];              // phase centre
+  double bpc[3];             // beam pointing centre
+  double* out;               // its sums: the cube slot (one split) or its nsplit partial cubes
+};
+
 struct SkyvisParams {
   // array (resident)
   const double* bl_x;        // [nbl] metres, East
@@ -62,6 +75,10 @@ struct SkyvisParams {
   // per block; 0 = block items
   int32_t wave_nbw;
   int32_t wave_nsplit;
+  // wave items over a batch of snapshots (k_skyvis_taper_f64_wave_batch): item g = (snapshot, split, baseline wave)
+  const BatchSnap* wave_snaps;
+  int32_t wave_nsnap;
+  int32_t pad4_;
 };
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);
@@ -73,6 +90,10 @@ hipError_t launch_skyvis_rec_f32pk_split(const SkyvisParams& p, int ct, hipStrea
 // fp64 sky-sum with the taper in the grouped form (ct = 16 or 32; rows packed in NATURAL channel order: launch_pack interleave = 0;
 // p.src_lo/src_hi, p.src_first, p.accumulate as for the packed fp32 kernels)
 hipError_t launch_skyvis_taper_f64(const SkyvisParams& p, int ct, hipStream_t stream);
+hipError_t launch_skyvis_taper_f64_wave_batch(const SkyvisParams& p, int ct, hipStream_t stream);
+hipError_t launch_pack_prep_batch(const double* pb, double* packed, int64_t pitch, int64_t max_nrow, int64_t nchan, int ct, int ntiles, const double* dirs,
+                                  double* prep, double inv_c, const BatchSnap* snaps, int nsnap, hipStream_t stream);
+hipError_t launch_reduce_partials_batch(const double* part, double* out, int64_t n2, int nsplit, int nsnap, hipStream_t stream);
 // beam-weighted sky moments of sources [s_lo, s_hi) per channel into out[4][nchan] (device), see k_taper_moments
 // flags of the split taper kernel's baseline groups from those moments, on the device (k_split_flags); *count += uncorrected groups
 hipError_t launch_split_flags(const double* mom, int64_t nchan, const double* grp_h, const double* grp_z, const int32_t* lift_flags, int nbg,
@@ -126,8 +147,11 @@ struct BeamParams {
   int64_t nsrc, nchan;
   double* pb_out;            // [nsrc][nchan]
   const int32_t* src_index;  // catalogue path: flux_ref / spindex / flux_spec rows are read at src_index[s] (nullptr: at s)
+  const BatchSnap* batch;    // many snapshots in one launch (blockIdx.y): directions / indices from row dir0, output rows from pb0, nsrc and the
+                             // beam pointing of that snapshot
 };
 hipError_t launch_beam_flux(const BeamParams& p, hipStream_t stream);
+hipError_t launch_beam_flux_batch(const BeamParams& p, int nsnap, hipStream_t stream);
 hipError_t launch_mul_inplace(double* a, const double* b, int64_t n, hipStream_t stream);
 // external HEALPix beam (aux_kernels.hip)
 hipError_t launch_extbeam_table(const double* beam, const double* interp, double* table, int64_t npix, int64_t nfreq,

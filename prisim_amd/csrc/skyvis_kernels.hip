@@ -357,11 +357,15 @@ __device__ __forceinline__ bool block_item(const SkyvisParams& p, int& slab, int
 //   is (baseline wave g mod nbw, source split g / nbw), nbw = ceil(nbl / 64), p.wave_nsplit splits.  A 171-baseline array (config 2)
 //   fills 3 of a block's 4 wavefronts: with block items one SIMD of every CU idles and the 4th wave costs nothing when added (256
 //   baselines take the time of 171, tools/config2_fullwave_probe.py); with wave items all four SIMDs carry sources.
-template <typename T, int CT, int TAPER, bool LIFT, bool WITEM = false>
+// WITEM = 2 (k_skyvis_taper_f64_wave_batch): wave items over a BATCH of snapshots -- item g is (snapshot g / (nbw nsplit), split, baseline
+//   wave); every snapshot has its own source range in the concatenated packed rows / prepared directions, its own phase centre and its
+//   own output (cube slot or partial cubes), read from the wave-uniform table p.wave_snaps.  A whole observing run of a small array
+//   (HERA-19: 3 baseline waves) fills the chip in ONE launch instead of one 50 us launch per snapshot.
+template <typename T, int CT, int TAPER, bool LIFT, int WITEM = 0>
 __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned char* flush_lds, unsigned char* pf_area, const double2* tab,
                                                 const double* etab = nullptr) {
   static_assert(CT % 8 == 0, "channel tile must be a multiple of 8");
-  static_assert(!WITEM || TAPER == 2, "wave items: the grouped fp64 taper kernel only");
+  static_assert(WITEM == 0 || TAPER == 2, "wave items: the grouped fp64 taper kernel only");
   static_assert(TAPER != 2 || (sizeof(T) == 8 && CT >= 16 && !LIFT), "the grouped fp64 taper: 16- or 32-channel tiles, folded (no lifting)");
   constexpr bool GROUPED = TAPER == 2;
   constexpr int HC = CT / 2;                       // channels per chain (here the taper multiplies pbflux, so z stays a pure rotation
@@ -382,14 +386,32 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   int split = slab / p.ntiles;
   int bwave = 0;                                    // WITEM: this wave's 64 baselines start at 64 bwave
   bool item_ok = true;
-  if constexpr (WITEM) {
+  // the source range, phase centre and output of this item's snapshot (WITEM = 2: from the batch table; else the launch's own)
+  int64_t src_lo = p.src_lo, src_hi = p.src_hi, src_per_split = p.src_per_split;
+  double pc_x = p.pc_x, pc_y = p.pc_y, pc_z = p.pc_z;
+  double* out_base = p.out;
+  if constexpr (WITEM != 0) {
     const int g = bg * (kBlockThreads / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    split = g / p.wave_nbw;                         // (block_item sees p.nsplit = 1 and p.nbgroups = quads of items)
-    bwave = g - split * p.wave_nbw;
-    item_ok = split < p.wave_nsplit;
+    if constexpr (WITEM == 2) {
+      const int per_snap = p.wave_nbw * p.wave_nsplit;
+      int snap = g / per_snap;
+      const int r = g - snap * per_snap;
+      split = r / p.wave_nbw;
+      bwave = r - split * p.wave_nbw;
+      item_ok = snap < p.wave_nsnap;
+      snap = __builtin_amdgcn_readfirstlane(item_ok ? snap : 0);
+      const BatchSnap* sn = p.wave_snaps + snap;
+      src_lo = sn->row0; src_hi = sn->row0 + sn->nsrc; src_per_split = sn->src_per_split;
+      pc_x = sn->pc[0]; pc_y = sn->pc[1]; pc_z = sn->pc[2];
+      out_base = sn->out;
+    } else {
+      split = g / p.wave_nbw;                       // (block_item sees p.nsplit = 1 and p.nbgroups = quads of items)
+      bwave = g - split * p.wave_nbw;
+      item_ok = split < p.wave_nsplit;
+    }
   }
-  const int nsp = WITEM ? p.wave_nsplit : p.nsplit;
-  const int cg = WITEM ? 0 : bg;                    // baseline group of the culling table (WITEM: one group)
+  const int nsp = WITEM != 0 ? p.wave_nsplit : p.nsplit;
+  const int cg = WITEM != 0 ? 0 : bg;               // baseline group of the culling table (WITEM: one group)
 
   int64_t s_begin = (int64_t)split * p.src_per_split;
   int64_t s_end = s_begin + p.src_per_split;
@@ -399,33 +421,33 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   // source range and accumulates: it sums the point-source runs of a mixed sky)
   constexpr bool RANGED = GROUPED || (sizeof(T) == 8 && TAPER == 0);
   if constexpr (RANGED && !GROUPED) {
-    s_begin = p.src_lo + (int64_t)split * p.src_per_split;
-    s_end = s_begin + p.src_per_split;
-    if (s_end > p.src_hi) s_end = p.src_hi;
+    s_begin = src_lo + (int64_t)split * src_per_split;
+    s_end = s_begin + src_per_split;
+    if (s_end > src_hi) s_end = src_hi;
   }
   if constexpr (GROUPED) {
     // sources [src_lo, src_hi) of the sky (a run of one source size when the host walks the sky run by run), cut into nsplit pieces;
     // taper culling as in the packed fp32 kernels: the group's leading sources are provably below the tolerance (capi.cpp) and what is
     // left is cut into nsplit equal pieces again
-    s_begin = p.src_lo + (int64_t)split * p.src_per_split;
-    s_end = s_begin + p.src_per_split;
-    if (s_end > p.src_hi) s_end = p.src_hi;
-    if (p.src_first != nullptr) {
+    s_begin = src_lo + (int64_t)split * src_per_split;
+    s_end = s_begin + src_per_split;
+    if (s_end > src_hi) s_end = src_hi;
+    if (WITEM != 2 && p.src_first != nullptr) {
       const int64_t f = p.src_first[cg];
-      if (f > p.src_lo) {
-        const int64_t per = (p.src_hi - f + nsp - 1) / nsp;
+      if (f > src_lo) {
+        const int64_t per = (src_hi - f + nsp - 1) / nsp;
         s_begin = f + (int64_t)split * per;
-        s_end = s_begin + per < p.src_hi ? s_begin + per : p.src_hi;
+        s_end = s_begin + per < src_hi ? s_begin + per : src_hi;
       }
     }
   }
 
   const int tid = threadIdx.x;
-  const int64_t b_raw = WITEM ? (int64_t)bwave * 64 + (tid & 63) : (int64_t)bg * kBlockThreads + tid;
+  const int64_t b_raw = WITEM != 0 ? (int64_t)bwave * 64 + (tid & 63) : (int64_t)bg * kBlockThreads + tid;
   const bool b_valid = b_raw < p.nbl;
   const int64_t b = b_valid ? b_raw : (p.nbl - 1);
   // a wavefront whose first baseline is out of range does no arithmetic (wave-uniform)
-  const bool wave_active = WITEM ? item_ok : ((int64_t)bg * kBlockThreads + (tid & ~63)) < p.nbl;
+  const bool wave_active = WITEM != 0 ? item_ok : ((int64_t)bg * kBlockThreads + (tid & ~63)) < p.nbl;
 
   const double bx = p.bl_x[b], by = p.bl_y[b], bz = p.bl_z[b];
   const int k0 = tile * CT;
@@ -438,7 +460,7 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   double bl2_c2 = 0.0, bpc = 0.0;
   if (TAPER) {
     bl2_c2 = (bx * bx + by * by + bz * bz) * (p.inv_c * p.inv_c);
-    bpc = (bx * p.pc_x + by * p.pc_y + bz * p.pc_z) * p.inv_c;   // tau_pc: un-offset delay = d + bpc
+    bpc = (bx * pc_x + by * pc_y + bz * pc_z) * p.inv_c;   // tau_pc: un-offset delay = d + bpc
   }
 
   T acc_re[CT], acc_im[CT];
@@ -450,14 +472,14 @@ __device__ __forceinline__ void skyvis_rec_body(const SkyvisParams& p, unsigned 
   const cdir_p gd = (cdir_p)(uintptr_t)p.dirs_prep;
   const cfsq_p gfq = (cfsq_p)(uintptr_t)(p.fsq_pairs ? p.fsq_pairs + (size_t)tile * CT : nullptr);   // fp32 taper only
 
-  double* const out = p.out + ((size_t)split * p.nbl * p.nchan) * 2;   // partial buffer of this split
+  double* const out = out_base + ((size_t)split * p.nbl * p.nchan) * 2;   // partial buffer of this split
   bool first_flush = !RANGED || p.accumulate == 0;     // accumulate: an earlier launch (another source run) already wrote this slot
 
   using FV = typename FlushCfg<T>::vec;
   constexpr int FCH = FlushCfg<T>::ch < CT ? FlushCfg<T>::ch : CT;
   FV* const wbuf = reinterpret_cast<FV*>(flush_lds) + (tid >> 6) * (64 * (FCH + 1));
   const int lane = tid & 63;
-  const int64_t bw0 = WITEM ? (int64_t)bwave * 64 : (int64_t)bg * kBlockThreads + (tid & ~63);      // first baseline of this wave
+  const int64_t bw0 = WITEM != 0 ? (int64_t)bwave * 64 : (int64_t)bg * kBlockThreads + (tid & ~63);      // first baseline of this wave
 
   auto flush = [&]() {
     if (wave_active) {
@@ -830,7 +852,21 @@ void k_skyvis_taper_f64_wave(const SkyvisParams p) {
   fill_phasor_table(tab_lds);
   fill_exp_table(etab_lds);
   __syncthreads();
-  skyvis_rec_body<double, CT, 2, false, true>(p, flush_lds, pf_area, tab_lds, etab_lds);
+  skyvis_rec_body<double, CT, 2, false, 1>(p, flush_lds, pf_area, tab_lds, etab_lds);
+}
+
+// Wave items over a batch of snapshots (WITEM = 2 above): p.wave_snaps[p.wave_nsnap], p.nbgroups = ceil(nsnap nbw wave_nsplit / 4).
+template <int CT>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2)))
+void k_skyvis_taper_f64_wave_batch(const SkyvisParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<double>()];
+  __shared__ __attribute__((aligned(16))) unsigned char pf_area[kPrefetchLdsBytes];
+  __shared__ double2 tab_lds[kTabN];
+  __shared__ double etab_lds[kExpTabN];
+  fill_phasor_table(tab_lds);
+  fill_exp_table(etab_lds);
+  __syncthreads();
+  skyvis_rec_body<double, CT, 2, false, 2>(p, flush_lds, pf_area, tab_lds, etab_lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1926,6 +1962,48 @@ __global__ void k_pack_prep(const double* __restrict__ pb, T* __restrict__ packe
   else prep_dirs(dirs, prep, nullptr, nsrc, nsrc_pad, pcx, pcy, pcz, inv_c, blockIdx.x - gpack, gridDim.x - gpack);
 }
 
+// The same two pre-passes for a BATCH of snapshots in one launch (blockIdx.y = snapshot): rows of snapshot t go to rows
+// [row0, row0 + nrow) of every tile's slab (pitch = all snapshots' rows), its beam x flux block starts at row pb0 of pb, its
+// directions at row dir0 of dirs; rows past nsrc are zero.  Natural channel order (the grouped fp64 taper kernel's layout).
+__global__ void k_pack_prep_batch(const double* __restrict__ pb, double* __restrict__ packed, int64_t pitch, int64_t nchan, int ct, int ntiles,
+                                  const double* __restrict__ dirs, double* __restrict__ prep, double inv_c, unsigned gpack,
+                                  const BatchSnap* __restrict__ snaps) {
+  const BatchSnap sn = snaps[blockIdx.y];
+  if (blockIdx.x < gpack) {
+    const int64_t total = (int64_t)ntiles * sn.nrow * ct;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gpack * blockDim.x) {
+      const int c = (int)(i % ct);
+      const int64_t s = (i / ct) % sn.nrow;
+      const int tile = (int)(i / ((int64_t)ct * sn.nrow));
+      const int64_t k = (int64_t)tile * ct + c;
+      double v = 0.0;
+      if (k < nchan && s < sn.nsrc) v = pb[(size_t)(sn.pb0 + s) * nchan + k];
+      packed[((size_t)tile * pitch + (size_t)(sn.row0 + s)) * ct + c] = v;
+    }
+  } else {
+    const unsigned bid = blockIdx.x - gpack, nb = gridDim.x - gpack;
+    for (int64_t s = (int64_t)bid * blockDim.x + threadIdx.x; s < sn.nrow; s += (int64_t)nb * blockDim.x) {
+      double4 v = make_double4(0, 0, 0, 0);
+      if (s < sn.nsrc) {
+        const double4 r = reinterpret_cast<const double4*>(dirs)[sn.dir0 + s];
+        v = make_double4((r.x - sn.pc[0]) * inv_c, (r.y - sn.pc[1]) * inv_c, (r.z - sn.pc[2]) * inv_c, r.w);
+      }
+      reinterpret_cast<double4*>(prep)[sn.row0 + s] = v;
+    }
+  }
+}
+
+// k_reduce_partials for a batch: blockIdx.y = snapshot, its nsplit partial cubes -> its (consecutive) cube slot
+__global__ void k_reduce_partials_batch(const double* __restrict__ part, double* __restrict__ out, int64_t n2, int nsplit) {
+  const double* pp = part + (size_t)blockIdx.y * (size_t)nsplit * (size_t)n2;
+  double* oo = out + (size_t)blockIdx.y * (size_t)n2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    double a = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) a += pp[(size_t)sp * n2 + i];
+    oo[i] = a;
+  }
+}
+
 // sum nsplit partial cubes [nsplit][n] (complex as 2 doubles, or 2 floats for the fp32 kernels' single-flush partials) -> out[n];
 // deterministic order, fp64 sum.
 template <typename TP>
@@ -2061,6 +2139,40 @@ hipError_t launch_skyvis_taper_f64(const SkyvisParams& p, int ct, hipStream_t st
     case 32: hipLaunchKernelGGL((k_skyvis_taper_f64<32>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// many snapshots in one launch: p.wave_snaps / p.wave_nsnap set, p.nbgroups = ceil(nsnap nbw wave_nsplit / 4), p.nsplit = 1
+hipError_t launch_skyvis_taper_f64_wave_batch(const SkyvisParams& p, int ct, hipStream_t stream) {
+  const int64_t items = (int64_t)p.ntiles * p.nbgroups;
+  if (items <= 0 || items > 0x3fffffffLL || !p.taper || p.nsplit != 1 || p.wave_nsplit < 1 || p.wave_nsnap < 1 || !p.wave_snaps || p.nbl > kBlockThreads ||
+      (int64_t)p.wave_nbw * 64 < p.nbl || (int64_t)p.nbgroups * (kBlockThreads / 64) < (int64_t)p.wave_nsnap * p.wave_nbw * p.wave_nsplit)
+    return hipErrorInvalidValue;
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
+  switch (ct) {
+    case 16: hipLaunchKernelGGL((k_skyvis_taper_f64_wave_batch<16>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
+    case 32: hipLaunchKernelGGL((k_skyvis_taper_f64_wave_batch<32>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_prep_batch(const double* pb, double* packed, int64_t pitch, int64_t max_nrow, int64_t nchan, int ct, int ntiles, const double* dirs,
+                                  double* prep, double inv_c, const BatchSnap* snaps, int nsnap, hipStream_t stream) {
+  if (nsnap <= 0 || max_nrow <= 0) return hipSuccess;
+  int64_t gp = ((int64_t)ntiles * max_nrow * ct + 255) / 256, gd = (max_nrow + 255) / 256;
+  if (gp > 2048) gp = 2048;
+  if (gd > 64) gd = 64;
+  hipLaunchKernelGGL(k_pack_prep_batch, dim3((unsigned)(gp + gd), (unsigned)nsnap), dim3(256), 0, stream, pb, packed, pitch, nchan, ct, ntiles, dirs, prep,
+                     inv_c, (unsigned)gp, snaps);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials_batch(const double* part, double* out, int64_t n2, int nsplit, int nsnap, hipStream_t stream) {
+  if (nsnap <= 0) return hipSuccess;
+  int64_t g = (n2 + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_reduce_partials_batch, dim3((unsigned)g, (unsigned)nsnap), dim3(256), 0, stream, part, out, n2, nsplit);
   return hipGetLastError();
 }
 

@@ -44,8 +44,8 @@ def test_struct_layouts_match_header():
     # prisim_beam_ext: 3 double, 4 int32, 3 double, 3 double, 3 double, 2 int32, 3 pointers, 4 double -> 176 bytes
     assert C.sizeof(_abi.PrisimBeamExt) == 176 and _abi.PrisimBeamExt.array_sep1.offset == 40 and _abi.PrisimBeamExt.bf_pos.offset == 120
     assert _abi.PrisimBeamSky.beam_kind.offset == 48 and _abi.PrisimBeamSky.diameter_m.offset == 56
-    # prisim_timing: 3 double, 2 int64, 6 int32, 1 double, 2 int32, 1 double -> 88 bytes
-    assert C.sizeof(_abi.PrisimTiming) == 88 and _abi.PrisimTiming.last_delay_ms.offset == 64 and _abi.PrisimTiming.last_taper_split.offset == 72
+    # prisim_timing: 3 double, 2 int64, 6 int32, 1 double, 2 int32, 1 double, 2 int32 -> 96 bytes
+    assert C.sizeof(_abi.PrisimTiming) == 96 and _abi.PrisimTiming.last_batch_snapshots.offset == 88 and _abi.PrisimTiming.last_delay_ms.offset == 64 and _abi.PrisimTiming.last_taper_split.offset == 72
     assert _abi.PrisimTiming.last_culled_fraction.offset == 80
     # prisim_comm_stats: 2 int64, 4 double, 4 int32 -> 64 bytes
     assert C.sizeof(_abi.PrisimCommStats) == 64 and _abi.PrisimCommStats.stream_priority.offset == 48

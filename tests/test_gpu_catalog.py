@@ -279,3 +279,122 @@ def test_catalogue_path_state_errors():
             ctx.set_sky_from_catalog(obs, 10.0, ZEN)                 # set_array drops the catalogue
         with pytest.raises(ValueError):
             ctx.set_catalog(NP.array([[NP.nan, 0.0]]), 'radec', flux_ref=NP.ones(1), spindex=NP.zeros(1), ref_freq_hz=150e6)
+
+
+# ---- many snapshots of a small array in one launch (prisim_hip_observe_catalog, wave items over a batch) ----
+def _small_array_case(nbl, nchan, nside=16, seed=2):
+    cfg = W.config2()
+    bl = cfg['baselines']
+    if nbl > bl.shape[0]:
+        bl = NP.vstack((bl, bl * 1.37))
+    bl = bl[:nbl]
+    ch = W.channel_grid(150e6, 390625.0, nchan)
+    sky = W.diffuse_sky(nside, seed)
+    return bl, ch, sky
+
+
+@pytest.mark.parametrize('nbl,nchan,k', [(171, 256, 64), (3, 64, 9), (64, 40, 5), (65, 96, 7), (256, 128, 12)])
+def test_batched_snapshots_bit_identical_to_single_launches(nbl, nchan, k):
+    """K LSTs of a small array in ONE sky-sum launch + ONE reduction; results bit-identical to K single launches cut
+    the same way (set_tuning with the batch's tile and split count), and within 1e-13 of the planner's own single launches."""
+    bl, ch, sky = _small_array_case(nbl, nchan)
+    lat, lst0 = -30.7224, 25.0
+    radec = radec_catalogue(sky, lat, lst0)
+    lsts = lst0 + 0.75 * NP.arange(k)
+    with _abi.Context(0) as ctx, _abi.Context(0) as one:
+        ctx.set_array(bl, ch, nt_max=k)
+        one.set_array(bl, ch, nt_max=1)
+        for c in (ctx, one):
+            c.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=14.0)
+        counts = ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP64)
+        tm = ctx.timing()
+        assert tm['last_batch_snapshots'] == k, tm                     # the whole chunk went into one launch
+        assert tm['last_chan_tile'] in (16, 32)
+        batch = [ctx.get_vis(slot=t) for t in range(k)]
+        # single launches, partitioned like the batch
+        one.set_tuning(tm['last_chan_tile'], 0, tm['last_nsplit'])
+        worst = 0.0
+        for t, lst in enumerate(lsts):
+            n = one.set_sky_from_catalog(obs, lst, ZEN, ZEN)
+            assert n == counts[t]
+            one.compute(precision=_abi.PRISIM_FP64)
+            assert NP.array_equal(batch[t], one.get_vis()), (t, float(NP.max(NP.abs(batch[t] - one.get_vis()))))
+        # ... and the planner's own single launches (other tiles, other splits): the same sums to rounding
+        one.set_tuning(0, 0, 0)
+        for t in (0, k // 2, k - 1):
+            one.set_sky_from_catalog(obs, lsts[t], ZEN, ZEN)
+            one.compute(precision=_abi.PRISIM_FP64)
+            scale = NP.sum(NP.abs(one.get_pbflux()), axis=0)[None, :]
+            worst = max(worst, float(NP.max(NP.abs(batch[t] - one.get_vis()) / scale)))
+        assert worst <= 1e-13, worst
+
+
+def test_batched_snapshots_against_the_oracle_with_empty_and_moving_pointings():
+    """The batched launch against the C oracle: per-snapshot phase and beam pointing centres, a snapshot with nothing above the horizon
+    (its slot must hold zeros), source sizes that vary from source to source (no runs), a flux-spectrum table read through the index list."""
+    from oracle import c_oracle as CO, beams_oracle as BO
+    bl, ch, _ = _small_array_case(100, 64)
+    lat = -30.7224
+    rng = NP.random.default_rng(21)
+    n = 900
+    radec = NP.stack((rng.uniform(40.0, 120.0, n), rng.uniform(-45.0, 0.0, n)), axis=1)       # a patch: below the horizon half a day later
+    fwhm = rng.uniform(0.0, 1.5, n)
+    spec = rng.uniform(1.0, 5.0, (n, 1)) * (ch[None, :] / 150e6) ** rng.uniform(-1.0, -0.5, (n, 1))
+    lsts = NP.array([80.0, 95.0, 260.0, 110.0])                                              # third one: nothing up
+    pcs = GEOM.altaz2dircos(NP.array([[90.0, 0.0], [80.0, 45.0], [90.0, 0.0], [70.0, 200.0]]), 'degrees')
+    with _abi.Context(0) as ctx:
+        ctx.set_array(bl, ch, nt_max=4)
+        ctx.set_catalog(radec, 'radec', flux_spectrum=spec, fwhm_deg=fwhm)
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_GAUSSIAN, diameter_m=14.0)
+        counts = ctx.observe_catalog(obs, lsts, pcs, pcs, precision=_abi.PRISIM_FP64)
+        assert ctx.timing()['last_batch_snapshots'] == 4
+        assert counts[2] == 0 and NP.all(ctx.get_vis(slot=2) == 0)
+        for t in (0, 1, 3):
+            m2, dc, altaz = host_roi(radec, lat, lsts[t])
+            assert counts[t] == m2.size > 0
+            pb = BO.gaussian_beam(14.0, altaz, ch, pointing_altaz=GEOM.dircos2altaz(pcs[t]).ravel(), power=True) * spec[m2]
+            ref = CO.skyvis(bl, ch, dc, pb, pcs[t], fwhm_deg=fwhm[m2])
+            scale = NP.sum(NP.abs(pb), axis=0)[None, :]
+            assert float(NP.max(NP.abs(ctx.get_vis(slot=t) - ref) / scale)) <= 1e-11
+
+
+def test_observing_run_on_a_small_array_uses_the_batched_launch():
+    """InterferometerArray.observing_run (interferometry.py:6414-6657) on HERA-19: the batched launch against the same run with
+    PRISIM_HIP_WAVE_BATCH=0 (one launch per snapshot) and against PRISIM_CATALOG=0 (the sky of every snapshot formed on the host)."""
+    from prisim_amd import interferometry as RI, skymodel as SM
+    cfg = W.config2()
+    lat = -30.7224
+    sky = cfg['sky']
+    radec = radec_catalogue(sky, lat, 15.0 * 1.0)
+    n = radec.shape[0]
+    tel = {'id': 'hera', 'shape': 'dish', 'size': 14.0, 'ocoords': 'altaz', 'orientation': NP.array([[90.0, 270.0]]), 'groundplane': None}
+
+    def run():
+        skymod = SM.SkyModel(location=radec, flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
+                             src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1))
+        ia = RI.InterferometerArray(['b%d' % i for i in range(cfg['baselines'].shape[0])], cfg['baselines'], cfg['channels'], telescope=tel,
+                                    latitude=lat, skycoords='radec', pointing_coords='hadec')
+        ia.observing_run(NP.array([0.0, lat]), skymod, 120.0, 120.0 * 24, cfg['channels'], NP.ones(cfg['channels'].size), 100.0, 1.0, mode='drift')
+        tm = ia._ctx.timing()
+        return ia, NP.array(ia.skyvis_freq), tm
+
+    ia, vis, tm = run()
+    assert vis.shape == (171, 256, 24) and tm['last_batch_snapshots'] == 24
+    assert [e.size for e in ia.obs_catalog_indices][0] == n and len(ia.lst) == 24 and ia.n_acc == 24
+    os.environ['PRISIM_HIP_WAVE_BATCH'] = '0'
+    try:
+        _, vis1, tm1 = run()
+    finally:
+        del os.environ['PRISIM_HIP_WAVE_BATCH']
+    assert tm1['last_batch_snapshots'] == 1
+    os.environ['PRISIM_CATALOG'] = '0'
+    try:
+        ia0, vis0, _ = run()
+    finally:
+        del os.environ['PRISIM_CATALOG']
+    scale = float(NP.max(NP.abs(vis0)))
+    assert float(NP.max(NP.abs(vis - vis1))) <= 1e-12 * scale and float(NP.max(NP.abs(vis - vis0))) <= 1e-12 * scale
+    # lazy class state of the catalogue path equals the host path's
+    assert NP.array_equal(NP.asarray(ia.obs_catalog_indices[5]), NP.asarray(ia0.obs_catalog_indices[5]))
+    assert float(NP.max(NP.abs(NP.asarray(ia.geometric_delays[5]) - NP.asarray(ia0.geometric_delays[5])))) <= 1e-20
