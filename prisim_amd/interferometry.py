@@ -818,8 +818,17 @@ class InterferometerArray(object):
                 cache = (key, self._ctx.make_obs(self.latitude, roi_radius, roi_center, use_external_beam=True))
                 self._catalog_obs_cache = cache
             return cache[1], None
-        kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz,
-                                                  first_frequency_hz=float(self.channels[0]))                   # :6252
+        if pb_info is None:
+            skey = (id(self.telescope), float(pc_altaz[0]), float(pc_altaz[1]))
+            spec = getattr(self, '_beam_spec_cache', None)
+            if spec is None or spec[0] != skey:
+                spec = (skey, PB.device_beam_spec(self.telescope, pointing_info=None, pointing_center=pc_altaz,
+                                                  first_frequency_hz=float(self.channels[0])))                  # :6252
+                self._beam_spec_cache = spec
+            kind, dia, bpc, ext = spec[1]
+        else:
+            kind, dia, bpc, ext = PB.device_beam_spec(self.telescope, pointing_info=pb_info, pointing_center=pc_altaz,
+                                                      first_frequency_hz=float(self.channels[0]))
         if pb_info is not None or (ext is not None and 'beamformer' in ext):
             return self._ctx.make_obs(self.latitude, roi_radius, roi_center, beam_kind=kind, diameter_m=dia, ext=ext), bpc
         key = (kind, dia, id(self.telescope), roi_radius, roi_center, self.latitude)
@@ -860,13 +869,21 @@ class InterferometerArray(object):
         else:
             self.pointing_center = NP.vstack((self.pointing_center, pc))
             self.phase_center = NP.vstack((self.phase_center, pc))
+        # (a drift scan points at one (HA, Dec) for hours: the conversion of the previous snapshot is kept while nothing it depends on changes)
+        key = (self.pointing_coords, float(pc[0, 0]), float(pc[0, 1]), lst if self.pointing_coords == 'radec' else None, self.latitude)
+        cache = getattr(self, '_pointing_cache', None)
+        if cache is not None and cache[0] == key:
+            return cache[1], cache[2]
         pc_altaz = self.pointing_center[-1, :]                                        # :6155-6162
         if self.pointing_coords == 'hadec':
             pc_altaz = GEOM.hadec2altaz(self.pointing_center[-1, :], self.latitude, units='degrees')
         elif self.pointing_coords == 'radec':
             pc_altaz = GEOM.hadec2altaz(NP.asarray([lst - self.pointing_center[-1, 0], self.pointing_center[-1, 1]]),
                                         self.latitude, units='degrees')
-        return pc_altaz, GEOM.altaz2dircos(pc_altaz, 'degrees').ravel()               # :6164
+        pc_altaz = NP.array(pc_altaz, dtype=NP.float64)
+        pc_dircos = GEOM.altaz2dircos(pc_altaz, 'degrees').ravel()                    # :6164
+        self._pointing_cache = (key, pc_altaz, pc_dircos)
+        return pc_altaz, pc_dircos
 
     def _unpark(self, slot):
         """Fetch whatever snapshot (and gradient block) still lives only in device slot `slot` before the slot is overwritten."""

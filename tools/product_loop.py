@@ -75,6 +75,11 @@ def run_case(cfgno, nranks, n_acc, memsave, mode, catalog, reps=2):
         nsrc = [int(e.size) for e in ia.obs_catalog_indices]
         # kernel-only: the last snapshot's sky is resident; its compute() queued n_acc times
         prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
+        batched = tm.get('last_batch_snapshots', 1)
+        if catalog:      # (a batched launch leaves no single current sky: make the last snapshot's sky current again)
+            from prisim_amd import geometry as G2
+            pcd = G2.altaz2dircos(G2.hadec2altaz(pc, lat, units='degrees'), 'degrees').ravel()
+            ia._ctx.set_sky_from_catalog(ia._catalog_obs_cache[1], float(lsts[-1]), pcd)
         ia._ctx.sync()
         ia._ctx.timing(reset=True)
         t1 = time.perf_counter()
@@ -90,7 +95,7 @@ def run_case(cfgno, nranks, n_acc, memsave, mode, catalog, reps=2):
                'kernel_only_wall_ms_per_snapshot': 1e3 * wall_k / n_acc,
                'kernel_only_kernel_ms_per_snapshot': tmk['sum_kernel_ms'] / max(tmk['n_kernel'], 1),
                'ratio_wall_over_kernel_only_wall': (wall / n_acc) / (wall_k / n_acc), 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
-               'culled_fraction_last': tm['last_culled_fraction']}
+               'culled_fraction_last': tm['last_culled_fraction'], 'snapshots_per_launch': batched}
         del ia
     return out
 
