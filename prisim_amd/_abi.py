@@ -589,6 +589,9 @@ class Context(object):
                                                                 float(power_scale), _ptr(lags), C.byref(nout)),
                     'prisim_hip_delay_transform_device')
         self._dt_nout = int(nout.value)
+        # every transform overwrites the context's ONE resident spectrum buffer: holders of a lazily fetched result (DelaySpectrum with
+        # action='store', InterferometerArray.skyvis_lag) remember the generation they produced and transform again when it has moved on
+        self._dt_generation = getattr(self, '_dt_generation', 0) + 1
         return lags, self._dt_nout
 
     def _get_resident(self, fn, what, dtype, t0, nt, rows):

@@ -234,10 +234,22 @@ class DelaySpectrum(object):
     def bp_wts(self, value):
         self._bp_wts_override = value
 
+    def _refresh_resident(self):
+        """The stored delay spectra live in the context's single resident buffer and are fetched when read.  Any later transform on that
+        context (another window or pad without action='store', InterferometerArray.delay_transform, a power-spectrum fetch) overwrites the
+        buffer: the transform is then simply run again (milliseconds) before the read -- a stored result never changes, as in the
+        reference, whose store is a host copy."""
+        ctx = self.ia._ctx
+        if getattr(ctx, '_dt_generation', None) != getattr(self, '_lag_gen', None):
+            nt, w0, pad = self._resident_args
+            ctx.delay_transform_device(nt, bpwts=w0, pad=pad, want_lag=True)
+            self._lag_gen = getattr(ctx, '_dt_generation', None)
+
     @property
     def skyvis_lag(self):
         if self._lag_resident is not None and self._skyvis_lag is None:
             nt, _ = self._lag_resident
+            self._refresh_resident()
             self._skyvis_lag = NP.transpose(self.ia._ctx.get_lags(0, nt), (1, 2, 0))
         return self._skyvis_lag
 
@@ -389,12 +401,12 @@ class DelaySpectrum(object):
                 and not any(type(sn).__name__ == '_DeviceSlot' for sn in ia._cube):
             ia._upload_cube()
         resident = bool(getattr(ia, '_cube', None)) and ia._reserved >= nt and getattr(ia, '_device_in_step', False)
-        lag_resident, skyvis_lag = None, None
+        lag_resident, skyvis_lag, resident_args = None, None, None
         if resident and same and decimate:
             w0 = layers[0][0] if layers[0].shape[0] == 1 else layers[0]
             _, nout = ctx.delay_transform_device(nt, bpwts=w0, pad=pad, want_lag=True)
             lag_resident = (nt, nout)
-            self._resident_args = (nt, w0, pad)
+            resident_args = (nt, NP.array(w0, dtype=NP.float64), pad)
         else:
             saved0 = ctx.get_vis(slot=0) if resident else None                          # the host-side transforms run through slot 0
             skyvis_lag = transform(NP.asarray(ia.skyvis_freq, dtype=NP.complex128))
@@ -437,6 +449,8 @@ class DelaySpectrum(object):
             if report is not None:
                 self._bp_wts_override = report
             self._skyvis_lag, self._lag_resident = skyvis_lag, lag_resident
+            if lag_resident is not None:               # (only a STORED result keeps a claim on the resident buffer)
+                self._resident_args, self._lag_gen = resident_args, getattr(ctx, '_dt_generation', None)
             self.vis_lag = vis_lag
             self.vis_noise_lag = vis_noise_lag
             self._lag_kernel, self._lag_kernel_maker = None, make_kernel
@@ -592,6 +606,7 @@ class DelayPowerSpectrum(object):
 
             def fetch():
                 ctx.delay_transform_device(nt, bpwts=w0, pad=pad, want_lag=True, want_power=True, power_scale=k)
+                ds._lag_gen = getattr(ctx, '_dt_generation', None)       # (the same spectra again, with their power beside them)
                 return NP.transpose(ctx.get_delay_power(0, nt), (1, 2, 0))
             dps['skyvis'] = _Deferred(fetch)
         elif ds.skyvis_lag is not None:

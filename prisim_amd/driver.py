@@ -348,9 +348,13 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
             raise ValueError('comm_uid is needed when world > 1')
         # communicator + self-test BEFORE the snapshots: a RCCL / xGMI setup that cannot move data must stop the job here, not write a
         # wrong cube (prisim_hip_comm_selftest: 1 MiB all-gather of a rank-dependent pattern, verified on every rank's host)
+        # comm_init is a collective: if it fails on this rank the exception ends the process (non-zero) and the launcher stops the peers,
+        # which sit inside ncclCommInitRank -- voting on it over the rendezvous would hang them all.  Only the self-test,
+        # which every rank reaches, is voted on.
+        ia.comm_setup(comm_uid, world, rank, selftest=False)
         ok, why = True, ''
         try:
-            ia.comm_setup(comm_uid, world, rank)
+            ia.comm_selftest()
         except _abi.PrisimHipError as exc:
             ok, why = False, str(exc)
             if rdzv is None:

@@ -570,16 +570,22 @@ class InterferometerArray(object):
         if getattr(self, '_extbeam', None) is not None:
             self._ctx.set_external_beam(*self._extbeam)
 
-    def comm_setup(self, comm_uid, nranks, rank):
+    def comm_setup(self, comm_uid, nranks, rank, selftest=True):
         """Build the RCCL communicator of this array's context (once) and run its self-test: a 1 MiB all-gather of a rank-dependent
         pattern verified on the host of every rank (prisim_hip_comm_selftest), so that a communicator that cannot move data raises HERE
         (PrisimHipError) and not as a silently wrong cube on disk.  Returns True; callers that can talk to the other ranks combine the
-        outcomes (driver.run does, over the rendezvous) so that every rank stops when one fails."""
+        outcomes of the SELF-TEST (driver.run does, over the rendezvous: selftest=False here, then comm_selftest()) so that every rank
+        stops when one fails.  comm_init itself is a collective (ncclCommInitRank): a rank whose init fails must END -- its peers are
+        inside that collective and only the launcher, seeing the exit, can stop them -- so its error is never swallowed into a vote."""
         if not getattr(self, '_comm_ready', False):
             self._ctx.comm_init(comm_uid, nranks, rank)
-            self._ctx.comm_selftest()
+            if selftest:
+                self._ctx.comm_selftest()
             self._comm_ready = True
         return True
+
+    def comm_selftest(self):
+        self._ctx.comm_selftest()
 
     def allgather(self, comm_uid, nranks, rank, download=True, root=None):
         """One RCCL all-gather of the baseline shards of all ranks (equal shard sizes; replaces the reference's per-rank
@@ -611,6 +617,7 @@ class InterferometerArray(object):
             raise RuntimeError('allgather() must be called first (it sets up the communicator)')
         if getattr(self, '_lag_resident', None) is not None:
             nt, nout = self._lag_resident
+            self._refresh_resident_lags()
             self._ctx.allgather_lags(nt)
             if not download:
                 return None
@@ -1233,10 +1240,19 @@ class InterferometerArray(object):
 
     # skyvis_lag / lag_kernel: computed on the GPU by delay_transform(); when the visibility cube is resident on the device the
     # spectra stay there too and are fetched on first read (config 5: 120 GB that a sharded run exchanges GPU -> GPU instead)
+    def _refresh_resident_lags(self):
+        """The context holds ONE resident spectrum buffer; when another transform (a DelaySpectrum of this array, a power-spectrum
+        fetch) has overwritten it since delay_transform(), the transform is run again before the spectra are read or exchanged."""
+        if getattr(self._ctx, '_dt_generation', None) != getattr(self, '_lag_gen', None) and getattr(self, '_lag_args', None) is not None:
+            nt, w, pad = self._lag_args
+            self._ctx.delay_transform_device(nt, bpwts=w, pad=pad, want_lag=True)
+            self._lag_gen = getattr(self._ctx, '_dt_generation', None)
+
     @property
     def skyvis_lag(self):
         if getattr(self, '_lag_resident', None) is not None and getattr(self, '_skyvis_lag', None) is None:
             nt, nout = self._lag_resident
+            self._refresh_resident_lags()
             self._skyvis_lag = NP.transpose(self._ctx.get_lags(0, nt), (1, 2, 0))
         return getattr(self, '_skyvis_lag', None)
 
@@ -1249,6 +1265,7 @@ class InterferometerArray(object):
         """Delay spectra (len(rows), nlag, n_acc) of selected baselines without fetching the whole cube from the device."""
         if getattr(self, '_lag_resident', None) is not None and getattr(self, '_skyvis_lag', None) is None:
             nt, nout = self._lag_resident
+            self._refresh_resident_lags()
             return NP.transpose(self._ctx.get_lags(0, nt, rows=rows), (1, 2, 0))
         if self.skyvis_lag is None:
             raise RuntimeError('delay_transform() must be called first')
@@ -1723,7 +1740,8 @@ class InterferometerArray(object):
             else:
                 labels = NP.asarray([str(l) for l in labels])
             f.write('array/labels', labels)
-            f.write('array/baselines', self.baselines, attrs={'coords': 'local-ENU', 'units': 'm'})
+            # (the reference labels the dataset 'local-ENU' whatever baseline_coords says, :8794; an equatorial array is labelled as what it holds)
+            f.write('array/baselines', self.baselines, attrs={'coords': 'equatorial-XYZ' if self.baseline_coords == 'equatorial' else 'local-ENU', 'units': 'm'})
             f.write('array/baseline_coords', str(self.baseline_coords))
             if self.projected_baselines is not None:
                 f.write('array/projected_baselines', self.projected_baselines, attrs={'coords': 'eq-XYZ', 'units': 'm'})
@@ -1894,6 +1912,8 @@ class InterferometerArray(object):
             # until skyvis_lag is read (the device cube is complex128 for memsave runs too: nothing is rounded on the way)
             self.lags, nout = self._ctx.delay_transform_device(nt_all, bpwts=w_first, pad=pad, want_lag=True)
             self._lag_resident = (nt_all, nout)
+            self._lag_args = (nt_all, None if w_first is None else NP.array(w_first, dtype=NP.float64), pad)
+            self._lag_gen = getattr(self._ctx, '_dt_generation', None)
         else:
             host_cube = NP.asarray(self.skyvis_freq, dtype=NP.complex128)
             saved0 = self._ctx.get_vis(slot=0) if resident else None       # the host-side transforms run through slot 0

@@ -179,6 +179,29 @@ def test_resident_cube_keeps_spectra_and_power_on_the_device_side_of_the_seam(mo
     assert NP.max(NP.abs(NP.abs(ds.skyvis_lag) ** 2 * dps.power_scale() - want)) <= 1e-9 * NP.max(want)
 
 
+def test_stored_spectra_survive_later_transforms_on_the_same_context(monkeypatch):
+    """delay_transform(action='store') keeps skyvis_lag lazy in the context's single resident buffer; a later transform on
+    the same context (another window without 'store', the array's own delay_transform, a power-spectrum fetch) overwrites that buffer.
+    The stored result must not change (the reference stores a host copy): the transform is run again before the read."""
+    import fake_context
+    ia, bpass = _observed_array(monkeypatch, reserve=True, ctxcls=fake_context.OracleContext)
+    w1 = NP.blackman(ia.channels.size) + 0.05
+    w2 = NP.hanning(ia.channels.size) + 0.5
+    ref = DS.DelaySpectrum(ia)
+    want = NP.array(ref.delay_transform(pad=1.0, freq_wts=w1, action=None, verbose=False)['skyvis_lag'])
+    ds = DS.DelaySpectrum(ia)
+    ds.delay_transform(pad=1.0, freq_wts=w1, action='store', verbose=False)
+    other = ds.delay_transform(pad=1.0, freq_wts=w2, action=None, verbose=False)['skyvis_lag']       # not stored: overwrites the buffer
+    assert NP.max(NP.abs(other - want)) > 1e-3 * NP.max(NP.abs(want))
+    ia.delay_transform(pad=1.0, freq_wts=w2, verbose=False)                                          # ... and so does the array's own
+    got = ds.skyvis_lag
+    assert NP.max(NP.abs(got - want)) <= 1e-12 * NP.max(NP.abs(want))
+    # the array's own lazily fetched spectra are as safe against the DelaySpectrum's transforms
+    ds2 = DS.DelaySpectrum(ia)
+    ds2.delay_transform(pad=1.0, freq_wts=w1, action='store', verbose=False)
+    assert NP.max(NP.abs(ia.skyvis_lag - other)) <= 1e-12 * NP.max(NP.abs(other))
+
+
 @pytest.mark.gpu
 def test_delay_power_spectrum_on_the_gpu_at_config2_size():
     """BASELINE config 2 (HERA-19, 256 channels, nside-16 diffuse, Airy 14 m) through observe() -> DelaySpectrum.delay_transform ->

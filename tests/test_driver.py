@@ -226,6 +226,19 @@ def test_sharded_run_stops_on_every_rank_when_any_self_test_fails(monkeypatch):
         driver.run(p, infile_dir=EX, rank=0, world=2, comm_uid=uid, verbose=False)
     with pytest.raises(ValueError):
         driver.run(p, infile_dir=EX, rank=0, world=2, comm_uid=None, verbose=False)
+    # comm_init is a collective -- a rank whose init fails must END (the launcher then stops its peers, who are inside
+    # ncclCommInitRank), not go into a rendezvous vote its peers never reach.  The error propagates even with a rendezvous at hand.
+    Ctx.fail = False
+
+    class NeverCalled(object):
+        def allgather(self, obj):
+            raise AssertionError('a failed comm_init must not be voted on')
+
+    def failing_init(self, uid, nranks, rank):
+        raise _abi.PrisimHipError('ncclCommInitRank: unhandled system error')
+    monkeypatch.setattr(Ctx, 'comm_init', failing_init)
+    with pytest.raises(_abi.PrisimHipError):
+        driver.run(p, infile_dir=EX, rank=1, world=2, comm_uid=uid, verbose=False, host_copy='root', rdzv=NeverCalled())
 
 
 @pytest.mark.gpu

@@ -308,6 +308,35 @@ def _oracle_array(monkeypatch, bl, ch):
                                   latitude=-30.7, skycoords='altaz', pointing_coords='hadec')
 
 
+def test_device_resident_gradients_and_catalogue_state_survive_conjugate(monkeypatch):
+    """with reserve() the gradient blocks of observe() live only in the device gradient cube, which prisim_hip_set_array
+    releases -- and conjugate() calls set_array.  They (and the catalogue-resident index lists) must be fetched first."""
+    from prisim_amd import skymodel as SM
+    rng = NP.random.default_rng(3)
+    bl = rng.uniform(-60.0, 60.0, size=(5, 3)) * NP.array([1.0, 1.0, 0.01])
+    ch = 150e6 + 1e5 * NP.arange(16)
+    ia = _oracle_array(monkeypatch, bl, ch)
+    skymod = SM.SkyModel(location=NP.stack((rng.uniform(20.0, 89.0, 30), rng.uniform(0.0, 360.0, 30)), axis=1), flux_ref=rng.uniform(0.5, 5.0, 30),
+                         spindex=NP.zeros(30), ref_freq=150e6)
+    ia.reserve(2)
+    for j in range(2):
+        ia.observe((2457000.5 + j, 10.0 + j), {'Tnet': 100.0}, NP.ones(16), [0.0, -30.7], skymod, 10.0, gradient_mode='baseline')
+    assert type(ia.obs_catalog_indices[0]).__name__ == '_CatalogROI' and ia.obs_catalog_indices[0].size == 30       # the catalogue path ran
+    want = NP.array(ia._ctx._grad[1])
+    ia.conjugate(ind=[0, 3])
+    got = ia.gradient['baseline']
+    assert got.shape == (3, 5, 16, 2) and NP.array_equal(got[:, :, :, 1], want)
+    assert NP.array_equal(NP.asarray(ia.obs_catalog_indices[1]), NP.arange(30))                                      # fetched before set_array dropped it
+    # the next snapshot uploads the catalogue again and goes on
+    ia2 = _oracle_array(monkeypatch, bl, ch)
+    ia2.reserve(3)
+    for j in range(2):
+        ia2.observe((2457000.5 + j, 10.0 + j), {'Tnet': 100.0}, NP.ones(16), [0.0, -30.7], skymod, 10.0)
+    ia2.conjugate(ind=[1])
+    ia2.observe((2457002.5, 12.0), {'Tnet': 100.0}, NP.ones(16), [0.0, -30.7], skymod, 10.0)
+    assert ia2.skyvis_freq.shape == (5, 16, 3)
+
+
 def test_apply_gradients_matches_the_reference_method(monkeypatch):
     """tests/golden/golden_apply_gradients.npz holds what the reference's own method returned (make_golden.make_apply_gradients)."""
     g = NP.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'golden_apply_gradients.npz'))
