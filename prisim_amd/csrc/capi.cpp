@@ -257,7 +257,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->cube, &ctx->grad, &ctx->dirs,
                     &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
-                    &ctx->dl_stage, &ctx->grp_hz, &ctx->step_tab, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
+                    &ctx->dl_stage, &ctx->grp_hz, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
   for (SkyBufs& k : ctx->skb) {
     for (DevBuf* b : {&k.pb, &k.packed, &k.dirs_prep, &k.dirs_c32, &k.lift_flags, &k.split_flags, &k.moments, &k.moments_part, &k.split_count, &k.cull_first,
@@ -1016,18 +1016,7 @@ static int run_pass(prisim_ctx* ctx, const Plan& pl, double* dst, int scale_comp
     }
     ctx->timing.last_taper_split = launches;
   } else if (pl.pk) {
-    // A/B hook of the round-4 step-table experiment (profiles/r04_ab_step_table.txt): no taper, 64-channel tiles, no source split
-    const char* stab_env = getenv("PRISIM_HIP_STEP_TABLE");
-    if (stab_env && atoi(stab_env) != 0 && !ctx->taper && pl.ct == 64 && pl.nsplit == 1 && scale_comp < 0) {
-      const int64_t pitch = (int64_t)pl.nbgroups * kBlockThreads;
-      int rc2;
-      if ((rc2 = ensure(ctx, ctx->step_tab, (size_t)pl.nsrc_pad * (size_t)pitch * sizeof(float) * 2))) return rc2;
-      p.step_tab = (const float2*)ctx->step_tab.p;
-      p.step_tab_pitch = pitch;
-      HIPCHK(ctx, launch_skyvis_rec_f32pk_stab(p, ctx->stream));
-    } else {
-      HIPCHK(ctx, launch_skyvis_rec_f32pk(p, pl.ct, ctx->stream));
-    }
+    HIPCHK(ctx, launch_skyvis_rec_f32pk(p, pl.ct, ctx->stream));
   } else if (g64) {
     // run by run when the sky comes in runs of one source size (so that every run's leading sources can be culled); with a source
     // split (partial cubes, written once per split) only a sky that is one run -- otherwise one launch over the whole sky

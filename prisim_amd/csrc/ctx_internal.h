@@ -120,7 +120,6 @@ struct prisim_ctx {
   // it contribute < exp(-18) (fp32) / exp(-28) (fp64) of sum|pbflux| to every baseline of the group.  cull_frac[prec]: culled share of
   // the snapshot's terms; cull_any[prec]: anything culled at all.
   std::vector<double> cull_rho, cull_an;    // scratch of the cull-table walk: sin / |cos| of the zenith angle of a run's leading sources
-  DevBuf step_tab;                        // round-4 experiment: step-phasor table of the packed fp32 kernel (PRISIM_HIP_STEP_TABLE=1)
   bool cull_any[2] = {false, false};
   double cull_frac[2] = {0.0, 0.0};
   int cull_nruns = 0;

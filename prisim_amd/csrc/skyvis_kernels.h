@@ -67,10 +67,6 @@ struct SkyvisParams {
   // taper culling (recurrence kernels with the taper): the sources [range start, src_first[bg]) contribute less than the precision's
   // cull threshold to every baseline of group bg and are skipped; nullptr = none
   const int32_t* src_first;
-  // step-phasor table experiment (k_skyvis_rec_f32pk_stab): [nsrc_pad][step_tab_pitch] float2 = (-sin alpha, tan alpha/2); pitch = baselines
-  // rounded up to the block size
-  const float2* step_tab;
-  int64_t step_tab_pitch;
   // wave items (k_skyvis_taper_f64_wave, nbl <= 256): wave_nbw = ceil(nbl / 64) baseline waves x wave_nsplit source splits, four items
   // per block; 0 = block items
   int32_t wave_nbw;
@@ -83,8 +79,6 @@ struct SkyvisParams {
 
 hipError_t launch_skyvis_rec(const SkyvisParams& p, bool f32, int ct, hipStream_t stream);
 hipError_t launch_skyvis_rec_f32pk(const SkyvisParams& p, int ct, hipStream_t stream);
-// round-4 experiment: the no-taper 64-channel kernel with the step phasors from a table built first (p.step_tab, p.step_tab_pitch)
-hipError_t launch_skyvis_rec_f32pk_stab(const SkyvisParams& p, hipStream_t stream);
 // split taper form for a source range of one source size (ct = 64; p.src_lo/src_hi, p.kappa0, p.split_flags, p.accumulate)
 hipError_t launch_skyvis_rec_f32pk_split(const SkyvisParams& p, int ct, hipStream_t stream);
 // fp64 sky-sum with the taper in the grouped form (ct = 16 or 32; rows packed in NATURAL channel order: launch_pack interleave = 0;

@@ -1104,15 +1104,6 @@ void k_skyvis_grad_f64(const SkyvisParams p) {
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Traffic experiment (tools/taper_traffic_ab.sh, profiles/r04_ab_taper_traffic.txt; never defined in the product build): with
-// -DPRISIM_EXPERIMENT_ROW_WRAP=N (a power of two) the packed kernels read row (s mod N) of their slab instead of row s, so the slab every
-// block streams is N x 256 bytes and stays in L2 whatever the blocks' drift -- the results are wrong, the arithmetic and the instruction
-// stream are the same: the launch then costs what it would cost if the row stream never missed L2.
-#ifdef PRISIM_EXPERIMENT_ROW_WRAP
-#define PRISIM_ROW_INDEX(s) ((s) & (PRISIM_EXPERIMENT_ROW_WRAP - 1))
-#else
-#define PRISIM_ROW_INDEX(s) (s)
-#endif
 
 __device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -1160,17 +1151,13 @@ __device__ __forceinline__ float exp2m1_small(float D) {
 //   per baseline group, capi.cpp:taper_split_plan) and, where that bound is below 2e-7 of sum|pbflux|, not corrected at all:
 //   3 = no parabola correction (6.375 packed instructions per pair of terms instead of 7.25), 2 = corrected (groups that fail the bound),
 //   4 = no correction and groups of 16 steps (the parabola is 4x larger: groups whose bound passes with that factor; 6.25 per pair).
-//   STAB (round-4 experiment, PRISIM_HIP_STEP_TABLE=1): the lifting bodies read their step phasor (sin alpha, tan alpha/2) of a
-//   (source, baseline) pair from a table a pre-pass wrote (k_step_table: [nsrc_pad][pitch] float2, 512 contiguous bytes per wavefront and
-//   source) instead of evaluating the two polynomials in each of the 16 channel tiles.
 //   GPK (GRAD bodies without the taper): the rows arrive PRE-MULTIPLIED by the gradient coefficients -- k_pack_grad writes, per source and
 //   16-channel tile, the four operand rows p, p l, p m, p n interleaved per pair as (set, up / down), 64 floats = one 256-byte row like a
 //   64-channel tile's -- so every accumulator set takes its own SGPR-pair operand straight into v_pk_fma_f32: 8 accumulate FMAs + the
 //   3-instruction lifting rotation = 11 packed instructions per pair of terms instead of 13 (term = p zeta first, then four adds / FMAs), and
 //   the per-source coefficient load disappears.
-template <int CT, bool TAPER, bool LIFT, int TGROUP = 0, int REANCHOR = 0, bool GRAD = false, bool STAB = false, bool GPK = false>
+template <int CT, bool TAPER, bool LIFT, int TGROUP = 0, int REANCHOR = 0, bool GRAD = false, bool GPK = false>
 __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, unsigned char* flush_lds) {
-  static_assert(!STAB || (LIFT && !TAPER && !GRAD), "the step table serves the plain lifting bodies");
   static_assert(!GPK || (GRAD && !TAPER), "pre-multiplied rows: the gradient bodies without the taper");
   constexpr int NR = GRAD ? 4 : 1;                   // accumulator sets: V (+ G_l, G_m, G_n)
   constexpr bool SPLIT = TGROUP >= 2;
@@ -1334,13 +1321,9 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
     double sv[4] = {0.0, 0.0, 0.0, 0.0};
     f32x8 cs = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // GRAD: (l, l, m, m, n, n, 0, 0) of the source: three SGPR pairs, one s_load_dwordx8
     const cf32x8_p gcs = (cf32x8_p)(uintptr_t)((GRAD && !GPK) ? p.dirs_c32 + (size_t)s_begin * 8 : nullptr);
-    // STAB: this lane's column of the step table, one source ahead in a register pair
-    const float2* const stab = STAB ? p.step_tab + (size_t)s_begin * (size_t)p.step_tab_pitch + (size_t)bw0 : nullptr;
-    float2 st_next = make_float2(0.f, 0.f);
-    if constexpr (STAB) st_next = stab[(size_t)seg0 * (size_t)p.step_tab_pitch + lane];
     {
       if constexpr (GRAD && !GPK) cs = gcs[seg0];
-      const cfloat_p r0 = gps + (size_t)PRISIM_ROW_INDEX(seg0) * ROWF;
+      const cfloat_p r0 = gps + (size_t)seg0 * ROWF;
 #pragma unroll
       for (int i = 0; i < NP; ++i) ra[i] = r0[i];
       // volatile: keeps instcombine from folding phi(load before the loop, load in the loop) into one load of a phi'd address at
@@ -1350,7 +1333,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       if (TAPER) sv[3] = d0[3];
     }
     for (int s = seg0; s < seg1; ++s) {
-      const cfloat_p row = gps + (size_t)PRISIM_ROW_INDEX(s) * ROWF;
+      const cfloat_p row = gps + (size_t)s * ROWF;
       const int sn = (s + 1 < seg1) ? s + 1 : s;                    // the last source is simply fetched again
       if (pf_on && ((s - seg0) & 3) == 0) {
         // every 4th source: the next 4 rows (64 lanes x 16 B) and 8 directions (64 lanes x 4 B), kPrefetchAhead sources ahead
@@ -1358,7 +1341,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
         const int spf = (s + kPrefetchAhead < n_loc - kPfRows) ? s + kPrefetchAhead : n_loc - kPfRows;
         int lane_pf = lane;
         asm volatile("" : "+v"(lane_pf));                            // formed here from the lane id: no per-lane pointers kept live across the loop
-        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)PRISIM_ROW_INDEX(spf) * ROWF + lane_pf * 4), pf_lds, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(pf_rows + (size_t)spf * ROWF + lane_pf * 4), pf_lds, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(pf_dirs + (size_t)spf * 8 + lane_pf), pf_lds, 4, 0, 0);
       }
       // the first use of sv waits for everything in flight (first piece + direction); only then ask for the second piece
@@ -1373,15 +1356,9 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
       const float ur0 = zc, ui0 = -zs;
       float rr = 1.f, ri, tpy = 0.f, dr0, di0;
       if (LIFT) {
-        if constexpr (STAB) {
-          ri = st_next.x;
-          tpy = st_next.y;
-          st_next = stab[(size_t)sn * (size_t)p.step_tab_pitch + lane];        // the next source's entry: a whole source of arithmetic ahead
-        } else {
-          const float yth = (float)(d * p.df);
-          ri = -sin_2pi_y(yth);
-          tpy = tan_pi_y(yth);
-        }
+        const float yth = (float)(d * p.df);
+        ri = -sin_2pi_y(yth);
+        tpy = tan_pi_y(yth);
         const float x1 = __builtin_fmaf(-tpy, ui0, ur0);
         di0 = __builtin_fmaf(-ri, x1, ui0);
         dr0 = __builtin_fmaf(-tpy, di0, x1);
@@ -1586,7 +1563,7 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
           }
         } else {
           // first piece + direction of the next source (NPART is even: it goes to ra)
-          const cfloat_p rn = gps + (size_t)PRISIM_ROW_INDEX(sn) * ROWF;
+          const cfloat_p rn = gps + (size_t)sn * ROWF;
 #pragma unroll
           for (int i = 0; i < NP; ++i) ra[i] = rn[i];
           const cvdouble_p dn = gds + (size_t)sn * 4;
@@ -1632,36 +1609,6 @@ void k_skyvis_rec_f32pk(const SkyvisParams p) {
     return;
   }
   skyvis_rec_f32pk_body<CT, TAPER, false>(p, flush_lds);
-}
-
-// Round-4 experiment (PRISIM_HIP_STEP_TABLE=1, profiles/r04_ab_step_table.txt): the no-taper packed kernel with the lifting groups'
-// step phasors read from a table (STAB bodies); groups without the small-angle guarantee run the plain body as before.
-template <int CT>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
-void k_skyvis_rec_f32pk_stab(const SkyvisParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char flush_lds[flush_lds_bytes<float>() + kPrefetchLdsBytes];
-  int slab_, bg;
-  if (!block_item(p, slab_, bg)) return;
-  if (p.lift_flags != nullptr && p.lift_flags[bg] != 0) {
-    skyvis_rec_f32pk_body<CT, false, true, 0, 0, false, true>(p, flush_lds);
-    return;
-  }
-  skyvis_rec_f32pk_body<CT, false, false>(p, flush_lds);
-}
-
-// step_tab[s][b] = (-sin(2 pi y), tan(pi y)), y = (float)(d df), d = b . (s - s_pc)/c: exactly what the lifting bodies evaluate themselves
-__global__ void k_step_table(const SkyvisParams p, float2* __restrict__ tab) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= p.step_tab_pitch) return;
-  const int64_t bb = b < p.nbl ? b : p.nbl - 1;
-  const double bx = p.bl_x[bb], by = p.bl_y[bb], bz = p.bl_z[bb];
-  const double4* dirs = reinterpret_cast<const double4*>(p.dirs_prep);
-  for (int64_t s = blockIdx.y; s < p.nsrc_pad; s += gridDim.y) {
-    const double4 sv = dirs[s];
-    const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));
-    const float yth = (float)(d * p.df);
-    tab[(size_t)s * (size_t)p.step_tab_pitch + b] = make_float2(-sin_2pi_y(yth), tan_pi_y(yth));
-  }
 }
 
 // Packed fp32 sky-sum of ONE source range whose sources share a size (kappa0): the split taper form (see skyvis_rec_f32pk_body).
@@ -1780,8 +1727,8 @@ void k_skyvis_grad_f32pk(const SkyvisParams p) {
   const bool small_step = p.lift_flags != nullptr && p.lift_flags[bg] != 0;
   if constexpr (!TAPER) {
     // rows pre-multiplied by (1, l, m, n) (k_pack_grad): the GPK bodies
-    if (small_step) skyvis_rec_f32pk_body<16, false, true, 0, 0, true, false, true>(p, flush_lds);
-    else skyvis_rec_f32pk_body<16, false, false, 0, 0, true, false, true>(p, flush_lds);
+    if (small_step) skyvis_rec_f32pk_body<16, false, true, 0, 0, true, true>(p, flush_lds);
+    else skyvis_rec_f32pk_body<16, false, false, 0, 0, true, true>(p, flush_lds);
   } else {
     // 8 steps per chain: one group of the grouped recurrence and no mid-chain re-anchoring (HC < 32); the REANCHOR = 2 bodies are the ones
     // that seed the step phasor for any step angle (groups without the |theta| <= 1/8 cycle guarantee)
@@ -2062,16 +2009,6 @@ hipError_t launch_skyvis_rec_f32pk(const SkyvisParams& p, int ct, hipStream_t st
     case 64: return launch_rec_pk_ct<64>(p, stream);
   }
   return hipErrorInvalidValue;
-}
-
-hipError_t launch_skyvis_rec_f32pk_stab(const SkyvisParams& p, hipStream_t stream) {
-  const int64_t items = (int64_t)p.ntiles * p.nsplit * p.nbgroups;
-  if (items <= 0 || items > 0x3fffffffLL || !p.step_tab || p.taper) return hipErrorInvalidValue;
-  // the table first (inside the caller's timed region: it is part of what this form costs per snapshot)
-  hipLaunchKernelGGL(k_step_table, dim3((unsigned)((p.step_tab_pitch + 255) / 256), 2048), dim3(256), 0, stream, p, const_cast<float2*>(p.step_tab));
-  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
-  hipLaunchKernelGGL((k_skyvis_rec_f32pk_stab<64>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
-  return hipGetLastError();
 }
 
 hipError_t launch_skyvis_rec_f32pk_split(const SkyvisParams& p, int ct, hipStream_t stream) {
