@@ -360,13 +360,20 @@ def other_kernels(ctx, cfg, zen, nlaunch=5):
     return res
 
 
-def config2_step(nlaunch=20):
-    """BASELINE config 2 as worded (HERA-19, 256 channels, nside-16 diffuse, fp64, taper): device time of one snapshot's compute
-    (prep + pack + kernel + partial reduce), minimum and median of `nlaunch` launches -- a 6.6e7-term problem: launch-bound."""
+def config2_step(nlaunch=20, nbatch=64):
+    """BASELINE config 2 as worded (HERA-19, 256 channels, nside-16 diffuse, fp64, taper).
+    `single`: device time of one snapshot's compute (prep + pack + kernel + partial reduce), minimum and median of `nlaunch` launches --
+    a 6.6e7-term problem: launch-bound.  `batch`: the same array over `nbatch` LSTs of a drift scan as ONE call of
+    prisim_hip_observe_catalog -- geometry of all snapshots on the device, one beam launch, one packing launch, ONE sky-sum launch
+    (work item = snapshot x baseline wave x channel tile x source split) and ONE reduction; per snapshot: the sky-sum kernel, the
+    sum + reduction on the compute stream ("compute"), and the wall clock of the whole call with the queue drained at both ends."""
+    from prisim_amd import geometry as GEOM
     cfg = W.config2()
     zen = NP.array([0.0, 0.0, 1.0])
     sky = cfg['sky']
-    with _abi.Context(int(os.environ.get('PRISIM_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))) as c2:
+    dev = int(os.environ.get('PRISIM_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    out = {'workload': cfg['name']}
+    with _abi.Context(dev) as c2:
         c2.set_array(cfg['baselines'], cfg['channels'], nt_max=1)
         c2.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, cfg['diameter'], zen, zen,
                             fwhm_deg=sky['fwhm_deg'])
@@ -380,11 +387,43 @@ def config2_step(nlaunch=20):
             ks.append(tm['last_kernel_ms'])
             cs.append(tm['last_compute_ms'])
         terms = float(tm['last_terms'])
-        return {'workload': cfg['name'], 'terms': terms, 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
-                'kernel_us_min': 1e3 * min(ks), 'kernel_us_median': 1e3 * float(NP.median(ks)),
-                'compute_us_min': 1e3 * min(cs), 'compute_us_median': 1e3 * float(NP.median(cs)),
-                'roofline_frac_10flop': terms * FLOPS_PER_TERM / (min(ks) * 1e-3) / 1e12 / PEAK_TFLOPS['f64'],
-                'terms_per_s_whole_compute': terms / (min(cs) * 1e-3)}
+        out.update({'terms': terms, 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
+                    'kernel_us_min': 1e3 * min(ks), 'kernel_us_median': 1e3 * float(NP.median(ks)),
+                    'compute_us_min': 1e3 * min(cs), 'compute_us_median': 1e3 * float(NP.median(cs)),
+                    'roofline_frac_10flop': terms * FLOPS_PER_TERM / (min(ks) * 1e-3) / 1e12 / PEAK_TFLOPS['f64'],
+                    'roofline_frac_10flop_whole_compute': terms * FLOPS_PER_TERM / (min(cs) * 1e-3) / 1e12 / PEAK_TFLOPS['f64'],
+                    'terms_per_s_whole_compute': terms / (min(cs) * 1e-3)})
+    lat, lst0 = -30.7224, 30.0
+    hadec = GEOM.altaz2hadec(sky['altaz'], lat, units='degrees')
+    radec = NP.stack(((lst0 - hadec[:, 0]) % 360.0, hadec[:, 1]), axis=1)
+    lsts = lst0 + 0.25 * NP.arange(nbatch)
+    with _abi.Context(dev) as c2:
+        c2.set_array(cfg['baselines'], cfg['channels'], nt_max=nbatch)
+        c2.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        obs = c2.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=cfg['diameter'])
+        best = None
+        for rep in range(6):
+            c2.sync()
+            c2.timing(reset=True)
+            t0 = time.perf_counter()
+            counts = c2.observe_catalog(obs, lsts, zen, precision=_abi.PRISIM_FP64)
+            c2.sync()
+            wall = time.perf_counter() - t0
+            tm = c2.timing()
+            bterms = float(cfg['baselines'].shape[0]) * cfg['channels'].size * float(NP.sum(counts))
+            rec = {'snapshots': nbatch, 'snapshots_per_launch': int(tm['last_batch_snapshots']), 'terms': bterms, 'chan_tile': tm['last_chan_tile'],
+                   'nsplit': tm['last_nsplit'], 'launches': int(tm['n_kernel']),
+                   'kernel_us_per_snapshot': 1e3 * tm['sum_kernel_ms'] / nbatch, 'compute_us_per_snapshot': 1e3 * tm['last_compute_ms'] * tm['n_kernel'] / nbatch,
+                   'call_us_per_snapshot': 1e6 * wall / nbatch,
+                   'roofline_frac_10flop': bterms * FLOPS_PER_TERM / (tm['sum_kernel_ms'] * 1e-3) / 1e12 / PEAK_TFLOPS['f64'],
+                   'roofline_frac_10flop_whole_compute': bterms * FLOPS_PER_TERM / (tm['last_compute_ms'] * tm['n_kernel'] * 1e-3) / 1e12 / PEAK_TFLOPS['f64'],
+                   'roofline_frac_10flop_whole_call': bterms * FLOPS_PER_TERM / wall / 1e12 / PEAK_TFLOPS['f64'],
+                   'what': 'whole_compute = sky-sum + reduction by hipEvents on the compute stream; whole_call = wall clock of prisim_hip_observe_catalog '
+                           '(geometry read-back, beam x flux, packing, sky-sum, reduction), queue drained at both ends'}
+            if rep > 0 and (best is None or rec['call_us_per_snapshot'] < best['call_us_per_snapshot']):
+                best = rec
+        out['batch'] = best
+    return out
 
 
 def shard_estimate(cfg, zen, prec, device, ranks=(1, 2, 4, 8), nqueue=6):
@@ -466,34 +505,54 @@ def power_clock(ctx, cfg, zen, prec):
     return res
 
 
-def e2e_observe(cfg, n_snap, device, memsave, to_host=False):
-    """The same workload through the reference's entry point for the path, InterferometerArray.observe() (interferometry.py:5874):
-    per snapshot the host geometry (hadec -> altaz -> direction cosines of every source), the sky staging (nsrc-sized vectors), the
-    fused beam x flux, prep, pack and the sky-sum.  Returns terms/s over n_snap snapshots, wall clock around the loop + final sync."""
-    from prisim_amd import interferometry as RI, skymodel as SM
-    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+def radec_skymodel(cfg, lat, lst0):
+    """The workload's sky (defined in the local frame at LST lst0) as a (RA, Dec) sky model -- what prisim_amd.driver.build_skymodel hands
+    to observe()."""
+    from prisim_amd import geometry as GEOM, skymodel as SM
+    sky = cfg['sky']
     n = sky['dircos'].shape[0]
-    skymod = SM.SkyModel(location=sky['altaz'], flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
-                         src_shape=(NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1) if cfg['taper'] else None))
+    hadec = GEOM.altaz2hadec(sky['altaz'], lat, units='degrees')
+    radec = NP.stack(((lst0 - hadec[:, 0]) % 360.0, hadec[:, 1]), axis=1)
+    return SM.SkyModel(location=radec, flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
+                       src_shape=(NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1) if cfg['taper'] else None))
 
-    def observe(ia, j):
-        ia.observe((2457000.5 + j * 1e-4, 0.1 * j), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, -30.7224], skymod, 10.7, memsave=memsave)
+
+def e2e_observe(cfg, n_snap, device, memsave, to_host=False, batch=False):
+    """The same workload through the reference's entry point for the path, InterferometerArray.observe() (interferometry.py:5874), on a
+    (RA, Dec) sky model with the LST advancing from snapshot to snapshot -- a drift scan as scripts/run_prisim.py:2165-2207 runs it.
+    Per snapshot: the sky geometry (hadec -> altaz -> direction cosines of every source, horizon cut), flux spectra, the fused beam x
+    flux, prep, pack and the sky-sum; since round 5 all of it on the device, from the sky model kept resident there (round 4 timed an
+    alt-az sky here, which never paid the per-snapshot transform).  batch: observe_batch() -- all snapshots in one call.
+    Returns terms/s over n_snap snapshots, wall clock around the loop + final sync."""
+    from prisim_amd import interferometry as RI
+    bl, ch = cfg['baselines'], cfg['channels']
+    lat, lst0, dlst = -30.7224, 40.0, 10.7 * 360.0 * 1.00273790935 / 86400.0
+    skymod = radec_skymodel(cfg, lat, lst0)
+    tsys, bp, pc = {'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat]
+
+    def when(j):
+        return (2457000.5 + j * 10.7 / 86400.0, lst0 + j * dlst)
 
     ia = RI.InterferometerArray(['b%d' % i for i in range(bl.shape[0])], bl, ch, telescope={'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'},
-                                latitude=-30.7224, skycoords='altaz', pointing_coords='hadec', device=device)
+                                latitude=lat, skycoords='radec', pointing_coords='hadec', device=device)
     ia.reserve(n_snap + 1, host_staging=to_host)
-    observe(ia, 0)                      # warm-up snapshot: allocations (incl. the pinned host cube), first-launch costs
+    ia.observe(when(0), tsys, bp, pc, skymod, 10.7, memsave=memsave)     # warm-up snapshot: catalogue upload, allocations, first-launch costs
     ia._ctx.sync()
     t0 = time.perf_counter()
-    for j in range(1, n_snap + 1):
-        observe(ia, j)
+    if batch:
+        ia.observe_batch([when(j) for j in range(1, n_snap + 1)], tsys, bp, pc, skymod, 10.7, memsave=memsave)
+    else:
+        for j in range(1, n_snap + 1):
+            ia.observe(when(j), tsys, bp, pc, skymod, 10.7, memsave=memsave)
     if to_host:
         cube = ia.skyvis_freq_snapshots()      # (n_acc, nbl, nchan) in page-locked host memory: waits for the last snapshot's copy only
         assert cube.shape == (n_snap + 1, bl.shape[0], ch.size)
     ia._ctx.sync()
     dt = time.perf_counter() - t0
-    terms = float(bl.shape[0]) * ch.size * n * n_snap
-    res = {'value': terms / dt, 'unit': 'terms/s', 'snapshots': n_snap, 'ms_per_snapshot': dt / n_snap * 1e3}
+    terms = float(bl.shape[0]) * ch.size * float(sum(int(e.size) for e in ia.obs_catalog_indices[1:]))
+    res = {'value': terms / dt, 'unit': 'terms/s', 'snapshots': n_snap, 'ms_per_snapshot': dt / n_snap * 1e3, 'skycoords': 'radec',
+           'sources_first_last': [int(ia.obs_catalog_indices[1].size), int(ia.obs_catalog_indices[-1].size)],
+           'catalogue_resident': type(ia.obs_catalog_indices[-1]).__name__ == '_CatalogROI'}
     if to_host:
         res['staged'] = bool(ia._stage and ia._host_cube is not None)
         res['host_bytes_per_snapshot'] = int(bl.shape[0]) * int(ch.size) * (8 if memsave else 16)
@@ -501,8 +560,147 @@ def e2e_observe(cfg, n_snap, device, memsave, to_host=False):
                        'cube on a copy stream under the next snapshot\'s sky-sum; the clock stops when the snapshot-major cube (skyvis_freq_snapshots) is '
                        'readable on the host')
     else:
-        res['path'] = 'InterferometerArray.observe(): host geometry + sky staging + fused beam + sky-sum, cube left resident on the device'
+        res['path'] = ('InterferometerArray.%s on a (RA, Dec) sky model: geometry + ROI + beam x flux on the device from the resident catalogue, '
+                       'sky-sum, cube left resident on the device' % ('observe_batch()' if batch else 'observe()'))
     ia._ctx.close()
+    return res
+
+
+def product_loop_case(cfgno, nranks, n_acc, memsave, mode, catalog, device=0, reps=2):
+    """Rank 0's share of a BASELINE configuration through the PRODUCT loop: InterferometerArray.observe() / observe_batch()
+    on a (RA, Dec) sky model as prisim_amd.driver.run drives it, wall per snapshot with the queue kept full (one synchronisation at the end),
+    beside the kernel-only figure (the same shard's compute() with the last sky resident, queued back to back).  catalog False =
+    PRISIM_CATALOG=0: every snapshot's sky formed on the host and uploaded (rounds 1-4).  The second repetition is reported."""
+    from prisim_amd import geometry as GEOM, interferometry as RI
+    os.environ['PRISIM_CATALOG'] = '1' if catalog else '0'
+    try:
+        if cfgno == 4:
+            cfg = W.config4(n_acc=n_acc)
+            tel = {'id': 'custom', 'shape': 'delta', 'size': 1.0, 'ocoords': 'altaz', 'orientation': NP.array([[90.0, 270.0]]), 'groundplane': None}
+        else:
+            cfg = W.config2() if cfgno == 2 else W.config3(with_diffuse=False)
+            cfg.update(latitude=-30.7224, t_acc=(60.0 if cfgno == 2 else 10.7))
+            tel = {'id': 'hera', 'shape': 'dish', 'size': 14.0, 'ocoords': 'altaz', 'orientation': NP.array([[90.0, 270.0]]), 'groundplane': None}
+        lat, lst0 = cfg['latitude'], 30.0
+        skymod = radec_skymodel(cfg, lat, lst0)
+        bl = sharding.shard_rows(cfg['baselines'], nranks, 0)[0]
+        ch = cfg['channels']
+        dlst = cfg['t_acc'] * 360.0 * 1.00273790935 / 86400.0
+        out = None
+        for rep in range(reps):
+            ia = RI.InterferometerArray(['b%d' % i for i in range(bl.shape[0])], bl, ch, telescope=tel, latitude=lat, skycoords='radec',
+                                        pointing_coords='hadec', device=device)
+            ia.reserve(n_acc)
+            if cfg['beam'] == 'external':
+                ia.set_external_beam(cfg['beam_table'], cfg['beam_freqs'])
+            lsts = lst0 + NP.arange(n_acc) * dlst
+            times = [(2455000.0 + j * cfg['t_acc'] / 86400.0, float(lsts[j])) for j in range(n_acc)]
+            tsys, bp, pc = {'Tnet': 100.0}, NP.ones(ch.size), NP.array([0.0, lat])
+            ia._ctx.sync()
+            ia._ctx.timing(reset=True)
+            t0 = time.perf_counter()
+            if mode == 'observe':
+                for j in range(n_acc):
+                    ia.observe(times[j], tsys, bp, pc, skymod, cfg['t_acc'], memsave=memsave)
+            else:
+                ia.observe_batch(times, tsys, bp, pc, skymod, cfg['t_acc'], memsave=memsave)
+            t_host = time.perf_counter() - t0          # the host is done queueing
+            ia._ctx.sync()
+            wall = time.perf_counter() - t0
+            tm = ia._ctx.timing()
+            nsrc = [int(e.size) for e in ia.obs_catalog_indices]
+            prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
+            batched = tm.get('last_batch_snapshots', 1)
+            if catalog:      # (a batched launch leaves no single current sky: make the last snapshot's sky current again)
+                pcd = GEOM.altaz2dircos(GEOM.hadec2altaz(pc, lat, units='degrees'), 'degrees').ravel()
+                ia._ctx.set_sky_from_catalog(ia._catalog_obs_cache[1], float(lsts[-1]), pcd)
+            ia._ctx.sync()
+            ia._ctx.timing(reset=True)
+            t1 = time.perf_counter()
+            for j in range(n_acc):
+                ia._ctx.compute(precision=prec, slot=j)
+            ia._ctx.sync()
+            wall_k = time.perf_counter() - t1
+            tmk = ia._ctx.timing()
+            out = {'config': cfgno, 'nranks': nranks, 'shard_baselines': int(bl.shape[0]), 'nchan': int(ch.size), 'n_acc': n_acc,
+                   'precision': 'fp32' if memsave else 'fp64', 'mode': mode, 'catalog': bool(catalog),
+                   'nsrc_roi_first_last': [nsrc[0], nsrc[-1]], 'wall_ms_per_snapshot': 1e3 * wall / n_acc, 'wall_ms_total': 1e3 * wall,
+                   'host_ms_per_snapshot': 1e3 * t_host / n_acc, 'kernel_ms_per_snapshot': tm['sum_kernel_ms'] / max(tm['n_kernel'], 1) / batched,
+                   'kernel_only_wall_ms_per_snapshot': 1e3 * wall_k / n_acc,
+                   'kernel_only_kernel_ms_per_snapshot': tmk['sum_kernel_ms'] / max(tmk['n_kernel'], 1),
+                   'ratio_wall_over_kernel_only_wall': (wall / n_acc) / (wall_k / n_acc), 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
+                   'culled_fraction_last': tm['last_culled_fraction'], 'snapshots_per_launch': batched}
+            ia._ctx.close()
+            del ia
+        return out
+    finally:
+        os.environ.pop('PRISIM_CATALOG', None)
+
+
+def e2e_shard_estimate(device, n_acc=32, ranks=(1, 8)):
+    """rank 0's share of BASELINE config 4 (MWA-128T, 768 channels, nside-64 diffuse, external HEALPix beam, drift
+    scan) at N = 1 and 8 THROUGH THE PRODUCT LOOP (observe_batch on the (RA, Dec) sky model) -- wall per snapshot, queued -- beside the
+    kernel-only figure.  `marginal` takes the difference of a 3 n_acc and an n_acc run: what one more snapshot costs once the catalogue
+    is resident and the clock is up (the first snapshots of any run carry the catalogue upload, the first allocations and ~30 ms of
+    clock ramp)."""
+    res = {'what': 'rank 0 of N on one GPU, config 4, fp32; wall ms per snapshot through InterferometerArray.observe_batch (driver.run\'s loop) '
+                   'against compute() alone with the sky resident; marginal = (wall(3 n) - wall(n)) / 2n', 'n_acc': n_acc}
+    for n in ranks:
+        a = product_loop_case(4, n, n_acc, True, 'batch', True, device=device)
+        b = product_loop_case(4, n, 3 * n_acc, True, 'batch', True, device=device, reps=1)
+        marg = (b['wall_ms_total'] - a['wall_ms_total']) / (2 * n_acc)
+        res[str(n)] = {'shard_baselines': a['shard_baselines'], 'wall_ms_per_snapshot': a['wall_ms_per_snapshot'], 'marginal_ms_per_snapshot': marg,
+                       'kernel_only_wall_ms_per_snapshot': a['kernel_only_wall_ms_per_snapshot'], 'kernel_ms_per_snapshot': a['kernel_ms_per_snapshot'],
+                       'over_kernel_only': a['wall_ms_per_snapshot'] / a['kernel_only_wall_ms_per_snapshot'],
+                       'marginal_over_kernel_only': marg / a['kernel_only_wall_ms_per_snapshot'], 'host_ms_per_snapshot': a['host_ms_per_snapshot'],
+                       'culled_fraction': a['culled_fraction_last'], 'nsplit': a['nsplit']}
+    return res
+
+
+def gather_rehearsal(cfg, zen, prec, device, nsnap=12):
+    """librccl in the driver-observed N = 1 record.  A 1-rank communicator (its own unique id), the self-test, then
+    `nsnap` snapshots of rank 0's 1/8 shard of the headline workload with prisim_hip_allgather_slot_async on the highest-priority
+    stream under the next sky-sum -- RCCL's kernels sharing the CUs with the sky-sum grid on real hardware.  It cannot measure xGMI (one
+    rank: the gather is a device-local copy through RCCL's own kernel), it does prove load, ABI and stream interplay of the box's RCCL."""
+    bl, ch, sky = cfg['baselines'], cfg['channels'], cfg['sky']
+    mine = shard_baselines(bl, 8, 0)[0]
+    c64 = prec == _abi.PRISIM_FP32
+    res = {'what': '1-rank RCCL communicator on the bench box: rank 0\'s 1/8 shard, ncclAllGather of every snapshot on the priority stream under the '
+                   'next sky-sum (no xGMI in it)', 'shard_baselines': int(mine.shape[0]), 'snapshots': nsnap, 'wire_dtype': 'complex64' if c64 else 'complex128'}
+    res['librccl'] = _abi.Context.comm_version()
+    with _abi.Context(device) as c:
+        c.set_array(mine, ch, nt_max=nsnap)
+        c.set_sky_analytic(sky['dircos'], sky['flux_ref'], sky['spindex'], sky['ref_freq'], _abi.PRISIM_BEAM_AIRY, cfg['diameter'], zen, zen,
+                           fwhm_deg=(sky['fwhm_deg'] if cfg['taper'] else None))
+        c.comm_init(_abi.Context.comm_unique_id(), 1, 0)
+        c.comm_selftest(1 << 20)
+        res['selftest'] = 'ok'
+
+        def loop(gather):
+            for t in range(3):
+                c.compute(precision=prec, slot=t)
+            c.sync()
+            c.timing(reset=True)
+            c.comm_stats(reset=True)
+            t0 = time.perf_counter()
+            for t in range(nsnap):
+                c.compute(precision=prec, slot=t)
+                if gather:
+                    c.allgather_slot_async(t, complex64=c64)
+            c.sync()
+            dt = (time.perf_counter() - t0) / nsnap * 1e3
+            tm = c.timing()
+            return dt, tm['sum_kernel_ms'] / max(tm['n_kernel'], 1)
+        wall0, kern0 = loop(False)
+        wall1, kern1 = loop(True)
+        st = c.comm_stats()
+        res.update({'compute_ms_without_gathers': wall0, 'compute_ms_with_gathers': wall1, 'kernel_ms_without_gathers': kern0, 'kernel_ms_with_gathers': kern1,
+                    'compute_slowdown': wall1 / wall0, 'per_snapshot_ms': st['sum_gather_ms'] / max(st['n_gathers'], 1), 'max_gather_ms': st['max_gather_ms'],
+                    'exposed_ms': st['last_gather_after_compute_ms'], 'bytes_per_gather': st['bytes_per_peer'], 'gathers_measured': st['n_gathers'],
+                    'comm_stream_priority': st['stream_priority'], 'lowest_priority': st['stream_priority_lowest']})
+        cs = c.gathered_checksum(nsnap, complex64=c64)
+        g = c.get_gathered(1, 1)[0][0]
+        res['gather_ok'] = bool(NP.isfinite(cs) and NP.array_equal(g, c.get_vis(slot=0, complex64=c64)))
     return res
 
 
@@ -776,9 +974,22 @@ def main():
             except Exception as exc:
                 out['shard_estimate'] = {'error': repr(exc)}
             try:
+                out['gather_rehearsal'] = gather_rehearsal(cfg, zen, prec, device)
+            except Exception as exc:
+                out['gather_rehearsal'] = {'error': repr(exc)}
+            try:
+                out['e2e_shard_estimate'] = e2e_shard_estimate(device)
+            except Exception as exc:
+                out['e2e_shard_estimate'] = {'error': repr(exc)}
+            try:
                 out['e2e'] = e2e_observe(cfg, 8, device, memsave=(prec == _abi.PRISIM_FP32))
+                out['e2e']['over_step'] = out['e2e']['ms_per_snapshot'] / (elapsed / K * 1e3)
             except Exception as exc:
                 out['e2e'] = {'value': None, 'error': repr(exc)}
+            try:
+                out['e2e_batch'] = e2e_observe(cfg, 8, device, memsave=(prec == _abi.PRISIM_FP32), batch=True)
+            except Exception as exc:
+                out['e2e_batch'] = {'value': None, 'error': repr(exc)}
             try:
                 out['e2e_host'] = e2e_observe(cfg, 8, device, memsave=(prec == _abi.PRISIM_FP32), to_host=True)
                 if out['e2e'].get('ms_per_snapshot'):

@@ -318,6 +318,8 @@ int prisim_hip_noise_indexed(prisim_ctx* ctx, int64_t nt, const double* rms, uin
 
 /* 128-byte RCCL unique id; rank 0 creates it, the launcher distributes it out of band. */
 int prisim_hip_comm_unique_id(char id[128]);
+/* "librccl <major>.<minor>.<patch> (<path it was loaded from>)" of the RCCL this library dlopen()ed -- for run records. */
+int prisim_hip_comm_version(char out[128]);
 int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int rank);
 /* All-gather the local cube (equal-sized baseline shards, [nt][nbl_shard][nchan]) into a device cube
  * [nt][nranks][nbl_shard][nchan] held by the context (snapshot-major: every snapshot's full baseline set is

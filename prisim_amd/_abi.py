@@ -34,6 +34,7 @@ EXPORTS = (
     'prisim_hip_allgather_grad', 'prisim_hip_comm_selftest', 'prisim_hip_get_comm_stats', 'prisim_hip_set_gather_root',
     'prisim_hip_host_alloc', 'prisim_hip_host_free', 'prisim_hip_get_vis_async', 'prisim_hip_wait_downloads',
     'prisim_hip_set_catalog', 'prisim_hip_set_sky_from_catalog', 'prisim_hip_catalog_roi', 'prisim_hip_observe_catalog',
+    'prisim_hip_comm_version',
 )
 
 
@@ -200,6 +201,7 @@ def load_library():
     lib.prisim_hip_noise_indexed.argtypes = [vp, i64, vp, C.c_uint64, vp, vp]
     lib.prisim_hip_comm_unique_id.argtypes = [C.c_char_p]
     lib.prisim_hip_comm_init.argtypes = [vp, C.c_char_p, i32, i32]
+    lib.prisim_hip_comm_version.argtypes = [C.c_char_p]
     lib.prisim_hip_allgather.argtypes = [vp, i64, i32]
     lib.prisim_hip_allgather_slot_async.argtypes = [vp, i64, i32]
     lib.prisim_hip_get_gathered.argtypes = [vp, i64, vp]
@@ -663,6 +665,16 @@ class Context(object):
         if rc != PRISIM_OK:
             _raise(rc, 'prisim_hip_comm_unique_id failed: ' + lib.prisim_hip_last_error(None).decode())
         return buf.raw
+
+    @staticmethod
+    def comm_version():
+        """'librccl <version> (<path>)' of the RCCL the library loads."""
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.prisim_hip_comm_version(buf)
+        if rc != PRISIM_OK:
+            _raise(rc, 'prisim_hip_comm_version failed: ' + lib.prisim_hip_last_error(None).decode())
+        return buf.value.decode()
 
     def comm_init(self, uid, nranks, rank):
         if len(uid) != 128:

@@ -16,11 +16,13 @@ bool load_rccl(std::string& err) {
   // The ROCm RCCL this library was compiled against (<rccl/rccl.h> of /opt/rocm) first, by absolute path: a bare soname would
   // resolve to whatever librccl the process already carries (a python process that imported torch carries torch's bundled one).
   void* h = nullptr;
-  if (const char* env = getenv("PRISIM_RCCL_LIB")) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  std::string path;
+  if (const char* env = getenv("PRISIM_RCCL_LIB")) { h = dlopen(env, RTLD_NOW | RTLD_LOCAL); if (h) path = env; }
+  for (const char* cand : {"/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"}) {
+    if (h) break;
+    h = dlopen(cand, RTLD_NOW | RTLD_LOCAL);
+    if (h) path = cand;
+  }
   if (!h) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
   bool ok = load_sym(h, "ncclGetUniqueId", g_rccl.GetUniqueId) && load_sym(h, "ncclCommInitRank", g_rccl.CommInitRank) &&
             load_sym(h, "ncclAllGather", g_rccl.AllGather) && load_sym(h, "ncclCommDestroy", g_rccl.CommDestroy) &&
@@ -29,6 +31,8 @@ bool load_rccl(std::string& err) {
   if (!(load_sym(h, "ncclSend", g_rccl.Send) && load_sym(h, "ncclRecv", g_rccl.Recv) && load_sym(h, "ncclGroupStart", g_rccl.GroupStart) &&
         load_sym(h, "ncclGroupEnd", g_rccl.GroupEnd)))
     g_rccl.Send = nullptr;                              // gather-to-root then reports PRISIM_ELIB
+  (void)load_sym(h, "ncclGetVersion", g_rccl.GetVersion);
+  g_rccl.path = path;
   g_rccl.handle = h;
   return true;
 }
@@ -1698,6 +1702,19 @@ int prisim_hip_comm_unique_id(char id[128]) {
   ncclResult_t r = g_rccl.GetUniqueId(&uid);
   if (r != ncclSuccess) return fail(nullptr, PRISIM_ELIB, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
   memcpy(id, &uid, 128);
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_comm_version(char out[128]) {
+  return guarded(nullptr, [&]() -> int {
+  if (!out) return PRISIM_EINVAL;
+  std::string lerr;
+  if (!load_rccl(lerr)) return fail(nullptr, PRISIM_ELIB, lerr);
+  int v = 0;
+  if (g_rccl.GetVersion) (void)g_rccl.GetVersion(&v);
+  // NCCL_VERSION_CODE: major * 10000 + minor * 100 + patch (2.9 and later)
+  snprintf(out, 128, "librccl %d.%d.%d (%s)", v / 10000, (v / 100) % 100, v % 100, g_rccl.path.c_str());
   return PRISIM_OK;
   });
 }

@@ -38,6 +38,8 @@ struct RcclApi {
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;         // optional
+  std::string path;                                       // what dlopen() took
 };
 extern RcclApi g_rccl;
 
