@@ -30,13 +30,20 @@ def _spot(bl, n=4):
     return NP.unique(NP.linspace(0, bl.shape[0] - 1, n).astype(int))
 
 
+def _kappa(fwhm_deg):
+    return float(NP.log(2.0) * (2.0 * NP.sin(0.5 * NP.radians(NP.max(fwhm_deg)))) ** 2)
+
+
 def test_config4_drift_external_beam():
     """MWA-128T drift scan with the external HEALPix beam: 3 accumulations of config 4 at full array size, fp32 (memsave),
     every snapshot spot-checked on 4 baselines against the C oracle fed with the restated beam interpolation."""
     from oracle import healpix_oracle as H
+    from conftest import body_class_sample
     cfg = W.config4(n_acc=3)
     bl, ch, sky, lat = cfg['baselines'], cfg['channels'], cfg['sky'], cfg['latitude']
-    sel = _spot(bl)
+    # every class of kernel body: lifting / non-lifting groups, the first groups whose leading sources are culled, the ragged last group
+    sel, _ = body_class_sample(bl, ch, sky['dircos'], NP.array([0.0, 0.0, 1.0]), f32=True, kappa=_kappa(sky['fwhm_deg']))
+    assert sel.size >= 12
     bl_run = NP.vstack((bl, -bl[sel]))                                   # the spot baselines once more, flipped
     lst0 = 40.0
     skymod = _radec_skymodel(sky, lat, lst0)
@@ -87,7 +94,9 @@ def test_config3_with_diffuse_half_one_snapshot():
     ia = RI.InterferometerArray(['b%d' % i for i in range(bl.shape[0])], bl, ch, telescope={'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'},
                                 latitude=lat, skycoords='altaz', pointing_coords='hadec')
     ia.observe((2457000.5, 0.0), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat], skymod, 10.7, memsave=True)
-    sel = _spot(bl, 5)
+    from conftest import body_class_sample
+    sel, lift = body_class_sample(bl, ch, sky['dircos'], NP.array([0.0, 0.0, 1.0]), f32=True)
+    assert sel.size >= 16 and lift.any() and (~lift).any()               # lifting and re-anchored groups, first / last / ragged
     pb = BO.airy_disk_pattern(14.0, sky['altaz'], ch, pointing_altaz=[90.0, 270.0]) * skymod.generate_spectrum(frequency=ch)
     ref = CO.skyvis(bl[sel], ch, sky['dircos'], pb, NP.array([0.0, 0.0, 1.0]), fwhm_deg=sky['fwhm_deg'])
     vis = ia._ctx.get_vis(slot=0)[sel]                       # complex128 device cube: five rows, not the whole 1 GB snapshot
@@ -109,8 +118,10 @@ def test_config5_two_lsts_and_delay_transform():
     for j in range(2):
         ia.observe((2457000.5 + j * cfg['t_acc'] / 86400.0, lst0 + j * cfg['t_acc'] * SIDEREAL_DEG_PER_SEC), {'Tnet': 100.0}, NP.ones(ch.size),
                    [0.0, lat], skymod, cfg['t_acc'], memsave=True)
-    sel = _spot(bl, 3)
+    from conftest import body_class_sample
     zen = NP.array([0.0, 0.0, 1.0])
+    sel, lift = body_class_sample(bl, ch, sky['dircos'], zen, f32=True)
+    assert sel.size >= 16 and lift.any() and (~lift).any()
     w = NP.blackman(ch.size) + 0.05
     ia.delay_transform(pad=1.0, freq_wts=w, verbose=False)
     assert all(isinstance(s, RI._DeviceSlot) for s in ia._cube)          # the 2 GB cube stayed on the device through both stages

@@ -40,6 +40,34 @@ def test_golden_fp64_reference_path(ctx, golden_skyvis, prec, kernel):
     assert max(relerr(gr[k], g['grad_f64_taper'][k], g['pbfluxes']) for k in range(3)) <= TOL[prec]
 
 
+@pytest.mark.parametrize('flush', [None, '16'])
+@pytest.mark.parametrize('nsplit', [1, 3])
+@pytest.mark.parametrize('ct', [8, 16, 32, 64])
+def test_golden_vectors_through_every_tile_split_and_flush(ctx, golden_skyvis, ct, nsplit, flush, monkeypatch):
+    """the vectors the reference's own statements produced (tests/golden, 24- and 32-channel grids: ragged in every tile
+    wider than 8) straight through the WIDE-tile kernels instead of only the planner's narrow choice for a 9 x 24 x 37 problem --
+    k_skyvis_rec_f32pk<32|64> (packed fp32, with and without the taper), k_skyvis_rec<double, 16|32>, the grouped fp64 taper kernel
+    k_skyvis_taper_f64<16|32> (as wave items when the sources are split), the fused gradient kernels (MFMA fp64, packed fp32) -- with the
+    sources split into partial cubes and with the fp32 accumulators flushed every 16 sources (read-modify-write flushes)."""
+    g = golden_skyvis
+    if flush is not None:
+        monkeypatch.setenv('PRISIM_HIP_FLUSH_SRC', flush)
+    ctx.set_array(g['baselines'], g['channels'])
+    ctx.set_tuning(ct, 0, nsplit)
+    try:
+        for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):
+            for fw, vkey, gkey in ((None, 'skyvis_f64', 'grad_f64'), (_fwhm(g), 'skyvis_f64_taper', 'grad_f64_taper')):
+                v = ctx.skyvis(g['dircos'], g['pbfluxes'], g['pc_dircos'], fwhm_deg=fw, precision=prec)
+                tm = ctx.timing()
+                assert tm['last_chan_tile'] == (min(ct, 32) if prec == _abi.PRISIM_FP64 else ct), tm       # the tile asked for did run
+                assert relerr(v, g[vkey], g['pbfluxes']) <= TOL[prec], (prec, fw is not None, tm)
+                v2, gr = ctx.skyvis(g['dircos'], g['pbfluxes'], g['pc_dircos'], fwhm_deg=fw, precision=prec, want_grad=True)
+                assert relerr(v2, g[vkey], g['pbfluxes']) <= TOL[prec]
+                assert max(relerr(gr[k], g[gkey][k], g['pbfluxes']) for k in range(3)) <= TOL[prec]
+    finally:
+        ctx.set_tuning(0, 0, 0)
+
+
 def test_golden_memsave_reference_path(ctx, golden_skyvis):
     """The reference's own fp32 path (:6323) forms the phase in fp32 and is ~1e-5 S_f away from its fp64 path;
     our fp32 mode must be at least as close to the reference fp32 result as that intrinsic error."""
@@ -721,7 +749,9 @@ def test_full_size_config5_snapshot_properties(ctx):
     assert tm['last_chan_tile'] == 64 and tm['last_taper_group'] == 1
     assert NP.all(NP.isfinite(full.view(NP.float64)))
     pb = ctx.get_pbflux()
-    sel_bl = NP.array([0, 20000, 45000, bl.shape[0] - 1])
+    from conftest import body_class_sample
+    sel_bl, lift = body_class_sample(bl, ch, sky['dircos'], zen, f32=True)      # every class of kernel body, not an even sprinkle
+    assert sel_bl.size >= 16 and lift.any() and (~lift).any()
     ref = CO.skyvis(bl[sel_bl], ch, sky['dircos'], pb, zen, fwhm_deg=sky['fwhm_deg'])
     assert relerr(full[sel_bl], ref, pb) <= 5e-6
     odd = NP.arange(n) % 3 == 1
