@@ -50,7 +50,7 @@ void k_beam_flux(BeamParams p) {
   const double sigma_dircos = 1.0 / (2.0 * kPi * sigma_aprtr);
   const double kh = kk * 0.5 * p.diameter;                           // dipole: k h, h = L/2 (:1203-1204)
   const double gp_den = p.gp_height > 0.0 ? 2.0 * sin(kk * p.gp_height) : 1.0;      // :965-966
-  const double fr = f / p.ref_freq;
+  const double lg_fr = log2(f / p.ref_freq);                         // S = S0 (f / f_ref)^alpha = S0 2^(alpha log2(f / f_ref)): the logarithm once per thread
   int64_t s = i0 / p.nchan;
   for (int64_t i = i0; i < total; i += stride, s += ds) {
     const double4 d = reinterpret_cast<const double4*>(p.dirs)[s];
@@ -148,7 +148,7 @@ void k_beam_flux(BeamParams p) {
     }
     // (catalogue path: the flux vectors / spectra stay in catalogue order and are read through the compacted index list)
     const int64_t cs = p.src_index ? (int64_t)p.src_index[s] : s;
-    const double flux = p.flux_spec ? p.flux_spec[cs * p.nchan + k] : p.flux_ref[cs] * pow(fr, p.spindex[cs]);
+    const double flux = p.flux_spec ? p.flux_spec[cs * p.nchan + k] : p.flux_ref[cs] * exp2(p.spindex[cs] * lg_fr);
     p.pb_out[i] = pb * flux;
   }
 }

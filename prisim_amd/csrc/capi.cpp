@@ -926,6 +926,11 @@ static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams
 // one sky-sum pass into `dst` ([nbl][nchan] complex128); scale_comp >= 0 multiplies pbflux rows by dircos[:,comp]
 // Wave items (k_skyvis_taper_f64_wave): the grouped fp64 taper kernel on an array of one baseline group whose sources are split.
 // PRISIM_HIP_WAVE_ITEMS=0: block items (the A/B baseline).
+static bool grad_taper_grouped() {
+  const char* env = getenv("PRISIM_HIP_GRAD_TAPER_GROUP");
+  return !(env && atoi(env) == 0);
+}
+
 static bool wave_items(const prisim_ctx* ctx, const Plan& pl) {
   bool on = !pl.f32 && ctx->taper && (pl.ct == 16 || pl.ct == 32) && pl.kernel == PRISIM_KERNEL_RECURRENCE && pl.nsplit > 1 &&
             ctx->nbl <= kBlockThreads;
@@ -1089,8 +1094,9 @@ static int run_grad_pass(prisim_ctx* ctx, const Plan& pl, double* dst, double* g
     HIPCHK(ctx, launch_pack_grad((const double*)ctx->sk->pb.p, (float*)ctx->sk->packed.p, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ntiles,
                                  ctx->dirs_p, pstream(ctx)));
   } else {
+    // (the grouped fp64 taper kernel takes its rows in natural channel order, everything else (up, down) pairs)
     HIPCHK(ctx, launch_pack((const double*)ctx->sk->pb.p, ctx->sk->packed.p, pl.f32, ctx->nsrc, pl.nsrc_pad, ctx->nchan, pl.ct, pl.ntiles,
-                            ctx->dirs_p, -1, 1, pstream(ctx)));
+                            ctx->dirs_p, -1, (!pl.f32 && ctx->taper && pl.ct == 32) ? 0 : 1, pstream(ctx)));
   }
   { int rcj = join_prep(ctx); if (rcj) return rcj; }
   HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ctx->ring_head], ctx->stream));
@@ -1143,7 +1149,9 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     const bool f32 = pl.f32;
     pl = make_plan(ctx, f32 ? PRISIM_FP32 : PRISIM_FP64, PRISIM_KERNEL_RECURRENCE);
     // fp32: 4 x 2 x 16 packed accumulators = 128 VGPRs; fp64: the taper's per-lane recurrence state does not fit beside 128 at 32
-    pl.ct = f32 ? 16 : (ctx->taper ? 16 : 32);
+    // fp64 with the taper: the grouped single-chain kernel on 32-channel tiles (k_skyvis_grad_taper_f64); PRISIM_HIP_GRAD_TAPER_GROUP=0 =
+    // round 3's exact form on 16-channel tiles (the A/B baseline)
+    pl.ct = f32 ? 16 : ((ctx->taper && !grad_taper_grouped()) ? 16 : 32);
     pl.pk = f32;
     pl.ntiles = (int)((ctx->nchan + pl.ct - 1) / pl.ct);
     pl.nsplit = 1;

@@ -1582,6 +1582,149 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
   } while (seg0 < n_loc);
 }
 
+// ------------------------------------------------------------------------------------------
+// V + baseline gradient in fp64 WITH the source-shape taper, in the grouped single-chain form of k_skyvis_taper_f64 (round 5).
+// Round 3's form (skyvis_grad_f64_body<16, true>: exact second-order amplitude recurrence beside the lifting rotation, 16-channel tiles
+// because its per-lane state did not fit beside 128 accumulator VGPRs, a 111-instruction seed with a library exp) ran the reference's
+// default-precision gradient on a diffuse sky at 0.27 of the 16-flop contract.  Here: 32-channel tiles, ONE chain from the tile's first
+// channel, zeta = w z advanced by the complex factor rho = r q_t held over a group of 8 steps (4 instructions), the parabola the held
+// ratio leaves put back on the B operand -- it depends on (source, baseline) through tau, and the A operand c_i(s) p(s, f) serves all
+// four baselines of its MFMA block -- and the four sources' rows and directions staged through LDS by two DMA loads a group ahead,
+// read out eight channels at a time (the row operands never occupy more than 16 VGPRs).
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_skyvis_grad_taper_f64(const SkyvisParams p) {
+  constexpr int CT = 32;
+  __shared__ double2 tab_lds[kTabN];
+  __shared__ double etab_lds[kExpTabN];
+  __shared__ __attribute__((aligned(16))) unsigned char stage_lds[(kBlockThreads / 64) * kGradStageWaveBytes];
+  fill_phasor_table(tab_lds);
+  fill_exp_table(etab_lds);
+  __syncthreads();
+  int slab, bg;
+  if (!block_item(p, slab, bg)) return;          // p.nbgroups counts groups of 64 baselines for this kernel
+  const int tile = slab % p.ntiles;
+  const double2* const tab = tab_lds;
+  const double* const etab = etab_lds;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int k = lane >> 4;                        // source of the group of four this lane follows (B / A role), sum index (D role)
+  const int x = lane & 3;                         // A role: which coefficient this lane supplies
+  const int64_t bw0 = (int64_t)bg * 64 + (tid >> 6) * 16;
+  const int64_t b_raw = bw0 + (lane & 15);
+  const bool b_valid = b_raw < p.nbl;
+  const int64_t b = b_valid ? b_raw : (p.nbl - 1);
+  if (bw0 >= p.nbl) return;
+
+  const double bx = p.bl_x[b], by = p.bl_y[b], bz = p.bl_z[b];
+  const int k0 = tile * CT;
+  const double fc = p.f0 + (double)k0 * p.df;     // the chain starts at the tile's first channel
+  const double df = p.df;
+  const double fcN = fc * kTabN, dfN = df * kTabN;
+  const double bl2_c2 = (bx * bx + by * by + bz * bz) * (p.inv_c * p.inv_c);
+  const double bpc = (bx * p.pc_x + by * p.pc_y + bz * p.pc_z) * p.inv_c;
+
+  double a_r[CT], a_i[CT];                        // sum (lane >> 4) of baseline (lane & 15), channel k0 + j
+#pragma unroll
+  for (int j = 0; j < CT; ++j) { a_r[j] = 0.0; a_i[j] = 0.0; }
+
+  const double* const rows = reinterpret_cast<const double*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT;      // natural channel order
+  const double4* const prep = reinterpret_cast<const double4*>(p.dirs_prep);
+  const double4* const raw = reinterpret_cast<const double4*>(p.dirs);
+  const int64_t ns_pad = p.nsrc_pad;
+
+  unsigned char* const wst = stage_lds + (tid >> 6) * kGradStageWaveBytes;
+  auto stage_issue = [&](int64_t s0n, int half) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const char* const grow = reinterpret_cast<const char*>(rows + (size_t)(s0n + (ln >> 4)) * CT) + (ln & 15) * 16;
+    const int64_t sd = s0n + ((ln & 31) >> 3);
+    const char* const gdir = (ln < 32) ? reinterpret_cast<const char*>(prep + sd) + (ln & 7) * 4
+                                       : reinterpret_cast<const char*>(raw + (sd < p.nsrc ? sd : p.nsrc - 1)) + (ln & 7) * 4;
+    __builtin_amdgcn_global_load_lds((gptr_t)grow, (lptr_t)(wst + half * 1280), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)gdir, (lptr_t)(wst + half * 1280 + 1024), 4, 0, 0);
+  };
+  if (ns_pad > 0) stage_issue(0, 0);
+  for (int64_t s0 = 0; s0 < ns_pad; s0 += 4) {
+    const int half = (int)((s0 >> 2) & 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0): this group's two DMA loads have landed
+    wave_lds_sync();
+    const unsigned char* const hb = wst + half * 1280;
+    const double4 sv = *reinterpret_cast<const double4*>(hb + 1024 + k * 32);
+    const double4 rw = *reinterpret_cast<const double4*>(hb + 1024 + 128 + k * 32);
+    const double2* const lrow = reinterpret_cast<const double2*>(hb + k * 256);       // this lane's source: 32 channels
+    // the next group goes into the other half; this half is read until the end of the iteration and rewritten one iteration later
+    if (s0 + 4 < ns_pad) stage_issue(s0 + 4, half ^ 1);
+    const double cx = (x == 0) ? 1.0 : (x == 1 ? rw.x : (x == 2 ? rw.y : rw.z));
+    const double d = __builtin_fma(bx, sv.x, __builtin_fma(by, sv.y, bz * sv.z));
+    const double tau = d + bpc;
+    double gq = sv.w * __builtin_fma(-tau, tau, bl2_c2);
+    gq = __builtin_fmax(gq, 0.0);
+    const ExpPhase ex = exp_tab_front(-gq * (fc * fc), etab);
+    const TabPhase pc = sincos_tab_front(d * fcN, tab);
+    const TabPhase ps = sincos_tab_front(d * dfN, tab);
+    double zc, zs, rc, rs;
+    sincos_tab_back(pc, zc, zs);
+    sincos_tab_back(ps, rc, rs);
+    // ln w_j = -g (f_0 + j df)^2: group t holds the ratio q_t = exp(-a - nu (16 t + 8)), a = 2 g df f_0, nu = g df^2 (skyvis_rec_body, GROUPED)
+    const double a = gq * (2.0 * df * fc);
+    const double u = gq * (df * df);
+    double E, y8, cm[4];
+    if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(a) < 0.1 && u < 3.0e-5)) == 0) {
+      E = exp_series9(-a);
+      const double X = __builtin_fma(u, __builtin_fma(u, __builtin_fma(u, 1.66666666666666666667e-01, 0.5), 1.0), 1.0);
+      const double X2 = X * X, X3 = X2 * X, X5 = X3 * X2;
+      cm[0] = X5 * X2;
+      cm[1] = cm[0] * X5;
+      cm[2] = cm[1] * X3;
+      cm[3] = cm[2] * X;
+      const double v = -8.0 * u;
+      y8 = __builtin_fma(v, __builtin_fma(v, __builtin_fma(v, __builtin_fma(v, 4.16666666666666666667e-02, 1.66666666666666666667e-01), 0.5), 1.0), 1.0);
+    } else {
+      E = exp(-a);
+      cm[0] = exp(7.0 * u); cm[1] = exp(12.0 * u); cm[2] = exp(15.0 * u); cm[3] = exp(16.0 * u);
+      y8 = exp(-8.0 * u);
+    }
+    const double hg = y8 * y8;
+    const double w0 = exp_tab_back(ex);
+    const double q0 = E * y8;
+    double ur = w0 * zc, ui = -(w0 * zs);            // zeta_0 = w_0 z_0, z = exp(-2 pi i phi)
+    double dr = q0 * rc, di = -(q0 * rs);            // rho_0
+#pragma unroll
+    for (int t = 0; t < CT / 8; ++t) {
+      double2 pr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pr[j] = lrow[4 * t + j];
+      constexpr int kmap[8] = {0, 0, 1, 2, 3, 2, 1, 0};
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int kk = 8 * t + m;
+        const double pv = (m & 1) ? pr[m >> 1].y : pr[m >> 1].x;
+        const double au = cx * pv;
+        double br = ur, bi = ui;
+        if (m != 0) { br *= cm[kmap[m]]; bi *= cm[kmap[m]]; }
+        a_r[kk] = __builtin_amdgcn_mfma_f64_4x4x4f64(au, br, a_r[kk], 0, 0, 0);
+        a_i[kk] = __builtin_amdgcn_mfma_f64_4x4x4f64(au, bi, a_i[kk], 0, 0, 0);
+        if (!(t == CT / 8 - 1 && m == 7)) {
+          const double t0 = ui * di, t1 = ur * di;
+          const double nr = __builtin_fma(ur, dr, -t0);
+          const double ni = __builtin_fma(ui, dr, t1);
+          ur = nr; ui = ni;
+        }
+      }
+      if (t + 1 < CT / 8) { dr *= hg; di *= hg; }
+    }
+  }
+  if (b_valid) {
+    const int i = k;
+    double2* const dst = (i == 0) ? reinterpret_cast<double2*>(p.out) : reinterpret_cast<double2*>(p.grad_out) + (size_t)(i - 1) * p.nbl * p.nchan;
+    double2* const o = dst + (size_t)b * p.nchan;
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+      if (k0 + j < p.nchan) o[k0 + j] = make_double2(a_r[j], a_i[j]);
+  }
+}
+
 template <int CT, bool TAPER>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void k_skyvis_rec_f32pk(const SkyvisParams p) {
@@ -2128,7 +2271,9 @@ hipError_t launch_skyvis_grad_f64(const SkyvisParams& p, int ct, hipStream_t str
   const int64_t items = (int64_t)p.ntiles * p.nbgroups;
   if (items <= 0 || items > 0x3fffffffLL || p.nsplit != 1) return hipErrorInvalidValue;
   const unsigned grid = 8u * (unsigned)((items + 7) / 8);
-  if (ct == 32 && !p.taper) {           // (the taper's per-lane recurrence state does not fit beside 128 accumulator VGPRs at 32 channels)
+  if (ct == 32 && p.taper) {            // grouped single-chain form, rows in natural channel order (launch_pack interleave = 0)
+    hipLaunchKernelGGL(k_skyvis_grad_taper_f64, dim3(grid), dim3(kBlockThreads), 0, stream, p);
+  } else if (ct == 32) {                // (the exact taper recurrence's per-lane state does not fit beside 128 accumulator VGPRs at 32 channels)
     hipLaunchKernelGGL((k_skyvis_grad_f64<32, false>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
   } else if (ct == 16) {
     if (p.taper) hipLaunchKernelGGL((k_skyvis_grad_f64<16, true>), dim3(grid), dim3(kBlockThreads), 0, stream, p);
