@@ -425,3 +425,49 @@ def test_equatorial_baselines_give_the_enu_visibilities():
     scale = NP.sum(NP.abs(pb), axis=0)[None, :]
     assert float(NP.max(NP.abs(out[0] - ref) / scale)) <= 1e-11
     assert float(NP.max(NP.abs(out[1] - out[0]) / scale)) <= 1e-12          # (the rotation to ENU and back rounds the baselines at 1e-16)
+
+
+def test_post_actions_of_a_batch_host_staging_and_one_rank_gather():
+    """What prisim_hip_observe_catalog queues behind every snapshot (prisim_post): the download into the page-locked host cube
+    (reserve(host_staging=True) through observe_batch -- loop chunks and the batched launch alike) and the RCCL all-gather of the slot on
+    the communication stream (a 1-rank communicator on this box)."""
+    from prisim_amd import interferometry as RI, skymodel as SM
+    lat = -30.7224
+    tel = {'id': 'hera', 'shape': 'dish', 'size': 14.0, 'ocoords': 'altaz', 'orientation': NP.array([[90.0, 270.0]]), 'groundplane': None}
+    for nbl, memsave in ((171, False), (400, True)):              # 171: one launch for all snapshots; 400: the per-snapshot loop, complex64 staging
+        bl, ch, sky = _small_array_case(nbl if nbl <= 256 else 256, 64)
+        if nbl > 256:
+            bl = NP.vstack((bl, bl[:nbl - 256] * 2.1))
+        radec = radec_catalogue(sky, lat, 20.0)
+        n = radec.shape[0]
+        skymod = SM.SkyModel(location=radec, flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
+                             src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1))
+        times = [(2457000.5 + j * 1e-3, 20.0 + 0.5 * j) for j in range(6)]
+        cubes = []
+        for staging in (True, False):
+            ia = RI.InterferometerArray(['b%d' % i for i in range(bl.shape[0])], bl, ch, telescope=tel, latitude=lat, skycoords='radec',
+                                        pointing_coords='hadec')
+            ia.reserve(6, host_staging=staging)
+            ia.observe_batch(times, {'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat], skymod, 10.0, memsave=memsave)
+            if staging:
+                snaps = ia.skyvis_freq_snapshots()
+                assert ia._host_cube is not None and snaps is ia._host_cube or snaps.base is ia._host_cube or NP.shares_memory(snaps, ia._host_cube)
+                assert all(sn.staged for sn in ia._cube)
+            cubes.append(NP.array(ia.skyvis_freq))
+            assert cubes[-1].dtype == (NP.complex64 if memsave else NP.complex128) and cubes[-1].shape == (bl.shape[0], ch.size, 6)
+        assert NP.array_equal(cubes[0], cubes[1])
+    # the slot gathers of a batch on a 1-rank communicator
+    bl, ch, sky = _small_array_case(171, 64)
+    radec = radec_catalogue(sky, lat, 20.0)
+    with _abi.Context(0) as ctx:
+        ctx.set_array(bl, ch, nt_max=5)
+        ctx.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        ctx.comm_init(_abi.Context.comm_unique_id(), 1, 0)
+        ctx.comm_selftest()
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=14.0)
+        ctx.observe_catalog(obs, 20.0 + 0.5 * NP.arange(5), ZEN, precision=_abi.PRISIM_FP64, gather='c128')
+        g = ctx.get_gathered(5, 1)                                  # (nt, nranks, nbl, nchan)
+        for t in range(5):
+            assert NP.array_equal(g[t, 0], ctx.get_vis(slot=t))
+        assert ctx.comm_stats()['n_gathers'] == 5
+        assert 'librccl' in _abi.Context.comm_version()
