@@ -297,6 +297,9 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   ctx->sky_set = false;
   ctx->ext_nside = 0;   // the external-beam table is per channel grid
   if (ctx->cat.gstream) HIPCHK(ctx, hipStreamSynchronize(ctx->cat.gstream));
+  if (ctx->prep_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->prep_stream));
+  ctx->prep_async = false;
+  ctx->sk = &ctx->skb[0];
   ctx->cat.loaded = false;   // ... and so are the catalogue's spectra
   ctx->cat.cur = -1;
   std::vector<double> x(nbl), y(nbl), z(nbl);

@@ -24,7 +24,13 @@ int cat_runtime(prisim_ctx* ctx, int64_t nsnap) {
       C.gstream = nullptr;
       HIPCHK(ctx, hipStreamCreateWithFlags(&C.gstream, hipStreamNonBlocking));
     }
-    ctx->prep_stream = C.gstream;
+    // the preparation stream is a stream of its own (same priority): the geometry of snapshot t+1, whose small record the host waits for,
+    // does not queue behind the preparation of snapshot t, which a sky-sum in progress can hold up for milliseconds
+    if (hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->prep_stream = nullptr;
+      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
+    }
     for (SkyBufs& k : ctx->skb) {
       HIPCHK(ctx, hipEventCreateWithFlags(&k.ev_prep, hipEventDisableTiming));
       HIPCHK(ctx, hipEventCreateWithFlags(&k.ev_sum, hipEventDisableTiming));
@@ -474,6 +480,7 @@ void catalog_destroy(prisim_ctx* ctx) {
   if (C.culled_host) (void)hipHostFree(C.culled_host);
   if (C.batch_host) (void)hipHostFree(C.batch_host);
   if (C.gstream) (void)hipStreamDestroy(C.gstream);
+  if (ctx->prep_stream) { (void)hipStreamSynchronize(ctx->prep_stream); (void)hipStreamDestroy(ctx->prep_stream); }
   ctx->prep_stream = nullptr;
   ctx->prep_async = false;
   C = prisim_ctx::Catalog();
