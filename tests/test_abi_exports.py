@@ -122,8 +122,8 @@ def test_sky_sum_kernels_use_no_scratch(tmp_path):
         found += 1
         assert row['scratch'] == 0, name
         assert row['vgpr_spill'] == 0, name
-        if 'grad_f64' in name:
-            continue                            # the MFMA kernel streams rows through vector loads: no scalar-row source loop to inspect
+        if 'grad_f64' in name or 'grad_taper_f64' in name:
+            continue                            # the MFMA kernels stream rows through vector loads: no scalar-row source loop to inspect
         # SGPR spills (v_readlane / v_writelane through a spare VGPR) are tolerated in the prologue and around the flush, never in
         # the source loops: round 1's fp64 kernels moved 103-134 SGPRs per source through lanes because their half-row operand
         # buffers (2 x 32 SGPRs) did not fit
