@@ -471,3 +471,32 @@ def test_post_actions_of_a_batch_host_staging_and_one_rank_gather():
             assert NP.array_equal(g[t, 0], ctx.get_vis(slot=t))
         assert ctx.comm_stats()['n_gathers'] == 5
         assert 'librccl' in _abi.Context.comm_version()
+
+
+def test_batched_launch_on_a_sky_of_several_source_runs():
+    """Point sources + a diffuse map (two runs of one source size each) on a small array: one batched launch for all snapshots (every source
+    carries its own kappa); against single launches (which sum the sky run by run, the point sources through the no-taper kernel) and the
+    C oracle."""
+    from oracle import c_oracle as CO, beams_oracle as BO
+    bl, ch, _ = _small_array_case(171, 96)
+    lat, lst0 = -30.7224, 50.0
+    sky = W.concat_skies(W.point_source_sky(700, 9), W.diffuse_sky(8, 10))
+    radec = radec_catalogue(sky, lat, lst0)
+    lsts = lst0 + 1.5 * NP.arange(6)
+    with _abi.Context(0) as ctx, _abi.Context(0) as one:
+        ctx.set_array(bl, ch, nt_max=6)
+        one.set_array(bl, ch, nt_max=1)
+        for c in (ctx, one):
+            c.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=14.0)
+        counts = ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP64)
+        assert ctx.timing()['last_batch_snapshots'] == 6
+        for t in (0, 3, 5):
+            assert one.set_sky_from_catalog(obs, lsts[t], ZEN, ZEN) == counts[t]
+            one.compute(precision=_abi.PRISIM_FP64)
+            pb = one.get_pbflux()
+            scale = NP.sum(NP.abs(pb), axis=0)[None, :]
+            assert float(NP.max(NP.abs(ctx.get_vis(slot=t) - one.get_vis()) / scale)) <= 1e-13
+            m2, dc, altaz = host_roi(radec, lat, lsts[t])
+            ref = CO.skyvis(bl, ch, dc, pb, ZEN, fwhm_deg=sky['fwhm_deg'][m2])
+            assert float(NP.max(NP.abs(ctx.get_vis(slot=t) - ref) / scale)) <= 1e-11
