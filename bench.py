@@ -566,11 +566,14 @@ def e2e_observe(cfg, n_snap, device, memsave, to_host=False, batch=False):
     return res
 
 
-def product_loop_case(cfgno, nranks, n_acc, memsave, mode, catalog, device=0, reps=2):
+def product_loop_case(cfgno, nranks, n_acc, memsave, mode, catalog, device=0, reps=2, passes=1):
     """Rank 0's share of a BASELINE configuration through the PRODUCT loop: InterferometerArray.observe() / observe_batch()
     on a (RA, Dec) sky model as prisim_amd.driver.run drives it, wall per snapshot with the queue kept full (one synchronisation at the end),
     beside the kernel-only figure (the same shard's compute() with the last sky resident, queued back to back).  catalog False =
-    PRISIM_CATALOG=0: every snapshot's sky formed on the host and uploaded (rounds 1-4).  The second repetition is reported."""
+    PRISIM_CATALOG=0: every snapshot's sky formed on the host and uploaded (rounds 1-4).  The second repetition is reported.  passes > 1: the
+    same instance goes on observing (n_acc more snapshots per pass, the queue drained in between) -- `wall_ms_per_snapshot` stays the FIRST
+    pass of a fresh instance (catalogue upload, every first allocation, pinned buffers, streams), `wall_ms_per_snapshot_resident` is the last
+    pass: what a snapshot costs once the run's state is resident."""
     from prisim_amd import geometry as GEOM, interferometry as RI
     os.environ['PRISIM_CATALOG'] = '1' if catalog else '0'
     try:
@@ -590,24 +593,29 @@ def product_loop_case(cfgno, nranks, n_acc, memsave, mode, catalog, device=0, re
         for rep in range(reps):
             ia = RI.InterferometerArray(['b%d' % i for i in range(bl.shape[0])], bl, ch, telescope=tel, latitude=lat, skycoords='radec',
                                         pointing_coords='hadec', device=device)
-            ia.reserve(n_acc)
+            ia.reserve(n_acc * passes)
             if cfg['beam'] == 'external':
                 ia.set_external_beam(cfg['beam_table'], cfg['beam_freqs'])
-            lsts = lst0 + NP.arange(n_acc) * dlst
-            times = [(2455000.0 + j * cfg['t_acc'] / 86400.0, float(lsts[j])) for j in range(n_acc)]
+            lsts = lst0 + NP.arange(n_acc * passes) * dlst
+            times = [(2455000.0 + j * cfg['t_acc'] / 86400.0, float(lsts[j])) for j in range(n_acc * passes)]
             tsys, bp, pc = {'Tnet': 100.0}, NP.ones(ch.size), NP.array([0.0, lat])
-            ia._ctx.sync()
-            ia._ctx.timing(reset=True)
-            t0 = time.perf_counter()
-            if mode == 'observe':
-                for j in range(n_acc):
-                    ia.observe(times[j], tsys, bp, pc, skymod, cfg['t_acc'], memsave=memsave)
-            else:
-                ia.observe_batch(times, tsys, bp, pc, skymod, cfg['t_acc'], memsave=memsave)
-            t_host = time.perf_counter() - t0          # the host is done queueing
-            ia._ctx.sync()
-            wall = time.perf_counter() - t0
-            tm = ia._ctx.timing()
+            walls = []
+            for ps in range(passes):
+                ia._ctx.sync()
+                ia._ctx.timing(reset=True)
+                t0 = time.perf_counter()
+                if mode == 'observe':
+                    for j in range(ps * n_acc, (ps + 1) * n_acc):
+                        ia.observe(times[j], tsys, bp, pc, skymod, cfg['t_acc'], memsave=memsave)
+                else:
+                    ia.observe_batch(times[ps * n_acc:(ps + 1) * n_acc], tsys, bp, pc, skymod, cfg['t_acc'], memsave=memsave)
+                if ps == 0:
+                    t_host = time.perf_counter() - t0          # the host is done queueing
+                ia._ctx.sync()
+                walls.append(time.perf_counter() - t0)
+                if ps == 0:
+                    tm = ia._ctx.timing()
+            wall = walls[0]
             nsrc = [int(e.size) for e in ia.obs_catalog_indices]
             prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
             batched = tm.get('last_batch_snapshots', 1)
@@ -630,6 +638,9 @@ def product_loop_case(cfgno, nranks, n_acc, memsave, mode, catalog, device=0, re
                    'kernel_only_kernel_ms_per_snapshot': tmk['sum_kernel_ms'] / max(tmk['n_kernel'], 1),
                    'ratio_wall_over_kernel_only_wall': (wall / n_acc) / (wall_k / n_acc), 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
                    'culled_fraction_last': tm['last_culled_fraction'], 'snapshots_per_launch': batched}
+            if passes > 1:
+                out['wall_ms_per_snapshot_resident'] = 1e3 * walls[-1] / n_acc
+                out['resident_over_kernel_only_wall'] = walls[-1] / wall_k
             ia._ctx.close()
             del ia
         return out
@@ -644,14 +655,17 @@ def e2e_shard_estimate(device, n_acc=32, ranks=(1, 8)):
     is resident and the clock is up (the first snapshots of any run carry the catalogue upload, the first allocations and ~30 ms of
     clock ramp)."""
     res = {'what': 'rank 0 of N on one GPU, config 4, fp32; wall ms per snapshot through InterferometerArray.observe_batch (driver.run\'s loop) '
-                   'against compute() alone with the sky resident; marginal = (wall(3 n) - wall(n)) / 2n', 'n_acc': n_acc}
+                   'against compute() alone with the last sky resident; wall / over_kernel_only = the first n_acc snapshots of a fresh instance '
+                   '(catalogue upload, first allocations, streams, pinned buffers included), resident = the next n_acc of the same instance; '
+                   'marginal = (wall(3 n) - wall(n)) / 2n of two fresh instances', 'n_acc': n_acc}
     for n in ranks:
-        a = product_loop_case(4, n, n_acc, True, 'batch', True, device=device)
+        a = product_loop_case(4, n, n_acc, True, 'batch', True, device=device, passes=2)
         b = product_loop_case(4, n, 3 * n_acc, True, 'batch', True, device=device, reps=1)
         marg = (b['wall_ms_total'] - a['wall_ms_total']) / (2 * n_acc)
         res[str(n)] = {'shard_baselines': a['shard_baselines'], 'wall_ms_per_snapshot': a['wall_ms_per_snapshot'], 'marginal_ms_per_snapshot': marg,
                        'kernel_only_wall_ms_per_snapshot': a['kernel_only_wall_ms_per_snapshot'], 'kernel_ms_per_snapshot': a['kernel_ms_per_snapshot'],
                        'over_kernel_only': a['wall_ms_per_snapshot'] / a['kernel_only_wall_ms_per_snapshot'],
+                       'resident_ms_per_snapshot': a['wall_ms_per_snapshot_resident'], 'resident_over_kernel_only': a['resident_over_kernel_only_wall'],
                        'marginal_over_kernel_only': marg / a['kernel_only_wall_ms_per_snapshot'], 'host_ms_per_snapshot': a['host_ms_per_snapshot'],
                        'culled_fraction': a['culled_fraction_last'], 'nsplit': a['nsplit']}
     return res

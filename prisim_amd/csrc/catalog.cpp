@@ -4,6 +4,7 @@
 // every snapshot's sky on the device (catalog_kernels.hip) -- what InterferometerArray.observe() of the reference does on the host at
 // every call (prisim/interferometry.py:6171-6180, 6204-6219, 6249-6254, 6263).  Host work per snapshot: a handful of launches and one
 // small read-back (source count, run boundaries, max |s - s_pc|) that waits for the GEOMETRY stream only.
+#include <cmath>
 #include <chrono>
 
 #include "ctx_internal.h"
@@ -322,7 +323,16 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   if (nsplit == 0) {
     const int64_t slots = 2LL * 4 * std::max(ctx->cu_count, 1);
     const int64_t items0 = kc * nbw * ntiles;
-    nsplit = std::max<int64_t>(1, (5 * slots / 2 + items0 - 1) / items0);
+    const int64_t lo = std::max<int64_t>(1, (5 * slots / 2 + items0 - 1) / items0);
+    // ... and of those counts the one whose last round is fullest (config 2 x 64 snapshots: 3 splits = 2.25 rounds 1.66 ms, 4 = 3.0 rounds
+    // 1.52 ms, 5 = 3.75 rounds 1.58 ms; tools/config2_batch_sweep.py)
+    double best = 1e30;
+    nsplit = lo;
+    for (int64_t n = lo; n <= 2 * lo; ++n) {
+      const double r = (double)(items0 * n) / (double)slots;
+      const double waste = std::ceil(r) / r + 0.002 * (double)(n - lo);
+      if (waste < best - 1e-12) { best = waste; nsplit = n; }
+    }
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, nmax / 16));
     nsplit = std::min<int64_t>(nsplit, 64);
   }
