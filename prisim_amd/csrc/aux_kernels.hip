@@ -22,8 +22,13 @@ static constexpr double kPi = 3.14159265358979323846;
 // multiple of nchan, so a thread keeps ONE channel over its whole grid-stride loop and everything that depends on the frequency alone
 // -- the wavenumber, the on-axis normalisation 2 J1(x0) / x0 of the Airy pattern (a second Bessel function per element otherwise), the
 // Gaussian's width, the ground plane's denominator -- is formed once per thread (config 2 x 64 snapshots: 1.40 -> see DESIGN 4.4).
-__global__ __launch_bounds__(256)
-void k_beam_flux(BeamParams p) {
+// One instance per element pattern (KIND), and per pattern one without array factor, beamformer and ground plane (EXTRAS = false: delta,
+// Gaussian, Airy -- the analytic beams of the BASELINE configurations).  ONE body with every pattern behind run-time branches needed 286
+// VGPRs: one wavefront per SIMD, and nothing to hide the index -> flux loads behind (config 2 x 64 snapshots spent 0.45 ms in it with a
+// UNIFORM beam, 0.65 with the Airy pattern; now 0.06 / 0.27).  The statements are the same ones; the dead patterns are compiled out.
+template <int KIND, bool EXTRAS>
+__device__ __forceinline__ void beam_flux_body(BeamParams p) {
+  constexpr int beam_kind = KIND;
   if (p.batch != nullptr) {            // one snapshot of a batch per blockIdx.y: its rows of the geometry set and of pb, its beam pointing
     const BatchSnap sn = p.batch[blockIdx.y];
     p.dirs += sn.dir0 * 4;
@@ -44,12 +49,12 @@ void k_beam_flux(BeamParams p) {
   // Airy: small-angle floor and on-axis value (:611-618)
   const double sin_tol = sin(1e-10);
   const double a0 = kk * 0.5 * p.diameter * sin_tol;
-  const double mx_airy = p.beam_kind == PRISIM_BEAM_AIRY ? 2.0 * j1(a0) / a0 : 1.0;
+  const double mx_airy = beam_kind == PRISIM_BEAM_AIRY ? 2.0 * j1(a0) / a0 : 1.0;
   // Gaussian (:717-721)
   const double sigma_aprtr = p.diameter / (2.0 * sqrt(2.0 * log(2.0))) / lam;
   const double sigma_dircos = 1.0 / (2.0 * kPi * sigma_aprtr);
   const double kh = kk * 0.5 * p.diameter;                           // dipole: k h, h = L/2 (:1203-1204)
-  const double gp_den = p.gp_height > 0.0 ? 2.0 * sin(kk * p.gp_height) : 1.0;      // :965-966
+  const double gp_den = (EXTRAS && p.gp_height > 0.0) ? 2.0 * sin(kk * p.gp_height) : 1.0;      // :965-966
   const double lg_fr = log2(f / p.ref_freq);                         // S = S0 (f / f_ref)^alpha = S0 2^(alpha log2(f / f_ref)): the logarithm once per thread
   int64_t s = i0 / p.nchan;
   for (int64_t i = i0; i < total; i += stride, s += ds) {
@@ -64,15 +69,15 @@ void k_beam_flux(BeamParams p) {
     const bool blank = (cosx <= 0.0) || (d.z <= 0.0);
     // element FIELD pattern
     double ep = 1.0;
-    if (p.beam_kind == PRISIM_BEAM_GAUSSIAN) {
+    if (beam_kind == PRISIM_BEAM_GAUSSIAN) {
       const double r = sinx / sigma_dircos;
       ep = blank ? 0.0 : exp(-0.5 * r * r);                                               // :724-725
-    } else if (p.beam_kind == PRISIM_BEAM_AIRY) {
+    } else if (beam_kind == PRISIM_BEAM_AIRY) {
       const double sx = sinx < sin_tol ? sin_tol : sinx;                                  // :611-612 (x >= tol)
       const double a = kk * 0.5 * p.diameter * sx;
       const double pat = 2.0 * j1(a) / a;                                                 // :614
       ep = blank ? 0.0 : pat / mx_airy;                                                   // :616, :623
-    } else if (p.beam_kind == PRISIM_BEAM_DIPOLE) {
+    } else if (beam_kind == PRISIM_BEAM_DIPOLE) {
       double dot = p.dip_x * d.x + p.dip_y * d.y + p.dip_z * d.z;                         // :1205
       dot = dot > 1.0 ? 1.0 : (dot < -1.0 ? -1.0 : dot);
       const double ang = acos(dot);                                                       // :1206
@@ -93,7 +98,7 @@ void k_beam_flux(BeamParams p) {
     }
     // isotropic-radiator array factor (:1436-1475)
     double af = 1.0;
-    if (p.nax1 > 0) {
+    if (EXTRAS && p.nax1 > 0) {
       const double rx = (p.rot_c * d.x + p.rot_s * d.y) - (p.rot_c * p.apc_x + p.rot_s * p.apc_y);      // :1443-1449
       const double ry = (-p.rot_s * d.x + p.rot_c * d.y) - (-p.rot_s * p.apc_x + p.rot_c * p.apc_y);
       const double phi = 2.0 * kPi * p.sep1 * rx / lam;                                   // :1458
@@ -104,7 +109,7 @@ void k_beam_flux(BeamParams p) {
       af = t1 * t2;
     }
     double pb = (ep * af) * (ep * af);                                                    // :317 / :349 / :416
-    if (p.bf_nelem > 0) {
+    if (EXTRAS && p.bf_nelem > 0) {
       // phased-array beamformer (:1728-1746): field of the elements with compensation delays and gains, power averaged over the
       // jitter realisations (:317, :416).  fp64 here; the reference forms the same sum in float32 / complex64.
       double acc = 0.0;
@@ -125,7 +130,7 @@ void k_beam_flux(BeamParams p) {
       const double n2 = (double)p.bf_nelem * (double)p.bf_nelem;
       pb = ep * ep * acc / (n2 * (double)p.bf_nrand);
     }
-    if (p.beam_kind == PRISIM_BEAM_POLY) {
+    if (beam_kind == PRISIM_BEAM_POLY) {
       // VLA / GMRT polynomial in x = (zenith angle [deg] * 60 * f [GHz])^2 (:503, :508-509 / :796, :801); no blanking, no pointing
       const double th = atan2(sqrt(d.x * d.x + d.y * d.y), d.z) * (180.0 / kPi);      // zenith angle; well conditioned near the axis
       const double u = th * 60.0 * (f * 1e-9);
@@ -134,7 +139,7 @@ void k_beam_flux(BeamParams p) {
       if (pb != pb) atomicOr(p.flag, 2);
       else if (pb >= 1.01) atomicOr(p.flag, 1);
     }
-    if (p.gp_height > 0.0) {                                                              // ground plane (:950-966)
+    if (EXTRAS && p.gp_height > 0.0) {                                                    // ground plane (:950-966)
       const double nz = d.z < -1.0 ? -1.0 : (d.z > 1.0 ? 1.0 : d.z);                      // sin(alt) = n
       double gp = 2.0 * sin(kk * p.gp_height * nz);                                       // :953
       if (p.gp_modify & 1) {
@@ -153,6 +158,15 @@ void k_beam_flux(BeamParams p) {
   }
 }
 
+
+template <int KIND>
+__global__ __launch_bounds__(256)
+void k_beam_flux(BeamParams p) { beam_flux_body<KIND, true>(p); }
+
+template <int KIND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+void k_beam_flux_plain(BeamParams p) { beam_flux_body<KIND, false>(p); }
+
 // grid of a beam launch: as many blocks as the work wants, rounded to a whole number of channel periods (blocks x 256 threads a
 // multiple of nchan) so that every thread keeps its channel
 static unsigned beam_grid(int64_t total, int64_t nchan, int64_t cap, int64_t rows) {
@@ -168,10 +182,26 @@ static unsigned beam_grid(int64_t total, int64_t nchan, int64_t cap, int64_t row
   return (unsigned)g;
 }
 
+static void launch_beam_kernel(const BeamParams& p, dim3 grid, hipStream_t stream) {
+  const bool plain = p.nax1 <= 0 && p.bf_nelem <= 0 && !(p.gp_height > 0.0);
+  if (plain && p.beam_kind == PRISIM_BEAM_AIRY) hipLaunchKernelGGL((k_beam_flux_plain<PRISIM_BEAM_AIRY>), grid, dim3(256), 0, stream, p);
+  else if (plain && p.beam_kind == PRISIM_BEAM_GAUSSIAN) hipLaunchKernelGGL((k_beam_flux_plain<PRISIM_BEAM_GAUSSIAN>), grid, dim3(256), 0, stream, p);
+  else if (plain && p.beam_kind == PRISIM_BEAM_DELTA) hipLaunchKernelGGL((k_beam_flux_plain<PRISIM_BEAM_DELTA>), grid, dim3(256), 0, stream, p);
+  else {
+    switch (p.beam_kind) {
+      case PRISIM_BEAM_DELTA: hipLaunchKernelGGL((k_beam_flux<PRISIM_BEAM_DELTA>), grid, dim3(256), 0, stream, p); break;
+      case PRISIM_BEAM_GAUSSIAN: hipLaunchKernelGGL((k_beam_flux<PRISIM_BEAM_GAUSSIAN>), grid, dim3(256), 0, stream, p); break;
+      case PRISIM_BEAM_AIRY: hipLaunchKernelGGL((k_beam_flux<PRISIM_BEAM_AIRY>), grid, dim3(256), 0, stream, p); break;
+      case PRISIM_BEAM_DIPOLE: hipLaunchKernelGGL((k_beam_flux<PRISIM_BEAM_DIPOLE>), grid, dim3(256), 0, stream, p); break;
+      default: hipLaunchKernelGGL((k_beam_flux<PRISIM_BEAM_POLY>), grid, dim3(256), 0, stream, p); break;
+    }
+  }
+}
+
 hipError_t launch_beam_flux(const BeamParams& p, hipStream_t stream) {
   const int64_t total = p.nsrc * p.nchan;
   if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_beam_flux, dim3(beam_grid(total, p.nchan, 16384, 1)), dim3(256), 0, stream, p);
+  launch_beam_kernel(p, dim3(beam_grid(total, p.nchan, 16384, 1)), stream);
   return hipGetLastError();
 }
 
@@ -179,7 +209,7 @@ hipError_t launch_beam_flux(const BeamParams& p, hipStream_t stream) {
 hipError_t launch_beam_flux_batch(const BeamParams& p, int nsnap, hipStream_t stream) {
   const int64_t total = p.nsrc * p.nchan;
   if (total == 0 || nsnap <= 0 || !p.batch) return hipSuccess;
-  hipLaunchKernelGGL(k_beam_flux, dim3(beam_grid(total, p.nchan, 4096, nsnap), (unsigned)nsnap), dim3(256), 0, stream, p);
+  launch_beam_kernel(p, dim3(beam_grid(total, p.nchan, 4096, nsnap), (unsigned)nsnap), stream);
   return hipGetLastError();
 }
 
