@@ -619,17 +619,22 @@ def product_loop_case(cfgno, nranks, n_acc, memsave, mode, catalog, device=0, re
             nsrc = [int(e.size) for e in ia.obs_catalog_indices]
             prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
             batched = tm.get('last_batch_snapshots', 1)
-            if catalog:      # (a batched launch leaves no single current sky: make the last snapshot's sky current again)
-                pcd = GEOM.altaz2dircos(GEOM.hadec2altaz(pc, lat, units='degrees'), 'degrees').ravel()
-                ia._ctx.set_sky_from_catalog(ia._catalog_obs_cache[1], float(lsts[-1]), pcd)
-            ia._ctx.sync()
-            ia._ctx.timing(reset=True)
-            t1 = time.perf_counter()
-            for j in range(n_acc):
-                ia._ctx.compute(precision=prec, slot=j)
-            ia._ctx.sync()
-            wall_k = time.perf_counter() - t1
-            tmk = ia._ctx.timing()
+            pcd = GEOM.altaz2dircos(GEOM.hadec2altaz(pc, lat, units='degrees'), 'degrees').ravel()
+
+            def kernel_only(ps):
+                """compute() alone, n_acc times back to back, on the sky of the MIDDLE snapshot of pass ps (the sky drifts: fewer sources and
+                more culling later in config 4's scan) -- after every pass, so both figures are taken at the same clock state"""
+                if catalog:      # (a batched launch leaves no single current sky either)
+                    ia._ctx.set_sky_from_catalog(ia._catalog_obs_cache[1], float(lsts[ps * n_acc + n_acc // 2]), pcd)
+                ia._ctx.sync()
+                ia._ctx.timing(reset=True)
+                t1 = time.perf_counter()
+                for j in range(n_acc):
+                    ia._ctx.compute(precision=prec, slot=j)
+                ia._ctx.sync()
+                return time.perf_counter() - t1, ia._ctx.timing()
+
+            wall_k, tmk = kernel_only(0)
             out = {'config': cfgno, 'nranks': nranks, 'shard_baselines': int(bl.shape[0]), 'nchan': int(ch.size), 'n_acc': n_acc,
                    'precision': 'fp32' if memsave else 'fp64', 'mode': mode, 'catalog': bool(catalog),
                    'nsrc_roi_first_last': [nsrc[0], nsrc[-1]], 'wall_ms_per_snapshot': 1e3 * wall / n_acc, 'wall_ms_total': 1e3 * wall,
@@ -639,8 +644,11 @@ def product_loop_case(cfgno, nranks, n_acc, memsave, mode, catalog, device=0, re
                    'ratio_wall_over_kernel_only_wall': (wall / n_acc) / (wall_k / n_acc), 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
                    'culled_fraction_last': tm['last_culled_fraction'], 'snapshots_per_launch': batched}
             if passes > 1:
+                wall_kr = kernel_only(passes - 1)[0]
                 out['wall_ms_per_snapshot_resident'] = 1e3 * walls[-1] / n_acc
-                out['resident_over_kernel_only_wall'] = walls[-1] / wall_k
+                out['kernel_only_wall_ms_per_snapshot_resident_sky'] = 1e3 * wall_kr / n_acc
+                out['resident_over_kernel_only_wall'] = walls[-1] / wall_kr
+                out['first_pass_extra_ms_total'] = 1e3 * ((wall - wall_k) - (walls[-1] - wall_kr))
             ia._ctx.close()
             del ia
         return out
@@ -655,8 +663,10 @@ def e2e_shard_estimate(device, n_acc=32, ranks=(1, 8)):
     is resident and the clock is up (the first snapshots of any run carry the catalogue upload, the first allocations and ~30 ms of
     clock ramp)."""
     res = {'what': 'rank 0 of N on one GPU, config 4, fp32; wall ms per snapshot through InterferometerArray.observe_batch (driver.run\'s loop) '
-                   'against compute() alone with the last sky resident; wall / over_kernel_only = the first n_acc snapshots of a fresh instance '
-                   '(catalogue upload, first allocations, streams, pinned buffers included), resident = the next n_acc of the same instance; '
+                   'against compute() alone on the sky of the pass\'s middle snapshot, queued back to back after all passes (same clock '
+                   'state); wall / over_kernel_only = the first n_acc snapshots of a FRESH instance (catalogue upload, two priority streams '
+                   '= 5 ms, first allocations, the first snapshot\'s preparation that nothing overlaps, clock ramp), resident = the next n_acc of '
+                   'the same instance; first_pass_extra_ms_total = what the fresh pass spends beyond the resident one, once per run; '
                    'marginal = (wall(3 n) - wall(n)) / 2n of two fresh instances', 'n_acc': n_acc}
     for n in ranks:
         a = product_loop_case(4, n, n_acc, True, 'batch', True, device=device, passes=2)
@@ -666,6 +676,8 @@ def e2e_shard_estimate(device, n_acc=32, ranks=(1, 8)):
                        'kernel_only_wall_ms_per_snapshot': a['kernel_only_wall_ms_per_snapshot'], 'kernel_ms_per_snapshot': a['kernel_ms_per_snapshot'],
                        'over_kernel_only': a['wall_ms_per_snapshot'] / a['kernel_only_wall_ms_per_snapshot'],
                        'resident_ms_per_snapshot': a['wall_ms_per_snapshot_resident'], 'resident_over_kernel_only': a['resident_over_kernel_only_wall'],
+                       'kernel_only_resident_sky_ms_per_snapshot': a['kernel_only_wall_ms_per_snapshot_resident_sky'],
+                       'first_pass_extra_ms_total': a['first_pass_extra_ms_total'],
                        'marginal_over_kernel_only': marg / a['kernel_only_wall_ms_per_snapshot'], 'host_ms_per_snapshot': a['host_ms_per_snapshot'],
                        'culled_fraction': a['culled_fraction_last'], 'nsplit': a['nsplit']}
     return res

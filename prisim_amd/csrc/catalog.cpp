@@ -13,11 +13,23 @@ namespace {
 
 using Clock = std::chrono::steady_clock;
 
+// PRISIM_HIP_TRACE_ALLOC (development hook, with the allocation trace of ensure()): host time of the steps of a catalogue-path call
+struct HostSpan {
+  const char* what;
+  Clock::time_point t0;
+  explicit HostSpan(const char* w) : what(w), t0(Clock::now()) {}
+  ~HostSpan() {
+    static const bool trace = getenv("PRISIM_HIP_TRACE_ALLOC") != nullptr;
+    if (trace) fprintf(stderr, "[prisim_hip host] %s: %.1f us\n", what, 1e6 * std::chrono::duration<double>(Clock::now() - t0).count());
+  }
+};
+
 constexpr double kCullThr[2] = {28.0, 18.0};      // index = precision (PRISIM_FP64 = 0, PRISIM_FP32 = 1); see upload_common (capi.cpp)
 
 int cat_runtime(prisim_ctx* ctx, int64_t nsnap) {
   auto& C = ctx->cat;
   if (!C.gstream) {
+    HostSpan sp0("cat_runtime: streams, events, first pinned block");
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
     if (hipStreamCreateWithPriority(&C.gstream, hipStreamNonBlocking, greatest) != hipSuccess) {
@@ -38,6 +50,7 @@ int cat_runtime(prisim_ctx* ctx, int64_t nsnap) {
     }
     HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_geom, hipEventDisableTiming));
     for (auto& s : C.set) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming));
+    HostSpan sp1("cat_runtime: first pinned block");
     if (hipHostMalloc((void**)&C.culled_host, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
       C.culled_host = nullptr;
       return fail(ctx, PRISIM_ENOMEM, "hipHostMalloc for the catalogue path failed");
@@ -45,6 +58,7 @@ int cat_runtime(prisim_ctx* ctx, int64_t nsnap) {
     C.culled_host[0] = C.culled_host[1] = 0;
   }
   if (nsnap > C.cap_snaps) {
+    HostSpan sp2("cat_runtime: per-snapshot pinned records + device tables");
     if (C.out_host) { (void)hipHostFree(C.out_host); C.out_host = nullptr; }
     if (C.snaps_host) { (void)hipHostFree(C.snaps_host); C.snaps_host = nullptr; }
     C.cap_snaps = 0;
@@ -94,7 +108,7 @@ int check_obs(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* sna
 int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int b, bool want_keys) {
   auto& C = ctx->cat;
   int rc;
-  if ((rc = cat_runtime(ctx, nsnap))) return rc;
+  { HostSpan sp("cat_runtime"); if ((rc = cat_runtime(ctx, nsnap))) return rc; }
   auto& S = C.set[b];
   const size_t rows = (size_t)nsnap * (size_t)std::max<int64_t>(C.n, 1);
   const int64_t nblocks = cat_blocks(C.n);
@@ -661,7 +675,7 @@ int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const pri
     const int64_t kc = std::min(chunk, nsnap - c0);
     const int b = C.next;
     ctx->sky_set = false;
-    if ((rc = geometry_run(ctx, obs, snaps + c0, kc, b, want_keys))) return rc;
+    { HostSpan sp("geometry_run"); if ((rc = geometry_run(ctx, obs, snaps + c0, kc, b, want_keys))) return rc; }
     if (wave_batch_eligible(ctx, obs, precision, want_grad, kc)) {
       if ((rc = run_wave_batch(ctx, obs, snaps + c0, b, kc, slot0 + c0, nsrc_roi ? nsrc_roi + c0 : nullptr))) return rc;
       for (int64_t t = 0; t < kc; ++t)
@@ -670,10 +684,10 @@ int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const pri
       continue;
     }
     for (int64_t t = 0; t < kc; ++t) {
-      if ((rc = activate_snapshot(ctx, obs, snaps[c0 + t], b, t, want_keys))) return rc;
+      { HostSpan sp("activate_snapshot"); if ((rc = activate_snapshot(ctx, obs, snaps[c0 + t], b, t, want_keys))) return rc; }
       if (nsrc_roi) nsrc_roi[c0 + t] = ctx->nsrc;
       const int64_t slot = slot0 + c0 + t;
-      if ((rc = prisim_hip_compute(ctx, precision, PRISIM_KERNEL_AUTO, want_grad, slot))) return rc;
+      { HostSpan sp("compute"); if ((rc = prisim_hip_compute(ctx, precision, PRISIM_KERNEL_AUTO, want_grad, slot))) return rc; }
       if ((rc = post_snapshot(ctx, post, slot))) return rc;
     }
     C.next = b ^ 1;

@@ -7,6 +7,7 @@
 #include <rocfft/rocfft.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -281,8 +282,14 @@ inline int guarded(prisim_ctx* ctx, F&& body) noexcept {
 inline int ensure(prisim_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes == 0) bytes = 16;
   if (b.bytes >= bytes && b.p) return PRISIM_OK;
+  static const bool trace = getenv("PRISIM_HIP_TRACE_ALLOC") != nullptr;      // development hook: every (re)allocation with its cost, on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t had = b.bytes;
   if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
   hipError_t e = hipMalloc(&b.p, bytes);
+  if (trace)
+    fprintf(stderr, "[prisim_hip alloc] %zu B (had %zu): %.1f us\n", bytes, had,
+            1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   if (e != hipSuccess) {
     b.p = nullptr;
     return fail(ctx, PRISIM_ENOMEM, std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e));
