@@ -423,6 +423,14 @@ def config2_step(nlaunch=20, nbatch=64):
             if rep > 0 and (best is None or rec['call_us_per_snapshot'] < best['call_us_per_snapshot']):
                 best = rec
         out['batch'] = best
+    # ... and through the class: InterferometerArray.observe() per snapshot / observe_batch() on the (RA, Dec) sky model, 64 snapshots queued
+    # (the second 64 of an instance: its catalogue, streams and buffers resident; `fresh` = the first 64, which carry those once)
+    cls = {}
+    for mode in ('observe', 'batch'):
+        r = product_loop_case(2, 1, nbatch, False, mode, True, device=dev, reps=1, passes=2)
+        cls[mode] = {'us_per_snapshot': 1e3 * r['wall_ms_per_snapshot_resident'], 'fresh_us_per_snapshot': 1e3 * r['wall_ms_per_snapshot'],
+                     'host_us_per_snapshot': 1e3 * r['host_ms_per_snapshot'], 'snapshots_per_launch': r['snapshots_per_launch']}
+    out['through_class'] = cls
     return out
 
 
