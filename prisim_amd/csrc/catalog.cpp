@@ -49,6 +49,7 @@ int cat_runtime(prisim_ctx* ctx, int64_t nsnap) {
       HIPCHK(ctx, hipEventCreateWithFlags(&k.ev_sum, hipEventDisableTiming));
     }
     HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_geom, hipEventDisableTiming));
+    for (auto& e : C.ev_tab) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& s : C.set) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming));
     HostSpan sp1("cat_runtime: first pinned block");
     if (hipHostMalloc((void**)&C.culled_host, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
@@ -310,9 +311,12 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   auto& C = ctx->cat;
   auto& S = C.set[b];
   int rc;
-  // buffer set and preparation stream, as activate_snapshot
-  bool async = true;
-  if (const char* env = getenv("PRISIM_HIP_PREP_ASYNC")) async = atoi(env) != 0;
+  // buffer set and preparation stream, as activate_snapshot -- but by default the chunk is prepared on the COMPUTE stream: its preparation
+  // is two large compute-bound launches (beam x flux, packing), and under the previous chunk's sky-sum they only take its CUs away
+  // (config 2 x 64 snapshots, 8 chunks queued: 1.975 ms per chunk on the preparation stream, the sky-sum slowed from 1.46 to 1.84 ms;
+  // 1.885 ms in line).  The host is ahead either way: the geometry of the next chunk runs on its own stream.
+  bool async = false;
+  if (const char* env = getenv("PRISIM_HIP_PREP_ASYNC_BATCH")) async = atoi(env) != 0;
   if (async) {
     ctx->sk = &ctx->skb[ctx->sk_next];
     ctx->sk_next ^= 1;
@@ -354,6 +358,10 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   // per-snapshot layout
   if ((rc = ensure(ctx, K.batch_tab, (size_t)kc * sizeof(BatchSnap)))) return rc;
   if (kc > C.cap_batch_host) {
+    for (int h = 0; h < 2; ++h) {
+      if (C.tab_recorded[h]) HIPCHK(ctx, hipEventSynchronize(C.ev_tab[h]));
+      C.tab_recorded[h] = false;
+    }
     if (C.batch_host) (void)hipHostFree(C.batch_host);
     C.batch_host = nullptr; C.cap_batch_host = 0;
     if (hipHostMalloc((void**)&C.batch_host, (size_t)std::max<int64_t>(kc, 64) * 2 * sizeof(BatchSnap), hipHostMallocDefault) != hipSuccess) {
@@ -362,8 +370,11 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
     }
     C.cap_batch_host = std::max<int64_t>(kc, 64);
   }
-  // (two halves of the pinned table alternate with the buffer sets: the copy of chunk c may still be in flight when chunk c+1 is laid out)
-  BatchSnap* tab = C.batch_host + (size_t)(ctx->sk == &ctx->skb[1] ? C.cap_batch_host : 0);
+  // (two halves of the pinned table alternate: the copy of chunk c may still be queued when chunk c+1 is laid out; a half is rewritten
+  // only after the copy that last read it has run)
+  C.tab_half ^= 1;
+  if (C.tab_recorded[C.tab_half]) HIPCHK(ctx, hipEventSynchronize(C.ev_tab[C.tab_half]));
+  BatchSnap* tab = C.batch_host + (size_t)(C.tab_half ? C.cap_batch_host : 0);
   if (nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)kc * (size_t)nsplit * slot_elems * sizeof(double)))) return rc;
   int64_t row = 0, pb0 = 0, max_nrow = 0;
   for (int64_t t = 0; t < kc; ++t) {
@@ -385,6 +396,8 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
       (rc = ensure(ctx, K.dirs_prep, (size_t)pitch * 4 * sizeof(double))) || (rc = ensure(ctx, ctx->sky_flag, sizeof(int32_t))))
     return rc;
   HIPCHK(ctx, hipMemcpyAsync(K.batch_tab.p, tab, (size_t)kc * sizeof(BatchSnap), hipMemcpyHostToDevice, ps));
+  HIPCHK(ctx, hipEventRecord(C.ev_tab[C.tab_half], ps));
+  C.tab_recorded[C.tab_half] = true;
   // beam x flux of all snapshots (:6249-6254), then rows + prepared directions of all snapshots
   if (ntot > 0) {
     BeamParams bp{};
@@ -502,6 +515,8 @@ void catalog_destroy(prisim_ctx* ctx) {
     s.ev_free = nullptr;
   }
   if (C.ev_geom) (void)hipEventDestroy(C.ev_geom);
+  for (auto& e : C.ev_tab) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+  C.tab_recorded[0] = C.tab_recorded[1] = false;
   if (C.out_host) (void)hipHostFree(C.out_host);
   if (C.snaps_host) (void)hipHostFree(C.snaps_host);
   if (C.culled_host) (void)hipHostFree(C.culled_host);

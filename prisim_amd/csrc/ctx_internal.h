@@ -184,6 +184,9 @@ struct prisim_ctx {
     uint64_t* culled_host = nullptr;    // pinned [2]
     BatchSnap* batch_host = nullptr;    // pinned [2][cap_batch_host]: per-snapshot layout of a batched chunk
     int64_t cap_batch_host = 0;
+    hipEvent_t ev_tab[2] = {nullptr, nullptr};      // the upload that last read half h of batch_host has run
+    bool tab_recorded[2] = {false, false};
+    int tab_half = 0;
     int64_t cap_snaps = 0;
     hipStream_t gstream = nullptr;      // geometry stream (highest priority: a few small kernels beside a sky-sum grid)
     hipEvent_t ev_geom = nullptr;

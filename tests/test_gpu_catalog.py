@@ -330,6 +330,42 @@ def test_batched_snapshots_bit_identical_to_single_launches(nbl, nchan, k):
         assert worst <= 1e-13, worst
 
 
+@pytest.mark.parametrize('prep_stream', [False, True])
+def test_batched_chunks_queued_back_to_back(prep_stream):
+    """More snapshots than one launch takes (chunks of 64): the chunks are queued without the host waiting for any of them -- the pinned
+    per-chunk tables, the geometry sets and the row buffers are all reused while earlier chunks are still queued.  Every slot must be
+    the single launch's result, with the chunk prepared in line (the default) and on the preparation stream."""
+    bl, ch, sky = _small_array_case(65, 40)
+    lat, lst0 = -30.7224, 25.0
+    radec = radec_catalogue(sky, lat, lst0)
+    k = 215                                                      # 64 + 64 + 64 + 23
+    lsts = lst0 + 0.4 * NP.arange(k)
+    os.environ['PRISIM_HIP_PREP_ASYNC_BATCH'] = '1' if prep_stream else '0'
+    try:
+        with _abi.Context(0) as ctx, _abi.Context(0) as one:
+            ctx.set_array(bl, ch, nt_max=k)
+            one.set_array(bl, ch, nt_max=1)
+            for c in (ctx, one):
+                c.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+            obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=14.0)
+            for rep in range(2):                                     # the second call finds every buffer in use by the first
+                counts = ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP64)
+            tm = ctx.timing()
+            assert tm['last_batch_snapshots'] == k - 3 * 64, tm
+            one.set_tuning(tm['last_chan_tile'], 0, tm['last_nsplit'])
+            for t in list(range(0, k, 7)) + [63, 64, 127, 128, 191, 192, k - 1]:
+                n = one.set_sky_from_catalog(obs, lsts[t], ZEN, ZEN)
+                assert n == counts[t]
+                one.compute(precision=_abi.PRISIM_FP64)
+                want, got = one.get_vis(), ctx.get_vis(slot=t)
+                scale = NP.sum(NP.abs(one.get_pbflux()), axis=0)[None, :]
+                # (the last chunk is cut into other source splits than the full ones: same sums to rounding there, bit-identical in the full chunks
+                # only if their split count equals the last chunk's)
+                assert float(NP.max(NP.abs(got - want) / scale)) <= 1e-13, t
+    finally:
+        del os.environ['PRISIM_HIP_PREP_ASYNC_BATCH']
+
+
 def test_batched_snapshots_against_the_oracle_with_empty_and_moving_pointings():
     """The batched launch against the C oracle: per-snapshot phase and beam pointing centres, a snapshot with nothing above the horizon
     (its slot must hold zeros), source sizes that vary from source to source (no runs), a flux-spectrum table read through the index list."""
