@@ -381,7 +381,7 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     # run_prisim.py:2180-2198 loops observe() over the accumulations.  Here they go to the device in batches (observe_batch): the sky
     # model is uploaded once, every batch's geometry is formed on the GPU with one small read-back, and its snapshots are then queued
     # back to back -- no nsrc-sized host array is touched per snapshot and nothing synchronises the compute stream inside the loop.
-    batch = max(1, int(proc.get('snapshot_batch') or 16))
+    batch = max(1, int(proc.get('snapshot_batch') or 64))
     for j0 in range(0, n_acc, batch):
         j1 = min(n_acc, j0 + batch)
         ia.observe_batch([(float(jd[j]), float(lst[j])) for j in range(j0, j1)], tsysinfo, NP.ones(chans.size), hadec[j0:j1], skymod, t_acc,
