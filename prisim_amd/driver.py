@@ -17,6 +17,8 @@ gains, uvfits/uvh5 writers, `pp.key: 'freq' | 'src'`, plots, resource monitor.  
 phasing.center, delay transform and the npz / HDF5 files, in the reference's order (:2278-2286); in a sharded run every rank does the
 per-baseline steps on its own shard and rank 0 puts the whole array together from the gathered cubes (assemble_full_array).  Two synthetic sky models
 are added because the reference's catalogs are not available offline: skyparm.model 'ptsrc_random' and 'healpix_synthetic'.
+Added key: processing.snapshot_batch (default 64) -- accumulations sent to the device per observe_batch() call (one geometry
+read-back per batch; arrays of at most 256 baselines put the whole batch into one sky-sum launch).
 Time: without astropy the LST ramp is lst_init + t * 15.0410686 deg/h (mean sidereal rate), jd from jd_init or obs_date.
 """
 import copy
