@@ -428,6 +428,15 @@ def test_device_dipole_array_ground_beams_match_reference_golden(ctx):
     ctx.set_sky_analytic(dc, one, zero, 150e6, _abi.PRISIM_BEAM_GAUSSIAN, 14.0, zen, zen, ext={'ground': {'height': 0.3, 'modifier': mod}})
     ref = BO.composite_power_beam(dc, f, element='gaussian', size=14.0, ground={'height': 0.3, 'modifier': mod})
     assert NP.max(NP.abs(ctx.get_pbflux() - ref)) <= 1e-12
+    # every element pattern has a kernel instance of its own with the extras (k_beam_flux<KIND>) and, for delta / Gaussian / Airy, one
+    # without (k_beam_flux_plain<KIND>): the Airy element under an array factor and a ground plane, and the three plain ones
+    arr = {'nax1': 2, 'nax2': 3, 'sep1': 0.9, 'sep2': 1.3, 'east2ax1': 20.0, 'pointing_dircos': g['array_pc']}
+    ctx.set_sky_analytic(dc, one, zero, 150e6, _abi.PRISIM_BEAM_AIRY, 6.0, zen, zen, ext={'array': arr, 'ground': {'height': 0.4}})
+    ref = BO.composite_power_beam(dc, f, element='dish', size=6.0, array=arr, ground={'height': 0.4})
+    assert NP.max(NP.abs(ctx.get_pbflux() - ref)) <= 1e-12
+    for kind, element, size in ((_abi.PRISIM_BEAM_DELTA, 'delta', 0.0), (_abi.PRISIM_BEAM_GAUSSIAN, 'gaussian', 6.0), (_abi.PRISIM_BEAM_AIRY, 'dish', 6.0)):
+        ctx.set_sky_analytic(dc, one, zero, 150e6, kind, size, zen, zen)
+        assert NP.max(NP.abs(ctx.get_pbflux() - BO.composite_power_beam(dc, f, element=element, size=size))) <= 1e-12, element
     with pytest.raises(ValueError):
         ctx.set_sky_analytic(dc, one, zero, 150e6, _abi.PRISIM_BEAM_DIPOLE, 0.74, zen, zen)       # dipole without ext
     with pytest.raises(ValueError):
