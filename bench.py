@@ -423,6 +423,24 @@ def config2_step(nlaunch=20, nbatch=64):
             if rep > 0 and (best is None or rec['call_us_per_snapshot'] < best['call_us_per_snapshot']):
                 best = rec
         out['batch'] = best
+        # the same chunk with an external HEALPix beam (what HERA-sized runs use): gather + column maximum + 10 ** (.) x flux of all 64 skies
+        # in four launches, then the same sky-sum launch
+        from prisim_amd import primary_beams as PBM
+        bfreq = NP.linspace(float(cfg['channels'][0]) - 5e6, float(cfg['channels'][-1]) + 5e6, 21)
+        c2.set_external_beam(W.synthetic_healpix_beam(32, bfreq), PBM.spectral_interp_matrix(bfreq, cfg['channels'], kind='cubic', chromatic=True, select_freq=None))
+        obs_x = c2.make_obs(lat, use_external_beam=True)
+        bx = None
+        for rep in range(4):
+            c2.sync()
+            c2.timing(reset=True)
+            t0 = time.perf_counter()
+            c2.observe_catalog(obs_x, lsts, zen, precision=_abi.PRISIM_FP64)
+            c2.sync()
+            wall = time.perf_counter() - t0
+            tm = c2.timing()
+            if rep > 0 and (bx is None or wall < bx[0]):
+                bx = (wall, int(tm['last_batch_snapshots']))
+        out['batch_external_beam'] = {'call_us_per_snapshot': 1e6 * bx[0] / nbatch, 'snapshots_per_launch': bx[1]}
     # ... and through the class: InterferometerArray.observe() per snapshot / observe_batch() on the (RA, Dec) sky model, 64 snapshots queued
     # (the second 64 of an instance: its catalogue, streams and buffers resident; `fresh` = the first 64, which carry those once)
     cls = {}

@@ -271,11 +271,18 @@ __device__ __forceinline__ RingInfo ring_info(int64_t nside, int64_t ir) {
 
 // work[s][c] = bilinear HEALPix interpolation of table[.][c] at the direction of source s
 // (Healpix_Base::get_interpol / healpy.get_interp_val).  One block per source; thread 0 forms the 4 pixels + weights.
+// batch != NULL: blockIdx.y = snapshot of a chunk (its directions in the geometry set, its rows of work; the external-beam kernels below alike)
 __global__ __launch_bounds__(256)
 void k_extbeam_gather(const double* __restrict__ table, int nside_i, const double* __restrict__ dirs, double* __restrict__ work,
-                      int64_t nsrc, int64_t nchan) {
+                      int64_t nsrc, int64_t nchan, const BatchSnap* __restrict__ batch) {
   __shared__ int64_t spix[4];
   __shared__ double swgt[4];
+  if (batch != nullptr) {
+    const BatchSnap sn = batch[blockIdx.y];
+    dirs += sn.dir0 * 4;
+    work += sn.pb0 * nchan;
+    nsrc = sn.nsrc;
+  }
   const int64_t nside = nside_i;
   for (int64_t s = blockIdx.x; s < nsrc; s += gridDim.x) {
     __syncthreads();
@@ -347,7 +354,14 @@ void k_extbeam_gather(const double* __restrict__ table, int nside_i, const doubl
 
 // partial[blk][c] = nan-ignoring max over the sources handled by block blk; fixed block count => deterministic
 __global__ __launch_bounds__(256)
-void k_colmax_partial(const double* __restrict__ work, double* __restrict__ partial, int64_t nsrc, int64_t nchan) {
+void k_colmax_partial(const double* __restrict__ work, double* __restrict__ partial, int64_t nsrc, int64_t nchan,
+                      const BatchSnap* __restrict__ batch) {
+  if (batch != nullptr) {            // (a maximum does not depend on how the rows are dealt to blocks: the same bits as the single launch)
+    const BatchSnap sn = batch[blockIdx.y];
+    work += sn.pb0 * nchan;
+    partial += (int64_t)blockIdx.y * gridDim.x * nchan;
+    nsrc = sn.nsrc;
+  }
   for (int64_t c = threadIdx.x; c < nchan; c += blockDim.x) {
     double m = -INFINITY;
     bool any = false;
@@ -365,6 +379,8 @@ __global__ __launch_bounds__(256)
 void k_colmax_final(const double* __restrict__ partial, double* __restrict__ colmax, int nblk, int64_t nchan) {
   __shared__ double sm[8][32];
   __shared__ int sa[8][32];
+  partial += (int64_t)blockIdx.y * nblk * nchan;          // batch: snapshot blockIdx.y (a single launch has gridDim.y = 1)
+  colmax += (int64_t)blockIdx.y * nchan;
   const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
   const int64_t c = (int64_t)blockIdx.x * 32 + cx;
   double m = -INFINITY;
@@ -390,7 +406,15 @@ void k_colmax_final(const double* __restrict__ partial, double* __restrict__ col
 __global__ void k_extbeam_finish(const double* __restrict__ work, const double* __restrict__ colmax, const double* __restrict__ fluxes,
                                  const double* __restrict__ flux_ref, const double* __restrict__ spindex, const double* __restrict__ freqs,
                                  double inv_ref_freq, double* __restrict__ pb_out, int64_t nsrc, int64_t nchan,
-                                 const int32_t* __restrict__ src_index) {
+                                 const int32_t* __restrict__ src_index, const BatchSnap* __restrict__ batch) {
+  if (batch != nullptr) {
+    const BatchSnap sn = batch[blockIdx.y];
+    work += sn.pb0 * nchan;
+    pb_out += sn.pb0 * nchan;
+    colmax += (int64_t)blockIdx.y * nchan;
+    if (src_index) src_index += sn.dir0;
+    nsrc = sn.nsrc;
+  }
   const int64_t total = nsrc * nchan;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = i % nchan;
@@ -426,14 +450,34 @@ hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs
                               const int32_t* src_index) {
   if (nsrc == 0) return hipSuccess;
   const unsigned gs = (unsigned)(nsrc < 16384 ? nsrc : 16384);
-  hipLaunchKernelGGL(k_extbeam_gather, dim3(gs), dim3(256), 0, stream, table, nside, dirs, work, nsrc, nchan);
+  hipLaunchKernelGGL(k_extbeam_gather, dim3(gs), dim3(256), 0, stream, table, nside, dirs, work, nsrc, nchan, (const BatchSnap*)nullptr);
   const int nblk = (int)(nsrc < 256 ? nsrc : 256);
   double* partial = colmax_scratch;
   double* colmax = colmax_scratch + (size_t)1024 * nchan;
-  hipLaunchKernelGGL(k_colmax_partial, dim3(nblk), dim3(256), 0, stream, work, partial, nsrc, nchan);
+  hipLaunchKernelGGL(k_colmax_partial, dim3(nblk), dim3(256), 0, stream, work, partial, nsrc, nchan, (const BatchSnap*)nullptr);
   hipLaunchKernelGGL(k_colmax_final, dim3((unsigned)((nchan + 31) / 32)), dim3(256), 0, stream, partial, colmax, nblk, nchan);
   hipLaunchKernelGGL(k_extbeam_finish, dim3(grid_for_(nsrc * nchan)), dim3(256), 0, stream, work, colmax, fluxes, flux_ref, spindex, freqs,
-                     1.0 / ref_freq, pb_out, nsrc, nchan, src_index);
+                     1.0 / ref_freq, pb_out, nsrc, nchan, src_index, (const BatchSnap*)nullptr);
+  return hipGetLastError();
+}
+
+// The same for the snapshots of a chunk (batch[nsnap]; dirs / src_index: the chunk's geometry set; work, pb_out: the concatenated
+// [sum nsrc][nchan] blocks; nsrc_max sizes the grids): four launches for the whole chunk.  colmax_scratch: nsnap * (kExtBatchBlocks + 1) * nchan.
+hipError_t launch_extbeam_sky_batch(const double* table, int nside, const double* dirs, const double* fluxes, const double* flux_ref,
+                                    const double* spindex, const double* freqs, double ref_freq, double* work, double* colmax_scratch,
+                                    double* pb_out, int64_t nsrc_max, int64_t nchan, const int32_t* src_index, const BatchSnap* batch, int nsnap,
+                                    hipStream_t stream) {
+  if (nsrc_max == 0 || nsnap <= 0) return hipSuccess;
+  const unsigned gs = (unsigned)std::min<int64_t>(nsrc_max, std::max<int64_t>(1, 16384 / nsnap));
+  hipLaunchKernelGGL(k_extbeam_gather, dim3(gs, (unsigned)nsnap), dim3(256), 0, stream, table, nside, dirs, work, nsrc_max, nchan, batch);
+  const int nblk = kExtBatchBlocks;
+  double* partial = colmax_scratch;
+  double* colmax = colmax_scratch + (size_t)nsnap * nblk * nchan;
+  hipLaunchKernelGGL(k_colmax_partial, dim3(nblk, (unsigned)nsnap), dim3(256), 0, stream, work, partial, nsrc_max, nchan, batch);
+  hipLaunchKernelGGL(k_colmax_final, dim3((unsigned)((nchan + 31) / 32), (unsigned)nsnap), dim3(256), 0, stream, partial, colmax, nblk, nchan);
+  const unsigned gf = (unsigned)std::min<int64_t>(grid_for_(nsrc_max * nchan), std::max<int64_t>(1, 65536 / nsnap));
+  hipLaunchKernelGGL(k_extbeam_finish, dim3(gf, (unsigned)nsnap), dim3(256), 0, stream, work, colmax, fluxes, flux_ref, spindex, freqs,
+                     1.0 / ref_freq, pb_out, nsrc_max, nchan, src_index, batch);
   return hipGetLastError();
 }
 

@@ -49,6 +49,7 @@ int cat_runtime(prisim_ctx* ctx, int64_t nsnap) {
       HIPCHK(ctx, hipEventCreateWithFlags(&k.ev_sum, hipEventDisableTiming));
     }
     HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_geom, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_join, hipEventDisableTiming));
     for (auto& e : C.ev_tab) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& s : C.set) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming));
     HostSpan sp1("cat_runtime: first pinned block");
@@ -103,6 +104,23 @@ int check_obs(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* sna
     return PRISIM_OK;
   }
   return check_beam_spec(ctx, obs->beam_kind, obs->diameter_m, snaps[0].beam_pc_dircos, obs->ext);
+}
+
+// A sky is about to be prepared on the preparation stream.  Between two such skies the events of the buffer sets order everything
+// (ev_prep / ev_sum); but when the previous sky was prepared in line on the compute stream -- an uploaded sky, a batched chunk, the A/B
+// hook -- nothing does: its sums may still be reading the set, the external-beam work area or the sort's temporaries this preparation is
+// about to write.  So the first preparation after such a sky waits for everything queued on the compute stream so far.
+int enter_prep_stream(prisim_ctx* ctx) {
+  auto& C = ctx->cat;
+  if (!ctx->prep_async) {
+    HIPCHK(ctx, hipEventRecord(C.ev_join, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->prep_stream, C.ev_join, 0));
+  }
+  ctx->sk = &ctx->skb[ctx->sk_next];
+  ctx->sk_next ^= 1;
+  ctx->prep_async = true;
+  if (ctx->sk->sum_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->prep_stream, ctx->sk->ev_sum, 0));
+  return PRISIM_OK;
 }
 
 // Geometry of nsnap snapshots into buffer set b, on the geometry stream; returns when the per-snapshot records are in C.out_host.
@@ -174,10 +192,7 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
   bool async = beamformer_doubles(obs->use_external_beam ? nullptr : obs->ext) == 0;
   if (const char* env = getenv("PRISIM_HIP_PREP_ASYNC")) async = async && atoi(env) != 0;      // A/B hook
   if (async) {
-    ctx->sk = &ctx->skb[ctx->sk_next];
-    ctx->sk_next ^= 1;
-    ctx->prep_async = true;
-    if (ctx->sk->sum_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->prep_stream, ctx->sk->ev_sum, 0));
+    if ((rc = enter_prep_stream(ctx))) return rc;
   } else {
     if (ctx->prep_async) HIPCHK(ctx, hipStreamSynchronize(ctx->prep_stream));
     ctx->prep_async = false;
@@ -284,7 +299,8 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
 // catalogue resident the snapshots of a chunk are independent work items: their beam x flux, their packing and their sky-sums each go
 // into ONE launch over (snapshot, ...) and one reduction -- the work item of the sky-sum is (snapshot, baseline wave, channel tile,
 // source split).  Eligible: fp64 with the source-shape taper (the grouped kernel), a uniform channel grid,
-// nothing the taper culling could skip, an analytic beam without a beamformer, no gradient.  Everything else takes the per-snapshot loop.
+// nothing the taper culling could skip, an analytic beam without a beamformer or the external HEALPix beam, no gradient.  Everything else
+// takes the per-snapshot loop.
 bool wave_batch_eligible(const prisim_ctx* ctx, const prisim_obs* obs, int precision, int want_grad, int64_t kc) {
   const auto& C = ctx->cat;
   if (const char* env = getenv("PRISIM_HIP_WAVE_BATCH")) { if (atoi(env) == 0) return false; }
@@ -294,7 +310,7 @@ bool wave_batch_eligible(const prisim_ctx* ctx, const prisim_obs* obs, int preci
   // carries its own kappa, and with nothing to cull the runs need no separate launches; point sources then pay the taper kernel's 9.7
   // instead of the plain kernel's 6.2 instructions per term, which a launch per run and snapshot would cost many times over)
   if (!C.have_shape || !taper_f64_grouped_enabled()) return false;
-  if (obs->use_external_beam || beamformer_doubles(obs->ext) != 0 || obs->beam_kind == PRISIM_BEAM_POLY) return false;
+  if (!obs->use_external_beam && (beamformer_doubles(obs->ext) != 0 || obs->beam_kind == PRISIM_BEAM_POLY)) return false;
   if (ctx->tune_chunk) return false;
   if (cat_sort_wanted(ctx)) return false;
   // nothing to cull for any precision (the cull table is per snapshot)
@@ -318,10 +334,7 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   bool async = false;
   if (const char* env = getenv("PRISIM_HIP_PREP_ASYNC_BATCH")) async = atoi(env) != 0;
   if (async) {
-    ctx->sk = &ctx->skb[ctx->sk_next];
-    ctx->sk_next ^= 1;
-    ctx->prep_async = true;
-    if (ctx->sk->sum_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->prep_stream, ctx->sk->ev_sum, 0));
+    if ((rc = enter_prep_stream(ctx))) return rc;
   } else {
     if (ctx->prep_async) HIPCHK(ctx, hipStreamSynchronize(ctx->prep_stream));
     ctx->prep_async = false;
@@ -399,7 +412,17 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   HIPCHK(ctx, hipEventRecord(C.ev_tab[C.tab_half], ps));
   C.tab_recorded[C.tab_half] = true;
   // beam x flux of all snapshots (:6249-6254), then rows + prepared directions of all snapshots
-  if (ntot > 0) {
+  if (ntot > 0 && obs->use_external_beam) {
+    // external HEALPix beam (run_prisim.py:2091-2103): gather, per-snapshot column maximum, 10 ** (.) x flux -- four launches for the chunk
+    if ((rc = ensure(ctx, ctx->ext_work, (size_t)ntot * ctx->nchan * sizeof(double))) ||
+        (rc = ensure(ctx, ctx->ext_colmax, std::max<size_t>((size_t)kc * (kExtBatchBlocks + 1), 1025) * ctx->nchan * sizeof(double))))
+      return rc;
+    HIPCHK(ctx, launch_extbeam_sky_batch((const double*)ctx->ext_table.p, ctx->ext_nside, (const double*)S.dirs.p,
+                                         C.have_spec ? (const double*)C.spec.p : nullptr, C.have_spec ? nullptr : (const double*)C.flux_ref.p,
+                                         C.have_spec ? nullptr : (const double*)C.spindex.p, (const double*)ctx->freqs.p, C.have_spec ? 1.0 : C.ref_freq,
+                                         (double*)ctx->ext_work.p, (double*)ctx->ext_colmax.p, (double*)K.pb.p, nmax, ctx->nchan,
+                                         (const int32_t*)S.idx.p, (const BatchSnap*)K.batch_tab.p, (int)kc, ps));
+  } else if (ntot > 0) {
     BeamParams bp{};
     bp.dirs = (const double*)S.dirs.p;
     bp.src_index = (const int32_t*)S.idx.p;
@@ -457,10 +480,8 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
     HIPCHK(ctx, launch_reduce_partials_batch((const double*)ctx->partial.p, (double*)ctx->cube.p + (size_t)slot0 * slot_elems, (int64_t)slot_elems, (int)nsplit,
                                              (int)kc, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev_c1[ri], ctx->stream));
-  if (ctx->prep_async) {
-    HIPCHK(ctx, hipEventRecord(K.ev_sum, ctx->stream));
-    K.sum_recorded = true;
-  }
+  HIPCHK(ctx, hipEventRecord(K.ev_sum, ctx->stream));      // (in line too: a later preparation-stream user of this set waits for these sums)
+  K.sum_recorded = true;
   C.cur = b;
   catalog_after_compute(ctx);
   ctx->ring_head = (ctx->ring_head + 1) % prisim_ctx::kTimingRing;
@@ -515,6 +536,7 @@ void catalog_destroy(prisim_ctx* ctx) {
     s.ev_free = nullptr;
   }
   if (C.ev_geom) (void)hipEventDestroy(C.ev_geom);
+  if (C.ev_join) (void)hipEventDestroy(C.ev_join);
   for (auto& e : C.ev_tab) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   C.tab_recorded[0] = C.tab_recorded[1] = false;
   if (C.out_host) (void)hipHostFree(C.out_host);

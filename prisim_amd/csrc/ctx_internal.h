@@ -190,6 +190,7 @@ struct prisim_ctx {
     int64_t cap_snaps = 0;
     hipStream_t gstream = nullptr;      // geometry stream (highest priority: a few small kernels beside a sky-sum grid)
     hipEvent_t ev_geom = nullptr;
+    hipEvent_t ev_join = nullptr;       // "everything queued on the compute stream so far" (first preparation-stream sky after an in-line one)
     int cur = -1;                       // set the current sky lives in; -1: the current sky was uploaded
     int next = 0;                       // set the next geometry call of the product path writes
     double geom_ms_sum = 0.0;           // host wall time spent waiting for geometry results (prisim_cat_stats)

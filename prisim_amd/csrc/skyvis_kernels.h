@@ -154,6 +154,11 @@ hipError_t launch_extbeam_sky(const double* table, int nside, const double* dirs
                               const double* flux_ref /*[nsrc]*/, const double* spindex /*[nsrc]*/, const double* freqs, double ref_freq,
                               double* work /*[nsrc][nchan]*/, double* colmax_scratch /*[1024*nchan + nchan]*/, double* pb_out,
                               int64_t nsrc, int64_t nchan, hipStream_t stream, const int32_t* src_index = nullptr);
+constexpr int kExtBatchBlocks = 64;      // row blocks of the per-snapshot column maximum in a batched external-beam launch
+hipError_t launch_extbeam_sky_batch(const double* table, int nside, const double* dirs, const double* fluxes, const double* flux_ref,
+                                    const double* spindex, const double* freqs, double ref_freq, double* work, double* colmax_scratch,
+                                    double* pb_out, int64_t nsrc_max, int64_t nchan, const int32_t* src_index, const BatchSnap* batch, int nsnap,
+                                    hipStream_t stream);
 
 // device-resident catalogue: per-snapshot geometry (catalog_kernels.hip)
 static constexpr int PRISIM_CAT_RADEC = 0, PRISIM_CAT_HADEC = 1, PRISIM_CAT_ALTAZ = 2;     // = PRISIM_COORDS_* of the public header

@@ -11,14 +11,17 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as NP
 
-from prisim_amd import _abi, geometry as GEOM
+from prisim_amd import _abi, geometry as GEOM, primary_beams as PB, workloads as W
 
 rng = NP.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 TOL_VS_UPLOADED = {_abi.PRISIM_FP64: 2e-13, _abi.PRISIM_FP32: 3e-6}     # (fp32: the altitude-sorted order sums in another order)
+TOL_EXT = 2e-7          # external beam: stored as float32 (:4466); direction cosines an ulp apart can land on either side of a rounding boundary
 fails = 0
+stats = {'external beam': 0, 'batched launches': 0, 'snapshots compared': 0, 'gradient': 0}
 t0 = time.time()
 ctx, ref = _abi.Context(0), _abi.Context(0)
+EXT_BEAM = W.synthetic_healpix_beam(8, NP.linspace(80e6, 260e6, 7))
 for case in range(ncase):
     nbl = int(rng.choice([1, 3, 63, 64, 65, 171, 255, 256, 257, 400, 700]))
     nchan = int(rng.choice([16, 17, 31, 32, 40, 64, 96, 128]))
@@ -52,22 +55,31 @@ for case in range(ncase):
     roi_radius = float(rng.choice([90.0, 90.0, 75.0, 30.0]))
     roi_center = 'pointing_center' if rng.integers(0, 5) == 0 else 'zenith'
     beam = int(rng.choice([_abi.PRISIM_BEAM_DELTA, _abi.PRISIM_BEAM_GAUSSIAN, _abi.PRISIM_BEAM_AIRY]))
+    ext_beam = bool(rng.integers(0, 4) == 0)         # the external HEALPix beam instead (its own batched preparation)
     lsts = rng.uniform(0.0, 360.0, k)
     pcs = GEOM.altaz2dircos(NP.stack((rng.uniform(60.0, 90.0, k), rng.uniform(0.0, 360.0, k)), axis=1), 'degrees')
     want_grad = bool(rng.integers(0, 6) == 0)
     what = dict(case=case, nbl=nbl, nchan=nchan, ncat=ncat, k=k, coords=coords, lat=lat, shape_kind=shape_kind, spectra=bool(spectra), roi=(roi_radius, roi_center),
-                beam=beam, grad=want_grad, maxbl=maxbl)
+                beam=beam, ext_beam=ext_beam, grad=want_grad, maxbl=maxbl)
+    stats['external beam'] += int(ext_beam)
+    stats['gradient'] += int(want_grad)
     try:
         for c, nt in ((ctx, k), (ref, 1)):
             c.set_array(bl, ch, nt_max=nt)
+            if ext_beam:
+                c.set_external_beam(EXT_BEAM, PB.spectral_interp_matrix(NP.linspace(80e6, 260e6, 7), ch, kind='cubic', chromatic=True, select_freq=None))
         if spectra:
             ctx.set_catalog(loc, coords, flux_spectrum=spec, fwhm_deg=fw)
         else:
             ctx.set_catalog(loc, coords, flux_ref=flux_ref, spindex=spindex, ref_freq_hz=150e6, fwhm_deg=fw)
-        obs = ctx.make_obs(lat, roi_radius_deg=roi_radius, roi_center=roi_center, beam_kind=beam, diameter_m=14.0)
+        if ext_beam:
+            obs = ctx.make_obs(lat, roi_radius_deg=roi_radius, roi_center=roi_center, use_external_beam=True)
+        else:
+            obs = ctx.make_obs(lat, roi_radius_deg=roi_radius, roi_center=roi_center, beam_kind=beam, diameter_m=14.0)
         for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):
             counts = ctx.observe_catalog(obs, lsts, pcs, pcs, precision=prec, want_grad=want_grad)
             batched = ctx.timing()['last_batch_snapshots'] if k > 1 else 1
+            stats['batched launches'] += int(batched > 1)
             for t in range(k):
                 # the host statements
                 if coords == 'radec':
@@ -103,7 +115,10 @@ for case in range(ncase):
                     continue
                 # the uploaded path on the host-formed sky (the order the catalogue path uses when it sorts by altitude does not matter to the sum)
                 fwm = None if fw is None else fw[m2]
-                if spectra:
+                if ext_beam:
+                    ref.set_sky_external_analytic(dc_all[m2], None if spectra else flux_ref[m2], None if spectra else spindex[m2], None if spectra else 150e6,
+                                                  pcs[t], fwhm_deg=fwm, flux_spectrum=spec[m2] if spectra else None)
+                elif spectra:
                     ref.set_sky_analytic(dc_all[m2], None, None, None, beam, 14.0, pcs[t], pcs[t], fwhm_deg=fwm, flux_spectrum=spec[m2])
                 else:
                     ref.set_sky_analytic(dc_all[m2], flux_ref[m2], spindex[m2], 150e6, beam, 14.0, pcs[t], pcs[t], fwhm_deg=fwm)
@@ -121,7 +136,8 @@ for case in range(ncase):
                 delta = 2.5e-15 + 4.5e-16 / NP.maximum(NP.cos(NP.radians(altaz[m2, 0])), 1e-6)
                 bound = float(NP.max(NP.sum(pbr * delta[:, None], axis=0) / NP.maximum(NP.sum(pbr, axis=0), 1e-300))) * 2.0 * NP.pi * lmax * float(ch[-1]) / 299792458.0
                 # (one source beside a null of the Airy pattern also turns 1e-15 of direction into 1e-12 of its own beam value)
-                tol = (TOL_VS_UPLOADED[prec] + bound) * max(1.0, 32.0 / m2.size)
+                tol = (max(TOL_VS_UPLOADED[prec], TOL_EXT if ext_beam else 0.0) + bound) * max(1.0, 32.0 / m2.size)
+                stats['snapshots compared'] += 1
                 for a, b in pairs:
                     err = float(NP.max(NP.abs(a - b) / scale))
                     if not err <= tol:
@@ -129,5 +145,5 @@ for case in range(ncase):
     except Exception as exc:      # noqa
         fails += 1
         print('FAIL', what, repr(exc), flush=True)
-print('fuzz_catalog: %d cases, %d fails, %.1f s' % (ncase, fails, time.time() - t0))
+print('fuzz_catalog: %d cases, %d fails, %.1f s; %s' % (ncase, fails, time.time() - t0, stats))
 sys.exit(1 if fails else 0)
