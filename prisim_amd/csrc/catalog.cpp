@@ -309,7 +309,9 @@ bool wave_batch_eligible(const prisim_ctx* ctx, const prisim_obs* obs, int preci
   // (sizes may vary from source to source and the sky may consist of several runs -- point sources + a diffuse map: every source
   // carries its own kappa, and with nothing to cull the runs need no separate launches; point sources then pay the taper kernel's 9.7
   // instead of the plain kernel's 6.2 instructions per term, which a launch per run and snapshot would cost many times over)
-  if (!C.have_shape || !taper_f64_grouped_enabled()) return false;
+  // (a catalogue without source shapes is the same with kappa = 0 everywhere: the weight is exactly 1, the sums those of the plain kernel
+  // to rounding)
+  if (!taper_f64_grouped_enabled()) return false;
   if (!obs->use_external_beam && (beamformer_doubles(obs->ext) != 0 || obs->beam_kind == PRISIM_BEAM_POLY)) return false;
   if (ctx->tune_chunk) return false;
   if (cat_sort_wanted(ctx)) return false;

@@ -441,6 +441,29 @@ def test_chunks_of_both_kinds_and_an_uploaded_sky_on_one_context():
             assert float(NP.max(NP.abs(ctx.get_vis(slot=t) - one.get_vis()) / scale)) <= 1e-13, t
 
 
+def test_batched_launch_on_a_catalogue_without_source_shapes():
+    """A sky model without src_shape (point sources, no taper) on a small array: the batched launch treats it as kappa = 0 everywhere --
+    weight exactly 1 -- and gives the plain kernel's sums to rounding."""
+    bl, ch, sky = _small_array_case(65, 96)
+    lat, lst0 = -30.7224, 25.0
+    radec = radec_catalogue(sky, lat, lst0)
+    k = 9
+    lsts = lst0 + 0.75 * NP.arange(k)
+    with _abi.Context(0) as ctx, _abi.Context(0) as one:
+        ctx.set_array(bl, ch, nt_max=k)
+        one.set_array(bl, ch, nt_max=1)
+        for c in (ctx, one):
+            c.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'])
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_GAUSSIAN, diameter_m=14.0)
+        counts = ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP64)
+        assert ctx.timing()['last_batch_snapshots'] == k
+        for t, lst in enumerate(lsts):
+            assert one.set_sky_from_catalog(obs, lst, ZEN, ZEN) == counts[t]
+            one.compute(precision=_abi.PRISIM_FP64)
+            scale = NP.sum(NP.abs(one.get_pbflux()), axis=0)[None, :]
+            assert float(NP.max(NP.abs(ctx.get_vis(slot=t) - one.get_vis()) / scale)) <= 1e-13, t
+
+
 def test_batched_snapshots_against_the_oracle_with_empty_and_moving_pointings():
     """The batched launch against the C oracle: per-snapshot phase and beam pointing centres, a snapshot with nothing above the horizon
     (its slot must hold zeros), source sizes that vary from source to source (no runs), a flux-spectrum table read through the index list."""
