@@ -690,8 +690,8 @@ def e2e_shard_estimate(device, n_acc=32, ranks=(1, 8)):
     clock ramp)."""
     res = {'what': 'rank 0 of N on one GPU, config 4, fp32; wall ms per snapshot through InterferometerArray.observe_batch (driver.run\'s loop) '
                    'against compute() alone on the sky of the pass\'s middle snapshot, queued back to back after all passes (same clock '
-                   'state); wall / over_kernel_only = the first n_acc snapshots of a FRESH instance (catalogue upload, two priority streams '
-                   '= 5 ms, first allocations, the first snapshot\'s preparation that nothing overlaps, clock ramp), resident = the next n_acc of '
+                   'state); wall / over_kernel_only = the first n_acc snapshots of a FRESH instance (catalogue upload, first allocations, the first '
+                   'snapshot\'s preparation that nothing overlaps, clock ramp; the context\'s streams exist since its creation), resident = the next n_acc of '
                    'the same instance; first_pass_extra_ms_total = what the fresh pass spends beyond the resident one, once per run; '
                    'marginal = (wall(3 n) - wall(n)) / 2n of two fresh instances', 'n_acc': n_acc}
     for n in ranks:

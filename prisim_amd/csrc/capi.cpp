@@ -230,6 +230,9 @@ int prisim_hip_create(int device, prisim_ctx** out) {
     prisim_hip_destroy(ctx);
     return fail(nullptr, PRISIM_ENODEV, m);
   }
+  // the catalogue path's two priority streams and their events belong to the context too (5 ms to create: not in front of a run's first
+  // snapshot); a failure here is not fatal -- the path tries again when it is first used and reports it then
+  if (catalog_streams(ctx) != PRISIM_OK) { ctx->err.clear(); (void)hipGetLastError(); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
     snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s)", prop.name, prop.gcnArchName);

@@ -26,38 +26,56 @@ struct HostSpan {
 
 constexpr double kCullThr[2] = {28.0, 18.0};      // index = precision (PRISIM_FP64 = 0, PRISIM_FP32 = 1); see upload_common (capi.cpp)
 
-int cat_runtime(prisim_ctx* ctx, int64_t nsnap) {
+}  // namespace
+
+namespace pint {
+// The streams, events and the first pinned block of the catalogue path.  prisim_hip_create calls this (two priority streams cost
+// 2.5 ms each to create -- 5 ms that used to sit in front of a run's first snapshot); cat_runtime calls it again if that failed.
+int catalog_streams(prisim_ctx* ctx) {
   auto& C = ctx->cat;
-  if (!C.gstream) {
-    HostSpan sp0("cat_runtime: streams, events, first pinned block");
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
-    if (hipStreamCreateWithPriority(&C.gstream, hipStreamNonBlocking, greatest) != hipSuccess) {
-      (void)hipGetLastError();
-      C.gstream = nullptr;
-      HIPCHK(ctx, hipStreamCreateWithFlags(&C.gstream, hipStreamNonBlocking));
-    }
-    // the preparation stream is a stream of its own (same priority): the geometry of snapshot t+1, whose small record the host waits for,
-    // does not queue behind the preparation of snapshot t, which a sky-sum in progress can hold up for milliseconds
-    if (hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
-      (void)hipGetLastError();
-      ctx->prep_stream = nullptr;
-      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
-    }
-    for (SkyBufs& k : ctx->skb) {
-      HIPCHK(ctx, hipEventCreateWithFlags(&k.ev_prep, hipEventDisableTiming));
-      HIPCHK(ctx, hipEventCreateWithFlags(&k.ev_sum, hipEventDisableTiming));
-    }
-    HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_geom, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_join, hipEventDisableTiming));
-    for (auto& e : C.ev_tab) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto& s : C.set) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming));
-    HostSpan sp1("cat_runtime: first pinned block");
+  if (C.gstream) return PRISIM_OK;
+  HostSpan sp0("catalog_streams: two priority streams, events, first pinned block");
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+  if (hipStreamCreateWithPriority(&C.gstream, hipStreamNonBlocking, greatest) != hipSuccess) {
+    (void)hipGetLastError();
+    C.gstream = nullptr;
+    HIPCHK(ctx, hipStreamCreateWithFlags(&C.gstream, hipStreamNonBlocking));
+  }
+  // the preparation stream is a stream of its own (same priority): the geometry of snapshot t+1, whose small record the host waits for,
+  // does not queue behind the preparation of snapshot t, which a sky-sum in progress can hold up for milliseconds
+  if (!ctx->prep_stream && hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->prep_stream = nullptr;
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
+  }
+  for (SkyBufs& k : ctx->skb) {
+    if (!k.ev_prep) HIPCHK(ctx, hipEventCreateWithFlags(&k.ev_prep, hipEventDisableTiming));
+    if (!k.ev_sum) HIPCHK(ctx, hipEventCreateWithFlags(&k.ev_sum, hipEventDisableTiming));
+  }
+  if (!C.ev_geom) HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_geom, hipEventDisableTiming));
+  if (!C.ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_join, hipEventDisableTiming));
+  for (auto& e : C.ev_tab) { if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+  for (auto& s : C.set) { if (!s.ev_free) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming)); }
+  if (!C.culled_host) {
     if (hipHostMalloc((void**)&C.culled_host, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
       C.culled_host = nullptr;
       return fail(ctx, PRISIM_ENOMEM, "hipHostMalloc for the catalogue path failed");
     }
     C.culled_host[0] = C.culled_host[1] = 0;
+  }
+  return PRISIM_OK;
+}
+}  // namespace pint
+
+namespace {
+
+int cat_runtime(prisim_ctx* ctx, int64_t nsnap) {
+  auto& C = ctx->cat;
+  if (!C.gstream || !ctx->prep_stream || !C.culled_host) {
+    if (C.gstream && (!ctx->prep_stream || !C.culled_host)) { (void)hipStreamDestroy(C.gstream); C.gstream = nullptr; }      // a half-made set: again
+    int rc = catalog_streams(ctx);
+    if (rc) return rc;
   }
   if (nsnap > C.cap_snaps) {
     HostSpan sp2("cat_runtime: per-snapshot pinned records + device tables");

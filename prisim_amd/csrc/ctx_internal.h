@@ -493,6 +493,7 @@ int extbeam_sky(prisim_ctx* ctx, int64_t nsrc, const double* d_fluxes, const dou
                 const int32_t* src_index);
 // catalog.cpp
 void catalog_destroy(prisim_ctx* ctx);
+int catalog_streams(prisim_ctx* ctx);             // the catalogue path's streams and events (created with the context)
 void catalog_after_compute(prisim_ctx* ctx);        // marks the current geometry set free once the compute just enqueued has run
 
 }  // namespace pint
