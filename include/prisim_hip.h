@@ -59,7 +59,9 @@ void prisim_hip_destroy(prisim_ctx* ctx);
 const char* prisim_hip_last_error(const prisim_ctx* ctx);
 /* Library version string "prisim_hip <major>.<minor> gfx950"; the minor number changes with every change of a struct or a signature
    in this header (0.2: prisim_timing carries the delay-stage fields; 0.3: prisim_comm_stats, self-test, gradient gather, asynchronous downloads;
-   0.4: the device-resident catalogue -- prisim_catalog / prisim_obs / prisim_snapshot and their four entries).  A binding should refuse a library that reports another one. */
+   0.4: the device-resident catalogue -- prisim_catalog / prisim_obs / prisim_snapshot and their four entries; 0.5: the snapshot carries its
+   frame -- prisim_snapshot.frame_given / cel2enu / aberr_beta, prisim_catalog.unitvec -- and the shard map / global-order gather).
+   A binding should refuse a library that reports another one. */
 const char* prisim_hip_version(void);
 
 /* ---- array: baselines + channels, resident across snapshots ---------------------------- */
@@ -196,13 +198,28 @@ int prisim_hip_get_pbflux(prisim_ctx* ctx, double* out);
  *
  * The reference re-derives the sky at every snapshot from a sky model that does not change over a run
  * (scripts/run_prisim.py:2165-2207 loops observe() over n_acc with ONE skymod; interferometry.py:6223-6247
- * store_prev_skymodel_file exists because that is expensive).  Here the catalogue is uploaded once and every snapshot's
- *   (RA, Dec) -> HA = LST - RA -> (alt, az)            interferometry.py:6113-6122, 6174-6180   (GEOM.hadec2altaz)
- *   region of interest                                 :6204-6219  (zenith: alt >= 90 - roi_radius; pointing centre: angle <= roi_radius)
- *   direction cosines                                  :6263       (GEOM.altaz2dircos)
- *   obs_catalog_indices (STABLE compaction)            :6377
- *   flux spectra of the ROI sources, pb * fluxes       :6249-6254
- * is formed on the device; the host reads back one small record per snapshot (source count, run boundaries). */
+ * store_prev_skymodel_file exists because that is expensive).  Here the catalogue is uploaded once, as unit vectors u in its own frame,
+ * and every snapshot's
+ *   catalogue frame -> local East-North-Up   s = normalise(R (u + beta))      interferometry.py:6174-6180 (radec), :6176-6177 (hadec)
+ *   region of interest                       :6204-6219  (zenith: n >= sin(90 - roi_radius); pointing centre: s . s_pc >= cos(roi_radius))
+ *   direction cosines                        :6263       (GEOM.altaz2dircos: they ARE s)
+ *   obs_catalog_indices (STABLE compaction)  :6377
+ *   flux spectra of the ROI sources, pb * fluxes   :6249-6254
+ * is formed on the device; the host reads back one small record per snapshot (source count, run boundaries).
+ *
+ * WHAT THE FRAME IS.  For skycoords 'radec' the reference goes FK5(equinox = skymodel.epoch) -> FK5(equinox = obstime) -> AltAz(obstime,
+ * location) through astropy (:6174-6180): precession, nutation, annual (and diurnal) aberration, Earth rotation, polar motion.  All of that
+ * is ONE rotation R (catalogue axes -> local East, North, Up) and ONE vector beta (observer velocity / c in the catalogue frame; first-order
+ * aberration, exact to 1e-3 arcsec), which is what prisim_snapshot carries (frame_given = 1).  The library does no astrometry of its own
+ * beyond the fall-back below; who fills R and beta decides what is modelled:
+ *   - prisim_amd/frames.py (the Python host mirror, default): IAU 2006 precession angles + truncated IAU 1980 nutation + annual
+ *     aberration + rotation by the caller's apparent LST + latitude tilt; NOT modelled: FK5/ICRS frame bias, light deflection, diurnal
+ *     aberration, polar motion (together < 1 arcsec; list with sizes in that module).  Parity with astropy is UNPINNED (not installable here);
+ *   - a PRISim-side binding that has astropy fills them from astropy itself and reproduces :6174-6180 exactly.
+ * frame_given = 0 (fall-back): R = tilt(latitude) . rot_z(lst_deg), beta = 0, i.e. hour angle = LST - RA with NO precession, nutation or
+ * aberration -- correct only for a catalogue already in the true equator and equinox of the snapshot; it is NOT what :6174-6180 computes.
+ * For 'hadec' catalogues the reference itself uses the plain rotation (GEOM.hadec2altaz, :6176-6177) and for 'altaz' none; frame_given = 0
+ * is exact for those. */
 enum { PRISIM_COORDS_RADEC = 0, PRISIM_COORDS_HADEC = 1, PRISIM_COORDS_ALTAZ = 2 };
 
 typedef struct prisim_catalog {
@@ -216,6 +233,10 @@ typedef struct prisim_catalog {
   const double* flux_spectrum;  /* ... or [nsrc][nchan] spectra on the channel grid (SkyModel.generate_spectrum of the whole catalogue, :6249);
                                    when non-NULL it replaces the power law */
   const double* fwhm_deg;       /* [nsrc] sqrt(maj * min) of skymodel.src_shape (:6267), or NULL (no source-shape taper) */
+  const double* unitvec;        /* optional [nsrc][3]: the catalogue's unit vectors in its own frame -- RA-Dec / HA-Dec (cos d cos a, cos d sin a, sin d),
+                                   alt-az East-North-Up direction cosines.  NULL: the device forms them from `location` (its sin / cos may
+                                   differ from the host's in the last place); given: `location` may be NULL, and a host that applies
+                                   s = normalise(R (u + beta)) with the same operation order selects the same sources bit for bit */
 } prisim_catalog;
 
 /* Upload the catalogue (once per run; set_array drops it: the spectra are per channel grid).  Synchronises the stream. */
@@ -234,9 +255,13 @@ typedef struct prisim_obs {
 } prisim_obs;
 
 typedef struct prisim_snapshot {
-  double lst_deg;               /* local sidereal time of the snapshot (:6113); ignored for HA-Dec and alt-az catalogues */
+  double lst_deg;               /* local sidereal time of the snapshot (:6113); used only when frame_given = 0 and the catalogue is RA-Dec */
   double pc_dircos[3];          /* pointing = phase centre, ENU direction cosines (:6155-6167) */
   double beam_pc_dircos[3];     /* beam pointing centre (zenith = {0,0,1}) */
+  int32_t frame_given;          /* 1: cel2enu / aberr_beta below are the snapshot's frame; 0: the fall-back rotation described above */
+  int32_t reserved_;
+  double cel2enu[9];            /* row-major rotation: catalogue-frame unit vectors -> local East, North, Up (must be orthonormal to 1e-9) */
+  double aberr_beta[3];         /* observer velocity / c in the CATALOGUE frame (|beta| < 0.01); zeros = no aberration */
 } prisim_snapshot;
 
 /* Make snapshot `snap` of the catalogue the current sky: geometry, compaction, (when long baselines can resolve sources out) the

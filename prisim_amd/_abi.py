@@ -10,7 +10,7 @@ import numpy as NP
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PRISIM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libprisim_hip.so')      # PRISIM_HIP_LIB: A/B another build of the same ABI
-ABI_VERSION = 'prisim_hip 0.4 gfx950'       # prisim_hip_version(): bumped whenever a struct or a signature of include/prisim_hip.h changes
+ABI_VERSION = 'prisim_hip 0.5 gfx950'       # prisim_hip_version(): bumped whenever a struct or a signature of include/prisim_hip.h changes
 
 PRISIM_OK = 0
 PRISIM_EINVAL, PRISIM_ENODEV, PRISIM_ENOMEM, PRISIM_ESTATE, PRISIM_ELIB, PRISIM_EINTERNAL = -1, -2, -3, -4, -5, -6
@@ -117,7 +117,8 @@ class PrisimBeamSky(C.Structure):
 
 class PrisimCatalog(C.Structure):
     _fields_ = [('nsrc', C.c_int64), ('coords', C.c_int32), ('reserved_', C.c_int32), ('location', C.c_void_p), ('flux_ref', C.c_void_p),
-                ('spindex', C.c_void_p), ('ref_freq_hz', C.c_double), ('flux_spectrum', C.c_void_p), ('fwhm_deg', C.c_void_p)]
+                ('spindex', C.c_void_p), ('ref_freq_hz', C.c_double), ('flux_spectrum', C.c_void_p), ('fwhm_deg', C.c_void_p),
+                ('unitvec', C.c_void_p)]
 
 
 class PrisimObs(C.Structure):
@@ -126,7 +127,8 @@ class PrisimObs(C.Structure):
 
 
 class PrisimSnapshot(C.Structure):
-    _fields_ = [('lst_deg', C.c_double), ('pc_dircos', C.c_double * 3), ('beam_pc_dircos', C.c_double * 3)]
+    _fields_ = [('lst_deg', C.c_double), ('pc_dircos', C.c_double * 3), ('beam_pc_dircos', C.c_double * 3), ('frame_given', C.c_int32),
+                ('reserved_', C.c_int32), ('cel2enu', C.c_double * 9), ('aberr_beta', C.c_double * 3)]
 
 
 class PrisimPost(C.Structure):
@@ -426,11 +428,27 @@ class Context(object):
         self.nsrc = nsrc
 
     # ---- device-resident catalogue ----
-    def set_catalog(self, location, coords, flux_ref=None, spindex=None, ref_freq_hz=None, flux_spectrum=None, fwhm_deg=None):
+    def set_catalog(self, location, coords, flux_ref=None, spindex=None, ref_freq_hz=None, flux_spectrum=None, fwhm_deg=None, unitvec='host'):
         """Upload a run's sky model once (prisim_hip_set_catalog): location (nsrc, 2) degrees in `coords` ('radec' | 'hadec' | 'altaz'),
-        the power law flux_ref (f / ref_freq_hz)^spindex or flux_spectrum (nsrc, nchan), source sizes fwhm_deg (or None)."""
+        the power law flux_ref (f / ref_freq_hz)^spindex or flux_spectrum (nsrc, nchan), source sizes fwhm_deg (or None).
+        unitvec: 'host' (default) -- the catalogue's unit vectors are formed here (geometry.catalog_unitvec) and uploaded, so that the host
+        mirror of the snapshot geometry (geometry.frame_dircos) and the device select the same sources bit for bit; 'device' -- only
+        `location` crosses and the device forms them; or an (nsrc, 3) array."""
         loc = NP.ascontiguousarray(location, dtype=NP.float64).reshape(-1, 2)
         nsrc = loc.shape[0]
+        if coords not in PRISIM_COORDS:
+            raise ValueError('coords must be "radec", "hadec" or "altaz"')
+        uv = None
+        if isinstance(unitvec, str):
+            if unitvec == 'host':
+                from . import geometry as _G
+                uv = NP.ascontiguousarray(_G.catalog_unitvec(loc, coords))
+            elif unitvec != 'device':
+                raise ValueError("unitvec must be 'host', 'device' or an (nsrc, 3) array")
+        elif unitvec is not None:
+            uv = NP.ascontiguousarray(unitvec, dtype=NP.float64).reshape(-1, 3)
+            if uv.shape[0] != nsrc:
+                raise ValueError('unitvec must have shape (nsrc, 3)')
         fs = fr = sp = fw = None
         if flux_spectrum is not None:
             fs = NP.ascontiguousarray(flux_spectrum, dtype=NP.float64)
@@ -446,11 +464,10 @@ class Context(object):
             fw = NP.ascontiguousarray(fwhm_deg, dtype=NP.float64).ravel()
             if fw.size != nsrc:
                 raise ValueError('fwhm_deg must have nsrc elements')
-        if coords not in PRISIM_COORDS:
-            raise ValueError('coords must be "radec", "hadec" or "altaz"')
-        cat = PrisimCatalog(nsrc, PRISIM_COORDS[coords], 0, _ptr(loc), _ptr(fr), _ptr(sp), float(ref_freq_hz), _ptr(fs), _ptr(fw))
+        cat = PrisimCatalog(nsrc, PRISIM_COORDS[coords], 0, _ptr(loc), _ptr(fr), _ptr(sp), float(ref_freq_hz), _ptr(fs), _ptr(fw), _ptr(uv))
         self._check(self._lib.prisim_hip_set_catalog(self._h, C.byref(cat)), 'prisim_hip_set_catalog')
         self.ncat = nsrc
+        self.cat_coords = coords
 
     @staticmethod
     def make_obs(latitude_deg, roi_radius_deg=90.0, roi_center='zenith', beam_kind=PRISIM_BEAM_DELTA, diameter_m=1.0, ext=None,
@@ -463,25 +480,37 @@ class Context(object):
         return obs
 
     @staticmethod
-    def _snapshot(lst_deg, pc_dircos, beam_pc_dircos):
-        sn = PrisimSnapshot()
+    def _fill_snapshot(sn, lst_deg, pc_dircos, beam_pc_dircos, frame=None):
+        """frame: None -- the library's fall-back rotation from lst and latitude (hour angle = LST - RA); or (R (3, 3), beta (3,)), the
+        snapshot's catalogue-frame -> East-North-Up rotation and aberration vector (prisim_amd/frames.py snapshot_frame)."""
         sn.lst_deg = float(lst_deg)
         sn.pc_dircos[0], sn.pc_dircos[1], sn.pc_dircos[2] = float(pc_dircos[0]), float(pc_dircos[1]), float(pc_dircos[2])
         b = pc_dircos if beam_pc_dircos is None else beam_pc_dircos
         sn.beam_pc_dircos[0], sn.beam_pc_dircos[1], sn.beam_pc_dircos[2] = float(b[0]), float(b[1]), float(b[2])
+        if frame is None:
+            sn.frame_given = 0
+        else:
+            rot, beta = frame
+            sn.frame_given = 1
+            sn.cel2enu[:] = NP.asarray(rot, dtype=NP.float64).reshape(9).tolist()
+            sn.aberr_beta[:] = NP.asarray(beta, dtype=NP.float64).reshape(3).tolist()
         return sn
 
-    def set_sky_from_catalog(self, obs, lst_deg, pc_dircos, beam_pc_dircos=None):
+    @classmethod
+    def _snapshot(cls, lst_deg, pc_dircos, beam_pc_dircos, frame=None):
+        return cls._fill_snapshot(PrisimSnapshot(), lst_deg, pc_dircos, beam_pc_dircos, frame)
+
+    def set_sky_from_catalog(self, obs, lst_deg, pc_dircos, beam_pc_dircos=None, frame=None):
         """Snapshot geometry, region of interest, beam x flux of the resident catalogue on the device; returns the ROI source count."""
-        sn = self._snapshot(lst_deg, pc_dircos, beam_pc_dircos)
+        sn = self._snapshot(lst_deg, pc_dircos, beam_pc_dircos, frame)
         n = C.c_int64()
         self._check(self._lib.prisim_hip_set_sky_from_catalog(self._h, C.byref(obs), C.byref(sn), C.byref(n)), 'prisim_hip_set_sky_from_catalog')
         self.nsrc = int(n.value)
         return self.nsrc
 
-    def catalog_roi(self, obs, lst_deg, pc_dircos, want_indices=True, want_dircos=True):
+    def catalog_roi(self, obs, lst_deg, pc_dircos, want_indices=True, want_dircos=True, frame=None):
         """(indices int64 [n], dircos [n, 3]) of the region of interest of one snapshot, catalogue order (prisim_hip_catalog_roi)."""
-        sn = self._snapshot(lst_deg, pc_dircos, None)
+        sn = self._snapshot(lst_deg, pc_dircos, None, frame)
         n = C.c_int64()
         self._check(self._lib.prisim_hip_catalog_roi(self._h, C.byref(obs), C.byref(sn), C.byref(n), None, None, 0), 'prisim_hip_catalog_roi')
         cnt = int(n.value)
@@ -493,20 +522,21 @@ class Context(object):
         return idx, dc
 
     def observe_catalog(self, obs, lst_deg, pc_dircos, beam_pc_dircos=None, precision=PRISIM_FP64, want_grad=False, slot0=0,
-                        host_cube=None, gather=None):
+                        host_cube=None, gather=None, frames=None):
         """K snapshots of the resident catalogue in one call (prisim_hip_observe_catalog): lst_deg (K,), pc_dircos (K, 3) or (3,),
         beam_pc_dircos likewise (default: pc_dircos).  Results land in cube slots slot0 ... slot0 + K - 1; returns the ROI counts (K,).
         host_cube: page-locked (nt_max, nbl, nchan) complex128 / complex64 array (host_empty) every finished slot is downloaded into,
-        behind its sky-sum; gather: None, or 'c128' / 'c64' -- every finished slot is all-gathered on the communication stream."""
+        behind its sky-sum; gather: None, or 'c128' / 'c64' -- every finished slot is all-gathered on the communication stream.
+        frames: None (the library's fall-back rotation from lst and latitude), or K pairs (R (3, 3), beta (3,)) -- see _fill_snapshot."""
         lst = NP.asarray(lst_deg, dtype=NP.float64).ravel()
         k = lst.size
         pc = NP.broadcast_to(NP.asarray(pc_dircos, dtype=NP.float64).reshape(-1, 3), (k, 3))
         bpc = pc if beam_pc_dircos is None else NP.broadcast_to(NP.asarray(beam_pc_dircos, dtype=NP.float64).reshape(-1, 3), (k, 3))
         snaps = (PrisimSnapshot * k)()
+        if frames is not None and len(frames) != k:
+            raise ValueError('frames must hold one (R, beta) pair per snapshot')
         for t in range(k):
-            snaps[t].lst_deg = lst[t]
-            snaps[t].pc_dircos[:] = pc[t].tolist()
-            snaps[t].beam_pc_dircos[:] = bpc[t].tolist()
+            self._fill_snapshot(snaps[t], lst[t], pc[t], bpc[t], None if frames is None else frames[t])
         counts = NP.zeros(k, dtype=NP.int64)
         post = None
         if host_cube is not None or gather is not None:

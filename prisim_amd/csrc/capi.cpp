@@ -201,7 +201,7 @@ Plan make_plan(const prisim_ctx* ctx, int precision, int kernel) {
 
 extern "C" {
 
-const char* prisim_hip_version(void) { return "prisim_hip 0.4 gfx950"; }     // 0.4: device-resident catalogue
+const char* prisim_hip_version(void) { return "prisim_hip 0.5 gfx950"; }     // 0.5: the snapshot carries its frame; shard map
 
 const char* prisim_hip_last_error(const prisim_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 

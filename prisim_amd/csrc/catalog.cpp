@@ -106,6 +106,43 @@ bool cat_sort_wanted(const prisim_ctx* ctx) {
   return C.kappa_max * x * x >= 18.0;
 }
 
+// The frame of a snapshot the caller gave no frame for (frame_given = 0): the plain rotation -- RA-Dec: tilt(latitude) . rot_z(lst), i.e. hour
+// angle = LST - RA (a catalogue in the true equator and equinox of date); HA-Dec: the tilt alone on (cos d cos H, cos d sin H, sin d)
+// (GEOM.hadec2altaz, interferometry.py:6176-6177); alt-az: identity.  prisim_amd/frames.py equatorial_to_enu / hadec_to_enu are the same matrices.
+void fallback_frame(int coords, double lst_deg, double latitude_deg, double rot[9], double beta[3]) {
+  beta[0] = beta[1] = beta[2] = 0.0;
+  const double lat = latitude_deg * (M_PI / 180.0);
+  const double sl = std::sin(lat), cl = std::cos(lat);
+  if (coords == PRISIM_COORDS_ALTAZ) {
+    const double id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(rot, id, sizeof(id));
+  } else if (coords == PRISIM_COORDS_HADEC) {
+    const double m[9] = {0.0, -1.0, 0.0, -sl, 0.0, cl, cl, 0.0, sl};
+    memcpy(rot, m, sizeof(m));
+  } else {
+    const double a = lst_deg * (M_PI / 180.0);
+    const double c = std::cos(a), s = std::sin(a);
+    // tilt . r3(a):  r3 = [[c, s, 0], [-s, c, 0], [0, 0, 1]],  tilt = [[0, 1, 0], [-sl, 0, cl], [cl, 0, sl]]
+    const double m[9] = {-s, c, 0.0, -sl * c, -sl * s, cl, cl * c, cl * s, sl};
+    memcpy(rot, m, sizeof(m));
+  }
+}
+
+int check_frame(prisim_ctx* ctx, const prisim_snapshot& sn) {
+  if (!sn.frame_given) return PRISIM_OK;
+  for (int i = 0; i < 9; ++i) if (!std::isfinite(sn.cel2enu[i])) return fail(ctx, PRISIM_EINVAL, "non-finite cel2enu");
+  double b2 = 0.0;
+  for (int i = 0; i < 3; ++i) { if (!std::isfinite(sn.aberr_beta[i])) return fail(ctx, PRISIM_EINVAL, "non-finite aberr_beta"); b2 += sn.aberr_beta[i] * sn.aberr_beta[i]; }
+  if (b2 >= 1e-4) return fail(ctx, PRISIM_EINVAL, "aberr_beta must be a velocity / c with |beta| < 0.01");
+  for (int r = 0; r < 3; ++r)
+    for (int q = r; q < 3; ++q) {
+      double d = 0.0;
+      for (int k = 0; k < 3; ++k) d += sn.cel2enu[3 * r + k] * sn.cel2enu[3 * q + k];
+      if (std::fabs(d - (r == q ? 1.0 : 0.0)) > 1e-9) return fail(ctx, PRISIM_EINVAL, "cel2enu is not a rotation matrix (rows must be orthonormal to 1e-9)");
+    }
+  return PRISIM_OK;
+}
+
 int check_obs(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap) {
   if (!obs || !snaps) return fail(ctx, PRISIM_EINVAL, "obs / snapshot is NULL");
   if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array must be called before the catalogue path");
@@ -113,7 +150,8 @@ int check_obs(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* sna
   if (!std::isfinite(obs->latitude_deg) || !std::isfinite(obs->roi_radius_deg)) return fail(ctx, PRISIM_EINVAL, "non-finite latitude / roi_radius");
   if (obs->roi_center != 0 && obs->roi_center != 1) return fail(ctx, PRISIM_EINVAL, "roi_center must be 0 (zenith) or 1 (pointing centre)");
   for (int64_t t = 0; t < nsnap; ++t) {
-    if (!std::isfinite(snaps[t].lst_deg)) return fail(ctx, PRISIM_EINVAL, "non-finite LST");
+    if (!snaps[t].frame_given && !std::isfinite(snaps[t].lst_deg)) return fail(ctx, PRISIM_EINVAL, "non-finite LST");
+    if (int rc = check_frame(ctx, snaps[t])) return rc;
     for (int i = 0; i < 3; ++i)
       if (!std::isfinite(snaps[t].pc_dircos[i]) || !std::isfinite(snaps[t].beam_pc_dircos[i])) return fail(ctx, PRISIM_EINVAL, "non-finite pointing / phase centre");
   }
@@ -155,7 +193,12 @@ int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* 
     return rc;
   for (int64_t t = 0; t < nsnap; ++t) {
     CatSnap& s = C.snaps_host[t];
-    s.lst_deg = snaps[t].lst_deg;
+    if (snaps[t].frame_given) {
+      memcpy(s.rot, snaps[t].cel2enu, sizeof(s.rot));
+      memcpy(s.beta, snaps[t].aberr_beta, sizeof(s.beta));
+    } else {
+      fallback_frame(C.coords, snaps[t].lst_deg, obs->latitude_deg, s.rot, s.beta);
+    }
     for (int i = 0; i < 3; ++i) { s.roi_pc[i] = snaps[t].pc_dircos[i]; s.pc[i] = snaps[t].pc_dircos[i]; }
   }
   if (C.n == 0) {
@@ -166,16 +209,13 @@ int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* 
     return PRISIM_OK;
   }
   CatGeomParams p{};
-  p.lon = (const double*)C.lon.p; p.lat = (const double*)C.lat.p;
-  p.sin_dec = (const double*)C.sin_dec.p; p.cos_dec = (const double*)C.cos_dec.p;
+  p.ux = (const double*)C.ux.p; p.uy = (const double*)C.uy.p; p.uz = (const double*)C.uz.p;
   p.kappa = C.have_shape ? (const double*)C.kappa.p : nullptr;
   p.run_id = C.runs.empty() ? nullptr : (const uint8_t*)C.run_id.p;
   p.n = C.n; p.nblocks = nblocks;
-  p.coords = C.coords; p.roi_center = obs->roi_center; p.want_keys = want_keys ? 1 : 0;
-  const double lat = obs->latitude_deg * (M_PI / 180.0);          // NP.radians(latitude)
-  p.sin_lat = std::sin(lat); p.cos_lat = std::cos(lat);
-  p.alt_min_deg = 90.0 - obs->roi_radius_deg;                      // interferometry.py:6216
-  p.roi_radius_deg = obs->roi_radius_deg;
+  p.roi_center = obs->roi_center; p.want_keys = want_keys ? 1 : 0;
+  p.sin_alt_min = std::sin((90.0 - obs->roi_radius_deg) * (M_PI / 180.0));      // interferometry.py:6216 on the direction cosine n
+  p.cos_radius = std::cos(obs->roi_radius_deg * (M_PI / 180.0));               // :6211 on s . s_pc  (geometry.roi_thresholds)
   p.snaps = (const CatSnap*)C.snaps.p;
   p.block_off = (int32_t*)C.block_off.p;
   p.idx = (int32_t*)S.idx.p; p.dirs = (double*)S.dirs.p;
@@ -547,7 +587,7 @@ void catalog_after_compute(prisim_ctx* ctx) {
 void catalog_destroy(prisim_ctx* ctx) {
   auto& C = ctx->cat;
   if (C.gstream) (void)hipStreamSynchronize(C.gstream);
-  for (DevBuf* b : {&C.lon, &C.lat, &C.sin_dec, &C.cos_dec, &C.kappa, &C.run_id, &C.flux_ref, &C.spindex, &C.spec, &C.block_off, &C.snaps, &C.out_dev,
+  for (DevBuf* b : {&C.lon, &C.lat, &C.ux, &C.uy, &C.uz, &C.kappa, &C.run_id, &C.flux_ref, &C.spindex, &C.spec, &C.block_off, &C.snaps, &C.out_dev,
                     &C.sort_tmp, &C.keys_out, &C.perm, &C.culled})
     release(*b);
   for (auto& s : C.set) {
@@ -582,25 +622,33 @@ int prisim_hip_set_catalog(prisim_ctx* ctx, const prisim_catalog* cat) {
   const int64_t n = cat->nsrc;
   if (n < 0 || n > (int64_t)0x7fff0000) return fail(ctx, PRISIM_EINVAL, "nsrc must be in [0, 2^31)");
   if (cat->coords < PRISIM_COORDS_RADEC || cat->coords > PRISIM_COORDS_ALTAZ) return fail(ctx, PRISIM_EINVAL, "unknown catalogue coordinates");
-  if (n > 0 && !cat->location) return fail(ctx, PRISIM_EINVAL, "location is NULL");
+  if (n > 0 && !cat->location && !cat->unitvec) return fail(ctx, PRISIM_EINVAL, "location and unitvec are both NULL");
   const bool have_spec = cat->flux_spectrum != nullptr;
   if (n > 0 && !have_spec && (!cat->flux_ref || !cat->spindex)) return fail(ctx, PRISIM_EINVAL, "flux_ref / spindex is NULL and no flux_spectrum given");
   if (!have_spec && !(cat->ref_freq_hz > 0.0)) return fail(ctx, PRISIM_EINVAL, "ref_freq_hz must be positive");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  auto& C = ctx->cat;
-  // a set of the previous catalogue may still be read by queued work
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (C.gstream) HIPCHK(ctx, hipStreamSynchronize(C.gstream));
-  C.loaded = false;
-  ctx->sky_set = ctx->sky_set && C.cur < 0;       // a sky that lives in the old catalogue's buffers is gone
-  C.cur = -1;
-  std::vector<double> lon((size_t)n), lat((size_t)n), kap;
-  for (int64_t i = 0; i < n; ++i) {
-    lon[(size_t)i] = cat->location[2 * i]; lat[(size_t)i] = cat->location[2 * i + 1];
-    if (!std::isfinite(lon[(size_t)i]) || !std::isfinite(lat[(size_t)i])) return fail(ctx, PRISIM_EINVAL, "non-finite catalogue position");
+  // ---- every input is validated BEFORE the resident catalogue is touched: a rejected call leaves the previous sky in place ----
+  std::vector<double> lon, lat, uvec[3], kap;
+  if (cat->unitvec) {
+    for (auto& v : uvec) v.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+      double r2 = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        const double v = cat->unitvec[3 * i + k];
+        if (!std::isfinite(v)) return fail(ctx, PRISIM_EINVAL, "non-finite catalogue unit vector");
+        uvec[k][(size_t)i] = v;
+        r2 += v * v;
+      }
+      if (std::fabs(r2 - 1.0) > 1e-9) return fail(ctx, PRISIM_EINVAL, "catalogue unit vectors must have unit length (to 1e-9)");
+    }
+  } else {
+    lon.resize((size_t)n); lat.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+      lon[(size_t)i] = cat->location[2 * i]; lat[(size_t)i] = cat->location[2 * i + 1];
+      if (!std::isfinite(lon[(size_t)i]) || !std::isfinite(lat[(size_t)i])) return fail(ctx, PRISIM_EINVAL, "non-finite catalogue position");
+    }
   }
-  C.runs.clear();
-  C.kappa_max = 0.0;
+  std::vector<prisim_ctx::Catalog::Run> runs;
+  double kappa_max = 0.0;
   std::vector<uint8_t> run_id;
   if (cat->fwhm_deg && n > 0) {
     kap.resize((size_t)n);
@@ -609,29 +657,53 @@ int prisim_hip_set_catalog(prisim_ctx* ctx, const prisim_catalog* cat) {
       if (!std::isfinite(fw) || fw < 0.0) return fail(ctx, PRISIM_EINVAL, "invalid source FWHM");
       const double fd = 2.0 * std::sin(0.5 * fw * M_PI / 180.0);          // interferometry.py:6268-6283, as upload_common
       kap[(size_t)i] = M_LN2 * fd * fd;
-      C.kappa_max = std::max(C.kappa_max, kap[(size_t)i]);
+      kappa_max = std::max(kappa_max, kap[(size_t)i]);
     }
     run_id.assign((size_t)n, 0);
     int64_t lo = 0;
     bool ok = true;
     for (int64_t s = 1; s <= n && ok; ++s) {
       if (s == n || kap[(size_t)s] != kap[(size_t)lo]) {
-        if (C.runs.size() == (size_t)PRISIM_CAT_MAX_RUNS) { ok = false; break; }
-        for (int64_t j = lo; j < s; ++j) run_id[(size_t)j] = (uint8_t)C.runs.size();
-        C.runs.push_back({lo, s, kap[(size_t)lo]});
+        if (runs.size() == (size_t)PRISIM_CAT_MAX_RUNS) { ok = false; break; }
+        for (int64_t j = lo; j < s; ++j) run_id[(size_t)j] = (uint8_t)runs.size();
+        runs.push_back({lo, s, kap[(size_t)lo]});
         lo = s;
       }
     }
-    if (!ok) C.runs.clear();                                                 // sizes vary source by source: no runs (like the uploaded path)
+    if (!ok) runs.clear();                                                   // sizes vary source by source: no runs (like the uploaded path)
   }
+  if (n > 0 && have_spec) {
+    for (size_t i = 0; i < (size_t)n * (size_t)ctx->nchan; ++i)
+      if (!std::isfinite(cat->flux_spectrum[i])) return fail(ctx, PRISIM_EINVAL, "non-finite flux spectrum");
+  } else if (n > 0) {
+    for (int64_t i = 0; i < n; ++i)
+      if (!std::isfinite(cat->flux_ref[i]) || !std::isfinite(cat->spindex[i])) return fail(ctx, PRISIM_EINVAL, "non-finite flux_ref / spindex");
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  auto& C = ctx->cat;
+  // a set of the previous catalogue may still be read by queued work
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (C.gstream) HIPCHK(ctx, hipStreamSynchronize(C.gstream));
+  if (ctx->prep_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->prep_stream));
+  C.loaded = false;
+  ctx->sky_set = ctx->sky_set && C.cur < 0;       // a sky that lives in the old catalogue's buffers is gone
+  C.cur = -1;
+  C.runs = runs;
+  C.kappa_max = kappa_max;
   int rc;
   const size_t nb = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
-  if ((rc = ensure(ctx, C.lon, nb)) || (rc = ensure(ctx, C.lat, nb)) || (rc = ensure(ctx, C.sin_dec, nb)) || (rc = ensure(ctx, C.cos_dec, nb))) return rc;
+  if ((rc = ensure(ctx, C.ux, nb)) || (rc = ensure(ctx, C.uy, nb)) || (rc = ensure(ctx, C.uz, nb))) return rc;
   if (n > 0) {
-    HIPCHK(ctx, hipMemcpy(C.lon.p, lon.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(C.lat.p, lat.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    if (cat->coords != PRISIM_COORDS_ALTAZ)
-      HIPCHK(ctx, launch_cat_prepare((const double*)C.lat.p, (double*)C.sin_dec.p, (double*)C.cos_dec.p, n, ctx->stream));
+    if (cat->unitvec) {
+      HIPCHK(ctx, hipMemcpy(C.ux.p, uvec[0].data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(ctx, hipMemcpy(C.uy.p, uvec[1].data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(ctx, hipMemcpy(C.uz.p, uvec[2].data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+      if ((rc = ensure(ctx, C.lon, nb)) || (rc = ensure(ctx, C.lat, nb))) return rc;
+      HIPCHK(ctx, hipMemcpy(C.lon.p, lon.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(ctx, hipMemcpy(C.lat.p, lat.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(ctx, launch_cat_prepare((const double*)C.lon.p, (const double*)C.lat.p, cat->coords, (double*)C.ux.p, (double*)C.uy.p, (double*)C.uz.p, n, ctx->stream));
+    }
     if (!kap.empty()) {
       if ((rc = ensure(ctx, C.kappa, nb)) || (rc = ensure(ctx, C.run_id, (size_t)n))) return rc;
       HIPCHK(ctx, hipMemcpy(C.kappa.p, kap.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
@@ -639,13 +711,9 @@ int prisim_hip_set_catalog(prisim_ctx* ctx, const prisim_catalog* cat) {
     }
     if (have_spec) {
       const size_t sb = (size_t)n * (size_t)ctx->nchan * sizeof(double);
-      for (size_t i = 0; i < (size_t)n * (size_t)ctx->nchan; ++i)
-        if (!std::isfinite(cat->flux_spectrum[i])) return fail(ctx, PRISIM_EINVAL, "non-finite flux spectrum");
       if ((rc = ensure(ctx, C.spec, sb))) return rc;
       HIPCHK(ctx, hipMemcpy(C.spec.p, cat->flux_spectrum, sb, hipMemcpyHostToDevice));
     } else {
-      for (int64_t i = 0; i < n; ++i)
-        if (!std::isfinite(cat->flux_ref[i]) || !std::isfinite(cat->spindex[i])) return fail(ctx, PRISIM_EINVAL, "non-finite flux_ref / spindex");
       if ((rc = ensure(ctx, C.flux_ref, nb)) || (rc = ensure(ctx, C.spindex, nb))) return rc;
       HIPCHK(ctx, hipMemcpy(C.flux_ref.p, cat->flux_ref, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
       HIPCHK(ctx, hipMemcpy(C.spindex.p, cat->spindex, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
@@ -688,8 +756,9 @@ int prisim_hip_catalog_roi(prisim_ctx* ctx, const prisim_obs* obs, const prisim_
   if (!ctx) return PRISIM_EINVAL;
   if (!obs || !snap) return fail(ctx, PRISIM_EINVAL, "obs / snapshot is NULL");
   if (!ctx->array_set || !ctx->cat.loaded) return fail(ctx, PRISIM_ESTATE, "set_array and set_catalog must be called first");
-  if (!std::isfinite(obs->latitude_deg) || !std::isfinite(obs->roi_radius_deg) || !std::isfinite(snap->lst_deg))
+  if (!std::isfinite(obs->latitude_deg) || !std::isfinite(obs->roi_radius_deg) || (!snap->frame_given && !std::isfinite(snap->lst_deg)))
     return fail(ctx, PRISIM_EINVAL, "non-finite latitude / roi_radius / LST");
+  if (int rcf = check_frame(ctx, *snap)) return rcf;
   if (obs->roi_center != 0 && obs->roi_center != 1) return fail(ctx, PRISIM_EINVAL, "roi_center must be 0 (zenith) or 1 (pointing centre)");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   auto& C = ctx->cat;

@@ -3,10 +3,10 @@
 // The reference re-derives the whole sky at every snapshot on the host (prisim/interferometry.py:6171-6180 hadec/radec -> alt-az,
 // :6204-6219 region of interest, :6263 direction cosines) from a sky model that does not change over a run
 // (scripts/run_prisim.py:2165-2207 loops observe() over n_acc with one skymod).  Here the catalogue is uploaded once
-// (prisim_hip_set_catalog) and every snapshot's (HA, Dec) -> (alt, az) -> (l, m, n), horizon / ROI mask, STABLE compaction (the
-// compacted index list is obs_catalog_indices, :6377), the altitude ordering the taper culling wants and the cull table itself are
-// formed on the device.  The arithmetic follows prisim_amd/geometry.py statement by statement with FMA contraction off, so that the
-// index lists agree with the host path and the direction cosines agree to a few ulp.
+// (prisim_hip_set_catalog) as unit vectors in its own frame, and every snapshot's frame -> (l, m, n), horizon / ROI mask, STABLE
+// compaction (the compacted index list is obs_catalog_indices, :6377), the altitude ordering the taper culling wants and the cull table
+// itself are formed on the device.  The arithmetic is geometry.frame_dircos() of the host mirror operation by operation with FMA
+// contraction off: index lists and direction cosines agree with the host path bit for bit.
 //
 // All kernels take a snapshot index from blockIdx.y: a batch of K snapshots is K rows of one launch.
 #include <hip/hip_runtime.h>
@@ -20,50 +20,46 @@ namespace prisim {
 
 static constexpr int kCatBlock = 256;
 
-// (alt, az) in degrees -> flag + direction cosines, exactly the statements of geometry.hadec2altaz / altaz2dircos and
-// interferometry.py:6176-6180, 6204-6216 (roi_center 'zenith': alt >= 90 - roi_radius; 'pointing_center': angle to it <= roi_radius)
+// One catalogue source in one snapshot's frame: s = normalise(R (u + beta)) and the region-of-interest flag
+// (interferometry.py:6174-6180 astropy FK5 -> AltAz / GEOM.hadec2altaz, :6263 altaz2dircos, :6204-6216 region of interest -- 'zenith':
+// altitude >= 90 - roi_radius <=> n >= sin(90 - roi_radius); 'pointing_center': angle to it <= roi_radius <=> s . s_pc >= cos(roi_radius)).
+// The frame (rotation + aberration vector) comes with the snapshot: prisim_snapshot.cel2enu / aberr_beta, or the plain sidereal rotation
+// the library builds from lst and latitude.  Only +, *, sqrt and / with contraction off, in the order of geometry.frame_dircos() on the
+// host: both sides round identically, so the index lists agree by construction and not by the luck of two maths libraries.
 __device__ __forceinline__ bool cat_source(const CatGeomParams& p, const CatSnap& sn, int64_t i, double& l, double& m, double& n) {
 #pragma clang fp contract(off)
-  constexpr double kPi = 3.141592653589793238462643383279502884;
-  constexpr double kD2R = kPi / 180.0, kR2D = 180.0 / kPi;          // numpy.radians / numpy.degrees multiply by these constants
-  double alt_deg, az_deg;
-  if (p.coords == PRISIM_CAT_ALTAZ) {
-    alt_deg = p.lon[i];
-    az_deg = p.lat[i];
-  } else {
-    const double ha_deg = p.coords == PRISIM_CAT_RADEC ? sn.lst_deg - p.lon[i] : p.lon[i];      // :6179  lst - RA
-    const double ha = ha_deg * kD2R;
-    const double sd = p.sin_dec[i], cd = p.cos_dec[i];
-    const double ch = cos(ha), sh = sin(ha);
-    double sin_alt = sd * p.sin_lat + cd * p.cos_lat * ch;
-    sin_alt = sin_alt < -1.0 ? -1.0 : (sin_alt > 1.0 ? 1.0 : sin_alt);
-    const double alt = asin(sin_alt);
-    const double east = -cd * sh;
-    const double north = sd * p.cos_lat - cd * p.sin_lat * ch;
-    double az = atan2(east, north);
-    if (az < 0.0) az = az + 2.0 * kPi;
-    alt_deg = alt * kR2D;
-    az_deg = az * kR2D;
-  }
-  const double alt_r = alt_deg * kD2R, az_r = az_deg * kD2R;      // altaz2dircos(units='degrees')
-  const double ca = cos(alt_r);
-  l = ca * sin(az_r);
-  m = ca * cos(az_r);
-  n = sin(alt_r);
-  if (p.roi_center == 0) return alt_deg >= p.alt_min_deg;
-  double cosd = l * sn.roi_pc[0] + m * sn.roi_pc[1] + n * sn.roi_pc[2];
-  cosd = cosd < -1.0 ? -1.0 : (cosd > 1.0 ? 1.0 : cosd);
-  return acos(cosd) * kR2D <= p.roi_radius_deg;
+  const double t0 = p.ux[i] + sn.beta[0], t1 = p.uy[i] + sn.beta[1], t2 = p.uz[i] + sn.beta[2];
+  const double v0 = (sn.rot[0] * t0 + sn.rot[1] * t1) + sn.rot[2] * t2;
+  const double v1 = (sn.rot[3] * t0 + sn.rot[4] * t1) + sn.rot[5] * t2;
+  const double v2 = (sn.rot[6] * t0 + sn.rot[7] * t1) + sn.rot[8] * t2;
+  const double nrm = sqrt((v0 * v0 + v1 * v1) + v2 * v2);
+  l = v0 / nrm;
+  m = v1 / nrm;
+  n = v2 / nrm;
+  if (p.roi_center == 0) return n >= p.sin_alt_min;
+  const double cosd = (l * sn.roi_pc[0] + m * sn.roi_pc[1]) + n * sn.roi_pc[2];
+  return cosd >= p.cos_radius;
 }
 
-// sin / cos of the declinations, once per catalogue
-__global__ void k_cat_prepare(const double* __restrict__ dec_deg, double* __restrict__ sd, double* __restrict__ cd, int64_t n) {
+// unit vectors of a catalogue given as (longitude, latitude) degrees, once per catalogue (a caller that wants the host's bits passes
+// prisim_catalog.unitvec instead: sin / cos of two maths libraries may differ in the last place)
+__global__ void k_cat_prepare(const double* __restrict__ lon_deg, const double* __restrict__ lat_deg, int coords, double* __restrict__ ux,
+                              double* __restrict__ uy, double* __restrict__ uz, int64_t n) {
 #pragma clang fp contract(off)
   constexpr double kD2R = 3.141592653589793238462643383279502884 / 180.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double d = dec_deg[i] * kD2R;
-    sd[i] = sin(d);
-    cd[i] = cos(d);
+    const double a = lon_deg[i] * kD2R, d = lat_deg[i] * kD2R;
+    if (coords == PRISIM_CAT_ALTAZ) {           // (alt, az): East-North-Up direction cosines, geometry.altaz2dircos
+      const double ca = cos(a);
+      ux[i] = ca * sin(d);
+      uy[i] = ca * cos(d);
+      uz[i] = sin(a);
+    } else {
+      const double cd = cos(d);
+      ux[i] = cd * cos(a);
+      uy[i] = cd * sin(a);
+      uz[i] = sin(d);
+    }
   }
 }
 
@@ -242,9 +238,9 @@ static unsigned grid1d(int64_t n) {
   return (unsigned)g;
 }
 
-hipError_t launch_cat_prepare(const double* dec_deg, double* sd, double* cd, int64_t n, hipStream_t stream) {
+hipError_t launch_cat_prepare(const double* lon_deg, const double* lat_deg, int coords, double* ux, double* uy, double* uz, int64_t n, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_cat_prepare, dim3(grid1d(n)), dim3(256), 0, stream, dec_deg, sd, cd, n);
+  hipLaunchKernelGGL(k_cat_prepare, dim3(grid1d(n)), dim3(256), 0, stream, lon_deg, lat_deg, coords, ux, uy, uz, n);
   return hipGetLastError();
 }
 

@@ -168,7 +168,7 @@ struct prisim_ctx {
     bool have_shape = false, have_spec = false;
     double ref_freq = 1.0;
     double kappa_max = 0.0;
-    DevBuf lon, lat, sin_dec, cos_dec, kappa, run_id, flux_ref, spindex, spec;
+    DevBuf lon, lat, ux, uy, uz, kappa, run_id, flux_ref, spindex, spec;      // lon / lat: staging of `location` for k_cat_prepare
     struct Run { int64_t lo, hi; double kappa; };
     std::vector<Run> runs;              // runs of one source size in catalogue order (<= 8); empty: no shapes, or sizes vary source by source
     // geometry outputs.  Sets 0 / 1 alternate so that the geometry of the next snapshot (or chunk of snapshots) runs on the geometry

@@ -164,7 +164,8 @@ hipError_t launch_extbeam_sky_batch(const double* table, int nside, const double
 static constexpr int PRISIM_CAT_RADEC = 0, PRISIM_CAT_HADEC = 1, PRISIM_CAT_ALTAZ = 2;     // = PRISIM_COORDS_* of the public header
 static constexpr int PRISIM_CAT_MAX_RUNS = 8;
 struct CatSnap {             // per-snapshot inputs (device array, one entry per snapshot of a batch)
-  double lst_deg;
+  double rot[9];             // catalogue frame -> local East-North-Up, row-major (prisim_snapshot.cel2enu, or built from lst / latitude)
+  double beta[3];            // aberration vector in the catalogue frame (observer velocity / c; zeros = none)
   double roi_pc[3];          // centre of the region of interest (roi_center = pointing centre)
   double pc[3];              // phase centre (for max |s - s_pc|)
 };
@@ -174,21 +175,17 @@ struct CatOut {              // per-snapshot results the host reads back (pinned
   uint64_t dmax2_bits;       // max |s - s_pc|^2, bit pattern of a non-negative double
 };
 struct CatGeomParams {
-  const double* lon;         // [n] RA | HA | alt, degrees
-  const double* lat;         // [n] Dec | Dec | az
-  const double* sin_dec;     // [n] sin / cos of the declination (RA-Dec, HA-Dec catalogues)
-  const double* cos_dec;
+  const double* ux;          // [n] catalogue unit vectors in the catalogue's own frame (RA-Dec / HA-Dec: cos d cos a, cos d sin a, sin d;
+  const double* uy;          //     alt-az: East-North-Up direction cosines)
+  const double* uz;
   const double* kappa;       // [n] ln2 (2 sin(fwhm/2))^2, or nullptr (no source shapes)
   const uint8_t* run_id;     // [n] catalogue run of every source (runs of one source size), or nullptr
   int64_t n;
   int64_t nblocks;           // ceil(n / 256)
-  int32_t coords;            // PRISIM_CAT_*
   int32_t roi_center;        // 0 zenith, 1 pointing centre
   int32_t want_keys;         // also write the altitude keys of the culling order
-  int32_t pad_;
-  double sin_lat, cos_lat;
-  double alt_min_deg;        // 90 - roi_radius
-  double roi_radius_deg;
+  double sin_alt_min;        // sin(90 - roi_radius): 'zenith' keeps n >= this         (interferometry.py:6216)
+  double cos_radius;         // cos(roi_radius): 'pointing_center' keeps s . s_pc >= this  (:6211)
   const CatSnap* snaps;      // [nsnap] device
   int32_t* block_off;        // [nsnap][nblocks] scratch
   int32_t* idx;              // [nsnap][n] compacted catalogue indices (catalogue order)
@@ -210,7 +207,7 @@ struct CullParams {
   uint64_t* culled;          // [2] skipped (source, baseline) pairs per precision
 };
 int64_t cat_blocks(int64_t n);
-hipError_t launch_cat_prepare(const double* dec_deg, double* sd, double* cd, int64_t n, hipStream_t stream);
+hipError_t launch_cat_prepare(const double* lon_deg, const double* lat_deg, int coords, double* ux, double* uy, double* uz, int64_t n, hipStream_t stream);
 hipError_t launch_cat_geometry(const CatGeomParams& p, int nsnap, hipStream_t stream);
 size_t cat_sort_temp_bytes(int64_t n);
 hipError_t launch_cat_sort(void* temp, size_t temp_bytes, const uint32_t* keys, uint32_t* keys_out, const uint32_t* pos, uint32_t* perm,

@@ -87,6 +87,55 @@ def altaz2hadec(altaz, latitude, units='degrees'):
     return out[0] if squeeze else out
 
 
+def catalog_unitvec(location, coords):
+    """Unit vectors (nsrc, 3) of a catalogue in ITS OWN frame -- what prisim_catalog.unitvec carries (include/prisim_hip.h):
+    'radec' (cos d cos a, cos d sin a, sin d);  'hadec' the same with the hour angle for a;  'altaz' East-North-Up direction cosines
+    (altaz2dircos).  The snapshot's frame (prisim_amd/frames.py snapshot_frame) takes them to the local East-North-Up frame."""
+    loc = NP.asarray(location, dtype=NP.float64).reshape(-1, 2)
+    if coords == 'altaz':
+        return altaz2dircos(loc, 'degrees')
+    if coords not in ('radec', 'hadec'):
+        raise ValueError('coords must be "radec", "hadec" or "altaz"')
+    lon, lat = NP.radians(loc[:, 0]), NP.radians(loc[:, 1])
+    cd = NP.cos(lat)
+    return NP.stack((cd * NP.cos(lon), cd * NP.sin(lon), NP.sin(lat)), axis=1)
+
+
+def frame_dircos(unitvec, rot, beta):
+    """East-North-Up direction cosines s = normalise(R (u + beta)) of catalogue unit vectors u (nsrc, 3) for one snapshot's frame
+    (R (3, 3), beta (3,)) -- the host statement of cat_source() in prisim_amd/csrc/catalog_kernels.hip.  Written operation by operation
+    (no dot products, whose BLAS kernels may fuse multiply-adds) in the order the device uses with contraction off: +, *, sqrt and /
+    are correctly rounded on both sides, so host and device agree to the last bit and select the same region of interest."""
+    u = NP.asarray(unitvec, dtype=NP.float64).reshape(-1, 3)
+    r = NP.asarray(rot, dtype=NP.float64).reshape(3, 3)
+    b = NP.asarray(beta, dtype=NP.float64).reshape(3)
+    t0, t1, t2 = u[:, 0] + b[0], u[:, 1] + b[1], u[:, 2] + b[2]
+    v0 = (r[0, 0] * t0 + r[0, 1] * t1) + r[0, 2] * t2
+    v1 = (r[1, 0] * t0 + r[1, 1] * t1) + r[1, 2] * t2
+    v2 = (r[2, 0] * t0 + r[2, 1] * t1) + r[2, 2] * t2
+    nrm = NP.sqrt((v0 * v0 + v1 * v1) + v2 * v2)
+    return NP.stack((v0 / nrm, v1 / nrm, v2 / nrm), axis=1)
+
+
+def roi_thresholds(roi_radius_deg):
+    """(sin(90 - roi_radius), cos(roi_radius)): the region-of-interest tests on direction cosines -- 'zenith' keeps n >= the first
+    (altitude >= 90 - roi_radius, interferometry.py:6216), 'pointing_center' keeps s . s_pc >= the second (angle <= roi_radius, :6211).
+    math.sin / math.cos (the C library's, as libprisim_hip.so's host code uses) so that both sides hold the same two numbers."""
+    import math
+    return math.sin(math.radians(90.0 - float(roi_radius_deg))), math.cos(math.radians(float(roi_radius_deg)))
+
+
+def roi_select(dircos, roi_center, roi_radius_deg, pc_dircos=None):
+    """Indices of the sources inside the region of interest (interferometry.py:6204-6216) from their direction cosines."""
+    sin_alt_min, cos_radius = roi_thresholds(roi_radius_deg)
+    dc = NP.asarray(dircos, dtype=NP.float64).reshape(-1, 3)
+    if roi_center == 'pointing_center':
+        pc = NP.asarray(pc_dircos, dtype=NP.float64).reshape(3)
+        cosd = (dc[:, 0] * pc[0] + dc[:, 1] * pc[1]) + dc[:, 2] * pc[2]
+        return NP.where(cosd >= cos_radius)[0]
+    return NP.where(dc[:, 2] >= sin_alt_min)[0]
+
+
 # ---- HEALPix (RING) pixel centres: healpy is not available, so this is a from-the-paper
 # implementation (Gorski et al. 2005, eqs. 2-9) of pix2ang for the RING scheme. ---------------
 

@@ -17,8 +17,12 @@ Differences kept on purpose:
       all-fp32 phase); results are complex64 like the reference's.
   Q7  the visibility cube is grown without O(nt^2) recopy; same logical shape (nbl, nchan, n_acc).
   Q20 delay_transform transforms whichever of the three cubes exist.
-  sky coordinates 'radec' are converted with HA = LST - RA (no precession / nutation / aberration;
-  astropy's FK5->AltAz is outside the boundary, SURVEY.md 7 "Hard parts").
+  sky coordinates 'radec': the reference's astropy chain FK5(skymodel.epoch) -> FK5(obstime) -> AltAz (:6174-6180) is ONE rotation and
+      ONE aberration vector per snapshot, applied on the device (prisim_snapshot.cel2enu / aberr_beta).  Without astropy they come from
+      prisim_amd/frames.py: IAU 2006 precession + truncated IAU 1980 nutation + annual aberration + rotation by the apparent LST
+      (``frame_model = 'apparent'``, the default; 'mean' = precession only; 'date' = none, HA = LST - RA).  Not modelled: frame bias,
+      light deflection, diurnal aberration, polar motion (< 1 arcsec together; parity with astropy unpinned).  A caller with astropy sets
+      ``frame_provider`` and reproduces the reference's frame exactly.
 Out of scope here: gain tables, FITS persistence, uvfits / uvh5.
 """
 import os
@@ -28,6 +32,7 @@ import numpy as NP
 
 from . import _abi
 from . import baseline_delay_horizon as DLY
+from . import frames as FRAMES
 from . import geometry as GEOM
 from . import primary_beams as PB
 
@@ -139,8 +144,9 @@ class _CatalogROI(object):
     they are read (prisim_hip_catalog_roi forms that snapshot's region of interest again; it is deterministic).  ``size`` / ``len``
     are known from the snapshot's own read-back.  Behaves like the int64 array the reference stores."""
 
-    def __init__(self, owner, obs, lst, pc_dircos, size):
+    def __init__(self, owner, obs, lst, pc_dircos, size, frame=None):
         self._owner, self._obs, self._lst, self._pc = owner, obs, float(lst), NP.array(pc_dircos, dtype=NP.float64)
+        self._frame = frame
         self.size = int(size)
         self.shape = (self.size,)
         self.ndim = 1
@@ -149,7 +155,7 @@ class _CatalogROI(object):
 
     def fetch(self):
         if self._idx is None:
-            self._idx, self._dc = self._owner._ctx.catalog_roi(self._obs, self._lst, self._pc)
+            self._idx, self._dc = self._owner._ctx.catalog_roi(self._obs, self._lst, self._pc, frame=self._frame)
             self._owner = self._obs = None
         return self._idx
 
@@ -185,6 +191,20 @@ class LazyGeometricDelays(object):
         dc = self._dc.dircos() if isinstance(self._dc, _CatalogROI) else self._dc
         out = DLY.geometric_delay(self._bl, dc, altaz=False, hadec=False, dircos=True).astype(self._dtype)
         return out if dtype is None else out.astype(dtype)
+
+
+_DIGEST_W = {}
+
+
+def _digest_weights(n):
+    """Fixed pseudo-random weights in [1, 2) for the content digest of the resident catalogue (a plain sum would miss a permutation and
+    two edits that cancel); one vector per size, kept."""
+    w = _DIGEST_W.get(n)
+    if w is None:
+        if len(_DIGEST_W) > 16:
+            _DIGEST_W.clear()
+        w = _DIGEST_W[n] = 1.0 + NP.random.default_rng(12345).random(n)
+    return w
 
 
 def _available_host_bytes():
@@ -227,6 +247,11 @@ class InterferometerArray(object):
     bp, bp_wts, Tsys, Tsysinfo, pointing_center, phase_center, geometric_delays, obs_catalog_indices,
     skyvis_freq, gradient, gradient_mode, timestamp, t_acc, t_obs, n_acc, lst.
     """
+
+    # Astrometric model of skycoords 'radec' (module docstring; prisim_amd/frames.py): 'apparent' | 'mean' | 'date', and an optional
+    # callable (jd, lst_deg, skymodel) -> (R (3, 3), beta (3,)) that replaces it (e.g. filled from astropy, INTEGRATION.md 2b)
+    frame_model = os.environ.get('PRISIM_FRAME_MODEL', 'apparent')
+    frame_provider = None
 
     def __init__(self, labels, baselines, channels, telescope=None, eff_Q=0.89,
                  latitude=34.0790, longitude=0.0, altitude=0.0, skycoords='radec',
@@ -779,12 +804,33 @@ class InterferometerArray(object):
     # hadec -> altaz -> dircos, region of interest, flux spectra and beam x flux are formed on the GPU.
 
     def _catalog_fingerprint(self, skymodel):
-        loc = skymodel.location
-        shape = getattr(skymodel, 'src_shape', None)
-        # identity of the object and of its arrays, plus a cheap content check of the positions (an in-place edit of the catalogue)
-        return (id(skymodel), id(loc), getattr(loc, 'shape', None), float(NP.sum(loc)), self.skycoords, getattr(skymodel, 'spec_type', None),
-                id(getattr(skymodel, 'flux_ref', None)), id(getattr(skymodel, 'spindex', None)), id(getattr(skymodel, 'spectrum', None)),
-                None if shape is None else id(shape), self.channels.size, float(self.channels[0]), self._reserved)
+        """What decides whether the catalogue resident on the device still IS this sky model: identity of the object and the CONTENT of
+        everything that was uploaded (an in-place edit -- ``skymodel.flux_ref *= 2`` between two observe() calls, a Monte-Carlo loop over
+        realisations -- must be seen; the reference re-reads the sky model at every call).  One pass of sums over the nsrc-sized vectors
+        (a microsecond or two per 1e4 sources each) and over a strided sample of a spectrum table."""
+        def digest(a, sample=False):
+            if a is None:
+                return None
+            a = NP.asarray(a)
+            if a.dtype.kind not in 'fiu':
+                return (a.shape, str(a.dtype))
+            flat = a.reshape(-1)
+            if sample and flat.size > (1 << 20):          # a spectrum table: 65536 evenly spaced samples (plus the shape) instead of gigabytes
+                flat = flat[::flat.size // (1 << 16)]
+            w = _digest_weights(flat.size)
+            return (a.shape, float(NP.dot(flat, w)))
+        return (id(skymodel), self.skycoords, getattr(skymodel, 'spec_type', None), digest(skymodel.location),
+                digest(getattr(skymodel, 'flux_ref', None)), digest(getattr(skymodel, 'spindex', None)),
+                None if getattr(skymodel, 'ref_freq', None) is None else float(NP.sum(skymodel.ref_freq)),
+                digest(getattr(skymodel, 'spectrum', None), sample=True), digest(getattr(skymodel, 'frequency', None)),
+                digest(getattr(skymodel, 'src_shape', None)), self.channels.size, float(self.channels[0]), float(self.channels[-1]),
+                self._reserved)
+
+    def invalidate_catalog(self):
+        """Forget the sky model resident on the device: the next observe() uploads it again (for edits the fingerprint cannot see,
+        e.g. a custom generate_spectrum whose parameters changed)."""
+        self._materialise_catalog_state()
+        self._catalog_key = None
 
     def _catalog_ready(self, skymodel):
         """True when `skymodel` is (now) the catalogue resident on the device.  PRISIM_CATALOG=0 switches the path off (A/B: every
@@ -794,6 +840,8 @@ class InterferometerArray(object):
         key = self._catalog_fingerprint(skymodel)
         if getattr(self, '_catalog_key', None) == key:
             return True
+        if getattr(self, '_catalog_refused', None) == id(skymodel):
+            return False                               # this sky model ran out of device memory on the resident path (observe())
         self._materialise_catalog_state()              # lazy class state of the previous catalogue is fetched while it is still there
         location = NP.asarray(skymodel.location, dtype=NP.float64).reshape(-1, 2)
         nsrc, nchan = location.shape[0], self.channels.size
@@ -803,15 +851,20 @@ class InterferometerArray(object):
             src_shape = NP.asarray(src_shape, dtype=NP.float64)
             fwhm = NP.sqrt(src_shape[:, 0] * src_shape[:, 1])
         powerlaw = (getattr(skymodel, 'spec_type', None) == 'func' and all(hasattr(skymodel, a) for a in ('flux_ref', 'spindex', 'ref_freq')))
-        if powerlaw:
-            self._ctx.set_catalog(location, self.skycoords, flux_ref=skymodel.flux_ref, spindex=skymodel.spindex, ref_freq_hz=float(skymodel.ref_freq),
-                                  fwhm_deg=fwhm)
-        else:
-            if nsrc * nchan * 8 > (16 << 30):
-                return False                           # a spectrum table this large stays on the per-snapshot path (ROI rows only)
-            spectra = NP.asarray(skymodel.generate_spectrum(ind=NP.arange(nsrc), frequency=self.channels, interp_method='pchip'),
-                                 dtype=NP.float64).reshape(-1, nchan)                  # :6249, once for the whole catalogue
-            self._ctx.set_catalog(location, self.skycoords, flux_spectrum=spectra, fwhm_deg=fwhm)
+        try:
+            if powerlaw:
+                self._ctx.set_catalog(location, self.skycoords, flux_ref=skymodel.flux_ref, spindex=skymodel.spindex,
+                                      ref_freq_hz=float(skymodel.ref_freq), fwhm_deg=fwhm)
+            else:
+                if nsrc * nchan * 8 > (16 << 30):
+                    return False                       # a spectrum table this large stays on the per-snapshot path (ROI rows only)
+                spectra = NP.asarray(skymodel.generate_spectrum(ind=NP.arange(nsrc), frequency=self.channels, interp_method='pchip'),
+                                     dtype=NP.float64).reshape(-1, nchan)              # :6249, once for the whole catalogue
+                self._ctx.set_catalog(location, self.skycoords, flux_spectrum=spectra, fwhm_deg=fwhm)
+        except MemoryError:
+            warnings.warn('the sky model does not fit on the device as a resident catalogue; it takes the per-snapshot upload path')
+            self._catalog_refused = id(skymodel)
+            return False
         self._catalog_key = key
         self._catalog_obs_cache = None
         return True
@@ -852,6 +905,20 @@ class InterferometerArray(object):
             if isinstance(entry, _CatalogROI):
                 entry.fetch()
         self._catalog_key = None
+
+    def _snapshot_frame(self, jd, lst, skymodel):
+        """(R, beta) of one snapshot: catalogue frame of `skymodel` -> local East, North, Up (interferometry.py:6174-6180; prisim_amd/frames.py).
+        The same pair goes to the device (prisim_snapshot.cel2enu / aberr_beta) and to the host path (geometry.frame_dircos)."""
+        if self.frame_provider is not None and self.skycoords == 'radec':
+            rot, beta = self.frame_provider(jd, lst, skymodel)
+            return NP.asarray(rot, dtype=NP.float64).reshape(3, 3), NP.asarray(beta, dtype=NP.float64).reshape(3)
+        key = (self.skycoords, float(lst), float(self.latitude), float(jd), getattr(skymodel, 'epoch', None), self.frame_model)
+        cache = getattr(self, '_frame_cache', None)
+        if cache is None or cache[0] != key:
+            cache = (key, FRAMES.snapshot_frame(self.skycoords, lst, self.latitude, jd=jd, epoch=getattr(skymodel, 'epoch', None),
+                                                model=self.frame_model))
+            self._frame_cache = cache
+        return cache[1]
 
     def _check_gradient_mode(self, gradient_mode):
         if gradient_mode is not None:                                                 # :6306-6311
@@ -936,14 +1003,27 @@ class InterferometerArray(object):
         prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
         slot = self.n_acc if self.n_acc < self._reserved else 0
 
+        frame = self._snapshot_frame(jd, lst, skymodel)                               # :6174-6180 as one rotation + aberration vector
         if roi_info is None and self._catalog_ready(skymodel):
             # ---- the sky model is resident on the device: geometry, ROI, spectra, beam x flux and the sky-sum in ONE call ----
             roi_radius, roi_center = self._roi_defaults(roi_radius, roi_center)
             obs, bpc = self._catalog_obs(pb_info, pc_altaz, roi_radius, roi_center)
             if slot != self.n_acc:
                 self._unpark(slot)
-            nroi = int(self._ctx.observe_catalog(obs, [lst], pc_dircos, bpc, precision=prec, want_grad=want_grad, slot0=slot)[0])
-            roi = _CatalogROI(self, obs, lst, pc_dircos, nroi)
+            try:
+                nroi = int(self._ctx.observe_catalog(obs, [lst], pc_dircos, bpc, precision=prec, want_grad=want_grad, slot0=slot,
+                                                     frames=[frame])[0])
+            except MemoryError:
+                # the resident path sizes its beam x flux for a whole chunk of snapshots; a catalogue that ran through the per-snapshot
+                # upload before must still run: drop the resident copy and take that path (ROI rows only)
+                warnings.warn('device memory exhausted on the resident-catalogue path; this sky model continues on the per-snapshot upload path')
+                self._catalog_refused = id(skymodel)
+                self._materialise_catalog_state()
+                nroi = None
+            roi = None if nroi is None else _CatalogROI(self, obs, lst, pc_dircos, nroi, frame)
+        else:
+            roi = None
+        if roi is not None:
             if nroi == 0:                                                             # :6378-6382 (the device slot holds zeros)
                 warnings.warn('No sources found in the catalog within matching radius. Simply populating the observed visibilities and/or gradients with noise.')
             self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(self._baselines_local(), roi,
@@ -951,7 +1031,7 @@ class InterferometerArray(object):
             self.obs_catalog_indices = self.obs_catalog_indices + [roi]               # :6377
             have_sky = True
         else:
-            have_sky = self._upload_snapshot_sky(skymodel, lst, pc_altaz, pc_dircos, pb_info, roi_info, roi_radius, roi_center, memsave)
+            have_sky = self._upload_snapshot_sky(skymodel, frame, pc_altaz, pc_dircos, pb_info, roi_info, roi_radius, roi_center, memsave)
             if have_sky:
                 if slot != self.n_acc:                                   # (a fresh reserved slot holds nothing: no O(n_acc) scan per snapshot)
                     self._unpark(slot)
@@ -1030,25 +1110,48 @@ class InterferometerArray(object):
         roi_radius, roi_center = self._roi_defaults(roi_radius, roi_center)
         datatype = NP.complex64 if memsave else NP.complex128
         prec = _abi.PRISIM_FP32 if memsave else _abi.PRISIM_FP64
-        jds, lsts, pc_dcs, bpcs, obs = [], [], [], [], None
-        for t in range(k):
-            self._stack_bandpass(bp_l[t])
-            self._stack_tsys(tsys_l[t], bpcorrect)
-            jd, lst = _lst_and_jd(timeobjs[t], None)
-            pc_altaz, pc_dircos = self._append_pointing(pcs[t], lst)
-            self.timestamp = self.timestamp + [jd]                                    # :6395-6399 (the pointing list grows with it)
-            o, bpc = self._catalog_obs(None, pc_altaz, roi_radius, roi_center)
-            obs = o if obs is None else obs
-            if o is not obs:
-                raise RuntimeError('the beam specification changed inside a batch')
-            jds.append(jd); lsts.append(lst); pc_dcs.append(pc_dircos); bpcs.append(pc_dircos if bpc is None else bpc)
-        slot0 = self.n_acc
-        host_cube = self._ensure_host_cube(datatype) if getattr(self, '_stage', False) else None
-        counts = self._ctx.observe_catalog(obs, lsts, NP.asarray(pc_dcs), NP.asarray(bpcs), precision=prec, want_grad=want_grad, slot0=slot0,
-                                           host_cube=host_cube)
+        # The per-snapshot class state grown before the device call (timestamp, pointing / phase centre rows, bandpass and Tsys layers) is
+        # rolled back if anything fails -- a changed beam specification, a device error -- so that the instance stays aligned with n_acc.
+        state0 = (self.pointing_center, self.phase_center, getattr(self, '_pointing_cache', None), self.timestamp, list(self.Tsysinfo),
+                  dict(self._stacks), {n: (None if st is None else list(st.layers)) for n, st in self._stacks.items()}, dict(self._dense))
+        jds, lsts, pc_dcs, bpcs, frames, obs = [], [], [], [], [], None
+        try:
+            for t in range(k):
+                self._stack_bandpass(bp_l[t])
+                self._stack_tsys(tsys_l[t], bpcorrect)
+                jd, lst = _lst_and_jd(timeobjs[t], None)
+                pc_altaz, pc_dircos = self._append_pointing(pcs[t], lst)
+                self.timestamp = self.timestamp + [jd]                                # (_append_pointing starts a fresh array on an empty list)
+                o, bpc = self._catalog_obs(None, pc_altaz, roi_radius, roi_center)
+                obs = o if obs is None else obs
+                if o is not obs:
+                    raise RuntimeError('the beam specification changed inside a batch')
+                jds.append(jd); lsts.append(lst); pc_dcs.append(pc_dircos); bpcs.append(pc_dircos if bpc is None else bpc)
+                frames.append(self._snapshot_frame(jd, lst, skymodel))
+            slot0 = self.n_acc
+            host_cube = self._ensure_host_cube(datatype) if getattr(self, '_stage', False) else None
+            counts = self._ctx.observe_catalog(obs, lsts, NP.asarray(pc_dcs), NP.asarray(bpcs), precision=prec, want_grad=want_grad, slot0=slot0,
+                                               host_cube=host_cube, frames=frames)
+        except Exception as exc:
+            self.pointing_center, self.phase_center, self._pointing_cache, self.timestamp, self.Tsysinfo, stacks, layers, dense = state0
+            self._stacks = stacks
+            for n, st in stacks.items():
+                if st is not None:
+                    st.layers = layers[n]
+            self._dense = dense
+            if not isinstance(exc, MemoryError):
+                raise
+            # the resident path ran out of device memory: this sky model continues on the per-snapshot upload path (ROI rows only)
+            warnings.warn('device memory exhausted on the resident-catalogue path; this sky model continues on the per-snapshot upload path')
+            self._catalog_refused = id(skymodel)
+            self._materialise_catalog_state()
+            for t in range(k):
+                self.observe(timeobjs[t], tsys_l[t], bp_l[t], pcs[t], skymodel, float(tacc_l[t]), pb_info=pb_info, bpcorrect=bpcorrect,
+                             roi_radius=roi_radius, roi_center=roi_center, gradient_mode=gradient_mode, memsave=memsave)
+            return
         base_bl = self._baselines_local()
         for t in range(k):
-            roi = _CatalogROI(self, obs, lsts[t], pc_dcs[t], int(counts[t]))
+            roi = _CatalogROI(self, obs, lsts[t], pc_dcs[t], int(counts[t]), frames[t])
             if counts[t] == 0:
                 warnings.warn('No sources found in the catalog within matching radius. Simply populating the observed visibilities and/or gradients with noise.')
             self.geometric_delays = self.geometric_delays + [LazyGeometricDelays(base_bl, roi, NP.float32 if memsave else NP.float64)]
@@ -1069,18 +1172,14 @@ class InterferometerArray(object):
                 self.gradient = _LazyGradients(self)
             self.gradient.invalidate(gradient_mode)
 
-    def _upload_snapshot_sky(self, skymodel, lst, pc_altaz, pc_dircos, pb_info, roi_info, roi_radius, roi_center, memsave):
+    def _upload_snapshot_sky(self, skymodel, frame, pc_altaz, pc_dircos, pb_info, roi_info, roi_radius, roi_center, memsave):
         """The snapshot's sky formed on the HOST and uploaded (roi_info given, PRISIM_CATALOG=0, or a spectrum table too large to keep
-        resident): interferometry.py:6171-6283 statement by statement.  Returns False when the region of interest is empty."""
+        resident): interferometry.py:6171-6283 statement by statement, with the astropy / GEOM coordinate chain of :6174-6180 as the
+        snapshot's frame (R, beta) applied by geometry.frame_dircos -- the host statement of the device's cat_source().  Returns False when
+        the region of interest is empty."""
         nchan = self.channels.size
         location = NP.asarray(skymodel.location, dtype=NP.float64).reshape(-1, 2)
-        if self.skycoords == 'hadec':                                                 # :6176-6180
-            skypos_altaz = GEOM.hadec2altaz(location, self.latitude, units='degrees')
-        elif self.skycoords == 'radec':
-            hadec = NP.stack((lst - location[:, 0], location[:, 1]), axis=1)
-            skypos_altaz = GEOM.hadec2altaz(hadec, self.latitude, units='degrees')
-        else:
-            skypos_altaz = location
+        dc_all = GEOM.frame_dircos(GEOM.catalog_unitvec(location, self.skycoords), frame[0], frame[1])     # :6174-6180, 6263
         pb = None
         if roi_info is not None:                                                      # :6189-6202
             if ('ind' not in roi_info) or ('pbeam' not in roi_info):
@@ -1097,17 +1196,10 @@ class InterferometerArray(object):
                         raise ValueError('Values in keys ind and pbeam in must carry same number of elements.')
         else:                                                                         # :6204-6216
             roi_radius, roi_center = self._roi_defaults(roi_radius, roi_center)
-            if roi_center == 'pointing_center':
-                dc_all = GEOM.altaz2dircos(skypos_altaz, 'degrees')
-                cosd = NP.clip(NP.dot(dc_all, pc_dircos), -1.0, 1.0)
-                m2 = NP.where(NP.degrees(NP.arccos(cosd)) <= roi_radius)[0]
-            else:
-                m2 = NP.arange(skypos_altaz.shape[0])
-                m2 = m2[NP.where(skypos_altaz[:, 0] >= 90.0 - roi_radius)]
+            m2 = GEOM.roi_select(dc_all, roi_center, roi_radius, pc_dircos)       # :6210-6216 on the direction cosines
         if len(m2) == 0:
             return False
-        skypos_altaz_roi = skypos_altaz[m2, :]                                    # :6219
-        dircos_roi = GEOM.altaz2dircos(skypos_altaz_roi, 'degrees')               # :6263 (unconditional, Q4)
+        dircos_roi = dc_all[m2, :]                                                # :6219, 6263 (unconditional, Q4)
         # flux spectra (:6249).  A power-law sky model (spec_type 'func') is described to the device by its nsrc-sized
         # flux_ref / spindex vectors and S = flux_ref (f / ref_freq)^spindex is formed there; anything else goes through
         # generate_spectrum on the host, as in the reference.
@@ -1132,7 +1224,7 @@ class InterferometerArray(object):
         # and those are the sources nearest the zenith (long baselines resolve them out: b_perp ~ |b|).  So when anything can be
         # culled at all -- kappa_max (|b|_max f_min / c)^2 >= 18 -- each run is listed by decreasing altitude.  Class state
         # (obs_catalog_indices, geometric_delays) keeps the catalog order.
-        up = self._cull_order(skypos_altaz_roi[:, 0], fwhm)
+        up = self._cull_order(dircos_roi[:, 2], fwhm)                             # (n = sin(altitude): the same order)
         dircos_up = dircos_roi
         if up is not None:
             dircos_up, fwhm = dircos_roi[up], fwhm[up]

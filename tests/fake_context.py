@@ -60,8 +60,8 @@ class OracleContext(object):
         self.pc = NP.asarray(pc_dircos, dtype=NP.float64).ravel()
         self.fwhm = None if fwhm_deg is None else NP.asarray(fwhm_deg, dtype=NP.float64)
 
-    # ---- device-resident catalogue (ABI 0.4): the host statements the device kernels restate (prisim_amd/geometry.py) ----
-    def set_catalog(self, location, coords, flux_ref=None, spindex=None, ref_freq_hz=None, flux_spectrum=None, fwhm_deg=None):
+    # ---- device-resident catalogue (ABI 0.5): the host statements the device kernels restate (prisim_amd/geometry.py) ----
+    def set_catalog(self, location, coords, flux_ref=None, spindex=None, ref_freq_hz=None, flux_spectrum=None, fwhm_deg=None, unitvec='host'):
         self._cat = {'loc': NP.asarray(location, dtype=NP.float64).reshape(-1, 2), 'coords': coords,
                      'flux_ref': None if flux_ref is None else NP.asarray(flux_ref, dtype=NP.float64),
                      'spindex': None if spindex is None else NP.asarray(spindex, dtype=NP.float64), 'ref_freq': ref_freq_hz,
@@ -77,30 +77,25 @@ class OracleContext(object):
         # (beam extensions are ignored, like set_sky_analytic of this stand-in does)
         return {'lat': float(latitude_deg), 'roi_radius': float(roi_radius_deg), 'roi_center': roi_center, 'kind': beam_kind, 'dia': diameter_m}
 
-    def _roi(self, obs, lst, pc_dircos):
-        from prisim_amd import geometry as GEOM
+    def _roi(self, obs, lst, pc_dircos, frame=None):
+        """geometry.frame_dircos / roi_select: the host statement of cat_source() (catalog_kernels.hip); frame None = the library's
+        fall-back rotation (hour angle = LST - RA)."""
+        from prisim_amd import geometry as GEOM, frames as FR
         cat = self._cat
         if cat is None:
             raise RuntimeError('set_catalog must be called first (set_array drops the catalogue)')
-        loc = cat['loc']
-        if cat['coords'] == 'radec':
-            altaz = GEOM.hadec2altaz(NP.stack((lst - loc[:, 0], loc[:, 1]), axis=1), obs['lat'], units='degrees')
-        elif cat['coords'] == 'hadec':
-            altaz = GEOM.hadec2altaz(loc, obs['lat'], units='degrees')
-        else:
-            altaz = loc
-        if obs['roi_center'] == 'pointing_center':
-            dc_all = GEOM.altaz2dircos(altaz, 'degrees')
-            m2 = NP.where(NP.degrees(NP.arccos(NP.clip(NP.dot(dc_all, pc_dircos), -1.0, 1.0))) <= obs['roi_radius'])[0]
-        else:
-            m2 = NP.arange(altaz.shape[0])[NP.where(altaz[:, 0] >= 90.0 - obs['roi_radius'])]
-        return m2, GEOM.altaz2dircos(altaz[m2], 'degrees')
+        if frame is None:
+            frame = FR.snapshot_frame(cat['coords'], lst, obs['lat'], model='date')
+        dc_all = GEOM.frame_dircos(GEOM.catalog_unitvec(cat['loc'], cat['coords']), frame[0], frame[1])
+        m2 = GEOM.roi_select(dc_all, obs['roi_center'], obs['roi_radius'], pc_dircos)
+        return m2, dc_all[m2]
 
-    def catalog_roi(self, obs, lst_deg, pc_dircos, want_indices=True, want_dircos=True):
-        m2, dc = self._roi(obs, float(lst_deg), NP.asarray(pc_dircos, dtype=NP.float64))
+    def catalog_roi(self, obs, lst_deg, pc_dircos, want_indices=True, want_dircos=True, frame=None):
+        m2, dc = self._roi(obs, float(lst_deg), NP.asarray(pc_dircos, dtype=NP.float64), frame)
         return m2.astype(NP.int64), dc
 
-    def observe_catalog(self, obs, lst_deg, pc_dircos, beam_pc_dircos=None, precision=0, want_grad=False, slot0=0, host_cube=None, gather=None):
+    def observe_catalog(self, obs, lst_deg, pc_dircos, beam_pc_dircos=None, precision=0, want_grad=False, slot0=0, host_cube=None, gather=None,
+                        frames=None):
         lst = NP.asarray(lst_deg, dtype=NP.float64).ravel()
         k = lst.size
         pc = NP.broadcast_to(NP.asarray(pc_dircos, dtype=NP.float64).reshape(-1, 3), (k, 3))
@@ -108,7 +103,7 @@ class OracleContext(object):
         counts = NP.zeros(k, dtype=NP.int64)
         cat = self._cat
         for t in range(k):
-            m2, dc = self._roi(obs, lst[t], pc[t])
+            m2, dc = self._roi(obs, lst[t], pc[t], None if frames is None else frames[t])
             counts[t] = m2.size
             if m2.size == 0:
                 self.cube[slot0 + t] = 0.0

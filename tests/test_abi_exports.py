@@ -49,10 +49,35 @@ def test_struct_layouts_match_header():
     assert _abi.PrisimTiming.last_culled_fraction.offset == 80
     # prisim_comm_stats: 2 int64, 4 double, 4 int32 -> 64 bytes
     assert C.sizeof(_abi.PrisimCommStats) == 64 and _abi.PrisimCommStats.stream_priority.offset == 48
-    # prisim_catalog: int64, 2 int32, 3 ptr, double, 2 ptr -> 64 bytes; prisim_obs: 2 double, 4 int32, double, ptr -> 48; prisim_snapshot: 7 double
-    assert C.sizeof(_abi.PrisimCatalog) == 64 and _abi.PrisimCatalog.location.offset == 16 and _abi.PrisimCatalog.fwhm_deg.offset == 56
+    # prisim_catalog: int64, 2 int32, 3 ptr, double, 3 ptr -> 72 bytes; prisim_obs: 2 double, 4 int32, double, ptr -> 48;
+    # prisim_snapshot: 7 double, 2 int32, 12 double -> 160
+    assert C.sizeof(_abi.PrisimCatalog) == 72 and _abi.PrisimCatalog.location.offset == 16 and _abi.PrisimCatalog.unitvec.offset == 64
     assert C.sizeof(_abi.PrisimObs) == 48 and _abi.PrisimObs.beam_kind.offset == 24 and _abi.PrisimObs.ext.offset == 40
-    assert C.sizeof(_abi.PrisimSnapshot) == 56 and _abi.PrisimSnapshot.beam_pc_dircos.offset == 32
+    assert C.sizeof(_abi.PrisimSnapshot) == 160 and _abi.PrisimSnapshot.frame_given.offset == 56 and _abi.PrisimSnapshot.cel2enu.offset == 64
+
+
+def test_struct_layouts_against_the_compiled_header(tmp_path):
+    """The same by construction: include/prisim_hip.h compiled by gcc reports sizeof / offsetof of every field of every struct, and the
+    ctypes mirrors must agree field by field."""
+    import subprocess
+    pairs = {'prisim_sky': _abi.PrisimSky, 'prisim_beam_ext': _abi.PrisimBeamExt, 'prisim_beam_sky': _abi.PrisimBeamSky,
+             'prisim_catalog': _abi.PrisimCatalog, 'prisim_obs': _abi.PrisimObs, 'prisim_snapshot': _abi.PrisimSnapshot,
+             'prisim_post': _abi.PrisimPost, 'prisim_timing': _abi.PrisimTiming, 'prisim_comm_stats': _abi.PrisimCommStats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "prisim_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('  printf("%s %zu\\n", "{0}", sizeof({0}));'.format(cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s.%s %zu\\n", "{0}", "{1}", offsetof({0}, {1}));'.format(cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[cname + '.' + fname]) == getattr(cls, fname).offset, (cname, fname)
 
 
 def test_every_export_is_guarded_against_cpp_exceptions():

@@ -390,6 +390,7 @@ def test_observing_run_drift():
     lat = -30.7224
     skymod = SM.SkyModel(location=[[10.0, lat], [355.0, lat + 5.0]], flux_ref=[1.0, 2.0], spindex=[0.0, -0.7], ref_freq=150e6)
     ia = RI.InterferometerArray(['a', 'b'], bl, ch, telescope={'shape': 'gaussian', 'size': 14.0}, latitude=lat, skycoords='radec')
+    ia.frame_model = 'date'        # the catalogue is taken to be in the equinox of date: HA = LST - RA, what the oracle lines below write out
     ia.observing_run([0.0, lat], skymod, 60.0, 180.0, ch, NP.ones(16), 100.0, 0.5, mode='drift', verbose=False)
     assert ia.skyvis_freq.shape == (2, 16, 3) and ia.n_acc == 3 and ia.t_obs == 180.0
     assert NP.allclose(ia.lst, (0.5 + 60.0 / 3600 * NP.arange(3)) * 15.0)
@@ -571,6 +572,7 @@ def test_observe_radec_sky_and_roi_selection():
     bl = rng.uniform(-100, 100, (11, 3)); bl[:, 2] = 0
     ia = RI.InterferometerArray(list(range(11)), bl, ch, telescope={'shape': 'dish', 'size': 14.0}, latitude=lat, skycoords='radec',
                                 pointing_coords='radec')
+    ia.frame_model = 'date'        # (catalogue in the equinox of date; the apparent-place frame is tests/test_gpu_catalog.py's)
     pc_radec = [lst - 20.0, lat + 10.0]                    # HA = 20 deg, Dec = lat + 10
     ia.observe((2457000.5, lst), {'Tnet': 100.0}, NP.ones(24), pc_radec, skymod, 10.0, roi_radius=40.0, roi_center='pointing_center')
     altaz = O.hadec2altaz(NP.stack((lst - ra, dec), 1), lat)
@@ -584,6 +586,7 @@ def test_observe_radec_sky_and_roi_selection():
     assert NP.max(NP.abs(ia.skyvis_freq[:, :, 0] - ref) / O.abs_flux_sum(pb)[None, :]) <= 1e-11
     # default region of interest: the visible hemisphere (alt >= 0)
     ia2 = RI.InterferometerArray(list(range(11)), bl, ch, telescope={'shape': 'delta'}, latitude=lat, skycoords='radec', pointing_coords='radec')
+    ia2.frame_model = 'date'
     ia2.observe((2457000.5, lst), {'Tnet': 100.0}, NP.ones(24), pc_radec, skymod, 10.0)
     up = NP.where(altaz[:, 0] >= 0.0)[0]
     assert NP.array_equal(ia2.obs_catalog_indices[0], up)

@@ -278,14 +278,14 @@ def test_bench_quotes_profiled_traffic_only_for_the_running_sources(tmp_path, mo
 
 
 def test_committed_round_profiles_match_the_committed_sources():
-    """The round's rocprofv3 summaries named in profiles/r05_MANIFEST.json (written by tools/profile_all_round5.sh after the last kernel
-    change of the round; r04_MANIFEST.json names round 4's, taken with round 4's sources) were taken with the kernel sources that are
+    """The round's rocprofv3 summaries named in profiles/r06_MANIFEST.json (written by tools/profile_all_round6.sh after the last kernel
+    change of the round; r04 / r05_MANIFEST.json name the earlier rounds', taken with those rounds' sources) were taken with the kernel sources that are
     committed beside them.  Summaries of earlier states of the round
     (A/B evidence) are not in the manifest; bench.py only quotes a summary as this build's traffic when its hash matches anyway."""
     import glob
     import json
     import bench
-    manifest = os.path.join(bench.ROOT, 'profiles', 'r05_MANIFEST.json')
+    manifest = os.path.join(bench.ROOT, 'profiles', 'r06_MANIFEST.json')
     if not os.path.exists(manifest):
         pytest.skip('no profile manifest yet (kernels still changing this round)')
     with open(manifest) as f:
