@@ -540,7 +540,8 @@ def radec_skymodel(cfg, lat, lst0):
     hadec = GEOM.altaz2hadec(sky['altaz'], lat, units='degrees')
     radec = NP.stack(((lst0 - hadec[:, 0]) % 360.0, hadec[:, 1]), axis=1)
     return SM.SkyModel(location=radec, flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
-                       src_shape=(NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1) if cfg['taper'] else None))
+                       src_shape=(NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1) if cfg['taper'] else None),
+                       epoch=None)           # (laid out in the local frame: coordinates of date)
 
 
 def e2e_observe(cfg, n_snap, device, memsave, to_host=False, batch=False):

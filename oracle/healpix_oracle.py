@@ -47,6 +47,7 @@ def get_interp_weights(nside, theta, phi):
     """(pix [4,n], wgt [4,n]) of the bilinear interpolation in the RING scheme (Healpix_Base::get_interpol)."""
     theta = NP.asarray(theta, dtype=NP.float64).ravel()
     phi = NP.mod(NP.asarray(phi, dtype=NP.float64).ravel(), 2 * NP.pi)
+    phi = NP.where(phi >= 2 * NP.pi, phi - 2 * NP.pi, phi)      # (mod of -1e-17 rounds to 2 pi itself: that direction is phi = 0)
     n = theta.size
     npix = 12 * nside * nside
     z = NP.cos(theta)

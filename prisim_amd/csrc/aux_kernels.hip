@@ -293,6 +293,8 @@ void k_extbeam_gather(const double* __restrict__ table, int nside_i, const doubl
       const double theta = acos(z);
       double phi = atan2(d.x, d.y);                     // azimuth from North through East
       if (phi < 0.0) phi += 2.0 * kPi;
+      if (phi >= 2.0 * kPi) phi -= 2.0 * kPi;           // (-1e-17 + 2 pi rounds to 2 pi: a source due North to the last bit belongs to phi = 0,
+                                                        //  not to a pixel index one past its ring)
       const int64_t npix = 12 * nside * nside;
       const double az = fabs(z);
       int64_t ir1;

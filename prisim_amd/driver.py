@@ -31,6 +31,7 @@ import numpy as NP
 import yaml
 
 from . import _abi
+from . import frames as FRAMES
 from . import geometry as GEOM
 from . import interferometry as RI
 from . import layouts as LAY
@@ -212,8 +213,10 @@ def build_skymodel(parms, infile_dir):
     hadec = GEOM.altaz2hadec(sky['altaz'], lat, units='degrees')         # local frame at lst_init -> (RA, Dec)
     radec = NP.stack(((lst0 - hadec[:, 0]) % 360.0, hadec[:, 1]), axis=1)
     n = radec.shape[0]
+    # (a synthetic sky is laid out in the LOCAL frame at lst_init: its (RA, Dec) are coordinates of date by construction -- epoch None,
+    # nothing to precess; skyparm.epoch applies to catalogues that come with an equinox)
     return SM.SkyModel(location=radec, flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
-                       src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1), epoch='J' + str(sp['epoch']))
+                       src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1), epoch=None)
 
 
 def load_external_beam(parms, infile_dir):
@@ -337,6 +340,13 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     tel = telescope_dict(parms)
     skymod = build_skymodel(parms, infile_dir)
     jd, lst, hadec, t_acc, n_acc = schedule(parms)
+    if getattr(skymod, 'epoch', None) is not None:
+        # "Precess Sky model to observing epoch" (scripts/run_prisim.py:1688-1692): once, to the first timestamp; every observe() then
+        # applies what is left up to ITS timestamp plus nutation and aberration (interferometry.py:6174-6180, prisim_amd/frames.py).  The
+        # two precessions compose exactly (both go through J2000), so the visibilities are those of one step from the catalogue's equinox.
+        to_epoch = FRAMES.jyear_of_jd(jd[0])
+        skymod.location = FRAMES.precess_radec(skymod.location, skymod.epoch, to_epoch)
+        skymod.epoch = 'J{0:.12f}'.format(to_epoch)
     proc = parms['processing']
     ia_kwargs = dict(telescope=tel, eff_Q=parms['telescope']['eff_Q'], latitude=tel['latitude'], longitude=tel['longitude'],
                      altitude=tel['altitude'], skycoords='radec', A_eff=parms['telescope']['A_eff'], pointing_coords='hadec', device=device,

@@ -211,7 +211,8 @@ def snapshot_frame(coords, lst_deg, latitude_deg, jd=None, epoch=None, model='ap
     """(R (3, 3), beta (3,)) of one snapshot for a catalogue in `coords`:
 
     'radec'   model 'date'      R = tilt(lat) r3(LST): the catalogue is taken to be in the true equator and equinox of date (HA = LST - RA,
-                                what this package did before ABI 0.5); beta = 0
+                                what this package did before ABI 0.5); beta = 0.  Also whenever epoch is None / 'date' (a sky model that
+                                SAYS its coordinates are of date -- the synthetic skies of prisim_amd/driver.py) or jd is None
               model 'mean'      ... times the precession matrix epoch -> jd
               model 'apparent'  ... times nutation, and beta = annual aberration turned back into the catalogue frame
     'hadec'   R = hadec_to_enu(lat), beta = 0     (interferometry.py:6176-6177: GEOM.hadec2altaz, no astropy)
@@ -226,8 +227,8 @@ def snapshot_frame(coords, lst_deg, latitude_deg, jd=None, epoch=None, model='ap
     if model not in MODELS:
         raise ValueError('frame model must be one of {0}'.format(MODELS))
     local = equatorial_to_enu(lst_deg, latitude_deg)
-    if model == 'date' or jd is None or epoch is None:
-        return local, NP.zeros(3)
+    if model == 'date' or jd is None or epoch is None or (isinstance(epoch, str) and epoch.strip().lower() == 'date'):
+        return local, NP.zeros(3)             # a catalogue given in the coordinates of date (SkyModel.epoch None / 'date'): nothing to add
     prec = precession_matrix(jyear(epoch), jyear_of_jd(jd))
     if model == 'mean':
         return local.dot(prec), NP.zeros(3)

@@ -15,6 +15,8 @@ class SkyModel(object):
     spindex    (nsrc,) spectral index                     [func]
     spectrum   (nsrc, nf) tabulated flux densities at frequency (nf,)   [spectrum]
     src_shape  (nsrc, 3) major axis, minor axis (degrees FWHM), position angle; or None
+    epoch      equinox of `location` for 'radec' skies, 'J2000' style (interferometry.py:6174); None or 'date': the coordinates are
+               already those of date (apparent place), nothing is precessed (prisim_amd/frames.py)
     """
 
     def __init__(self, name=None, location=None, flux_ref=None, spindex=None, ref_freq=None, frequency=None,

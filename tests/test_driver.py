@@ -241,6 +241,16 @@ def test_sharded_run_stops_on_every_rank_when_any_self_test_fails(monkeypatch):
         driver.run(p, infile_dir=EX, rank=1, world=2, comm_uid=uid, verbose=False, host_copy='root', rdzv=NeverCalled())
 
 
+def _catalogue_in_the_snapshot_frame(parms, skymod, lat):
+    """(direction cosines, alt-az) of every source of config 1's catalogue at the run's one snapshot, with all sources above the horizon."""
+    from prisim_amd import frames as FR, geometry as GEOM
+    jd, lst, _, _, _ = driver.schedule(parms)
+    rot, beta = FR.snapshot_frame('radec', float(lst[0]), lat, jd=float(jd[0]), epoch=skymod.epoch, model='apparent')
+    dc = GEOM.frame_dircos(GEOM.catalog_unitvec(skymod.location, 'radec'), rot, beta)
+    assert NP.all(dc[:, 2] > 0.0)
+    return dc, GEOM.dircos2altaz(dc)
+
+
 @pytest.mark.gpu
 def test_config1_yaml_end_to_end_matches_oracle(tmp_path):
     """BASELINE config 1 through scripts/run_prisim.py -i examples/config1.yaml, checked against the oracle."""
@@ -261,15 +271,16 @@ def test_config1_yaml_end_to_end_matches_oracle(tmp_path):
     assert NP.allclose(out['vis_freq'], out['skyvis_freq'] + out['vis_noise_freq'], rtol=1e-12, atol=0) and NP.std(out['vis_noise_freq'].real) > 0
     vis = out['skyvis_freq']
     assert vis.shape == (6, 64, 1)
-    # oracle: same catalog in the local frame at lst = 0
+    # oracle: the same catalogue (equinox J2000, skyparm.epoch) in the local frame of the snapshot -- precession to the date of the run,
+    # nutation, aberration, rotation by the LST (prisim_amd/frames.py; run_prisim.py:1690-1692 + interferometry.py:6174-6180)
     p = driver.load_parms(str(infile))
     sm = driver.build_skymodel(p, EX)
     lat = p['telescope']['latitude']
-    altaz = O.hadec2altaz(NP.stack((0.0 - sm.location[:, 0], sm.location[:, 1]), 1), lat)
+    dc, altaz = _catalogue_in_the_snapshot_frame(p, sm, lat)
     ch = out['freq']
     pb = BO.gaussian_beam(14.0, altaz, ch, pointing_altaz=O.hadec2altaz([[0.0, lat]], lat)[0]) * sm.generate_spectrum(frequency=ch)
     pc = O.altaz2dircos(O.hadec2altaz([[0.0, lat]], lat))[0]
-    ref = O.skyvis(out['bl'], ch, O.altaz2dircos(altaz), pb, pc, fwhm_deg=NP.zeros(altaz.shape[0]))
+    ref = O.skyvis(out['bl'], ch, dc, pb, pc, fwhm_deg=NP.zeros(altaz.shape[0]))
     assert NP.max(NP.abs(vis[:, :, 0] - ref) / O.abs_flux_sum(pb)[None, :]) <= 1e-11
     w = driver.window(64, 'bhw')
     lag, lags = DO.delay_transform(ref[:, :, None], NP.ones((6, 64, 1)), NP.broadcast_to(w[None, :, None], (6, 64, 1)), ch[1] - ch[0], pad=1.0)
@@ -291,11 +302,11 @@ def test_phasing_center_of_the_yaml_is_where_the_visibilities_end_up():
     assert 'vis_freq' not in out
     sm = driver.build_skymodel(p, EX)
     lat = p['telescope']['latitude']
-    altaz = O.hadec2altaz(NP.stack((0.0 - sm.location[:, 0], sm.location[:, 1]), 1), lat)
+    dc, altaz = _catalogue_in_the_snapshot_frame(p, sm, lat)
     ch = out['freq']
     pb = BO.gaussian_beam(14.0, altaz, ch, pointing_altaz=O.hadec2altaz([[0.0, lat]], lat)[0]) * sm.generate_spectrum(frequency=ch)
     pc_new = O.altaz2dircos(NP.array([[80.0, 30.0]]))[0]
-    ref = O.skyvis(out['bl'], ch, O.altaz2dircos(altaz), pb, pc_new, fwhm_deg=NP.zeros(altaz.shape[0]))
+    ref = O.skyvis(out['bl'], ch, dc, pb, pc_new, fwhm_deg=NP.zeros(altaz.shape[0]))
     assert NP.max(NP.abs(out['skyvis_freq'][:, :, 0] - ref) / O.abs_flux_sum(pb)[None, :]) <= 1e-11
     assert NP.allclose(out['ia'].phase_center, [[80.0, 30.0]] if out['ia'].phase_center_coords == 'altaz' else out['ia'].phase_center)
 

@@ -96,8 +96,8 @@ def test_roi_indices_and_dircos_bit_identical_to_the_host_statement(case):
                 m2a, dca, altaza = host_roi(radec, lat, lst, roi_radius, frame=frame)
                 assert NP.array_equal(idx, m2a)
                 _check_dircos(dc, dca, altaza, (case[0], lst, roi_radius, 'apparent'))
-                if m2.size > 1000:
-                    assert not NP.array_equal(m2a, m2)             # (sources cross the rim of the region of interest)
+                if m2a.size == m2.size and m2.size:
+                    assert float(NP.max(NP.abs(dca - dc_host))) > 1e-3      # (0.37 degrees = 6e-3 rad: not the same sky)
 
 
 def test_device_unit_vectors_and_the_host_rotated_catalogue():
@@ -613,7 +613,7 @@ def test_equatorial_baselines_give_the_enu_visibilities():
                                     baseline_coords=coords)
         ia.observe((2457000.5, 72.5), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat], skymod, 10.0)
         out.append(NP.array(ia.skyvis_freq[:, :, 0]))
-    m2, dc, altaz = host_roi(radec, lat, 72.5)
+    m2, dc, altaz = host_roi(radec, lat, 72.5, frame=FR.snapshot_frame('radec', 72.5, lat, jd=2457000.5, epoch='J2000', model='apparent'))
     pb = BO.gaussian_beam(14.0, altaz, ch, power=True) * sky['flux_ref'][m2, None] * (ch[None, :] / sky['ref_freq']) ** sky['spindex'][m2, None]
     ref = CO.skyvis(bl, ch, dc, pb, ZEN)
     scale = NP.sum(NP.abs(pb), axis=0)[None, :]
@@ -751,7 +751,7 @@ def test_observe_radec_sky_in_the_apparent_frame_of_the_snapshot():
     assert float(NP.max(NP.abs(old.skyvis_freq[:, :, 0] - ia.skyvis_freq[:, :, 0]) / scale)) > 1e-2
     mean = make('mean')
     d_mean = float(NP.max(NP.abs(mean.skyvis_freq[:, :, 0] - ia.skyvis_freq[:, :, 0]) / scale))
-    assert 1e-6 < d_mean < 1e-2                              # nutation + aberration: tens of arcseconds
+    assert 1e-4 < d_mean < 0.2                               # nutation + aberration: tens of arcseconds (0.1 rad of phase on 300 m)
     # a caller-supplied frame (filled from astropy on the PRISim side) replaces the built-in model
     calls = []
 
@@ -797,3 +797,31 @@ def test_observe_batch_failure_leaves_the_instance_aligned():
     ia.observe_batch(times, {'Tnet': 100.0}, NP.ones(nchan), [0.0, lat], skymod, 10.0)
     assert ia.n_acc == 4 and len(ia.timestamp) == 4 and ia.pointing_center.shape == (4, 2) and ia.bp.shape == (3, nchan, 4)
     assert ia.skyvis_freq.shape == (3, nchan, 4) and ia.Tsys.shape == (3, nchan, 4)
+
+
+def test_external_beam_at_a_source_due_north_to_the_last_bit():
+    """A source whose East direction cosine is -1e-17 has azimuth 2 pi - 1e-17, which rounds to 2 pi itself: the HEALPix ring
+    interpolation must treat it as azimuth 0 (found when the snapshot frame replaced the asin / atan2 chain: 11 pixels of config 4's
+    nside-64 sky sit due North and their beam values came from one pixel past the ring -- 4e-4 of the peak)."""
+    from oracle import healpix_oracle as H
+    from prisim_amd import primary_beams as PB
+    cfg = W.config4(n_acc=1)
+    ch = cfg['channels'][:16]
+    m = PB.spectral_interp_matrix(cfg['beam_freqs'], ch, kind='cubic', chromatic=True, select_freq=None)
+    alts = NP.radians(NP.array([5.379379, 18.839405, 32.089951, 37.921651, 60.0, 85.0]))
+    variants = []
+    for east in (0.0, -1e-17, 1e-17):
+        dc = NP.stack((NP.full(alts.size, east), NP.cos(alts), NP.sin(alts)), axis=1)
+        with _abi.Context(0) as ctx:
+            ctx.set_array(cfg['baselines'][:4], ch, nt_max=1)
+            ctx.set_external_beam(cfg['beam_table'], m)
+            ctx.set_sky_external(dc, NP.ones((alts.size, ch.size)), ZEN)
+            variants.append(ctx.get_pbflux())
+    scale = NP.max(NP.abs(variants[0]))
+    assert float(NP.max(NP.abs(variants[1] - variants[0])) / scale) <= 1e-7          # (float32 beam storage: one rounding may flip)
+    assert float(NP.max(NP.abs(variants[2] - variants[0])) / scale) <= 1e-7
+    # the checker has the same property
+    for ph in (-1e-17, 2 * NP.pi - 1e-17):
+        a = H.get_interp_val(NP.log10(cfg['beam_table'][:, 0]), NP.pi / 2 - alts, NP.full(alts.size, ph))
+        b = H.get_interp_val(NP.log10(cfg['beam_table'][:, 0]), NP.pi / 2 - alts, NP.zeros(alts.size))
+        assert float(NP.max(NP.abs(a - b))) <= 1e-12

@@ -18,12 +18,13 @@ SIDEREAL_DEG_PER_SEC = 360.0 * 1.00273790935 / 86400.0
 
 
 def _radec_skymodel(sky, lat, lst0_deg):
-    """The local-frame sky of a workload as a (RA, Dec) sky model that stands where the workload puts it at LST = lst0."""
+    """The local-frame sky of a workload as a (RA, Dec) sky model that stands where the workload puts it at LST = lst0 (coordinates of
+    date: epoch None, like the synthetic skies of prisim_amd/driver.py)."""
     hadec = GEOM.altaz2hadec(sky['altaz'], lat, units='degrees')
     radec = NP.stack(((lst0_deg - hadec[:, 0]) % 360.0, hadec[:, 1]), axis=1)
     n = radec.shape[0]
     return SM.SkyModel(location=radec, flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
-                       src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1))
+                       src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1), epoch=None)
 
 
 def _spot(bl, n=4):
