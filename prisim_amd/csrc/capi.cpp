@@ -750,7 +750,9 @@ int extbeam_sky(prisim_ctx* ctx, int64_t nsrc, const double* d_fluxes, const dou
                 double ref_freq, const int32_t* src_index) {
   const int64_t n = nsrc * ctx->nchan;
   int rc;
-  if ((rc = ensure(ctx, ctx->ext_work, (size_t)n * sizeof(double))) ||
+  // (grown with headroom: the region of interest of a drift scan grows by a few sources per snapshot, and an exact fit would re-allocate
+  // -- and so drain the queue of -- almost every snapshot)
+  if ((rc = ensure_grow(ctx, ctx->ext_work, (size_t)n * sizeof(double))) ||
       (rc = ensure(ctx, ctx->ext_colmax, (size_t)1025 * ctx->nchan * sizeof(double))))
     return rc;
   HIPCHK(ctx, launch_extbeam_sky((const double*)ctx->ext_table.p, ctx->ext_nside, ctx->dirs_p, d_fluxes, d_flux_ref, d_spindex,
@@ -1143,6 +1145,7 @@ int prisim_hip_compute(prisim_ctx* ctx, int precision, int kernel, int want_grad
     if (want_grad)
       HIPCHK(ctx, hipMemsetAsync((double*)ctx->grad.p + (size_t)slot * 3 * slot_elems, 0, 3 * slot_elems * sizeof(double), ctx->stream));
     ctx->timing.last_terms = 0;
+    catalog_after_compute(ctx);      // (an empty region of interest still releases the catalogue's buffer set in stream order)
     return PRISIM_OK;
   }
   Plan pl = make_plan(ctx, precision, kernel);

@@ -56,7 +56,10 @@ int catalog_streams(prisim_ctx* ctx) {
   if (!C.ev_geom) HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_geom, hipEventDisableTiming));
   if (!C.ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_join, hipEventDisableTiming));
   for (auto& e : C.ev_tab) { if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
-  for (auto& s : C.set) { if (!s.ev_free) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming)); }
+  for (auto& s : C.set) {
+    if (!s.ev_free) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming));
+    if (!s.ev_prepared) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_prepared, hipEventDisableTiming));
+  }
   if (!C.culled_host) {
     if (hipHostMalloc((void**)&C.culled_host, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
       C.culled_host = nullptr;
@@ -206,6 +209,7 @@ int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* 
       C.out_host[t].nsrc = 0; C.out_host[t].dmax2_bits = 0;
       for (auto& v : C.out_host[t].run_start) v = 0;
     }
+    if (b != 2) C.chunk_nmax = 0;
     return PRISIM_OK;
   }
   CatGeomParams p{};
@@ -223,6 +227,8 @@ int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* 
   p.out = (CatOut*)C.out_dev.p;
   // the set may still be read by sky-sums queued earlier on the compute stream
   if (S.ev_recorded) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, S.ev_free, 0));
+  // ... or by the preparation of a sky nobody summed (two set_sky_from_catalog calls in a row, an empty region of interest)
+  if (S.prep_recorded) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, S.ev_prepared, 0));
   const auto t0 = Clock::now();
   HIPCHK(ctx, hipMemcpyAsync(C.snaps.p, C.snaps_host, (size_t)nsnap * sizeof(CatSnap), hipMemcpyHostToDevice, C.gstream));
   HIPCHK(ctx, launch_cat_geometry(p, (int)nsnap, C.gstream));
@@ -231,6 +237,10 @@ int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* 
   HIPCHK(ctx, hipEventSynchronize(C.ev_geom));
   C.geom_ms_sum += std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
   C.geom_calls += 1;
+  if (b != 2) {
+    C.chunk_nmax = 0;
+    for (int64_t t = 0; t < nsnap; ++t) C.chunk_nmax = std::max(C.chunk_nmax, C.out_host[t].nsrc);
+  }
   return PRISIM_OK;
 }
 
@@ -328,8 +338,13 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
     }
   }
   // pb * fluxes (:6249-6254); the flux vectors / spectra stay in catalogue order and are read through the index list.  Sized for the
-  // whole catalogue once: the ROI of a drift scan grows and shrinks, and every re-allocation would synchronise the device.
-  if ((rc = ensure(ctx, ctx->sk->pb, (size_t)std::max<int64_t>(C.n * ctx->nchan, 1) * sizeof(double)))) return rc;
+  // largest region of interest of the chunk (known from the geometry) plus a quarter, never beyond the whole catalogue: a horizon ROI sees
+  // at most half of an all-sky catalogue, and sizing both buffer sets for all of it was 4x what the uploaded path ever allocated (a large
+  // catalogue that ran before must not run out of memory here); the headroom keeps a drift scan's growing ROI from re-allocating -- a
+  // device-wide synchronisation -- at every snapshot.
+  if ((rc = ensure_grow(ctx, ctx->sk->pb, (size_t)std::max<int64_t>(std::max(C.chunk_nmax, N) * ctx->nchan, 1) * sizeof(double),
+                        (size_t)std::max<int64_t>(C.n * ctx->nchan, 1) * sizeof(double))))
+    return rc;
   if (N > 0) {
     const double* fr = C.have_spec ? nullptr : (const double*)C.flux_ref.p;
     const double* sp = C.have_spec ? nullptr : (const double*)C.spindex.p;
@@ -345,6 +360,8 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
       if (obs->beam_kind == PRISIM_BEAM_POLY && (rc = check_poly_beam_flag(ctx))) return rc;
     }
   }
+  HIPCHK(ctx, hipEventRecord(S.ev_prepared, ps));
+  S.prep_recorded = true;
   C.cur = b;
   ctx->sky_set = true;
   return PRISIM_OK;
@@ -593,7 +610,8 @@ void catalog_destroy(prisim_ctx* ctx) {
   for (auto& s : C.set) {
     for (DevBuf* b : {&s.idx, &s.dirs, &s.keys, &s.pos}) release(*b);
     if (s.ev_free) (void)hipEventDestroy(s.ev_free);
-    s.ev_free = nullptr;
+    if (s.ev_prepared) (void)hipEventDestroy(s.ev_prepared);
+    s.ev_free = s.ev_prepared = nullptr;
   }
   if (C.ev_geom) (void)hipEventDestroy(C.ev_geom);
   if (C.ev_join) (void)hipEventDestroy(C.ev_join);
@@ -726,7 +744,7 @@ int prisim_hip_set_catalog(prisim_ctx* ctx, const prisim_catalog* cat) {
   C.have_spec = have_spec;
   C.ref_freq = have_spec ? 1.0 : cat->ref_freq_hz;
   release(C.sort_tmp);                 // sized per catalogue
-  for (auto& s : C.set) s.ev_recorded = false;
+  for (auto& s : C.set) s.ev_recorded = s.prep_recorded = false;
   C.loaded = true;
   return PRISIM_OK;
   });

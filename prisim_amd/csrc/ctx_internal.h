@@ -177,6 +177,8 @@ struct prisim_ctx {
       DevBuf idx, dirs, keys, pos;
       hipEvent_t ev_free = nullptr;     // recorded on the compute stream behind the last kernel that reads the set
       bool ev_recorded = false;
+      hipEvent_t ev_prepared = nullptr; // recorded behind the preparation (sort, cull table, beam x flux) that reads the set: a second
+      bool prep_recorded = false;       // set_sky_from_catalog without a compute() in between must not scatter under it
     } set[3];
     DevBuf block_off, snaps, out_dev, sort_tmp, keys_out, perm, culled;
     CatOut* out_host = nullptr;         // pinned [cap_snaps]
@@ -188,6 +190,7 @@ struct prisim_ctx {
     bool tab_recorded[2] = {false, false};
     int tab_half = 0;
     int64_t cap_snaps = 0;
+    int64_t chunk_nmax = 0;             // largest region of interest among the snapshots of the chunk whose geometry was formed last
     hipStream_t gstream = nullptr;      // geometry stream (highest priority: a few small kernels beside a sky-sum grid)
     hipEvent_t ev_geom = nullptr;
     hipEvent_t ev_join = nullptr;       // "everything queued on the compute stream so far" (first preparation-stream sky after an in-line one)
@@ -300,6 +303,17 @@ inline int ensure(prisim_ctx* ctx, DevBuf& b, size_t bytes) {
   }
   b.bytes = bytes;
   return PRISIM_OK;
+}
+
+// A buffer whose size follows something that drifts (the region of interest of a drift scan grows and shrinks by a few sources per
+// snapshot): grow with a quarter of headroom, never beyond `cap` bytes, so that re-allocations -- each one a device-wide
+// synchronisation -- stay rare without sizing for the worst case (a whole catalogue x nchan) up front.
+inline int ensure_grow(prisim_ctx* ctx, DevBuf& b, size_t bytes, size_t cap = (size_t)-1) {
+  if (b.bytes >= bytes && b.p) return PRISIM_OK;
+  size_t want = bytes + bytes / 4;
+  if (want > cap) want = cap;
+  if (want < bytes) want = bytes;
+  return ensure(ctx, b, want);
 }
 
 inline void release(DevBuf& b) {

@@ -19,7 +19,7 @@ Algorithms" 2nd ed., examples 12.a, 21.b, 22.a, 23.a):
   not modelled FK5 <-> ICRS frame bias (0.02 arcsec), light deflection by the Sun (< 0.01 arcsec beyond 30 deg elongation), diurnal
                aberration (<= 0.32 arcsec), polar motion (<= 0.5 arcsec), TT - UTC in the precession / nutation / aberration epoch
                (1e-4 arcsec), refraction (off in the reference: pressure = 0).
-  A caller that HAS astropy fills R and beta exactly (INTEGRATION.md 2b shows the six lines) and hands them to observe(frame=...).
+  A caller that HAS astropy fills R and beta exactly (INTEGRATION.md 2b shows the six lines) and sets InterferometerArray.frame_provider.
 
 Conventions: every rotation below is a FRAME rotation (ERFA rx/ry/rz, astropy rotation_matrix): r3(a) takes the coordinates of a
 fixed vector to a frame turned anticlockwise by a about z.  Angles in radians unless the name says _deg.

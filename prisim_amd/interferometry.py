@@ -826,6 +826,18 @@ class InterferometerArray(object):
                 digest(getattr(skymodel, 'src_shape', None)), self.channels.size, float(self.channels[0]), float(self.channels[-1]),
                 self._reserved)
 
+    def close(self):
+        """Release the GPU context.  Class state that still lives on the device is fetched first: obs_catalog_indices / geometric_delays of
+        snapshots formed from the resident catalogue, snapshots and gradient blocks parked in device slots."""
+        if getattr(self, '_ctx', None) is None:
+            return
+        self._materialise_catalog_state()
+        if getattr(self, '_cube', None):
+            self.skyvis_freq
+        if isinstance(self.gradient, _LazyGradients) and self.gradient_mode is not None:
+            self.gradient.get(self.gradient_mode)
+        self._ctx.close()
+
     def invalidate_catalog(self):
         """Forget the sky model resident on the device: the next observe() uploads it again (for edits the fingerprint cannot see,
         e.g. a custom generate_spectrum whose parameters changed)."""
