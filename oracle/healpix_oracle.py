@@ -130,7 +130,14 @@ def external_beam(beam, beam_freqs, theta, phi, chans, kind='cubic', chromatic=T
         j = int(NP.argmin(NP.abs(NP.asarray(beam_freqs) - select_freq)))                               # :2096
         logchan = NP.repeat(logbeam[:, [j]], chans.size, axis=1)                                       # :2097
     interp_logbeam = get_interp_val(logchan, theta, phi)
-    mx = NP.nanmax(interp_logbeam, axis=0)                                                             # :2098
-    mx = NP.where(mx <= 0.0, 0.0, mx).reshape(1, -1)                                                   # :2099-2100
-    pb = 10 ** (interp_logbeam - mx)                                                                   # :2101-2102
+    return normalise_logbeam(interp_logbeam, quantise_f32=quantise_f32)
+
+
+def normalise_logbeam(interp_logbeam, quantise_f32=True):
+    """scripts/run_prisim.py:2099-2103 (per-channel maximum over the sources, clamped at 0, subtracted; 10 ** (.)) and the float32
+    storage of a supplied beam (interferometry.py:4466).  Pinned by tests/golden/golden_aux.npz (the reference's statements executed)."""
+    interp_logbeam = NP.asarray(interp_logbeam, dtype=NP.float64)
+    mx = NP.nanmax(interp_logbeam, axis=0)                                                             # :2099
+    mx = NP.where(mx <= 0.0, 0.0, mx).reshape(1, -1)                                                   # :2100-2101
+    pb = 10 ** (interp_logbeam - mx)                                                                   # :2102-2103
     return pb.astype(NP.float32).astype(NP.float64) if quantise_f32 else pb                            # interferometry.py:4466

@@ -13,7 +13,7 @@ itself through prisim_amd.launch; any launcher that sets RANK / WORLD_SIZE / LOC
 visibility cube;
 the rank-0 ROI/beam precompute through FITS files disappears (beams are fused on the device).
 Not offered (out of scope): survey catalogs (SUMSS/NVSS/GLEAM/GSM need prisim/data, absent),
-gains, uvfits/uvh5 writers, `pp.key: 'freq' | 'src'`, plots, resource monitor.  After the snapshots: thermal noise, re-centring on
+gains, uvfits/uvh5 writers, plots, resource monitor (`pp.key: 'freq' | 'src'` are accepted and run on baseline shards).  After the snapshots: thermal noise, re-centring on
 phasing.center, delay transform and the npz / HDF5 files, in the reference's order (:2278-2286); in a sharded run every rank does the
 per-baseline steps on its own shard and rank 0 puts the whole array together from the gathered cubes (assemble_full_array).  Two synthetic sky models
 are added because the reference's catalogs are not available offline: skyparm.model 'ptsrc_random' and 'healpix_synthetic'.
@@ -26,6 +26,7 @@ import hashlib
 import datetime
 import os
 import time
+import warnings
 
 import numpy as NP
 import yaml
@@ -321,8 +322,17 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     extbeam = None
     if parms['beam'].get('use_external'):
         extbeam = load_external_beam(parms, infile_dir)
-    if parms['pp']['key'] != 'bl':
-        raise NotImplementedError("pp.key must be 'bl': baselines are the natural shard axis on GPUs (SURVEY.md 2.2)")
+    pp_key = parms['pp'].get('key')
+    if pp_key in ('freq', 'src'):
+        # run_prisim.py:1858-1995 ('freq': chunks of channels, the shipped default, defaultparms.yaml:939) / :1996-2080 ('src': chunks of
+        # sources): the key only chooses how the work is cut, never the result -- every chunk is a sub-block of the same sum.  On GPUs the
+        # baselines are the natural shard axis (each shard keeps whole channel recurrences and sums every source), so the run proceeds on
+        # baseline shards; the visibilities are identical by construction.
+        if rank == 0:
+            warnings.warn("pp.key = {0!r}: the work is cut over baselines instead (the partition key changes how the sum is split, not "
+                          "its result)".format(pp_key))
+    elif pp_key != 'bl':
+        raise ValueError("pp.key must be 'bl', 'freq' or 'src' (scripts/run_prisim.py:1775-2080); got {0!r}".format(pp_key))
     bp = parms['bandpass']
     chans = W.channel_grid(float(bp['freq']), float(bp['freq_resolution']), int(bp['nchan']))      # run_prisim.py:900
     bl, labels, antpos, blgroups = baseline_info(parms)

@@ -24,6 +24,11 @@ source text is stored in this repository.
                        delay and gain jitter, complex64 arithmetic), 9-441 (id 'mwa' and shape 'dipole' with pointing_info)
   golden_apply_gradients.npz  interferometry.py:6726-6819 (method apply_gradients, called on a stand-in object that holds the
                        attributes it reads: gradient, gradient_mode, channels, labels, lst)
+  golden_aux.npz       the last executable statements next to the path:
+                       scripts/run_prisim.py:2099-2103 (log-beam normalisation after the HEALPix interpolation) + interferometry.py:4466
+                       (the supplied beam stored as float32); interferometry.py:7980-7985 (uvw rotation matrix and projection, on given
+                       equatorial baselines and (HA, Dec) in radians); :8035-8045 (conjugate: flipped baselines, conjugated cubes, labels);
+                       :6676-6691 (vis_rms_freq, flux_unit 'JY' and 'K'; CNST.Jy of the un-vendored astroutils = 1e-26 W m^-2 Hz^-1)
 """
 import os
 import sys
@@ -305,6 +310,59 @@ def make_apply_gradients():
     print('golden_apply_gradients.npz:', {k: v.shape for k, v in out.items()})
 
 
+def make_aux():
+    rng = NP.random.default_rng(20261006)
+    out = {}
+    # ---- run_prisim.py:2098-2102 + interferometry.py:4466: normalisation of the interpolated log-beam, stored as float32 ----
+    nsrc, nchan = 23, 9
+    interp_logbeam = rng.uniform(-6.0, 0.4, size=(nsrc, nchan))
+    interp_logbeam[:, 3] -= 1.0                       # a channel whose maximum is below 0: the clamp of :2100 keeps it un-normalised
+    interp_logbeam[5, 6] = NP.nan                     # nanmax ignores it (:2099); the NaN itself propagates
+    ns = {'NP': NP, 'interp_logbeam': interp_logbeam.copy(), 'roiinfo': {}}
+    exec(ref_stmts('../scripts/run_prisim.py', [(2099, 2103)]), ns)
+    out['logbeam_in'] = interp_logbeam
+    out['pbeam'] = ns['roiinfo']['pbeam']
+    roi_info = {'pbeam': ns['roiinfo']['pbeam']}
+    holder = types.SimpleNamespace(info={'pbeam': []})
+    exec(ref_stmts('interferometry.py', [(4466, 4466)]), {'NP': NP, 'self': holder, 'roi_info': roi_info})
+    out['pbeam_f32'] = holder.info['pbeam'][0]
+    # ---- interferometry.py:7980-7985: the uvw rotation matrix and the projection ----
+    nbl, nt = 6, 4
+    eq_baselines = rng.uniform(-300.0, 300.0, size=(nbl, 3))
+    ha = NP.radians(rng.uniform(-80.0, 80.0, nt))
+    dec = NP.radians(rng.uniform(-70.0, 40.0, nt))
+    holder = types.SimpleNamespace()
+    exec(ref_block('interferometry.py', [(7980, 7985)]), {'NP': NP, 'self': holder, 'ha': ha, 'dec': dec, 'eq_baselines': eq_baselines})
+    out.update(proj_eq_baselines=eq_baselines, proj_ha=ha, proj_dec=dec, projected_baselines=holder.projected_baselines)
+    exec(ref_block('interferometry.py', [(7980, 7985)]), {'NP': NP, 'self': holder, 'ha': ha[:1], 'dec': dec[:1], 'eq_baselines': eq_baselines})
+    out['projected_baselines_one'] = holder.projected_baselines
+    # ---- interferometry.py:8035-8045: conjugate ----
+    nchan2 = 5
+    def cube():
+        return rng.normal(size=(nbl, nchan2, nt)) + 1j * rng.normal(size=(nbl, nchan2, nt))
+    holder = types.SimpleNamespace(labels=[(i, 100 + i) for i in range(nbl)], baselines=rng.uniform(-100, 100, size=(nbl, 3)),
+                                   vis_freq=cube(), skyvis_freq=cube(), vis_noise_freq=cube(), projected_baselines=rng.normal(size=(nbl, 3, nt)))
+    ind = NP.asarray([1, 4, 5])
+    out.update(conj_ind=ind, conj_baselines_in=holder.baselines.copy(), conj_vis_in=holder.vis_freq.copy(), conj_skyvis_in=holder.skyvis_freq.copy(),
+               conj_noise_in=holder.vis_noise_freq.copy(), conj_proj_in=holder.projected_baselines.copy())
+    exec(ref_block('interferometry.py', [(8035, 8045)]), {'NP': NP, 'self': holder, 'ind': ind, 'xrange': range})
+    out.update(conj_baselines=holder.baselines, conj_orientations=holder.baseline_orientations, conj_vis=holder.vis_freq,
+               conj_skyvis=holder.skyvis_freq, conj_noise=holder.vis_noise_freq, conj_proj=holder.projected_baselines,
+               conj_labels=NP.array([list(l) for l in holder.labels]))
+    # ---- interferometry.py:6676-6691: vis_rms_freq ----
+    CNST = types.SimpleNamespace(Jy=1.0e-26)
+    nchan3 = 7
+    for unit in ('JY', 'K'):
+        holder = types.SimpleNamespace(eff_Q=rng.uniform(0.8, 0.95, size=(nbl, nchan3)), A_eff=rng.uniform(100.0, 200.0, size=(nbl, nchan3)),
+                                       t_acc=[10.0, 10.0, 12.5, 8.0], flux_unit=unit, freq_resolution=97656.25,
+                                       Tsys=rng.uniform(80.0, 400.0, size=(nbl, nchan3, nt)))
+        exec(ref_block('interferometry.py', [(6676, 6691)]), {'NP': NP, 'FCNST': FCNST, 'CNST': CNST, 'self': holder})
+        out.update({'rms_effQ_' + unit: holder.eff_Q, 'rms_Aeff_' + unit: holder.A_eff, 'rms_tacc_' + unit: NP.asarray(holder.t_acc),
+                    'rms_Tsys_' + unit: holder.Tsys, 'rms_df': NP.asarray(holder.freq_resolution), 'rms_out_' + unit: holder.vis_rms_freq})
+    NP.savez_compressed(os.path.join(HERE, 'golden_aux.npz'), **out)
+    print('golden_aux.npz:', {k: v.shape for k, v in out.items()})
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree not available: golden vectors can only be regenerated in the build container')
@@ -315,3 +373,4 @@ if __name__ == '__main__':
     make_beamformer()
     make_polybeams()
     make_apply_gradients()
+    make_aux()

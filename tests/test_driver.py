@@ -1,4 +1,5 @@
 """YAML driver (prisim_amd/driver.py, scripts/run_prisim.py): host logic on CPU, end-to-end runs on the GPU."""
+import copy
 import os
 import subprocess
 import sys
@@ -149,8 +150,8 @@ def test_window_shapes():
 
 def test_unsupported_modes_fail_loudly():
     p = driver.load_parms(os.path.join(EX, 'config1.yaml'))
-    p['pp']['key'] = 'freq'
-    with pytest.raises(NotImplementedError):
+    p['pp']['key'] = 'pixels'                   # ('freq' and 'src' are accepted: test_stock_partition_keys_run_on_baseline_shards)
+    with pytest.raises(ValueError):
         driver.run(p)
     p['pp']['key'] = 'bl'
     p['beam']['use_external'] = True
@@ -181,6 +182,36 @@ def test_shipped_yaml_files_describe_the_baseline_configs():
         bad = driver.load_parms(os.path.join(EX, 'config3.yaml'))
         bad['skyparm']['components'] = []
         driver.build_skymodel(bad, EX)
+
+
+def test_stock_partition_keys_run_on_baseline_shards(monkeypatch):
+    """defaultparms.yaml:939 ships pp.key 'freq' (loop at run_prisim.py:1858-1995; 'src' :1996-2080).  The key only chooses how the sum is
+    cut: the run proceeds on baseline shards with a warning naming the substitution, and gives the visibilities of pp.key 'bl' exactly.
+    When the reference tree is at hand (the build container; never on the GPU box) its own defaultparms.yaml is what gets loaded."""
+    import warnings
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import fake_context
+    from prisim_amd import _abi
+    monkeypatch.setattr(_abi, 'Context', fake_context.OracleContext)
+    stock = '/root/reference/prisim/examples/simparms/defaultparms.yaml'
+    if os.path.exists(stock):
+        ref = driver.load_parms(stock)
+        assert ref['pp']['key'] == 'freq'
+    base = driver.load_parms(os.path.join(EX, 'config1.yaml'))
+    base['array']['file'] = os.path.join(EX, 'config1_layout.txt')
+    base['catalog']['custom_file'] = os.path.join(EX, 'config1_catalog.txt')
+    base['processing']['add_noise'] = False
+    base['processing']['delay_transform'] = False
+    out = {}
+    for key in ('bl', 'freq', 'src'):
+        p = copy.deepcopy(base)
+        p['pp']['key'] = key
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            out[key] = driver.run(p, infile_dir=EX, verbose=False)['skyvis_freq']
+        named = [str(x.message) for x in w if 'pp.key' in str(x.message)]
+        assert (len(named) == 1 and repr(key) in named[0] and 'baselines' in named[0]) if key != 'bl' else not named
+    assert NP.array_equal(out['freq'], out['bl']) and NP.array_equal(out['src'], out['bl']) and NP.any(out['bl'] != 0)
 
 
 def test_sharded_run_stops_on_every_rank_when_any_self_test_fails(monkeypatch):

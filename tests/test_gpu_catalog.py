@@ -825,3 +825,36 @@ def test_external_beam_at_a_source_due_north_to_the_last_bit():
         a = H.get_interp_val(NP.log10(cfg['beam_table'][:, 0]), NP.pi / 2 - alts, NP.full(alts.size, ph))
         b = H.get_interp_val(NP.log10(cfg['beam_table'][:, 0]), NP.pi / 2 - alts, NP.zeros(alts.size))
         assert float(NP.max(NP.abs(a - b))) <= 1e-12
+
+
+def test_device_external_beam_normalisation_against_the_reference_statements():
+    """scripts/run_prisim.py:2099-2103 + interferometry.py:4466 on the device, against the golden vector of those statements executed
+    (tests/golden/golden_aux.npz): a nside-2 beam table holds 10 ** logbeam_in at 23 pixels and the sources sit exactly on those pixel
+    centres, where the HEALPix interpolation returns the pixel itself; unit fluxes.  The one NaN of the vector is replaced by a low finite
+    value (the API wants a positive table) -- the reference's nanmax skipped it, so every other number is unchanged.  Tolerance: 1.5
+    float32 ulp (log10(10 ** x) rounds x in the last place before the float32 store)."""
+    from conftest import GOLDEN
+    g = NP.load(os.path.join(GOLDEN, 'golden_aux.npz'))
+    logb = g['logbeam_in'].copy()
+    want = g['pbeam_f32'].astype(NP.float64)
+    nsrc, nchan = logb.shape
+    nanpos = NP.argwhere(NP.isnan(logb))
+    assert nanpos.shape == (1, 2)
+    logb[tuple(nanpos[0])] = -6.0
+    nside = 2
+    theta, phi = GEOM.healpix_pix2ang_ring(nside)
+    pix = NP.arange(nsrc)                                   # rings 1-3 (20 pixels) and three of the equatorial ring: altitude >= 0
+    table = NP.full((12 * nside * nside, nchan), 1e-9)
+    table[pix] = 10.0 ** logb
+    st = NP.sin(theta[pix])
+    dc = NP.stack((st * NP.sin(phi[pix]), st * NP.cos(phi[pix]), NP.cos(theta[pix])), axis=1)      # azimuth from North through East
+    ch = 150e6 + 1e5 * NP.arange(nchan)
+    with _abi.Context(0) as ctx:
+        ctx.set_array(NP.array([[14.6, 0.0, 0.0]]), ch, nt_max=1)
+        ctx.set_external_beam(table, NP.eye(nchan))
+        ctx.set_sky_external(dc, NP.ones((nsrc, nchan)), ZEN)
+        pb = ctx.get_pbflux()
+    keep = NP.ones(logb.shape, dtype=bool)
+    keep[tuple(nanpos[0])] = False
+    assert float(NP.max(NP.abs(pb[keep] / want[keep] - 1.0))) <= 1.5 * 2.0 ** -23
+    assert NP.max(pb[:, 3]) < 1.0 and abs(NP.max(NP.delete(pb, 3, axis=1)) - 1.0) <= 2.0 ** -23     # the clamp of :2100 on the device

@@ -552,3 +552,64 @@ def test_gradient_blocks_stay_on_the_device_until_read(monkeypatch):
             assert ia.gradient['baseline'].shape == (3, 5, 6, 4)                                   # a fourth snapshot (slot 0 reused)
             assert NP.array_equal(ia.gradient['baseline'][..., :3], res[True])
     assert NP.max(NP.abs(res[True] - res[False])) <= 1e-12 * NP.max(NP.abs(res[False]))
+
+
+# ---- the last executable statements next to the path, against tests/golden/golden_aux.npz (the reference's lines executed) ----
+def _golden_aux():
+    from conftest import GOLDEN
+    return NP.load(os.path.join(GOLDEN, 'golden_aux.npz'))
+
+
+def test_project_baselines_matches_reference_statements(monkeypatch):
+    """interferometry.py:7980-7985: the uvw rotation matrix per snapshot and the projection NP.dot(eq_baselines, rot_matrix).  The inputs
+    of the golden vector are equatorial baselines and (HA, Dec) in radians; they reach the class method through GEOM.xyz2enu / hadec
+    reference points (astroutils conventions, unpinned), whose round trips cost a few ulp: tolerance 1e-12 of the baseline length."""
+    from prisim_amd import geometry as GEOM
+    g = _golden_aux()
+    lat = -30.7
+    bl = GEOM.xyz2enu(g['proj_eq_baselines'], lat, 'degrees')
+    ia = _oracle_array(monkeypatch, bl, 150e6 + 1e5 * NP.arange(4))
+    ia.latitude = lat
+    nt = g['proj_ha'].size
+    ia.n_acc, ia.lst = nt, [0.0] * nt
+    ia.project_baselines({'location': NP.degrees(NP.stack((g['proj_ha'], g['proj_dec']), axis=1)), 'coords': 'hadec'})
+    scale = NP.max(NP.abs(g['proj_eq_baselines']))
+    assert ia.projected_baselines.shape == g['projected_baselines'].shape == (6, 3, nt)
+    assert NP.max(NP.abs(ia.projected_baselines - g['projected_baselines'])) <= 1e-12 * scale
+    ia.n_acc, ia.lst = 1, [0.0]
+    ia.project_baselines({'location': NP.degrees(NP.array([g['proj_ha'][0], g['proj_dec'][0]])), 'coords': 'hadec'})
+    assert NP.max(NP.abs(ia.projected_baselines - g['projected_baselines_one'])) <= 1e-12 * scale
+
+
+def test_conjugate_matches_reference_statements(monkeypatch):
+    """interferometry.py:8035-8045: flipped baselines, conjugated cubes, reversed label pairs, negated projected baselines -- exactly."""
+    g = _golden_aux()
+    ia = _oracle_array(monkeypatch, g['conj_baselines_in'].copy(), 150e6 + 1e5 * NP.arange(5))
+    ia.labels = [(i, 100 + i) for i in range(6)]
+    ia.n_acc = 4
+    ia.skyvis_freq = g['conj_skyvis_in'].copy()
+    ia.vis_freq, ia.vis_noise_freq = g['conj_vis_in'].copy(), g['conj_noise_in'].copy()
+    ia.projected_baselines = g['conj_proj_in'].copy()
+    ia.conjugate(ind=g['conj_ind'], verbose=False)
+    assert NP.array_equal(ia.baselines, g['conj_baselines']) and NP.array_equal(ia.baseline_orientations, g['conj_orientations'])
+    assert NP.array_equal(ia.skyvis_freq, g['conj_skyvis']) and NP.array_equal(ia.vis_freq, g['conj_vis'])
+    assert NP.array_equal(ia.vis_noise_freq, g['conj_noise']) and NP.array_equal(ia.projected_baselines, g['conj_proj'])
+    assert NP.array_equal(NP.array([list(l) for l in ia.labels]), g['conj_labels'])
+
+
+@pytest.mark.parametrize('unit', ['JY', 'K'])
+def test_vis_rms_freq_matches_reference_statements(monkeypatch, unit):
+    """interferometry.py:6676-6691: vis_rms_freq = 2 k / sqrt(t_acc df) Tsys / (A_eff eff_Q) / Jy, or Tsys / eff_Q / sqrt(t_acc df) in K
+    (CNST.Jy of the un-vendored astroutils is 1e-26).  Tolerance 4 ulp (the order of the products differs)."""
+    g = _golden_aux()
+    ia = _oracle_array(monkeypatch, NP.zeros((6, 3)) + NP.arange(6)[:, None], 150e6 + float(g['rms_df']) * NP.arange(7))
+    ia.freq_resolution = float(g['rms_df'])
+    ia.eff_Q, ia.A_eff = g['rms_effQ_' + unit], g['rms_Aeff_' + unit]
+    ia.Tsys = g['rms_Tsys_' + unit]
+    ia.t_acc = list(g['rms_tacc_' + unit])
+    ia.timestamp = [2457000.5 + t for t in range(4)]
+    ia.flux_unit = unit
+    ia.generate_noise(seed=7)
+    want = g['rms_out_' + unit]
+    assert ia.vis_rms_freq.shape == want.shape and NP.max(NP.abs(ia.vis_rms_freq / want - 1.0)) <= 1e-15
+    assert ia.vis_noise_freq.shape == want.shape and NP.iscomplexobj(ia.vis_noise_freq)

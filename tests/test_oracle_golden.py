@@ -169,3 +169,18 @@ def test_polynomial_dish_beams_match_reference_functions():
         pb = BO.polynomial_beam(coef, 90.0 - g['altaz_' + name][:, 0], f)
         assert NP.max(NP.abs(pb - g['pbg_' + name])) <= 1e-13, name
         assert pb[0, 0] == 1.0
+
+
+def test_external_beam_normalisation_matches_reference_statements():
+    """scripts/run_prisim.py:2099-2103 + interferometry.py:4466 executed on a seeded log-beam (a channel whose maximum is below 0 stays
+    un-normalised; a NaN is skipped by the maximum): the checker's normalise_logbeam gives the same numbers bit for bit."""
+    import os
+    from conftest import GOLDEN
+    from oracle import healpix_oracle as H
+    g = NP.load(os.path.join(GOLDEN, 'golden_aux.npz'))
+    with NP.errstate(invalid='ignore'):
+        pb = H.normalise_logbeam(g['logbeam_in'], quantise_f32=False)
+        pb32 = H.normalise_logbeam(g['logbeam_in'], quantise_f32=True)
+    assert NP.array_equal(pb, g['pbeam'], equal_nan=True) and NP.isnan(pb[5, 6]) and NP.sum(NP.isnan(pb)) == 1
+    assert g['pbeam_f32'].dtype == NP.float32 and NP.array_equal(pb32, g['pbeam_f32'].astype(NP.float64), equal_nan=True)
+    assert NP.max(pb[:, 3]) < 1.0 and abs(NP.nanmax(NP.delete(pb, 3, axis=1)) - 1.0) < 1e-15       # the clamp of :2100
