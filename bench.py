@@ -839,6 +839,17 @@ def main():
                 ctx.comm_selftest(1 << 20)     # 1 MiB per rank through ncclAllGather, every rank's pattern verified on the host
             except Exception as exc:
                 err = 'RCCL self-test failed: %r' % (exc,)
+        if err is None:
+            try:
+                # every rank's rows in the global numbering (-1 = padding): each gathered snapshot is put into the reference's baseline
+                # order by a copy kernel behind the gather, on the communication stream (prisim_hip_set_shard_map)
+                smap = NP.full((world, bl_mine.shape[0]), -1, dtype=NP.int64)
+                for r in range(world):
+                    idx_r = sharding.shard_index(nbl_total, world, r)
+                    smap[r, :idx_r.size] = idx_r
+                ctx.set_shard_map(smap, nbl_total)
+            except Exception as exc:
+                err = 'shard map refused: %r' % (exc,)
         errs = [e for e in rdzv.allgather(err) if e]
         if errs:
             sys.stderr.write('rank %d: %s\n' % (rank, '; '.join(errs)))
@@ -882,7 +893,8 @@ def main():
         cs_ = ctx.comm_stats()
         per_snap = cs_['sum_gather_ms'] / max(1, cs_['n_gathers'])
         mine_g = {'per_snapshot_ms': per_snap, 'max_ms': cs_['max_gather_ms'], 'exposed_ms': cs_['last_gather_after_compute_ms'],
-                  'bytes_per_peer': cs_['bytes_per_peer'], 'n': cs_['n_gathers'], 'prio': [cs_['stream_priority'], cs_['stream_priority_lowest']]}
+                  'bytes_per_peer': cs_['bytes_per_peer'], 'n': cs_['n_gathers'], 'prio': [cs_['stream_priority'], cs_['stream_priority_lowest']],
+                  'undeal_ms': cs_['sum_undeal_ms'] / max(1, cs_['n_gathers'])}
         allg = rdzv.allgather(mine_g)
         worst = max(allg, key=lambda g: g['per_snapshot_ms'])
         gbps = (worst['bytes_per_peer'] / (worst['per_snapshot_ms'] * 1e-3) / 1e9) if worst['per_snapshot_ms'] > 0 else None
@@ -894,16 +906,21 @@ def main():
                   'exposed_ms_what': 'end of the LAST snapshot\'s gather minus end of its sky-sum, slowest rank: the part no compute hides',
                   'GBps_per_link': gbps, 'link_peak_GBps': XGMI_LINK_GBS, 'link_frac': (gbps / XGMI_LINK_GBS) if gbps else None,
                   'GBps_per_link_what': 'one shard to each of N-1 peers over its own xGMI link, while the sky-sum grid occupies the CUs (slowest rank)',
-                  'gathers_measured': worst['n'], 'comm_stream_priority': worst['prio'][0], 'lowest_priority': worst['prio'][1]}
+                  'gathers_measured': worst['n'], 'comm_stream_priority': worst['prio'][0], 'lowest_priority': worst['prio'][1],
+                  'order': 'global', 'order_what': 'every receiving GPU holds [nt][nbl_total][nchan] in the unsharded array\'s baseline order '
+                                                   '(run_prisim.py:2233-2242), put there by a copy kernel behind each gather; its time is part of per_snapshot_ms',
+                  'undeal_ms_per_snapshot': max(g['undeal_ms'] for g in allg)}
     if world > 1:
-        # every rank must hold the same gathered cube (device checksums agree) AND rank r's block of it must be rank r's own
-        # shard, element for element (a plain checksum would not see swapped rank blocks)
+        # every rank must hold the same gathered cube (device checksums agree) AND the rows of this rank's baselines in it -- global
+        # order -- must be this rank's own shard, element for element (a plain checksum would not see swapped blocks)
         cs = ctx.gathered_checksum(K, complex64=c64)
         allcs = rdzv.allgather(cs)
         gather_ok = bool(all(abs(c - allcs[0]) <= 1e-9 * max(1.0, abs(allcs[0])) for c in allcs))
-        g = ctx.get_gathered(1, world)[0]                                  # snapshot 0: [rank][b][f]
+        g = ctx.get_gathered(1, world)[0]                                  # snapshot 0: [global baseline][f]
         mine = ctx.get_vis(slot=0, complex64=c64)
-        gather_ok = gather_ok and bool(all(rdzv.allgather(bool(NP.array_equal(g[rank], mine)))))
+        idx_mine = sharding.shard_index(nbl_total, world, rank)
+        gather_ok = gather_ok and g.shape[0] == nbl_total
+        gather_ok = gather_ok and bool(all(rdzv.allgather(bool(NP.array_equal(g[idx_mine], mine[:n_real])))))
 
     if rank == 0:
         terms_total = float(nbl_total) * nchan * nsrc * K

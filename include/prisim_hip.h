@@ -359,8 +359,8 @@ int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt, int as_c64);
  * compute stream: the RCCL transfer of snapshot t overlaps the sky-sum of snapshot t+1 (xGMI copies beside VALU work).
  * prisim_hip_sync / _get_gathered / _gathered_checksum wait for it. */
 int prisim_hip_allgather_slot_async(prisim_ctx* ctx, int64_t slot, int as_c64);
-/* Copy the gathered cube to the host: out [nt][nranks][nbl_shard][nchan], complex128 or complex64
- * according to the as_c64 of the last allgather. */
+/* Copy the gathered cube to the host: out [nt][nranks][nbl_shard][nchan] -- or [nt][nbl_total][nchan] in global baseline order once a
+ * shard map is set (prisim_hip_set_shard_map) --, complex128 or complex64 according to the as_c64 of the last allgather. */
 int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out);
 /* All-gather of the RESIDENT lag spectra (prisim_hip_delay_transform_device with want_lag) of nt snapshots, device to device:
  * the FFT runs along frequency, so every rank transforms its own baseline shard and the spectra are exchanged like the
@@ -373,6 +373,16 @@ int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out);
  * interferometry.py:8349-8350): gathers [nt][3][nbl_shard][nchan] into [nt][nranks][3][nbl_shard][nchan]; read with
  * prisim_hip_get_gathered (its rows are then 3 nchan long). */
 int prisim_hip_allgather_grad(prisim_ctx* ctx, int64_t nt, int as_c64);
+/* The gathered cube in the REFERENCE'S baseline order, on the device.  Shards need not be contiguous ranges of the array (this
+ * repository deals groups of baselines round-robin so that every GPU gets its share of the long, expensive baselines, prisim_amd/sharding.py)
+ * and are padded to equal size for the exchange.  bl_index: [nranks][nbl_shard] = global baseline of local row j of rank r, negative =
+ * padding; every baseline in [0, nbl_total) must occur exactly once.  After this call every gather (allgather, allgather_slot_async,
+ * allgather_lags, allgather_grad) lands in a staging block and a copy kernel behind it, on the same stream, writes the gathered cube as
+ *   [nt][nbl_total][row]            (gradients: [nt][3][nbl_total][nchan])
+ * -- the unsharded array's order, padding dropped: what the reference's rank-0 concatenate of its _part_i files leaves
+ * (scripts/run_prisim.py:2233-2242).  prisim_hip_get_gathered / _gathered_checksum then speak of that cube.  bl_index = NULL goes back to
+ * the rank-major layout.  Needs set_array (and comm_init when nranks > 1) first; set_array with another shard size drops the map. */
+int prisim_hip_set_shard_map(prisim_ctx* ctx, const int64_t* bl_index, int64_t nbl_total);
 /* Who receives the gathered cubes of every LATER gather call (allgather, allgather_slot_async, allgather_lags, allgather_grad):
  * root = -1 (default) every rank (ncclAllGather: each GPU ends up with the whole cube, 60-120 GB at config 5); root = r only rank r
  * (grouped ncclSend / ncclRecv: SURVEY 8(e) `gather_to_root`, the layout of the reference's rank-0 concatenate, run_prisim.py:2233-2242) --
@@ -394,6 +404,8 @@ typedef struct prisim_comm_stats {
   int32_t stream_priority_lowest;        /* ... and the lowest the device offers (the compute stream runs at default priority 0) */
   int32_t nranks;
   int32_t reserved_;
+  double sum_undeal_ms;                  /* of sum_gather_ms: the un-deal copy kernels behind the gathers (0 without a shard map) */
+  double last_undeal_ms;
 } prisim_comm_stats;
 int prisim_hip_get_comm_stats(prisim_ctx* ctx, prisim_comm_stats* out, int reset);
 

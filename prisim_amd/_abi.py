@@ -31,7 +31,7 @@ EXPORTS = (
     'prisim_hip_comm_init',
     'prisim_hip_allgather', 'prisim_hip_allgather_slot_async', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
-    'prisim_hip_allgather_grad', 'prisim_hip_comm_selftest', 'prisim_hip_get_comm_stats', 'prisim_hip_set_gather_root',
+    'prisim_hip_allgather_grad', 'prisim_hip_comm_selftest', 'prisim_hip_get_comm_stats', 'prisim_hip_set_gather_root', 'prisim_hip_set_shard_map',
     'prisim_hip_host_alloc', 'prisim_hip_host_free', 'prisim_hip_get_vis_async', 'prisim_hip_wait_downloads',
     'prisim_hip_set_catalog', 'prisim_hip_set_sky_from_catalog', 'prisim_hip_catalog_roi', 'prisim_hip_observe_catalog',
     'prisim_hip_comm_version',
@@ -147,7 +147,8 @@ class PrisimTiming(C.Structure):
 class PrisimCommStats(C.Structure):
     _fields_ = [('n_gathers', C.c_int64), ('bytes_per_peer', C.c_int64), ('sum_gather_ms', C.c_double), ('last_gather_ms', C.c_double),
                 ('max_gather_ms', C.c_double), ('last_gather_after_compute_ms', C.c_double), ('stream_priority', C.c_int32),
-                ('stream_priority_lowest', C.c_int32), ('nranks', C.c_int32), ('reserved_', C.c_int32)]
+                ('stream_priority_lowest', C.c_int32), ('nranks', C.c_int32), ('reserved_', C.c_int32), ('sum_undeal_ms', C.c_double),
+                ('last_undeal_ms', C.c_double)]
 
 
 class PrisimHipError(RuntimeError):
@@ -215,6 +216,7 @@ def load_library():
     lib.prisim_hip_allgather_grad.argtypes = [vp, i64, i32]
     lib.prisim_hip_comm_selftest.argtypes = [vp, i64]
     lib.prisim_hip_set_gather_root.argtypes = [vp, i32]
+    lib.prisim_hip_set_shard_map.argtypes = [vp, vp, i64]
     lib.prisim_hip_get_comm_stats.argtypes = [vp, C.POINTER(PrisimCommStats), i32]
     lib.prisim_hip_host_alloc.argtypes = [i64, C.POINTER(vp)]
     lib.prisim_hip_host_free.argtypes = [vp]
@@ -306,6 +308,8 @@ class Context(object):
         fr = NP.ascontiguousarray(freqs_hz, dtype=NP.float64).ravel()
         self._check(self._lib.prisim_hip_set_array(self._h, _ptr(bl), bl.shape[0], _ptr(fr), fr.size, int(nt_max)),
                     'prisim_hip_set_array')
+        if getattr(self, 'nbl_total', 0) and bl.shape[0] != self.nbl:
+            self.nbl_total = 0                       # (the library drops a shard map made for another shard size)
         self.nbl, self.nchan, self.nt_max = bl.shape[0], fr.size, int(nt_max)
 
     # ---- sky ----
@@ -722,11 +726,31 @@ class Context(object):
                     'prisim_hip_allgather_slot_async')
         self._gathered_c64 = bool(complex64)
 
+    def set_shard_map(self, bl_index, nbl_total):
+        """bl_index (nranks, nbl_shard): global baseline of every local row of every rank (negative = padding), or None to go back to the
+        rank-major layout.  Afterwards every gather leaves the gathered cube in the global baseline order of the unsharded array,
+        (nt, nbl_total, row), on the device (prisim_hip_set_shard_map)."""
+        if bl_index is None:
+            self._check(self._lib.prisim_hip_set_shard_map(self._h, None, 0), 'prisim_hip_set_shard_map')
+            self.nbl_total = 0
+            return
+        m = NP.ascontiguousarray(bl_index, dtype=NP.int64)
+        if m.size != getattr(self, 'nranks', 1) * self.nbl:
+            raise ValueError('bl_index must have shape (nranks, nbl_shard)')
+        self._check(self._lib.prisim_hip_set_shard_map(self._h, _ptr(m), int(nbl_total)), 'prisim_hip_set_shard_map')
+        self.nbl_total = int(nbl_total)
+
     def get_gathered(self, nt, nranks=None, row=None):
-        """(nt, nranks, nbl_shard, row): snapshot-major, rank blocks in rank order; row = nchan (visibilities) or nout (delay spectra)."""
+        """(nt, nranks, nbl_shard, row): snapshot-major, rank blocks in rank order; row = nchan (visibilities) or nout (delay spectra).
+        With a shard map set: (nt, nbl_total, row) in global baseline order."""
         nranks = getattr(self, 'nranks', 1) if nranks is None else nranks
         row = self.nchan if row is None else int(row)
-        out = NP.empty((nt, nranks, self.nbl, row), dtype=NP.complex64 if getattr(self, '_gathered_c64', False) else NP.complex128)
+        dtype = NP.complex64 if getattr(self, '_gathered_c64', False) else NP.complex128
+        if getattr(self, 'nbl_total', 0) > 0:
+            out = NP.empty((nt, self.nbl_total, row), dtype=dtype)
+            self._check(self._lib.prisim_hip_get_gathered(self._h, int(nt), _ptr(out)), 'prisim_hip_get_gathered')
+            return out
+        out = NP.empty((nt, nranks, self.nbl, row), dtype=dtype)
         self._check(self._lib.prisim_hip_get_gathered(self._h, int(nt), _ptr(out)), 'prisim_hip_get_gathered')
         return out
 
@@ -736,8 +760,10 @@ class Context(object):
         self._gathered_c64 = bool(complex64)
 
     def get_gathered_grad(self, nt, nranks=None):
-        """(nt, nranks, 3, nbl_shard, nchan) after allgather_grad."""
+        """(nt, nranks, 3, nbl_shard, nchan) after allgather_grad; with a shard map set (nt, 3, nbl_total, nchan) in global order."""
         nranks = getattr(self, 'nranks', 1) if nranks is None else nranks
+        if getattr(self, 'nbl_total', 0) > 0:
+            return self.get_gathered(nt, nranks, row=3 * self.nchan).reshape(nt, 3, self.nbl_total, self.nchan)
         g = self.get_gathered(nt, nranks, row=3 * self.nchan)                  # rows of 3*nchan: the block is [3][nbl][nchan] per rank
         return g.reshape(nt, nranks, 3, self.nbl, self.nchan)
 

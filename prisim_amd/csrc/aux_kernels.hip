@@ -665,6 +665,36 @@ hipError_t launch_f64_to_f32(const double* in, float* out, int64_t n, hipStream_
   return hipGetLastError();
 }
 
+// Un-deal one gathered snapshot: stage [nranks][planes][nbl_shard][row words] (rank blocks as the all-gather leaves them; shards were dealt
+// round-robin in groups of baselines and padded, prisim_amd/sharding.py) -> out [planes][nbl_total][row words] in the GLOBAL baseline order
+// of the unsharded array -- the order of the reference's rank-0 concatenate (scripts/run_prisim.py:2233-2242); map[r * nbl_shard + j] =
+// global baseline of local row j of rank r, -1 = padding (dropped).  A pure copy: every word is read once and written once, rows are
+// contiguous on both sides (coalesced 8-byte words; one block per (rank row, plane)).
+__global__ __launch_bounds__(256)
+void k_undeal(const uint64_t* __restrict__ stage, uint64_t* __restrict__ out, const int64_t* __restrict__ map, int64_t nbl_shard, int64_t nbl_total,
+              int planes, int64_t row_words, int64_t nrows) {
+  for (int64_t rj = blockIdx.x; rj < nrows; rj += gridDim.x) {
+    const int64_t g = map[rj];
+    if (g < 0) continue;
+    const int64_t r = rj / nbl_shard, j = rj - r * nbl_shard;
+    const int k = blockIdx.y;
+    const uint64_t* src = stage + ((size_t)(r * planes + k) * (size_t)nbl_shard + (size_t)j) * (size_t)row_words;
+    uint64_t* dst = out + ((size_t)k * (size_t)nbl_total + (size_t)g) * (size_t)row_words;
+    for (int64_t w = threadIdx.x; w < row_words; w += blockDim.x) dst[w] = src[w];
+  }
+}
+
+hipError_t launch_undeal(const void* stage, void* out, const int64_t* map, int nranks, int64_t nbl_shard, int64_t nbl_total, int planes,
+                         int64_t row_words, hipStream_t stream) {
+  const int64_t nrows = (int64_t)nranks * nbl_shard;
+  if (nrows == 0 || row_words == 0) return hipSuccess;
+  const unsigned gx = (unsigned)std::min<int64_t>(nrows, 65535);
+  hipLaunchKernelGGL(k_undeal, dim3(gx, (unsigned)planes), dim3(256), 0, stream, (const uint64_t*)stage, (uint64_t*)out, map, nbl_shard, nbl_total,
+                     planes, row_words, nrows);
+  return hipGetLastError();
+}
+
+
 hipError_t launch_checksum(const void* data, bool is_f32, int64_t n, double* out /* [1025] device scratch: out[0]=result */,
                            hipStream_t stream) {
   if (is_f32)

@@ -254,7 +254,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   if (ctx->ev_slot_done) (void)hipEventDestroy(ctx->ev_slot_done);
   for (int i = 0; i < prisim_ctx::kCommRing; ++i)
-    for (hipEvent_t ev : {ctx->ev_gc[i], ctx->ev_g0[i], ctx->ev_g1[i]})
+    for (hipEvent_t ev : {ctx->ev_gc[i], ctx->ev_g0[i], ctx->ev_g1[i], ctx->ev_gu[i]})
       if (ev) (void)hipEventDestroy(ev);
   if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
   if (ctx->ev_copy_ready) (void)hipEventDestroy(ctx->ev_copy_ready);
@@ -262,7 +262,7 @@ void prisim_hip_destroy(prisim_ctx* ctx) {
   if (ctx->fft_plan && g_rocfft.plan_destroy) g_rocfft.plan_destroy(ctx->fft_plan);
   if (ctx->fft_info && g_rocfft.execution_info_destroy) g_rocfft.execution_info_destroy(ctx->fft_info);
   for (DevBuf* b : {&ctx->blx, &ctx->bly, &ctx->blz, &ctx->freqs, &ctx->fsq, &ctx->fsq_pairs, &ctx->cube, &ctx->grad, &ctx->dirs,
-                    &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->ext_table,
+                    &ctx->partial, &ctx->scratch, &ctx->gathered, &ctx->sendbuf, &ctx->shard_map, &ctx->stage_main, &ctx->stage_comm, &ctx->ext_table,
                     &ctx->ext_work, &ctx->ext_colmax, &ctx->sky_flux, &ctx->sky_sp, &ctx->sky_bf, &ctx->sky_flag,
                     &ctx->dl_stage, &ctx->grp_hz, &ctx->fft_work, &ctx->fft_buf, &ctx->dt_out, &ctx->dt_pow, &ctx->dt_wts, &ctx->dt_lag_all, &ctx->dt_pow_all, &ctx->dt_tw})
     release(*b);
@@ -359,6 +359,10 @@ int prisim_hip_set_array(prisim_ctx* ctx, const double* bl_enu, int64_t nbl, con
   release(ctx->grad);
   release(ctx->gathered);
   release(ctx->sendbuf);
+  release(ctx->stage_main); release(ctx->stage_comm);
+  if (ctx->nbl_total > 0 && (int64_t)ctx->shard_map_h.size() != (int64_t)ctx->nranks * nbl) {   // a shard map is per shard size
+    ctx->nbl_total = 0; ctx->shard_map_h.clear(); release(ctx->shard_map);
+  }
   release(ctx->dt_lag_all);
   release(ctx->dt_pow_all);
   ctx->dt_nt = ctx->dt_nout = 0;
@@ -1756,10 +1760,12 @@ int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int ra
   });
 }
 
-// Gather snapshot `slot` of every rank into gathered[slot][rank][b][row] on stream `st`.  src_all: this rank's [nt][nbl][row] complex128
-// (the visibility cube or the resident lag spectra), row = reals / 2 per baseline.
-static int gather_one_slot(prisim_ctx* ctx, const double* src_all, int64_t row, int64_t slot, int as_c64, hipStream_t st) {
-  const size_t shard = (size_t)ctx->nbl * row * 2;   // reals per snapshot shard
+// Gather snapshot `slot` of every rank on stream `st`.  src_all: this rank's [nt][planes][nbl][row] complex128 (the visibility cube, the
+// resident lag spectra, or the gradient cube with planes = 3).  Without a shard map the snapshot lands in gathered[slot][rank][planes][b][row]
+// (rank blocks as the all-gather leaves them); with one (prisim_hip_set_shard_map) it lands in a staging block of that stream and the
+// un-deal kernel behind it writes gathered[slot][planes][global baseline][row] -- the reference's order (run_prisim.py:2233-2242).
+static int gather_one_slot(prisim_ctx* ctx, const double* src_all, int64_t row, int planes, int64_t slot, int as_c64, hipStream_t st, int ring = -1) {
+  const size_t shard = (size_t)ctx->nbl * row * 2 * (size_t)planes;   // reals per snapshot shard
   const size_t esz = as_c64 ? sizeof(float) : sizeof(double);
   const double* src = src_all + (size_t)slot * shard;
   const void* send = src;
@@ -1769,44 +1775,67 @@ static int gather_one_slot(prisim_ctx* ctx, const double* src_all, int64_t row, 
     send = sb;
   }
   const bool receiver = ctx->gather_root < 0 || ctx->gather_root == ctx->rank;
-  char* dst = receiver ? (char*)ctx->gathered.p + (size_t)slot * shard * (size_t)ctx->nranks * esz : nullptr;
+  const bool ordered = ctx->nbl_total > 0;
+  char* dst = nullptr;
+  if (receiver) {
+    if (ordered) {
+      DevBuf& stage = (st == ctx->comm_stream && ctx->comm_stream) ? ctx->stage_comm : ctx->stage_main;
+      int rc;
+      if ((rc = ensure(ctx, stage, shard * (size_t)ctx->nranks * esz))) return rc;
+      dst = (char*)stage.p;
+    } else {
+      dst = (char*)ctx->gathered.p + (size_t)slot * shard * (size_t)ctx->nranks * esz;
+    }
+  }
   if (ctx->nranks == 1 && !ctx->comm) {
     HIPCHK(ctx, hipMemcpyAsync(dst, send, shard * esz, hipMemcpyDeviceToDevice, st));
-    return PRISIM_OK;
-  }
-  if (!ctx->comm) return fail(ctx, PRISIM_ESTATE, "comm_init has not been called");
-  const ncclDataType_t ty = as_c64 ? ncclFloat : ncclDouble;
-  if (ctx->gather_root < 0) {
-    ncclResult_t r = g_rccl.AllGather(send, dst, shard, ty, ctx->comm, st);
-    if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
-    return PRISIM_OK;
-  }
-  // gather to ONE rank (SURVEY 8(e) `gather_to_root`): the other GPUs keep no copy of the whole cube -- 120 GB at config 5.  One
-  // grouped call: the root posts a receive per peer into that peer's block, every other rank one send; the root's own block is a copy.
-  if (!g_rccl.Send) return fail(ctx, PRISIM_ELIB, "this librccl has no ncclSend / ncclRecv: gather to a root is unavailable");
-  ncclResult_t r = g_rccl.GroupStart();
-  if (r == ncclSuccess) {
-    if (receiver) {
-      for (int q = 0; q < ctx->nranks && r == ncclSuccess; ++q)
-        if (q != ctx->rank) r = g_rccl.Recv(dst + (size_t)q * shard * esz, shard, ty, q, ctx->comm, st);
+  } else {
+    if (!ctx->comm) return fail(ctx, PRISIM_ESTATE, "comm_init has not been called");
+    const ncclDataType_t ty = as_c64 ? ncclFloat : ncclDouble;
+    if (ctx->gather_root < 0) {
+      ncclResult_t r = g_rccl.AllGather(send, dst, shard, ty, ctx->comm, st);
+      if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
     } else {
-      r = g_rccl.Send(send, shard, ty, ctx->gather_root, ctx->comm, st);
+      // gather to ONE rank (SURVEY 8(e) `gather_to_root`): the other GPUs keep no copy of the whole cube -- 120 GB at config 5.  One
+      // grouped call: the root posts a receive per peer into that peer's block, every other rank one send; the root's own block is a copy.
+      if (!g_rccl.Send) return fail(ctx, PRISIM_ELIB, "this librccl has no ncclSend / ncclRecv: gather to a root is unavailable");
+      ncclResult_t r = g_rccl.GroupStart();
+      if (r == ncclSuccess) {
+        if (receiver) {
+          for (int q = 0; q < ctx->nranks && r == ncclSuccess; ++q)
+            if (q != ctx->rank) r = g_rccl.Recv(dst + (size_t)q * shard * esz, shard, ty, q, ctx->comm, st);
+        } else {
+          r = g_rccl.Send(send, shard, ty, ctx->gather_root, ctx->comm, st);
+        }
+        const ncclResult_t r2 = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+      }
+      if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclSend/ncclRecv (gather to root): ") + g_rccl.GetErrorString(r));
+      if (receiver) HIPCHK(ctx, hipMemcpyAsync(dst + (size_t)ctx->rank * shard * esz, send, shard * esz, hipMemcpyDeviceToDevice, st));
     }
-    const ncclResult_t r2 = g_rccl.GroupEnd();
-    if (r == ncclSuccess) r = r2;
   }
-  if (r != ncclSuccess) return fail(ctx, PRISIM_ELIB, std::string("ncclSend/ncclRecv (gather to root): ") + g_rccl.GetErrorString(r));
-  if (receiver) HIPCHK(ctx, hipMemcpyAsync(dst + (size_t)ctx->rank * shard * esz, send, shard * esz, hipMemcpyDeviceToDevice, st));
+  if (ordered && receiver) {
+    if (ring >= 0) HIPCHK(ctx, hipEventRecord(ctx->ev_gu[ring], st));
+    const size_t row_words = (size_t)row * 2 * esz / 8;               // a row of complex numbers in 8-byte words
+    char* out = (char*)ctx->gathered.p + (size_t)slot * (size_t)planes * (size_t)ctx->nbl_total * row_words * 8;
+    HIPCHK(ctx, launch_undeal(dst, out, (const int64_t*)ctx->shard_map.p, ctx->nranks, ctx->nbl, ctx->nbl_total, planes, (int64_t)row_words, st));
+  }
   return PRISIM_OK;
+}
+
+// bytes of the gathered cube for nt snapshots of rows of `row` complex numbers (x planes)
+static size_t gathered_bytes(const prisim_ctx* ctx, int64_t nt, int64_t row_total, bool c64) {
+  const size_t esz = c64 ? sizeof(float) : sizeof(double);
+  const size_t rows = ctx->nbl_total > 0 ? (size_t)ctx->nbl_total : (size_t)ctx->nbl * (size_t)ctx->nranks;
+  return (size_t)nt * rows * (size_t)row_total * 2 * esz;
 }
 
 static int ensure_gather_buffers(prisim_ctx* ctx, int64_t row, int as_c64) {
   const size_t shard = (size_t)ctx->nbl * row * 2;
-  const size_t esz = as_c64 ? sizeof(float) : sizeof(double);
   int rc;
   if (ctx->gathered.p && (ctx->gathered_c64 != (as_c64 != 0) || ctx->gathered_row != row)) release(ctx->gathered);
   const bool receiver = ctx->gather_root < 0 || ctx->gather_root == ctx->rank;       // only receivers hold the whole cube
-  if ((rc = ensure(ctx, ctx->gathered, receiver ? shard * (size_t)ctx->nt_max * (size_t)ctx->nranks * esz : 16))) return rc;
+  if ((rc = ensure(ctx, ctx->gathered, receiver ? gathered_bytes(ctx, ctx->nt_max, row, as_c64 != 0) : 16))) return rc;
   if (as_c64 && (rc = ensure(ctx, ctx->sendbuf, shard * (size_t)ctx->nt_max * sizeof(float)))) return rc;
   ctx->gathered_c64 = as_c64 != 0;
   ctx->gathered_row = row;
@@ -1823,7 +1852,7 @@ int prisim_hip_allgather(prisim_ctx* ctx, int64_t nt, int as_c64) {
   if (ctx->comm_stream && ctx->comm_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
   if ((rc = ensure_gather_buffers(ctx, ctx->nchan, as_c64))) return rc;
   for (int64_t t = 0; t < nt; ++t)
-    if ((rc = gather_one_slot(ctx, (const double*)ctx->cube.p, ctx->nchan, t, as_c64, ctx->stream))) return rc;
+    if ((rc = gather_one_slot(ctx, (const double*)ctx->cube.p, ctx->nchan, 1, t, as_c64, ctx->stream))) return rc;
   return PRISIM_OK;
   });
 }
@@ -1839,7 +1868,7 @@ int prisim_hip_allgather_lags(prisim_ctx* ctx, int64_t nt) {
   if (ctx->comm_stream && ctx->comm_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
   if ((rc = ensure_gather_buffers(ctx, ctx->dt_nout, 0))) return rc;
   for (int64_t t = 0; t < nt; ++t)
-    if ((rc = gather_one_slot(ctx, (const double*)ctx->dt_lag_all.p, ctx->dt_nout, t, 0, ctx->stream))) return rc;
+    if ((rc = gather_one_slot(ctx, (const double*)ctx->dt_lag_all.p, ctx->dt_nout, 1, t, 0, ctx->stream))) return rc;
   return PRISIM_OK;
   });
 }
@@ -1868,7 +1897,7 @@ int prisim_hip_allgather_slot_async(prisim_ctx* ctx, int64_t slot, int as_c64) {
   HIPCHK(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_gc[ri], 0));
   // ... and runs on the (highest-priority) communication stream, overlapping the next snapshot's compute
   HIPCHK(ctx, hipEventRecord(ctx->ev_g0[ri], ctx->comm_stream));
-  if ((rc = gather_one_slot(ctx, (const double*)ctx->cube.p, ctx->nchan, slot, as_c64, ctx->comm_stream))) return rc;
+  if ((rc = gather_one_slot(ctx, (const double*)ctx->cube.p, ctx->nchan, 1, slot, as_c64, ctx->comm_stream, ri))) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->ev_g1[ri], ctx->comm_stream));
   ctx->cring_head = (ctx->cring_head + 1) % prisim_ctx::kCommRing;
   ctx->cring_pending += 1;
@@ -1886,8 +1915,7 @@ int prisim_hip_get_gathered(prisim_ctx* ctx, int64_t nt, void* out) {
   if (!ctx->gathered.p) return fail(ctx, PRISIM_ESTATE, "allgather has not been called");
   if (ctx->gather_root >= 0 && ctx->gather_root != ctx->rank) return fail(ctx, PRISIM_ESTATE, "the cube was gathered to another rank (set_gather_root)");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  const size_t esz = ctx->gathered_c64 ? sizeof(float) : sizeof(double);
-  const size_t bytes = (size_t)nt * ctx->nbl * ctx->gathered_row * 2 * (size_t)ctx->nranks * esz;
+  const size_t bytes = gathered_bytes(ctx, nt, ctx->gathered_row, ctx->gathered_c64);
   if (nt <= 0 || bytes > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt does not match the gathered cube");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->comm_stream) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
@@ -1904,7 +1932,7 @@ int prisim_hip_gathered_checksum(prisim_ctx* ctx, int64_t nt, double* out) {
   if (ctx->gather_root >= 0 && ctx->gather_root != ctx->rank) return fail(ctx, PRISIM_ESTATE, "the cube was gathered to another rank (set_gather_root)");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t esz = ctx->gathered_c64 ? sizeof(float) : sizeof(double);
-  const int64_t n = nt * ctx->nbl * ctx->gathered_row * 2 * (int64_t)ctx->nranks;
+  const int64_t n = (int64_t)(gathered_bytes(ctx, nt, ctx->gathered_row, ctx->gathered_c64) / esz);
   if (nt <= 0 || (size_t)n * esz > ctx->gathered.bytes) return fail(ctx, PRISIM_EINVAL, "nt does not match the gathered cube");
   int rc;
   if ((rc = ensure(ctx, ctx->scratch, 1025 * sizeof(double)))) return rc;
@@ -1928,7 +1956,45 @@ int prisim_hip_allgather_grad(prisim_ctx* ctx, int64_t nt, int as_c64) {
   // a snapshot's gradient block is [3][nbl][nchan]: the same exchange with rows of 3 nchan -> gathered [nt][nranks][3][nbl][nchan]
   if ((rc = ensure_gather_buffers(ctx, 3 * ctx->nchan, as_c64))) return rc;
   for (int64_t t = 0; t < nt; ++t)
-    if ((rc = gather_one_slot(ctx, (const double*)ctx->grad.p, 3 * ctx->nchan, t, as_c64, ctx->stream))) return rc;
+    if ((rc = gather_one_slot(ctx, (const double*)ctx->grad.p, ctx->nchan, 3, t, as_c64, ctx->stream))) return rc;
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_set_shard_map(prisim_ctx* ctx, const int64_t* bl_index, int64_t nbl_total) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return PRISIM_EINVAL;
+  if (!ctx->array_set) return fail(ctx, PRISIM_ESTATE, "set_array (and comm_init on more than one rank) must be called before set_shard_map");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->nranks * (size_t)ctx->nbl;
+  std::vector<int64_t> map;
+  if (bl_index) {
+    if (nbl_total <= 0 || (size_t)nbl_total > n) return fail(ctx, PRISIM_EINVAL, "nbl_total must be in [1, nranks x nbl_shard]");
+    // every global baseline exactly once; anything else is padding (-1)
+    std::vector<uint8_t> seen((size_t)nbl_total, 0);
+    map.assign(bl_index, bl_index + n);
+    for (size_t i = 0; i < n; ++i) {
+      if (map[i] < 0) { map[i] = -1; continue; }
+      if (map[i] >= nbl_total) return fail(ctx, PRISIM_EINVAL, "shard map: global baseline index out of range");
+      if (seen[(size_t)map[i]]) return fail(ctx, PRISIM_EINVAL, "shard map: a global baseline is listed twice (padding rows must be -1)");
+      seen[(size_t)map[i]] = 1;
+    }
+    for (int64_t g = 0; g < nbl_total; ++g)
+      if (!seen[(size_t)g]) return fail(ctx, PRISIM_EINVAL, "shard map: a global baseline is missing");
+  }
+  // gathers in flight use the old layout
+  if (ctx->comm_stream && ctx->comm_pending) { HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream)); ctx->comm_pending = false; }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  release(ctx->gathered);                  // its layout follows the map
+  if (!bl_index) {
+    ctx->nbl_total = 0; ctx->shard_map_h.clear(); release(ctx->shard_map);
+    return PRISIM_OK;
+  }
+  int rc;
+  if ((rc = ensure(ctx, ctx->shard_map, n * sizeof(int64_t)))) return rc;
+  HIPCHK(ctx, hipMemcpy(ctx->shard_map.p, map.data(), n * sizeof(int64_t), hipMemcpyHostToDevice));
+  ctx->shard_map_h.swap(map);
+  ctx->nbl_total = nbl_total;
   return PRISIM_OK;
   });
 }
@@ -1998,6 +2064,7 @@ int prisim_hip_get_comm_stats(prisim_ctx* ctx, prisim_comm_stats* out, int reset
   if (reset) {
     ctx->cstats.n_gathers = 0;
     ctx->cstats.sum_gather_ms = ctx->cstats.max_gather_ms = ctx->cstats.last_gather_ms = ctx->cstats.last_gather_after_compute_ms = 0.0;
+    ctx->cstats.sum_undeal_ms = ctx->cstats.last_undeal_ms = 0.0;
   }
   return PRISIM_OK;
   });

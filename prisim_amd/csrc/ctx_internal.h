@@ -249,6 +249,12 @@ struct prisim_ctx {
   bool dt_have_lag = false, dt_have_pow = false;
   hipEvent_t ev_d0 = nullptr, ev_d1 = nullptr;
   int64_t gathered_row = 0;         // row length of the gathered cube (nchan for visibilities, nout for delay spectra)
+  // shard map (prisim_hip_set_shard_map): with it every gather lands in a per-stream staging block and is un-dealt into the gathered
+  // cube in GLOBAL baseline order, [nt][planes][nbl_total][row]; without it the cube keeps the rank-major layout of the all-gather
+  std::vector<int64_t> shard_map_h; // [nranks][nbl] global baseline of every (rank, local row); -1 = padding
+  DevBuf shard_map, stage_main, stage_comm;
+  int64_t nbl_total = 0;            // > 0: the map is set
+  hipEvent_t ev_gu[32] = {};        // between a gather and its un-deal kernel (communication-stream ring, as ev_g0 / ev_g1)
 };
 
 namespace pint {
@@ -423,6 +429,10 @@ inline void harvest_comm(prisim_ctx* ctx, bool wait_all) {
     // what the overlap did not hide of THIS gather: its end against the compute-stream marker recorded when it was enqueued
     // (= the end of the snapshot's own sky-sum); only the last harvested entry is kept -- the gathers before it ran under later compute
     if (hipEventElapsedTime(&ms, ctx->ev_gc[i], ctx->ev_g1[i]) == hipSuccess) ctx->cstats.last_gather_after_compute_ms = ms;
+    if (ctx->nbl_total > 0 && hipEventElapsedTime(&ms, ctx->ev_gu[i], ctx->ev_g1[i]) == hipSuccess) {
+      ctx->cstats.last_undeal_ms = ms;
+      ctx->cstats.sum_undeal_ms += ms;
+    }
     ctx->cring_pending -= 1;
   }
 }
@@ -446,6 +456,7 @@ inline int ensure_comm_stream(prisim_ctx* ctx) {
     HIPCHK(ctx, hipEventCreate(&ctx->ev_gc[i]));
     HIPCHK(ctx, hipEventCreate(&ctx->ev_g0[i]));
     HIPCHK(ctx, hipEventCreate(&ctx->ev_g1[i]));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev_gu[i]));
   }
   return PRISIM_OK;
 }

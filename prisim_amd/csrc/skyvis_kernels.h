@@ -231,5 +231,7 @@ hipError_t launch_noise(const double* rms, double* out, int64_t nbl, int64_t nch
                         hipStream_t stream);
 hipError_t launch_checksum(const void* data, bool is_f32, int64_t n, double* out, hipStream_t stream);
 hipError_t launch_f64_to_f32(const double* in, float* out, int64_t n, hipStream_t stream);
+hipError_t launch_undeal(const void* stage, void* out, const int64_t* map /*[nranks][nbl_shard] device*/, int nranks, int64_t nbl_shard,
+                         int64_t nbl_total, int planes, int64_t row_words, hipStream_t stream);
 
 }  // namespace prisim

@@ -339,14 +339,21 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     nbl_total = bl.shape[0]
     # :1775-1791 cuts contiguous chunks; here groups of baselines are dealt round-robin (prisim_amd/sharding.py): the list is sorted by
     # length and long baselines cost more (and are what the taper culling shortens), so every rank gets its share of them; shards are
-    # padded to equal size for the all-gather and the gathered cubes are put back into the global order (SH.unshard_rows)
+    # padded to equal size for the all-gather and the gathered cubes are put back into the global order on the receiving GPU (shard map)
     bl_mine, idx_mine, n_real = SH.shard_rows(bl, world, rank)
     per = bl_mine.shape[0]
     labels_mine = [labels[i] for i in idx_mine] + ['pad'] * (per - n_real)
     idx_padded = NP.concatenate((idx_mine, NP.full(per - n_real, nbl_total - 1, dtype=NP.int64)))     # padding rows repeat the last baseline
 
+    # every rank's rows of the padded shards in the global numbering (-1 = padding): with it the receiving GPU puts each gathered cube
+    # into the reference's baseline order itself (prisim_hip_set_shard_map; rank-0 concatenate order of run_prisim.py:2233-2242)
+    shard_map = NP.full((world, per), -1, dtype=NP.int64)
+    for r in range(world):
+        idx_r = SH.shard_index(nbl_total, world, r)
+        shard_map[r, :idx_r.size] = idx_r
+
     def unshard(gathered):
-        return None if gathered is None else SH.unshard_rows(gathered, nbl_total, world)
+        return gathered                         # already (nbl_total, ...) in global order
     tel = telescope_dict(parms)
     skymod = build_skymodel(parms, infile_dir)
     jd, lst, hadec, t_acc, n_acc = schedule(parms)
@@ -365,6 +372,8 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
     # unsharded runs hand the cube to the host (files, the caller): each snapshot's download is queued under the next one's sky-sum;
     # sharded runs gather on the device and never copy their own shard
     ia.reserve(n_acc, host_staging=(world == 1))
+    if world > 1:
+        ia.set_shard_map(shard_map, nbl_total)
     if world > 1:
         if comm_uid is None:
             raise ValueError('comm_uid is needed when world > 1')
@@ -455,7 +464,7 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         if ia.gradient_mode is not None:
             # the gradient cubes are per baseline too: gathered like the visibilities (interferometry.py:8349-8350 concatenates them)
             g = ia.allgather_gradient(world, download=download)
-            grad_all = {ia.gradient_mode: NP.moveaxis(unshard(NP.moveaxis(g, 1, 0)), 0, 1)} if g is not None else None
+            grad_all = {ia.gradient_mode: g} if g is not None else None       # (3, nbl_total, nchan, n_acc), global order
     else:
         cube, labels_all, bl_all = ia.skyvis_freq[:nbl_total], labels, bl
         grad_all = {k: v[:, :nbl_total] for k, v in ia.gradient.items()} if ia.gradient_mode is not None else None

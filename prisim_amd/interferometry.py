@@ -607,14 +607,51 @@ class InterferometerArray(object):
             if selftest:
                 self._ctx.comm_selftest()
             self._comm_ready = True
+        self._apply_shard_map()
         return True
+
+    def set_shard_map(self, bl_index, nbl_total):
+        """This array is one baseline shard of a larger array: bl_index (nranks, nbl_shard) = global baseline of every (padded) local row of
+        every rank, negative = padding.  With it every gather (allgather, allgather_lags, allgather_gradient, allgather_cube) leaves -- and
+        returns -- the cube in the GLOBAL baseline order of the unsharded array, padding dropped, put in order by a copy kernel on the
+        receiving GPU (prisim_hip_set_shard_map): the order of the reference's rank-0 concatenate (scripts/run_prisim.py:2233-2242).
+        Without it the gathered cubes are rank-major (nranks * nbl_shard rows)."""
+        if bl_index is None:
+            self._shard_map = None
+        else:
+            m = NP.ascontiguousarray(bl_index, dtype=NP.int64)
+            if m.ndim != 2 or m.shape[1] != self.baselines.shape[0]:
+                raise ValueError('bl_index must have shape (nranks, nbl_shard)')
+            self._shard_map = (m, int(nbl_total))
+        self._shard_map_applied = False
+        if getattr(self, '_comm_ready', False):
+            self._apply_shard_map()
+
+    def _apply_shard_map(self):
+        if getattr(self, '_shard_map_applied', True):
+            return
+        sm = getattr(self, '_shard_map', None)
+        if sm is None:
+            self._ctx.set_shard_map(None, 0)
+        else:
+            self._ctx.set_shard_map(sm[0], sm[1])
+        self._shard_map_applied = True
+
+    def _gathered_cube(self, g, nranks, row):
+        """The host copy of a gathered cube, baseline axis first like every cube of the class: (rows, row, nt) with rows = nbl_total in
+        global order when a shard map is set, nranks * nbl_shard (rank-major) otherwise."""
+        nt = g.shape[0]
+        if getattr(self, '_shard_map', None) is not None:
+            return NP.transpose(g, (1, 2, 0))                         # [t][global baseline][row]
+        return NP.transpose(g.reshape(nt, nranks * self.baselines.shape[0], row), (1, 2, 0))
 
     def comm_selftest(self):
         self._ctx.comm_selftest()
 
     def allgather(self, comm_uid, nranks, rank, download=True, root=None):
         """One RCCL all-gather of the baseline shards of all ranks (equal shard sizes; replaces the reference's per-rank
-        part files + rank-0 concatenate, scripts/run_prisim.py:2207, 2233-2242).  Returns (nranks*nbl, nchan, n_acc), or None with
+        part files + rank-0 concatenate, scripts/run_prisim.py:2207, 2233-2242).  Returns (nranks*nbl, nchan, n_acc) rank-major -- or, with
+        set_shard_map(), (nbl_total, nchan, n_acc) in the global baseline order, put in order on the device --, or None with
         download=False (the gathered cube then stays in HBM only: a rank that writes nothing need not pull it over PCIe).
         root = r: this and every later gather of this array (lags, gradients, noise) deliver to rank r ONLY -- the other GPUs keep no
         copy of the whole cube (SURVEY 8(e) gather_to_root); download must then be False everywhere else."""
@@ -630,8 +667,7 @@ class InterferometerArray(object):
         self._ctx.allgather(self.n_acc, complex64=c64)
         if not download:
             return None
-        g = self._ctx.get_gathered(self.n_acc, nranks)                 # [t][rank][b][f]
-        return NP.transpose(g.reshape(self.n_acc, nranks * self.baselines.shape[0], self.channels.size), (1, 2, 0))
+        return self._gathered_cube(self._ctx.get_gathered(self.n_acc, nranks), nranks, self.channels.size)      # [t][rank][b][f] | [t][bl][f]
 
     def allgather_lags(self, nranks, download=True):
         """All-gather of the delay spectra of the baseline shards (the FFT is along frequency, so every rank transforms
@@ -646,8 +682,7 @@ class InterferometerArray(object):
             self._ctx.allgather_lags(nt)
             if not download:
                 return None
-            g = self._ctx.get_gathered(nt, nranks, row=nout)            # [t][rank][b][lag]
-            return NP.transpose(g.reshape(nt, nranks * self.baselines.shape[0], nout), (1, 2, 0))
+            return self._gathered_cube(self._ctx.get_gathered(nt, nranks, row=nout), nranks, nout)             # [t][rank][b][lag] | [t][bl][lag]
         if self.skyvis_lag is None:
             raise RuntimeError('delay_transform() must be called first')
         if self.skyvis_lag.shape != (self.baselines.shape[0], self.channels.size, self.n_acc):
@@ -668,7 +703,9 @@ class InterferometerArray(object):
         self._ctx.allgather_grad(self.n_acc, complex64=c64)
         if not download:
             return None
-        g = self._ctx.get_gathered_grad(self.n_acc, nranks)             # [t][rank][k][b][f]
+        g = self._ctx.get_gathered_grad(self.n_acc, nranks)             # [t][rank][k][b][f], or [t][k][global baseline][f] with a shard map
+        if getattr(self, '_shard_map', None) is not None:
+            return NP.transpose(g, (1, 2, 3, 0))
         nbl, nchan = self.baselines.shape[0], self.channels.size
         return NP.transpose(g, (2, 1, 3, 4, 0)).reshape(3, nranks * nbl, nchan, self.n_acc)
 
@@ -690,7 +727,7 @@ class InterferometerArray(object):
             self._ctx.set_vis(NP.asarray(self.skyvis_freq[:, :, t], dtype=NP.complex128), slot=t)
         if g is None:
             return None
-        return NP.transpose(g.reshape(self.n_acc, nranks * self.baselines.shape[0], self.channels.size), (1, 2, 0))
+        return self._gathered_cube(g, nranks, self.channels.size)
 
     # ------------------------------------------------------------------------------------------
     def _broadcast_bl_chan(self, value, what, lo, hi):

@@ -25,7 +25,40 @@ def _host_allgather(arr):
     return [NP.frombuffer(p, dtype=a.dtype).reshape(a.shape).copy() for p in parts]
 
 
-class OracleContext(object):
+class _HostShardMap(object):
+    """Host statement of prisim_hip_set_shard_map + the un-deal kernel for the stand-in contexts: gathered cubes in the global baseline
+    order of the unsharded array, padding rows (negative entries) dropped."""
+    nbl_total = 0
+    _smap = None
+
+    def set_shard_map(self, bl_index, nbl_total):
+        if bl_index is None:
+            self._smap, self.nbl_total = None, 0
+            return
+        m = NP.asarray(bl_index, dtype=NP.int64)
+        assert m.ndim == 2 and m.shape == (getattr(self, 'nranks', 1), self.nbl), (m.shape, getattr(self, 'nranks', 1), self.nbl)
+        real = m[m >= 0]
+        assert NP.array_equal(NP.sort(real), NP.arange(nbl_total))
+        self._smap, self.nbl_total = m, int(nbl_total)
+
+    def _undeal(self, g, bl_axis):
+        """g: [t][rank]...[b]...: rank axis 1, local baseline axis `bl_axis` -> the rank axis dropped, baseline axis global."""
+        if self._smap is None:
+            return g
+        shape = list(g.shape)
+        del shape[1]
+        shape[bl_axis - 1] = self.nbl_total
+        out = NP.empty(shape, dtype=g.dtype)
+        for r in range(self._smap.shape[0]):
+            keep = self._smap[r] >= 0
+            src = NP.take(g[:, r], NP.flatnonzero(keep), axis=bl_axis - 1)
+            idx = [slice(None)] * out.ndim
+            idx[bl_axis - 1] = self._smap[r][keep]
+            out[tuple(idx)] = src
+        return out
+
+
+class OracleContext(_HostShardMap):
     def __init__(self, device=0):
         self.nbl = self.nchan = self.nt_max = self.nsrc = 0
         self._timing = {'last_terms': 0, 'last_delay_ms': 0.0, 'last_delay_fused': 0, 'last_chan_tile': 0, 'last_nsplit': 1,
@@ -179,14 +212,14 @@ class OracleContext(object):
         self._gathered = NP.stack(parts, axis=1)                              # [t][rank][b][f]
 
     def get_gathered(self, nt, nranks=None, row=None):
-        return self._gathered[:nt]
+        return self._undeal(self._gathered[:nt], 2)
 
     def allgather_grad(self, nt, complex64=False):
         mine = NP.stack([self._grad[t] for t in range(nt)])                   # [t][k][b][f]
         self._gathered_grad = NP.stack(_host_allgather(mine), axis=1)         # [t][rank][k][b][f]
 
     def get_gathered_grad(self, nt, nranks=None):
-        return self._gathered_grad[:nt]
+        return self._undeal(self._gathered_grad[:nt], 3)
 
     def comm_selftest(self, nbytes=1 << 20):
         got = _host_allgather(NP.full(4, self.rank, dtype=NP.int32))
@@ -249,7 +282,7 @@ def _altaz(dircos):
     return NP.stack((alt, az), axis=1)
 
 
-class HostCommContext(_abi.Context):
+class HostCommContext(_HostShardMap, _abi.Context):
     """The real GPU context; only the exchange goes through the host (socket rendezvous), so that two ranks can share one GPU."""
 
     def comm_init(self, uid, nranks, rank):
@@ -271,11 +304,11 @@ class HostCommContext(_abi.Context):
         self._gathered_grad_host = NP.stack(_host_allgather(mine), axis=1)
 
     def get_gathered_grad(self, nt, nranks=None):
-        return self._gathered_grad_host[:nt]
+        return self._undeal(self._gathered_grad_host[:nt], 3)
 
     def comm_selftest(self, nbytes=1 << 20):
         got = _host_allgather(NP.full(4, self.rank, dtype=NP.int32))
         assert [int(g[0]) for g in got] == list(range(self.nranks))
 
     def get_gathered(self, nt, nranks=None, row=None):
-        return self._gathered_host[:nt]
+        return self._undeal(self._gathered_host[:nt], 2)

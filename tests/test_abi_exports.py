@@ -47,8 +47,8 @@ def test_struct_layouts_match_header():
     # prisim_timing: 3 double, 2 int64, 6 int32, 1 double, 2 int32, 1 double, 2 int32 -> 96 bytes
     assert C.sizeof(_abi.PrisimTiming) == 96 and _abi.PrisimTiming.last_batch_snapshots.offset == 88 and _abi.PrisimTiming.last_delay_ms.offset == 64 and _abi.PrisimTiming.last_taper_split.offset == 72
     assert _abi.PrisimTiming.last_culled_fraction.offset == 80
-    # prisim_comm_stats: 2 int64, 4 double, 4 int32 -> 64 bytes
-    assert C.sizeof(_abi.PrisimCommStats) == 64 and _abi.PrisimCommStats.stream_priority.offset == 48
+    # prisim_comm_stats: 2 int64, 4 double, 4 int32, 2 double -> 80 bytes
+    assert C.sizeof(_abi.PrisimCommStats) == 80 and _abi.PrisimCommStats.stream_priority.offset == 48 and _abi.PrisimCommStats.sum_undeal_ms.offset == 64
     # prisim_catalog: int64, 2 int32, 3 ptr, double, 3 ptr -> 72 bytes; prisim_obs: 2 double, 4 int32, double, ptr -> 48;
     # prisim_snapshot: 7 double, 2 int32, 12 double -> 160
     assert C.sizeof(_abi.PrisimCatalog) == 72 and _abi.PrisimCatalog.location.offset == 16 and _abi.PrisimCatalog.unitvec.offset == 64

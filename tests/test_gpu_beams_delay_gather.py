@@ -862,3 +862,70 @@ def test_sharded_run_gathers_visibilities_then_delay_spectra():
     assert NP.max(NP.abs(lags - ref_lag)) <= 1e-10 * NP.max(NP.abs(ref_lag))
     for t in range(2):                                                 # the visibilities are back in their slots afterwards
         assert NP.array_equal(ia._ctx.get_vis(slot=t), ia.skyvis_freq[:, :, t])
+
+
+def test_shard_map_puts_every_gathered_cube_into_global_baseline_order(ctx):
+    """prisim_hip_set_shard_map on one rank (with the box's RCCL): the shard's rows are a shuffled, padded listing of a 61-baseline array;
+    after every kind of gather -- whole cube, complex64 on the wire, per-slot on the communication stream, to a root, delay spectra,
+    gradients -- the gathered cube on the device is [nt][nbl_total][row] in the array's own order with the padding rows dropped
+    (scripts/run_prisim.py:2233-2242: what the rank-0 concatenate leaves).  Multi-rank: tests/test_gpu_multirank_standin.py."""
+    rng = NP.random.default_rng(17)
+    nbl_total, nbl, nchan, nt = 61, 70, 32, 3
+    ch = 150e6 + NP.arange(nchan) * 1.0e5
+    smap = NP.full(nbl, -1, dtype=NP.int64)
+    rows = rng.permutation(nbl)[:nbl_total]                       # the local rows that are real; the other 9 are padding
+    smap[rows] = rng.permutation(nbl_total)
+    real = smap >= 0
+    bl = rng.uniform(-100, 100, (nbl, 3))
+    s = O.altaz2dircos(NP.stack((rng.uniform(20, 90, 40), rng.uniform(0, 360, 40)), 1))
+    p = rng.uniform(0, 3, (40, nchan))
+    zen = NP.array([0.0, 0.0, 1.0])
+
+    def ordered(local):                                           # (..., nbl, row) -> (..., nbl_total, row)
+        out = NP.empty(local.shape[:-2] + (nbl_total, local.shape[-1]), dtype=local.dtype)
+        out[..., smap[real], :] = local[..., real, :]
+        return out
+    c = _abi.Context(0)
+    try:
+        c.set_array(bl, ch, nt_max=nt)
+        c.comm_init(_abi.Context.comm_unique_id(), 1, 0)
+        with pytest.raises(ValueError):
+            c.set_shard_map(NP.zeros((1, nbl), dtype=NP.int64), nbl_total)           # a baseline listed twice
+        bad = smap.copy(); bad[rows[0]] = -1
+        with pytest.raises(ValueError):
+            c.set_shard_map(bad[None, :], nbl_total)                                  # a baseline missing
+        c.set_shard_map(smap[None, :], nbl_total)
+        c.set_sky(s, p, zen)
+        c.comm_stats(reset=True)
+        for t in range(nt):
+            c.compute(want_grad=True, slot=t)
+            c.allgather_slot_async(t)                             # gather + un-deal on the communication stream, under the next sky-sum
+        c.sync()
+        vis = NP.stack([c.get_vis(slot=t) for t in range(nt)])
+        grad = NP.stack([c.get_vis(slot=t, want_grad=True)[1] for t in range(nt)])
+        g = c.get_gathered(nt)
+        assert g.shape == (nt, nbl_total, nchan) and NP.array_equal(g, ordered(vis))
+        st = c.comm_stats()
+        assert st['n_gathers'] == nt and 0.0 < st['sum_undeal_ms'] < st['sum_gather_ms'] and st['last_undeal_ms'] > 0.0
+        assert abs(c.gathered_checksum(nt) - (g.real.sum() + g.imag.sum())) <= 1e-9 * NP.abs(g).sum()
+        c.allgather(nt, complex64=True)
+        g32 = c.get_gathered(nt)
+        assert g32.dtype == NP.complex64 and NP.array_equal(g32, ordered(vis.astype(NP.complex64)))
+        c.set_gather_root(0)
+        c.allgather(nt)
+        assert NP.array_equal(c.get_gathered(nt), ordered(vis))
+        c.set_gather_root(None)
+        c.allgather_grad(nt)
+        gg = c.get_gathered_grad(nt)
+        assert gg.shape == (nt, 3, nbl_total, nchan) and NP.array_equal(gg, ordered(grad))
+        c.delay_transform_device(nt, pad=1.0, want_lag=True)
+        lags = c.get_lags(0, nt)
+        c.allgather_lags(nt)
+        gl = c.get_gathered(nt, row=lags.shape[2])
+        assert NP.array_equal(gl, ordered(lags))
+        # back to the rank-major layout
+        c.set_shard_map(None, 0)
+        c.allgather(nt)
+        assert NP.array_equal(c.get_gathered(nt, 1)[:, 0], vis)
+    finally:
+        c.close()
