@@ -818,39 +818,47 @@ def main():
                          cfg['diameter'], zen, zen, fwhm_deg=(sky['fwhm_deg'] if cfg['taper'] else None))
     c64 = (prec == _abi.PRISIM_FP32)
     if world > 1:
-        # RCCL communicator: rank 0 creates the 128-byte id, the rendezvous carries it to the other ranks.  Any failure is fatal.
+        # RCCL communicator: rank 0 creates the 128-byte id, the rendezvous carries it to the other ranks.  Any failure is fatal.  The whole
+        # block runs under one deadline (PRISIM_COMM_TIMEOUT_S, default 120 s; prisim_amd/watchdog.py): ncclCommInitRank and the exchanges
+        # around it wait for every rank, and a rank that never arrives must end the job with a message, not with the driver's timeout.
+        from prisim_amd import watchdog
         err = None
         uid = b''
-        if rank == 0:
-            try:
-                uid = _abi.Context.comm_unique_id()
-            except Exception as exc:
-                err = 'RCCL unique id failed: %r' % (exc,)
-        uid = rdzv.broadcast_bytes(uid)
-        if len(uid) == 128:
-            try:
-                ctx.comm_init(uid, world, rank)
-            except Exception as exc:
-                err = 'RCCL comm_init failed: %r' % (exc,)
-        elif err is None:
-            err = 'no RCCL unique id received'
-        if err is None:
-            try:
-                ctx.comm_selftest(1 << 20)     # 1 MiB per rank through ncclAllGather, every rank's pattern verified on the host
-            except Exception as exc:
-                err = 'RCCL self-test failed: %r' % (exc,)
-        if err is None:
-            try:
-                # every rank's rows in the global numbering (-1 = padding): each gathered snapshot is put into the reference's baseline
-                # order by a copy kernel behind the gather, on the communication stream (prisim_hip_set_shard_map)
-                smap = NP.full((world, bl_mine.shape[0]), -1, dtype=NP.int64)
-                for r in range(world):
-                    idx_r = sharding.shard_index(nbl_total, world, r)
-                    smap[r, :idx_r.size] = idx_r
-                ctx.set_shard_map(smap, nbl_total)
-            except Exception as exc:
-                err = 'shard map refused: %r' % (exc,)
-        errs = [e for e in rdzv.allgather(err) if e]
+        with watchdog.for_context(rank, device, _abi) as deadline:
+            if rank == 0:
+                try:
+                    uid = _abi.Context.comm_unique_id()
+                except Exception as exc:
+                    err = 'RCCL unique id failed: %r' % (exc,)
+            deadline.step('rendezvous: broadcast of the RCCL unique id')
+            uid = rdzv.broadcast_bytes(uid)
+            if len(uid) == 128:
+                try:
+                    deadline.step('ncclCommInitRank (prisim_hip_comm_init)')
+                    ctx.comm_init(uid, world, rank)
+                except Exception as exc:
+                    err = 'RCCL comm_init failed: %r' % (exc,)
+            elif err is None:
+                err = 'no RCCL unique id received'
+            if err is None:
+                try:
+                    deadline.step('self-test all-gather (prisim_hip_comm_selftest)')
+                    ctx.comm_selftest(1 << 20)     # 1 MiB per rank through ncclAllGather, every rank's pattern verified on the host
+                except Exception as exc:
+                    err = 'RCCL self-test failed: %r' % (exc,)
+            if err is None:
+                try:
+                    # every rank's rows in the global numbering (-1 = padding): each gathered snapshot is put into the reference's baseline
+                    # order by a copy kernel behind the gather, on the communication stream (prisim_hip_set_shard_map)
+                    smap = NP.full((world, bl_mine.shape[0]), -1, dtype=NP.int64)
+                    for r in range(world):
+                        idx_r = sharding.shard_index(nbl_total, world, r)
+                        smap[r, :idx_r.size] = idx_r
+                    ctx.set_shard_map(smap, nbl_total)
+                except Exception as exc:
+                    err = 'shard map refused: %r' % (exc,)
+            deadline.step('rendezvous: exchange of the set-up outcomes')
+            errs = [e for e in rdzv.allgather(err) if e]
         if errs:
             sys.stderr.write('rank %d: %s\n' % (rank, '; '.join(errs)))
             rdzv.close()

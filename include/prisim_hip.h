@@ -348,6 +348,12 @@ int prisim_hip_comm_unique_id(char id[128]);
 /* "librccl <major>.<minor>.<patch> (<path it was loaded from>)" of the RCCL this library dlopen()ed -- for run records. */
 int prisim_hip_comm_version(char out[128]);
 int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int rank);
+/* For run records and for a watchdog around the two calls above (ncclCommInitRank is a collective: it blocks until every rank has
+ * arrived, for ever when one never does): the PCI bus id of HIP device `device`, and the text of librccl's last error / warning
+ * (ncclGetLastError).  prisim_hip_comm_last_error touches neither a context nor the HIP runtime and may be called from another thread
+ * while prisim_hip_comm_init is still inside RCCL -- the one exception to "calls on one context are serialised" (it takes no context). */
+int prisim_hip_device_pci(int device, char out[64]);
+int prisim_hip_comm_last_error(char out[512]);
 /* All-gather the local cube (equal-sized baseline shards, [nt][nbl_shard][nchan]) into a device cube
  * [nt][nranks][nbl_shard][nchan] held by the context (snapshot-major: every snapshot's full baseline set is
  * contiguous, rank blocks in rank order).  as_c64 = 0: complex128 on the wire; 1: the

@@ -31,7 +31,7 @@ EXPORTS = (
     'prisim_hip_comm_init',
     'prisim_hip_allgather', 'prisim_hip_allgather_slot_async', 'prisim_hip_get_gathered', 'prisim_hip_gathered_checksum',
     'prisim_hip_sync', 'prisim_hip_get_timing', 'prisim_hip_device_info', 'prisim_hip_set_tuning',
-    'prisim_hip_allgather_grad', 'prisim_hip_comm_selftest', 'prisim_hip_get_comm_stats', 'prisim_hip_set_gather_root', 'prisim_hip_set_shard_map',
+    'prisim_hip_allgather_grad', 'prisim_hip_comm_selftest', 'prisim_hip_get_comm_stats', 'prisim_hip_set_gather_root', 'prisim_hip_set_shard_map', 'prisim_hip_device_pci', 'prisim_hip_comm_last_error',
     'prisim_hip_host_alloc', 'prisim_hip_host_free', 'prisim_hip_get_vis_async', 'prisim_hip_wait_downloads',
     'prisim_hip_set_catalog', 'prisim_hip_set_sky_from_catalog', 'prisim_hip_catalog_roi', 'prisim_hip_observe_catalog',
     'prisim_hip_comm_version',
@@ -217,6 +217,8 @@ def load_library():
     lib.prisim_hip_comm_selftest.argtypes = [vp, i64]
     lib.prisim_hip_set_gather_root.argtypes = [vp, i32]
     lib.prisim_hip_set_shard_map.argtypes = [vp, vp, i64]
+    lib.prisim_hip_device_pci.argtypes = [i32, C.c_char_p]
+    lib.prisim_hip_comm_last_error.argtypes = [C.c_char_p]
     lib.prisim_hip_get_comm_stats.argtypes = [vp, C.POINTER(PrisimCommStats), i32]
     lib.prisim_hip_host_alloc.argtypes = [i64, C.POINTER(vp)]
     lib.prisim_hip_host_free.argtypes = [vp]
@@ -708,6 +710,21 @@ class Context(object):
         rc = lib.prisim_hip_comm_version(buf)
         if rc != PRISIM_OK:
             _raise(rc, 'prisim_hip_comm_version failed: ' + lib.prisim_hip_last_error(None).decode())
+        return buf.value.decode()
+
+    @staticmethod
+    def device_pci(device):
+        lib = load_library()
+        buf = C.create_string_buffer(64)
+        lib.prisim_hip_device_pci(int(device), buf)
+        return buf.value.decode()
+
+    @staticmethod
+    def comm_last_error():
+        """Text of librccl's last error / warning; safe to call from a watchdog thread while comm_init blocks in another."""
+        lib = load_library()
+        buf = C.create_string_buffer(512)
+        lib.prisim_hip_comm_last_error(buf)
         return buf.value.decode()
 
     def comm_init(self, uid, nranks, rank):

@@ -32,6 +32,7 @@ bool load_rccl(std::string& err) {
         load_sym(h, "ncclGroupEnd", g_rccl.GroupEnd)))
     g_rccl.Send = nullptr;                              // gather-to-root then reports PRISIM_ELIB
   (void)load_sym(h, "ncclGetVersion", g_rccl.GetVersion);
+  (void)load_sym(h, "ncclGetLastError", g_rccl.GetLastError);
   g_rccl.path = path;
   g_rccl.handle = h;
   return true;
@@ -1736,6 +1737,26 @@ int prisim_hip_comm_version(char out[128]) {
   if (g_rccl.GetVersion) (void)g_rccl.GetVersion(&v);
   // NCCL_VERSION_CODE: major * 10000 + minor * 100 + patch (2.9 and later)
   snprintf(out, 128, "librccl %d.%d.%d (%s)", v / 10000, (v / 100) % 100, v % 100, g_rccl.path.c_str());
+  return PRISIM_OK;
+  });
+}
+
+int prisim_hip_comm_last_error(char out[512]) {
+  // Deliberately NOT through guarded() and without touching any context or the HIP runtime: this is what a watchdog thread calls while
+  // the main thread sits inside ncclCommInitRank -- it must not wait for anything that thread holds.
+  if (!out) return PRISIM_EINVAL;
+  out[0] = 0;
+  if (!g_rccl.handle) { snprintf(out, 512, "librccl not loaded"); return PRISIM_OK; }
+  const char* msg = g_rccl.GetLastError ? g_rccl.GetLastError(nullptr) : nullptr;
+  snprintf(out, 512, "%s", (msg && msg[0]) ? msg : "(librccl reports no error text; NCCL_DEBUG=WARN prints its warnings on stderr)");
+  return PRISIM_OK;
+}
+
+int prisim_hip_device_pci(int device, char out[64]) {
+  return guarded(nullptr, [&]() -> int {
+  if (!out) return PRISIM_EINVAL;
+  out[0] = 0;
+  if (hipDeviceGetPCIBusId(out, 64, device) != hipSuccess) { (void)hipGetLastError(); snprintf(out, 64, "unknown"); }
   return PRISIM_OK;
   });
 }

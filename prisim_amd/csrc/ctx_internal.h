@@ -40,6 +40,7 @@ struct RcclApi {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclGetVersion) GetVersion = nullptr;         // optional
+  const char* (*GetLastError)(ncclComm_t) = nullptr;      // optional (NCCL >= 2.13): text of the last error / warning
   std::string path;                                       // what dlopen() took
 };
 extern RcclApi g_rccl;

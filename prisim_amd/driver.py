@@ -33,6 +33,7 @@ import yaml
 
 from . import _abi
 from . import frames as FRAMES
+from . import watchdog as WATCHDOG
 from . import geometry as GEOM
 from . import interferometry as RI
 from . import layouts as LAY
@@ -382,16 +383,24 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         # comm_init is a collective: if it fails on this rank the exception ends the process (non-zero) and the launcher stops the peers,
         # which sit inside ncclCommInitRank -- voting on it over the rendezvous would hang them all.  Only the self-test,
         # which every rank reaches, is voted on.
-        ia.comm_setup(comm_uid, world, rank, selftest=False)
-        ok, why = True, ''
-        try:
-            ia.comm_selftest()
-        except _abi.PrisimHipError as exc:
-            ok, why = False, str(exc)
-            if rdzv is None:
-                raise
-        if rdzv is not None:
-            outcomes = rdzv.allgather([bool(ok), why])
+        # All of it under one deadline (PRISIM_COMM_TIMEOUT_S, default 120 s): these calls wait for every rank, for ever when one never
+        # arrives; on expiry the rank says who and where it is and exits non-zero (prisim_amd/watchdog.py), and the launcher stops the rest.
+        with WATCHDOG.for_context(rank, device, _abi) as deadline:
+            deadline.step('ncclCommInitRank (prisim_hip_comm_init)')
+            ia.comm_setup(comm_uid, world, rank, selftest=False)
+            ok, why = True, ''
+            try:
+                deadline.step('self-test all-gather (prisim_hip_comm_selftest)')
+                ia.comm_selftest()
+            except _abi.PrisimHipError as exc:
+                ok, why = False, str(exc)
+                if rdzv is None:
+                    raise
+            outcomes = None
+            if rdzv is not None:
+                deadline.step('rendezvous: exchange of the self-test outcomes')
+                outcomes = rdzv.allgather([bool(ok), why])
+        if outcomes is not None:
             bad = [(r, o[1]) for r, o in enumerate(outcomes) if not o[0]]
             if bad:
                 if rank == 0 or not ok:
@@ -609,7 +618,9 @@ def main(argv=None):
     rdzv = rendezvous.Rendezvous(rank, world)      # loopback sockets; no torch, nothing touches the GPU before this returns
     if world > 1:
         os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
-        uid = rdzv.broadcast_bytes(_abi.Context.comm_unique_id() if rank == 0 else b'')
+        with WATCHDOG.CommDeadline(rank, local_rank) as deadline:
+            deadline.step('rendezvous: broadcast of the RCCL unique id')
+            uid = rdzv.broadcast_bytes(_abi.Context.comm_unique_id() if rank == 0 else b'')
     device = int(os.environ.get('PRISIM_DEVICE', local_rank))       # PRISIM_DEVICE: rehearsal hook (several ranks on the one GPU of a test box)
     out = run(parms, infile_dir=os.path.dirname(os.path.abspath(args.infile)), rank=rank, world=world, device=device, comm_uid=uid,
               host_copy='root', rdzv=rdzv)         # only rank 0 writes: by default (pp.gather: null) only its GPU receives the cube

@@ -88,6 +88,13 @@ def test_every_export_is_guarded_against_cpp_exceptions():
     entries = re.findall(r'^int (prisim_hip_\w+)\(', src, flags=re.M)
     assert sorted(entries) == sorted(n for n in _abi.EXPORTS if n not in ('prisim_hip_destroy', 'prisim_hip_last_error', 'prisim_hip_version'))
     for name in entries:
+        if name == 'prisim_hip_comm_last_error':
+            # a watchdog thread calls it while another thread is inside RCCL: one snprintf into the caller's buffer, no allocation, no
+            # context, no HIP call -- nothing in it can throw, and it must not wait for anything
+            body = src[src.index('int %s(' % name):]
+            body = body[:body.index('\n}\n')]
+            assert 'snprintf' in body and 'std::string' not in body and 'hip' not in body.replace('prisim_hip', '')
+            continue
         body = src[src.index('int %s(' % name):]
         head = body[:body.index('{') + 200]
         assert 'return guarded(' in head.split('\n', 3)[-1] or 'return guarded(' in head, name

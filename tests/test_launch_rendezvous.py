@@ -190,3 +190,52 @@ def test_launcher_takes_its_ranks_along_when_it_is_terminated(tmp_path):
     for pid in pids:
         with pytest.raises(OSError):
             os.kill(pid, 0)                                   # gone
+
+
+def test_a_rank_stuck_in_comm_init_ends_the_job_with_a_message(tmp_path):
+    """VERDICT r5 next #3a: ncclCommInitRank waits for every rank.  Rank 1 never arrives (it sleeps); rank 0 sits inside its comm_init (a
+    blocking call standing in for the collective).  PRISIM_COMM_TIMEOUT_S = 2: rank 0 prints who and where it is -- rank, device, the
+    step, librccl's last error text -- and exits 124; the launcher reaps rank 1; the job is over in seconds, not at a driver's timeout."""
+    script = _script(tmp_path, '''
+        import threading, time
+        from prisim_amd import rendezvous, watchdog
+        r = rendezvous.Rendezvous()
+        r.barrier()
+        if r.rank == 1:
+            time.sleep(600)                       # "died before its comm_init"
+        never = threading.Event()
+        with watchdog.CommDeadline(r.rank, 0, describe=lambda: '0000:05:00.0', last_error=lambda: 'unhandled system error (stand-in)') as dl:
+            dl.step('ncclCommInitRank (prisim_hip_comm_init)')
+            never.wait()                          # a C call that never returns, GIL released
+        print('NOT REACHED')
+    ''')
+    env = _clean_env()
+    env['PRISIM_COMM_TIMEOUT_S'] = '2'
+    t0 = time.time()
+    res = subprocess.run([sys.executable, '-m', 'prisim_amd.launch', '-n', '2', script], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    took = time.time() - t0
+    assert res.returncode != 0 and 'NOT REACHED' not in res.stdout
+    assert took < 40.0, took
+    err = res.stderr
+    assert 'rank 0 (device 0, PCI 0000:05:00.0)' in err and 'PRISIM_COMM_TIMEOUT_S = 2 s' in err
+    assert 'stuck in step "ncclCommInitRank (prisim_hip_comm_init)"' in err
+    assert 'last RCCL error: unhandled system error (stand-in)' in err and 'exiting with code 124' in err
+
+
+def test_comm_deadline_is_silent_when_the_block_finishes_and_can_be_switched_off(monkeypatch):
+    from prisim_amd import watchdog
+    fired = []
+    with watchdog.CommDeadline(3, 1, seconds=0.2, _exit=lambda code: fired.append(code)) as dl:
+        dl.step('quick')
+    time.sleep(0.4)
+    assert fired == []
+    with watchdog.CommDeadline(3, 1, seconds=0.1, describe=lambda: 1 / 0, _exit=lambda code: fired.append(code)) as dl:   # a failing diagnostic is no failure
+        dl.step('slow')
+        time.sleep(0.5)
+    assert fired == [watchdog.EXIT_CODE]
+    monkeypatch.setenv('PRISIM_COMM_TIMEOUT_S', '0')
+    assert watchdog.timeout_seconds() is None
+    with watchdog.CommDeadline(0, 0) as dl:
+        assert dl._timer is None
+    monkeypatch.setenv('PRISIM_COMM_TIMEOUT_S', 'soon')
+    assert watchdog.timeout_seconds() == 120.0
