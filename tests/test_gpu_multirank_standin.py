@@ -56,6 +56,7 @@ def test_bench_gpus_n_runs_end_to_end_on_one_gpu(fake_rccl, nranks, precision):
     assert g['wire_dtype'] == ('complex64' if precision == 'fp32' else 'complex128')
     assert g['bytes_per_peer'] == per * 1024 * (8 if precision == 'fp32' else 16) and g['gathers_measured'] == 2
     assert g['comm_stream_priority'] <= 0 <= g['lowest_priority'] and g['per_snapshot_ms'] >= 0 and g['exposed_ms'] >= 0
+    assert g['order'] == 'global' and 0.0 < g['undeal_ms_per_snapshot'] < g['per_snapshot_ms']      # un-dealt on the device, behind each gather
     assert len(d['kernel_ms_per_rank']['all']) == nranks and d['kernel_ms_per_rank']['min'] > 0
     assert abs(d['value_n1_equiv'] * nranks - d['value']) <= 1e-9 * d['value']
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 * 2 - 61075.0 * 1024 * 1500 * 2) <= 1e-6 * 61075.0 * 1024 * 1500 * 2
