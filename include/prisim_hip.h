@@ -292,7 +292,7 @@ typedef struct prisim_post {
  * sky + compute into cube slot slot0 + t, queued back to back without any host synchronisation on the compute stream.  Arrays of at
  * most 256 baselines in fp64 (uniform channel grid, no gradient; analytic Gaussian / Airy / delta / dipole beams with or without array
  * factor and ground plane, or the external HEALPix beam; catalogues with or without source shapes, unless the taper culling could
- * shorten something) put the beam x flux, the packing and the sky-sums of a whole chunk of up to 64 snapshots into ONE launch each -- the
+ * shorten something) put the beam x flux, the packing and the sky-sums of a whole chunk of up to 256 snapshots into ONE launch each -- the
  * sky-sum's work item is (snapshot, baseline wave, channel tile, source split) -- and ONE reduction.  Replaces the loop of
  * interferometry.py:6641-6647 / scripts/run_prisim.py:2165-2207.  nsrc_roi: [nsnap] or NULL; post: NULL = nothing. */
 int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int precision,

@@ -536,13 +536,26 @@ class Context(object):
         frames: None (the library's fall-back rotation from lst and latitude), or K pairs (R (3, 3), beta (3,)) -- see _fill_snapshot."""
         lst = NP.asarray(lst_deg, dtype=NP.float64).ravel()
         k = lst.size
-        pc = NP.broadcast_to(NP.asarray(pc_dircos, dtype=NP.float64).reshape(-1, 3), (k, 3))
-        bpc = pc if beam_pc_dircos is None else NP.broadcast_to(NP.asarray(beam_pc_dircos, dtype=NP.float64).reshape(-1, 3), (k, 3))
-        snaps = (PrisimSnapshot * k)()
         if frames is not None and len(frames) != k:
             raise ValueError('frames must hold one (R, beta) pair per snapshot')
-        for t in range(k):
-            self._fill_snapshot(snaps[t], lst[t], pc[t], bpc[t], None if frames is None else frames[t])
+        # the K prisim_snapshot structs are filled through numpy views of their memory (20 doubles each: lst, pc[3], beam_pc[3],
+        # {frame_given, reserved}, cel2enu[9], aberr_beta[3]) -- a per-field ctypes fill costs more than the C call of a small array
+        cache = self.__dict__.get('_snap_cache')
+        if cache is None or cache[0] != k:
+            snaps = (PrisimSnapshot * k)()
+            cache = self.__dict__['_snap_cache'] = (k, snaps, NP.frombuffer(snaps, dtype=NP.float64).reshape(k, 20),
+                                                    NP.frombuffer(snaps, dtype=NP.int32).reshape(k, 40))
+        _, snaps, fv, iv = cache
+        fv[:, 0] = lst
+        fv[:, 1:4] = NP.asarray(pc_dircos, dtype=NP.float64).reshape(-1, 3)
+        fv[:, 4:7] = fv[:, 1:4] if beam_pc_dircos is None else NP.asarray(beam_pc_dircos, dtype=NP.float64).reshape(-1, 3)
+        if frames is None:
+            iv[:, 14] = 0
+        else:
+            iv[:, 14] = 1
+            for t in range(k):
+                fv[t, 8:17] = NP.asarray(frames[t][0], dtype=NP.float64).reshape(9)
+                fv[t, 17:20] = frames[t][1]
         counts = NP.zeros(k, dtype=NP.int64)
         post = None
         if host_cube is not None or gather is not None:

@@ -182,8 +182,19 @@ int enter_prep_stream(prisim_ctx* ctx) {
   return PRISIM_OK;
 }
 
-// Geometry of nsnap snapshots into buffer set b, on the geometry stream; returns when the per-snapshot records are in C.out_host.
-int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int b, bool want_keys) {
+// What a batched launch (small arrays, run_wave_batch) tells the geometry so that the scan pass can write the launch's per-snapshot table
+struct BatchLayout {
+  BatchSnap* tab = nullptr;
+  int64_t npad = 0;
+  int32_t nsplit = 1;
+  double* out = nullptr;
+  int64_t slot_elems = 0;
+};
+
+// Geometry of nsnap snapshots into buffer set b, queued on the geometry stream; ev_geom is recorded behind the copy of the per-snapshot
+// records into C.out_host.  geometry_wait() makes them readable; device work that needs the geometry waits for ev_geom in its own stream.
+int geometry_enqueue(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int b, bool want_keys,
+                     const BatchLayout* batch = nullptr) {
   auto& C = ctx->cat;
   int rc;
   { HostSpan sp("cat_runtime"); if ((rc = cat_runtime(ctx, nsnap))) return rc; }
@@ -202,14 +213,15 @@ int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* 
     } else {
       fallback_frame(C.coords, snaps[t].lst_deg, obs->latitude_deg, s.rot, s.beta);
     }
-    for (int i = 0; i < 3; ++i) { s.roi_pc[i] = snaps[t].pc_dircos[i]; s.pc[i] = snaps[t].pc_dircos[i]; }
+    for (int i = 0; i < 3; ++i) { s.roi_pc[i] = snaps[t].pc_dircos[i]; s.pc[i] = snaps[t].pc_dircos[i]; s.bpc[i] = snaps[t].beam_pc_dircos[i]; }
   }
+  C.geom_pending = false;
+  C.geom_nsnap = nsnap; C.geom_set = b;
   if (C.n == 0) {
     for (int64_t t = 0; t < nsnap; ++t) {
       C.out_host[t].nsrc = 0; C.out_host[t].dmax2_bits = 0;
       for (auto& v : C.out_host[t].run_start) v = 0;
     }
-    if (b != 2) C.chunk_nmax = 0;
     return PRISIM_OK;
   }
   CatGeomParams p{};
@@ -225,23 +237,51 @@ int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* 
   p.idx = (int32_t*)S.idx.p; p.dirs = (double*)S.dirs.p;
   p.keys = want_keys ? (uint32_t*)S.keys.p : nullptr; p.pos = want_keys ? (uint32_t*)S.pos.p : nullptr;
   p.out = (CatOut*)C.out_dev.p;
+  if (batch) {
+    p.batch = batch->tab; p.batch_npad = batch->npad; p.batch_nsplit = batch->nsplit; p.batch_out = batch->out; p.batch_slot_elems = batch->slot_elems;
+  }
   // the set may still be read by sky-sums queued earlier on the compute stream
   if (S.ev_recorded) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, S.ev_free, 0));
   // ... or by the preparation of a sky nobody summed (two set_sky_from_catalog calls in a row, an empty region of interest)
   if (S.prep_recorded) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, S.ev_prepared, 0));
   const auto t0 = Clock::now();
-  HIPCHK(ctx, hipMemcpyAsync(C.snaps.p, C.snaps_host, (size_t)nsnap * sizeof(CatSnap), hipMemcpyHostToDevice, C.gstream));
+  const bool small = C.n <= kCatSmallMax;
+  if (small && nsnap == 1) {
+    p.inline_snap = 1;                       // the one snapshot's inputs travel in the kernel arguments
+    p.snap0 = C.snaps_host[0];
+  } else {
+    HIPCHK(ctx, hipMemcpyAsync(C.snaps.p, C.snaps_host, (size_t)nsnap * sizeof(CatSnap), hipMemcpyHostToDevice, C.gstream));
+  }
+  // small catalogues: one block per snapshot writes its record straight into the page-locked host array (device-visible); otherwise
+  // the three passes write device records and a copy follows
+  if (small) p.out = C.out_host;
   HIPCHK(ctx, launch_cat_geometry(p, (int)nsnap, C.gstream));
-  HIPCHK(ctx, hipMemcpyAsync(C.out_host, C.out_dev.p, (size_t)nsnap * sizeof(CatOut), hipMemcpyDeviceToHost, C.gstream));
+  if (!small) HIPCHK(ctx, hipMemcpyAsync(C.out_host, C.out_dev.p, (size_t)nsnap * sizeof(CatOut), hipMemcpyDeviceToHost, C.gstream));
   HIPCHK(ctx, hipEventRecord(C.ev_geom, C.gstream));
-  HIPCHK(ctx, hipEventSynchronize(C.ev_geom));
-  C.geom_ms_sum += std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
-  C.geom_calls += 1;
-  if (b != 2) {
+  C.geom_pending = true;
+  C.geom_t0 = t0;
+  return PRISIM_OK;
+}
+
+// The per-snapshot records of the last geometry_enqueue are in C.out_host when this returns.
+int geometry_wait(prisim_ctx* ctx) {
+  auto& C = ctx->cat;
+  if (C.geom_pending) {
+    HIPCHK(ctx, hipEventSynchronize(C.ev_geom));
+    C.geom_pending = false;
+    C.geom_ms_sum += std::chrono::duration<double, std::milli>(Clock::now() - C.geom_t0).count();
+    C.geom_calls += 1;
+  }
+  if (C.geom_set != 2) {
     C.chunk_nmax = 0;
-    for (int64_t t = 0; t < nsnap; ++t) C.chunk_nmax = std::max(C.chunk_nmax, C.out_host[t].nsrc);
+    for (int64_t t = 0; t < C.geom_nsnap; ++t) C.chunk_nmax = std::max(C.chunk_nmax, C.out_host[t].nsrc);
   }
   return PRISIM_OK;
+}
+
+int geometry_run(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int b, bool want_keys) {
+  int rc = geometry_enqueue(ctx, obs, snaps, nsnap, b, want_keys);
+  return rc ? rc : geometry_wait(ctx);
 }
 
 // Make snapshot t of buffer set b the current sky: runs, altitude order, cull table, pb * flux.  Everything is queued on the compute
@@ -380,7 +420,10 @@ bool wave_batch_eligible(const prisim_ctx* ctx, const prisim_obs* obs, int preci
   const auto& C = ctx->cat;
   if (const char* env = getenv("PRISIM_HIP_WAVE_BATCH")) { if (atoi(env) == 0) return false; }
   if (const char* env = getenv("PRISIM_HIP_WAVE_ITEMS")) { if (atoi(env) == 0) return false; }
-  if (kc < 2 || precision != PRISIM_FP64 || want_grad || !ctx->uniform || ctx->nbl > kBlockThreads || ctx->nchan < 16) return false;
+  if (kc < 1 || precision != PRISIM_FP64 || want_grad || !ctx->uniform || ctx->nbl > kBlockThreads || ctx->nchan < 16) return false;
+  // one snapshot per call: the per-snapshot chain (its planner cuts a single snapshot finer: 16-channel tiles x 42 splits; through the
+  // batched launch a lone HERA-19 snapshot took 143 us against 118).  PRISIM_HIP_WAVE_BATCH_SINGLE=1: the A/B hook.
+  if (kc < 2) { const char* env = getenv("PRISIM_HIP_WAVE_BATCH_SINGLE"); if (!(env && atoi(env) != 0)) return false; }
   // (sizes may vary from source to source and the sky may consist of several runs -- point sources + a diffuse map: every source
   // carries its own kappa, and with nothing to cull the runs need no separate launches; point sources then pay the taper kernel's 9.7
   // instead of the plain kernel's 6.2 instructions per term, which a launch per run and snapshot would cost many times over)
@@ -400,10 +443,17 @@ bool wave_batch_eligible(const prisim_ctx* ctx, const prisim_obs* obs, int preci
   return true;
 }
 
-int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int b, int64_t kc, int64_t slot0, int64_t* nsrc_roi) {
+// The geometry of the chunk is queued from in here: the scan pass writes the launch's per-snapshot table on the device (BatchSnap: counts,
+// split sizes, phase / beam centres, output pointers), every snapshot owning a fixed-size block of the direction, beam x flux and packed-row
+// buffers -- so beam x flux, packing, the sky-sums and the reduction are queued without the host having seen a single count, and the
+// compute stream waits for the geometry by event.  The host reads the counts (nsrc_roi, timing) at the END, when they have long arrived:
+// a chunk costs no round trip to the device any more (a single observe() of HERA-19 spent 45 of its 118 us waiting for one).
+int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int b, int64_t kc, int64_t slot0, int64_t* nsrc_roi,
+                   bool want_keys) {
   auto& C = ctx->cat;
   auto& S = C.set[b];
   int rc;
+  if ((rc = cat_runtime(ctx, kc))) return rc;
   // buffer set and preparation stream, as activate_snapshot -- but by default the chunk is prepared on the COMPUTE stream: its preparation
   // is two large compute-bound launches (beam x flux, packing), and under the previous chunk's sky-sum they only take its CUs away
   // (config 2 x 64 snapshots, 8 chunks queued: 1.975 ms per chunk on the preparation stream, the sky-sum slowed from 1.46 to 1.84 ms;
@@ -420,13 +470,13 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   const hipStream_t ps = pstream(ctx);
   SkyBufs& K = *ctx->sk;
   // plan: 32-channel tiles (the seed of a (source, baseline, tile) triple is 26 % of a 32-channel tile's instructions, 41 % of a
-  // 16-channel tile's), source splits so that the grid is about three rounds of two wavefronts per SIMD
+  // 16-channel tile's), source splits so that the grid is about three rounds of two wavefronts per SIMD.  Everything here is a function
+  // of the array, the catalogue and the chunk length -- never of the counts, which the host has not seen.
   int ct = ctx->tune_ct ? ctx->tune_ct : (ctx->nchan >= 32 ? 32 : 16);
   if (ct != 16 && ct != 32) ct = 32;
   const int ntiles = (int)((ctx->nchan + ct - 1) / ct);
   const int nbw = (int)((ctx->nbl + 63) / 64);
-  int64_t nmax = 0, ntot = 0;
-  for (int64_t t = 0; t < kc; ++t) { nmax = std::max(nmax, C.out_host[t].nsrc); ntot += C.out_host[t].nsrc; }
+  const int64_t npad = round_up(std::max<int64_t>(C.n, 1), 4);
   int64_t nsplit = ctx->tune_nsplit;
   if (nsplit == 0) {
     const int64_t slots = 2LL * 4 * std::max(ctx->cu_count, 1);
@@ -441,65 +491,43 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
       const double waste = std::ceil(r) / r + 0.002 * (double)(n - lo);
       if (waste < best - 1e-12) { best = waste; nsplit = n; }
     }
-    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, nmax / 16));
+    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, C.n / 32));      // (a horizon region of interest holds about half the catalogue)
     nsplit = std::min<int64_t>(nsplit, 64);
   }
   const size_t slot_elems = (size_t)ctx->nbl * ctx->nchan * 2;
-  // per-snapshot layout
-  if ((rc = ensure(ctx, K.batch_tab, (size_t)kc * sizeof(BatchSnap)))) return rc;
-  if (kc > C.cap_batch_host) {
-    for (int h = 0; h < 2; ++h) {
-      if (C.tab_recorded[h]) HIPCHK(ctx, hipEventSynchronize(C.ev_tab[h]));
-      C.tab_recorded[h] = false;
-    }
-    if (C.batch_host) (void)hipHostFree(C.batch_host);
-    C.batch_host = nullptr; C.cap_batch_host = 0;
-    if (hipHostMalloc((void**)&C.batch_host, (size_t)std::max<int64_t>(kc, 64) * 2 * sizeof(BatchSnap), hipHostMallocDefault) != hipSuccess) {
-      C.batch_host = nullptr;
-      return fail(ctx, PRISIM_ENOMEM, "hipHostMalloc for the batch table failed");
-    }
-    C.cap_batch_host = std::max<int64_t>(kc, 64);
-  }
-  // (two halves of the pinned table alternate: the copy of chunk c may still be queued when chunk c+1 is laid out; a half is rewritten
-  // only after the copy that last read it has run)
-  C.tab_half ^= 1;
-  if (C.tab_recorded[C.tab_half]) HIPCHK(ctx, hipEventSynchronize(C.ev_tab[C.tab_half]));
-  BatchSnap* tab = C.batch_host + (size_t)(C.tab_half ? C.cap_batch_host : 0);
-  if (nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)kc * (size_t)nsplit * slot_elems * sizeof(double)))) return rc;
-  int64_t row = 0, pb0 = 0, max_nrow = 0;
-  for (int64_t t = 0; t < kc; ++t) {
-    const int64_t N = C.out_host[t].nsrc;
-    if (N < 0 || N > C.n) return fail(ctx, PRISIM_EINTERNAL, "catalogue geometry returned an impossible source count");
-    BatchSnap& e = tab[t];
-    e.dir0 = t * C.n; e.nsrc = N; e.pb0 = pb0; e.row0 = row;
-    e.nrow = round_up(std::max<int64_t>(N, 1), 4);
-    e.src_per_split = wave_split_sources(N, nsplit);
-    for (int i = 0; i < 3; ++i) { e.pc[i] = snaps[t].pc_dircos[i]; e.bpc[i] = snaps[t].beam_pc_dircos[i]; }
-    e.out = nsplit > 1 ? (double*)ctx->partial.p + (size_t)t * (size_t)nsplit * slot_elems : (double*)ctx->cube.p + (size_t)(slot0 + t) * slot_elems;
-    row += e.nrow; pb0 += N;
-    max_nrow = std::max(max_nrow, e.nrow);
-    if (nsrc_roi) nsrc_roi[t] = N;
-  }
-  const int64_t pitch = row;
-  if ((rc = ensure(ctx, K.pb, (size_t)std::max<int64_t>(ntot * ctx->nchan, 1) * sizeof(double))) ||
+  const int64_t pitch = kc * npad;                     // packed rows / prepared directions: snapshot t owns rows [t npad, (t + 1) npad)
+  const size_t pb_rows = (size_t)kc * (size_t)std::max<int64_t>(C.n, 1);
+  if ((rc = ensure(ctx, K.batch_tab, (size_t)kc * sizeof(BatchSnap))) ||
+      (nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)kc * (size_t)nsplit * slot_elems * sizeof(double)))) ||
+      (rc = ensure(ctx, K.pb, pb_rows * ctx->nchan * sizeof(double))) ||
       (rc = ensure(ctx, K.packed, (size_t)ntiles * (size_t)pitch * ct * sizeof(double))) ||
       (rc = ensure(ctx, K.dirs_prep, (size_t)pitch * 4 * sizeof(double))) || (rc = ensure(ctx, ctx->sky_flag, sizeof(int32_t))))
     return rc;
-  HIPCHK(ctx, hipMemcpyAsync(K.batch_tab.p, tab, (size_t)kc * sizeof(BatchSnap), hipMemcpyHostToDevice, ps));
-  HIPCHK(ctx, hipEventRecord(C.ev_tab[C.tab_half], ps));
-  C.tab_recorded[C.tab_half] = true;
+  if (obs->use_external_beam &&
+      ((rc = ensure(ctx, ctx->ext_work, pb_rows * ctx->nchan * sizeof(double))) ||
+       (rc = ensure(ctx, ctx->ext_colmax, std::max<size_t>((size_t)kc * (kExtBatchBlocks + 1), 1025) * ctx->nchan * sizeof(double)))))
+    return rc;
+  BatchLayout lay;
+  lay.tab = (BatchSnap*)K.batch_tab.p;
+  lay.npad = npad;
+  lay.nsplit = (int32_t)nsplit;
+  lay.slot_elems = (int64_t)slot_elems;
+  lay.out = nsplit > 1 ? (double*)ctx->partial.p : (double*)ctx->cube.p + (size_t)slot0 * slot_elems;
+  // the table lives in the sky-buffer set: an earlier chunk's launches that read it are on the compute / preparation stream, the
+  // geometry stream writes it -- order the write behind them (the set's geometry buffers are ordered by ev_free / ev_prepared already)
+  if (K.sum_recorded) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, K.ev_sum, 0));
+  { HostSpan sp("geometry_enqueue"); if ((rc = geometry_enqueue(ctx, obs, snaps, kc, b, want_keys, &lay))) return rc; }
+  HIPCHK(ctx, hipStreamWaitEvent(ps, C.ev_geom, 0));
+  const int64_t nmax = C.n;
   // beam x flux of all snapshots (:6249-6254), then rows + prepared directions of all snapshots
-  if (ntot > 0 && obs->use_external_beam) {
+  if (obs->use_external_beam) {
     // external HEALPix beam (run_prisim.py:2091-2103): gather, per-snapshot column maximum, 10 ** (.) x flux -- four launches for the chunk
-    if ((rc = ensure(ctx, ctx->ext_work, (size_t)ntot * ctx->nchan * sizeof(double))) ||
-        (rc = ensure(ctx, ctx->ext_colmax, std::max<size_t>((size_t)kc * (kExtBatchBlocks + 1), 1025) * ctx->nchan * sizeof(double))))
-      return rc;
     HIPCHK(ctx, launch_extbeam_sky_batch((const double*)ctx->ext_table.p, ctx->ext_nside, (const double*)S.dirs.p,
                                          C.have_spec ? (const double*)C.spec.p : nullptr, C.have_spec ? nullptr : (const double*)C.flux_ref.p,
                                          C.have_spec ? nullptr : (const double*)C.spindex.p, (const double*)ctx->freqs.p, C.have_spec ? 1.0 : C.ref_freq,
                                          (double*)ctx->ext_work.p, (double*)ctx->ext_colmax.p, (double*)K.pb.p, nmax, ctx->nchan,
                                          (const int32_t*)S.idx.p, (const BatchSnap*)K.batch_tab.p, (int)kc, ps));
-  } else if (ntot > 0) {
+  } else {
     BeamParams bp{};
     bp.dirs = (const double*)S.dirs.p;
     bp.src_index = (const int32_t*)S.idx.p;
@@ -526,7 +554,7 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
     bp.batch = (const BatchSnap*)K.batch_tab.p;
     HIPCHK(ctx, launch_beam_flux_batch(bp, (int)kc, ps));
   }
-  HIPCHK(ctx, launch_pack_prep_batch((const double*)K.pb.p, (double*)K.packed.p, pitch, max_nrow, ctx->nchan, ct, ntiles, (const double*)S.dirs.p,
+  HIPCHK(ctx, launch_pack_prep_batch((const double*)K.pb.p, (double*)K.packed.p, pitch, npad, ctx->nchan, ct, ntiles, (const double*)S.dirs.p,
                                      (double*)K.dirs_prep.p, 1.0 / kC, (const BatchSnap*)K.batch_tab.p, (int)kc, ps));
   if ((rc = join_prep(ctx))) return rc;
   // the sky-sums of the whole chunk: ONE launch, ONE reduction
@@ -563,6 +591,15 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   catalog_after_compute(ctx);
   ctx->ring_head = (ctx->ring_head + 1) % prisim_ctx::kTimingRing;
   ctx->ring_pending += 1;
+  // only now the counts: they arrived while the launches above were being queued
+  { HostSpan sp("geometry_wait"); if ((rc = geometry_wait(ctx))) return rc; }
+  int64_t ntot = 0;
+  for (int64_t t = 0; t < kc; ++t) {
+    const int64_t N = C.out_host[t].nsrc;
+    if (N < 0 || N > C.n) return fail(ctx, PRISIM_EINTERNAL, "catalogue geometry returned an impossible source count");
+    if (nsrc_roi) nsrc_roi[t] = N;
+    ntot += N;
+  }
   ctx->timing.last_terms = ctx->nbl * ctx->nchan * ntot;
   ctx->timing.last_kernel_id = PRISIM_KERNEL_RECURRENCE;
   ctx->timing.last_chan_tile = ct;
@@ -814,19 +851,28 @@ int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const pri
   const bool want_keys = cat_sort_wanted(ctx);
   // chunks of snapshots whose geometry (44 bytes per catalogue source and snapshot) stays under 512 MiB
   const int64_t per_snap = 44 * std::max<int64_t>(C.n, 1);
-  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)512 << 20) / per_snap));
+  int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)512 << 20) / per_snap));
+  if (nsnap > 64 && wave_batch_eligible(ctx, obs, precision, want_grad, nsnap)) {
+    // small arrays whose snapshots share one launch: up to 256 snapshots per chunk (a 64-snapshot launch of HERA-19 lasts 1.7 ms and
+    // starts from the idle clock; 256 snapshots fill the grid without source splits -- no partial cubes, no reduction pass) while the
+    // chunk's beam x flux and packed rows (2 x 8 B per catalogue source and channel, at most) stay under 4 GiB
+    int64_t big = 256;
+    if (const char* env = getenv("PRISIM_HIP_BATCH_CHUNK")) big = std::max<int64_t>(1, atoll(env));
+    const int64_t per_batch = 16 * std::max<int64_t>(C.n, 1) * std::max<int64_t>(ctx->nchan, 1) + per_snap;
+    chunk = std::max<int64_t>(chunk, std::min<int64_t>(big, ((int64_t)4 << 30) / per_batch));
+  }
   for (int64_t c0 = 0; c0 < nsnap; c0 += chunk) {
     const int64_t kc = std::min(chunk, nsnap - c0);
     const int b = C.next;
     ctx->sky_set = false;
-    { HostSpan sp("geometry_run"); if ((rc = geometry_run(ctx, obs, snaps + c0, kc, b, want_keys))) return rc; }
-    if (wave_batch_eligible(ctx, obs, precision, want_grad, kc)) {
-      if ((rc = run_wave_batch(ctx, obs, snaps + c0, b, kc, slot0 + c0, nsrc_roi ? nsrc_roi + c0 : nullptr))) return rc;
+    if (C.n > 0 && wave_batch_eligible(ctx, obs, precision, want_grad, kc)) {
+      if ((rc = run_wave_batch(ctx, obs, snaps + c0, b, kc, slot0 + c0, nsrc_roi ? nsrc_roi + c0 : nullptr, want_keys))) return rc;
       for (int64_t t = 0; t < kc; ++t)
         if ((rc = post_snapshot(ctx, post, slot0 + c0 + t))) return rc;
       C.next = b ^ 1;
       continue;
     }
+    { HostSpan sp("geometry_run"); if ((rc = geometry_run(ctx, obs, snaps + c0, kc, b, want_keys))) return rc; }
     for (int64_t t = 0; t < kc; ++t) {
       { HostSpan sp("activate_snapshot"); if ((rc = activate_snapshot(ctx, obs, snaps[c0 + t], b, t, want_keys))) return rc; }
       if (nsrc_roi) nsrc_roi[c0 + t] = ctx->nsrc;

@@ -111,6 +111,20 @@ void k_cat_scan(const CatGeomParams p) {
     p.out[snap].nsrc = carry_s;
     p.out[snap].dmax2_bits = 0;
     for (int r = 0; r <= PRISIM_CAT_MAX_RUNS; ++r) p.out[snap].run_start[r] = carry_s;      // runs with no catalogue source at all
+    if (p.batch) {
+      // the snapshot's entry of the batched launch's table (catalog.cpp run_wave_batch lays the blocks out; wave_split_sources there)
+      const CatSnap& sn = p.snaps[snap];
+      BatchSnap e;
+      const int64_t N = carry_s;
+      e.dir0 = (int64_t)snap * p.n; e.nsrc = N; e.pb0 = (int64_t)snap * p.n; e.row0 = (int64_t)snap * p.batch_npad;
+      const int64_t n1 = N > 1 ? N : 1;
+      e.nrow = (n1 + 3) / 4 * 4;
+      const int64_t sw = p.batch_nsplit > 1 ? p.batch_nsplit : 1;
+      e.src_per_split = ((n1 + sw - 1) / sw + 3) / 4 * 4;
+      for (int i = 0; i < 3; ++i) { e.pc[i] = sn.pc[i]; e.bpc[i] = sn.bpc[i]; }
+      e.out = p.batch_out + (size_t)snap * (size_t)(p.batch_nsplit > 1 ? p.batch_nsplit : 1) * (size_t)p.batch_slot_elems;
+      p.batch[snap] = e;
+    }
   }
 }
 
@@ -161,6 +175,93 @@ void k_cat_scatter(const CatGeomParams p) {
     double mx = wmax[0];
     for (int w = 1; w < kCatBlock / 64; ++w) mx = fmax(mx, wmax[w]);
     if (mx > 0.0) atomicMax((unsigned long long*)&p.out[snap].dmax2_bits, (unsigned long long)__double_as_longlong(mx));   // non-negative doubles order like their bits
+  }
+}
+
+// Small catalogues (n <= kCatSmallMax): count, scan and scatter of a snapshot in ONE block of 1024 threads (grid = snapshots) -- thread t owns
+// the contiguous sources [t m, (t + 1) m), m = ceil(n / 1024) <= 64: it counts its region-of-interest sources (flags kept as a bit mask),
+// the block scans the 1024 counts, and the thread walks its sources again writing them at their ranks.  The same cat_source(), the same
+// stable order, the same records as the three-pass form -- but one launch instead of three dependent ones, the snapshot's inputs in the
+// kernel arguments instead of behind a host-to-device copy, and the result record written straight into page-locked host memory instead of
+// through a device-to-host copy: a single snapshot's geometry costs the host one launch latency, not five (observe() on HERA-19: 45 us).
+__global__ __launch_bounds__(1024)
+void k_cat_small(const CatGeomParams p) {
+  __shared__ int64_t wsum[16];
+  __shared__ double wmax[16];
+  __shared__ int64_t total_s;
+  const int snap = blockIdx.x;
+  const CatSnap sn = p.inline_snap ? p.snap0 : p.snaps[snap];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m = (p.n + 1023) / 1024;
+  const int64_t i0 = (int64_t)tid * m, i1 = i0 + m < p.n ? i0 + m : p.n;
+  uint64_t mask = 0;
+  for (int64_t i = i0; i < i1; ++i) {
+    double l, mm, n;
+    if (cat_source(p, sn, i, l, mm, n)) mask |= 1ull << (i - i0);
+  }
+  const int64_t cnt = __popcll(mask);
+  int64_t x = cnt;                                     // inclusive scan inside the wave, then over the 16 waves
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int64_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  int64_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wsum[w];
+  if (tid == 1023) total_s = wbase + x;
+  int64_t rank = wbase + x - cnt;                      // region-of-interest sources before source i0
+  const size_t row0 = (size_t)snap * (size_t)p.n;
+  double e2 = 0.0;
+  for (int64_t i = i0; i < i1; ++i) {
+    const int run = p.run_id ? p.run_id[i] : 0;
+    if (p.run_id && i > 0 && p.run_id[i - 1] != run) p.out[snap].run_start[run] = rank;      // (run 0 starts at 0: written below)
+    if (mask & (1ull << (i - i0))) {
+      double l, mm, n;
+      (void)cat_source(p, sn, i, l, mm, n);
+      p.idx[row0 + rank] = (int32_t)i;
+      reinterpret_cast<double4*>(p.dirs)[row0 + rank] = make_double4(l, mm, n, p.kappa ? p.kappa[i] : 0.0);
+      const double ex = l - sn.pc[0], ey = mm - sn.pc[1], ez = n - sn.pc[2];
+      e2 = fmax(e2, ex * ex + ey * ey + ez * ez);
+      if (p.want_keys) {
+        double q = (1.0 - n) * 134217728.0;                      // as k_cat_scatter
+        q = q < 0.0 ? 0.0 : (q > 268435455.0 ? 268435455.0 : q);
+        p.keys[row0 + rank] = ((uint32_t)run << 28) | (uint32_t)q;
+        p.pos[row0 + rank] = (uint32_t)rank;
+      }
+      rank += 1;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) e2 = fmax(e2, __shfl_xor(e2, d, 64));
+  if (lane == 0) wmax[wave] = e2;
+  __syncthreads();
+  if (tid == 0) {
+    const int64_t N = total_s;
+    double mx = wmax[0];
+    for (int w = 1; w < 16; ++w) mx = fmax(mx, wmax[w]);
+    p.out[snap].nsrc = N;
+    p.out[snap].dmax2_bits = mx > 0.0 ? (uint64_t)__double_as_longlong(mx) : 0;
+    // runs no source of the catalogue starts (none exist past the last run id) keep "start = N"; run 0 starts at 0
+    if (p.run_id) {
+      const int last_run = p.run_id[p.n - 1];
+      for (int r = last_run + 1; r <= PRISIM_CAT_MAX_RUNS; ++r) p.out[snap].run_start[r] = N;
+      p.out[snap].run_start[0] = 0;
+    } else {
+      for (int r = 0; r <= PRISIM_CAT_MAX_RUNS; ++r) p.out[snap].run_start[r] = N;
+    }
+    if (p.batch) {
+      BatchSnap e;
+      e.dir0 = (int64_t)snap * p.n; e.nsrc = N; e.pb0 = (int64_t)snap * p.n; e.row0 = (int64_t)snap * p.batch_npad;
+      const int64_t n1 = N > 1 ? N : 1;
+      e.nrow = (n1 + 3) / 4 * 4;
+      const int64_t sw = p.batch_nsplit > 1 ? p.batch_nsplit : 1;
+      e.src_per_split = ((n1 + sw - 1) / sw + 3) / 4 * 4;
+      for (int i = 0; i < 3; ++i) { e.pc[i] = sn.pc[i]; e.bpc[i] = sn.bpc[i]; }
+      e.out = p.batch_out + (size_t)snap * (size_t)sw * (size_t)p.batch_slot_elems;
+      p.batch[snap] = e;
+    }
   }
 }
 
@@ -248,6 +349,10 @@ int64_t cat_blocks(int64_t n) { return (n + kCatBlock - 1) / kCatBlock; }
 
 hipError_t launch_cat_geometry(const CatGeomParams& p, int nsnap, hipStream_t stream) {
   if (p.n == 0 || nsnap == 0) return hipSuccess;
+  if (p.n <= kCatSmallMax) {
+    hipLaunchKernelGGL(k_cat_small, dim3((unsigned)nsnap), dim3(1024), 0, stream, p);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_cat_count, dim3((unsigned)p.nblocks, (unsigned)nsnap), dim3(kCatBlock), 0, stream, p);
   hipLaunchKernelGGL(k_cat_scan, dim3((unsigned)nsnap), dim3(1024), 0, stream, p);
   hipLaunchKernelGGL(k_cat_scatter, dim3((unsigned)p.nblocks, (unsigned)nsnap), dim3(kCatBlock), 0, stream, p);

@@ -192,6 +192,10 @@ struct prisim_ctx {
     int tab_half = 0;
     int64_t cap_snaps = 0;
     int64_t chunk_nmax = 0;             // largest region of interest among the snapshots of the chunk whose geometry was formed last
+    bool geom_pending = false;          // a geometry is queued whose records nobody has waited for yet (geometry_enqueue / geometry_wait)
+    int64_t geom_nsnap = 0;
+    int geom_set = 0;
+    std::chrono::steady_clock::time_point geom_t0;
     hipStream_t gstream = nullptr;      // geometry stream (highest priority: a few small kernels beside a sky-sum grid)
     hipEvent_t ev_geom = nullptr;
     hipEvent_t ev_join = nullptr;       // "everything queued on the compute stream so far" (first preparation-stream sky after an in-line one)

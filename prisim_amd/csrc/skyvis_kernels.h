@@ -168,6 +168,7 @@ struct CatSnap {             // per-snapshot inputs (device array, one entry per
   double beta[3];            // aberration vector in the catalogue frame (observer velocity / c; zeros = none)
   double roi_pc[3];          // centre of the region of interest (roi_center = pointing centre)
   double pc[3];              // phase centre (for max |s - s_pc|)
+  double bpc[3];             // beam pointing centre (the batched launch's per-snapshot table is built on the device from this)
 };
 struct CatOut {              // per-snapshot results the host reads back (pinned memory)
   int64_t nsrc;              // sources inside the region of interest
@@ -193,7 +194,20 @@ struct CatGeomParams {
   uint32_t* keys;            // [nsnap][n] (want_keys)
   uint32_t* pos;             // [nsnap][n] (want_keys) 0, 1, 2, ...
   CatOut* out;               // [nsnap] device
+  // The per-snapshot table of a batched launch (BatchSnap, small arrays), written by the scan pass from the counts it has just formed --
+  // so that beam x flux, packing and the sky-sums of the chunk can be queued WITHOUT the host having seen the counts.  Every snapshot owns
+  // a fixed-size block: directions at t * n, beam x flux rows at t * n, packed rows at t * batch_npad (n rounded up to 4).
+  BatchSnap* batch;          // [nsnap] device, or nullptr
+  int64_t batch_npad;
+  int32_t batch_nsplit;      // source splits of the sky-sum launch
+  int32_t pad2_;
+  double* batch_out;         // nsplit == 1: cube slot of snapshot 0 of the chunk; else the partial cubes [nsnap][nsplit][slot]
+  int64_t batch_slot_elems;  // doubles per snapshot slot (nbl * nchan * 2)
+  int32_t inline_snap;       // 1: the (single) snapshot's inputs are `snap0` below, not snaps[0] -- no host-to-device copy in front of the kernel
+  int32_t pad3_;
+  CatSnap snap0;
 };
+static constexpr int64_t kCatSmallMax = 65536;     // catalogues up to this size: the whole geometry of a snapshot in ONE block (k_cat_small)
 struct CullParams {
   const double* dirs;        // [nsrc][4] in upload order
   int64_t run_lo[PRISIM_CAT_MAX_RUNS], run_hi[PRISIM_CAT_MAX_RUNS];

@@ -131,27 +131,29 @@ _NUT_TERMS = (
 )
 
 
+_NUT = NP.array(_NUT_TERMS, dtype=NP.float64)
+_NUT_MULT, _NUT_P0, _NUT_P1, _NUT_E0, _NUT_E1 = _NUT[:, :5].copy(), _NUT[:, 5].copy(), _NUT[:, 6].copy(), _NUT[:, 7].copy(), _NUT[:, 8].copy()
+
+
 def nutation_angles(jd):
     """(dpsi, deps, eps0) in radians at Julian date jd: nutation in longitude and obliquity (truncated IAU 1980) and the mean obliquity
     of the ecliptic (IAU 1980: 23 26 21.448 - 46.8150 T - 0.00059 T^2 + 0.001813 T^3)."""
     t = (float(jd) - JD_J2000) / 36525.0
-    d = math.radians(297.85036 + 445267.111480 * t - 0.0019142 * t * t + t ** 3 / 189474.0)
-    m = math.radians(357.52772 + 35999.050340 * t - 0.0001603 * t * t - t ** 3 / 300000.0)
-    mp = math.radians(134.96298 + 477198.867398 * t + 0.0086972 * t * t + t ** 3 / 56250.0)
-    f = math.radians(93.27191 + 483202.017538 * t - 0.0036825 * t * t + t ** 3 / 327270.0)
-    om = math.radians(125.04452 - 1934.136261 * t + 0.0020708 * t * t + t ** 3 / 450000.0)
-    dpsi = deps = 0.0
-    for kd, km, kmp, kf, kom, p0, p1, e0, e1 in _NUT_TERMS:
-        arg = kd * d + km * m + kmp * mp + kf * f + kom * om
-        dpsi += (p0 + p1 * t) * math.sin(arg)
-        deps += (e0 + e1 * t) * math.cos(arg)
+    fund = NP.radians(NP.array([297.85036 + 445267.111480 * t - 0.0019142 * t * t + t ** 3 / 189474.0,            # D
+                                357.52772 + 35999.050340 * t - 0.0001603 * t * t - t ** 3 / 300000.0,             # M
+                                134.96298 + 477198.867398 * t + 0.0086972 * t * t + t ** 3 / 56250.0,             # M'
+                                93.27191 + 483202.017538 * t - 0.0036825 * t * t + t ** 3 / 327270.0,             # F
+                                125.04452 - 1934.136261 * t + 0.0020708 * t * t + t ** 3 / 450000.0]))            # Omega
+    arg = _NUT_MULT.dot(fund)
+    dpsi = float(NP.dot(_NUT_P0 + _NUT_P1 * t, NP.sin(arg)))
+    deps = float(NP.dot(_NUT_E0 + _NUT_E1 * t, NP.cos(arg)))
     eps0 = (84381.448 - 46.8150 * t - 0.00059 * t * t + 0.001813 * t ** 3) * ARCSEC
     return dpsi * 1e-4 * ARCSEC, deps * 1e-4 * ARCSEC, eps0
 
 
-def nutation_matrix(jd):
+def nutation_matrix(jd, angles=None):
     """Mean equator and equinox of date -> true equator and equinox of date: r1(-(eps0 + deps)) r3(-dpsi) r1(eps0)."""
-    dpsi, deps, eps0 = nutation_angles(jd)
+    dpsi, deps, eps0 = nutation_angles(jd) if angles is None else angles
     return r1(-(eps0 + deps)).dot(r3(-dpsi)).dot(r1(eps0))
 
 
@@ -168,7 +170,7 @@ def sun_longitude(jd):
     return math.radians((l0 + c) % 360.0), e, math.radians(peri)
 
 
-def aberration_beta(jd):
+def aberration_beta(jd, eps0=None):
     """Earth's barycentric velocity / c in the MEAN equatorial frame of date, from the velocity of a Kepler orbit:
     kappa (sin L - e sin w, -cos L + e cos w, 0) in the ecliptic frame (L: longitude of the Sun, w: longitude of the perihelion),
     turned about x by the mean obliquity.  First-order annual aberration is then s' = normalise(s + beta)."""
@@ -176,7 +178,8 @@ def aberration_beta(jd):
     k = KAPPA_ABERRATION_ARCSEC * ARCSEC
     bx = k * (math.sin(lon) - e * math.sin(peri))
     by = k * (-math.cos(lon) + e * math.cos(peri))
-    eps0 = nutation_angles(jd)[2]
+    if eps0 is None:
+        eps0 = nutation_angles(jd)[2]
     return NP.array([bx, by * math.cos(eps0), by * math.sin(eps0)])
 
 
@@ -195,10 +198,12 @@ def apparent_lst_deg(jd_ut1, longitude_deg):
 
 def equatorial_to_enu(lst_deg, latitude_deg):
     """Equatorial frame of date (x to the equinox, z to the pole) -> East, North, Up at local sidereal time lst and the given latitude:
-    hour-angle frame first (x to the meridian, y to the EAST: -sin of the hour angle), then the tilt by the co-latitude."""
-    sl, cl = math.sin(math.radians(latitude_deg)), math.cos(math.radians(latitude_deg))
-    tilt = NP.array([[0.0, 1.0, 0.0], [-sl, 0.0, cl], [cl, 0.0, sl]])
-    return tilt.dot(r3(math.radians(lst_deg)))
+    hour-angle frame first (x to the meridian, y to the EAST: -sin of the hour angle), then the tilt by the co-latitude --
+    tilt . r3(lst) with tilt = [[0, 1, 0], [-sin lat, 0, cos lat], [cos lat, 0, sin lat]], written out (the entries libprisim_hip.so's
+    fall-back frame computes, catalog.cpp fallback_frame)."""
+    lat, a = math.radians(latitude_deg), math.radians(lst_deg)
+    sl, cl, s, c = math.sin(lat), math.cos(lat), math.sin(a), math.cos(a)
+    return NP.array([[-s, c, 0.0], [-sl * c, -sl * s, cl], [cl * c, cl * s, sl]])
 
 
 def hadec_to_enu(latitude_deg):
@@ -229,10 +234,25 @@ def snapshot_frame(coords, lst_deg, latitude_deg, jd=None, epoch=None, model='ap
     local = equatorial_to_enu(lst_deg, latitude_deg)
     if model == 'date' or jd is None or epoch is None or (isinstance(epoch, str) and epoch.strip().lower() == 'date'):
         return local, NP.zeros(3)             # a catalogue given in the coordinates of date (SkyModel.epoch None / 'date'): nothing to add
-    prec = precession_matrix(jyear(epoch), jyear_of_jd(jd))
+    prec = precession_from_j2000(jyear_of_jd(jd)).dot(_from_epoch_to_j2000(epoch))
     if model == 'mean':
         return local.dot(prec), NP.zeros(3)
-    return local.dot(nutation_matrix(jd)).dot(prec), prec.T.dot(aberration_beta(jd))
+    ang = nutation_angles(jd)
+    return local.dot(nutation_matrix(jd, ang)).dot(prec), prec.T.dot(aberration_beta(jd, ang[2]))
+
+
+_EPOCH_CACHE = {}
+
+
+def _from_epoch_to_j2000(epoch):
+    """Transpose of precession_from_j2000(epoch): the catalogue's equinox does not change over a run, one matrix per epoch is kept."""
+    key = epoch if isinstance(epoch, (str, float, int)) else jyear(epoch)
+    m = _EPOCH_CACHE.get(key)
+    if m is None:
+        if len(_EPOCH_CACHE) > 64:
+            _EPOCH_CACHE.clear()
+        m = _EPOCH_CACHE[key] = precession_from_j2000(jyear(epoch)).T.copy()
+    return m
 
 
 def precess_radec(radec_deg, from_epoch, to_epoch):

@@ -75,11 +75,30 @@ class _LayerStack(object):
     _ONE = NP.ones((1, 1))
 
     def ones_like(self):
-        # (one shared (1, 1) layer repeated: observe() resets bp_wts like this at EVERY snapshot (:6024), and a fresh array per existing
-        # layer made that O(n_acc^2) allocations over a run -- 0.5 ms of a 0.76 ms config-2 snapshot after 300 snapshots)
-        out = _LayerStack(self.nbl, self.nchan, self._ONE)
-        out.layers = [self._ONE] * len(self.layers)
-        return out
+        # (observe() resets bp_wts to ones of the shape of bp at EVERY snapshot (:6024): a stack that simply follows this one's length --
+        # a fresh array per existing layer made that O(n_acc^2) allocations over a run, 0.5 ms of a 0.76 ms config-2 snapshot after 300
+        # snapshots; a fresh list per snapshot still O(n_acc))
+        return _OnesStack(self)
+
+
+class _OnesStack(_LayerStack):
+    """bp_wts after observe(): ones with as many layers as the bandpass stack it follows."""
+
+    def __init__(self, parent):
+        self.nbl, self.nchan = parent.nbl, parent.nchan
+        self.initial = self._ONE
+        self.parent = parent
+
+    @property
+    def layers(self):
+        return [self._ONE] * len(self.parent.layers)
+
+    @layers.setter
+    def layers(self, value):          # (the rollback of observe_batch restores lists: nothing to restore here)
+        pass
+
+    def append(self, layer):
+        raise TypeError('bp_wts follows the bandpass stack; assign an array to replace it')
 
 
 class _LazyGradients(dict):
@@ -777,7 +796,9 @@ class InterferometerArray(object):
             raise ValueError('Specified bandpass has too many dimensions')
         self._append_layer('bp', layer)                                      # :6019-6022
         if self._stacks.get('bp') is not None:
-            self._stacks['bp_wts'] = self._stacks['bp'].ones_like()          # :6024
+            cur = self._stacks.get('bp_wts')
+            if not (isinstance(cur, _OnesStack) and cur.parent is self._stacks['bp']):
+                self._stacks['bp_wts'] = self._stacks['bp'].ones_like()      # :6024
             self._dense.pop('bp_wts', None)
         else:
             self.bp_wts = NP.ones_like(self.bp)
@@ -848,20 +869,21 @@ class InterferometerArray(object):
         def digest(a, sample=False):
             if a is None:
                 return None
-            a = NP.asarray(a)
-            if a.dtype.kind not in 'fiu':
-                return (a.shape, str(a.dtype))
+            if type(a) is not NP.ndarray:
+                a = NP.asarray(a)
+            if a.dtype != NP.float64:
+                if a.dtype.kind not in 'fiu':
+                    return (a.shape, str(a.dtype))
+                a = a.astype(NP.float64)
             flat = a.reshape(-1)
             if sample and flat.size > (1 << 20):          # a spectrum table: 65536 evenly spaced samples (plus the shape) instead of gigabytes
                 flat = flat[::flat.size // (1 << 16)]
-            w = _digest_weights(flat.size)
-            return (a.shape, float(NP.dot(flat, w)))
-        return (id(skymodel), self.skycoords, getattr(skymodel, 'spec_type', None), digest(skymodel.location),
-                digest(getattr(skymodel, 'flux_ref', None)), digest(getattr(skymodel, 'spindex', None)),
-                None if getattr(skymodel, 'ref_freq', None) is None else float(NP.sum(skymodel.ref_freq)),
-                digest(getattr(skymodel, 'spectrum', None), sample=True), digest(getattr(skymodel, 'frequency', None)),
-                digest(getattr(skymodel, 'src_shape', None)), self.channels.size, float(self.channels[0]), float(self.channels[-1]),
-                self._reserved)
+            return (a.shape, float(flat.dot(_digest_weights(flat.size))))
+        g = skymodel.__dict__.get if hasattr(skymodel, '__dict__') else (lambda k, d=None: getattr(skymodel, k, d))
+        ref_freq = g('ref_freq')
+        return (id(skymodel), self.skycoords, g('spec_type'), digest(skymodel.location), digest(g('flux_ref')), digest(g('spindex')),
+                None if ref_freq is None else float(NP.sum(ref_freq)), digest(g('spectrum'), sample=True), digest(g('frequency')),
+                digest(g('src_shape')), self.channels.size, float(self.channels[0]), float(self.channels[-1]), self._reserved)
 
     def close(self):
         """Release the GPU context.  Class state that still lives on the device is fetched first: obs_catalog_indices / geometric_delays of
@@ -986,12 +1008,19 @@ class InterferometerArray(object):
         pc = NP.asarray(pointing_center, dtype=NP.float64).reshape(1, -1)
         if pc.size != 2:
             raise ValueError('pointing_center must be a 2-element vector')
-        if not self.timestamp:
-            self.pointing_center = pc
-            self.phase_center = pc.copy()
-        else:
-            self.pointing_center = NP.vstack((self.pointing_center, pc))
-            self.phase_center = NP.vstack((self.phase_center, pc))
+        # pointing_center / phase_center are (n_acc, 2) arrays like the reference's (:6103-6108, grown there by NP.vstack: O(n) per
+        # snapshot); here both are views of buffers that grow by doubling
+        n = len(self.timestamp)
+        for name in ('pointing_center', 'phase_center'):
+            cur = getattr(self, name)
+            buf = self.__dict__.get('_buf_' + name)
+            if n == 0 or buf is None or cur.base is not buf or cur.shape[0] != n or buf.shape[0] <= n:
+                newbuf = NP.empty((max(16, 2 * (n + 1)), 2))
+                if n > 0:
+                    newbuf[:n] = NP.asarray(cur, dtype=NP.float64).reshape(-1, 2)[:n]
+                buf = self.__dict__['_buf_' + name] = newbuf
+            buf[n] = pc[0]
+            setattr(self, name, buf[:n + 1])
         # (a drift scan points at one (HA, Dec) for hours: the conversion of the previous snapshot is kept while nothing it depends on changes)
         key = (self.pointing_coords, float(pc[0, 0]), float(pc[0, 1]), lst if self.pointing_coords == 'radec' else None, self.latitude)
         cache = getattr(self, '_pointing_cache', None)

@@ -393,6 +393,7 @@ def test_batched_chunks_queued_back_to_back(prep_stream):
     k = 215                                                      # 64 + 64 + 64 + 23
     lsts = lst0 + 0.4 * NP.arange(k)
     os.environ['PRISIM_HIP_PREP_ASYNC_BATCH'] = '1' if prep_stream else '0'
+    os.environ['PRISIM_HIP_BATCH_CHUNK'] = '64'                 # (the default takes up to 256 snapshots per launch: see the test below)
     try:
         with _abi.Context(0) as ctx, _abi.Context(0) as one:
             ctx.set_array(bl, ch, nt_max=k)
@@ -403,7 +404,7 @@ def test_batched_chunks_queued_back_to_back(prep_stream):
             for rep in range(2):                                     # the second call finds every buffer in use by the first
                 counts = ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP64)
             tm = ctx.timing()
-            assert tm['last_batch_snapshots'] == k - 3 * 64, tm
+            assert tm['last_batch_snapshots'] == k - 3 * 64, tm       # (PRISIM_HIP_BATCH_CHUNK = 64 below: four chunks)
             one.set_tuning(tm['last_chan_tile'], 0, tm['last_nsplit'])
             for t in list(range(0, k, 7)) + [63, 64, 127, 128, 191, 192, k - 1]:
                 n = one.set_sky_from_catalog(obs, lsts[t], ZEN, ZEN)
@@ -416,6 +417,33 @@ def test_batched_chunks_queued_back_to_back(prep_stream):
                 assert float(NP.max(NP.abs(got - want) / scale)) <= 1e-13, t
     finally:
         del os.environ['PRISIM_HIP_PREP_ASYNC_BATCH']
+        del os.environ['PRISIM_HIP_BATCH_CHUNK']
+
+
+def test_long_runs_take_up_to_256_snapshots_per_launch():
+    """A call with more than 64 snapshots of a small array cuts chunks of up to 256 (no source splits at that length: every wave item
+    writes its cube slot directly, no partial cubes, no reduction pass); slots equal single launches cut the same way."""
+    bl, ch, sky = _small_array_case(171, 64)
+    lat, lst0 = -30.7224, 25.0
+    radec = radec_catalogue(sky, lat, lst0)
+    k = 300                                                      # 256 + 44
+    lsts = lst0 + 0.3 * NP.arange(k)
+    with _abi.Context(0) as ctx, _abi.Context(0) as one:
+        ctx.set_array(bl, ch, nt_max=k)
+        one.set_array(bl, ch, nt_max=1)
+        for c in (ctx, one):
+            c.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=14.0)
+        ctx.timing(reset=True)
+        counts = ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP64)
+        tm = ctx.timing()
+        assert tm['n_kernel'] == 2 and tm['last_batch_snapshots'] == k - 256, tm
+        for t in (0, 100, 255, 256, k - 1):
+            n = one.set_sky_from_catalog(obs, lsts[t], ZEN, ZEN)
+            assert n == counts[t]
+            one.compute(precision=_abi.PRISIM_FP64)
+            scale = NP.sum(NP.abs(one.get_pbflux()), axis=0)[None, :]
+            assert float(NP.max(NP.abs(ctx.get_vis(slot=t) - one.get_vis()) / scale)) <= 1e-13, t
 
 
 @pytest.mark.parametrize('spectra', [False, True])
