@@ -245,7 +245,10 @@ int geometry_enqueue(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapsh
   // ... or by the preparation of a sky nobody summed (two set_sky_from_catalog calls in a row, an empty region of interest)
   if (S.prep_recorded) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, S.ev_prepared, 0));
   const auto t0 = Clock::now();
-  const bool small = C.n <= kCatSmallMax;
+  // the one-block form is for the latency of small problems (HERA-19 x nside-16: a snapshot's geometry in one launch, no copies); a large
+  // array's geometry runs beside a sky-sum grid that fills the chip and must consist of many small blocks
+  const bool small = C.n <= kCatSmallMax && ctx->nbl <= kBlockThreads;
+  p.small_form = small ? 1 : 0;
   if (small && nsnap == 1) {
     p.inline_snap = 1;                       // the one snapshot's inputs travel in the kernel arguments
     p.snap0 = C.snaps_host[0];
@@ -382,7 +385,8 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
   // at most half of an all-sky catalogue, and sizing both buffer sets for all of it was 4x what the uploaded path ever allocated (a large
   // catalogue that ran before must not run out of memory here); the headroom keeps a drift scan's growing ROI from re-allocating -- a
   // device-wide synchronisation -- at every snapshot.
-  if ((rc = ensure_grow(ctx, ctx->sk->pb, (size_t)std::max<int64_t>(std::max(C.chunk_nmax, N) * ctx->nchan, 1) * sizeof(double),
+  static const bool dbg_pb_full = getenv("PRISIM_DBG_PB_FULL") != nullptr;
+  if ((rc = ensure_grow(ctx, ctx->sk->pb, (size_t)std::max<int64_t>((dbg_pb_full ? C.n : std::max(C.chunk_nmax, N)) * ctx->nchan, 1) * sizeof(double),
                         (size_t)std::max<int64_t>(C.n * ctx->nchan, 1) * sizeof(double))))
     return rc;
   if (N > 0) {
@@ -400,8 +404,11 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
       if (obs->beam_kind == PRISIM_BEAM_POLY && (rc = check_poly_beam_flag(ctx))) return rc;
     }
   }
-  HIPCHK(ctx, hipEventRecord(S.ev_prepared, ps));
-  S.prep_recorded = true;
+  static const bool dbg_no_evprep = getenv("PRISIM_DBG_NO_EVPREP") != nullptr;
+  if (!dbg_no_evprep) {
+    HIPCHK(ctx, hipEventRecord(S.ev_prepared, ps));
+    S.prep_recorded = true;
+  }
   C.cur = b;
   ctx->sky_set = true;
   return PRISIM_OK;

@@ -178,22 +178,24 @@ void k_cat_scatter(const CatGeomParams p) {
   }
 }
 
-// Small catalogues (n <= kCatSmallMax): count, scan and scatter of a snapshot in ONE block of 1024 threads (grid = snapshots) -- thread t owns
-// the contiguous sources [t m, (t + 1) m), m = ceil(n / 1024) <= 64: it counts its region-of-interest sources (flags kept as a bit mask),
-// the block scans the 1024 counts, and the thread walks its sources again writing them at their ranks.  The same cat_source(), the same
+// Small catalogues (n <= kCatSmallMax) of small arrays: count, scan and scatter of a snapshot in ONE block of 256 threads (grid = snapshots) --
+// thread t owns the contiguous sources [t m, (t + 1) m), m = ceil(n / 256) <= 64: it counts its region-of-interest sources (flags kept as a
+// bit mask), the block scans the 256 counts, and the thread walks its sources again writing them at their ranks.  (A 1024-thread block
+// was tried first: beside a large array's sky-sum grid it waited 36 ms for a whole CU to drain -- small blocks slip in as sky-sum blocks
+// retire, and large arrays keep the three-pass form anyway.)  The same cat_source(), the same
 // stable order, the same records as the three-pass form -- but one launch instead of three dependent ones, the snapshot's inputs in the
 // kernel arguments instead of behind a host-to-device copy, and the result record written straight into page-locked host memory instead of
 // through a device-to-host copy: a single snapshot's geometry costs the host one launch latency, not five (observe() on HERA-19: 45 us).
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(256)
 void k_cat_small(const CatGeomParams p) {
-  __shared__ int64_t wsum[16];
-  __shared__ double wmax[16];
+  __shared__ int64_t wsum[4];
+  __shared__ double wmax[4];
   __shared__ int64_t total_s;
   const int snap = blockIdx.x;
   const CatSnap sn = p.inline_snap ? p.snap0 : p.snaps[snap];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m = (p.n + 1023) / 1024;
-  const int64_t i0 = (int64_t)tid * m, i1 = i0 + m < p.n ? i0 + m : p.n;
+  const int64_t m = (p.n + 255) / 256;
+  const int64_t i0 = (int64_t)tid * m < p.n ? (int64_t)tid * m : p.n, i1 = i0 + m < p.n ? i0 + m : p.n;
   uint64_t mask = 0;
   for (int64_t i = i0; i < i1; ++i) {
     double l, mm, n;
@@ -210,7 +212,7 @@ void k_cat_small(const CatGeomParams p) {
   __syncthreads();
   int64_t wbase = 0;
   for (int w = 0; w < wave; ++w) wbase += wsum[w];
-  if (tid == 1023) total_s = wbase + x;
+  if (tid == 255) total_s = wbase + x;
   int64_t rank = wbase + x - cnt;                      // region-of-interest sources before source i0
   const size_t row0 = (size_t)snap * (size_t)p.n;
   double e2 = 0.0;
@@ -240,7 +242,7 @@ void k_cat_small(const CatGeomParams p) {
   if (tid == 0) {
     const int64_t N = total_s;
     double mx = wmax[0];
-    for (int w = 1; w < 16; ++w) mx = fmax(mx, wmax[w]);
+    for (int w = 1; w < 4; ++w) mx = fmax(mx, wmax[w]);
     p.out[snap].nsrc = N;
     p.out[snap].dmax2_bits = mx > 0.0 ? (uint64_t)__double_as_longlong(mx) : 0;
     // runs no source of the catalogue starts (none exist past the last run id) keep "start = N"; run 0 starts at 0
@@ -349,8 +351,8 @@ int64_t cat_blocks(int64_t n) { return (n + kCatBlock - 1) / kCatBlock; }
 
 hipError_t launch_cat_geometry(const CatGeomParams& p, int nsnap, hipStream_t stream) {
   if (p.n == 0 || nsnap == 0) return hipSuccess;
-  if (p.n <= kCatSmallMax) {
-    hipLaunchKernelGGL(k_cat_small, dim3((unsigned)nsnap), dim3(1024), 0, stream, p);
+  if (p.small_form) {
+    hipLaunchKernelGGL(k_cat_small, dim3((unsigned)nsnap), dim3(256), 0, stream, p);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_cat_count, dim3((unsigned)p.nblocks, (unsigned)nsnap), dim3(kCatBlock), 0, stream, p);

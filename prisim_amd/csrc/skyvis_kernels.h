@@ -204,10 +204,10 @@ struct CatGeomParams {
   double* batch_out;         // nsplit == 1: cube slot of snapshot 0 of the chunk; else the partial cubes [nsnap][nsplit][slot]
   int64_t batch_slot_elems;  // doubles per snapshot slot (nbl * nchan * 2)
   int32_t inline_snap;       // 1: the (single) snapshot's inputs are `snap0` below, not snaps[0] -- no host-to-device copy in front of the kernel
-  int32_t pad3_;
+  int32_t small_form;        // 1: k_cat_small (one block per snapshot, records written to page-locked host memory); 0: the three passes
   CatSnap snap0;
 };
-static constexpr int64_t kCatSmallMax = 65536;     // catalogues up to this size: the whole geometry of a snapshot in ONE block (k_cat_small)
+static constexpr int64_t kCatSmallMax = 16384;     // catalogues up to this size (of arrays of at most 256 baselines): a snapshot's geometry in ONE block
 struct CullParams {
   const double* dirs;        // [nsrc][4] in upload order
   int64_t run_lo[PRISIM_CAT_MAX_RUNS], run_hi[PRISIM_CAT_MAX_RUNS];
