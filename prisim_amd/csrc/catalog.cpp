@@ -385,8 +385,7 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
   // at most half of an all-sky catalogue, and sizing both buffer sets for all of it was 4x what the uploaded path ever allocated (a large
   // catalogue that ran before must not run out of memory here); the headroom keeps a drift scan's growing ROI from re-allocating -- a
   // device-wide synchronisation -- at every snapshot.
-  static const bool dbg_pb_full = getenv("PRISIM_DBG_PB_FULL") != nullptr;
-  if ((rc = ensure_grow(ctx, ctx->sk->pb, (size_t)std::max<int64_t>((dbg_pb_full ? C.n : std::max(C.chunk_nmax, N)) * ctx->nchan, 1) * sizeof(double),
+  if ((rc = ensure_grow(ctx, ctx->sk->pb, (size_t)std::max<int64_t>(std::max(C.chunk_nmax, N) * ctx->nchan, 1) * sizeof(double),
                         (size_t)std::max<int64_t>(C.n * ctx->nchan, 1) * sizeof(double))))
     return rc;
   if (N > 0) {
@@ -404,11 +403,8 @@ int activate_snapshot(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snaps
       if (obs->beam_kind == PRISIM_BEAM_POLY && (rc = check_poly_beam_flag(ctx))) return rc;
     }
   }
-  static const bool dbg_no_evprep = getenv("PRISIM_DBG_NO_EVPREP") != nullptr;
-  if (!dbg_no_evprep) {
-    HIPCHK(ctx, hipEventRecord(S.ev_prepared, ps));
-    S.prep_recorded = true;
-  }
+  HIPCHK(ctx, hipEventRecord(S.ev_prepared, ps));
+  S.prep_recorded = true;
   C.cur = b;
   ctx->sky_set = true;
   return PRISIM_OK;
