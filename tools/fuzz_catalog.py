@@ -1,5 +1,6 @@
 """Development helper: randomized sweep of the device-resident catalogue path (prisim_hip_set_catalog / _observe_catalog / _catalog_roi)
-against the host statements (prisim_amd/geometry.py) and the uploaded-sky path (set_sky_analytic + compute on the host-formed sky) --
+against the host statement of the snapshot's frame (prisim_amd/geometry.py frame_dircos / roi_select: index lists and direction cosines
+must be bit-identical -- fall-back rotation, explicit 'date' frames and apparent-place frames of prisim_amd/frames.py) and the uploaded-sky path (set_sky_analytic + compute on the host-formed sky) --
 array sizes around the wave / block / batch boundaries, catalogue sizes around the 256-source block boundaries, coordinate systems,
 regions of interest, source runs, flux spectra, several snapshots per call (loop chunks and the batched launch), both precisions, gradients.
 
@@ -11,7 +12,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as NP
 
-from prisim_amd import _abi, geometry as GEOM, primary_beams as PB, workloads as W
+from prisim_amd import _abi, frames as FR, geometry as GEOM, primary_beams as PB, workloads as W
 
 rng = NP.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -59,8 +60,14 @@ for case in range(ncase):
     lsts = rng.uniform(0.0, 360.0, k)
     pcs = GEOM.altaz2dircos(NP.stack((rng.uniform(60.0, 90.0, k), rng.uniform(0.0, 360.0, k)), axis=1), 'degrees')
     want_grad = bool(rng.integers(0, 6) == 0)
+    # the snapshots' frames: the library's fall-back rotation, or explicit frames -- the same rotation, or a full apparent-place frame
+    frame_kind = str(rng.choice(['fallback', 'date', 'apparent', 'mean']))
+    jd0 = float(rng.uniform(2451545.0, 2466154.0))              # 2000 ... 2040
+    host_frames = [FR.snapshot_frame(coords, float(lsts[t]), lat, jd=jd0 + 0.01 * t, epoch='J2000', model=('date' if frame_kind == 'fallback' else frame_kind))
+                   for t in range(k)]
+    frames = None if frame_kind == 'fallback' else host_frames
     what = dict(case=case, nbl=nbl, nchan=nchan, ncat=ncat, k=k, coords=coords, lat=lat, shape_kind=shape_kind, spectra=bool(spectra), roi=(roi_radius, roi_center),
-                beam=beam, ext_beam=ext_beam, grad=want_grad, maxbl=maxbl)
+                beam=beam, ext_beam=ext_beam, grad=want_grad, maxbl=maxbl, frame=frame_kind)
     stats['external beam'] += int(ext_beam)
     stats['gradient'] += int(want_grad)
     try:
@@ -77,35 +84,21 @@ for case in range(ncase):
         else:
             obs = ctx.make_obs(lat, roi_radius_deg=roi_radius, roi_center=roi_center, beam_kind=beam, diameter_m=14.0)
         for prec in (_abi.PRISIM_FP64, _abi.PRISIM_FP32):
-            counts = ctx.observe_catalog(obs, lsts, pcs, pcs, precision=prec, want_grad=want_grad)
+            counts = ctx.observe_catalog(obs, lsts, pcs, pcs, precision=prec, want_grad=want_grad, frames=frames)
             batched = ctx.timing()['last_batch_snapshots'] if k > 1 else 1
             stats['batched launches'] += int(batched > 1)
             for t in range(k):
-                # the host statements
-                if coords == 'radec':
-                    altaz = GEOM.hadec2altaz(NP.stack((lsts[t] - loc[:, 0], loc[:, 1]), axis=1), lat, units='degrees') if ncat else NP.zeros((0, 2))
-                elif coords == 'hadec':
-                    altaz = GEOM.hadec2altaz(loc, lat, units='degrees') if ncat else NP.zeros((0, 2))
-                else:
-                    altaz = loc
-                dc_all = GEOM.altaz2dircos(altaz, 'degrees') if ncat else NP.zeros((0, 3))
-                if roi_center == 'zenith':
-                    keep = altaz[:, 0] >= 90.0 - roi_radius
-                    rim = NP.abs(altaz[:, 0] - (90.0 - roi_radius)) < 1e-12
-                else:
-                    ang = NP.degrees(NP.arccos(NP.clip(dc_all @ pcs[t], -1.0, 1.0)))
-                    keep = ang <= roi_radius
-                    rim = NP.abs(ang - roi_radius) < 1e-9
-                m2 = NP.flatnonzero(keep)
-                if rim.any():
-                    continue                                   # a source on the rim: either answer is right (see tests/test_gpu_catalog.py)
+                # the host statement of the device's cat_source(): bit-identical by construction, no rim exceptions
+                dc_all = GEOM.frame_dircos(GEOM.catalog_unitvec(loc, coords), host_frames[t][0], host_frames[t][1]) if ncat else NP.zeros((0, 3))
+                m2 = GEOM.roi_select(dc_all, roi_center, roi_radius, pcs[t]) if ncat else NP.zeros(0, dtype=NP.int64)
+                altaz = GEOM.dircos2altaz(dc_all) if ncat else NP.zeros((0, 2))
                 if counts[t] != m2.size:
                     raise AssertionError('ROI count %d vs host %d (snapshot %d)' % (counts[t], m2.size, t))
                 if prec == _abi.PRISIM_FP64 and t == 0:
-                    idx, dc = ctx.catalog_roi(obs, lsts[t], pcs[t])
+                    idx, dc = ctx.catalog_roi(obs, lsts[t], pcs[t], frame=None if frames is None else frames[t])
                     if not NP.array_equal(idx, m2):
                         raise AssertionError('index lists differ')
-                    if m2.size and float(NP.max(NP.abs(dc - dc_all[m2]))) > 5e-14:
+                    if m2.size and not NP.array_equal(dc, dc_all[m2]):
                         raise AssertionError('dircos differ by %.2e' % float(NP.max(NP.abs(dc - dc_all[m2]))))
                 got = ctx.get_vis(slot=t, want_grad=want_grad)
                 if m2.size == 0:
