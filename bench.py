@@ -413,7 +413,10 @@ def config2_step(nlaunch=20, nbatch=64):
                 tm = c2.timing()
                 nb = len(ls)
                 bterms = float(cfg['baselines'].shape[0]) * cfg['channels'].size * float(NP.sum(counts))
-                kern_ms, comp_ms = tm['sum_kernel_ms'], tm['last_compute_ms'] * tm['n_kernel']
+                # (the library keeps the compute time -- sky-sum + reduction -- of the LAST launch only: with several launches per call and no
+                # source splits there is no reduction pass and compute = kernel; with splits the figure is not available)
+                kern_ms = tm['sum_kernel_ms']
+                comp_ms = tm['last_compute_ms'] if tm['n_kernel'] == 1 else (kern_ms if tm['last_nsplit'] == 1 else float('nan'))
                 if rep > 0:                                       # the first call carries the allocations
                     recs.append({'snapshots': nb, 'snapshots_per_launch': int(tm['last_batch_snapshots']), 'terms': bterms, 'chan_tile': tm['last_chan_tile'],
                                  'nsplit': tm['last_nsplit'], 'launches': int(tm['n_kernel']),
