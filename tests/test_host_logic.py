@@ -613,3 +613,144 @@ def test_vis_rms_freq_matches_reference_statements(monkeypatch, unit):
     want = g['rms_out_' + unit]
     assert ia.vis_rms_freq.shape == want.shape and NP.max(NP.abs(ia.vis_rms_freq / want - 1.0)) <= 1e-15
     assert ia.vis_noise_freq.shape == want.shape and NP.iscomplexobj(ia.vis_noise_freq)
+
+
+# ---- round 6: the resident-catalogue path of the class under failure, edits and frames (CPU: the oracle stand-in for the context) ----
+def _radec_case(monkeypatch, ctx_cls=None, nsrc=60, nbl=4, nchan=8):
+    import fake_context
+    from prisim_amd import interferometry as RI, skymodel as SM
+    monkeypatch.setattr(_abi, 'Context', ctx_cls or fake_context.OracleContext)
+    rng = NP.random.default_rng(19)
+    lat = -30.7224
+    ch = 150e6 + 2e5 * NP.arange(nchan)
+    bl = rng.uniform(-120.0, 120.0, size=(nbl, 3)) * NP.array([1.0, 1.0, 0.02])
+    skymod = SM.SkyModel(location=NP.stack((rng.uniform(0, 360, nsrc), NP.degrees(NP.arcsin(rng.uniform(-1, 0.5, nsrc)))), axis=1),
+                         flux_ref=rng.uniform(1, 5, nsrc), spindex=rng.uniform(-1, 0, nsrc), ref_freq=150e6, epoch='J2000')
+    ia = RI.InterferometerArray(['b%d' % i for i in range(nbl)], bl, ch, telescope={'id': 'hera'}, latitude=lat, skycoords='radec',
+                                pointing_coords='hadec')
+    return ia, skymod, ch, lat
+
+
+def test_out_of_device_memory_on_the_resident_path_falls_back_to_the_upload_path(monkeypatch):
+    """the resident-catalogue path sizes buffers for whole chunks; when the device says MemoryError -- in set_catalog, in a
+    single observe(), or in a batch -- the sky model continues on the per-snapshot upload path (ROI rows only), with a warning, and the
+    results are those of that path; the instance stays aligned."""
+    import warnings
+    import fake_context
+
+    class Tight(fake_context.OracleContext):
+        refuse = 'observe'
+
+        def set_catalog(self, *a, **k):
+            if Tight.refuse == 'catalog':
+                raise MemoryError('hipMalloc: out of memory (stand-in)')
+            return fake_context.OracleContext.set_catalog(self, *a, **k)
+
+        def observe_catalog(self, *a, **k):
+            if Tight.refuse in ('observe', 'batch'):
+                raise MemoryError('hipMalloc: out of memory (stand-in)')
+            return fake_context.OracleContext.observe_catalog(self, *a, **k)
+
+    want, _, _, _ = _radec_case(monkeypatch)
+    _, skymod, ch, lat = _radec_case(monkeypatch)
+    times = [(2461041.5 + 0.001 * t, 40.0 + 0.5 * t) for t in range(3)]
+    for t in times:
+        want.observe(t, {'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat], skymod, 10.0)
+    assert type(want.obs_catalog_indices[0]).__name__ == '_CatalogROI'
+    for mode in ('observe', 'catalog', 'batch'):
+        Tight.refuse = mode
+        ia, _, _, _ = _radec_case(monkeypatch, Tight)
+        ia.reserve(3)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            if mode == 'batch':
+                ia.observe_batch(times, {'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat], skymod, 10.0)
+            else:
+                for t in times:
+                    ia.observe(t, {'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat], skymod, 10.0)
+        assert sum('per-snapshot upload path' in str(x.message) for x in w) == 1, [str(x.message) for x in w]     # said once, then remembered
+        assert ia.n_acc == 3 and len(ia.timestamp) == 3 and ia.pointing_center.shape == (3, 2) and ia.bp.shape == (4, ch.size, 3)
+        assert isinstance(ia.obs_catalog_indices[0], NP.ndarray)                       # the upload path's index arrays
+        for t in range(3):
+            assert NP.array_equal(NP.asarray(ia.obs_catalog_indices[t]), NP.asarray(want.obs_catalog_indices[t]))
+        assert NP.max(NP.abs(ia.skyvis_freq - want.skyvis_freq)) <= 1e-12 * NP.max(NP.abs(want.skyvis_freq))
+
+
+def test_in_place_edits_of_the_sky_model_and_epoch_of_date(monkeypatch):
+    """The resident catalogue follows the sky model's CONTENT (flux, positions, sizes, epoch) -- an edit in place between two observe() calls
+    is seen; invalidate_catalog() forces an upload; epoch None / 'date' means coordinates of date (nothing is precessed); PRISIM_FRAME_MODEL
+    / frame_model pick the astrometric model."""
+    from prisim_amd import frames as FR, geometry as GEOM
+    ia, skymod, ch, lat = _radec_case(monkeypatch)
+    uploads = {'n': 0}
+    orig = ia._ctx.set_catalog
+
+    def counting(*a, **k):
+        uploads['n'] += 1
+        return orig(*a, **k)
+    ia._ctx.set_catalog = counting
+    args = ({'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat], skymod, 10.0)
+    ia.observe((2461041.5, 40.0), *args)
+    ia.observe((2461041.6, 41.0), *args)
+    assert uploads['n'] == 1                                             # unchanged model: stays resident
+    skymod.flux_ref[7] *= 3.0                                            # one element, in place
+    ia.observe((2461041.5, 40.0), *args)
+    assert uploads['n'] == 2 and NP.max(NP.abs(ia.skyvis_freq[:, :, 2] - ia.skyvis_freq[:, :, 0])) > 0
+    skymod.flux_ref[7] /= 3.0
+    skymod.location[3, 1] += 0.5
+    ia.observe((2461041.5, 40.0), *args)
+    assert uploads['n'] == 3
+    ia.invalidate_catalog()
+    ia.observe((2461041.5, 40.0), *args)
+    assert uploads['n'] == 4
+    # epoch: J2000 -> precessed; None / 'date' -> hour angle = LST - RA on the coordinates as given
+    sel_app = NP.asarray(ia.obs_catalog_indices[-1])
+    rot, beta = FR.snapshot_frame('radec', 40.0, lat, jd=2461041.5, epoch='J2000', model='apparent')
+    assert NP.array_equal(sel_app, GEOM.roi_select(GEOM.frame_dircos(GEOM.catalog_unitvec(skymod.location, 'radec'), rot, beta), 'zenith', 90.0))
+    for epoch in (None, 'date'):
+        skymod.epoch = epoch
+        ia.observe((2461041.5, 40.0), *args)
+        rot, beta = FR.snapshot_frame('radec', 40.0, lat, model='date')
+        dc = GEOM.frame_dircos(GEOM.catalog_unitvec(skymod.location, 'radec'), rot, beta)
+        assert NP.array_equal(NP.asarray(ia.obs_catalog_indices[-1]), GEOM.roi_select(dc, 'zenith', 90.0))
+        assert NP.max(NP.abs(NP.asarray(ia.geometric_delays[-1]) - dc[GEOM.roi_select(dc, 'zenith', 90.0)].dot(ia.baselines.T) / 299792458.0)) <= 1e-18
+    skymod.epoch = 'J2000'
+    ia.frame_model = 'mean'
+    ia.observe((2461041.5, 40.0), *args)
+    rot, beta = FR.snapshot_frame('radec', 40.0, lat, jd=2461041.5, epoch='J2000', model='mean')
+    assert NP.all(beta == 0.0)
+    assert NP.array_equal(NP.asarray(ia.obs_catalog_indices[-1]),
+                          GEOM.roi_select(GEOM.frame_dircos(GEOM.catalog_unitvec(skymod.location, 'radec'), rot, beta), 'zenith', 90.0))
+    with pytest.raises(ValueError):
+        ia.frame_model = 'ptolemaic'
+        ia.observe((2461041.5, 40.0), *args)
+
+
+def test_frame_provider_in_a_batch_and_close(monkeypatch):
+    """A caller-supplied frame is asked once per snapshot of a batch, with that snapshot's (jd, lst); close() fetches
+    what still lives on the device (index lists, snapshots) before the context goes."""
+    from prisim_amd import frames as FR
+    ia, skymod, ch, lat = _radec_case(monkeypatch)
+    calls = []
+
+    def provider(jd, lst, sm):
+        calls.append((jd, lst))
+        return FR.snapshot_frame('radec', lst, lat, jd=jd, epoch=sm.epoch, model='apparent')
+    ia.frame_provider = provider
+    times = [(2461041.5 + 0.002 * t, 10.0 + t) for t in range(4)]
+    ia.observe_batch(times, {'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat], skymod, 10.0)
+    assert calls == times
+    builtin, _, _, _ = _radec_case(monkeypatch)
+    builtin.observe_batch(times, {'Tnet': 100.0}, NP.ones(ch.size), [0.0, lat], skymod, 10.0)
+    assert NP.array_equal(ia.skyvis_freq, builtin.skyvis_freq)
+    closed = {'n': 0}
+    real_close = ia._ctx.close
+
+    def closing():
+        closed['n'] += 1
+        real_close()
+    ia._ctx.close = closing
+    assert type(ia.obs_catalog_indices[2]).__name__ == '_CatalogROI' and ia.obs_catalog_indices[2]._idx is None      # still lazy
+    ia.close()
+    assert closed['n'] == 1 and ia.obs_catalog_indices[2]._idx is not None                                            # fetched first
+    assert NP.array_equal(NP.asarray(ia.obs_catalog_indices[2]), NP.asarray(builtin.obs_catalog_indices[2]))
