@@ -56,6 +56,7 @@ int catalog_streams(prisim_ctx* ctx) {
   if (!C.ev_geom) HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_geom, hipEventDisableTiming));
   if (!C.ev_join) HIPCHK(ctx, hipEventCreateWithFlags(&C.ev_join, hipEventDisableTiming));
   for (auto& e : C.ev_tab) { if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+  for (auto& e : C.ev_tabfree) { if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
   for (auto& s : C.set) {
     if (!s.ev_free) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming));
     if (!s.ev_prepared) HIPCHK(ctx, hipEventCreateWithFlags(&s.ev_prepared, hipEventDisableTiming));
@@ -424,9 +425,10 @@ bool wave_batch_eligible(const prisim_ctx* ctx, const prisim_obs* obs, int preci
   if (const char* env = getenv("PRISIM_HIP_WAVE_BATCH")) { if (atoi(env) == 0) return false; }
   if (const char* env = getenv("PRISIM_HIP_WAVE_ITEMS")) { if (atoi(env) == 0) return false; }
   if (kc < 1 || precision != PRISIM_FP64 || want_grad || !ctx->uniform || ctx->nbl > kBlockThreads || ctx->nchan < 16) return false;
-  // one snapshot per call: the per-snapshot chain (its planner cuts a single snapshot finer: 16-channel tiles x 42 splits; through the
-  // batched launch a lone HERA-19 snapshot took 143 us against 118).  PRISIM_HIP_WAVE_BATCH_SINGLE=1: the A/B hook.
-  if (kc < 2) { const char* env = getenv("PRISIM_HIP_WAVE_BATCH_SINGLE"); if (!(env && atoi(env) != 0)) return false; }
+  // one snapshot per call (observe() on a small array) takes the batched launch too -- 16-channel tiles, one round of wave slots, prepared
+  // on the preparation stream under the previous snapshot's sky-sum, queued without a count (run_wave_batch): 100 us per observe() of
+  // HERA-19 against 115 through the per-snapshot chain (tools/observe_single_ab.py).  PRISIM_HIP_WAVE_BATCH_SINGLE=0: that chain (A/B).
+  if (kc < 2) { const char* env = getenv("PRISIM_HIP_WAVE_BATCH_SINGLE"); if (env && atoi(env) == 0) return false; }
   // (sizes may vary from source to source and the sky may consist of several runs -- point sources + a diffuse map: every source
   // carries its own kappa, and with nothing to cull the runs need no separate launches; point sources then pay the taper kernel's 9.7
   // instead of the plain kernel's 6.2 instructions per term, which a launch per run and snapshot would cost many times over)
@@ -461,7 +463,9 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   // is two large compute-bound launches (beam x flux, packing), and under the previous chunk's sky-sum they only take its CUs away
   // (config 2 x 64 snapshots, 8 chunks queued: 1.975 ms per chunk on the preparation stream, the sky-sum slowed from 1.46 to 1.84 ms;
   // 1.885 ms in line).  The host is ahead either way: the geometry of the next chunk runs on its own stream.
-  bool async = false;
+  // ... A SINGLE snapshot per call (observe() on a small array) is the opposite case: its preparation is a few latency-bound launches, and
+  // on the preparation stream (two sky-buffer sets) it runs under the previous snapshot's sky-sum.
+  bool async = kc == 1;
   if (const char* env = getenv("PRISIM_HIP_PREP_ASYNC_BATCH")) async = atoi(env) != 0;
   if (async) {
     if ((rc = enter_prep_stream(ctx))) return rc;
@@ -475,7 +479,8 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   // plan: 32-channel tiles (the seed of a (source, baseline, tile) triple is 26 % of a 32-channel tile's instructions, 41 % of a
   // 16-channel tile's), source splits so that the grid is about three rounds of two wavefronts per SIMD.  Everything here is a function
   // of the array, the catalogue and the chunk length -- never of the counts, which the host has not seen.
-  int ct = ctx->tune_ct ? ctx->tune_ct : (ctx->nchan >= 32 ? 32 : 16);
+  // (one snapshot alone: 16-channel tiles and one round of wave slots -- the cut the single-launch planner arrives at for HERA-19)
+  int ct = ctx->tune_ct ? ctx->tune_ct : ((ctx->nchan >= 32 && kc > 1) ? 32 : 16);
   if (ct != 16 && ct != 32) ct = 32;
   const int ntiles = (int)((ctx->nchan + ct - 1) / ct);
   const int nbw = (int)((ctx->nbl + 63) / 64);
@@ -484,7 +489,7 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   if (nsplit == 0) {
     const int64_t slots = 2LL * 4 * std::max(ctx->cu_count, 1);
     const int64_t items0 = kc * nbw * ntiles;
-    const int64_t lo = std::max<int64_t>(1, (5 * slots / 2 + items0 - 1) / items0);
+    const int64_t lo = std::max<int64_t>(1, ((kc > 1 ? 5 * slots / 2 : slots) + items0 - 1) / items0);
     // ... and of those counts the one whose last round is fullest (config 2 x 64 snapshots: 3 splits = 2.25 rounds 1.66 ms, 4 = 3.0 rounds
     // 1.52 ms, 5 = 3.75 rounds 1.58 ms; tools/config2_batch_sweep.py)
     double best = 1e30;
@@ -494,13 +499,17 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
       const double waste = std::ceil(r) / r + 0.002 * (double)(n - lo);
       if (waste < best - 1e-12) { best = waste; nsplit = n; }
     }
+    if (kc == 1) nsplit = std::max<int64_t>(1, slots / items0);              // one snapshot alone: ONE round of wave slots, never a second
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, C.n / 32));      // (a horizon region of interest holds about half the catalogue)
     nsplit = std::min<int64_t>(nsplit, 64);
   }
   const size_t slot_elems = (size_t)ctx->nbl * ctx->nchan * 2;
   const int64_t pitch = kc * npad;                     // packed rows / prepared directions: snapshot t owns rows [t npad, (t + 1) npad)
   const size_t pb_rows = (size_t)kc * (size_t)std::max<int64_t>(C.n, 1);
-  if ((rc = ensure(ctx, K.batch_tab, (size_t)kc * sizeof(BatchSnap))) ||
+  const int ti = C.tab_next;
+  C.tab_next = (ti + 1) & 3;
+  DevBuf& tabbuf = C.batch_tabs[ti];
+  if ((rc = ensure(ctx, tabbuf, (size_t)std::max<int64_t>(kc, 64) * sizeof(BatchSnap))) ||
       (nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)kc * (size_t)nsplit * slot_elems * sizeof(double)))) ||
       (rc = ensure(ctx, K.pb, pb_rows * ctx->nchan * sizeof(double))) ||
       (rc = ensure(ctx, K.packed, (size_t)ntiles * (size_t)pitch * ct * sizeof(double))) ||
@@ -511,14 +520,14 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
        (rc = ensure(ctx, ctx->ext_colmax, std::max<size_t>((size_t)kc * (kExtBatchBlocks + 1), 1025) * ctx->nchan * sizeof(double)))))
     return rc;
   BatchLayout lay;
-  lay.tab = (BatchSnap*)K.batch_tab.p;
+  lay.tab = (BatchSnap*)tabbuf.p;
   lay.npad = npad;
   lay.nsplit = (int32_t)nsplit;
   lay.slot_elems = (int64_t)slot_elems;
   lay.out = nsplit > 1 ? (double*)ctx->partial.p : (double*)ctx->cube.p + (size_t)slot0 * slot_elems;
-  // the table lives in the sky-buffer set: an earlier chunk's launches that read it are on the compute / preparation stream, the
-  // geometry stream writes it -- order the write behind them (the set's geometry buffers are ordered by ev_free / ev_prepared already)
-  if (K.sum_recorded) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, K.ev_sum, 0));
+  // the table is one of a ring of four: the launches of the chunk that used this one four chunks ago read it on the compute / preparation
+  // stream, the geometry stream writes it -- order the write behind them (the set's geometry buffers are ordered by ev_free / ev_prepared)
+  if (C.tabfree_rec[ti]) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, C.ev_tabfree[ti], 0));
   { HostSpan sp("geometry_enqueue"); if ((rc = geometry_enqueue(ctx, obs, snaps, kc, b, want_keys, &lay))) return rc; }
   HIPCHK(ctx, hipStreamWaitEvent(ps, C.ev_geom, 0));
   const int64_t nmax = C.n;
@@ -529,7 +538,7 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
                                          C.have_spec ? (const double*)C.spec.p : nullptr, C.have_spec ? nullptr : (const double*)C.flux_ref.p,
                                          C.have_spec ? nullptr : (const double*)C.spindex.p, (const double*)ctx->freqs.p, C.have_spec ? 1.0 : C.ref_freq,
                                          (double*)ctx->ext_work.p, (double*)ctx->ext_colmax.p, (double*)K.pb.p, nmax, ctx->nchan,
-                                         (const int32_t*)S.idx.p, (const BatchSnap*)K.batch_tab.p, (int)kc, ps));
+                                         (const int32_t*)S.idx.p, (const BatchSnap*)tabbuf.p, (int)kc, ps));
   } else {
     BeamParams bp{};
     bp.dirs = (const double*)S.dirs.p;
@@ -554,11 +563,11 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
     bp.flag = (int32_t*)ctx->sky_flag.p;
     bp.nsrc = nmax; bp.nchan = ctx->nchan;
     bp.pb_out = (double*)K.pb.p;
-    bp.batch = (const BatchSnap*)K.batch_tab.p;
+    bp.batch = (const BatchSnap*)tabbuf.p;
     HIPCHK(ctx, launch_beam_flux_batch(bp, (int)kc, ps));
   }
   HIPCHK(ctx, launch_pack_prep_batch((const double*)K.pb.p, (double*)K.packed.p, pitch, npad, ctx->nchan, ct, ntiles, (const double*)S.dirs.p,
-                                     (double*)K.dirs_prep.p, 1.0 / kC, (const BatchSnap*)K.batch_tab.p, (int)kc, ps));
+                                     (double*)K.dirs_prep.p, 1.0 / kC, (const BatchSnap*)tabbuf.p, (int)kc, ps));
   if ((rc = join_prep(ctx))) return rc;
   // the sky-sums of the whole chunk: ONE launch, ONE reduction
   harvest_timing(ctx, ctx->ring_pending >= prisim_ctx::kTimingRing ? 1 : 0);
@@ -576,7 +585,7 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   p.ntiles = ntiles; p.nsplit = 1; p.src_per_split = 0; p.src_chunk = 4;
   p.flush_src = 16384; p.scale_comp = -1;
   p.wave_nbw = nbw; p.wave_nsplit = (int32_t)nsplit;
-  p.wave_snaps = (const BatchSnap*)K.batch_tab.p; p.wave_nsnap = (int32_t)kc;
+  p.wave_snaps = (const BatchSnap*)tabbuf.p; p.wave_nsnap = (int32_t)kc;
   p.nbgroups = (int32_t)((kc * nbw * nsplit + kBlockThreads / 64 - 1) / (kBlockThreads / 64));
   p.out = (double*)ctx->cube.p;
   const int ri = ctx->ring_head;
@@ -590,6 +599,8 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   HIPCHK(ctx, hipEventRecord(ctx->ev_c1[ri], ctx->stream));
   HIPCHK(ctx, hipEventRecord(K.ev_sum, ctx->stream));      // (in line too: a later preparation-stream user of this set waits for these sums)
   K.sum_recorded = true;
+  HIPCHK(ctx, hipEventRecord(C.ev_tabfree[ti], ctx->stream));
+  C.tabfree_rec[ti] = true;
   C.cur = b;
   catalog_after_compute(ctx);
   ctx->ring_head = (ctx->ring_head + 1) % prisim_ctx::kTimingRing;
@@ -656,6 +667,8 @@ void catalog_destroy(prisim_ctx* ctx) {
   if (C.ev_geom) (void)hipEventDestroy(C.ev_geom);
   if (C.ev_join) (void)hipEventDestroy(C.ev_join);
   for (auto& e : C.ev_tab) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& e : C.ev_tabfree) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& b : C.batch_tabs) release(b);
   C.tab_recorded[0] = C.tab_recorded[1] = false;
   if (C.out_host) (void)hipHostFree(C.out_host);
   if (C.snaps_host) (void)hipHostFree(C.snaps_host);
@@ -785,6 +798,7 @@ int prisim_hip_set_catalog(prisim_ctx* ctx, const prisim_catalog* cat) {
   C.ref_freq = have_spec ? 1.0 : cat->ref_freq_hz;
   release(C.sort_tmp);                 // sized per catalogue
   for (auto& s : C.set) s.ev_recorded = s.prep_recorded = false;
+  for (auto& r : C.tabfree_rec) r = false;
   C.loaded = true;
   return PRISIM_OK;
   });

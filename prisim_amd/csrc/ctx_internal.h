@@ -192,6 +192,12 @@ struct prisim_ctx {
     int tab_half = 0;
     int64_t cap_snaps = 0;
     int64_t chunk_nmax = 0;             // largest region of interest among the snapshots of the chunk whose geometry was formed last
+    // per-snapshot tables of the batched launches: a ring of four, so that the geometry that WRITES the table of chunk c never waits for
+    // the sums of chunk c - 1 that still read theirs (one event per table: recorded behind the sums that read it)
+    DevBuf batch_tabs[4];
+    hipEvent_t ev_tabfree[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool tabfree_rec[4] = {false, false, false, false};
+    int tab_next = 0;
     bool geom_pending = false;          // a geometry is queued whose records nobody has waited for yet (geometry_enqueue / geometry_wait)
     int64_t geom_nsnap = 0;
     int geom_set = 0;
