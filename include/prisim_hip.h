@@ -293,7 +293,9 @@ typedef struct prisim_post {
  * most 256 baselines in fp64 (uniform channel grid, no gradient; analytic Gaussian / Airy / delta / dipole beams with or without array
  * factor and ground plane, or the external HEALPix beam; catalogues with or without source shapes, unless the taper culling could
  * shorten something) put the beam x flux, the packing and the sky-sums of a whole chunk of up to 256 snapshots into ONE launch each -- the
- * sky-sum's work item is (snapshot, baseline wave, channel tile, source split) -- and ONE reduction.  Replaces the loop of
+ * sky-sum's work item is (snapshot, baseline wave, channel tile, source split) -- and ONE reduction; the launch's per-snapshot table is
+ * written by the geometry on the device, so such a chunk (a single snapshot included: nsnap = 1 is a chunk of one) is queued without the
+ * host having seen a count, and the counts are read when everything is queued.  Replaces the loop of
  * interferometry.py:6641-6647 / scripts/run_prisim.py:2165-2207.  nsrc_roi: [nsnap] or NULL; post: NULL = nothing. */
 int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int precision,
                                int want_grad, int64_t slot0, int64_t* nsrc_roi, const prisim_post* post);
