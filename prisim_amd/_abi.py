@@ -744,6 +744,8 @@ class Context(object):
         if len(uid) != 128:
             raise ValueError('unique id must be 128 bytes')
         self._check(self._lib.prisim_hip_comm_init(self._h, uid, int(nranks), int(rank)), 'prisim_hip_comm_init')
+        if getattr(self, 'nranks', 1) != int(nranks):
+            self.nbl_total = 0                       # (the library drops a shard map made for another communicator size)
         self.nranks = int(nranks)
 
     def allgather(self, nt, complex64=False):

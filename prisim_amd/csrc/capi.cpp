@@ -1776,6 +1776,10 @@ int prisim_hip_comm_init(prisim_ctx* ctx, const char id[128], int nranks, int ra
     ctx->comm = nullptr;
     return fail(ctx, PRISIM_ELIB, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
   }
+  if (nranks != ctx->nranks && ctx->nbl_total > 0) {
+    // a shard map is a table of nranks x nbl_shard rows: one made for another communicator size must not be walked with this one
+    ctx->nbl_total = 0; ctx->shard_map_h.clear(); release(ctx->shard_map); release(ctx->gathered);
+  }
   ctx->nranks = nranks; ctx->rank = rank;
   return PRISIM_OK;
   });
@@ -1797,6 +1801,8 @@ static int gather_one_slot(prisim_ctx* ctx, const double* src_all, int64_t row, 
   }
   const bool receiver = ctx->gather_root < 0 || ctx->gather_root == ctx->rank;
   const bool ordered = ctx->nbl_total > 0;
+  if (ordered && ctx->shard_map_h.size() != (size_t)ctx->nranks * (size_t)ctx->nbl)
+    return fail(ctx, PRISIM_ESTATE, "the shard map does not match the communicator size and the shard size (set it after comm_init and set_array)");
   char* dst = nullptr;
   if (receiver) {
     if (ordered) {
