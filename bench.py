@@ -830,6 +830,7 @@ def main():
     os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')          # single node: RCCL bootstraps over loopback (one node is all this bench does)
     if world > 1:
         os.environ.setdefault('NCCL_DEBUG', 'WARN')            # a communicator that cannot be built says why, on stderr
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (what RCCL's peer-to-peer set-up needs on this driver); set before HIP loads, as prisim_amd.launch does
     rdzv = rendezvous.Rendezvous(rank, world)                  # sockets only: before any GPU call
 
     if args.workload == 'cfg5':

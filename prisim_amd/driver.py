@@ -618,6 +618,7 @@ def main(argv=None):
     rdzv = rendezvous.Rendezvous(rank, world)      # loopback sockets; no torch, nothing touches the GPU before this returns
     if world > 1:
         os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # (as prisim_amd.launch sets it: ranks started by another launcher need it too)
         with WATCHDOG.CommDeadline(rank, local_rank) as deadline:
             deadline.step('rendezvous: broadcast of the RCCL unique id')
             uid = rdzv.broadcast_bytes(_abi.Context.comm_unique_id() if rank == 0 else b'')
