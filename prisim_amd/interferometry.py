@@ -872,7 +872,8 @@ class InterferometerArray(object):
                 flat = NP.ascontiguousarray(flat)
             u = flat.view(NP.uint64)
             return (a.shape, int(NP.add.reduce(u)))
-        g = skymodel.__dict__.get if hasattr(skymodel, '__dict__') else (lambda k, d=None: getattr(skymodel, k, d))
+        def g(k):
+            return getattr(skymodel, k, None)      # (attributes, class-level defaults and properties alike)
         ref_freq = g('ref_freq')
         return (id(skymodel), self.skycoords, g('spec_type'), digest(skymodel.location), digest(g('flux_ref')), digest(g('spindex')),
                 None if ref_freq is None else float(NP.sum(ref_freq)), digest(g('spectrum'), sample=True), digest(g('frequency')),
