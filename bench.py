@@ -459,6 +459,31 @@ def config2_step(nlaunch=20, nbatch=64):
         c2.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
         obs = c2.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=cfg['diameter'])
         out['batch_long'] = batch_case(lst0 + 0.05 * NP.arange(nlong), 3)
+        # the other two modes of interferometry.py:6320-6343 through the same launch, 256 LSTs in one call: an fp32 request (memsave; served by
+        # the fp64 launch on arrays this small -- include/prisim_hip.h) and visibilities + baseline gradients (16-flop contract)
+        def mode_case(prec, grad, flop):
+            ls = lst0 + 0.05 * NP.arange(256)
+            recs = []
+            for rep in range(4):
+                c2.sync()
+                c2.timing(reset=True)
+                t0 = time.perf_counter()
+                counts = c2.observe_catalog(obs, ls, zen, precision=prec, want_grad=grad)
+                c2.sync()
+                wall = time.perf_counter() - t0
+                tm = c2.timing()
+                bterms = float(cfg['baselines'].shape[0]) * cfg['channels'].size * float(NP.sum(counts))
+                if rep > 0:
+                    recs.append({'snapshots_per_launch': int(tm['last_batch_snapshots']), 'launches': int(tm['n_kernel']), 'chan_tile': tm['last_chan_tile'],
+                                 'nsplit': tm['last_nsplit'], 'kernel_us_per_snapshot': 1e3 * tm['sum_kernel_ms'] / ls.size,
+                                 'call_us_per_snapshot': 1e6 * wall / ls.size, 'flop_per_term_fp64_contract': flop,
+                                 'roofline_frac_kernel': bterms * flop / (tm['sum_kernel_ms'] * 1e-3) / 1e12 / PEAK_TFLOPS['f64'],
+                                 'roofline_frac_whole_call': bterms * flop / wall / 1e12 / PEAK_TFLOPS['f64']})
+            mid = sorted(recs, key=lambda r: r['call_us_per_snapshot'])[len(recs) // 2]
+            return dict(mid, passes=len(recs), call_us_spread=spread([r['call_us_per_snapshot'] for r in recs]))
+        out['batch_modes'] = {'fp32_request': dict(mode_case(_abi.PRISIM_FP32, False, FLOPS_PER_TERM), arithmetic='fp64 (the batched launch serves fp32 requests of small arrays)'),
+                              'gradient': mode_case(_abi.PRISIM_FP64, True, 16.0),
+                              'what': '256 LSTs of config 2 in one call; median of 3 calls after a warm-up; fractions of the fp64 vector peak'}
     # ... and through the class: InterferometerArray.observe() per snapshot / observe_batch() on the (RA, Dec) sky model, 64 snapshots queued
     # (the second 64 of an instance: its catalogue, streams and buffers resident; `fresh` = the first 64, which carry those once); median of 3
     cls = {}

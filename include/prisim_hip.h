@@ -290,12 +290,16 @@ typedef struct prisim_post {
 
 /* nsnap snapshots in one call: the geometry of all of them first (chunks of snapshots, ONE readback per chunk), then for snapshot t
  * sky + compute into cube slot slot0 + t, queued back to back without any host synchronisation on the compute stream.  Arrays of at
- * most 256 baselines in fp64 (uniform channel grid, no gradient; analytic Gaussian / Airy / delta / dipole beams with or without array
+ * most 256 baselines (uniform channel grid; analytic Gaussian / Airy / delta / dipole beams with or without array
  * factor and ground plane, or the external HEALPix beam; catalogues with or without source shapes, unless the taper culling could
  * shorten something) put the beam x flux, the packing and the sky-sums of a whole chunk of up to 256 snapshots into ONE launch each -- the
  * sky-sum's work item is (snapshot, baseline wave, channel tile, source split) -- and ONE reduction; the launch's per-snapshot table is
  * written by the geometry on the device, so such a chunk (a single snapshot included: nsnap = 1 is a chunk of one) is queued without the
- * host having seen a count, and the counts are read when everything is queued.  Replaces the loop of
+ * host having seen a count, and the counts are read when everything is queued.  All three modes of interferometry.py:6320-6343 take that
+ * launch: fp64; want_grad (visibilities + the three baseline-gradient sums, wave items of 16 baselines x 4 sources on the fp64 matrix
+ * instruction); and precision = PRISIM_FP32 -- on arrays this small the ARITHMETIC of an fp32 request is done by the same fp64 launch (a
+ * snapshot costs its launches, not its flops: HERA-19 39 us per snapshot against 106 through a per-snapshot fp32 chain), so the result
+ * is the fp64 one, inside the fp32 tolerance by nine orders of magnitude; PRISIM_HIP_BATCH_FP32_AS_FP64=0 keeps fp32 arithmetic.  Replaces the loop of
  * interferometry.py:6641-6647 / scripts/run_prisim.py:2165-2207.  nsrc_roi: [nsnap] or NULL; post: NULL = nothing. */
 int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int64_t nsnap, int precision,
                                int want_grad, int64_t slot0, int64_t* nsrc_roi, const prisim_post* post);

@@ -939,11 +939,6 @@ static bool taper_split_plan(prisim_ctx* ctx, const Plan& pl, const SkyvisParams
 // one sky-sum pass into `dst` ([nbl][nchan] complex128); scale_comp >= 0 multiplies pbflux rows by dircos[:,comp]
 // Wave items (k_skyvis_taper_f64_wave): the grouped fp64 taper kernel on an array of one baseline group whose sources are split.
 // PRISIM_HIP_WAVE_ITEMS=0: block items (the A/B baseline).
-static bool grad_taper_grouped() {
-  const char* env = getenv("PRISIM_HIP_GRAD_TAPER_GROUP");
-  return !(env && atoi(env) == 0);
-}
-
 static bool wave_items(const prisim_ctx* ctx, const Plan& pl) {
   bool on = !pl.f32 && ctx->taper && (pl.ct == 16 || pl.ct == 32) && pl.kernel == PRISIM_KERNEL_RECURRENCE && pl.nsplit > 1 &&
             ctx->nbl <= kBlockThreads;

@@ -190,6 +190,7 @@ struct BatchLayout {
   int32_t nsplit = 1;
   double* out = nullptr;
   int64_t slot_elems = 0;
+  double* gout = nullptr;      // gradient batches (BatchSnap::gout)
 };
 
 // Geometry of nsnap snapshots into buffer set b, queued on the geometry stream; ev_geom is recorded behind the copy of the per-snapshot
@@ -240,6 +241,7 @@ int geometry_enqueue(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapsh
   p.out = (CatOut*)C.out_dev.p;
   if (batch) {
     p.batch = batch->tab; p.batch_npad = batch->npad; p.batch_nsplit = batch->nsplit; p.batch_out = batch->out; p.batch_slot_elems = batch->slot_elems;
+    p.batch_gout = batch->gout;
   }
   // the set may still be read by sky-sums queued earlier on the compute stream
   if (S.ev_recorded) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, S.ev_free, 0));
@@ -424,7 +426,18 @@ bool wave_batch_eligible(const prisim_ctx* ctx, const prisim_obs* obs, int preci
   const auto& C = ctx->cat;
   if (const char* env = getenv("PRISIM_HIP_WAVE_BATCH")) { if (atoi(env) == 0) return false; }
   if (const char* env = getenv("PRISIM_HIP_WAVE_ITEMS")) { if (atoi(env) == 0) return false; }
-  if (kc < 1 || precision != PRISIM_FP64 || want_grad || !ctx->uniform || ctx->nbl > kBlockThreads || ctx->nchan < 16) return false;
+  // precision: a request for fp32 arithmetic (PRISim's memsave) on an array this small is served by the SAME fp64 launch -- the cost of
+  // a small array's snapshot is its launches, not its arithmetic (HERA-19: 26 us per snapshot batched in fp64 against a 45-50 us launch
+  // chain per snapshot in either precision), and the result is the fp64 one (well inside the fp32 tolerance).  PRISIM_HIP_BATCH_FP32_AS_FP64=0:
+  // fp32 requests keep the per-snapshot fp32 chain.
+  if (precision != PRISIM_FP64) { const char* env = getenv("PRISIM_HIP_BATCH_FP32_AS_FP64"); if (env && atoi(env) == 0) return false; }
+  // want_grad: the grouped fp64 gradient kernel on wave items of 16 baselines (k_skyvis_grad_taper_f64_batch), 32-channel tiles
+  if (kc < 1 || !ctx->uniform || ctx->nbl > kBlockThreads || ctx->nchan < 16) return false;
+  if (want_grad) {
+    if (!grad_taper_grouped()) return false;
+    if (const char* env = getenv("PRISIM_HIP_WAVE_BATCH_GRAD")) { if (atoi(env) == 0) return false; }
+    if (const char* env = getenv("PRISIM_HIP_FUSED_GRAD")) { if (atoi(env) == 0) return false; }
+  }
   // one snapshot per call (observe() on a small array) takes the batched launch too -- 16-channel tiles, one round of wave slots, prepared
   // on the preparation stream under the previous snapshot's sky-sum, queued without a count (run_wave_batch): 100 us per observe() of
   // HERA-19 against 115 through the per-snapshot chain (tools/observe_single_ab.py).  PRISIM_HIP_WAVE_BATCH_SINGLE=0: that chain (A/B).
@@ -454,7 +467,7 @@ bool wave_batch_eligible(const prisim_ctx* ctx, const prisim_obs* obs, int preci
 // compute stream waits for the geometry by event.  The host reads the counts (nsrc_roi, timing) at the END, when they have long arrived:
 // a chunk costs no round trip to the device any more (a single observe() of HERA-19 spent 45 of its 118 us waiting for one).
 int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot* snaps, int b, int64_t kc, int64_t slot0, int64_t* nsrc_roi,
-                   bool want_keys) {
+                   bool want_keys, bool want_grad) {
   auto& C = ctx->cat;
   auto& S = C.set[b];
   int rc;
@@ -480,10 +493,12 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   // 16-channel tile's), source splits so that the grid is about three rounds of two wavefronts per SIMD.  Everything here is a function
   // of the array, the catalogue and the chunk length -- never of the counts, which the host has not seen.
   // (one snapshot alone: 16-channel tiles and one round of wave slots -- the cut the single-launch planner arrives at for HERA-19)
+  // (V + gradient: the MFMA kernel's wave follows 16 baselines x 4 sources on 32-channel tiles)
   int ct = ctx->tune_ct ? ctx->tune_ct : ((ctx->nchan >= 32 && kc > 1) ? 32 : 16);
   if (ct != 16 && ct != 32) ct = 32;
+  if (want_grad) ct = 32;
   const int ntiles = (int)((ctx->nchan + ct - 1) / ct);
-  const int nbw = (int)((ctx->nbl + 63) / 64);
+  const int nbw = want_grad ? (int)((ctx->nbl + 15) / 16) : (int)((ctx->nbl + 63) / 64);
   const int64_t npad = round_up(std::max<int64_t>(C.n, 1), 4);
   int64_t nsplit = ctx->tune_nsplit;
   if (nsplit == 0) {
@@ -509,8 +524,15 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   const int ti = C.tab_next;
   C.tab_next = (ti + 1) & 3;
   DevBuf& tabbuf = C.batch_tabs[ti];
+  // partial cubes: [kc][nsplit][slot] of V, then (gradient) [kc][nsplit][3 slot]
+  const size_t part_v = (size_t)kc * (size_t)nsplit * slot_elems;
+  if (want_grad && !ctx->grad.p) {
+    const size_t gbytes = (size_t)ctx->nt_max * 3 * slot_elems * sizeof(double);
+    if ((rc = ensure(ctx, ctx->grad, gbytes))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->grad.p, 0, gbytes, ctx->stream));
+  }
   if ((rc = ensure(ctx, tabbuf, (size_t)std::max<int64_t>(kc, 64) * sizeof(BatchSnap))) ||
-      (nsplit > 1 && (rc = ensure(ctx, ctx->partial, (size_t)kc * (size_t)nsplit * slot_elems * sizeof(double)))) ||
+      (nsplit > 1 && (rc = ensure(ctx, ctx->partial, part_v * (want_grad ? 4 : 1) * sizeof(double)))) ||
       (rc = ensure(ctx, K.pb, pb_rows * ctx->nchan * sizeof(double))) ||
       (rc = ensure(ctx, K.packed, (size_t)ntiles * (size_t)pitch * ct * sizeof(double))) ||
       (rc = ensure(ctx, K.dirs_prep, (size_t)pitch * 4 * sizeof(double))) || (rc = ensure(ctx, ctx->sky_flag, sizeof(int32_t))))
@@ -525,6 +547,7 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   lay.nsplit = (int32_t)nsplit;
   lay.slot_elems = (int64_t)slot_elems;
   lay.out = nsplit > 1 ? (double*)ctx->partial.p : (double*)ctx->cube.p + (size_t)slot0 * slot_elems;
+  if (want_grad) lay.gout = nsplit > 1 ? (double*)ctx->partial.p + part_v : (double*)ctx->grad.p + (size_t)slot0 * 3 * slot_elems;
   // the table is one of a ring of four: the launches of the chunk that used this one four chunks ago read it on the compute / preparation
   // stream, the geometry stream writes it -- order the write behind them (the set's geometry buffers are ordered by ev_free / ev_prepared)
   if (C.tabfree_rec[ti]) HIPCHK(ctx, hipStreamWaitEvent(C.gstream, C.ev_tabfree[ti], 0));
@@ -591,11 +614,16 @@ int run_wave_batch(prisim_ctx* ctx, const prisim_obs* obs, const prisim_snapshot
   const int ri = ctx->ring_head;
   HIPCHK(ctx, hipEventRecord(ctx->ev_c0[ri], ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev_k0[ri], ctx->stream));
-  HIPCHK(ctx, launch_skyvis_taper_f64_wave_batch(p, ct, ctx->stream));
+  if (want_grad) HIPCHK(ctx, launch_skyvis_grad_taper_f64_batch(p, ctx->stream));
+  else HIPCHK(ctx, launch_skyvis_taper_f64_wave_batch(p, ct, ctx->stream));
   HIPCHK(ctx, hipEventRecord(ctx->ev_k1[ri], ctx->stream));
-  if (nsplit > 1)
+  if (nsplit > 1) {
     HIPCHK(ctx, launch_reduce_partials_batch((const double*)ctx->partial.p, (double*)ctx->cube.p + (size_t)slot0 * slot_elems, (int64_t)slot_elems, (int)nsplit,
                                              (int)kc, ctx->stream));
+    if (want_grad)
+      HIPCHK(ctx, launch_reduce_partials_batch((const double*)ctx->partial.p + part_v, (double*)ctx->grad.p + (size_t)slot0 * 3 * slot_elems,
+                                               3 * (int64_t)slot_elems, (int)nsplit, (int)kc, ctx->stream));
+  }
   HIPCHK(ctx, hipEventRecord(ctx->ev_c1[ri], ctx->stream));
   HIPCHK(ctx, hipEventRecord(K.ev_sum, ctx->stream));      // (in line too: a later preparation-stream user of this set waits for these sums)
   K.sum_recorded = true;
@@ -883,7 +911,7 @@ int prisim_hip_observe_catalog(prisim_ctx* ctx, const prisim_obs* obs, const pri
     const int b = C.next;
     ctx->sky_set = false;
     if (C.n > 0 && wave_batch_eligible(ctx, obs, precision, want_grad, kc)) {
-      if ((rc = run_wave_batch(ctx, obs, snaps + c0, b, kc, slot0 + c0, nsrc_roi ? nsrc_roi + c0 : nullptr, want_keys))) return rc;
+      if ((rc = run_wave_batch(ctx, obs, snaps + c0, b, kc, slot0 + c0, nsrc_roi ? nsrc_roi + c0 : nullptr, want_keys, want_grad != 0))) return rc;
       for (int64_t t = 0; t < kc; ++t)
         if ((rc = post_snapshot(ctx, post, slot0 + c0 + t))) return rc;
       C.next = b ^ 1;

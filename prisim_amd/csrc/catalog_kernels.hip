@@ -123,6 +123,7 @@ void k_cat_scan(const CatGeomParams p) {
       e.src_per_split = ((n1 + sw - 1) / sw + 3) / 4 * 4;
       for (int i = 0; i < 3; ++i) { e.pc[i] = sn.pc[i]; e.bpc[i] = sn.bpc[i]; }
       e.out = p.batch_out + (size_t)snap * (size_t)(p.batch_nsplit > 1 ? p.batch_nsplit : 1) * (size_t)p.batch_slot_elems;
+      e.gout = p.batch_gout ? p.batch_gout + (size_t)snap * (size_t)sw * 3 * (size_t)p.batch_slot_elems : nullptr;
       p.batch[snap] = e;
     }
   }
@@ -262,6 +263,7 @@ void k_cat_small(const CatGeomParams p) {
       e.src_per_split = ((n1 + sw - 1) / sw + 3) / 4 * 4;
       for (int i = 0; i < 3; ++i) { e.pc[i] = sn.pc[i]; e.bpc[i] = sn.bpc[i]; }
       e.out = p.batch_out + (size_t)snap * (size_t)sw * (size_t)p.batch_slot_elems;
+      e.gout = p.batch_gout ? p.batch_gout + (size_t)snap * (size_t)sw * 3 * (size_t)p.batch_slot_elems : nullptr;
       p.batch[snap] = e;
     }
   }

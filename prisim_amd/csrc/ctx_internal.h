@@ -505,6 +505,12 @@ inline bool taper_f64_grouped_enabled() {
   return !(env && atoi(env) == 0);
 }
 
+// PRISIM_HIP_GRAD_TAPER_GROUP=0 (A/B hook): fp64 gradients of a tapered sky run round 3's exact form on 16-channel tiles
+inline bool grad_taper_grouped() {
+  const char* env = getenv("PRISIM_HIP_GRAD_TAPER_GROUP");
+  return !(env && atoi(env) == 0);
+}
+
 // the stream a sky is prepared on: the preparation stream when the current sky came from the resident catalogue, else the compute stream
 inline hipStream_t pstream(const prisim_ctx* ctx) { return ctx->prep_async ? ctx->prep_stream : ctx->stream; }
 

@@ -19,6 +19,7 @@ struct BatchSnap {
   double pc[3];              // phase centre
   double bpc[3];             // beam pointing centre
   double* out;               // its sums: the cube slot (one split) or its nsplit partial cubes
+  double* gout;              // gradient batches: its three gradient sums [3][nbl][nchan] -- the gradient slot or nsplit partial sets
 };
 
 struct SkyvisParams {
@@ -85,6 +86,7 @@ hipError_t launch_skyvis_rec_f32pk_split(const SkyvisParams& p, int ct, hipStrea
 // p.src_lo/src_hi, p.src_first, p.accumulate as for the packed fp32 kernels)
 hipError_t launch_skyvis_taper_f64(const SkyvisParams& p, int ct, hipStream_t stream);
 hipError_t launch_skyvis_taper_f64_wave_batch(const SkyvisParams& p, int ct, hipStream_t stream);
+hipError_t launch_skyvis_grad_taper_f64_batch(const SkyvisParams& p, hipStream_t stream);
 hipError_t launch_pack_prep_batch(const double* pb, double* packed, int64_t pitch, int64_t max_nrow, int64_t nchan, int ct, int ntiles, const double* dirs,
                                   double* prep, double inv_c, const BatchSnap* snaps, int nsnap, hipStream_t stream);
 hipError_t launch_reduce_partials_batch(const double* part, double* out, int64_t n2, int nsplit, int nsnap, hipStream_t stream);
@@ -203,6 +205,7 @@ struct CatGeomParams {
   int32_t pad2_;
   double* batch_out;         // nsplit == 1: cube slot of snapshot 0 of the chunk; else the partial cubes [nsnap][nsplit][slot]
   int64_t batch_slot_elems;  // doubles per snapshot slot (nbl * nchan * 2)
+  double* batch_gout;        // gradient batches: gradient slot of snapshot 0 of the chunk / the gradient partial sets [nsnap][nsplit][3 slot]; else nullptr
   int32_t inline_snap;       // 1: the (single) snapshot's inputs are `snap0` below, not snaps[0] -- no host-to-device copy in front of the kernel
   int32_t small_form;        // 1: k_cat_small (one block per snapshot, records written to page-locked host memory); 0: the three passes
   CatSnap snap0;

@@ -1591,26 +1591,48 @@ __device__ __forceinline__ void skyvis_rec_f32pk_body(const SkyvisParams& p, uns
 // ratio leaves put back on the B operand -- it depends on (source, baseline) through tau, and the A operand c_i(s) p(s, f) serves all
 // four baselines of its MFMA block -- and the four sources' rows and directions staged through LDS by two DMA loads a group ahead,
 // read out eight channels at a time (the row operands never occupy more than 16 VGPRs).
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_skyvis_grad_taper_f64(const SkyvisParams p) {
+// BATCH (k_skyvis_grad_taper_f64_batch, arrays of at most 256 baselines): wave items over a batch of snapshots, as WITEM = 2 of
+// skyvis_rec_body -- item g = 4 bg + wave is (snapshot, source split, wave of 16 baselines); the snapshot's rows, directions, phase
+// centre and the destinations of its four sums (cube / gradient slot, or its partial cubes when the sources are split) come from the
+// wave-uniform table p.wave_snaps.  p.wave_nbw counts waves of SIXTEEN baselines here.
+template <bool BATCH>
+__device__ __forceinline__ void skyvis_grad_taper_f64_body(const SkyvisParams& p, const double2* tab, const double* etab, unsigned char* stage_lds) {
   constexpr int CT = 32;
-  __shared__ double2 tab_lds[kTabN];
-  __shared__ double etab_lds[kExpTabN];
-  __shared__ __attribute__((aligned(16))) unsigned char stage_lds[(kBlockThreads / 64) * kGradStageWaveBytes];
-  fill_phasor_table(tab_lds);
-  fill_exp_table(etab_lds);
-  __syncthreads();
   int slab, bg;
-  if (!block_item(p, slab, bg)) return;          // p.nbgroups counts groups of 64 baselines for this kernel
+  if (!block_item(p, slab, bg)) return;          // p.nbgroups counts groups of 64 baselines for this kernel (BATCH: quads of wave items)
   const int tile = slab % p.ntiles;
-  const double2* const tab = tab_lds;
-  const double* const etab = etab_lds;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int k = lane >> 4;                        // source of the group of four this lane follows (B / A role), sum index (D role)
   const int x = lane & 3;                         // A role: which coefficient this lane supplies
-  const int64_t bw0 = (int64_t)bg * 64 + (tid >> 6) * 16;
+  int64_t bw0 = (int64_t)bg * 64 + (tid >> 6) * 16;
+  // the snapshot's source rows [s_lo, s_hi) (multiples of four), directions, phase centre and destinations
+  int64_t s_lo = 0, s_hi = p.nsrc_pad, dir0 = 0, dir_last = p.nsrc - 1;
+  double pc_x = p.pc_x, pc_y = p.pc_y, pc_z = p.pc_z;
+  double* out_v = p.out;
+  double* out_g = p.grad_out;
+  if constexpr (BATCH) {
+    const int g = bg * (kBlockThreads / 64) + __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int per_snap = p.wave_nbw * p.wave_nsplit;
+    int snap = g / per_snap;
+    if (snap >= p.wave_nsnap) return;             // wave-uniform: a padding item of the last block
+    snap = __builtin_amdgcn_readfirstlane(snap);
+    const int r = g - snap * per_snap;
+    const int split = r / p.wave_nbw;
+    bw0 = (int64_t)(r - split * p.wave_nbw) * 16;
+    const BatchSnap* sn = p.wave_snaps + snap;
+    const int64_t nrow = sn->nsrc > 0 ? sn->nrow : 0;      // (an empty region of interest: nothing is read, zeros are written)
+    s_lo = (int64_t)split * sn->src_per_split;
+    s_hi = s_lo + sn->src_per_split < nrow ? s_lo + sn->src_per_split : nrow;
+    if (s_lo > s_hi) s_lo = s_hi;
+    s_lo += sn->row0; s_hi += sn->row0;
+    dir0 = sn->dir0 - sn->row0;                   // raw direction of packed row s: dirs[dir0 + s]
+    dir_last = sn->dir0 + sn->nsrc - 1;
+    pc_x = sn->pc[0]; pc_y = sn->pc[1]; pc_z = sn->pc[2];
+    out_v = sn->out + (size_t)split * (size_t)p.nbl * p.nchan * 2;
+    out_g = sn->gout + (size_t)split * (size_t)p.nbl * p.nchan * 6;
+  }
   const int64_t b_raw = bw0 + (lane & 15);
   const bool b_valid = b_raw < p.nbl;
   const int64_t b = b_valid ? b_raw : (p.nbl - 1);
@@ -1622,7 +1644,7 @@ void k_skyvis_grad_taper_f64(const SkyvisParams p) {
   const double df = p.df;
   const double fcN = fc * kTabN, dfN = df * kTabN;
   const double bl2_c2 = (bx * bx + by * by + bz * bz) * (p.inv_c * p.inv_c);
-  const double bpc = (bx * p.pc_x + by * p.pc_y + bz * p.pc_z) * p.inv_c;
+  const double bpc = (bx * pc_x + by * pc_y + bz * pc_z) * p.inv_c;
 
   double a_r[CT], a_i[CT];                        // sum (lane >> 4) of baseline (lane & 15), channel k0 + j
 #pragma unroll
@@ -1631,7 +1653,7 @@ void k_skyvis_grad_taper_f64(const SkyvisParams p) {
   const double* const rows = reinterpret_cast<const double*>(p.pb_packed) + (size_t)tile * (size_t)p.nsrc_pad * CT;      // natural channel order
   const double4* const prep = reinterpret_cast<const double4*>(p.dirs_prep);
   const double4* const raw = reinterpret_cast<const double4*>(p.dirs);
-  const int64_t ns_pad = p.nsrc_pad;
+  const int64_t ns_pad = s_hi;
 
   unsigned char* const wst = stage_lds + (tid >> 6) * kGradStageWaveBytes;
   auto stage_issue = [&](int64_t s0n, int half) {
@@ -1639,14 +1661,15 @@ void k_skyvis_grad_taper_f64(const SkyvisParams p) {
     asm volatile("" : "+v"(ln));
     const char* const grow = reinterpret_cast<const char*>(rows + (size_t)(s0n + (ln >> 4)) * CT) + (ln & 15) * 16;
     const int64_t sd = s0n + ((ln & 31) >> 3);
+    const int64_t sr = BATCH ? dir0 + sd : sd;
     const char* const gdir = (ln < 32) ? reinterpret_cast<const char*>(prep + sd) + (ln & 7) * 4
-                                       : reinterpret_cast<const char*>(raw + (sd < p.nsrc ? sd : p.nsrc - 1)) + (ln & 7) * 4;
+                                       : reinterpret_cast<const char*>(raw + (sr < dir_last ? sr : dir_last)) + (ln & 7) * 4;
     __builtin_amdgcn_global_load_lds((gptr_t)grow, (lptr_t)(wst + half * 1280), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)gdir, (lptr_t)(wst + half * 1280 + 1024), 4, 0, 0);
   };
-  if (ns_pad > 0) stage_issue(0, 0);
-  for (int64_t s0 = 0; s0 < ns_pad; s0 += 4) {
-    const int half = (int)((s0 >> 2) & 1);
+  if (ns_pad > s_lo) stage_issue(s_lo, 0);
+  for (int64_t s0 = s_lo; s0 < ns_pad; s0 += 4) {
+    const int half = (int)(((s0 - s_lo) >> 2) & 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0): this group's two DMA loads have landed
     wave_lds_sync();
     const unsigned char* const hb = wst + half * 1280;
@@ -1717,12 +1740,35 @@ void k_skyvis_grad_taper_f64(const SkyvisParams p) {
   }
   if (b_valid) {
     const int i = k;
-    double2* const dst = (i == 0) ? reinterpret_cast<double2*>(p.out) : reinterpret_cast<double2*>(p.grad_out) + (size_t)(i - 1) * p.nbl * p.nchan;
+    double2* const dst = (i == 0) ? reinterpret_cast<double2*>(out_v) : reinterpret_cast<double2*>(out_g) + (size_t)(i - 1) * p.nbl * p.nchan;
     double2* const o = dst + (size_t)b * p.nchan;
 #pragma unroll
     for (int j = 0; j < CT; ++j)
       if (k0 + j < p.nchan) o[k0 + j] = make_double2(a_r[j], a_i[j]);
   }
+}
+
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_skyvis_grad_taper_f64(const SkyvisParams p) {
+  __shared__ double2 tab_lds[kTabN];
+  __shared__ double etab_lds[kExpTabN];
+  __shared__ __attribute__((aligned(16))) unsigned char stage_lds[(kBlockThreads / 64) * kGradStageWaveBytes];
+  fill_phasor_table(tab_lds);
+  fill_exp_table(etab_lds);
+  __syncthreads();
+  skyvis_grad_taper_f64_body<false>(p, tab_lds, etab_lds, stage_lds);
+}
+
+// V + baseline gradient of a whole chunk of snapshots of a small array in one launch (interferometry.py:6330, 6338, 6343 per snapshot)
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_skyvis_grad_taper_f64_batch(const SkyvisParams p) {
+  __shared__ double2 tab_lds[kTabN];
+  __shared__ double etab_lds[kExpTabN];
+  __shared__ __attribute__((aligned(16))) unsigned char stage_lds[(kBlockThreads / 64) * kGradStageWaveBytes];
+  fill_phasor_table(tab_lds);
+  fill_exp_table(etab_lds);
+  __syncthreads();
+  skyvis_grad_taper_f64_body<true>(p, tab_lds, etab_lds, stage_lds);
 }
 
 template <int CT, bool TAPER>
@@ -2234,6 +2280,17 @@ hipError_t launch_skyvis_taper_f64_wave_batch(const SkyvisParams& p, int ct, hip
     case 32: hipLaunchKernelGGL((k_skyvis_taper_f64_wave_batch<32>), dim3(grid), dim3(kBlockThreads), 0, stream, p); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// V + gradient of many snapshots in one launch: p.wave_nbw = waves of 16 baselines, p.nbgroups = ceil(nsnap wave_nbw wave_nsplit / 4), 32-channel tiles
+hipError_t launch_skyvis_grad_taper_f64_batch(const SkyvisParams& p, hipStream_t stream) {
+  const int64_t items = (int64_t)p.ntiles * p.nbgroups;
+  if (items <= 0 || items > 0x3fffffffLL || !p.taper || p.nsplit != 1 || p.wave_nsplit < 1 || p.wave_nsnap < 1 || !p.wave_snaps || p.nbl > kBlockThreads ||
+      (int64_t)p.wave_nbw * 16 < p.nbl || (int64_t)p.nbgroups * (kBlockThreads / 64) < (int64_t)p.wave_nsnap * p.wave_nbw * p.wave_nsplit)
+    return hipErrorInvalidValue;
+  const unsigned grid = 8u * (unsigned)((items + 7) / 8);
+  hipLaunchKernelGGL(k_skyvis_grad_taper_f64_batch, dim3(grid), dim3(kBlockThreads), 0, stream, p);
   return hipGetLastError();
 }
 

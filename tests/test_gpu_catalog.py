@@ -446,6 +446,115 @@ def test_long_runs_take_up_to_256_snapshots_per_launch():
             assert float(NP.max(NP.abs(ctx.get_vis(slot=t) - one.get_vis()) / scale)) <= 1e-13, t
 
 
+@pytest.mark.parametrize('nbl,nchan,k', [(171, 256, 64), (3, 64, 9), (65, 96, 7), (256, 128, 12), (17, 40, 1), (171, 64, 300)])
+def test_batched_gradient_snapshots_equal_single_launches(nbl, nchan, k):
+    """visibilities AND baseline gradients (interferometry.py:6330, 6338, 6343) of K LSTs of a small array in one launch
+    (k_skyvis_grad_taper_f64_batch: wave items of 16 baselines x 4 sources over the chunk's snapshot table).  A chunk whose sources are not
+    split walks every snapshot's sources in the single launch's order, four at a time from a multiple of four: bit-identical; split
+    sources (few snapshots: the grid is filled by cutting the sources) are the same sums to rounding, 1e-13 of sum |beam x flux|."""
+    bl, ch, sky = _small_array_case(nbl, nchan)
+    lat, lst0 = -30.7224, 25.0
+    radec = radec_catalogue(sky, lat, lst0)
+    lsts = lst0 + 0.75 * NP.arange(k)
+    with _abi.Context(0) as ctx, _abi.Context(0) as one:
+        ctx.set_array(bl, ch, nt_max=k)
+        one.set_array(bl, ch, nt_max=1)
+        for c in (ctx, one):
+            c.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=14.0)
+        ctx.timing(reset=True)
+        counts = ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP64, want_grad=True)
+        tm = ctx.timing()
+        assert tm['last_batch_snapshots'] == (k if k <= 256 else k - 256) and tm['n_kernel'] == (1 if k <= 256 else 2), tm
+        assert tm['last_chan_tile'] == 32
+        exact = tm['last_nsplit'] == 1
+        picks = range(k) if k <= 64 else (0, 1, 100, 255, 256, k - 1)
+        for t in picks:
+            n = one.set_sky_from_catalog(obs, lsts[t], ZEN, ZEN)
+            assert n == counts[t]
+            one.compute(precision=_abi.PRISIM_FP64, want_grad=True)
+            v1, g1 = one.get_vis(want_grad=True)
+            vb, gb = ctx.get_vis(slot=t, want_grad=True)
+            if exact:
+                assert NP.array_equal(vb, v1) and NP.array_equal(gb, g1), (t, float(NP.max(NP.abs(gb - g1))))
+            else:
+                scale = NP.sum(NP.abs(one.get_pbflux()), axis=0)[None, :]
+                assert float(NP.max(NP.abs(vb - v1) / scale)) <= 1e-13, t
+                assert float(NP.max(NP.abs(gb - g1) / scale[None])) <= 1e-13, t
+        # the visibilities of the gradient launch are those of the plain batched launch to rounding (other kernel, other summation order)
+        plain = ctx.observe_catalog(obs, lsts[:min(k, 8)], ZEN, precision=_abi.PRISIM_FP64)
+        assert NP.array_equal(plain, counts[:min(k, 8)])
+        one.set_sky_from_catalog(obs, lsts[0], ZEN, ZEN)
+        scale = NP.sum(NP.abs(one.get_pbflux()), axis=0)[None, :]
+        one.compute(precision=_abi.PRISIM_FP64, want_grad=True)
+        assert float(NP.max(NP.abs(ctx.get_vis(slot=0) - one.get_vis()) / scale)) <= 1e-13
+
+
+def test_batched_gradient_against_the_oracle_with_an_empty_snapshot():
+    """The batched gradient launch against the CPU oracle's four sums (tolerance 1e-11 of sum |beam x flux|, the fp64 bar), on a run whose
+    middle snapshot looks at a patch of sky holding no catalogue source (zeros, and nothing read through the empty snapshot's rows)."""
+    from oracle import skyvis_oracle as O, beams_oracle as BO
+    bl, ch, sky = _small_array_case(40, 48)
+    lat, lst0 = -30.7224, 25.0
+    radec = radec_catalogue(sky, lat, lst0)
+    keep = NP.where(NP.abs(((radec[:, 0] - lst0 + 180.0) % 360.0) - 180.0) < 60.0)[0]      # a catalogue around RA = lst0 only
+    radec = radec[keep]
+    lsts = NP.array([lst0, lst0 + 180.0, lst0 + 5.0])                                     # the second LST sees none of it
+    with _abi.Context(0) as ctx:
+        ctx.set_array(bl, ch, nt_max=3)
+        ctx.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'][keep], spindex=sky['spindex'][keep], ref_freq_hz=sky['ref_freq'],
+                        fwhm_deg=sky['fwhm_deg'][keep])
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_GAUSSIAN, diameter_m=14.0, roi_radius_deg=25.0)
+        counts = ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP64, want_grad=True)
+        assert ctx.timing()['last_batch_snapshots'] == 3
+        assert counts[1] == 0 and counts[0] > 0 and counts[2] > 0
+        for t, lst in enumerate(lsts):
+            m2, dc, altaz = host_roi(radec, lat, lst, roi_radius=25.0)
+            assert m2.size == counts[t]
+            v, g = ctx.get_vis(slot=t, want_grad=True)
+            if m2.size == 0:
+                assert not v.any() and not g.any()
+                continue
+            pb = BO.gaussian_beam(14.0, altaz, ch, power=True) * sky['flux_ref'][keep][m2, None] \
+                * (ch[None, :] / sky['ref_freq']) ** sky['spindex'][keep][m2, None]
+            ref, gref = O.skyvis(bl, ch, dc, pb, ZEN, fwhm_deg=sky['fwhm_deg'][keep][m2], gradient=True)
+            scale = O.abs_flux_sum(pb)[None, :]
+            assert float(NP.max(NP.abs(v - ref) / scale)) <= 1e-11
+            assert float(NP.max(NP.abs(g - gref) / scale[None])) <= 1e-11
+
+
+def test_fp32_requests_on_a_small_array_are_served_by_the_fp64_batch():
+    """PRISim's memsave (fp32 arithmetic, interferometry.py:6320-6343) on an array this small: the cost of a snapshot is its launches, so the
+    request is served by the batched fp64 launch -- the fp64 result, bit for bit (well inside the fp32 tolerance 5e-6);
+    PRISIM_HIP_BATCH_FP32_AS_FP64=0 keeps the per-snapshot fp32 chain (the A/B)."""
+    bl, ch, sky = _small_array_case(171, 96)
+    lat, lst0 = -30.7224, 25.0
+    radec = radec_catalogue(sky, lat, lst0)
+    k = 10
+    lsts = lst0 + 0.75 * NP.arange(k)
+    with _abi.Context(0) as ctx:
+        ctx.set_array(bl, ch, nt_max=k)
+        ctx.set_catalog(radec, 'radec', flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq_hz=sky['ref_freq'], fwhm_deg=sky['fwhm_deg'])
+        obs = ctx.make_obs(lat, beam_kind=_abi.PRISIM_BEAM_AIRY, diameter_m=14.0)
+        ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP64)
+        v64 = [ctx.get_vis(slot=t) for t in range(k)]
+        ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP32)
+        assert ctx.timing()['last_batch_snapshots'] == k
+        for t in range(k):
+            assert NP.array_equal(ctx.get_vis(slot=t), v64[t])
+        os.environ['PRISIM_HIP_BATCH_FP32_AS_FP64'] = '0'
+        try:
+            ctx.observe_catalog(obs, lsts, ZEN, precision=_abi.PRISIM_FP32)
+            assert ctx.timing()['last_batch_snapshots'] == 1
+            for t in (0, k - 1):
+                ctx.set_sky_from_catalog(obs, lsts[t], ZEN, ZEN)
+                scale = NP.sum(NP.abs(ctx.get_pbflux()), axis=0)[None, :]
+                err = float(NP.max(NP.abs(ctx.get_vis(slot=t) - v64[t]) / scale))
+                assert 0.0 < err <= 5e-6, err
+        finally:
+            del os.environ['PRISIM_HIP_BATCH_FP32_AS_FP64']
+
+
 @pytest.mark.parametrize('spectra', [False, True])
 def test_batched_snapshots_with_the_external_healpix_beam(spectra):
     """Small arrays with an external HEALPix beam (what HERA-sized runs use) go through the batched launch too: gather, per-snapshot
