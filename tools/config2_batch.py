@@ -1,7 +1,8 @@
 """BASELINE config 2 (HERA-19 x 256 ch x nside-16 diffuse, fp64, taper) as a RUN: K LSTs through prisim_hip_observe_catalog -- the
 batched launch (one sky-sum launch + one reduction for all K) against one launch per snapshot (PRISIM_HIP_WAVE_BATCH=0) -- whole
 device time of the call by wall clock with the queue drained at both ends, kernel time by hipEvents, roofline against the fp64
-10-flop contract.  usage: python tools/config2_batch.py [K ...]"""
+10-flop contract.  With `grad`: visibilities + baseline gradients (the batched MFMA kernel, 16-flop contract; batched mode only).
+usage: python tools/config2_batch.py [K ...] [grad]"""
 import json
 import os
 import sys
@@ -16,7 +17,9 @@ PEAK_F64 = 78.6e12
 
 
 def main():
-    ks = [int(x) for x in sys.argv[1:]] or [64]
+    grad = 'grad' in sys.argv[1:]
+    flop = 16.0 if grad else 10.0
+    ks = [int(x) for x in sys.argv[1:] if x != 'grad'] or [64]
     cfg = W.config2()
     lat, lst0 = -30.7224, 30.0
     sky = cfg['sky']
@@ -25,7 +28,7 @@ def main():
     zen = NP.array([0.0, 0.0, 1.0])
     for k in ks:
         lsts = lst0 + 0.25 * NP.arange(k)
-        for mode in ('batch', 'single'):
+        for mode in (('batch',) if grad else ('batch', 'single')):
             os.environ['PRISIM_HIP_WAVE_BATCH'] = '1' if mode == 'batch' else '0'
             with _abi.Context(0) as ctx:
                 ctx.set_array(cfg['baselines'], cfg['channels'], nt_max=k)
@@ -36,17 +39,17 @@ def main():
                     ctx.sync()
                     ctx.timing(reset=True)
                     t0 = time.perf_counter()
-                    counts = ctx.observe_catalog(obs, lsts, zen, precision=_abi.PRISIM_FP64)
+                    counts = ctx.observe_catalog(obs, lsts, zen, precision=_abi.PRISIM_FP64, want_grad=grad)
                     ctx.sync()
                     wall = time.perf_counter() - t0
                     tm = ctx.timing()
                     terms = float(cfg['baselines'].shape[0]) * cfg['channels'].size * float(NP.sum(counts))
                     nsum = float(NP.sum(counts))
                     alg = nsum * cfg['channels'].size * 8 + 32 * nsum + 24 * cfg['baselines'].shape[0] + 8 * cfg['channels'].size + \
-                        k * 16.0 * cfg['baselines'].shape[0] * cfg['channels'].size
-                    rec = {'K': k, 'mode': mode, 'wall_ms': 1e3 * wall, 'wall_us_per_snapshot': 1e6 * wall / k, 'kernel_ms_total': tm['sum_kernel_ms'],
+                        k * 16.0 * (4 if grad else 1) * cfg['baselines'].shape[0] * cfg['channels'].size
+                    rec = {'K': k, 'mode': mode + ('_grad' if grad else ''), 'flop_per_term': flop, 'wall_ms': 1e3 * wall, 'wall_us_per_snapshot': 1e6 * wall / k, 'kernel_ms_total': tm['sum_kernel_ms'],
                            'launches': tm['n_kernel'], 'terms': terms, 'chan_tile': tm['last_chan_tile'], 'nsplit': tm['last_nsplit'],
-                           'roofline_whole_call': terms * 10.0 / wall / PEAK_F64, 'roofline_kernel_only': terms * 10.0 / (tm['sum_kernel_ms'] * 1e-3) / PEAK_F64,
+                           'roofline_whole_call': terms * flop / wall / PEAK_F64, 'roofline_kernel_only': terms * flop / (tm['sum_kernel_ms'] * 1e-3) / PEAK_F64,
                            # (the keys tools/summarize_pmc.py reads: per launch of the dominant kernel)
                            'roofline': {'terms_per_launch': terms / max(tm['n_kernel'], 1), 'avg_kernel_ms': tm['sum_kernel_ms'] / max(tm['n_kernel'], 1)},
                            'roofline_hbm': {'algorithmic_bytes_per_launch': alg / max(tm['n_kernel'], 1)}}

@@ -3,7 +3,7 @@
 # tests/test_host_logic.py checks: profiles/r06_MANIFEST.json names the directories taken with the sources that are committed.
 #   tools/profile_all_round6.sh [tags...]      default: all
 set -e
-TAGS=${@:-"headline fp64 taper64_3d taper64_5 taper32_5 taper32_3d grad64 grad32 grad64_taper delay cfg2 cfg2_batch cfg2_batch256"}
+TAGS=${@:-"headline fp64 taper64_3d taper64_5 taper32_5 taper32_3d grad64 grad32 grad64_taper delay cfg2 cfg2_batch cfg2_batch256 cfg2_grad_batch256"}
 DONE=""
 for t in $TAGS; do
   case $t in
@@ -20,6 +20,7 @@ for t in $TAGS; do
     cfg2) PROFILE_KERNEL=k_skyvis_taper_f64_wave PROFILE_CMD="python3 @REPO@/tools/profile_cfg2.py" tools/profile_round.sh r06_cfg2_fp64; DONE="$DONE r06_cfg2_fp64" ;;
     cfg2_batch) PROFILE_KERNEL=k_skyvis_taper_f64_wave_batch PROFILE_CMD="python3 @REPO@/tools/config2_batch.py 64" tools/profile_round.sh r06_cfg2_batch64_fp64; DONE="$DONE r06_cfg2_batch64_fp64" ;;
     cfg2_batch256) PROFILE_KERNEL=k_skyvis_taper_f64_wave_batch PROFILE_CMD="python3 @REPO@/tools/config2_batch.py 256" tools/profile_round.sh r06_cfg2_batch256_fp64; DONE="$DONE r06_cfg2_batch256_fp64" ;;
+    cfg2_grad_batch256) PROFILE_KERNEL=k_skyvis_grad_taper_f64_batch PROFILE_EXTRA_PMC="SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" PROFILE_CMD="python3 @REPO@/tools/config2_batch.py 256 grad" tools/profile_round.sh r06_cfg2_grad_batch256_fp64; DONE="$DONE r06_cfg2_grad_batch256_fp64" ;;
   esac
   echo "== $t done"
 done
