@@ -24,6 +24,14 @@ for d in dirs:
     s = json.load(open(os.path.join(dst, 'pmc_summary.json')))
     assert s['_csrc_hash'] == bench.csrc_hash(), d
     der = s['_derived']
+    # the record of the profiled launch (tools/summarize_pmc.py: a batched call's own line, not the per-snapshot chain printed after it)
+    recs = [json.loads(l) for l in open(os.path.join(dst, 'bench_under_rocprof.json')).read().splitlines() if l.startswith('{')]
+    rec = ([r for r in recs if str(r.get('mode', '')).startswith('batch')] or recs)[-1] if recs else None
+    if rec and 'roofline' in rec and rec['roofline'].get('terms_per_launch'):
+        der['algorithmic_bytes_per_launch'] = rec['roofline_hbm']['algorithmic_bytes_per_launch']
+        der['valu_wave_instructions_per_wave_term'] = s['SQ_INSTS_VALU']['mean_per_launch'] / (rec['roofline']['terms_per_launch'] / 64.0)
+        der['hipEvent_avg_kernel_ms_under_rocprof'] = rec['roofline']['avg_kernel_ms']
+        json.dump(s, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1)
     ms = der['avg_kernel_ms (rocprofv3 --kernel-trace --stats)']
     clock = der['clock_GHz (GRBM_GUI_ACTIVE/8/avg kernel time)']
     hbm = der['hbm_bytes_per_launch (2*FETCH_SIZE + WRITE_SIZE, KiB->B, gfx950 FETCH correction)']
@@ -31,9 +39,8 @@ for d in dirs:
     busy = s['SQ_INSTS_VALU']['mean_per_launch'] * 4 / (1024 * ms * 1e-3 * clock * 1e9)
     wait = s['SQ_WAIT_ANY']['mean_per_launch'] / s['SQ_WAVE_CYCLES']['mean_per_launch']
     terms = None
-    lines = [l for l in open(os.path.join(dst, 'bench_under_rocprof.json')).read().splitlines() if l.startswith('{')]
-    if lines:
-        terms = json.loads(lines[-1]).get('roofline', {}).get('terms_per_launch')
+    if rec:
+        terms = rec.get('roofline', {}).get('terms_per_launch')
     print('%-26s ms %.5g  clock %.3f  valu/wave-term %.3f  hbm %.4g B = %.2f x alg  wait %.3f  valu-issue %.3f' % (
         d, ms, clock, der['valu_wave_instructions_per_wave_term'], hbm, hbm / alg, wait, busy), end='')
     if terms:

@@ -48,8 +48,9 @@ if 'GRBM_GUI_ACTIVE' in summary and avg_ms:
     d['clock_GHz (GRBM_GUI_ACTIVE/8/avg kernel time)'] = summary['GRBM_GUI_ACTIVE']['mean_per_launch'] / 8.0 / (avg_ms * 1e-3) * 1e-9
 try:
     with open(os.path.join(out, 'bench_under_rocprof.json')) as f:
-        line = [l for l in f if l.startswith('{')][-1]
-    b = json.loads(line)
+        recs = [json.loads(l) for l in f if l.startswith('{')]
+    # (tools/config2_batch.py prints the batched call and then the per-snapshot chain it replaces: the profiled kernel is the batched one)
+    b = ([r for r in recs if str(r.get('mode', '')).startswith('batch')] or recs)[-1]
     terms = b['roofline']['terms_per_launch']
     d['algorithmic_bytes_per_launch'] = b['roofline_hbm']['algorithmic_bytes_per_launch']
     if 'SQ_INSTS_VALU' in summary:
