@@ -533,7 +533,9 @@ class Context(object):
         beam_pc_dircos likewise (default: pc_dircos).  Results land in cube slots slot0 ... slot0 + K - 1; returns the ROI counts (K,).
         host_cube: page-locked (nt_max, nbl, nchan) complex128 / complex64 array (host_empty) every finished slot is downloaded into,
         behind its sky-sum; gather: None, or 'c128' / 'c64' -- every finished slot is all-gathered on the communication stream.
-        frames: None (the library's fall-back rotation from lst and latitude), or K pairs (R (3, 3), beta (3,)) -- see _fill_snapshot."""
+        frames: None (the library's fall-back rotation from lst and latitude), or K pairs (R (3, 3), beta (3,)) -- see _fill_snapshot.
+        Arrays of at most 256 baselines take ONE launch per chunk of up to 256 snapshots in every mode (fp64, want_grad, and
+        precision=PRISIM_FP32, whose arithmetic is then the fp64 launch's)."""
         lst = NP.asarray(lst_deg, dtype=NP.float64).ravel()
         k = lst.size
         if frames is not None and len(frames) != k:

@@ -14,7 +14,9 @@ Differences kept on purpose:
   Q2  ``observing_run`` works (the reference's passes a str as timeobj and cannot run).
   Q4  baseline gradients work for shapeless sky models too.
   Q5  ``memsave`` reduces the phase in fp64 before the fp32 recurrence (more accurate than the reference's
-      all-fp32 phase); results are complex64 like the reference's.
+      all-fp32 phase); results are complex64 like the reference's.  On arrays of at most 256 baselines observed from the resident
+      catalogue the arithmetic of a ``memsave`` snapshot is fp64 (the batched launch of include/prisim_hip.h serves it: faster than any
+      fp32 launch chain at that size); the stored type stays complex64.
   Q7  the visibility cube is grown without O(nt^2) recopy; same logical shape (nbl, nchan, n_acc).
   Q20 delay_transform transforms whichever of the three cubes exist.
   sky coordinates 'radec': the reference's astropy chain FK5(skymodel.epoch) -> FK5(obstime) -> AltAz (:6174-6180) is ONE rotation and
