@@ -493,6 +493,35 @@ def config2_step(nlaunch=20, nbatch=64):
         cls[mode] = {'us_per_snapshot': 1e3 * r['wall_ms_per_snapshot_resident'], 'fresh_us_per_snapshot': 1e3 * r['wall_ms_per_snapshot'],
                      'host_us_per_snapshot': 1e3 * r['host_ms_per_snapshot'], 'snapshots_per_launch': r['snapshots_per_launch'],
                      'us_per_snapshot_spread': spread([1e3 * x['wall_ms_per_snapshot_resident'] for x in rs])}
+    # ... and the other two modes of the sum through the class (memsave = an fp32 request, gradient_mode='baseline'): second pass of a
+    # resident instance, median of 3 instances
+    from prisim_amd import interferometry as RI
+    skymod = radec_skymodel(cfg, lat, 30.0)
+    tel = {'id': 'hera', 'shape': 'dish', 'size': 14.0, 'ocoords': 'altaz', 'orientation': NP.array([[90.0, 270.0]]), 'groundplane': None}
+    def class_mode(mode, kw):
+        vals = []
+        for rep in range(3):
+            ia = RI.InterferometerArray(['b%d' % i for i in range(cfg['baselines'].shape[0])], cfg['baselines'], cfg['channels'], telescope=tel,
+                                        latitude=lat, skycoords='radec', pointing_coords='hadec', device=dev)
+            ia.reserve(2 * nbatch)
+            times = [(2455000.0 + j * 60.0 / 86400.0, 30.0 + 0.25 * j) for j in range(2 * nbatch)]
+            for ps in range(2):
+                ia._ctx.sync()
+                t0 = time.perf_counter()
+                if mode == 'observe':
+                    for j in range(ps * nbatch, (ps + 1) * nbatch):
+                        ia.observe(times[j], {'Tnet': 100.0}, NP.ones(cfg['channels'].size), NP.array([0.0, lat]), skymod, 60.0, **kw)
+                else:
+                    ia.observe_batch(times[ps * nbatch:(ps + 1) * nbatch], {'Tnet': 100.0}, NP.ones(cfg['channels'].size), NP.array([0.0, lat]), skymod, 60.0, **kw)
+                ia._ctx.sync()
+                wall = time.perf_counter() - t0
+            per_launch = int(ia._ctx.timing().get('last_batch_snapshots', 1))
+            ia.close()
+            vals.append(1e6 * wall / nbatch)
+        return {'us_per_snapshot': float(NP.median(vals)), 'us_per_snapshot_spread': spread(vals), 'snapshots_per_launch': per_launch}
+    for name, kw in (('memsave', {'memsave': True}), ('gradient', {'gradient_mode': 'baseline'})):
+        for mode in ('observe', 'batch'):
+            cls['%s_%s' % (mode, name)] = class_mode(mode, kw)
     out['through_class'] = cls
     return out
 
