@@ -117,7 +117,10 @@ for case in range(ncase):
                     ref.set_sky_analytic(dc_all[m2], flux_ref[m2], spindex[m2], 150e6, beam, 14.0, pcs[t], pcs[t], fwhm_deg=fwm)
                 ref.compute(precision=prec, want_grad=want_grad)
                 want = ref.get_vis(want_grad=want_grad)
-                scale = NP.maximum(NP.sum(NP.abs(ref.get_pbflux()), axis=0), 1e-300)[None, :]
+                # (fp32: a sky whose whole beam-weighted flux lies below the normal range of a float -- one source 60 degrees off a Gaussian
+                # beam is 1e-50 Jy -- underflows in the fp32 chain of the uploaded path and not in the batched launch, which serves fp32
+                # requests of small arrays in fp64: relative to the range of the type there)
+                scale = NP.maximum(NP.sum(NP.abs(ref.get_pbflux()), axis=0), 1e-300 if prec == _abi.PRISIM_FP64 else 1e-30)[None, :]
                 pairs = [(got[0], want[0])] + [(got[1][i], want[1][i]) for i in range(3)] if want_grad else [(got, want)]
                 # The two paths' direction cosines differ by a few ulp (tests/test_gpu_catalog.py: <= 2.5e-15, and 2 ulp / cos(alt) near the
                 # zenith, where the reference's chain alt = arcsin(.), cos(alt) is ill-conditioned on the host and on the device alike).  On a
