@@ -731,6 +731,53 @@ def test_observing_run_on_a_small_array_uses_the_batched_launch(external_beam):
     assert float(NP.max(NP.abs(NP.asarray(ia.geometric_delays[5]) - NP.asarray(ia0.geometric_delays[5])))) <= 1e-20
 
 
+def test_class_surface_gradient_and_memsave_runs_of_a_small_array_share_launches():
+    """observe_batch / observe() with gradient_mode='baseline' and with memsave=True on HERA-19 (interferometry.py:6320-6343, all three modes):
+    the whole run in one launch; visibilities and gradient cubes equal those of the host-formed sky path (PRISIM_CATALOG=0: per-snapshot
+    kernels on uploaded skies) to 1e-12 of the largest visibility in fp64 and 5e-6 of it for memsave (complex64 storage, fp64 arithmetic)."""
+    from prisim_amd import interferometry as RI, skymodel as SM
+    cfg = W.config2()
+    lat = -30.7224
+    sky = cfg['sky']
+    radec = radec_catalogue(sky, lat, 15.0)
+    n = radec.shape[0]
+    tel = {'id': 'hera', 'shape': 'dish', 'size': 14.0, 'ocoords': 'altaz', 'orientation': NP.array([[90.0, 270.0]]), 'groundplane': None}
+    k = 12
+    times = [(2457000.5 + j * 1e-3, 15.0 + 0.5 * j) for j in range(k)]
+
+    def run(mode, **kw):
+        skymod = SM.SkyModel(location=radec, flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
+                             src_shape=NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1), epoch=None)
+        ia = RI.InterferometerArray(['b%d' % i for i in range(cfg['baselines'].shape[0])], cfg['baselines'], cfg['channels'], telescope=tel,
+                                    latitude=lat, skycoords='radec', pointing_coords='hadec')
+        if mode == 'batch':
+            ia.observe_batch(times, {'Tnet': 100.0}, NP.ones(cfg['channels'].size), [0.0, lat], skymod, 10.0, **kw)
+        else:
+            for t in times:
+                ia.observe(t, {'Tnet': 100.0}, NP.ones(cfg['channels'].size), [0.0, lat], skymod, 10.0, **kw)
+        tm = ia._ctx.timing() if ia._ctx is not None else {}
+        vis = NP.array(ia.skyvis_freq)
+        grad = NP.array(ia.gradient['baseline']) if kw.get('gradient_mode') else None
+        ia.close()
+        return vis, grad, tm
+
+    os.environ['PRISIM_CATALOG'] = '0'
+    try:
+        v0, g0, _ = run('observe', gradient_mode='baseline')
+    finally:
+        del os.environ['PRISIM_CATALOG']
+    scale = float(NP.max(NP.abs(v0)))
+    vb, gb, tmb = run('batch', gradient_mode='baseline')
+    assert tmb['last_batch_snapshots'] == k and vb.shape == (171, 256, k) and gb.shape == g0.shape
+    assert float(NP.max(NP.abs(vb - v0))) <= 1e-12 * scale and float(NP.max(NP.abs(gb - g0))) <= 1e-12 * scale
+    vo, go, tmo = run('observe', gradient_mode='baseline')
+    assert tmo['last_batch_snapshots'] == 1 and tmo['last_chan_tile'] == 32           # a chunk of one through the batched gradient launch
+    assert float(NP.max(NP.abs(vo - v0))) <= 1e-12 * scale and float(NP.max(NP.abs(go - g0))) <= 1e-12 * scale
+    vm, _, tmm = run('batch', memsave=True)
+    assert tmm['last_batch_snapshots'] == k and vm.dtype == NP.complex64
+    assert float(NP.max(NP.abs(vm - v0))) <= 5e-6 * scale
+
+
 def test_equatorial_baselines_give_the_enu_visibilities():
     """baseline_coords='equatorial' (rotated to ENU at the array's latitude, interferometry.py:6151-6153) against the same array
     given in ENU, through observe() on the catalogue path, and against the oracle."""
