@@ -615,7 +615,7 @@ def radec_skymodel(cfg, lat, lst0):
     radec = NP.stack(((lst0 - hadec[:, 0]) % 360.0, hadec[:, 1]), axis=1)
     return SM.SkyModel(location=radec, flux_ref=sky['flux_ref'], spindex=sky['spindex'], ref_freq=sky['ref_freq'],
                        src_shape=(NP.stack((sky['fwhm_deg'], sky['fwhm_deg'], NP.zeros(n)), axis=1) if cfg['taper'] else None),
-                       epoch=None)           # (laid out in the local frame: coordinates of date)
+                       epoch=None).freeze()  # (laid out in the local frame: coordinates of date; frozen as driver.run freezes its model)
 
 
 def e2e_observe(cfg, n_snap, device, memsave, to_host=False, batch=False):

@@ -365,6 +365,8 @@ def run(parms, infile_dir='.', rank=0, world=1, device=0, comm_uid=None, verbose
         to_epoch = FRAMES.jyear_of_jd(jd[0])
         skymod.location = FRAMES.precess_radec(skymod.location, skymod.epoch, to_epoch)
         skymod.epoch = 'J{0:.12f}'.format(to_epoch)
+    if hasattr(skymod, 'freeze'):
+        skymod.freeze()                         # nothing edits the model from here on: observe() recognises it by identity (no content pass)
     proc = parms['processing']
     ia_kwargs = dict(telescope=tel, eff_Q=parms['telescope']['eff_Q'], latitude=tel['latitude'], longitude=tel['longitude'],
                      altitude=tel['altitude'], skycoords='radec', A_eff=parms['telescope']['A_eff'], pointing_coords='hadec', device=device,

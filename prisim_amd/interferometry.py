@@ -103,6 +103,22 @@ class _OnesStack(_LayerStack):
         raise TypeError('bp_wts follows the bandpass stack; assign an array to replace it')
 
 
+class _SameObject(object):
+    """Equal only to a wrapper of the very same object (which it keeps alive: its identity cannot be handed to another object)."""
+    __slots__ = ('obj',)
+
+    def __init__(self, obj):
+        self.obj = obj
+
+    def __eq__(self, other):
+        return isinstance(other, _SameObject) and other.obj is self.obj
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+
 class _LazyGradients(dict):
     """InterferometerArray.gradient: {gradient_mode: (3, nbl, nchan, n_acc)} like the reference's, but the per-snapshot gradient blocks that
     observe() left in the device gradient cube (reserve()) are only fetched -- and stacked, once, instead of the reference's per-snapshot
@@ -877,6 +893,14 @@ class InterferometerArray(object):
         def g(k):
             return getattr(skymodel, k, None)      # (attributes, class-level defaults and properties alike)
         ref_freq = g('ref_freq')
+        frozen = getattr(skymodel, '_frozen', None)
+        if frozen is not None:
+            # prisim_amd.skymodel.SkyModel.freeze(): the arrays are private read-only copies -- their identity stands for their content (the key
+            # holds them, so no identity can be reused); anything assigned or made writeable since falls through to the content pass
+            cur = (g('location'), g('flux_ref'), g('spindex'), g('spectrum'), g('frequency'), g('src_shape'))
+            if len(frozen) == len(cur) and all(c is f and (c is None or not c.flags.writeable) for c, f in zip(cur, frozen)):
+                return (id(skymodel), self.skycoords, g('spec_type'), _SameObject(frozen), None if ref_freq is None else float(NP.sum(ref_freq)),
+                        self.channels.size, float(self.channels[0]), float(self.channels[-1]), self._reserved)
         return (id(skymodel), self.skycoords, g('spec_type'), digest(skymodel.location), digest(g('flux_ref')), digest(g('spindex')),
                 None if ref_freq is None else float(NP.sum(ref_freq)), digest(g('spectrum'), sample=True), digest(g('frequency')),
                 digest(g('src_shape')), self.channels.size, float(self.channels[0]), float(self.channels[-1]), self._reserved)

@@ -754,3 +754,47 @@ def test_frame_provider_in_a_batch_and_close(monkeypatch):
     ia.close()
     assert closed['n'] == 1 and ia.obs_catalog_indices[2]._idx is not None                                            # fetched first
     assert NP.array_equal(NP.asarray(ia.obs_catalog_indices[2]), NP.asarray(builtin.obs_catalog_indices[2]))
+
+
+def test_frozen_sky_model_is_recognised_by_identity_and_edits_are_still_seen(monkeypatch):
+    """SkyModel.freeze() (what driver.run does to the model it builds): the resident catalogue is recognised by the identity of the model's
+    private read-only arrays -- no pass over their contents per observe() -- while everything that can still change is still seen: a new
+    array assigned to an attribute, an array made writeable again, another model."""
+    import fake_context
+    from prisim_amd import _abi, interferometry as RI, skymodel as SM
+    monkeypatch.setattr(_abi, 'Context', fake_context.OracleContext)
+    rng = NP.random.default_rng(8)
+    n = 40
+    loc = NP.stack((rng.uniform(0, 360, n), rng.uniform(-60, 0, n)), axis=1)
+    flux = rng.uniform(1, 2, n)
+    sm = SM.SkyModel(location=loc, flux_ref=flux, spindex=NP.zeros(n), ref_freq=150e6, epoch=None)
+    bl = NP.array([[14.6, 0.0, 0.0], [0.0, 14.6, 0.0]])
+    ch = 150e6 + 1e6 * NP.arange(8)
+    ia = RI.InterferometerArray(['a', 'b'], bl, ch, telescope={'id': 'hera', 'orientation': [90.0, 270.0], 'ocoords': 'altaz'}, latitude=-30.7,
+                                skycoords='radec', pointing_coords='hadec')
+    k_content = ia._catalog_fingerprint(sm)
+    assert sm.freeze() is sm and not sm.flux_ref.flags.writeable and sm.flux_ref is not flux and sm.location.flags.owndata
+    flux[:] = 7.0                                           # the caller's own array is no longer the model's
+    assert NP.all(sm.flux_ref < 3.0)
+    k1, k2 = ia._catalog_fingerprint(sm), ia._catalog_fingerprint(sm)
+    assert k1 == k2 and k1 != k_content and len(k1) < len(k_content)          # the identity form, stable from call to call
+    # an attribute assigned after the freeze: back to the content pass, and the key differs
+    sm.flux_ref = NP.array(sm.flux_ref) * 2.0
+    k3 = ia._catalog_fingerprint(sm)
+    assert k3 != k1 and len(k3) == len(k_content)
+    sm.freeze()
+    k4 = ia._catalog_fingerprint(sm)
+    assert k4 != k1 and len(k4) == len(k1)                   # frozen again: new private arrays, a new identity
+    # an array made writeable again is not trusted
+    sm.spindex.setflags(write=True)
+    assert len(ia._catalog_fingerprint(sm)) == len(k_content)
+    sm.spindex.setflags(write=False)
+    assert ia._catalog_fingerprint(sm) == k4
+    # another frozen model with the same content is another catalogue (identity), and observing works through the frozen model
+    sm2 = SM.SkyModel(location=sm.location, flux_ref=sm.flux_ref, spindex=sm.spindex, ref_freq=150e6, epoch=None).freeze()
+    assert ia._catalog_fingerprint(sm2) != k4
+    for j in range(2):
+        ia.observe((2457000.5 + j, 30.0 + j), {'Tnet': 100.0}, NP.ones(ch.size), [0.0, -30.7], sm, 10.0)
+    assert ia._catalog_key == ia._catalog_fingerprint(sm)
+    v = NP.array(ia.skyvis_freq)
+    assert v.shape == (2, 8, 2) and NP.all(NP.isfinite(v))
