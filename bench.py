@@ -812,6 +812,14 @@ def gather_rehearsal(cfg, zen, prec, device, nsnap=12):
         c.comm_init(_abi.Context.comm_unique_id(), 1, 0)
         c.comm_selftest(1 << 20)
         res['selftest'] = 'ok'
+        # a shard map as an N > 1 run sets one (prisim_hip_set_shard_map): here the 1-rank map is a fixed PERMUTATION of the rows with the last
+        # three rows declared padding, so the staging buffer and the un-deal kernel run behind librccl's gather on real hardware
+        nbl_tot = int(mine.shape[0]) - 3
+        perm = NP.random.default_rng(20).permutation(nbl_tot).astype(NP.int64)
+        smap = NP.full((1, mine.shape[0]), -1, dtype=NP.int64)
+        smap[0, :nbl_tot] = perm
+        c.set_shard_map(smap, nbl_tot)
+        res['order'] = 'a fixed permutation of the shard\'s rows as the 1-rank shard map (3 padding rows dropped): staging + un-deal kernel behind every gather'
 
         def loop(gather):
             for t in range(3):
@@ -837,10 +845,12 @@ def gather_rehearsal(cfg, zen, prec, device, nsnap=12):
                     'compute_slowdown': wall1 / wall0, 'compute_slowdown_spread': spread(ratios),
                     'per_snapshot_ms': st['sum_gather_ms'] / max(st['n_gathers'], 1), 'max_gather_ms': st['max_gather_ms'],
                     'exposed_ms': st['last_gather_after_compute_ms'], 'bytes_per_gather': st['bytes_per_peer'], 'gathers_measured': st['n_gathers'],
-                    'comm_stream_priority': st['stream_priority'], 'lowest_priority': st['stream_priority_lowest']})
+                    'comm_stream_priority': st['stream_priority'], 'lowest_priority': st['stream_priority_lowest'],
+                    'undeal_ms_per_snapshot': st['sum_undeal_ms'] / max(st['n_gathers'], 1)})
         cs = c.gathered_checksum(nsnap, complex64=c64)
-        g = c.get_gathered(1, 1)[0][0]
-        res['gather_ok'] = bool(NP.isfinite(cs) and NP.array_equal(g, c.get_vis(slot=0, complex64=c64)))
+        g = c.get_gathered(1, 1)[0]                                        # (nbl_tot, nchan) in the map's order
+        v = c.get_vis(slot=0, complex64=c64)
+        res['gather_ok'] = bool(NP.isfinite(cs) and g.shape[0] == nbl_tot and NP.array_equal(g[perm], v[:nbl_tot]))
     return res
 
 
